@@ -1,0 +1,184 @@
+"""bench.py — HR frames/s of the PFNL forward hot path on N MI355X GPUs (one process per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: PFNL 4xSR, 7 LR frames 128x128 -> one 512x512 HR frame per clip,
+batch 4 clips per GPU, fp32, synthetic U[0,1) clips and seeded Xavier weights (no checkpoint/dataset
+can be fetched).  A "step" = one pfnl_forward over the rank's batch with the input already resident in
+HBM.  Clips are independent, so ranks share nothing on the data path (weak scaling: 4 clips per GPU);
+RCCL is used for the weight broadcast, the barriers and the max-over-ranks time only.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel class: the
+3x3 64->64 MFMA implicit-GEMM conv, timed live with HIP events on the launch stream) and, at N=1,
+`cpu_baseline` (the torch-CPU fp32 oracle = the stand-in for the reference's TF1 CPU path, timed on a
+bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, no xf32 on gfx950
+B_PER_GPU, T, H, W = 4, 7, 128, 128
+
+
+def cpu_baseline(weights, sample_clips, budget_s=20.0):
+    """Times oracle/pfnl_fast.py (the CPU port of the reference graph) on this host."""
+    import numpy as np
+    import torch
+    from oracle import pfnl_fast
+
+    def run(threads):
+        torch.set_num_threads(threads)
+        fo = pfnl_fast.FastOracle(weights)
+        fo.forward(sample_clips)                      # warm-up, discarded (reference model/pfnl.py:262)
+        times = []
+        t_end = time.time() + budget_s
+        while len(times) < 3 or (time.time() < t_end and len(times) < 5):
+            t0 = time.time()
+            fo.forward(sample_clips)
+            times.append(time.time() - t0)
+            if time.time() > t_end and len(times) >= 2:
+                break
+        return sample_clips.shape[0] / min(times), sample_clips.shape[0] / float(np.mean(times))
+
+    ncpu = os.cpu_count() or 1
+    all_thr = max(1, min(ncpu, torch.get_num_threads() if torch.get_num_threads() > 1 else ncpu))
+    best_all, mean_all = run(all_thr)
+    out = {"value": round(best_all, 4), "unit": "HR frames/s", "cores": all_thr, "kind": "port",
+           "sample": "%d clip(s) of 7x%dx%d->%dx%d fp32 through oracle/pfnl_fast.py (torch-CPU, oneDNN), "
+                     "1 warm-up + min of >=2 runs" % (sample_clips.shape[0], H, W, 4 * H, 4 * W),
+           "mean_value": round(mean_all, 4), "host_logical_cpus": ncpu}
+    if all_thr > 8:
+        b8, _ = run(8)
+        out["value_8_threads"] = round(b8, 4)
+        torch.set_num_threads(all_thr)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from pfnl_amd import dist as pd
+    from pfnl_amd import synth
+    from pfnl_amd.engine import PFNLEngine
+    from pfnl_amd.spec import PFNLGeometry
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    geom = PFNLGeometry()
+
+    use_dist = world > 1
+    if use_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        weights = pd.broadcast_weights(geom, synth.synthetic_weights(geom, seed=0) if rank == 0 else None,
+                                       src=0, device=dev)            # RCCL broadcast, 12 MB, once
+    else:
+        weights = synth.synthetic_weights(geom, seed=0)
+
+    eng = PFNLEngine(geom, device=local_rank)
+    eng.load_weights(weights)
+    x = torch.from_numpy(synth.uniform_clips(B_PER_GPU, T, H, W, seed=1234 + rank)).to(dev)   # resident in HBM
+    out = torch.empty(eng.out_shape(B_PER_GPU, H, W), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eng.forward_device(x.data_ptr(), out.data_ptr(), B_PER_GPU, H, W, stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.profile_reset()
+    eng.profile(True)                 # HIP events around every kernel launch, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    eng.profile(False)
+    prof = eng.profile_read()
+
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    assert torch.isfinite(out).all().item(), "non-finite output"
+
+    clips_total = world * B_PER_GPU * args.steps
+    value = clips_total / elapsed                                     # 1 HR frame per clip
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    # dominant kernel class: conv_mfma_kernel<3,*> = conv1_i, both halves of conv2_i
+    P = H * W
+    F = B_PER_GPU * T
+    flops3 = geom.num_block * (2 * F + B_PER_GPU) * P * 9 * 64 * 64 * 2.0         # per forward, executed = algorithmic
+    k = prof["conv3x3"]
+    roof = None
+    if k["launches"]:
+        avg_ms = k["ms"] / k["launches"]
+        flops_per_launch = flops3 * args.steps / k["launches"]
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "kernel": "conv_mfma_kernel<3,*> (3x3 64->64 f32 MFMA implicit GEMM)",
+                "avg_launch_ms": round(avg_ms, 4), "launches": k["launches"],
+                "gflop_per_launch": round(flops_per_launch / 1e9, 3)}
+    f_ref = geom.flops_per_clip(H, W) * B_PER_GPU
+    f_exec = geom.flops_per_clip(H, W, shared_base=True) * B_PER_GPU
+    breakdown = {n: round(v["ms"] / args.steps, 4) for n, v in prof.items()}
+
+    res = {
+        "metric": "HR frames/sec at 4xSR, 7-frame 128x128->512x512", "value": round(value, 3), "unit": "HR frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "PFNL 4xSR, 7 frames, 128x128->512x512, batch=4 fp32 per MI355X (BASELINE.json configs[1])",
+                   "clips_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU, "parallelism": "dp%d" % world,
+                   "weights": "synthetic Xavier (seed 0)", "input": "resident in HBM"},
+        "roofline": roof,
+        "whole_forward": {"tflops_ref_graph": round(f_ref / (ms_per_step * 1e-3) / 1e12, 2),
+                          "tflops_executed": round(f_exec / (ms_per_step * 1e-3) / 1e12, 2),
+                          "frac_of_f32_mfma_peak_executed": round(f_exec / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                          "kernel_ms_per_step": breakdown},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sample = synth.uniform_clips(1, T, H, W, seed=1234)
+        res["cpu_baseline"] = cpu_baseline(weights, sample)
+        res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,129 @@
+/*
+ * pfnl_hip.h — C-ABI of libpfnl_hip.so: the MI355X (gfx950) implementation of PFNL's
+ * forward/inference hot path.
+ *
+ * The reference (psychopa4/PFNL) is pure Python on TensorFlow 1.12 and has no FFI/operator
+ * interface of its own; the seam this library replaces is the TF runtime underneath
+ *   - PFNL.forward                 (reference model/pfnl.py:39-80)   -> pfnl_forward
+ *   - utils.NonLocalBlock          (reference utils.py:18-71)        -> pfnl_op_nonlocal
+ *   - tf.layers.Conv2D instances   (reference model/pfnl.py:48-53)   -> pfnl_op_conv2d
+ *   - tf.image.resize_images(..,2) (reference model/pfnl.py:63)      -> pfnl_op_bicubic
+ *   - tf.train.Saver.restore       (reference model/base_model.py:231-243): variables arrive
+ *     through pfnl_set_weight under their TF names (nlvsr/conv0/kernel ...), HWIO float32.
+ *   - sess.run(SR_test, feed_dict) (reference model/pfnl.py:252,309) -> pfnl_forward with host
+ *     pointers (H2D/D2H inside, like the reference's timing includes).
+ *
+ * Conventions: every entry point is extern "C", takes plain pointers and sizes, returns 0 on
+ * success or a negative pfnl_status; the message of the last failure on the calling thread is
+ * available from pfnl_last_error().  A handle is bound to one device and is not re-entrant;
+ * distinct handles are independent.  "device pointer" = memory accessible from that device
+ * (e.g. a torch-ROCm tensor's data_ptr()); "stream" = a hipStream_t passed as void* (NULL = the
+ * handle's own stream).  All tensors are float32, contiguous, NHWC-style as in the reference:
+ *   input  [B, T, H, W, 3]      values nominally in [0,1]
+ *   output [B, 1, s*H, s*W, 3]  not clipped (the harness clips, reference model/pfnl.py:255-257)
+ */
+#ifndef PFNL_HIP_H
+#define PFNL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pfnl_handle pfnl_handle;
+
+typedef enum pfnl_status {
+    PFNL_OK = 0,
+    PFNL_ERR_INVALID = -1,     /* bad argument / shape (odd H or W, unknown tensor name ...) */
+    PFNL_ERR_STATE = -2,       /* e.g. forward before finalize_weights, missing weights        */
+    PFNL_ERR_HIP = -3,         /* a HIP runtime call failed                                    */
+    PFNL_ERR_NOMEM = -4,
+    PFNL_ERR_NODEVICE = -5     /* no gfx950-capable device visible                             */
+} pfnl_status;
+
+/* Mirrors the constants hard-coded in the reference (model/pfnl.py:21-23, 40-43). */
+typedef struct pfnl_config {
+    int32_t num_frames;   /* T: 7 (reference); 3 and 5 also supported                    */
+    int32_t scale;        /* 4 (reference) or 2 (build-defined tail)      */
+    int32_t mf;           /* trunk width, must be 64                                     */
+    int32_t num_block;    /* progressive-fusion blocks, 20 in the reference (>=0)        */
+    int32_t device_id;    /* HIP device ordinal                                          */
+    int32_t reserved[3];  /* must be 0                                                   */
+} pfnl_config;
+
+const char* pfnl_last_error(void);
+int pfnl_version(void);                        /* ABI version, currently 1 */
+int pfnl_device_count(int* count);
+
+/* ---- model lifetime ---------------------------------------------------------------------- */
+int pfnl_create(const pfnl_config* cfg, pfnl_handle** out);
+int pfnl_destroy(pfnl_handle* h);
+
+/* Replaces tf.train.Saver.restore (reference model/base_model.py:231-243).  `tf_name` is the TF
+ * variable name ("nlvsr/conv1_3/kernel", "nlvsr/nlblock_0/g/g/bias" ...; reference
+ * model/pfnl.py:47-53, utils.py:23-26,66-67).  `host` is float32 HWIO (kernels) / [Cout] (biases)
+ * and stays owned by the caller; the library keeps its own repacked device copies. */
+int pfnl_set_weight(pfnl_handle* h, const char* tf_name, const float* host,
+                    const int64_t* shape, int rank);
+/* Number of variables still missing (0 = complete). */
+int pfnl_missing_weights(pfnl_handle* h, int* count);
+/* Repack + upload: splits conv2_i into its shared-`base` half and per-frame half, folds
+ * Wg*Ww of the non-local block, chunks the implicit-GEMM weights. */
+int pfnl_finalize_weights(pfnl_handle* h);
+
+/* ---- the hot path ------------------------------------------------------------------------ */
+/* Replaces sess.run(SR_test, feed_dict={L_test: ...}) (reference model/pfnl.py:252,309) /
+ * PFNL.forward (model/pfnl.py:39-80).  `in`  = [B,T,H,W,3] float32, `out` = [B,1,sH,sW,3]
+ * float32.  H and W must be even (tf.space_to_depth, model/pfnl.py:57).  With device pointers
+ * the call is asynchronous on `stream`; with host pointers it returns when `out` is filled. */
+int pfnl_forward(pfnl_handle* h, const void* in, int in_is_device, void* out, int out_is_device,
+                 int B, int H, int W, void* stream);
+int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes);
+int pfnl_sync(pfnl_handle* h);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+/* Per-kernel-class HIP-event timing on the launch stream.  enable!=0: every launch of the
+ * classes below is bracketed by hipEvents until disabled; pfnl_profile_read synchronises and
+ * returns accumulated milliseconds and launch counts since the last reset. */
+enum {
+    PFNL_K_NL_PACK = 0, PFNL_K_NL_ATTN = 1, PFNL_K_CONV0 = 2, PFNL_K_CONV3X3 = 3,
+    PFNL_K_CONV1X1 = 4, PFNL_K_MERGE1 = 5, PFNL_K_TAIL = 6, PFNL_K_COUNT = 7
+};
+int pfnl_profile_enable(pfnl_handle* h, int enable);
+int pfnl_profile_reset(pfnl_handle* h);
+int pfnl_profile_read(pfnl_handle* h, double* ms /*[PFNL_K_COUNT]*/, int64_t* launches /*[PFNL_K_COUNT]*/);
+
+/* ---- debugging / per-stage parity --------------------------------------------------------- */
+/* Copy an internal buffer of the last forward to host (synchronises).  Names:
+ *   "nl_out"  [B,H,W,3T]   frame stack after the non-local residual (model/pfnl.py:60)
+ *   "trunk"   [B,T,H,W,64] inp0 after the last PF block          (model/pfnl.py:71)
+ *   "merge1"  [B,H,W,48]   after convmerge1                       (model/pfnl.py:74)  */
+int pfnl_debug_tap(pfnl_handle* h, const char* name, float* host_dst, size_t count);
+
+/* ---- single ops (the TF kernels the reference calls), device pointers, async on stream ---- */
+/* tf.layers.Conv2D(k=1|3, 'same') + bias + optional leaky_relu(0.2) on NHWC float32 with the MFMA
+ * implicit-GEMM kernel.  in [items*frames_per_item, H, W, 64] viewed as [items,H,W,64*fpi];
+ * kernel_host = HWIO [k,k,64*fpi,cout] (host), bias_host [cout] or NULL; cout <= 64;
+ * addend (device, [items/add_div,H,W,64]) or NULL is added before the activation, resid (device,
+ * [items,H,W,cout]) or NULL after it; out [items,H,W,cout].  (model/pfnl.py:49-52,66-74) */
+int pfnl_op_conv2d(const float* in, const float* kernel_host, const float* bias_host,
+                   const float* addend, int add_div, const float* resid, float* out,
+                   int items, int frames_per_item, int H, int W, int ksize, int cout, int act,
+                   void* stream);
+/* utils.NonLocalBlock(nltype=1) + the residual of model/pfnl.py:55-60:
+ * x [B,T,H,W,3] -> out [B,H,W,3T] = stack(x) + depth_to_space(NL(space_to_depth(stack(x)))). */
+int pfnl_op_nonlocal(const float* x, const float* wg_host, const float* bg_host,
+                     const float* ww_host, const float* bw_host, float* out,
+                     int B, int T, int H, int W, void* stream);
+/* tf.image.resize_images(method=2) of TF1.12 (model/pfnl.py:63): x [B,H,W,3] -> [B,sH,sW,3]. */
+int pfnl_op_bicubic(const float* x, float* out, int B, int H, int W, int scale, void* stream);
+/* MFMA operand/accumulator layout self-test (asymmetric operands); returns 0 if the f32
+ * 32x32x2 fragment maps this library assumes hold on the device. */
+int pfnl_selftest_mfma(int device_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFNL_HIP_H */

@@ -1,0 +1,106 @@
+"""Checkpoint directory handling with the reference's conventions (model/base_model.py:223-243):
+
+    <dir>/checkpoint                  text state file:  model_checkpoint_path: "VSR-<step>"
+    <dir>/VSR-<step>.index / .data-00000-of-00001      TF tensor-bundle (read + written by tfbundle.py)
+    <dir>/VSR-<step>.npz                               this build's own fast format, same tensor names
+
+Tensor names are the TF variable names of SURVEY.md §8(a)-W (``nlvsr/conv0/kernel`` ...).  Training
+checkpoints also contain optimizer slots (``.../Adam``, ``beta1_power``, ``Variable``); they are
+ignored.  Names are matched exactly first, then by suffix (``conv0/kernel``) so that a bundle saved
+under a different outer scope still loads; anything unmatched is reported.
+"""
+from __future__ import annotations
+
+import os
+import re
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from .spec import PFNLGeometry
+
+
+def read_state_file(checkpoint_dir: str) -> Optional[str]:
+    """Returns the basename in ``model_checkpoint_path`` (tf.train.get_checkpoint_state) or None."""
+    path = os.path.join(checkpoint_dir, "checkpoint")
+    if not os.path.isfile(path):
+        return None
+    with open(path, "rt") as f:
+        for line in f:
+            m = re.match(r'\s*model_checkpoint_path:\s*"(.*)"\s*$', line)
+            if m:
+                return os.path.basename(m.group(1))
+    return None
+
+
+def write_state_file(checkpoint_dir: str, basename: str) -> None:
+    path = os.path.join(checkpoint_dir, "checkpoint")
+    prev = []
+    if os.path.isfile(path):
+        with open(path, "rt") as f:
+            for line in f:
+                m = re.match(r'\s*all_model_checkpoint_paths:\s*"(.*)"\s*$', line)
+                if m and m.group(1) != basename:
+                    prev.append(m.group(1))
+    with open(path, "wt") as f:
+        f.write('model_checkpoint_path: "{}"\n'.format(basename))
+        for p in prev + [basename]:
+            f.write('all_model_checkpoint_paths: "{}"\n'.format(p))
+
+
+def match_tensors(geom: PFNLGeometry, tensors: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """Pick the model's variables out of an arbitrary name->array dict (exact, then suffix match)."""
+    out: Dict[str, np.ndarray] = {}
+    missing = []
+    for name, shape in geom.weight_shapes():
+        cand = None
+        if name in tensors:
+            cand = tensors[name]
+        else:
+            suffix = name.split("/", 1)[1]
+            hits = [k for k in tensors if (k == suffix or k.endswith("/" + suffix)) and
+                    tuple(np.shape(tensors[k])) == tuple(shape)]
+            if len(hits) == 1:
+                cand = tensors[hits[0]]
+        if cand is None or tuple(np.shape(cand)) != tuple(shape):
+            missing.append(name)
+        else:
+            out[name] = np.asarray(cand, dtype=np.float32)
+    if missing:
+        raise KeyError("checkpoint lacks {} of {} tensors, e.g. {}".format(
+            len(missing), len(geom.weight_shapes()), missing[:3]))
+    return out
+
+
+def load_checkpoint(checkpoint_dir: str, geom: PFNLGeometry, step: Optional[int] = None
+                    ) -> Optional[Tuple[str, Dict[str, np.ndarray]]]:
+    """None if the directory holds no checkpoint (the reference prints ERROR and returns False)."""
+    if not os.path.isdir(checkpoint_dir):
+        return None
+    base = "VSR-{}".format(step) if step is not None else read_state_file(checkpoint_dir)
+    if base is None:
+        return None
+    prefix = os.path.join(checkpoint_dir, base)
+    if os.path.isfile(prefix + ".npz"):
+        with np.load(prefix + ".npz") as z:
+            tensors = {k: z[k] for k in z.files}
+    elif os.path.isfile(prefix + ".index"):
+        from . import tfbundle
+        tensors = tfbundle.read_bundle(prefix)
+    else:
+        return None
+    return base, match_tensors(geom, tensors)
+
+
+def save_checkpoint(checkpoint_dir: str, weights: Dict[str, np.ndarray], step: int, model_name: str = "VSR",
+                    fmt: str = "both") -> str:
+    os.makedirs(checkpoint_dir, exist_ok=True)
+    base = "{}-{}".format(model_name, int(step))
+    prefix = os.path.join(checkpoint_dir, base)
+    if fmt in ("npz", "both"):
+        np.savez(prefix + ".npz", **{k: np.asarray(v, np.float32) for k, v in weights.items()})
+    if fmt in ("tf", "both"):
+        from . import tfbundle
+        tfbundle.write_bundle(prefix, {k: np.asarray(v, np.float32) for k, v in weights.items()})
+    write_state_file(checkpoint_dir, base)
+    return prefix

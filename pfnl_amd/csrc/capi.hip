@@ -1,0 +1,629 @@
+// C-ABI of libpfnl_hip.so (see include/pfnl_hip.h): handle, weight repacking, the forward
+// schedule of PFNL.forward (reference model/pfnl.py:39-80) as a sequence of HIP kernel launches.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pfnl_hip.h"
+#include "common.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return fail(PFNL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
+    } while (0)
+
+struct DevBuf {
+    float* p = nullptr;
+    size_t n = 0;   // floats
+    int ensure(size_t count) {
+        if (count <= n) return 0;
+        if (p) hipFree(p);
+        p = nullptr;
+        n = 0;
+        if (hipMalloc(&p, count * sizeof(float)) != hipSuccess) return -1;
+        n = count;
+        return 0;
+    }
+    void release() {
+        if (p) hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+}  // namespace
+
+struct pfnl_handle {
+    pfnl_config cfg;
+    hipStream_t stream = nullptr;
+    std::map<std::string, std::vector<int64_t>> expected;   // tf name -> shape
+    std::map<std::string, HostTensor> host;                  // tensors received so far
+    bool finalized = false;
+
+    // device weights (offsets in floats into `wdev`)
+    DevBuf wdev;
+    size_t off_conv0_w = 0, off_conv0_b = 0;
+    std::vector<size_t> off_c1_w, off_c1_b, off_c10_w, off_c10_b, off_c2a_w, off_c2b_w, off_c2_b;
+    size_t off_m1_w = 0, off_m1_b = 0, off_m2_w = 0, off_m2_b = 0, off_nl_w = 0, off_nl_b = 0, off_zero = 0;
+
+    // workspace
+    DevBuf X, Xo, inp0, inp1, base, pb, merge, stage_in, stage_out, scratch;
+    int lastB = 0, lastH = 0, lastW = 0;
+
+    // profiling
+    bool prof = false;
+    struct Ev {
+        hipEvent_t a, b;
+        int cls;
+    };
+    std::vector<Ev> evs;
+    size_t evs_used = 0;
+    double prof_ms[PFNL_K_COUNT] = {0};
+    int64_t prof_n[PFNL_K_COUNT] = {0};
+};
+
+namespace {
+
+using namespace pfnl;
+
+struct ProfScope {
+    pfnl_handle* h;
+    hipStream_t s;
+    int idx = -1;
+    ProfScope(pfnl_handle* h_, hipStream_t s_, int cls) : h(h_), s(s_) {
+        if (!h || !h->prof) return;
+        if (h->evs_used == h->evs.size()) {
+            pfnl_handle::Ev e;
+            if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+            h->evs.push_back(e);
+        }
+        idx = (int)h->evs_used++;
+        h->evs[idx].cls = cls;
+        hipEventRecord(h->evs[idx].a, s);
+    }
+    ~ProfScope() {
+        if (idx >= 0) hipEventRecord(h->evs[idx].b, s);
+    }
+};
+
+int prof_collect(pfnl_handle* h) {
+    for (size_t i = 0; i < h->evs_used; ++i) {
+        if (hipEventSynchronize(h->evs[i].b) != hipSuccess) return -1;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->evs[i].a, h->evs[i].b) != hipSuccess) return -1;
+        h->prof_ms[h->evs[i].cls] += ms;
+        h->prof_n[h->evs[i].cls] += 1;
+    }
+    h->evs_used = 0;
+    return 0;
+}
+
+int check_geometry(const pfnl_config& c) {
+    if (c.num_frames != 3 && c.num_frames != 5 && c.num_frames != 7)
+        return fail(PFNL_ERR_INVALID, "num_frames must be 3, 5 or 7");
+    if (c.scale != 2 && c.scale != 4) return fail(PFNL_ERR_INVALID, "scale must be 2 or 4");
+    if (c.mf != 64) return fail(PFNL_ERR_INVALID, "mf must be 64");
+    if (c.num_block < 0 || c.num_block > 1024) return fail(PFNL_ERR_INVALID, "bad num_block");
+    for (int r : c.reserved)
+        if (r != 0) return fail(PFNL_ERR_INVALID, "reserved config fields must be 0");
+    return 0;
+}
+
+void add_expected(pfnl_handle* h, const std::string& layer, int k, int cin, int cout) {
+    h->expected["nlvsr/" + layer + "/kernel"] = {k, k, cin, cout};
+    h->expected["nlvsr/" + layer + "/bias"] = {cout};
+}
+
+size_t numel(const std::vector<int64_t>& s) {
+    size_t n = 1;
+    for (auto d : s) n *= (size_t)d;
+    return n;
+}
+
+// forward over device buffers
+int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, int W, hipStream_t s) {
+    const pfnl_config& c = h->cfg;
+    const int T = c.num_frames, F = B * T;
+    const size_t P = (size_t)H * W;
+    const int N = (H / 2) * (W / 2);
+    const int C = 12 * T, CP = nl_padded_ch(C);
+    const float* wd = h->wdev.p;
+
+    if (h->X.ensure((size_t)B * N * CP) || h->Xo.ensure((size_t)B * N * CP) ||
+        h->inp0.ensure((size_t)F * P * 64) || h->inp1.ensure((size_t)F * P * 64) ||
+        h->base.ensure((size_t)B * P * 64) || h->pb.ensure((size_t)B * P * 64) ||
+        h->merge.ensure((size_t)B * P * 48))
+        return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
+    h->lastB = B;
+    h->lastH = H;
+    h->lastW = W;
+
+    {   // model/pfnl.py:55-60 (+ utils.py:18-71)
+        ProfScope ps(h, s, PFNL_K_NL_PACK);
+        HIPCHK(launch_nl_pack(in, h->X.p, B, T, H, W, s));
+    }
+    {
+        ProfScope ps(h, s, PFNL_K_NL_ATTN);
+        HIPCHK(launch_nl_attn(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, B, N, C, s));
+    }
+    {   // model/pfnl.py:61-62
+        ProfScope ps(h, s, PFNL_K_CONV0);
+        HIPCHK(launch_conv0(h->Xo.p, wd + h->off_conv0_w, wd + h->off_conv0_b, h->inp0.p, B, T, H, W, s));
+    }
+
+    ConvParams p{};
+    p.H = H;
+    p.W = W;
+    p.in_cstride = 64;
+    p.chunks_per_frame = 64 / CONV_CK;
+    for (int i = 0; i < c.num_block; ++i) {   // model/pfnl.py:65-71
+        {   // conv1_i: per frame 3x3 64->64 + lrelu                       (:66)
+            ProfScope ps(h, s, PFNL_K_CONV3X3);
+            p.in = h->inp0.p;
+            p.wpack = wd + h->off_c1_w[i];
+            p.bias = wd + h->off_c1_b[i];
+            p.addend = nullptr;
+            p.resid = nullptr;
+            p.out = h->inp1.p;
+            p.out_cstride = 64;
+            p.cout = 64;
+            p.frames_per_item = 1;
+            p.nchunks = p.chunks_per_frame;
+            p.add_div = 1;
+            p.act = 1;
+            HIPCHK(launch_conv_mfma(p, 3, F, s));
+        }
+        {   // conv10_i: 1x1 over the concat of T frames -> base + lrelu    (:67-68)
+            ProfScope ps(h, s, PFNL_K_CONV1X1);
+            p.in = h->inp1.p;
+            p.wpack = wd + h->off_c10_w[i];
+            p.bias = wd + h->off_c10_b[i];
+            p.out = h->base.p;
+            p.frames_per_item = T;
+            p.nchunks = T * p.chunks_per_frame;
+            HIPCHK(launch_conv_mfma(p, 1, B, s));
+        }
+        {   // conv2_i, shared half: 3x3 over `base` (kernel rows 0..63), once per clip, raw
+            ProfScope ps(h, s, PFNL_K_CONV3X3);
+            p.in = h->base.p;
+            p.wpack = wd + h->off_c2a_w[i];
+            p.bias = wd + h->off_zero;
+            p.out = h->pb.p;
+            p.frames_per_item = 1;
+            p.nchunks = p.chunks_per_frame;
+            p.act = 0;
+            HIPCHK(launch_conv_mfma(p, 3, B, s));
+        }
+        {   // conv2_i, per-frame half (kernel rows 64..127) + shared half + bias, lrelu, residual (:69-71)
+            ProfScope ps(h, s, PFNL_K_CONV3X3);
+            p.in = h->inp1.p;
+            p.wpack = wd + h->off_c2b_w[i];
+            p.bias = wd + h->off_c2_b[i];
+            p.addend = h->pb.p;
+            p.add_div = T;
+            p.resid = h->inp0.p;
+            p.out = h->inp0.p;
+            p.act = 1;
+            HIPCHK(launch_conv_mfma(p, 3, F, s));
+        }
+    }
+    {   // convmerge1: 3x3 over the concat of T frames -> 48 + lrelu        (:73-74)
+        ProfScope ps(h, s, PFNL_K_MERGE1);
+        p.in = h->inp0.p;
+        p.wpack = wd + h->off_m1_w;
+        p.bias = wd + h->off_m1_b;
+        p.addend = nullptr;
+        p.resid = nullptr;
+        p.out = h->merge.p;
+        p.out_cstride = 48;
+        p.cout = 48;
+        p.frames_per_item = T;
+        p.nchunks = T * p.chunks_per_frame;
+        p.add_div = 1;
+        p.act = 1;
+        HIPCHK(launch_conv_mfma(p, 3, B, s));
+    }
+    {   // model/pfnl.py:63,76-80
+        ProfScope ps(h, s, PFNL_K_TAIL);
+        HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, H, W, c.scale, s));
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pfnl_last_error(void) { return g_err.c_str(); }
+int pfnl_version(void) { return 1; }
+
+int pfnl_device_count(int* count) {
+    if (!count) return fail(PFNL_ERR_INVALID, "count is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return 0;
+}
+
+int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
+    if (!cfg || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (int e = check_geometry(*cfg)) return e;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(PFNL_ERR_NODEVICE, "no HIP device visible: libpfnl_hip has no CPU fallback");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(PFNL_ERR_INVALID, "bad device_id");
+    HIPCHK(hipSetDevice(cfg->device_id));
+    pfnl_handle* h = new pfnl_handle();
+    h->cfg = *cfg;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return fail(PFNL_ERR_HIP, "hipStreamCreate failed");
+    }
+    const int T = cfg->num_frames, C = 12 * T;
+    add_expected(h, "conv0", 5, 3, 64);
+    for (int i = 0; i < cfg->num_block; ++i) {
+        add_expected(h, "conv1_" + std::to_string(i), 3, 64, 64);
+        add_expected(h, "conv10_" + std::to_string(i), 1, 64 * T, 64);
+        add_expected(h, "conv2_" + std::to_string(i), 3, 128, 64);
+    }
+    add_expected(h, "convmerge1", 3, 64 * T, 48);
+    add_expected(h, "convmerge2", 3, 12, cfg->scale == 4 ? 12 : 3);
+    add_expected(h, "nlblock_0/g/g", 1, C, C);
+    add_expected(h, "nlblock_0/w/w", 1, C, C);
+    *out = h;
+    return 0;
+}
+
+int pfnl_destroy(pfnl_handle* h) {
+    if (!h) return 0;
+    hipSetDevice(h->cfg.device_id);
+    if (h->stream) {
+        hipStreamSynchronize(h->stream);
+        hipStreamDestroy(h->stream);
+    }
+    for (auto& e : h->evs) {
+        hipEventDestroy(e.a);
+        hipEventDestroy(e.b);
+    }
+    for (DevBuf* b : {&h->wdev, &h->X, &h->Xo, &h->inp0, &h->inp1, &h->base, &h->pb, &h->merge,
+                      &h->stage_in, &h->stage_out, &h->scratch})
+        b->release();
+    delete h;
+    return 0;
+}
+
+int pfnl_set_weight(pfnl_handle* h, const char* tf_name, const float* host, const int64_t* shape,
+                    int rank) {
+    if (!h || !tf_name || !host || !shape) return fail(PFNL_ERR_INVALID, "NULL argument");
+    std::string name(tf_name);
+    // tolerate a ":0" suffix and a missing "nlvsr/" prefix (checkpoint readers differ)
+    if (name.size() > 2 && name.compare(name.size() - 2, 2, ":0") == 0) name.resize(name.size() - 2);
+    auto it = h->expected.find(name);
+    if (it == h->expected.end()) it = h->expected.find("nlvsr/" + name);
+    if (it == h->expected.end()) return fail(PFNL_ERR_INVALID, "unknown tensor name: " + name);
+    if ((int)it->second.size() != rank) return fail(PFNL_ERR_INVALID, "rank mismatch for " + name);
+    for (int i = 0; i < rank; ++i)
+        if (shape[i] != it->second[i]) return fail(PFNL_ERR_INVALID, "shape mismatch for " + name);
+    HostTensor t;
+    t.shape = it->second;
+    t.data.assign(host, host + numel(t.shape));
+    h->host[it->first] = std::move(t);
+    h->finalized = false;
+    return 0;
+}
+
+int pfnl_missing_weights(pfnl_handle* h, int* count) {
+    if (!h || !count) return fail(PFNL_ERR_INVALID, "NULL argument");
+    int n = 0;
+    for (auto& kv : h->expected)
+        if (!h->host.count(kv.first)) ++n;
+    *count = n;
+    return 0;
+}
+
+int pfnl_finalize_weights(pfnl_handle* h) {
+    if (!h) return fail(PFNL_ERR_INVALID, "NULL handle");
+    for (auto& kv : h->expected)
+        if (!h->host.count(kv.first)) return fail(PFNL_ERR_STATE, "missing tensor " + kv.first);
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    const int T = h->cfg.num_frames, nb = h->cfg.num_block, C = 12 * T, CP = pfnl::nl_padded_ch(C);
+    std::vector<float> blob;
+    auto W = [&](const std::string& l) -> const std::vector<float>& { return h->host["nlvsr/" + l + "/kernel"].data; };
+    auto Bv = [&](const std::string& l) -> const std::vector<float>& { return h->host["nlvsr/" + l + "/bias"].data; };
+    auto reserve = [&](size_t n) {
+        size_t off = (blob.size() + 63) / 64 * 64;   // 256-byte aligned segments
+        blob.resize(off + n, 0.f);
+        return off;
+    };
+    auto put_bias = [&](const std::vector<float>& b) {
+        size_t off = reserve(64);
+        std::memcpy(&blob[off], b.data(), b.size() * sizeof(float));
+        return off;
+    };
+    auto put_pack = [&](const std::vector<float>& k, int ks, int cin_total, int cin_begin, int cin, int cout) {
+        size_t off = reserve(pfnl::conv_pack_floats(ks, cin));
+        pfnl::conv_pack_weights(k.data(), ks, cin_total, cin_begin, cin, cout, &blob[off]);
+        return off;
+    };
+
+    h->off_zero = reserve(64);
+    h->off_conv0_w = reserve(75 * 64);
+    std::memcpy(&blob[h->off_conv0_w], W("conv0").data(), 75 * 64 * sizeof(float));
+    h->off_conv0_b = put_bias(Bv("conv0"));
+    h->off_c1_w.assign(nb, 0);
+    h->off_c1_b.assign(nb, 0);
+    h->off_c10_w.assign(nb, 0);
+    h->off_c10_b.assign(nb, 0);
+    h->off_c2a_w.assign(nb, 0);
+    h->off_c2b_w.assign(nb, 0);
+    h->off_c2_b.assign(nb, 0);
+    for (int i = 0; i < nb; ++i) {
+        const std::string s = std::to_string(i);
+        h->off_c1_w[i] = put_pack(W("conv1_" + s), 3, 64, 0, 64, 64);
+        h->off_c1_b[i] = put_bias(Bv("conv1_" + s));
+        h->off_c10_w[i] = put_pack(W("conv10_" + s), 1, 64 * T, 0, 64 * T, 64);
+        h->off_c10_b[i] = put_bias(Bv("conv10_" + s));
+        // conv2_i input = concat([base, inp1_t]) (model/pfnl.py:69): rows 0..63 see `base`.
+        h->off_c2a_w[i] = put_pack(W("conv2_" + s), 3, 128, 0, 64, 64);
+        h->off_c2b_w[i] = put_pack(W("conv2_" + s), 3, 128, 64, 64, 64);
+        h->off_c2_b[i] = put_bias(Bv("conv2_" + s));
+    }
+    h->off_m1_w = put_pack(W("convmerge1"), 3, 64 * T, 0, 64 * T, 48);
+    h->off_m1_b = put_bias(Bv("convmerge1"));
+    {
+        const auto& k = W("convmerge2");
+        h->off_m2_w = reserve(k.size());
+        std::memcpy(&blob[h->off_m2_w], k.data(), k.size() * sizeof(float));
+        h->off_m2_b = put_bias(Bv("convmerge2"));
+    }
+    {   // fold the two 1x1 projections of the non-local block: W' = Wg Ww, b' = bg Ww + bw
+        const auto& wg = W("nlblock_0/g/g");   // [C][C] (ci, cm)
+        const auto& ww = W("nlblock_0/w/w");   // [C][C] (cm, co)
+        const auto& bg = Bv("nlblock_0/g/g");
+        const auto& bw = Bv("nlblock_0/w/w");
+        h->off_nl_w = reserve((size_t)CP * CP);
+        h->off_nl_b = reserve(CP);
+        for (int ci = 0; ci < C; ++ci)
+            for (int co = 0; co < C; ++co) {
+                double acc = 0.0;
+                for (int cm = 0; cm < C; ++cm) acc += (double)wg[(size_t)ci * C + cm] * (double)ww[(size_t)cm * C + co];
+                blob[h->off_nl_w + (size_t)ci * CP + co] = (float)acc;
+            }
+        for (int co = 0; co < C; ++co) {
+            double acc = bw[co];
+            for (int cm = 0; cm < C; ++cm) acc += (double)bg[cm] * (double)ww[(size_t)cm * C + co];
+            blob[h->off_nl_b + co] = (float)acc;
+        }
+    }
+    if (h->wdev.ensure(blob.size())) return fail(PFNL_ERR_NOMEM, "weight allocation failed");
+    HIPCHK(hipMemcpy(h->wdev.p, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->finalized = true;
+    return 0;
+}
+
+int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes) {
+    if (!h || !bytes) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return fail(PFNL_ERR_INVALID, "bad shape");
+    const size_t T = h->cfg.num_frames, P = (size_t)H * W, N = P / 4;
+    const size_t CP = pfnl::nl_padded_ch(12 * (int)T);
+    size_t f = 2 * B * N * CP + 2 * B * T * P * 64 + 2 * B * P * 64 + B * P * 48;
+    *bytes = f * sizeof(float);
+    return 0;
+}
+
+int pfnl_forward(pfnl_handle* h, const void* in, int in_is_device, void* out, int out_is_device, int B,
+                 int H, int W, void* stream) {
+    if (!h || !in || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (!h->finalized) return fail(PFNL_ERR_STATE, "pfnl_finalize_weights has not been called");
+    if (B <= 0 || H <= 0 || W <= 0) return fail(PFNL_ERR_INVALID, "B, H, W must be positive");
+    if ((H & 1) || (W & 1))
+        return fail(PFNL_ERR_INVALID, "H and W must be even (space_to_depth(2), reference model/pfnl.py:57)");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    const int T = h->cfg.num_frames, sc = h->cfg.scale;
+    const size_t n_in = (size_t)B * T * H * W * 3, n_out = (size_t)B * H * W * sc * sc * 3;
+    const float* din = (const float*)in;
+    float* dout = (float*)out;
+    if (!in_is_device) {
+        if (h->stage_in.ensure(n_in)) return fail(PFNL_ERR_NOMEM, "staging allocation failed");
+        HIPCHK(hipMemcpyAsync(h->stage_in.p, in, n_in * sizeof(float), hipMemcpyHostToDevice, s));
+        din = h->stage_in.p;
+    }
+    if (!out_is_device) {
+        if (h->stage_out.ensure(n_out)) return fail(PFNL_ERR_NOMEM, "staging allocation failed");
+        dout = h->stage_out.p;
+    }
+    if (int e = forward_device(h, din, dout, B, H, W, s)) return e;
+    if (!out_is_device) {
+        HIPCHK(hipMemcpyAsync(out, dout, n_out * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    } else if (!in_is_device) {
+        HIPCHK(hipStreamSynchronize(s));   // the caller may reuse its host buffer on return
+    }
+    return 0;
+}
+
+int pfnl_sync(pfnl_handle* h) {
+    if (!h) return fail(PFNL_ERR_INVALID, "NULL handle");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int pfnl_profile_enable(pfnl_handle* h, int enable) {
+    if (!h) return fail(PFNL_ERR_INVALID, "NULL handle");
+    if (!enable && h->prof) {
+        if (prof_collect(h)) return fail(PFNL_ERR_HIP, "event collection failed");
+    }
+    h->prof = enable != 0;
+    return 0;
+}
+
+int pfnl_profile_reset(pfnl_handle* h) {
+    if (!h) return fail(PFNL_ERR_INVALID, "NULL handle");
+    if (prof_collect(h)) return fail(PFNL_ERR_HIP, "event collection failed");
+    for (int i = 0; i < PFNL_K_COUNT; ++i) {
+        h->prof_ms[i] = 0;
+        h->prof_n[i] = 0;
+    }
+    return 0;
+}
+
+int pfnl_profile_read(pfnl_handle* h, double* ms, int64_t* launches) {
+    if (!h || !ms || !launches) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (prof_collect(h)) return fail(PFNL_ERR_HIP, "event collection failed");
+    for (int i = 0; i < PFNL_K_COUNT; ++i) {
+        ms[i] = h->prof_ms[i];
+        launches[i] = h->prof_n[i];
+    }
+    return 0;
+}
+
+int pfnl_debug_tap(pfnl_handle* h, const char* name, float* host_dst, size_t count) {
+    if (!h || !name || !host_dst) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (!h->lastB) return fail(PFNL_ERR_STATE, "no forward has run");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipDeviceSynchronize());
+    const int B = h->lastB, H = h->lastH, W = h->lastW, T = h->cfg.num_frames;
+    const std::string n(name);
+    const float* src = nullptr;
+    size_t need = 0;
+    if (n == "nl_out") {
+        need = (size_t)B * H * W * 3 * T;
+        if (h->scratch.ensure(need)) return fail(PFNL_ERR_NOMEM, "scratch allocation failed");
+        HIPCHK(pfnl::launch_nl_unpack(h->Xo.p, h->scratch.p, B, T, H, W, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        src = h->scratch.p;
+    } else if (n == "trunk") {
+        need = (size_t)B * T * H * W * 64;
+        src = h->inp0.p;
+    } else if (n == "merge1") {
+        need = (size_t)B * H * W * 48;
+        src = h->merge.p;
+    } else {
+        return fail(PFNL_ERR_INVALID, "unknown tap " + n);
+    }
+    if (count != need) return fail(PFNL_ERR_INVALID, "tap size mismatch");
+    HIPCHK(hipMemcpy(host_dst, src, need * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- single ops -------------------------------------------------------------------------------
+
+int pfnl_op_conv2d(const float* in, const float* kernel_host, const float* bias_host, const float* addend,
+                   int add_div, const float* resid, float* out, int items, int frames_per_item, int H, int W,
+                   int ksize, int cout, int act, void* stream) {
+    if (!in || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if ((ksize != 1 && ksize != 3) || cout < 1 || cout > 64 || items < 1 || frames_per_item < 1 || H < 1 || W < 1)
+        return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
+    if ((addend != nullptr) != (resid != nullptr))
+        return fail(PFNL_ERR_INVALID, "addend and resid must be given together (fused conv2 epilogue) or not at all");
+    if (addend && add_div < 1) return fail(PFNL_ERR_INVALID, "add_div must be >= 1");
+    if (addend && cout != 64) return fail(PFNL_ERR_INVALID, "fused epilogue needs cout == 64");
+    hipStream_t s = (hipStream_t)stream;
+    const int cin = 64 * frames_per_item;
+    std::vector<float> pack(pfnl::conv_pack_floats(ksize, cin) + 64, 0.f);
+    pfnl::conv_pack_weights(kernel_host, ksize, cin, 0, cin, cout, pack.data());
+    const size_t boff = pack.size() - 64;
+    if (bias_host) std::memcpy(&pack[boff], bias_host, cout * sizeof(float));
+    float* dw = nullptr;
+    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(float)));
+    hipError_t e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        pfnl::ConvParams p{};
+        p.in = in;
+        p.wpack = dw;
+        p.bias = dw + boff;   // zeros when bias_host is NULL
+        p.addend = addend;
+        p.resid = resid;
+        p.out = out;
+        p.H = H;
+        p.W = W;
+        p.in_cstride = 64;
+        p.out_cstride = cout;
+        p.cout = cout;
+        p.chunks_per_frame = 64 / pfnl::CONV_CK;
+        p.frames_per_item = frames_per_item;
+        p.nchunks = frames_per_item * p.chunks_per_frame;
+        p.add_div = addend ? add_div : 1;
+        p.act = act;
+        e = pfnl::launch_conv_mfma(p, ksize, items, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    hipFree(dw);
+    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv op: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int pfnl_op_nonlocal(const float* x, const float* wg, const float* bg, const float* ww, const float* bw,
+                     float* out, int B, int T, int H, int W, void* stream) {
+    if (!x || !wg || !bg || !ww || !bw || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if ((T != 3 && T != 5 && T != 7) || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1))
+        return fail(PFNL_ERR_INVALID, "unsupported non-local geometry");
+    hipStream_t s = (hipStream_t)stream;
+    const int C = 12 * T, CP = pfnl::nl_padded_ch(C), N = (H / 2) * (W / 2);
+    std::vector<float> blob((size_t)CP * CP + CP, 0.f);
+    for (int ci = 0; ci < C; ++ci)
+        for (int co = 0; co < C; ++co) {
+            double acc = 0.0;
+            for (int cm = 0; cm < C; ++cm) acc += (double)wg[(size_t)ci * C + cm] * (double)ww[(size_t)cm * C + co];
+            blob[(size_t)ci * CP + co] = (float)acc;
+        }
+    for (int co = 0; co < C; ++co) {
+        double acc = bw[co];
+        for (int cm = 0; cm < C; ++cm) acc += (double)bg[cm] * (double)ww[(size_t)cm * C + co];
+        blob[(size_t)CP * CP + co] = (float)acc;
+    }
+    float* d = nullptr;
+    const size_t nX = (size_t)B * N * CP;
+    HIPCHK(hipMalloc(&d, (blob.size() + 2 * nX) * sizeof(float)));
+    float* dX = d + blob.size();
+    float* dXo = dX + nX;
+    hipError_t e = hipMemcpy(d, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = pfnl::launch_nl_pack(x, dX, B, T, H, W, s);
+    if (e == hipSuccess) e = pfnl::launch_nl_attn(dX, dXo, d, d + (size_t)CP * CP, B, N, C, s);
+    if (e == hipSuccess) e = pfnl::launch_nl_unpack(dXo, out, B, T, H, W, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    hipFree(d);
+    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("nonlocal op: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int pfnl_op_bicubic(const float* x, float* out, int B, int H, int W, int scale, void* stream) {
+    if (!x || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (B < 1 || H < 1 || W < 1 || (scale != 2 && scale != 4)) return fail(PFNL_ERR_INVALID, "bad bicubic geometry");
+    HIPCHK(pfnl::launch_bicubic(x, out, B, H, W, scale, (hipStream_t)stream));
+    return 0;
+}
+
+int pfnl_selftest_mfma(int device_id) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(PFNL_ERR_NODEVICE, "no HIP device visible");
+    HIPCHK(hipSetDevice(device_id));
+    int bad = -1;
+    HIPCHK(pfnl::run_mfma_selftest(&bad));
+    if (bad != 0) return fail(PFNL_ERR_STATE, "MFMA fragment layout mismatch: " + std::to_string(bad) + " elements");
+    return 0;
+}
+
+}  // extern "C"

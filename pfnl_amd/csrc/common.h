@@ -1,0 +1,68 @@
+// Shared declarations of libpfnl_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace pfnl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32], exact f32 (fmaf chain), 64 cycles/SIMD.
+// Fragment maps (cdna_hip_programming.md §3): lane l holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
+// D register r of lane l is D[i=(r&3)+8*(r>>2)+4*(l>>5)][j=l&31].
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int drow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, 0.2f * v); }  // tf.nn.leaky_relu
+
+// ---- MFMA implicit-GEMM convolution (conv_mfma.hip) ------------------------------------------
+// Output tile of one workgroup: 8 rows x 32 columns x 64 output channels of one item.
+constexpr int CONV_TW = 32;
+constexpr int CONV_TH = 8;
+constexpr int CONV_CK = 16;       // input channels per K-chunk
+constexpr int CONV_NPAD = 64;     // output channels are padded to 64 in the packed weights
+
+struct ConvParams {
+    const float* in;       // [items*frames_per_item][H][W][in_cstride]
+    const float* wpack;    // [nchunks][ks*ks][CONV_CK][64]
+    const float* bias;     // [64] (zero padded); never null (use a zero vector)
+    const float* addend;   // [items/add_div][H][W][64]  (added before the activation) \ both or
+    const float* resid;    // [items][H][W][out_cstride] (added after the activation)  / neither
+    float* out;            // [items][H][W][out_cstride]
+    int H, W;
+    int in_cstride;        // floats per input pixel (64)
+    int out_cstride;       // floats per output pixel (= cout)
+    int cout;              // valid output channels (<= 64)
+    int chunks_per_frame;  // in_cstride / CONV_CK
+    int frames_per_item;   // 1: per-frame conv; T: conv over the concat of T frames
+    int nchunks;           // frames_per_item * chunks_per_frame
+    int add_div;           // addend item = item / add_div
+    int act;               // 1 = leaky_relu(0.2)
+};
+
+hipError_t launch_conv_mfma(const ConvParams& p, int ksize, int items, hipStream_t s);
+size_t conv_pack_floats(int ksize, int cin);                 // floats in the packed weight blob
+// HWIO [k,k,cin_total,cout] rows [cin_begin, cin_begin+cin) -> [chunk][tap][CK][64]
+void conv_pack_weights(const float* hwio, int ksize, int cin_total, int cin_begin, int cin,
+                       int cout, float* dst);
+
+// ---- non-local block (nonlocal.hip) ----------------------------------------------------------
+int nl_padded_ch(int C);                                      // 32*ceil(C/32)
+hipError_t launch_nl_pack(const float* x, float* X, int B, int T, int H, int W, hipStream_t s);
+hipError_t launch_nl_attn(const float* X, float* Xo, const float* Wp, const float* bp, int B, int N,
+                          int C, hipStream_t s);
+hipError_t launch_nl_unpack(const float* Xo, float* out, int B, int T, int H, int W, hipStream_t s);
+
+// ---- head / tail (misc_kernels.hip) ----------------------------------------------------------
+hipError_t launch_conv0(const float* Xo, const float* w75x64, const float* bias, float* out, int B,
+                        int T, int H, int W, hipStream_t s);
+hipError_t launch_tail(const float* merge, const float* x, const float* w2, const float* b2,
+                       float* out, int B, int T, int H, int W, int scale, hipStream_t s);
+hipError_t launch_bicubic(const float* x, float* out, int B, int H, int W, int scale, hipStream_t s);
+hipError_t run_mfma_selftest(int* mismatches);
+
+}  // namespace pfnl

@@ -1,0 +1,256 @@
+// Head and tail of PFNL.forward (gfx950): bandwidth-class kernels, f32 VALU.
+//   conv0   : lrelu(conv5x5 3->64) on each frame of the non-local output   (model/pfnl.py:48,61-62)
+//   tail    : depth_to_space -> convmerge2 3x3 (no activation) -> depth_to_space -> + bicubic(x_centre)
+//             -> [B,1,sH,sW,3]                                            (model/pfnl.py:53,63,76-80)
+//   bicubic : TF1.12 legacy ResizeBicubic (align_corners=False, no half-pixel centres, A=-0.75,
+//             clamped taps, no renormalisation)                           (model/pfnl.py:63)
+#include "common.h"
+
+namespace pfnl {
+
+// ------------------------------------------------------------------------------------------------
+// conv0.  Input is the packed non-local output Xo [B][N][CP] (space_to_depth layout, see
+// nonlocal.hip); pixel (y,x), stack channel k lives at Xo[b][(y/2)(W/2)+x/2][((y&1)*2+(x&1))*3T+k].
+// Workgroup = 16x16 output pixels of one frame; thread = one pixel x 64 output channels.
+constexpr int C0_T = 16;
+constexpr int C0_IN = C0_T + 4;
+
+__global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ Xo,
+                                                    const float* __restrict__ w,     // [75][64]
+                                                    const float* __restrict__ bias,  // [64]
+                                                    float* __restrict__ out, int T, int H, int W,
+                                                    int CP) {
+    __shared__ __attribute__((aligned(16))) float sw[75 * 64];
+    __shared__ float s_in[C0_IN * C0_IN * 3];
+    const int tid = threadIdx.x;
+    const int f = blockIdx.z;
+    const int b = f / T, t = f % T;
+    const int x0 = blockIdx.x * C0_T, y0 = blockIdx.y * C0_T;
+    const int W2 = W / 2, C3 = 3 * T;
+    const float* Xb = Xo + (size_t)b * (H / 2) * W2 * CP;
+
+    for (int i = tid; i < 75 * 64; i += 256) sw[i] = w[i];
+    for (int i = tid; i < C0_IN * C0_IN * 3; i += 256) {
+        const int c = i % 3, pix = i / 3;
+        const int py = pix / C0_IN, px = pix % C0_IN;
+        const int gy = y0 + py - 2, gx = x0 + px - 2;
+        float v = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+            v = Xb[((size_t)(gy >> 1) * W2 + (gx >> 1)) * CP + ((gy & 1) * 2 + (gx & 1)) * C3 + 3 * t + c];
+        s_in[i] = v;
+    }
+    __syncthreads();
+
+    const int ty = tid / C0_T, tx = tid % C0_T;
+    float acc[64];
+#pragma unroll
+    for (int o = 0; o < 64; ++o) acc[o] = bias[o];
+    for (int ky = 0; ky < 5; ++ky) {
+        for (int kx = 0; kx < 5; ++kx) {
+            const float* ip = s_in + ((ty + ky) * C0_IN + tx + kx) * 3;
+            const float* wp = sw + (ky * 5 + kx) * 3 * 64;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float a = ip[c];
+#pragma unroll
+                for (int o4 = 0; o4 < 16; ++o4) {
+                    const float4 wv = *reinterpret_cast<const float4*>(wp + c * 64 + o4 * 4);
+                    acc[o4 * 4 + 0] = fmaf(a, wv.x, acc[o4 * 4 + 0]);
+                    acc[o4 * 4 + 1] = fmaf(a, wv.y, acc[o4 * 4 + 1]);
+                    acc[o4 * 4 + 2] = fmaf(a, wv.z, acc[o4 * 4 + 2]);
+                    acc[o4 * 4 + 3] = fmaf(a, wv.w, acc[o4 * 4 + 3]);
+                }
+            }
+        }
+    }
+    const int y = y0 + ty, x = x0 + tx;
+    if (y < H && x < W) {
+        float4* dst = reinterpret_cast<float4*>(out + (((size_t)f * H + y) * W + x) * 64);
+#pragma unroll
+        for (int o4 = 0; o4 < 16; ++o4)
+            dst[o4] = make_float4(lrelu(acc[o4 * 4]), lrelu(acc[o4 * 4 + 1]), lrelu(acc[o4 * 4 + 2]),
+                                  lrelu(acc[o4 * 4 + 3]));
+    }
+}
+
+hipError_t launch_conv0(const float* Xo, const float* w75x64, const float* bias, float* out, int B,
+                        int T, int H, int W, hipStream_t s) {
+    dim3 grid((W + C0_T - 1) / C0_T, (H + C0_T - 1) / C0_T, B * T);
+    hipLaunchKernelGGL(conv0_kernel, grid, dim3(256), 0, s, Xo, w75x64, bias, out, T, H, W,
+                       nl_padded_ch(12 * T));
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Keys cubic (A = -0.75) tap weights at fractional offset t; exact in f32 for t = k/4 and k/2.
+__device__ __forceinline__ void cubic_taps(float t, float w[4]) {
+    const float A = -0.75f;
+    const float d0 = 1.f + t, d1 = t, d2 = 1.f - t, d3 = 2.f - t;
+    w[0] = ((A * d0 - 5.f * A) * d0 + 8.f * A) * d0 - 4.f * A;
+    w[1] = ((A + 2.f) * d1 - (A + 3.f)) * d1 * d1 + 1.f;
+    w[2] = ((A + 2.f) * d2 - (A + 3.f)) * d2 * d2 + 1.f;
+    w[3] = ((A * d3 - 5.f * A) * d3 + 8.f * A) * d3 - 4.f * A;
+}
+
+// src [H][W][3] with row pitch `pitch` floats; returns the 3 channels of HR pixel (oy, ox).
+__device__ __forceinline__ void bicubic_px(const float* __restrict__ src, int H, int W, size_t pitch,
+                                           int scale, int oy, int ox, float res[3]) {
+    const int iy = oy / scale, ix = ox / scale;
+    float wy[4], wx[4];
+    cubic_taps((float)(oy % scale) / (float)scale, wy);
+    cubic_taps((float)(ox % scale) / (float)scale, wx);
+    res[0] = res[1] = res[2] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int yy = min(max(iy - 1 + a, 0), H - 1);
+        float row[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const int xx = min(max(ix - 1 + bb, 0), W - 1);
+            const float* p = src + (size_t)yy * pitch + (size_t)xx * 3;
+            row[0] = fmaf(wx[bb], p[0], row[0]);
+            row[1] = fmaf(wx[bb], p[1], row[1]);
+            row[2] = fmaf(wx[bb], p[2], row[2]);
+        }
+        res[0] = fmaf(wy[a], row[0], res[0]);
+        res[1] = fmaf(wy[a], row[1], res[1]);
+        res[2] = fmaf(wy[a], row[2], res[2]);
+    }
+}
+
+__global__ void bicubic_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int H,
+                               int W, int scale) {
+    const int OH = H * scale, OW = W * scale;
+    const size_t total = (size_t)B * OH * OW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % OW);
+        const int oy = (int)((i / OW) % OH);
+        const int b = (int)(i / ((size_t)OW * OH));
+        float r[3];
+        bicubic_px(x + (size_t)b * H * W * 3, H, W, (size_t)W * 3, scale, oy, ox, r);
+        out[i * 3 + 0] = r[0];
+        out[i * 3 + 1] = r[1];
+        out[i * 3 + 2] = r[2];
+    }
+}
+
+hipError_t launch_bicubic(const float* x, float* out, int B, int H, int W, int scale, hipStream_t s) {
+    const size_t total = (size_t)B * H * W * scale * scale;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(bicubic_kernel, dim3(blocks), dim3(256), 0, s, x, out, B, H, W, scale);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// tail.  merge [B][H][W][48] -> large1 = depth_to_space (virtual) [B][2H][2W][12]
+//   out1 = conv3x3(large1; w2 [3][3][12][CO]) + b2, CO = 12 (4x) or 3 (2x)
+//   4x: out[b][0][2Y+i][2X+j][c] = out1[Y][X][(2i+j)*3+c] + bic ;  2x: out[b][0][Y][X][c] = out1 + bic
+// Thread = one (Y,X) of the 2H x 2W grid.  Weights are wave-uniform -> scalar loads.
+template <int CO>
+__global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ merge,
+                                                   const float* __restrict__ x,   // [B][T][H][W][3]
+                                                   const float* __restrict__ w2,  // [3][3][12][CO]
+                                                   const float* __restrict__ b2,  // [CO]
+                                                   float* __restrict__ out, int B, int T, int H, int W) {
+    constexpr int SCALE = (CO == 12) ? 4 : 2;
+    const int H2 = 2 * H, W2 = 2 * W;
+    const int X = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int Y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    const int b = blockIdx.z;
+    if (X >= W2 || Y >= H2) return;
+    const float* mb = merge + (size_t)b * H * W * 48;
+
+    float acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] = b2[o];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = Y + dy - 1;
+        if (yy < 0 || yy >= H2) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int xx = X + dx - 1;
+            if (xx < 0 || xx >= W2) continue;
+            // large1[yy][xx][k] = merge[yy/2][xx/2][((yy&1)*2+(xx&1))*12 + k]   (model/pfnl.py:76)
+            const float4* src = reinterpret_cast<const float4*>(
+                mb + ((size_t)(yy >> 1) * W + (xx >> 1)) * 48 + ((yy & 1) * 2 + (xx & 1)) * 12);
+            const float4 v0 = src[0], v1 = src[1], v2 = src[2];
+            const float v[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+            const float* wp = w2 + (dy * 3 + dx) * 12 * CO;
+#pragma unroll
+            for (int k = 0; k < 12; ++k)
+#pragma unroll
+                for (int o = 0; o < CO; ++o) acc[o] = fmaf(v[k], wp[k * CO + o], acc[o]);
+        }
+    }
+
+    const float* xc = x + (((size_t)b * T + T / 2) * H) * W * 3;   // centre frame, model/pfnl.py:63
+    const int OH = SCALE * H, OW = SCALE * W;
+    float* ob = out + (size_t)b * OH * OW * 3;
+    if (CO == 12) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int oy = 2 * Y + i, ox = 2 * X + j;
+                float bic[3];
+                bicubic_px(xc, H, W, (size_t)W * 3, SCALE, oy, ox, bic);
+                float* dst = ob + ((size_t)oy * OW + ox) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dst[c] = acc[(2 * i + j) * 3 + c] + bic[c];
+            }
+    } else {
+        float bic[3];
+        bicubic_px(xc, H, W, (size_t)W * 3, SCALE, Y, X, bic);
+        float* dst = ob + ((size_t)Y * OW + X) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dst[c] = acc[c] + bic[c];
+    }
+}
+
+hipError_t launch_tail(const float* merge, const float* x, const float* w2, const float* b2, float* out,
+                       int B, int T, int H, int W, int scale, hipStream_t s) {
+    dim3 grid((2 * W + 31) / 32, (2 * H + 7) / 8, B);
+    if (scale == 4)
+        hipLaunchKernelGGL(tail_kernel<12>, grid, dim3(256), 0, s, merge, x, w2, b2, out, B, T, H, W);
+    else if (scale == 2)
+        hipLaunchKernelGGL(tail_kernel<3>, grid, dim3(256), 0, s, merge, x, w2, b2, out, B, T, H, W);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA layout self-test: D = A(32x2) * B(2x32) with asymmetric integer-valued operands.
+__global__ void mfma_selftest_kernel(int* mismatches) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 31, k = lane >> 5;
+    const float a = (float)(3 * i + 7 * k + 1);        // A[i][k]
+    const float bv = (float)(5 * (lane & 31) - 11 * k + 2);  // B[k][j], j = lane&31
+    f32x16 d;
+    for (int r = 0; r < 16; ++r) d[r] = 0.f;
+    d = mfma32(a, bv, d);
+    int bad = 0;
+    for (int r = 0; r < 16; ++r) {
+        const int row = drow(r, lane), col = lane & 31;
+        float ref = 0.f;
+        for (int kk = 0; kk < 2; ++kk)
+            ref += (float)(3 * row + 7 * kk + 1) * (float)(5 * col - 11 * kk + 2);
+        if (d[r] != ref) ++bad;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+hipError_t run_mfma_selftest(int* mismatches) {
+    int* d = nullptr;
+    hipError_t e = hipMalloc(&d, sizeof(int));
+    if (e != hipSuccess) return e;
+    hipMemset(d, 0, sizeof(int));
+    hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, 0, d);
+    e = hipMemcpy(mismatches, d, sizeof(int), hipMemcpyDeviceToHost);
+    hipFree(d);
+    return e;
+}
+
+}  // namespace pfnl

@@ -1,0 +1,255 @@
+// Non-local spatio-temporal correlation block (gfx950, f32 MFMA, flash-style streaming softmax).
+//
+// Replaces utils.NonLocalBlock(nltype=1, sub_sample=1) of the reference (utils.py:18-71) together
+// with the gather/scatter around it in PFNL.forward (model/pfnl.py:55-60):
+//   X  = space_to_depth(concat_t x_t, 2)            [B, N=(H/2)(W/2), C=12T]
+//   P  = exp(X X^T) / rowsum                        (utils.py:53-58; theta = phi = X at nltype 1)
+//   Z  = (P (X Wg + bg)) Ww + bw                    (utils.py:26,64,67)
+//      = (P X) (Wg Ww) + (bg Ww + bw)               (rows of P sum to 1; W' = Wg Ww folded on host)
+//   out = X + Z   kept in the space_to_depth ("packed") layout; conv0 reads it through the
+//                 depth_to_space index map, so model/pfnl.py:59-61 costs no pass over memory.
+// The N x N affinity is never materialised: one wave owns 32 queries, streams 32-key tiles from an
+// LDS-staged X tile, keeps a running max/sum per query (mathematically identical to the
+// reference's un-stabilised exp/sum/divide wherever that does not overflow) and accumulates
+// O^T = X^T P^T with MFMA.  Everything is computed transposed (keys/channels on the MFMA row axis,
+// queries on the column axis = lane) so that softmax state is per-lane and the probabilities feed
+// the second MFMA straight from the accumulator registers of the first.
+#include "common.h"
+
+namespace pfnl {
+
+int nl_padded_ch(int C) { return 32 * ((C + 31) / 32); }
+
+// x [B,T,H,W,3] -> X [B,N,CP]; channel (dy*2+dx)*3T + 3t + c (model/pfnl.py:55-57); pad columns = 0.
+__global__ void nl_pack_kernel(const float* __restrict__ x, float* __restrict__ X, int B, int T, int H,
+                               int W, int CP) {
+    const int C3 = 3 * T;
+    const int W2 = W / 2;
+    const size_t N = (size_t)(H / 2) * W2;
+    const size_t total = (size_t)B * N * CP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % CP);
+        const size_t n = (i / CP) % N;
+        const int b = (int)(i / ((size_t)CP * N));
+        float v = 0.f;
+        if (co < 4 * C3) {
+            const int sub = co / C3, k = co % C3;
+            const int t = k / 3, c = k % 3;
+            const int y = 2 * (int)(n / W2) + (sub >> 1);
+            const int xx = 2 * (int)(n % W2) + (sub & 1);
+            v = x[((((size_t)b * T + t) * H + y) * W + xx) * 3 + c];
+        }
+        X[i] = v;
+    }
+}
+
+// packed [B,N,CP] -> [B,H,W,3T] (depth_to_space, model/pfnl.py:59); used by the debug tap / op hook.
+__global__ void nl_unpack_kernel(const float* __restrict__ Xo, float* __restrict__ out, int B, int T,
+                                 int H, int W, int CP) {
+    const int C3 = 3 * T;
+    const int W2 = W / 2;
+    const size_t total = (size_t)B * H * W * C3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % C3);
+        const int xx = (int)((i / C3) % W);
+        const int y = (int)((i / ((size_t)C3 * W)) % H);
+        const int b = (int)(i / ((size_t)C3 * W * H));
+        const size_t n = (size_t)(y >> 1) * W2 + (xx >> 1);
+        const int co = ((y & 1) * 2 + (xx & 1)) * C3 + k;
+        out[i] = Xo[((size_t)b * (H / 2) * W2 + n) * CP + co];
+    }
+}
+
+constexpr int NL_KT = 64;   // keys per LDS tile (two 32-key MFMA sub-tiles)
+
+// One workgroup = 4 waves x 32 queries.  C = 12T real channels, CT = ceil(C/32) channel tiles.
+template <int C>
+__global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict__ X,
+                                                         float* __restrict__ Xo,
+                                                         const float* __restrict__ Wp,   // [CP][CP], row = ci
+                                                         const float* __restrict__ bp,   // [CP]
+                                                         int N) {
+    constexpr int CT = (C + 31) / 32;
+    constexpr int CP = CT * 32;
+    constexpr int LS = CP + 1;            // odd LDS row stride: key rows land on distinct banks
+    constexpr int KSTEPS = C / 2;
+    static_assert(C % 2 == 0, "channel count must be even");
+    __shared__ float sk[NL_KT * LS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int xl = lane & 31;
+    const int kh = lane >> 5;
+    const int b = blockIdx.y;
+    const float* Xb = X + (size_t)b * N * CP;
+    float* Xob = Xo + (size_t)b * N * CP;
+    const int q = blockIdx.x * 128 + wave * 32 + xl;       // this lane's query
+    const int qc = q < N ? q : N - 1;
+
+    // B operand of S^T = Xk Xq^T: lane holds Xq[q][2s + kh].
+    float bq[KSTEPS];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) bq[s] = Xb[(size_t)qc * CP + 2 * s + kh];
+
+    f32x16 o[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
+    float m = -INFINITY;   // running max of the logits of this lane's query
+    float l = 0.f;         // running sum over this lane's half of the keys
+
+    constexpr int TILE_F4 = NL_KT * CP / 4;
+    constexpr int LD_ITERS = (TILE_F4 + 255) / 256;
+    f32x4 rk[LD_ITERS];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < LD_ITERS; ++i) {
+            const int it = tid + i * 256;
+            rk[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (it < TILE_F4) {
+                const int row = it / (CP / 4), c4 = it % (CP / 4);
+                if (k0 + row < N)
+                    rk[i] = *reinterpret_cast<const f32x4*>(Xb + (size_t)(k0 + row) * CP + c4 * 4);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < LD_ITERS; ++i) {
+            const int it = tid + i * 256;
+            if (it < TILE_F4) {
+                const int row = it / (CP / 4), c4 = it % (CP / 4);
+                float* d = sk + row * LS + c4 * 4;
+                d[0] = rk[i].x;
+                d[1] = rk[i].y;
+                d[2] = rk[i].z;
+                d[3] = rk[i].w;
+            }
+        }
+    };
+
+    const int ntiles = (N + NL_KT - 1) / NL_KT;
+    load_tile(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        if (kt > 0) __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < ntiles) load_tile((kt + 1) * NL_KT);
+#pragma unroll
+        for (int sub = 0; sub < NL_KT / 32; ++sub) {
+            const int kbase = kt * NL_KT + sub * 32;
+            if (kbase >= N) break;                         // wave-uniform
+            // S^T[key i][query j]: A = Xk[i = xl][c = 2s + kh] from LDS, B = bq.
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+            const float* ka = sk + (sub * 32 + xl) * LS + kh;
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) st = mfma32(ka[2 * s], bq[s], st);
+
+            // online softmax; register r of this lane is key kbase + drow(r, lane).
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (kbase + drow(r, lane) >= N) st[r] = -INFINITY;
+                tmax = fmaxf(tmax, st[r]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float mn = fmaxf(m, tmax);
+            const float alpha = expf(m - mn);              // m = -inf on the first tile -> 0
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[r] = expf(st[r] - mn);
+                psum += st[r];
+            }
+            l = l * alpha + psum;
+            m = mn;
+            if (!__all(alpha == 1.0f)) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+            }
+            // O^T[ch i][query j] += V^T[i][key] P^T[key][j]; contraction step s uses the key that
+            // accumulator register s of this lane's half already holds: key = drow(s, lane).
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const float* va = sk + (sub * 32 + 4 * kh) * LS + ct * 32 + xl;
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    o[ct] = mfma32(va[((s & 3) + 8 * (s >> 2)) * LS], st[s], o[ct]);
+            }
+        }
+    }
+
+    // normalise: both halves of a query's keys
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] *= inv;
+
+    // Z^T[co][query] = sum_ci W'[ci][co] O^T[ci][query]; register s of o[ct] is ci = 32ct + drow(s).
+    // Pad rows/cols of W' are zero and pad channels of O^T are exactly zero (X pad columns are 0).
+#pragma unroll
+    for (int cot = 0; cot < CT; ++cot) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const float* wa = Wp + (size_t)(ct * 32 + 4 * kh) * CP + cot * 32 + xl;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                z = mfma32(wa[((s & 3) + 8 * (s >> 2)) * CP], o[ct][s], z);
+        }
+        if (q < N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cot * 32 + drow(r, lane);
+                if (co < C) {
+                    const size_t idx = (size_t)q * CP + co;
+                    Xob[idx] = Xb[idx] + z[r] + bp[co];    // residual, model/pfnl.py:60
+                }
+            }
+        }
+    }
+    // pad columns of the output are never read by conv0.
+}
+
+hipError_t launch_nl_pack(const float* x, float* X, int B, int T, int H, int W, hipStream_t s) {
+    const int CP = nl_padded_ch(12 * T);
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * CP;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(nl_pack_kernel, dim3(blocks), dim3(256), 0, s, x, X, B, T, H, W, CP);
+    return hipGetLastError();
+}
+
+hipError_t launch_nl_unpack(const float* Xo, float* out, int B, int T, int H, int W, hipStream_t s) {
+    const int CP = nl_padded_ch(12 * T);
+    const size_t total = (size_t)B * H * W * 3 * T;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(nl_unpack_kernel, dim3(blocks), dim3(256), 0, s, Xo, out, B, T, H, W, CP);
+    return hipGetLastError();
+}
+
+hipError_t launch_nl_attn(const float* X, float* Xo, const float* Wp, const float* bp, int B, int N,
+                          int C, hipStream_t s) {
+    dim3 grid((N + 127) / 128, B);
+    dim3 block(256);
+    switch (C) {
+        case 84: hipLaunchKernelGGL(nl_attn_kernel<84>, grid, block, 0, s, X, Xo, Wp, bp, N); break;
+        case 60: hipLaunchKernelGGL(nl_attn_kernel<60>, grid, block, 0, s, X, Xo, Wp, bp, N); break;
+        case 36: hipLaunchKernelGGL(nl_attn_kernel<36>, grid, block, 0, s, X, Xo, Wp, bp, N); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace pfnl

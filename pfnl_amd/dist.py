@@ -1,0 +1,92 @@
+"""Data-parallel driver pieces: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL
+over xGMI on the GPU box, "gloo" in the CPU tests).
+
+PFNL's forward has no cross-batch op (reference model/pfnl.py:44,55: the batch is only the leading
+dimension), so clips shard across ranks with NO collective on the data path.  The only exchanges are
+(1) one broadcast of the packed weights from rank 0 (12 MB), (2) an optional gather of the SR frames
+to rank 0, (3) an all-reduce of a few scalars (squared error, frame count, max time) for PSNR /
+throughput.  SURVEY.md §8(e).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .spec import PFNLGeometry
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced split of n items: the first n % world ranks get one extra."""
+    if world < 1 or not (0 <= rank < world) or n < 0:
+        raise ValueError("bad shard request")
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def flatten_weights(geom: PFNLGeometry, weights: Dict[str, np.ndarray]) -> np.ndarray:
+    return np.concatenate([np.asarray(weights[n], np.float32).ravel() for n, _ in geom.weight_shapes()])
+
+
+def unflatten_weights(geom: PFNLGeometry, flat: np.ndarray) -> Dict[str, np.ndarray]:
+    out, pos = {}, 0
+    for name, shape in geom.weight_shapes():
+        n = int(np.prod(shape))
+        out[name] = np.asarray(flat[pos:pos + n], np.float32).reshape(shape).copy()
+        pos += n
+    if pos != flat.size:
+        raise ValueError("weight blob has {} floats, geometry needs {}".format(flat.size, pos))
+    return out
+
+
+def broadcast_weights(geom: PFNLGeometry, weights: Optional[Dict[str, np.ndarray]], src: int = 0,
+                      device: Optional[str] = None) -> Dict[str, np.ndarray]:
+    """Rank ``src`` passes its weights, the others pass None; everyone returns the same dict."""
+    import torch
+    dist = _dist()
+    n = geom.num_params()
+    if dist.get_rank() == src:
+        t = torch.from_numpy(flatten_weights(geom, weights))
+    else:
+        t = torch.empty(n, dtype=torch.float32)
+    if device is not None:
+        t = t.to(device)
+    dist.broadcast(t, src=src)
+    return unflatten_weights(geom, t.cpu().numpy())
+
+
+def allreduce_stats(sq_err: float, count: float, seconds: float, device: Optional[str] = None):
+    """(sum of squared error, sum of counts, max of seconds) over all ranks."""
+    import torch
+    dist = _dist()
+    s = torch.tensor([sq_err, count], dtype=torch.float64)
+    m = torch.tensor([seconds], dtype=torch.float64)
+    if device is not None:
+        s, m = s.to(device), m.to(device)
+    dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    dist.all_reduce(m, op=dist.ReduceOp.MAX)
+    return float(s[0]), float(s[1]), float(m[0])
+
+
+def sharded_forward(forward_fn: Callable[[np.ndarray], np.ndarray], clips: np.ndarray,
+                    gather_to: Optional[int] = 0) -> Optional[np.ndarray]:
+    """Run ``forward_fn`` on this rank's contiguous share of ``clips`` [B,T,H,W,3] (every rank holds the
+    same array or at least its own slice) and gather the [B,1,sH,sW,3] result on ``gather_to``
+    (None: leave outputs sharded, return the local part)."""
+    dist = _dist()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lo, hi = shard_range(clips.shape[0], rank, world)
+    local = forward_fn(np.ascontiguousarray(clips[lo:hi])) if hi > lo else None
+    if gather_to is None:
+        return local
+    parts: List = [None] * world
+    dist.all_gather_object(parts, local)
+    if rank != gather_to:
+        return None
+    return np.concatenate([p for p in parts if p is not None], axis=0)

@@ -1,0 +1,143 @@
+"""PFNLEngine — the host-side owner of one libpfnl_hip handle (one GPU).
+
+This is the thin Python layer above the C-ABI: shape/dtype validation, weight hand-over, and the
+numpy / torch container handling that ``PFNL.forward`` (pfnl_amd/model.py) needs.  All arithmetic
+happens in the HIP kernels behind ``pfnl_forward``; nothing here computes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _capi
+from .spec import PFNLGeometry, check_weights
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+class PFNLEngine:
+    def __init__(self, geom: PFNLGeometry = PFNLGeometry(), device: int = 0):
+        self.geom = geom
+        self.device = int(device)
+        self._lib = _capi.load_library()
+        cfg = _capi.pfnl_config(geom.num_frames, geom.scale, geom.mf, geom.num_block, self.device,
+                                (C.c_int32 * 3)(0, 0, 0))
+        h = C.c_void_p()
+        _capi.check(self._lib.pfnl_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._ready = False
+
+    # ---- lifetime --------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.pfnl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights (TF names, HWIO float32) --------------------------------
+    def load_weights(self, weights: Dict[str, np.ndarray]) -> None:
+        check_weights(self.geom, weights)
+        for name, shape in self.geom.weight_shapes():
+            arr = np.ascontiguousarray(weights[name], dtype=np.float32)
+            shp = (C.c_int64 * len(shape))(*shape)
+            _capi.check(self._lib.pfnl_set_weight(self._h, name.encode(), arr.ctypes.data_as(C.c_void_p),
+                                                  shp, len(shape)))
+        _capi.check(self._lib.pfnl_finalize_weights(self._h))
+        self._ready = True
+
+    def missing_weights(self) -> int:
+        n = C.c_int(0)
+        _capi.check(self._lib.pfnl_missing_weights(self._h, C.byref(n)))
+        return n.value
+
+    # ---- forward ------------------------------------------------------------------------------
+    def _check_input(self, shape, dtype_ok: bool):
+        if len(shape) != 5:
+            raise ValueError(f"expected [B,T,H,W,3], got shape {tuple(shape)}")
+        B, T, H, W, c = (int(s) for s in shape)
+        if c != 3 or T != self.geom.num_frames:
+            raise ValueError(f"expected [B,{self.geom.num_frames},H,W,3], got {tuple(shape)}")
+        if B < 1 or H < 2 or W < 2:
+            raise ValueError(f"empty or degenerate input {tuple(shape)}")
+        if H % 2 or W % 2:
+            raise ValueError("H and W must be even (tf.space_to_depth(2), reference model/pfnl.py:57)")
+        if not dtype_ok:
+            raise TypeError("input must be float32")
+        if not self._ready:
+            raise RuntimeError("weights have not been loaded")
+        return B, T, H, W
+
+    def out_shape(self, B: int, H: int, W: int):
+        s = self.geom.scale
+        return (B, 1, s * H, s * W, 3)
+
+    def forward(self, x):
+        """x: [B,T,H,W,3] float32 (numpy array, torch CPU tensor or torch tensor on this engine's
+        GPU) -> [B,1,sH,sW,3] float32 in the same kind of container (reference model/pfnl.py:39-80).
+        Host containers: synchronous (H2D + kernels + D2H inside pfnl_forward).  Device tensors:
+        enqueued on torch's current stream."""
+        if _is_torch(x):
+            import torch
+            if x.is_cuda:
+                B, T, H, W = self._check_input(x.shape, x.dtype == torch.float32)
+                if x.device.index != self.device:
+                    raise ValueError(f"tensor on {x.device}, engine on cuda:{self.device}")
+                x = x.contiguous()
+                out = torch.empty(self.out_shape(B, H, W), dtype=torch.float32, device=x.device)
+                stream = torch.cuda.current_stream(x.device).cuda_stream
+                _capi.check(self._lib.pfnl_forward(self._h, C.c_void_p(x.data_ptr()), 1,
+                                                   C.c_void_p(out.data_ptr()), 1, B, H, W,
+                                                   C.c_void_p(stream)))
+                return out
+            return torch.from_numpy(self.forward(x.detach().numpy()))
+        x = np.asarray(x)
+        B, T, H, W = self._check_input(x.shape, x.dtype == np.float32)
+        x = np.ascontiguousarray(x)
+        out = np.empty(self.out_shape(B, H, W), np.float32)
+        _capi.check(self._lib.pfnl_forward(self._h, x.ctypes.data_as(C.c_void_p), 0,
+                                           out.ctypes.data_as(C.c_void_p), 0, B, H, W, None))
+        return out
+
+    def forward_device(self, in_ptr: int, out_ptr: int, B: int, H: int, W: int, stream: int = 0) -> None:
+        """Raw device-pointer form (asynchronous on ``stream``; 0 = the handle's own stream)."""
+        self._check_input((B, self.geom.num_frames, H, W, 3), True)
+        _capi.check(self._lib.pfnl_forward(self._h, C.c_void_p(in_ptr), 1, C.c_void_p(out_ptr), 1, B, H, W,
+                                           C.c_void_p(stream) if stream else None))
+
+    def sync(self) -> None:
+        _capi.check(self._lib.pfnl_sync(self._h))
+
+    def workspace_bytes(self, B: int, H: int, W: int) -> int:
+        n = C.c_size_t(0)
+        _capi.check(self._lib.pfnl_workspace_bytes(self._h, B, H, W, C.byref(n)))
+        return n.value
+
+    # ---- measurement / debugging ---------------------------------------------------------------
+    def profile(self, enable: bool) -> None:
+        _capi.check(self._lib.pfnl_profile_enable(self._h, 1 if enable else 0))
+
+    def profile_reset(self) -> None:
+        _capi.check(self._lib.pfnl_profile_reset(self._h))
+
+    def profile_read(self) -> Dict[str, Dict[str, float]]:
+        n = len(_capi.K_NAMES)
+        ms = (C.c_double * n)()
+        cnt = (C.c_int64 * n)()
+        _capi.check(self._lib.pfnl_profile_read(self._h, ms, cnt))
+        return {k: {"ms": ms[i], "launches": int(cnt[i])} for i, k in enumerate(_capi.K_NAMES)}
+
+    def tap(self, name: str, B: int, H: int, W: int) -> np.ndarray:
+        T = self.geom.num_frames
+        shape = {"nl_out": (B, H, W, 3 * T), "trunk": (B, T, H, W, 64), "merge1": (B, H, W, 48)}[name]
+        out = np.empty(shape, np.float32)
+        _capi.check(self._lib.pfnl_debug_tap(self._h, name.encode(), out.ctypes.data_as(C.c_void_p), out.size))
+        return out

@@ -1,0 +1,84 @@
+"""Single-op entry points of libpfnl_hip (the TF kernels the reference calls), on torch-ROCm
+device tensors.  Used by the per-op parity tests; ``PFNLEngine.forward`` does not go through here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _capi
+
+
+def _req(t, name):
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise TypeError(f"{name} must be a contiguous float32 tensor on the GPU")
+    return C.c_void_p(t.data_ptr())
+
+
+def _host(a, name) -> Optional[np.ndarray]:
+    if a is None:
+        return None
+    return np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+
+
+def _stream(t):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def conv2d(x, kernel, bias=None, act=True, frames_per_item=1, addend=None, add_div=1, resid=None):
+    """tf.layers.Conv2D(k in {1,3}, 'same') [+ bias] [+ addend] [lrelu] [+ resid] via the MFMA kernel.
+
+    x: [items*frames_per_item, H, W, 64] (cuda) viewed as [items, H, W, 64*fpi]; kernel: HWIO host
+    array [k,k,64*fpi,cout], cout <= 64.  Reference: model/pfnl.py:49-52 applied at :66-74."""
+    import torch
+    lib = _capi.load_library()
+    k = _host(kernel, "kernel")
+    b = _host(bias, "bias")
+    ks, _, cin, cout = k.shape
+    F, H, W, c = x.shape
+    if c != 64 or cin != 64 * frames_per_item or F % frames_per_item:
+        raise ValueError("conv2d: channel / frame grouping mismatch")
+    items = F // frames_per_item
+    out = torch.empty((items, H, W, cout), dtype=torch.float32, device=x.device)
+    _capi.check(lib.pfnl_op_conv2d(
+        _req(x, "x"), k.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p) if b is not None else None,
+        _req(addend, "addend") if addend is not None else None, int(add_div),
+        _req(resid, "resid") if resid is not None else None, _req(out, "out"),
+        items, frames_per_item, H, W, ks, cout, 1 if act else 0, _stream(x)))
+    return out
+
+
+def nonlocal_residual(x, wg, bg, ww, bw):
+    """x [B,T,H,W,3] (cuda) -> [B,H,W,3T] = stack + depth_to_space(NonLocalBlock(space_to_depth(stack)))
+    (reference utils.py:18-71 with nltype=1, model/pfnl.py:55-60)."""
+    import torch
+    lib = _capi.load_library()
+    B, T, H, W, c = x.shape
+    C_ = 12 * T
+    arrs = [_host(a, n) for a, n in ((wg, "wg"), (bg, "bg"), (ww, "ww"), (bw, "bw"))]
+    if arrs[0].size != C_ * C_ or arrs[2].size != C_ * C_ or arrs[1].size != C_ or arrs[3].size != C_:
+        raise ValueError("nonlocal: weight shapes do not match 12*T channels")
+    out = torch.empty((B, H, W, 3 * T), dtype=torch.float32, device=x.device)
+    _capi.check(lib.pfnl_op_nonlocal(_req(x, "x"), *[a.ctypes.data_as(C.c_void_p) for a in arrs],
+                                     _req(out, "out"), B, T, H, W, _stream(x)))
+    return out
+
+
+def bicubic(x, scale: int):
+    """TF1.12 legacy ResizeBicubic (reference model/pfnl.py:63): x [B,H,W,3] (cuda) -> [B,sH,sW,3]."""
+    import torch
+    lib = _capi.load_library()
+    B, H, W, c = x.shape
+    if c != 3:
+        raise ValueError("bicubic expects 3 channels")
+    out = torch.empty((B, scale * H, scale * W, 3), dtype=torch.float32, device=x.device)
+    _capi.check(lib.pfnl_op_bicubic(_req(x, "x"), _req(out, "out"), B, H, W, scale, _stream(x)))
+    return out
+
+
+def selftest_mfma(device: int = 0) -> None:
+    _capi.check(_capi.load_library().pfnl_selftest_mfma(device))

@@ -1,0 +1,130 @@
+"""End-to-end parity of pfnl_forward (through the C-ABI / PFNLEngine / the drop-in PFNL class) on a
+real MI355X against the committed golden vectors and the oracle, plus size-independent properties at
+BASELINE.json's full single-GPU size (7x128x128 -> 512x512, batch 4)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from conftest import geometry_of, load_golden  # noqa: E402
+from oracle import pfnl_fast, pfnl_spec  # noqa: E402
+from pfnl_amd import synth  # noqa: E402
+from pfnl_amd.engine import PFNLEngine  # noqa: E402
+from pfnl_amd.spec import PFNLGeometry  # noqa: E402
+
+PSNR_TOL_DB = 0.01          # BASELINE.json: |dPSNR| <= 0.01 dB (fp32)
+ABS_TOL = 2e-4              # direct element-wise bound on [0,1]-scale outputs (expect ~1e-5)
+
+_engines = {}
+
+
+def engine_for(geom):
+    key = (geom.num_frames, geom.scale, geom.num_block)
+    if key not in _engines:
+        e = PFNLEngine(geom, device=0)
+        e.load_weights(synth.synthetic_weights(geom, seed=0))
+        _engines[key] = e
+    return _engines[key]
+
+
+@pytest.mark.parametrize("name", ["t3_3x12x40_nb1", "x2_5x16x24_nb2", "ragged_7x20x36_nb2", "cfg1_7x32x32",
+                                  "field_7x32x32"])
+def test_forward_matches_golden(name):
+    gd = load_golden(name)
+    geom = geometry_of(gd["meta"])
+    eng = engine_for(geom)
+    y = eng.forward(gd["x"])
+    B, H, W = (int(v) for v in gd["meta"][3:6])
+    assert y.shape == gd["y"].shape and y.dtype == np.float32
+    # stage-by-stage, so that a failure names the kernel
+    assert np.abs(eng.tap("nl_out", B, H, W) - gd["nl_out"]).max() < 5e-5, "non-local block"
+    assert np.abs(eng.tap("merge1", B, H, W) - gd["merge1"]).max() < ABS_TOL, "trunk / convmerge1"
+    err = np.abs(y - gd["y"]).max()
+    assert err < ABS_TOL, err
+    assert synth.psnr(y, gd["y"]) > 80.0
+    if "gt" in gd:
+        d = abs(synth.psnr(y[:, 0], gd["gt"]) - synth.psnr(gd["y"][:, 0], gd["gt"]))
+        assert d <= PSNR_TOL_DB, d
+
+
+def test_container_types_and_device_path():
+    gd = load_golden("ragged_7x20x36_nb2")
+    eng = engine_for(geometry_of(gd["meta"]))
+    y_np = eng.forward(gd["x"])
+    y_t = eng.forward(torch.from_numpy(gd["x"]))
+    assert isinstance(y_t, torch.Tensor) and not y_t.is_cuda
+    xd = torch.from_numpy(gd["x"]).cuda()
+    y_d = eng.forward(xd)
+    assert y_d.is_cuda and y_d.shape == tuple(y_np.shape)
+    torch.cuda.synchronize()
+    assert np.array_equal(y_d.cpu().numpy(), y_np) and np.array_equal(y_t.numpy(), y_np)   # deterministic
+    # batch independence (model/pfnl.py has no cross-batch op): clip 1 alone == clip 1 inside the batch
+    assert np.array_equal(eng.forward(gd["x"][1:2]), y_np[1:2])
+
+
+def test_bad_inputs_raise():
+    eng = engine_for(PFNLGeometry(num_block=1))
+    with pytest.raises(ValueError):
+        eng.forward(np.zeros((1, 7, 9, 8, 3), np.float32))       # odd H (space_to_depth needs even)
+    with pytest.raises(ValueError):
+        eng.forward(np.zeros((1, 5, 8, 8, 3), np.float32))       # wrong T
+    with pytest.raises(TypeError):
+        eng.forward(np.zeros((1, 7, 8, 8, 3), np.float64))
+    with pytest.raises(ValueError):
+        eng.forward(np.zeros((0, 7, 8, 8, 3), np.float32))       # empty batch
+
+
+def test_zero_weights_give_bicubic():
+    geom = PFNLGeometry(num_block=2)
+    w = {k: np.zeros_like(v) for k, v in synth.synthetic_weights(geom).items()}
+    eng = PFNLEngine(geom)
+    eng.load_weights(w)
+    x = synth.uniform_clips(1, 7, 12, 20, seed=9)
+    y = eng.forward(x)
+    ref = pfnl_spec.resize_bicubic_tf1(x[:, 3].astype(np.float64), 4)
+    assert np.abs(y[:, 0] - ref).max() < 2e-6
+    eng.close()
+
+
+def test_dropin_class_and_harness(tmp_path):
+    """PFNL().test_video_lr on a tiny PNG sequence reproduces the oracle's uint8 frames."""
+    from PIL import Image
+    from model.pfnl import PFNL
+    gd = load_golden("harness_5x16x24_nb1")
+    seq = tmp_path / "seq0"
+    (seq / "blur4").mkdir(parents=True)
+    for i, im in enumerate(gd["lr_u8"]):
+        Image.fromarray(im).save(seq / "blur4" / f"{i:04d}.png")
+    m = PFNL()
+    m.num_block = 1
+    m.save_dir = str(tmp_path / "ckpt")
+    m.set_weights(synth.synthetic_weights(PFNLGeometry(num_block=1), seed=0))
+    m.save(None, m.save_dir, 1000)
+    m2 = PFNL()
+    m2.num_block = 1
+    m2.save_dir = m.save_dir
+    m2.test_video_lr(str(seq), name="result", part=2)            # 5 frames, part=2 -> num_once=3
+    outs = sorted((seq / "result").glob("*.png"))
+    assert [p.name for p in outs] == [f"{i:04d}.png" for i in range(5)]
+    got = np.stack([np.asarray(Image.open(p)) for p in outs])
+    diff = np.abs(got.astype(np.int32) - gd["sr_u8"].astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3           # rounding ties only
+
+
+def test_full_size_properties_and_sampled_parity():
+    """BASELINE.json configs[1]: 7x128x128 -> 512x512, batch 4.  The fp64 oracle is too slow here; use
+    (a) the fp32 fast oracle on ONE clip, (b) batch independence, (c) bic[::4,::4] anchoring through
+    zeroed tail weights is covered above; here: determinism + permutation equivariance over clips."""
+    geom = PFNLGeometry()
+    eng = engine_for(geom)
+    lr, gt = synth.moving_field_clips(2, 7, 128, 128, seed=4321)
+    x = np.concatenate([lr, synth.uniform_clips(2, 7, 128, 128, seed=8)], 0)
+    y = eng.forward(x)
+    assert y.shape == (4, 1, 512, 512, 3) and np.isfinite(y).all()
+    assert np.array_equal(eng.forward(x[::-1].copy()), y[::-1])
+    ref = pfnl_fast.FastOracle(synth.synthetic_weights(geom, 0)).forward(x[:1])
+    assert np.abs(y[:1] - ref).max() < ABS_TOL
+    d = abs(synth.psnr(y[0, 0], gt[0]) - synth.psnr(ref[0, 0], gt[0]))
+    assert d <= PSNR_TOL_DB, d

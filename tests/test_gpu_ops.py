@@ -1,0 +1,131 @@
+"""Per-op parity on a real MI355X: each HIP kernel class against the fp64 spec oracle
+(oracle/pfnl_spec.py), through the C-ABI op hooks.  Tolerances: f32 MFMA is an exact fmaf chain
+(cdna guide §3), so differences are summation-order round-off: |err| <= 2e-6 * sum|a*b| scale."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import pfnl_spec  # noqa: E402
+from pfnl_amd import ops  # noqa: E402
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def test_library_loaded_and_mfma_layout():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    ops.selftest_mfma(0)
+
+
+@pytest.mark.parametrize("B,H,W,scale", [(1, 5, 7, 4), (2, 16, 24, 4), (1, 9, 6, 2), (1, 1, 1, 4), (1, 2, 33, 4)])
+def test_bicubic(B, H, W, scale):
+    rng = np.random.default_rng(H * 100 + W)
+    x = rng.random((B, H, W, 3), dtype=np.float32)
+    got = ops.bicubic(dev(x), scale).cpu().numpy()
+    ref = pfnl_spec.resize_bicubic_tf1(x.astype(np.float64), scale)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 2e-6
+    assert np.array_equal(got[:, ::scale, ::scale], x)          # t = 0 taps are exactly [0,1,0,0]
+
+
+def _conv_case(rng, items, fpi, H, W, ks, cout, act, fused):
+    cin = 64 * fpi
+    x = rng.normal(size=(items * fpi, H, W, 64)).astype(np.float32)
+    k = (rng.normal(size=(ks, ks, cin, cout)) / np.sqrt(ks * ks * cin)).astype(np.float32)
+    b = rng.normal(size=cout).astype(np.float32) * 0.1
+    xin = x.reshape(items, fpi, H, W, 64).transpose(0, 2, 3, 1, 4).reshape(items, H, W, cin)   # concat over frames
+    ref = pfnl_spec.conv2d_same(xin.astype(np.float64), k.astype(np.float64), b.astype(np.float64))
+    kw = {}
+    if fused:
+        div = 7 if items % 7 == 0 else 1
+        add = rng.normal(size=(items // div, H, W, 64)).astype(np.float32)
+        res = rng.normal(size=(items, H, W, 64)).astype(np.float32)
+        ref = ref + np.repeat(add.astype(np.float64), div, axis=0)
+        kw = dict(addend=dev(add), add_div=div, resid=dev(res))
+    if act:
+        ref = pfnl_spec.lrelu(ref)
+    if fused:
+        ref = ref + res
+    got = ops.conv2d(dev(x), k, b, act=act, frames_per_item=fpi, **kw).cpu().numpy()
+    return got, ref
+
+
+@pytest.mark.parametrize("items,fpi,H,W,ks,cout,act,fused", [
+    (2, 1, 8, 32, 3, 64, True, False),       # exactly one tile
+    (3, 1, 20, 36, 3, 64, True, False),      # ragged tiles in both directions
+    (7, 1, 10, 34, 3, 64, True, True),       # conv2 epilogue: + addend(item/7) , lrelu, + resid
+    (2, 1, 9, 70, 3, 64, False, False),      # raw (the shared-base half of conv2)
+    (2, 7, 16, 40, 1, 64, True, False),      # conv10: 1x1 over 7 concatenated frames
+    (1, 7, 12, 33, 3, 48, True, False),      # convmerge1: 3x3 over 448 -> 48
+    (1, 5, 6, 8, 1, 64, True, False),        # T = 5
+    (1, 1, 1, 1, 3, 64, True, False),        # a single pixel: everything is halo
+])
+def test_conv_mfma(items, fpi, H, W, ks, cout, act, fused):
+    rng = np.random.default_rng(items * 1000 + H * 10 + W + ks)
+    got, ref = _conv_case(rng, items, fpi, H, W, ks, cout, act, fused)
+    assert got.shape == ref.shape
+    err = np.abs(got - ref).max()
+    assert err < 5e-6 * max(1.0, np.abs(ref).max()), err
+
+
+def test_conv_delta_kernel_shift_is_exact():
+    rng = np.random.default_rng(5)
+    x = rng.random((1, 12, 40, 64), dtype=np.float32)
+    k = np.zeros((3, 3, 64, 64), np.float32)
+    for c in range(64):
+        k[0, 2, c, (c * 7 + 3) % 64] = 1.0          # tap (dy=-1,dx=+1) + a channel permutation
+    got = ops.conv2d(dev(x), k, None, act=False).cpu().numpy()
+    ref = pfnl_spec.conv2d_same(x.astype(np.float64), k.astype(np.float64), None)
+    assert np.array_equal(got, ref.astype(np.float32))            # pure data movement: bit exact
+
+
+@pytest.mark.parametrize("B,T,H,W", [(1, 7, 8, 8), (2, 7, 20, 36), (1, 5, 16, 24), (1, 3, 12, 40), (1, 7, 2, 2),
+                                     (1, 7, 32, 32)])
+def test_nonlocal_residual(B, T, H, W):
+    rng = np.random.default_rng(B + T + H + W)
+    C = 12 * T
+    x = rng.random((B, T, H, W, 3), dtype=np.float32)
+    wg = (rng.normal(size=(1, 1, C, C)) / np.sqrt(C)).astype(np.float32)
+    ww = (rng.normal(size=(1, 1, C, C)) / np.sqrt(C)).astype(np.float32)
+    bg = rng.normal(size=C).astype(np.float32) * 0.1
+    bw = rng.normal(size=C).astype(np.float32) * 0.1
+    got = ops.nonlocal_residual(dev(x), wg, bg, ww, bw).cpu().numpy()
+    x64 = x.astype(np.float64)
+    stack = np.concatenate([x64[:, t] for t in range(T)], -1)
+    z = pfnl_spec.nonlocal_block(pfnl_spec.space_to_depth2(stack), wg.astype(np.float64), bg.astype(np.float64),
+                                 ww.astype(np.float64), bw.astype(np.float64))
+    ref = stack + pfnl_spec.depth_to_space2(z)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 2e-5, np.abs(got - ref).max()
+
+
+def test_nonlocal_constant_and_peaked_inputs():
+    """Known answers: constant frames -> uniform affinity; a very bright pixel block -> the running-max
+    rescale branch of the streaming softmax is exercised (logits ~ 84 vs ~ 2)."""
+    T, H, W = 7, 16, 16
+    C = 12 * T
+    rng = np.random.default_rng(0)
+    wg = (rng.normal(size=(1, 1, C, C)) / np.sqrt(C)).astype(np.float32)
+    ww = (rng.normal(size=(1, 1, C, C)) / np.sqrt(C)).astype(np.float32)
+    bg = rng.normal(size=C).astype(np.float32) * 0.1
+    bw = rng.normal(size=C).astype(np.float32) * 0.1
+    x = np.full((1, T, H, W, 3), 0.25, np.float32)
+    got = ops.nonlocal_residual(dev(x), wg, bg, ww, bw).cpu().numpy()
+    g = np.full(C, 0.25) @ wg[0, 0].astype(np.float64) + bg
+    zc = g @ ww[0, 0].astype(np.float64) + bw
+    ref = 0.25 + pfnl_spec.depth_to_space2(np.broadcast_to(zc, (1, H // 2, W // 2, C)).copy())
+    assert np.abs(got - ref).max() < 1e-5
+    x = (rng.random((1, T, H, W, 3)) * 0.15).astype(np.float32)
+    x[:, :, 10:14, 4:8] = 0.97 + 0.03 * rng.random((1, T, 4, 4, 3)).astype(np.float32)   # late, dominant keys
+    got = ops.nonlocal_residual(dev(x), wg, bg, ww, bw).cpu().numpy()
+    x64 = x.astype(np.float64)
+    stack = np.concatenate([x64[:, t] for t in range(T)], -1)
+    z = pfnl_spec.nonlocal_block(pfnl_spec.space_to_depth2(stack), wg.astype(np.float64), bg.astype(np.float64),
+                                 ww.astype(np.float64), bw.astype(np.float64), stabilise=True)
+    ref = stack + pfnl_spec.depth_to_space2(z)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() < 5e-5
