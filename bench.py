@@ -29,38 +29,39 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 B_PER_GPU, T, H, W = 4, 7, 128, 128
 
 
-def cpu_baseline(weights, sample_clips, budget_s=20.0):
+def cpu_baseline(weights, sample_clips, budget_s=24.0):
     """Times oracle/pfnl_fast.py (the CPU port of the reference graph) on this host."""
     import numpy as np
     import torch
     from oracle import pfnl_fast
 
-    def run(threads):
+    def run(threads, budget):
         torch.set_num_threads(threads)
         fo = pfnl_fast.FastOracle(weights)
         fo.forward(sample_clips)                      # warm-up, discarded (reference model/pfnl.py:262)
         times = []
-        t_end = time.time() + budget_s
-        while len(times) < 3 or (time.time() < t_end and len(times) < 5):
+        t_end = time.time() + budget
+        while len(times) < 2 or (time.time() < t_end and len(times) < 5):
             t0 = time.time()
             fo.forward(sample_clips)
             times.append(time.time() - t0)
-            if time.time() > t_end and len(times) >= 2:
-                break
         return sample_clips.shape[0] / min(times), sample_clips.shape[0] / float(np.mean(times))
 
     ncpu = os.cpu_count() or 1
-    all_thr = max(1, min(ncpu, torch.get_num_threads() if torch.get_num_threads() > 1 else ncpu))
-    best_all, mean_all = run(all_thr)
-    out = {"value": round(best_all, 4), "unit": "HR frames/s", "cores": all_thr, "kind": "port",
-           "sample": "%d clip(s) of 7x%dx%d->%dx%d fp32 through oracle/pfnl_fast.py (torch-CPU, oneDNN), "
-                     "1 warm-up + min of >=2 runs" % (sample_clips.shape[0], H, W, 4 * H, 4 * W),
-           "mean_value": round(mean_all, 4), "host_logical_cpus": ncpu}
-    if all_thr > 8:
-        b8, _ = run(8)
-        out["value_8_threads"] = round(b8, 4)
-        torch.set_num_threads(all_thr)
-    return out
+    default_thr = torch.get_num_threads()
+    cands = sorted({c for c in (8, 16, 32, 64, default_thr) if 1 <= c <= max(ncpu, 1)})
+    per_run_budget = max(3.0, budget_s / len(cands))
+    results = {}
+    for c in cands:                                   # oversubscription hurts oneDNN: report the best
+        results[c] = run(c, per_run_budget)
+    torch.set_num_threads(default_thr)
+    best = max(results, key=lambda c: results[c][0])
+    return {"value": round(results[best][0], 4), "unit": "HR frames/s", "cores": best, "kind": "port",
+            "sample": "%d clip(s) of 7x%dx%d->%dx%d fp32 through oracle/pfnl_fast.py (torch-CPU, oneDNN), "
+                      "1 warm-up + min of >=2 runs per thread count; best thread count reported"
+                      % (sample_clips.shape[0], H, W, 4 * H, 4 * W),
+            "mean_value": round(results[best][1], 4), "host_logical_cpus": ncpu,
+            "by_threads": {str(c): round(v[0], 4) for c, v in results.items()}}
 
 
 def main():
