@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--conv3x3", choices=["winograd", "direct"], default=None, help="override the 3x3 conv algorithm")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events (no roofline object)")
     args = ap.parse_args()
 
     import numpy as np
@@ -103,6 +105,8 @@ def main():
 
     eng = PFNLEngine(geom, device=local_rank)
     eng.load_weights(weights)
+    if args.conv3x3:
+        eng.set_option("conv3x3", args.conv3x3)
     x = torch.from_numpy(synth.uniform_clips(B_PER_GPU, T, H, W, seed=1234 + rank)).to(dev)   # resident in HBM
     out = torch.empty(eng.out_shape(B_PER_GPU, H, W), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
@@ -120,7 +124,7 @@ def main():
         step()
     fence()
     eng.profile_reset()
-    eng.profile(True)                 # HIP events around every kernel launch, on the launch stream
+    eng.profile(not args.no_profile)  # HIP events around every kernel launch, on the launch stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

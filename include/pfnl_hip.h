@@ -73,6 +73,11 @@ int pfnl_missing_weights(pfnl_handle* h, int* count);
  * Wg*Ww of the non-local block, chunks the implicit-GEMM weights. */
 int pfnl_finalize_weights(pfnl_handle* h);
 
+/* Tuning knobs (all parity-tested):  key "conv3x3" = "winograd" (default: fused Winograd F(2x2,3x3),
+ * f32 MFMA, 2.25x fewer multiplies) | "direct" (implicit-GEMM f32 MFMA).  The default can also be
+ * set with the environment variable PFNL_CONV3X3 read by pfnl_create. */
+int pfnl_set_option(pfnl_handle* h, const char* key, const char* value);
+
 /* ---- the hot path ------------------------------------------------------------------------ */
 /* Replaces sess.run(SR_test, feed_dict={L_test: ...}) (reference model/pfnl.py:252,309) /
  * PFNL.forward (model/pfnl.py:39-80).  `in`  = [B,T,H,W,3] float32, `out` = [B,1,sH,sW,3]
@@ -112,6 +117,11 @@ int pfnl_op_conv2d(const float* in, const float* kernel_host, const float* bias_
                    const float* addend, int add_div, const float* resid, float* out,
                    int items, int frames_per_item, int H, int W, int ksize, int cout, int act,
                    void* stream);
+/* The same 3x3 64->64 convolution (frames_per_item = 1, cout = 64) through the fused Winograd
+ * F(2x2,3x3) kernel; H and W must be even. */
+int pfnl_op_conv3x3_winograd(const float* in, const float* kernel_host, const float* bias_host,
+                             const float* addend, int add_div, const float* resid, float* out,
+                             int items, int H, int W, int act, void* stream);
 /* utils.NonLocalBlock(nltype=1) + the residual of model/pfnl.py:55-60:
  * x [B,T,H,W,3] -> out [B,H,W,3T] = stack(x) + depth_to_space(NL(space_to_depth(stack(x)))). */
 int pfnl_op_nonlocal(const float* x, const float* wg_host, const float* bg_host,

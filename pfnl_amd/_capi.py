@@ -42,6 +42,7 @@ SIGNATURES = {
     "pfnl_set_weight": (_i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i]),
     "pfnl_missing_weights": (_i, [_vp, C.POINTER(_i)]),
     "pfnl_finalize_weights": (_i, [_vp]),
+    "pfnl_set_option": (_i, [_vp, C.c_char_p, C.c_char_p]),
     "pfnl_forward": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_workspace_bytes": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_size_t)]),
     "pfnl_sync": (_i, [_vp]),
@@ -50,6 +51,7 @@ SIGNATURES = {
     "pfnl_profile_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pfnl_debug_tap": (_i, [_vp, C.c_char_p, _vp, C.c_size_t]),
     "pfnl_op_conv2d": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "pfnl_op_conv3x3_winograd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_nonlocal": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_bicubic": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_selftest_mfma": (_i, [_i]),

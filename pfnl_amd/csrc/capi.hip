@@ -59,11 +59,13 @@ struct pfnl_handle {
     std::map<std::string, std::vector<int64_t>> expected;   // tf name -> shape
     std::map<std::string, HostTensor> host;                  // tensors received so far
     bool finalized = false;
+    bool use_wino = true;                                     // conv3x3 algorithm (pfnl_set_option)
 
     // device weights (offsets in floats into `wdev`)
     DevBuf wdev;
     size_t off_conv0_w = 0, off_conv0_b = 0;
     std::vector<size_t> off_c1_w, off_c1_b, off_c10_w, off_c10_b, off_c2a_w, off_c2b_w, off_c2_b;
+    std::vector<size_t> off_c1_u, off_c2a_u, off_c2b_u;       // Winograd-packed variants
     size_t off_m1_w = 0, off_m1_b = 0, off_m2_w = 0, off_m2_b = 0, off_nl_w = 0, off_nl_b = 0, off_zero = 0;
 
     // workspace
@@ -191,7 +193,12 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             p.nchunks = p.chunks_per_frame;
             p.add_div = 1;
             p.act = 1;
-            HIPCHK(launch_conv_mfma(p, 3, F, s));
+            if (h->use_wino) {
+                WinoParams wp{p.in, wd + h->off_c1_u[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 1};
+                HIPCHK(launch_conv_wino(wp, F, s));
+            } else {
+                HIPCHK(launch_conv_mfma(p, 3, F, s));
+            }
         }
         {   // conv10_i: 1x1 over the concat of T frames -> base + lrelu    (:67-68)
             ProfScope ps(h, s, PFNL_K_CONV1X1);
@@ -212,7 +219,12 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             p.frames_per_item = 1;
             p.nchunks = p.chunks_per_frame;
             p.act = 0;
-            HIPCHK(launch_conv_mfma(p, 3, B, s));
+            if (h->use_wino) {
+                WinoParams wp{p.in, wd + h->off_c2a_u[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 0};
+                HIPCHK(launch_conv_wino(wp, B, s));
+            } else {
+                HIPCHK(launch_conv_mfma(p, 3, B, s));
+            }
         }
         {   // conv2_i, per-frame half (kernel rows 64..127) + shared half + bias, lrelu, residual (:69-71)
             ProfScope ps(h, s, PFNL_K_CONV3X3);
@@ -224,7 +236,12 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             p.resid = h->inp0.p;
             p.out = h->inp0.p;
             p.act = 1;
-            HIPCHK(launch_conv_mfma(p, 3, F, s));
+            if (h->use_wino) {
+                WinoParams wp{p.in, wd + h->off_c2b_u[i], p.bias, p.addend, p.resid, p.out, H, W, T, 1};
+                HIPCHK(launch_conv_wino(wp, F, s));
+            } else {
+                HIPCHK(launch_conv_mfma(p, 3, F, s));
+            }
         }
     }
     {   // convmerge1: 3x3 over the concat of T frames -> 48 + lrelu        (:73-74)
@@ -275,6 +292,7 @@ int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
     HIPCHK(hipSetDevice(cfg->device_id));
     pfnl_handle* h = new pfnl_handle();
     h->cfg = *cfg;
+    if (const char* e = std::getenv("PFNL_CONV3X3")) h->use_wino = std::string(e) != "direct";
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return fail(PFNL_ERR_HIP, "hipStreamCreate failed");
@@ -332,6 +350,18 @@ int pfnl_set_weight(pfnl_handle* h, const char* tf_name, const float* host, cons
     return 0;
 }
 
+int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
+    if (!h || !key || !value) return fail(PFNL_ERR_INVALID, "NULL argument");
+    const std::string k(key), v(value);
+    if (k == "conv3x3") {
+        if (v == "winograd") h->use_wino = true;
+        else if (v == "direct") h->use_wino = false;
+        else return fail(PFNL_ERR_INVALID, "conv3x3 must be winograd or direct");
+        return 0;
+    }
+    return fail(PFNL_ERR_INVALID, "unknown option " + k);
+}
+
 int pfnl_missing_weights(pfnl_handle* h, int* count) {
     if (!h || !count) return fail(PFNL_ERR_INVALID, "NULL argument");
     int n = 0;
@@ -360,6 +390,11 @@ int pfnl_finalize_weights(pfnl_handle* h) {
         std::memcpy(&blob[off], b.data(), b.size() * sizeof(float));
         return off;
     };
+    auto put_wino = [&](const std::vector<float>& k, int cin_total, int cin_begin) {
+        size_t off = reserve(pfnl::wino_pack_floats());
+        pfnl::wino_pack_weights(k.data(), cin_total, cin_begin, &blob[off]);
+        return off;
+    };
     auto put_pack = [&](const std::vector<float>& k, int ks, int cin_total, int cin_begin, int cin, int cout) {
         size_t off = reserve(pfnl::conv_pack_floats(ks, cin));
         pfnl::conv_pack_weights(k.data(), ks, cin_total, cin_begin, cin, cout, &blob[off]);
@@ -377,6 +412,9 @@ int pfnl_finalize_weights(pfnl_handle* h) {
     h->off_c2a_w.assign(nb, 0);
     h->off_c2b_w.assign(nb, 0);
     h->off_c2_b.assign(nb, 0);
+    h->off_c1_u.assign(nb, 0);
+    h->off_c2a_u.assign(nb, 0);
+    h->off_c2b_u.assign(nb, 0);
     for (int i = 0; i < nb; ++i) {
         const std::string s = std::to_string(i);
         h->off_c1_w[i] = put_pack(W("conv1_" + s), 3, 64, 0, 64, 64);
@@ -387,6 +425,9 @@ int pfnl_finalize_weights(pfnl_handle* h) {
         h->off_c2a_w[i] = put_pack(W("conv2_" + s), 3, 128, 0, 64, 64);
         h->off_c2b_w[i] = put_pack(W("conv2_" + s), 3, 128, 64, 64, 64);
         h->off_c2_b[i] = put_bias(Bv("conv2_" + s));
+        h->off_c1_u[i] = put_wino(W("conv1_" + s), 64, 0);
+        h->off_c2a_u[i] = put_wino(W("conv2_" + s), 128, 0);
+        h->off_c2b_u[i] = put_wino(W("conv2_" + s), 128, 64);
     }
     h->off_m1_w = put_pack(W("convmerge1"), 3, 64 * T, 0, 64 * T, 48);
     h->off_m1_b = put_bias(Bv("convmerge1"));
@@ -572,6 +613,32 @@ int pfnl_op_conv2d(const float* in, const float* kernel_host, const float* bias_
     }
     hipFree(dw);
     if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv op: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int pfnl_op_conv3x3_winograd(const float* in, const float* kernel_host, const float* bias_host,
+                             const float* addend, int add_div, const float* resid, float* out, int items, int H,
+                             int W, int act, void* stream) {
+    if (!in || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (items < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return fail(PFNL_ERR_INVALID, "winograd conv needs even H, W");
+    if ((addend != nullptr) != (resid != nullptr))
+        return fail(PFNL_ERR_INVALID, "addend and resid must be given together or not at all");
+    if (addend && add_div < 1) return fail(PFNL_ERR_INVALID, "add_div must be >= 1");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<float> pack(pfnl::wino_pack_floats() + 64, 0.f);
+    pfnl::wino_pack_weights(kernel_host, 64, 0, pack.data());
+    const size_t boff = pack.size() - 64;
+    if (bias_host) std::memcpy(&pack[boff], bias_host, 64 * sizeof(float));
+    float* dw = nullptr;
+    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(float)));
+    hipError_t e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        pfnl::WinoParams wp{in, dw, dw + boff, addend, resid, out, H, W, addend ? add_div : 1, act};
+        e = pfnl::launch_conv_wino(wp, items, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    (void)hipFree(dw);
+    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("winograd conv op: ") + hipGetErrorString(e));
     return 0;
 }
 

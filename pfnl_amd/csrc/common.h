@@ -50,6 +50,22 @@ size_t conv_pack_floats(int ksize, int cin);                 // floats in the pa
 void conv_pack_weights(const float* hwio, int ksize, int cin_total, int cin_begin, int cin,
                        int cout, float* dst);
 
+// ---- fused Winograd F(2x2,3x3) 64->64 convolution (conv_wino.hip) -------------------------------
+struct WinoParams {
+    const float* in;       // [items][H][W][64]
+    const float* upack;    // U = G g G^T, packed [chunk][xi][kk][lane][nu*2+nt] (wino_pack_weights)
+    const float* bias;     // [64]; never null
+    const float* addend;   // [items/add_div][H][W][64] \ both or
+    const float* resid;    // [items][H][W][64]         / neither
+    float* out;            // [items][H][W][64]
+    int H, W;              // both even
+    int add_div;
+    int act;
+};
+hipError_t launch_conv_wino(const WinoParams& p, int items, hipStream_t s);
+size_t wino_pack_floats();
+void wino_pack_weights(const float* hwio, int cin_total, int cin_begin, float* dst);
+
 // ---- non-local block (nonlocal.hip) ----------------------------------------------------------
 int nl_padded_ch(int C);                                      // 32*ceil(C/32)
 hipError_t launch_nl_pack(const float* x, float* X, int B, int T, int H, int W, hipStream_t s);

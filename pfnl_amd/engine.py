@@ -54,6 +54,10 @@ class PFNLEngine:
         _capi.check(self._lib.pfnl_finalize_weights(self._h))
         self._ready = True
 
+    def set_option(self, key: str, value: str) -> None:
+        """e.g. ("conv3x3", "winograd" | "direct"); see include/pfnl_hip.h."""
+        _capi.check(self._lib.pfnl_set_option(self._h, key.encode(), value.encode()))
+
     def missing_weights(self) -> int:
         n = C.c_int(0)
         _capi.check(self._lib.pfnl_missing_weights(self._h, C.byref(n)))

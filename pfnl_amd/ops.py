@@ -52,6 +52,23 @@ def conv2d(x, kernel, bias=None, act=True, frames_per_item=1, addend=None, add_d
     return out
 
 
+def conv3x3_winograd(x, kernel, bias=None, act=True, addend=None, add_div=1, resid=None):
+    """The 3x3 64->64 'same' convolution through the fused Winograd F(2x2,3x3) kernel (even H, W)."""
+    import torch
+    lib = _capi.load_library()
+    k = _host(kernel, "kernel")
+    b = _host(bias, "bias")
+    if k.shape != (3, 3, 64, 64):
+        raise ValueError("winograd path is 3x3, 64 -> 64 only")
+    F, H, W, c = x.shape
+    out = torch.empty((F, H, W, 64), dtype=torch.float32, device=x.device)
+    _capi.check(lib.pfnl_op_conv3x3_winograd(
+        _req(x, "x"), k.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p) if b is not None else None,
+        _req(addend, "addend") if addend is not None else None, int(add_div),
+        _req(resid, "resid") if resid is not None else None, _req(out, "out"), F, H, W, 1 if act else 0, _stream(x)))
+    return out
+
+
 def nonlocal_residual(x, wg, bg, ww, bw):
     """x [B,T,H,W,3] (cuda) -> [B,H,W,3T] = stack + depth_to_space(NonLocalBlock(space_to_depth(stack)))
     (reference utils.py:18-71 with nltype=1, model/pfnl.py:55-60)."""

@@ -64,6 +64,19 @@ def test_container_types_and_device_path():
     assert np.array_equal(eng.forward(gd["x"][1:2]), y_np[1:2])
 
 
+def test_winograd_and_direct_paths_agree():
+    gd = load_golden("ragged_7x20x36_nb2")
+    eng = engine_for(geometry_of(gd["meta"]))
+    eng.set_option("conv3x3", "direct")
+    y_d = eng.forward(gd["x"])
+    eng.set_option("conv3x3", "winograd")
+    y_w = eng.forward(gd["x"])
+    assert np.abs(y_d - gd["y"]).max() < ABS_TOL and np.abs(y_w - gd["y"]).max() < ABS_TOL
+    assert np.abs(y_d - y_w).max() < 5e-5
+    with pytest.raises(Exception):
+        eng.set_option("conv3x3", "fft")
+
+
 def test_bad_inputs_raise():
     eng = engine_for(PFNLGeometry(num_block=1))
     with pytest.raises(ValueError):

@@ -72,6 +72,38 @@ def test_conv_mfma(items, fpi, H, W, ks, cout, act, fused):
     assert err < 5e-6 * max(1.0, np.abs(ref).max()), err
 
 
+@pytest.mark.parametrize("items,H,W,act,fused", [
+    (2, 4, 32, True, False),        # exactly one workgroup tile
+    (3, 20, 36, True, False),       # ragged in both directions
+    (7, 10, 34, True, True),        # conv2 epilogue: + addend(item/7), lrelu, + resid
+    (2, 6, 70, False, False),       # raw (the shared-base half of conv2)
+    (1, 2, 2, True, False),         # a single 2x2 tile: everything is halo
+    (4, 64, 64, True, True),
+])
+def test_conv3x3_winograd(items, H, W, act, fused):
+    rng = np.random.default_rng(items * 1000 + H * 10 + W)
+    x = rng.normal(size=(items, H, W, 64)).astype(np.float32)
+    k = (rng.normal(size=(3, 3, 64, 64)) / np.sqrt(9 * 64)).astype(np.float32)
+    b = rng.normal(size=64).astype(np.float32) * 0.1
+    ref = pfnl_spec.conv2d_same(x.astype(np.float64), k.astype(np.float64), b.astype(np.float64))
+    kw = {}
+    if fused:
+        div = 7 if items % 7 == 0 else 1
+        add = rng.normal(size=(items // div, H, W, 64)).astype(np.float32)
+        res = rng.normal(size=(items, H, W, 64)).astype(np.float32)
+        ref = ref + np.repeat(add.astype(np.float64), div, axis=0)
+        kw = dict(addend=dev(add), add_div=div, resid=dev(res))
+    if act:
+        ref = pfnl_spec.lrelu(ref)
+    if fused:
+        ref = ref + res
+    got = ops.conv3x3_winograd(dev(x), k, b, act=act, **kw).cpu().numpy()
+    direct = ops.conv2d(dev(x), k, b, act=act, **kw).cpu().numpy()
+    err = np.abs(got - ref).max()
+    assert err < 2e-5 * max(1.0, np.abs(ref).max()), err          # Winograd: a few ulp more than direct
+    assert np.abs(got - direct).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
 def test_conv_delta_kernel_shift_is_exact():
     rng = np.random.default_rng(5)
     x = rng.random((1, 12, 40, 64), dtype=np.float32)
