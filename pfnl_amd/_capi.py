@@ -13,7 +13,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpfnl_hip.so")
+LIB_PATH = os.environ.get("PFNL_HIP_LIB", os.path.join(_HERE, "lib", "libpfnl_hip.so"))
 
 K_NAMES = ("nl_pack", "nl_attn", "conv0", "conv3x3", "conv1x1", "merge1", "tail")
 

@@ -72,13 +72,12 @@ struct pfnl_handle {
     DevBuf X, Xo, inp0, inp1, base, pb, merge, stage_in, stage_out, scratch;
     int lastB = 0, lastH = 0, lastW = 0;
 
-    // profiling
+    // profiling: boundary events.  One event after every kernel launch (plus one at the start of a
+    // forward); a launch's time = its event - the previous event, i.e. kernel + the gap before it.
     bool prof = false;
-    struct Ev {
-        hipEvent_t a, b;
-        int cls;
-    };
-    std::vector<Ev> evs;
+    bool chain_open = false;          // an event has been recorded in the current forward
+    std::vector<hipEvent_t> evs;
+    std::vector<int> ev_cls;          // class of the interval ENDING at event i (-1: chain start)
     size_t evs_used = 0;
     double prof_ms[PFNL_K_COUNT] = {0};
     int64_t prof_n[PFNL_K_COUNT] = {0};
@@ -88,35 +87,44 @@ namespace {
 
 using namespace pfnl;
 
+int prof_mark(pfnl_handle* h, hipStream_t s, int cls) {
+    if (h->evs_used == h->evs.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return -1;
+        h->evs.push_back(e);
+        h->ev_cls.push_back(-1);
+    }
+    h->ev_cls[h->evs_used] = cls;
+    return hipEventRecord(h->evs[h->evs_used++], s) == hipSuccess ? 0 : -1;
+}
+
 struct ProfScope {
     pfnl_handle* h;
     hipStream_t s;
-    int idx = -1;
-    ProfScope(pfnl_handle* h_, hipStream_t s_, int cls) : h(h_), s(s_) {
-        if (!h || !h->prof) return;
-        if (h->evs_used == h->evs.size()) {
-            pfnl_handle::Ev e;
-            if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
-            h->evs.push_back(e);
+    int cls;
+    ProfScope(pfnl_handle* h_, hipStream_t s_, int cls_) : h(h_), s(s_), cls(cls_) {
+        if (h && h->prof && !h->chain_open) {
+            prof_mark(h, s, -1);
+            h->chain_open = true;
         }
-        idx = (int)h->evs_used++;
-        h->evs[idx].cls = cls;
-        hipEventRecord(h->evs[idx].a, s);
     }
     ~ProfScope() {
-        if (idx >= 0) hipEventRecord(h->evs[idx].b, s);
+        if (h && h->prof) prof_mark(h, s, cls);
     }
 };
 
 int prof_collect(pfnl_handle* h) {
     for (size_t i = 0; i < h->evs_used; ++i) {
-        if (hipEventSynchronize(h->evs[i].b) != hipSuccess) return -1;
+        const int cls = h->ev_cls[i];
+        if (cls < 0 || i == 0) continue;
+        if (hipEventSynchronize(h->evs[i]) != hipSuccess) return -1;
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, h->evs[i].a, h->evs[i].b) != hipSuccess) return -1;
-        h->prof_ms[h->evs[i].cls] += ms;
-        h->prof_n[h->evs[i].cls] += 1;
+        if (hipEventElapsedTime(&ms, h->evs[i - 1], h->evs[i]) != hipSuccess) return -1;
+        h->prof_ms[cls] += ms;
+        h->prof_n[cls] += 1;
     }
     h->evs_used = 0;
+    h->chain_open = false;
     return 0;
 }
 
@@ -194,8 +202,8 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             p.add_div = 1;
             p.act = 1;
             if (h->use_wino) {
-                WinoParams wp{p.in, wd + h->off_c1_u[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 1};
-                HIPCHK(launch_conv_wino(wp, F, s));
+                WinoParams wp{p.in, wd + h->off_c1_u[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 1, F, nullptr};
+                HIPCHK(launch_conv_wino(wp, s));
             } else {
                 HIPCHK(launch_conv_mfma(p, 3, F, s));
             }
@@ -220,8 +228,8 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             p.nchunks = p.chunks_per_frame;
             p.act = 0;
             if (h->use_wino) {
-                WinoParams wp{p.in, wd + h->off_c2a_u[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 0};
-                HIPCHK(launch_conv_wino(wp, B, s));
+                WinoParams wp{p.in, wd + h->off_c2a_u[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 0, B, nullptr};
+                HIPCHK(launch_conv_wino(wp, s));
             } else {
                 HIPCHK(launch_conv_mfma(p, 3, B, s));
             }
@@ -237,8 +245,8 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             p.out = h->inp0.p;
             p.act = 1;
             if (h->use_wino) {
-                WinoParams wp{p.in, wd + h->off_c2b_u[i], p.bias, p.addend, p.resid, p.out, H, W, T, 1};
-                HIPCHK(launch_conv_wino(wp, F, s));
+                WinoParams wp{p.in, wd + h->off_c2b_u[i], p.bias, p.addend, p.resid, p.out, H, W, T, 1, F, nullptr};
+                HIPCHK(launch_conv_wino(wp, s));
             } else {
                 HIPCHK(launch_conv_mfma(p, 3, F, s));
             }
@@ -264,6 +272,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
         ProfScope ps(h, s, PFNL_K_TAIL);
         HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, H, W, c.scale, s));
     }
+    h->chain_open = false;
     return 0;
 }
 
@@ -319,10 +328,7 @@ int pfnl_destroy(pfnl_handle* h) {
         hipStreamSynchronize(h->stream);
         hipStreamDestroy(h->stream);
     }
-    for (auto& e : h->evs) {
-        hipEventDestroy(e.a);
-        hipEventDestroy(e.b);
-    }
+    for (auto& e : h->evs) hipEventDestroy(e);
     for (DevBuf* b : {&h->wdev, &h->X, &h->Xo, &h->inp0, &h->inp1, &h->base, &h->pb, &h->merge,
                       &h->stage_in, &h->stage_out, &h->scratch})
         b->release();
@@ -633,9 +639,30 @@ int pfnl_op_conv3x3_winograd(const float* in, const float* kernel_host, const fl
     HIPCHK(hipMalloc(&dw, pack.size() * sizeof(float)));
     hipError_t e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        pfnl::WinoParams wp{in, dw, dw + boff, addend, resid, out, H, W, addend ? add_div : 1, act};
-        e = pfnl::launch_conv_wino(wp, items, s);
+        pfnl::WinoParams wp{in, dw, dw + boff, addend, resid, out, H, W, addend ? add_div : 1, act, items, nullptr};
+#ifdef PFNL_WINO_TIMING
+        long long* dbg = nullptr;
+        const size_t dbg_n = 4096 * 64;
+        if (hipMalloc(&dbg, dbg_n * sizeof(long long)) == hipSuccess) {
+            (void)hipMemset(dbg, 0, dbg_n * sizeof(long long));
+            wp.dbg = dbg;
+        }
+#endif
+        e = pfnl::launch_conv_wino(wp, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
+#ifdef PFNL_WINO_TIMING
+        if (dbg) {
+            std::vector<long long> hst(dbg_n);
+            (void)hipMemcpy(hst.data(), dbg, dbg_n * sizeof(long long), hipMemcpyDeviceToHost);
+            for (int b : {0, 1, 8, 256, 264, 511}) {
+                std::fprintf(stderr, "WINO_TIMING wg %d:", b);
+                for (int i = 1; i < 64 && hst[(size_t)b * 64 + i]; ++i)
+                    std::fprintf(stderr, " %lld", hst[(size_t)b * 64 + i] - hst[(size_t)b * 64]);
+                std::fprintf(stderr, " | t0-min %lld\n", hst[(size_t)b * 64] - hst[0]);
+            }
+            (void)hipFree(dbg);
+        }
+#endif
     }
     (void)hipFree(dw);
     if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("winograd conv op: ") + hipGetErrorString(e));

@@ -4,6 +4,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#ifndef PFNL_WINO_UDEPTH
+#define PFNL_WINO_UDEPTH 4
+#endif
+
 namespace pfnl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -61,8 +65,10 @@ struct WinoParams {
     int H, W;              // both even
     int add_div;
     int act;
+    int items;
+    long long* dbg;        // PFNL_WINO_TIMING builds only: 64 clock64() stamps per workgroup (else null)
 };
-hipError_t launch_conv_wino(const WinoParams& p, int items, hipStream_t s);
+hipError_t launch_conv_wino(const WinoParams& p, hipStream_t s);
 size_t wino_pack_floats();
 void wino_pack_weights(const float* hwio, int cin_total, int cin_begin, float* dst);
 
