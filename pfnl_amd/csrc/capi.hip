@@ -654,11 +654,11 @@ int pfnl_op_conv3x3_winograd(const float* in, const float* kernel_host, const fl
         if (dbg) {
             std::vector<long long> hst(dbg_n);
             (void)hipMemcpy(hst.data(), dbg, dbg_n * sizeof(long long), hipMemcpyDeviceToHost);
-            for (int b : {0, 1, 8, 256, 264, 511}) {
+            for (int b : {0, 8, 16, 1024, 2048, 4096, 7000}) {
                 std::fprintf(stderr, "WINO_TIMING wg %d:", b);
-                for (int i = 1; i < 64 && hst[(size_t)b * 64 + i]; ++i)
-                    std::fprintf(stderr, " %lld", hst[(size_t)b * 64 + i] - hst[(size_t)b * 64]);
-                std::fprintf(stderr, " | t0-min %lld\n", hst[(size_t)b * 64] - hst[0]);
+                for (int i = 1; i < 16 && hst[(size_t)b * 16 + i]; ++i)
+                    std::fprintf(stderr, " %lld", hst[(size_t)b * 16 + i] - hst[(size_t)b * 16]);
+                std::fprintf(stderr, " | t0-t0[wg0] %lld\n", hst[(size_t)b * 16] - hst[0]);
             }
             (void)hipFree(dbg);
         }

@@ -4,8 +4,11 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#ifndef PFNL_WINO_WPS
+#define PFNL_WINO_WPS 3      // waves per SIMD the Winograd kernel is compiled for (= workgroups per CU)
+#endif
 #ifndef PFNL_WINO_UDEPTH
-#define PFNL_WINO_UDEPTH 4
+#define PFNL_WINO_UDEPTH 2
 #endif
 
 namespace pfnl {
