@@ -69,7 +69,7 @@ struct pfnl_handle {
     size_t off_m1_w = 0, off_m1_b = 0, off_m2_w = 0, off_m2_b = 0, off_nl_w = 0, off_nl_b = 0, off_zero = 0;
 
     // workspace
-    DevBuf X, Xo, inp0, inp1, base, pb, merge, stage_in, stage_out, scratch;
+    DevBuf X, Xo, nlp, inp0, inp1, base, pb, merge, stage_in, stage_out, scratch;
     int lastB = 0, lastH = 0, lastW = 0;
 
     // profiling: boundary events.  One event after every kernel launch (plus one at the start of a
@@ -160,6 +160,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
     const float* wd = h->wdev.p;
 
     if (h->X.ensure((size_t)B * N * CP) || h->Xo.ensure((size_t)B * N * CP) ||
+        h->nlp.ensure(nl_partial_floats(B, N, C)) ||
         h->inp0.ensure((size_t)F * P * 64) || h->inp1.ensure((size_t)F * P * 64) ||
         h->base.ensure((size_t)B * P * 64) || h->pb.ensure((size_t)B * P * 64) ||
         h->merge.ensure((size_t)B * P * 48))
@@ -174,7 +175,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
     }
     {
         ProfScope ps(h, s, PFNL_K_NL_ATTN);
-        HIPCHK(launch_nl_attn(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, B, N, C, s));
+        HIPCHK(launch_nl_attn(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p, B, N, C, s));
     }
     {   // model/pfnl.py:61-62
         ProfScope ps(h, s, PFNL_K_CONV0);
@@ -329,7 +330,7 @@ int pfnl_destroy(pfnl_handle* h) {
         hipStreamDestroy(h->stream);
     }
     for (auto& e : h->evs) hipEventDestroy(e);
-    for (DevBuf* b : {&h->wdev, &h->X, &h->Xo, &h->inp0, &h->inp1, &h->base, &h->pb, &h->merge,
+    for (DevBuf* b : {&h->wdev, &h->X, &h->Xo, &h->nlp, &h->inp0, &h->inp1, &h->base, &h->pb, &h->merge,
                       &h->stage_in, &h->stage_out, &h->scratch})
         b->release();
     delete h;
@@ -690,12 +691,14 @@ int pfnl_op_nonlocal(const float* x, const float* wg, const float* bg, const flo
     }
     float* d = nullptr;
     const size_t nX = (size_t)B * N * CP;
-    HIPCHK(hipMalloc(&d, (blob.size() + 2 * nX) * sizeof(float)));
+    const size_t nP = pfnl::nl_partial_floats(B, N, C);
+    HIPCHK(hipMalloc(&d, (blob.size() + 2 * nX + nP) * sizeof(float)));
     float* dX = d + blob.size();
     float* dXo = dX + nX;
+    float* dP = nP ? dXo + nX : nullptr;
     hipError_t e = hipMemcpy(d, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = pfnl::launch_nl_pack(x, dX, B, T, H, W, s);
-    if (e == hipSuccess) e = pfnl::launch_nl_attn(dX, dXo, d, d + (size_t)CP * CP, B, N, C, s);
+    if (e == hipSuccess) e = pfnl::launch_nl_attn(dX, dXo, d, d + (size_t)CP * CP, dP, B, N, C, s);
     if (e == hipSuccess) e = pfnl::launch_nl_unpack(dXo, out, B, T, H, W, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     hipFree(d);

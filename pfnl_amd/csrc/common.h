@@ -30,7 +30,7 @@ __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, 0.2f * v); }  
 // Output tile of one workgroup: 8 rows x 32 columns x 64 output channels of one item.
 constexpr int CONV_TW = 32;
 constexpr int CONV_TH = 8;
-constexpr int CONV_CK = 16;       // input channels per K-chunk
+constexpr int CONV_CK = 16;       // input channels per K-chunk of the 3x3 kernel (conv_ck(): 32 for 1x1)
 constexpr int CONV_NPAD = 64;     // output channels are padded to 64 in the packed weights
 
 struct ConvParams {
@@ -52,6 +52,7 @@ struct ConvParams {
 };
 
 hipError_t launch_conv_mfma(const ConvParams& p, int ksize, int items, hipStream_t s);
+int conv_ck(int ksize);
 size_t conv_pack_floats(int ksize, int cin);                 // floats in the packed weight blob
 // HWIO [k,k,cin_total,cout] rows [cin_begin, cin_begin+cin) -> [chunk][tap][CK][64]
 void conv_pack_weights(const float* hwio, int ksize, int cin_total, int cin_begin, int cin,
@@ -78,8 +79,9 @@ void wino_pack_weights(const float* hwio, int cin_total, int cin_begin, float* d
 // ---- non-local block (nonlocal.hip) ----------------------------------------------------------
 int nl_padded_ch(int C);                                      // 32*ceil(C/32)
 hipError_t launch_nl_pack(const float* x, float* X, int B, int T, int H, int W, hipStream_t s);
-hipError_t launch_nl_attn(const float* X, float* Xo, const float* Wp, const float* bp, int B, int N,
-                          int C, hipStream_t s);
+size_t nl_partial_floats(int B, int N, int C);               // scratch for the key-split partials (0 if unsplit)
+hipError_t launch_nl_attn(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, int B,
+                          int N, int C, hipStream_t s);
 hipError_t launch_nl_unpack(const float* Xo, float* out, int B, int T, int H, int W, hipStream_t s);
 
 // ---- head / tail (misc_kernels.hip) ----------------------------------------------------------

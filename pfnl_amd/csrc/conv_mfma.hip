@@ -15,9 +15,9 @@
 
 namespace pfnl {
 
-template <int KS>
+template <int KS, int CK_>
 struct ConvGeom {
-    static constexpr int CK = CONV_CK;
+    static constexpr int CK = CK_;
     static constexpr int HALO = KS - 1;
     static constexpr int IW = CONV_TW + HALO;
     static constexpr int IH = CONV_TH + HALO;
@@ -36,9 +36,9 @@ struct ConvGeom {
 };
 
 // FUSE = false: out = act(conv + bias);  FUSE = true: out = act(conv + bias + addend) + resid.
-template <int KS, bool FUSE>
+template <int KS, int CK_, bool FUSE>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
-    using G = ConvGeom<KS>;
+    using G = ConvGeom<KS, CK_>;
     constexpr int CK = G::CK, IW = G::IW, PS = G::PS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sw = smem;                    // [KS*KS][CK][64]
@@ -205,48 +205,56 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     }
 }
 
-template <int KS, bool FUSE>
+template <int KS, int CK_, bool FUSE>
 static hipError_t launch_variant(const ConvParams& p, dim3 grid, hipStream_t s) {
     static bool attr_set[64] = {false};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<KS, FUSE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ConvGeom<KS>::LDS_BYTES);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<KS, CK_, FUSE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ConvGeom<KS, CK_>::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, FUSE>), grid, dim3(256), ConvGeom<KS>::LDS_BYTES, s, p);
+    constexpr size_t lds_bytes = ConvGeom<KS, CK_>::LDS_BYTES;
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, CK_, FUSE>), grid, dim3(256), lds_bytes, s, p);
     return hipGetLastError();
 }
 
-hipError_t launch_conv_mfma(const ConvParams& p, int ksize, int items, hipStream_t s) {
-    if (!p.bias || !p.in || !p.wpack || !p.out) return hipErrorInvalidValue;
-    const bool fuse = p.addend != nullptr || p.resid != nullptr;
-    if (fuse && (!p.addend || !p.resid || p.add_div < 1)) return hipErrorInvalidValue;
+// K-chunk depth per kernel size.  The next chunk's global loads are issued one chunk of MFMAs ahead; a
+// 1x1 chunk of 16 channels is only 32 MFMAs per wave (~2k cycles), far less than the loaded memory
+// latency (~8k cycles), so the 1x1 kernel walks 32-channel chunks (64-channel chunks measured slower: 1 workgroup per CU).
+int conv_ck(int ksize) { return ksize == 1 ? 32 : CONV_CK; }
+
+hipError_t launch_conv_mfma(const ConvParams& p0, int ksize, int items, hipStream_t s) {
+    if (!p0.bias || !p0.in || !p0.wpack || !p0.out) return hipErrorInvalidValue;
+    const bool fuse = p0.addend != nullptr || p0.resid != nullptr;
+    if (fuse && (!p0.addend || !p0.resid || p0.add_div < 1)) return hipErrorInvalidValue;
+    ConvParams p = p0;
+    p.chunks_per_frame = p.in_cstride / conv_ck(ksize);
+    p.nchunks = p.frames_per_item * p.chunks_per_frame;
     dim3 grid((p.W + CONV_TW - 1) / CONV_TW, (p.H + CONV_TH - 1) / CONV_TH, items);
-    if (ksize == 3) return fuse ? launch_variant<3, true>(p, grid, s) : launch_variant<3, false>(p, grid, s);
-    if (ksize == 1) return fuse ? launch_variant<1, true>(p, grid, s) : launch_variant<1, false>(p, grid, s);
+    if (ksize == 3) return fuse ? launch_variant<3, 16, true>(p, grid, s) : launch_variant<3, 16, false>(p, grid, s);
+    if (ksize == 1) return fuse ? launch_variant<1, 32, true>(p, grid, s) : launch_variant<1, 32, false>(p, grid, s);
     return hipErrorInvalidValue;
 }
 
-size_t conv_pack_floats(int ksize, int cin) {
-    return (size_t)(cin / CONV_CK) * ksize * ksize * CONV_CK * CONV_NPAD;
-}
+size_t conv_pack_floats(int ksize, int cin) { return (size_t)cin * ksize * ksize * CONV_NPAD; }
 
 void conv_pack_weights(const float* hwio, int ksize, int cin_total, int cin_begin, int cin, int cout,
                        float* dst) {
     const int taps = ksize * ksize;
-    const int nchunks = cin / CONV_CK;
+    const int ck = conv_ck(ksize);
+    const int nchunks = cin / ck;
     for (int q = 0; q < nchunks; ++q)
         for (int t = 0; t < taps; ++t)
-            for (int c = 0; c < CONV_CK; ++c)
+            for (int c = 0; c < ck; ++c)
                 for (int o = 0; o < CONV_NPAD; ++o) {
-                    const int ci = cin_begin + q * CONV_CK + c;
+                    const int ci = cin_begin + q * ck + c;
                     float v = 0.f;
                     if (o < cout) v = hwio[((size_t)t * cin_total + ci) * cout + o];
-                    dst[(((size_t)q * taps + t) * CONV_CK + c) * CONV_NPAD + o] = v;
+                    dst[(((size_t)q * taps + t) * ck + c) * CONV_NPAD + o] = v;
                 }
 }
 

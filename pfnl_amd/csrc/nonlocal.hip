@@ -70,6 +70,8 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
                                                          float* __restrict__ Xo,
                                                          const float* __restrict__ Wp,   // [CP][CP], row = ci
                                                          const float* __restrict__ bp,   // [CP]
+                                                         float* __restrict__ Zp,         // [B][ks][N][CP] partial W'^T O (ks > 1)
+                                                         float* __restrict__ ML,         // [B][ks][N][2]  partial (max, sum)
                                                          int N) {
     constexpr int CT = (C + 31) / 32;
     constexpr int CP = CT * 32;
@@ -132,13 +134,17 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
         }
     };
 
+    // key split: workgroup z of gridDim.z handles key tiles [kt0, kt1) (flash-decoding style); the
+    // partial results are merged by nl_merge_kernel.  gridDim.z == 1: everything here, final output.
     const int ntiles = (N + NL_KT - 1) / NL_KT;
-    load_tile(0);
-    for (int kt = 0; kt < ntiles; ++kt) {
-        if (kt > 0) __syncthreads();
+    const int ks = gridDim.z, sp = blockIdx.z;
+    const int kt0 = (int)((long long)ntiles * sp / ks), kt1 = (int)((long long)ntiles * (sp + 1) / ks);
+    load_tile(kt0 * NL_KT);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        if (kt > kt0) __syncthreads();
         store_tile();
         __syncthreads();
-        if (kt + 1 < ntiles) load_tile((kt + 1) * NL_KT);
+        if (kt + 1 < kt1) load_tile((kt + 1) * NL_KT);
 #pragma unroll
         for (int sub = 0; sub < NL_KT / 32; ++sub) {
             const int kbase = kt * NL_KT + sub * 32;
@@ -187,9 +193,9 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
         }
     }
 
-    // normalise: both halves of a query's keys
+    // normalise: both halves of a query's keys (partial results stay un-normalised: the projection is linear)
     l += __shfl_xor(l, 32);
-    const float inv = 1.0f / l;
+    const float inv = (ks == 1) ? 1.0f / l : 1.0f;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -210,17 +216,64 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
                 z = mfma32(wa[((s & 3) + 8 * (s >> 2)) * CP], o[ct][s], z);
         }
         if (q < N) {
+            if (ks == 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = cot * 32 + drow(r, lane);
-                if (co < C) {
-                    const size_t idx = (size_t)q * CP + co;
-                    Xob[idx] = Xb[idx] + z[r] + bp[co];    // residual, model/pfnl.py:60
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cot * 32 + drow(r, lane);
+                    if (co < C) {
+                        const size_t idx = (size_t)q * CP + co;
+                        Xob[idx] = Xb[idx] + z[r] + bp[co];    // residual, model/pfnl.py:60
+                    }
                 }
+            } else {
+                float* zp = Zp + (((size_t)b * ks + sp) * N + q) * CP;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zp[cot * 32 + drow(r, lane)] = z[r];
             }
         }
     }
+    if (ks > 1 && q < N && kh == 0) {
+        float* ml = ML + (((size_t)b * ks + sp) * N + q) * 2;
+        ml[0] = m;
+        ml[1] = l;
+    }
     // pad columns of the output are never read by conv0.
+}
+
+// out = X + sum_p e^{m_p - m} Zp_p / sum_p e^{m_p - m} l_p + b'   (merge of the key-split partials)
+__global__ void nl_merge_kernel(const float* __restrict__ X, const float* __restrict__ Zp,
+                                const float* __restrict__ ML, const float* __restrict__ bp,
+                                float* __restrict__ Xo, int B, int N, int C, int CP, int ks) {
+    const size_t total = (size_t)B * N * CP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % CP);
+        if (co >= C) continue;
+        const size_t qn = (i / CP) % N;
+        const size_t b = i / ((size_t)CP * N);
+        float m = -INFINITY;
+        for (int p = 0; p < ks; ++p) m = fmaxf(m, ML[((b * ks + p) * N + qn) * 2]);
+        float num = 0.f, den = 0.f;
+        for (int p = 0; p < ks; ++p) {
+            const float* ml = ML + ((b * ks + p) * N + qn) * 2;
+            const float w = expf(ml[0] - m);
+            num = fmaf(w, Zp[((b * ks + p) * N + qn) * CP + co], num);
+            den = fmaf(w, ml[1], den);
+        }
+        Xo[i] = X[i] + num / den + bp[co];
+    }
+}
+
+int nl_key_splits(int B, int N) {
+    const int qblocks = (N + 127) / 128, ntiles = (N + NL_KT - 1) / NL_KT;
+    int ks = (512 + qblocks * B - 1) / (qblocks * B);          // aim at >= 2 workgroups per CU
+    if (ks > 8) ks = 8;
+    if (ks > ntiles / 4) ks = ntiles / 4;                       // keep >= 4 key tiles per split
+    return ks < 1 ? 1 : ks;
+}
+
+size_t nl_partial_floats(int B, int N, int C) {
+    const int ks = nl_key_splits(B, N);
+    return ks > 1 ? (size_t)B * ks * N * (nl_padded_ch(C) + 2) : 0;
 }
 
 hipError_t launch_nl_pack(const float* x, float* X, int B, int T, int H, int W, hipStream_t s) {
@@ -239,16 +292,26 @@ hipError_t launch_nl_unpack(const float* Xo, float* out, int B, int T, int H, in
     return hipGetLastError();
 }
 
-hipError_t launch_nl_attn(const float* X, float* Xo, const float* Wp, const float* bp, int B, int N,
+hipError_t launch_nl_attn(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, int B, int N,
                           int C, hipStream_t s) {
-    dim3 grid((N + 127) / 128, B);
+    const int ks = nl_key_splits(B, N);
+    const int CP = nl_padded_ch(C);
+    if (ks > 1 && !partial) return hipErrorInvalidValue;
+    float* Zp = partial;
+    float* ML = partial ? partial + (size_t)B * ks * N * CP : nullptr;
+    dim3 grid((N + 127) / 128, B, ks);
     dim3 block(256);
     switch (C) {
-        case 84: hipLaunchKernelGGL(nl_attn_kernel<84>, grid, block, 0, s, X, Xo, Wp, bp, N); break;
-        case 60: hipLaunchKernelGGL(nl_attn_kernel<60>, grid, block, 0, s, X, Xo, Wp, bp, N); break;
-        case 36: hipLaunchKernelGGL(nl_attn_kernel<36>, grid, block, 0, s, X, Xo, Wp, bp, N); break;
+        case 84: hipLaunchKernelGGL(nl_attn_kernel<84>, grid, block, 0, s, X, Xo, Wp, bp, Zp, ML, N); break;
+        case 60: hipLaunchKernelGGL(nl_attn_kernel<60>, grid, block, 0, s, X, Xo, Wp, bp, Zp, ML, N); break;
+        case 36: hipLaunchKernelGGL(nl_attn_kernel<36>, grid, block, 0, s, X, Xo, Wp, bp, Zp, ML, N); break;
         default: return hipErrorInvalidValue;
     }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || ks == 1) return e;
+    const size_t total = (size_t)B * N * CP;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(nl_merge_kernel, dim3(blocks), dim3(256), 0, s, X, Zp, ML, bp, Xo, B, N, C, CP, ks);
     return hipGetLastError();
 }
 

@@ -116,7 +116,7 @@ def test_conv_delta_kernel_shift_is_exact():
 
 
 @pytest.mark.parametrize("B,T,H,W", [(1, 7, 8, 8), (2, 7, 20, 36), (1, 5, 16, 24), (1, 3, 12, 40), (1, 7, 2, 2),
-                                     (1, 7, 32, 32)])
+                                     (1, 7, 32, 32), (1, 7, 48, 48), (2, 5, 64, 48), (1, 7, 62, 70)])   # last three: key-split path
 def test_nonlocal_residual(B, T, H, W):
     rng = np.random.default_rng(B + T + H + W)
     C = 12 * T
