@@ -143,21 +143,37 @@ def main():
     value = clips_total / elapsed                                     # 1 HR frame per clip
     ms_per_step = 1e3 * elapsed / args.steps
 
-    # dominant kernel class: conv_mfma_kernel<3,*> = conv1_i, both halves of conv2_i
+    # dominant kernel class (PFNL_K_CONV3X3): the 3x3 64->64 convs conv1_i and both halves of conv2_i
+    #  = conv_wino_kernel<*> (default) or conv_mfma_kernel<3,16,*> (--conv3x3 direct).
+    # ALGORITHMIC flops = direct-convolution flops with the shared-base split; the Winograd
+    # kernel executes 2.25x fewer MFMA flops, reported separately as mfma_executed / mfma_util.
     P = H * W
     F = B_PER_GPU * T
-    flops3 = geom.num_block * (2 * F + B_PER_GPU) * P * 9 * 64 * 64 * 2.0         # per forward, executed = algorithmic
+    flops3 = geom.num_block * (2 * F + B_PER_GPU) * P * 9 * 64 * 64 * 2.0         # per forward
+    algo = args.conv3x3 or os.environ.get("PFNL_CONV3X3", "winograd")
     k = prof["conv3x3"]
     roof = None
     if k["launches"]:
         avg_ms = k["ms"] / k["launches"]
         flops_per_launch = flops3 * args.steps / k["launches"]
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        executed = achieved / 2.25 if algo == "winograd" else achieved
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("algo") == algo:
+                traffic = tj.get("hbm_bytes_per_launch_avg")
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                "kernel": "conv_mfma_kernel<3,*> (3x3 64->64 f32 MFMA implicit GEMM)",
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "kernel": ("conv_wino_kernel<*> (fused Winograd F(2x2,3x3) 64->64, f32 MFMA)" if algo == "winograd"
+                           else "conv_mfma_kernel<3,16,*> (3x3 64->64 f32 MFMA implicit GEMM)"),
                 "avg_launch_ms": round(avg_ms, 4), "launches": k["launches"],
-                "gflop_per_launch": round(flops_per_launch / 1e9, 3)}
+                "gflop_per_launch": round(flops_per_launch / 1e9, 3),
+                "mfma_executed_tflops": round(executed, 2),
+                "mfma_util": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
+                "note": "achieved = algorithmic (direct-conv) FLOPs / time; Winograd executes 1/2.25 of them on the matrix pipe"
+                        if algo == "winograd" else "achieved = executed = algorithmic"}
     f_ref = geom.flops_per_clip(H, W) * B_PER_GPU
     f_exec = geom.flops_per_clip(H, W, shared_base=True) * B_PER_GPU
     breakdown = {n: round(v["ms"] / args.steps, 4) for n, v in prof.items()}

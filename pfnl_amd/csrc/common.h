@@ -7,6 +7,9 @@
 #ifndef PFNL_WINO_WPS
 #define PFNL_WINO_WPS 3      // waves per SIMD the Winograd kernel is compiled for (= workgroups per CU)
 #endif
+#ifndef PFNL_WINO_TPW
+#define PFNL_WINO_TPW 1      // tiles per workgroup (sequential)
+#endif
 #ifndef PFNL_WINO_UDEPTH
 #define PFNL_WINO_UDEPTH 2
 #endif
