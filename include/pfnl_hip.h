@@ -129,6 +129,10 @@ int pfnl_op_nonlocal(const float* x, const float* wg_host, const float* bg_host,
                      int B, int T, int H, int W, void* stream);
 /* tf.image.resize_images(method=2) of TF1.12 (model/pfnl.py:63): x [B,H,W,3] -> [B,sH,sW,3]. */
 int pfnl_op_bicubic(const float* x, float* out, int B, int H, int W, int scale, void* stream);
+/* The step before the path in test_video_truth / eval (reference utils.py:95-105,169-192:
+ * DownSample_4D with BLUR): reflect-pad 6, 13x13 Gaussian sigma 1.6, stride `scale`, VALID.
+ * hr [F,H,W,3] -> lr [F,ceil(H/scale),ceil(W/scale),3], device pointers, async on stream. */
+int pfnl_op_blur_decimate(const float* hr, float* lr, int F, int H, int W, int scale, void* stream);
 /* MFMA operand/accumulator layout self-test (asymmetric operands); returns 0 if the f32
  * 32x32x2 fragment maps this library assumes hold on the device. */
 int pfnl_selftest_mfma(int device_id);

@@ -54,6 +54,7 @@ SIGNATURES = {
     "pfnl_op_conv3x3_winograd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_nonlocal": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_bicubic": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "pfnl_op_blur_decimate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_selftest_mfma": (_i, [_i]),
 }
 

@@ -713,6 +713,14 @@ int pfnl_op_bicubic(const float* x, float* out, int B, int H, int W, int scale, 
     return 0;
 }
 
+int pfnl_op_blur_decimate(const float* hr, float* lr, int F, int H, int W, int scale, void* stream) {
+    if (!hr || !lr) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (F < 1 || H < 7 || W < 7 || (scale != 2 && scale != 4))
+        return fail(PFNL_ERR_INVALID, "blur_decimate needs H, W >= 7 (reflect pad 6) and scale 2 or 4");
+    HIPCHK(pfnl::launch_blur_decimate(hr, lr, F, H, W, scale, (hipStream_t)stream));
+    return 0;
+}
+
 int pfnl_selftest_mfma(int device_id) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(PFNL_ERR_NODEVICE, "no HIP device visible");

@@ -92,6 +92,7 @@ hipError_t launch_conv0(const float* Xo, const float* w75x64, const float* bias,
                         int T, int H, int W, hipStream_t s);
 hipError_t launch_tail(const float* merge, const float* x, const float* w2, const float* b2,
                        float* out, int B, int T, int H, int W, int scale, hipStream_t s);
+hipError_t launch_blur_decimate(const float* hr, float* lr, int F, int H, int W, int scale, hipStream_t s);
 hipError_t launch_bicubic(const float* x, float* out, int B, int H, int W, int scale, hipStream_t s);
 hipError_t run_mfma_selftest(int* mismatches);
 

@@ -222,6 +222,69 @@ hipError_t launch_tail(const float* merge, const float* x, const float* w2, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// blur + decimate (the step BEFORE the path in test_video_truth / eval: reference utils.py:95-105,
+// 169-192): reflect-pad 6 (edge sample not repeated), 13x13 Gaussian sigma 1.6 (float32 taps, as the
+// reference's BLUR.astype(float32)), depthwise, stride `scale`, VALID.  hr [F][H][W][3] -> lr
+// [F][ceil(H/s)][ceil(W/s)][3].  HBM-bound: one thread per output pixel, taps in constant memory.
+__constant__ float c_blur[13 * 13];
+
+__global__ void blur_decimate_kernel(const float* __restrict__ hr, float* __restrict__ lr, int F, int H, int W,
+                                     int oh, int ow, int scale) {
+    const size_t total = (size_t)F * oh * ow;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % ow);
+        const int oy = (int)((i / ow) % oh);
+        const int f = (int)(i / ((size_t)ow * oh));
+        const float* src = hr + (size_t)f * H * W * 3;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int ky = 0; ky < 13; ++ky) {
+            int y = oy * scale + ky - 6;
+            y = y < 0 ? -y : (y >= H ? 2 * H - 2 - y : y);          // tf.pad(mode='REFLECT')
+            for (int kx = 0; kx < 13; ++kx) {
+                int x = ox * scale + kx - 6;
+                x = x < 0 ? -x : (x >= W ? 2 * W - 2 - x : x);
+                const float w = c_blur[ky * 13 + kx];
+                const float* p = src + ((size_t)y * W + x) * 3;
+                a0 = fmaf(w, p[0], a0);
+                a1 = fmaf(w, p[1], a1);
+                a2 = fmaf(w, p[2], a2);
+            }
+        }
+        lr[i * 3 + 0] = a0;
+        lr[i * 3 + 1] = a1;
+        lr[i * 3 + 2] = a2;
+    }
+}
+
+hipError_t launch_blur_decimate(const float* hr, float* lr, int F, int H, int W, int scale, hipStream_t s) {
+    static bool init[64] = {false};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && !init[dev]) {
+        // scipy.ndimage.gaussian_filter(delta, 1.6) on a 13x13 grid == outer(k, k), k truncated at +-6
+        // and normalised (verified to 1e-17, tests/test_host.py)
+        double k[13], sum = 0.0;
+        for (int i = 0; i < 13; ++i) {
+            const double d = (i - 6) / 1.6;
+            k[i] = exp(-0.5 * d * d);
+            sum += k[i];
+        }
+        float w[169];
+        for (int a = 0; a < 13; ++a)
+            for (int b = 0; b < 13; ++b) w[a * 13 + b] = (float)((k[a] / sum) * (k[b] / sum));
+        e = hipMemcpyToSymbol(HIP_SYMBOL(c_blur), w, sizeof(w));
+        if (e != hipSuccess) return e;
+        init[dev] = true;
+    }
+    const int oh = (H + scale - 1) / scale, ow = (W + scale - 1) / scale;
+    const size_t total = (size_t)F * oh * ow;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(blur_decimate_kernel, dim3(blocks), dim3(256), 0, s, hr, lr, F, H, W, oh, ow, scale);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // MFMA layout self-test: D = A(32x2) * B(2x32) with asymmetric integer-valued operands.
 __global__ void mfma_selftest_kernel(int* mismatches) {
     const int lane = threadIdx.x & 63;

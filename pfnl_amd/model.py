@@ -22,7 +22,7 @@ import numpy as np
 
 from . import checkpoint as ckpt
 from .spec import PFNLGeometry
-from .synth import blur_decimate, synthetic_weights
+from .synth import synthetic_weights
 
 
 def automkdir(path):                       # reference utils.py:84-86
@@ -204,7 +204,12 @@ class PFNL(VSR):
         self._ensure_loaded(reuse)
         if hr.shape[0] == 0:
             return self._run_sequence(np.zeros((0, 0, 0, 3), np.float32), save_path, part)
-        lrs = blur_decimate(hr, self.scale)      # unquantised float LR, as model/pfnl.py:224,234
+        # unquantised float LR, as model/pfnl.py:224,234 - on the GPU (pfnl_op_blur_decimate)
+        import torch
+        from . import ops
+        self._get_engine()                       # fails loudly without a device
+        dev = "cuda:%d" % self.device
+        lrs = ops.blur_decimate(torch.from_numpy(np.ascontiguousarray(hr, np.float32)).to(dev), self.scale).cpu().numpy()
         self._run_sequence(lrs, save_path, part)
 
     def test_video_lr(self, path, name='result', reuse=False, part=50):

@@ -97,5 +97,17 @@ def bicubic(x, scale: int):
     return out
 
 
+def blur_decimate(hr, scale: int = 4):
+    """reference utils.py:169-192 (DownSample_4D with BLUR): hr [F,H,W,3] (cuda) -> [F,ceil(H/s),ceil(W/s),3]."""
+    import torch
+    lib = _capi.load_library()
+    F, H, W, c = hr.shape
+    if c != 3:
+        raise ValueError("blur_decimate expects 3 channels")
+    out = torch.empty((F, -(-H // scale), -(-W // scale), 3), dtype=torch.float32, device=hr.device)
+    _capi.check(lib.pfnl_op_blur_decimate(_req(hr, "hr"), _req(out, "out"), F, H, W, scale, _stream(hr)))
+    return out
+
+
 def selftest_mfma(device: int = 0) -> None:
     _capi.check(_capi.load_library().pfnl_selftest_mfma(device))

@@ -126,6 +126,33 @@ def test_dropin_class_and_harness(tmp_path):
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3           # rounding ties only
 
 
+def test_test_video_truth_harness(tmp_path):
+    """HR pngs -> GPU blur+decimate -> sliding windows -> forward -> pngs; against the oracle chain."""
+    from PIL import Image
+    from model.pfnl import PFNL
+    rng = np.random.default_rng(3)
+    hr_u8 = rng.integers(0, 256, size=(3, 32, 48, 3), dtype=np.uint8)
+    seq = tmp_path / "seqA"
+    (seq / "truth").mkdir(parents=True)
+    for i, im in enumerate(hr_u8):
+        Image.fromarray(im).save(seq / "truth" / f"{i:03d}.png")
+    geom = PFNLGeometry(num_block=1)
+    w = synth.synthetic_weights(geom, seed=0)
+    m = PFNL()
+    m.num_block = 1
+    m.save_dir = str(tmp_path / "none")          # no checkpoint: load() prints ERROR, returns False, run continues
+    m.set_weights(w)
+    m.testvideos(str(tmp_path), name="pfnl")
+    outs = sorted((seq / "pfnl").glob("*.png"))
+    assert [p.name for p in outs] == ["0000.png", "0001.png", "0002.png"]
+    lrs = synth.blur_decimate(hr_u8 / 255., 4)
+    ref = pfnl_spec.quantise(pfnl_spec.forward(pfnl_spec.sliding_windows(lrs, 7), w, num_block=1)[:, 0])
+    got = np.stack([np.asarray(Image.open(p)) for p in outs])
+    assert got.shape == ref.shape == (3, 32, 48, 3)
+    diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3
+
+
 def test_full_size_properties_and_sampled_parity():
     """BASELINE.json configs[1]: 7x128x128 -> 512x512, batch 4.  The fp64 oracle is too slow here; use
     (a) the fp32 fast oracle on ONE clip, (b) batch independence, (c) bic[::4,::4] anchoring through

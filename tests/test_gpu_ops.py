@@ -161,3 +161,14 @@ def test_nonlocal_constant_and_peaked_inputs():
     ref = stack + pfnl_spec.depth_to_space2(z)
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() < 5e-5
+
+
+@pytest.mark.parametrize("F,H,W,scale", [(2, 24, 32, 4), (1, 37, 29, 4), (3, 16, 16, 2), (1, 7, 7, 4)])
+def test_blur_decimate(F, H, W, scale):
+    from pfnl_amd import synth
+    rng = np.random.default_rng(F + H + W)
+    hr = rng.random((F, H, W, 3), dtype=np.float32)
+    got = ops.blur_decimate(dev(hr), scale).cpu().numpy()
+    ref = synth.blur_decimate(hr.astype(np.float64), scale)        # numpy restatement of utils.py:169-192
+    assert got.shape == ref.shape == (F, -(-H // scale), -(-W // scale), 3)
+    assert np.abs(got - ref).max() < 2e-6

@@ -126,3 +126,24 @@ def test_many_tensor_bundle_spans_several_blocks(tmp_path):
     tfbundle.write_bundle(str(tmp_path / "big"), t, block_size=512)
     back = tfbundle.read_bundle(str(tmp_path / "big"))
     assert set(back) == set(t) and all(np.array_equal(back[k], t[k]) for k in t)
+
+
+def test_metrics_known_answers():
+    from pfnl_amd import metrics as mt
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, size=(24, 32, 3)).astype(np.float64)
+    assert mt.psnr_y(a, a) == float("inf") and abs(mt.ssim(a[..., 0], a[..., 0]) - 1.0) < 1e-12
+    # BT.601 studio swing: black -> Y 16, white -> Y 235, grey keeps Cb = Cr = 128
+    assert np.allclose(mt.rgb2ycbcr(np.zeros(3)), [16, 128, 128])
+    assert np.allclose(mt.rgb2ycbcr(np.full(3, 255.0)), [235, 128, 128], atol=1e-9)
+    # constant offset d on all channels -> Y offset d*(sum of the Y row) = d*219/255
+    b = a + 3.0
+    assert abs(mt.psnr_y(a, b) - 20 * np.log10(255.0 / (3.0 * 219.0 / 255.0))) < 1e-9
+    assert abs(mt.psnr_rgb(a / 255, b / 255) - 10 * np.log10(1.0 / (3.0 / 255) ** 2)) < 1e-9
+    # AVG_PSNR protocol: borders are excluded, frames are rounded to uint8 first
+    vt = rng.random((6, 40, 48, 3))
+    vp = vt.copy()
+    vp[:, :8] += 0.5
+    vp[:2] += 0.5                                   # spatial / temporal borders only
+    assert mt.avg_psnr(vt, np.clip(vp, 0, 2)) == float("inf") or mt.avg_psnr(vt, np.clip(vp, 0, 2)) > 100
+    assert mt.ssim(a[..., 0], 255 - a[..., 0]) < 0.1
