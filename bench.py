@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--conv3x3", choices=["winograd", "direct"], default=None, help="override the 3x3 conv algorithm")
+    ap.add_argument("--conv3x3", choices=["winograd", "winograd16", "direct"], default=None, help="override the 3x3 conv algorithm")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events (no roofline object)")
     args = ap.parse_args()
 
@@ -157,7 +157,7 @@ def main():
         avg_ms = k["ms"] / k["launches"]
         flops_per_launch = flops3 * args.steps / k["launches"]
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        executed = achieved / 2.25 if algo == "winograd" else achieved
+        executed = achieved / 2.25 if algo.startswith("winograd") else achieved
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
         if os.path.exists(tpath):
@@ -166,14 +166,15 @@ def main():
                 traffic = tj.get("hbm_bytes_per_launch_avg")
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                "kernel": ("conv_wino_kernel<*> (fused Winograd F(2x2,3x3) 64->64, f32 MFMA)" if algo == "winograd"
+                "kernel": ("conv_wino16_kernel<*> (fused Winograd F(2x2,3x3), one wave per SIMD)" if algo == "winograd16" else
+                           "conv_wino_kernel<*> (fused Winograd F(2x2,3x3) 64->64, f32 MFMA)" if algo == "winograd"
                            else "conv_mfma_kernel<3,16,*> (3x3 64->64 f32 MFMA implicit GEMM)"),
                 "avg_launch_ms": round(avg_ms, 4), "launches": k["launches"],
                 "gflop_per_launch": round(flops_per_launch / 1e9, 3),
                 "mfma_executed_tflops": round(executed, 2),
                 "mfma_util": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
                 "note": "achieved = algorithmic (direct-conv) FLOPs / time; Winograd executes 1/2.25 of them on the matrix pipe"
-                        if algo == "winograd" else "achieved = executed = algorithmic"}
+                        if algo.startswith("winograd") else "achieved = executed = algorithmic"}
     f_ref = geom.flops_per_clip(H, W) * B_PER_GPU
     f_exec = geom.flops_per_clip(H, W, shared_base=True) * B_PER_GPU
     breakdown = {n: round(v["ms"] / args.steps, 4) for n, v in prof.items()}

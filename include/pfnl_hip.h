@@ -74,7 +74,8 @@ int pfnl_missing_weights(pfnl_handle* h, int* count);
 int pfnl_finalize_weights(pfnl_handle* h);
 
 /* Tuning knobs (all parity-tested):  key "conv3x3" = "winograd" (default: fused Winograd F(2x2,3x3),
- * f32 MFMA, 2.25x fewer multiplies) | "direct" (implicit-GEMM f32 MFMA).  The default can also be
+ * f32 MFMA, 2.25x fewer multiplies) | "winograd16" (same maths, one wave per SIMD owning all 16
+ * positions) | "direct" (implicit-GEMM f32 MFMA).  The default can also be
  * set with the environment variable PFNL_CONV3X3 read by pfnl_create. */
 int pfnl_set_option(pfnl_handle* h, const char* key, const char* value);
 
@@ -122,6 +123,10 @@ int pfnl_op_conv2d(const float* in, const float* kernel_host, const float* bias_
 int pfnl_op_conv3x3_winograd(const float* in, const float* kernel_host, const float* bias_host,
                              const float* addend, int add_div, const float* resid, float* out,
                              int items, int H, int W, int act, void* stream);
+/* Same contract, one-wave-per-SIMD variant (all 16 Winograd positions in one wave's 512 registers). */
+int pfnl_op_conv3x3_winograd16(const float* in, const float* kernel_host, const float* bias_host,
+                               const float* addend, int add_div, const float* resid, float* out,
+                               int items, int H, int W, int act, void* stream);
 /* utils.NonLocalBlock(nltype=1) + the residual of model/pfnl.py:55-60:
  * x [B,T,H,W,3] -> out [B,H,W,3T] = stack(x) + depth_to_space(NL(space_to_depth(stack(x)))). */
 int pfnl_op_nonlocal(const float* x, const float* wg_host, const float* bg_host,

@@ -59,13 +59,14 @@ struct pfnl_handle {
     std::map<std::string, std::vector<int64_t>> expected;   // tf name -> shape
     std::map<std::string, HostTensor> host;                  // tensors received so far
     bool finalized = false;
-    bool use_wino = true;                                     // conv3x3 algorithm (pfnl_set_option)
+    int conv_algo = 1;                                        // conv3x3: 0 direct, 1 winograd (4 waves), 2 winograd16 (1 wave / SIMD)
 
     // device weights (offsets in floats into `wdev`)
     DevBuf wdev;
     size_t off_conv0_w = 0, off_conv0_b = 0;
     std::vector<size_t> off_c1_w, off_c1_b, off_c10_w, off_c10_b, off_c2a_w, off_c2b_w, off_c2_b;
     std::vector<size_t> off_c1_u, off_c2a_u, off_c2b_u;       // Winograd-packed variants
+    std::vector<size_t> off_c1_u16, off_c2a_u16, off_c2b_u16; // ... for conv_wino16_kernel
     size_t off_m1_w = 0, off_m1_b = 0, off_m2_w = 0, off_m2_b = 0, off_nl_w = 0, off_nl_b = 0, off_zero = 0;
 
     // workspace
@@ -202,7 +203,10 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             p.nchunks = p.chunks_per_frame;
             p.add_div = 1;
             p.act = 1;
-            if (h->use_wino) {
+            if (h->conv_algo == 2) {
+                WinoParams wp{p.in, wd + h->off_c1_u16[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 1, F, nullptr};
+                HIPCHK(launch_conv_wino16(wp, s));
+            } else if (h->conv_algo == 1) {
                 WinoParams wp{p.in, wd + h->off_c1_u[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 1, F, nullptr};
                 HIPCHK(launch_conv_wino(wp, s));
             } else {
@@ -228,7 +232,10 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             p.frames_per_item = 1;
             p.nchunks = p.chunks_per_frame;
             p.act = 0;
-            if (h->use_wino) {
+            if (h->conv_algo == 2) {
+                WinoParams wp{p.in, wd + h->off_c2a_u16[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 0, B, nullptr};
+                HIPCHK(launch_conv_wino16(wp, s));
+            } else if (h->conv_algo == 1) {
                 WinoParams wp{p.in, wd + h->off_c2a_u[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 0, B, nullptr};
                 HIPCHK(launch_conv_wino(wp, s));
             } else {
@@ -245,7 +252,10 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             p.resid = h->inp0.p;
             p.out = h->inp0.p;
             p.act = 1;
-            if (h->use_wino) {
+            if (h->conv_algo == 2) {
+                WinoParams wp{p.in, wd + h->off_c2b_u16[i], p.bias, p.addend, p.resid, p.out, H, W, T, 1, F, nullptr};
+                HIPCHK(launch_conv_wino16(wp, s));
+            } else if (h->conv_algo == 1) {
                 WinoParams wp{p.in, wd + h->off_c2b_u[i], p.bias, p.addend, p.resid, p.out, H, W, T, 1, F, nullptr};
                 HIPCHK(launch_conv_wino(wp, s));
             } else {
@@ -302,7 +312,10 @@ int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
     HIPCHK(hipSetDevice(cfg->device_id));
     pfnl_handle* h = new pfnl_handle();
     h->cfg = *cfg;
-    if (const char* e = std::getenv("PFNL_CONV3X3")) h->use_wino = std::string(e) != "direct";
+    if (const char* e = std::getenv("PFNL_CONV3X3")) {
+        const std::string v(e);
+        h->conv_algo = v == "direct" ? 0 : (v == "winograd16" ? 2 : 1);
+    }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return fail(PFNL_ERR_HIP, "hipStreamCreate failed");
@@ -361,9 +374,10 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
     if (!h || !key || !value) return fail(PFNL_ERR_INVALID, "NULL argument");
     const std::string k(key), v(value);
     if (k == "conv3x3") {
-        if (v == "winograd") h->use_wino = true;
-        else if (v == "direct") h->use_wino = false;
-        else return fail(PFNL_ERR_INVALID, "conv3x3 must be winograd or direct");
+        if (v == "winograd") h->conv_algo = 1;
+        else if (v == "winograd16") h->conv_algo = 2;
+        else if (v == "direct") h->conv_algo = 0;
+        else return fail(PFNL_ERR_INVALID, "conv3x3 must be winograd, winograd16 or direct");
         return 0;
     }
     return fail(PFNL_ERR_INVALID, "unknown option " + k);
@@ -397,6 +411,11 @@ int pfnl_finalize_weights(pfnl_handle* h) {
         std::memcpy(&blob[off], b.data(), b.size() * sizeof(float));
         return off;
     };
+    auto put_wino16 = [&](const std::vector<float>& k, int cin_total, int cin_begin) {
+        size_t off = reserve(pfnl::wino_pack_floats());
+        pfnl::wino16_pack_weights(k.data(), cin_total, cin_begin, &blob[off]);
+        return off;
+    };
     auto put_wino = [&](const std::vector<float>& k, int cin_total, int cin_begin) {
         size_t off = reserve(pfnl::wino_pack_floats());
         pfnl::wino_pack_weights(k.data(), cin_total, cin_begin, &blob[off]);
@@ -422,6 +441,9 @@ int pfnl_finalize_weights(pfnl_handle* h) {
     h->off_c1_u.assign(nb, 0);
     h->off_c2a_u.assign(nb, 0);
     h->off_c2b_u.assign(nb, 0);
+    h->off_c1_u16.assign(nb, 0);
+    h->off_c2a_u16.assign(nb, 0);
+    h->off_c2b_u16.assign(nb, 0);
     for (int i = 0; i < nb; ++i) {
         const std::string s = std::to_string(i);
         h->off_c1_w[i] = put_pack(W("conv1_" + s), 3, 64, 0, 64, 64);
@@ -435,6 +457,9 @@ int pfnl_finalize_weights(pfnl_handle* h) {
         h->off_c1_u[i] = put_wino(W("conv1_" + s), 64, 0);
         h->off_c2a_u[i] = put_wino(W("conv2_" + s), 128, 0);
         h->off_c2b_u[i] = put_wino(W("conv2_" + s), 128, 64);
+        h->off_c1_u16[i] = put_wino16(W("conv1_" + s), 64, 0);
+        h->off_c2a_u16[i] = put_wino16(W("conv2_" + s), 128, 0);
+        h->off_c2b_u16[i] = put_wino16(W("conv2_" + s), 128, 64);
     }
     h->off_m1_w = put_pack(W("convmerge1"), 3, 64 * T, 0, 64 * T, 48);
     h->off_m1_b = put_bias(Bv("convmerge1"));
@@ -667,6 +692,53 @@ int pfnl_op_conv3x3_winograd(const float* in, const float* kernel_host, const fl
     }
     (void)hipFree(dw);
     if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("winograd conv op: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int pfnl_op_conv3x3_winograd16(const float* in, const float* kernel_host, const float* bias_host,
+                             const float* addend, int add_div, const float* resid, float* out, int items, int H,
+                             int W, int act, void* stream) {
+    if (!in || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (items < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return fail(PFNL_ERR_INVALID, "winograd conv needs even H, W");
+    if ((addend != nullptr) != (resid != nullptr))
+        return fail(PFNL_ERR_INVALID, "addend and resid must be given together or not at all");
+    if (addend && add_div < 1) return fail(PFNL_ERR_INVALID, "add_div must be >= 1");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<float> pack(pfnl::wino_pack_floats() + 64, 0.f);
+    pfnl::wino16_pack_weights(kernel_host, 64, 0, pack.data());
+    const size_t boff = pack.size() - 64;
+    if (bias_host) std::memcpy(&pack[boff], bias_host, 64 * sizeof(float));
+    float* dw = nullptr;
+    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(float)));
+    hipError_t e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        pfnl::WinoParams wp{in, dw, dw + boff, addend, resid, out, H, W, addend ? add_div : 1, act, items, nullptr};
+#if 0
+        long long* dbg = nullptr;
+        const size_t dbg_n = 4096 * 64;
+        if (hipMalloc(&dbg, dbg_n * sizeof(long long)) == hipSuccess) {
+            (void)hipMemset(dbg, 0, dbg_n * sizeof(long long));
+            wp.dbg = dbg;
+        }
+#endif
+        e = pfnl::launch_conv_wino16(wp, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+#if 0
+        if (dbg) {
+            std::vector<long long> hst(dbg_n);
+            (void)hipMemcpy(hst.data(), dbg, dbg_n * sizeof(long long), hipMemcpyDeviceToHost);
+            for (int b : {0, 8, 16, 1024, 2048, 4096, 7000}) {
+                std::fprintf(stderr, "WINO_TIMING wg %d:", b);
+                for (int i = 1; i < 16 && hst[(size_t)b * 16 + i]; ++i)
+                    std::fprintf(stderr, " %lld", hst[(size_t)b * 16 + i] - hst[(size_t)b * 16]);
+                std::fprintf(stderr, " | t0-t0[wg0] %lld\n", hst[(size_t)b * 16] - hst[0]);
+            }
+            (void)hipFree(dbg);
+        }
+#endif
+    }
+    (void)hipFree(dw);
+    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("winograd16 conv op: ") + hipGetErrorString(e));
     return 0;
 }
 

@@ -7,9 +7,6 @@
 #ifndef PFNL_WINO_WPS
 #define PFNL_WINO_WPS 3      // waves per SIMD the Winograd kernel is compiled for (= workgroups per CU)
 #endif
-#ifndef PFNL_WINO_TPW
-#define PFNL_WINO_TPW 1      // tiles per workgroup (sequential)
-#endif
 #ifndef PFNL_WINO_UDEPTH
 #define PFNL_WINO_UDEPTH 2
 #endif
@@ -76,6 +73,8 @@ struct WinoParams {
     long long* dbg;        // PFNL_WINO_TIMING builds only: 64 clock64() stamps per workgroup (else null)
 };
 hipError_t launch_conv_wino(const WinoParams& p, hipStream_t s);
+hipError_t launch_conv_wino16(const WinoParams& p, hipStream_t s);   // one-wave-per-SIMD variant (conv_wino16.hip)
+void wino16_pack_weights(const float* hwio, int cin_total, int cin_begin, float* dst);
 size_t wino_pack_floats();
 void wino_pack_weights(const float* hwio, int cin_total, int cin_begin, float* dst);
 

@@ -120,11 +120,8 @@ __global__ __launch_bounds__(WN_THREADS, PFNL_WINO_WPS) void conv_wino_kernel(Wi
     const int rs = (ntiles + 7) >> 3;
     const int xcd = blockIdx.x & 7;
     const int ng = (blockIdx.x >> 3) & 1;
-    for (int rep = 0; rep < PFNL_WINO_TPW; ++rep) {
-    const int tidx = (int)(blockIdx.x >> 4) * PFNL_WINO_TPW + rep;
-    const int tile = xcd * rs + tidx;
-    if (tidx >= rs || tile >= ntiles) return;
-    if (rep > 0) __syncthreads();
+    const int tile = xcd * rs + (blockIdx.x >> 4);
+    if ((int)(blockIdx.x >> 4) >= rs || tile >= ntiles) return;
     const int item = tile / per_item;
     const int rem = tile - item * per_item;
     const int by = rem / tiles_x;
@@ -334,7 +331,6 @@ __global__ __launch_bounds__(WN_THREADS, PFNL_WINO_WPS) void conv_wino_kernel(Wi
         }
     }
     WN_STAMP();                                                 // 7: stores issued
-    }
 }
 
 template <bool FUSE>
@@ -350,7 +346,7 @@ hipError_t launch_conv_wino(const WinoParams& p, hipStream_t s) {
     if ((p.H & 1) || (p.W & 1)) return hipErrorInvalidValue;     // 2x2 tiles must not straddle the border
     const int ntiles = ((p.W + 2 * WN_TX - 1) / (2 * WN_TX)) * ((p.H + 2 * WN_TY - 1) / (2 * WN_TY)) * p.items;
     const int rs = (ntiles + 7) / 8;
-    const int nblocks = 16 * ((rs + PFNL_WINO_TPW - 1) / PFNL_WINO_TPW);   // 8 XCD regions x 2 N-tiles x tiles
+    const int nblocks = 16 * rs;                                  // 8 XCD regions x 2 N-tiles x rs tiles
     return fuse ? launch_wino_variant<true>(p, nblocks, s) : launch_wino_variant<false>(p, nblocks, s);
 }
 

@@ -52,7 +52,7 @@ def conv2d(x, kernel, bias=None, act=True, frames_per_item=1, addend=None, add_d
     return out
 
 
-def conv3x3_winograd(x, kernel, bias=None, act=True, addend=None, add_div=1, resid=None):
+def conv3x3_winograd(x, kernel, bias=None, act=True, addend=None, add_div=1, resid=None, variant="winograd"):
     """The 3x3 64->64 'same' convolution through the fused Winograd F(2x2,3x3) kernel (even H, W)."""
     import torch
     lib = _capi.load_library()
@@ -62,7 +62,8 @@ def conv3x3_winograd(x, kernel, bias=None, act=True, addend=None, add_div=1, res
         raise ValueError("winograd path is 3x3, 64 -> 64 only")
     F, H, W, c = x.shape
     out = torch.empty((F, H, W, 64), dtype=torch.float32, device=x.device)
-    _capi.check(lib.pfnl_op_conv3x3_winograd(
+    fn = lib.pfnl_op_conv3x3_winograd16 if variant == "winograd16" else lib.pfnl_op_conv3x3_winograd
+    _capi.check(fn(
         _req(x, "x"), k.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p) if b is not None else None,
         _req(addend, "addend") if addend is not None else None, int(add_div),
         _req(resid, "resid") if resid is not None else None, _req(out, "out"), F, H, W, 1 if act else 0, _stream(x)))

@@ -80,7 +80,8 @@ def test_conv_mfma(items, fpi, H, W, ks, cout, act, fused):
     (1, 2, 2, True, False),         # a single 2x2 tile: everything is halo
     (4, 64, 64, True, True),
 ])
-def test_conv3x3_winograd(items, H, W, act, fused):
+@pytest.mark.parametrize("variant", ["winograd", "winograd16"])
+def test_conv3x3_winograd(items, H, W, act, fused, variant):
     rng = np.random.default_rng(items * 1000 + H * 10 + W)
     x = rng.normal(size=(items, H, W, 64)).astype(np.float32)
     k = (rng.normal(size=(3, 3, 64, 64)) / np.sqrt(9 * 64)).astype(np.float32)
@@ -97,7 +98,7 @@ def test_conv3x3_winograd(items, H, W, act, fused):
         ref = pfnl_spec.lrelu(ref)
     if fused:
         ref = ref + res
-    got = ops.conv3x3_winograd(dev(x), k, b, act=act, **kw).cpu().numpy()
+    got = ops.conv3x3_winograd(dev(x), k, b, act=act, variant=variant, **kw).cpu().numpy()
     direct = ops.conv2d(dev(x), k, b, act=act, **kw).cpu().numpy()
     err = np.abs(got - ref).max()
     assert err < 2e-5 * max(1.0, np.abs(ref).max()), err          # Winograd: a few ulp more than direct
