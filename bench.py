@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv3x3", choices=["winograd", "winograd16", "direct"], default=None, help="override the 3x3 conv algorithm")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to exercise the N>1 plumbing on a 1-GPU box)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events (no roofline object)")
     args = ap.parse_args()
 
@@ -88,8 +90,12 @@ def main():
         raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = "cuda:%d" % local_rank
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= ndev:
+        raise SystemExit("rank %d has no GPU (%d visible)" % (local_rank, ndev))
+    local_dev = local_rank % ndev                      # gloo test mode may stack ranks on one GPU
+    torch.cuda.set_device(local_dev)
+    dev = "cuda:%d" % local_dev
     geom = PFNLGeometry()
 
     use_dist = world > 1
@@ -97,13 +103,17 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        cdev = dev if args.backend == "nccl" else None                # where collective tensors live
         weights = pd.broadcast_weights(geom, synth.synthetic_weights(geom, seed=0) if rank == 0 else None,
-                                       src=0, device=dev)            # RCCL broadcast, 12 MB, once
+                                       src=0, device=cdev)           # RCCL broadcast, 12 MB, once
     else:
         weights = synth.synthetic_weights(geom, seed=0)
 
-    eng = PFNLEngine(geom, device=local_rank)
+    eng = PFNLEngine(geom, device=local_dev)
     eng.load_weights(weights)
     if args.conv3x3:
         eng.set_option("conv3x3", args.conv3x3)
@@ -134,7 +144,7 @@ def main():
     prof = eng.profile_read()
 
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev or "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
     assert torch.isfinite(out).all().item(), "non-finite output"
@@ -184,7 +194,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "PFNL 4xSR, 7 frames, 128x128->512x512, batch=4 fp32 per MI355X (BASELINE.json configs[1])",
-                   "clips_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU, "parallelism": "dp%d" % world,
+                   "clips_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU, "parallelism": "dp%d" % world, "backend": (args.backend if world > 1 else None),
                    "weights": "synthetic Xavier (seed 0)", "input": "resident in HBM"},
         "roofline": roof,
         "whole_forward": {"tflops_ref_graph": round(f_ref / (ms_per_step * 1e-3) / 1e12, 2),

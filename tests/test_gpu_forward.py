@@ -168,3 +168,39 @@ def test_full_size_properties_and_sampled_parity():
     assert np.abs(y[:1] - ref).max() < ABS_TOL
     d = abs(synth.psnr(y[0, 0], gt[0]) - synth.psnr(ref[0, 0], gt[0]))
     assert d <= PSNR_TOL_DB, d
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_random_geometry_fuzz(seed):
+    """Random (T, scale, blocks, B, H, W) against the fp32 oracle: ragged tiles, tiny images, all T."""
+    rng = np.random.default_rng(1000 + seed)
+    T = int(rng.choice([3, 5, 7]))
+    scale = int(rng.choice([2, 4]))
+    nb = int(rng.integers(0, 3))
+    B = int(rng.integers(1, 3))
+    H, W = 2 * int(rng.integers(1, 24)), 2 * int(rng.integers(1, 40))
+    geom = PFNLGeometry(num_frames=T, scale=scale, num_block=nb)
+    w = synth.synthetic_weights(geom, seed=seed)
+    x = synth.uniform_clips(B, T, H, W, seed=seed)
+    eng = PFNLEngine(geom)
+    eng.load_weights(w)
+    ref = pfnl_fast.FastOracle(w, T, scale, nb).forward(x)
+    for algo in ("winograd", "direct"):
+        eng.set_option("conv3x3", algo)
+        y = eng.forward(x)
+        assert y.shape == ref.shape
+        assert np.abs(y - ref).max() < ABS_TOL, (algo, T, scale, nb, B, H, W, np.abs(y - ref).max())
+    eng.close()
+
+
+def test_1080p_single_clip_runs():
+    """BASELINE.json configs[3] geometry in fp32: 7x270x480 -> 1080x1920, batch 1 (N = 32400: 16 | N, 32 !| N)."""
+    geom = PFNLGeometry()
+    eng = engine_for(geom)
+    x = synth.uniform_clips(1, 7, 270, 480, seed=77)
+    y = eng.forward(x)
+    assert y.shape == (1, 1, 1080, 1920, 3) and np.isfinite(y).all()
+    # bicubic anchor: with the trunk residual removed the skip is exact at ::4; here just a sanity band
+    assert abs(float(y.mean()) - float(x[:, 3].mean())) < 0.2
+    # batch independence at this size: a 64x480 strip cannot be compared (non-local is global), so compare determinism
+    assert np.array_equal(eng.forward(x), y)
