@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--conv3x3", choices=["winograd", "winograd16", "direct"], default=None, help="override the 3x3 conv algorithm")
+    ap.add_argument("--conv3x3", choices=["winograd", "winograd_ws", "winograd16", "direct"], default=None, help="override the 3x3 conv algorithm")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to exercise the N>1 plumbing on a 1-GPU box)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events (no roofline object)")

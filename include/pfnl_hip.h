@@ -124,6 +124,9 @@ int pfnl_op_conv3x3_winograd(const float* in, const float* kernel_host, const fl
                              const float* addend, int add_div, const float* resid, float* out,
                              int items, int H, int W, int act, void* stream);
 /* Same contract, one-wave-per-SIMD variant (all 16 Winograd positions in one wave's 512 registers). */
+int pfnl_op_conv3x3_winograd_ws(const float* in, const float* kernel_host, const float* bias_host,
+                                const float* addend, int add_div, const float* resid, float* out, int items, int H,
+                                int W, int act, void* stream);
 int pfnl_op_conv3x3_winograd16(const float* in, const float* kernel_host, const float* bias_host,
                                const float* addend, int add_div, const float* resid, float* out,
                                int items, int H, int W, int act, void* stream);

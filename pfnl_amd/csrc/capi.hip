@@ -59,7 +59,7 @@ struct pfnl_handle {
     std::map<std::string, std::vector<int64_t>> expected;   // tf name -> shape
     std::map<std::string, HostTensor> host;                  // tensors received so far
     bool finalized = false;
-    int conv_algo = 1;                                        // conv3x3: 0 direct, 1 winograd (4 waves), 2 winograd16 (1 wave / SIMD)
+    int conv_algo = 1;                                        // conv3x3: 0 direct, 1 winograd (4 waves / tile), 2 winograd16 (1 wave / SIMD), 3 winograd_ws (persistent, wave-specialised)
 
     // device weights (offsets in floats into `wdev`)
     DevBuf wdev;
@@ -206,9 +206,9 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             if (h->conv_algo == 2) {
                 WinoParams wp{p.in, wd + h->off_c1_u16[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 1, F, nullptr};
                 HIPCHK(launch_conv_wino16(wp, s));
-            } else if (h->conv_algo == 1) {
+            } else if (h->conv_algo == 1 || h->conv_algo == 3) {
                 WinoParams wp{p.in, wd + h->off_c1_u[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 1, F, nullptr};
-                HIPCHK(launch_conv_wino(wp, s));
+                HIPCHK(h->conv_algo == 3 ? launch_conv_wino_ws(wp, s) : launch_conv_wino(wp, s));
             } else {
                 HIPCHK(launch_conv_mfma(p, 3, F, s));
             }
@@ -235,9 +235,9 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             if (h->conv_algo == 2) {
                 WinoParams wp{p.in, wd + h->off_c2a_u16[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 0, B, nullptr};
                 HIPCHK(launch_conv_wino16(wp, s));
-            } else if (h->conv_algo == 1) {
+            } else if (h->conv_algo == 1 || h->conv_algo == 3) {
                 WinoParams wp{p.in, wd + h->off_c2a_u[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 0, B, nullptr};
-                HIPCHK(launch_conv_wino(wp, s));
+                HIPCHK(h->conv_algo == 3 ? launch_conv_wino_ws(wp, s) : launch_conv_wino(wp, s));
             } else {
                 HIPCHK(launch_conv_mfma(p, 3, B, s));
             }
@@ -255,9 +255,9 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             if (h->conv_algo == 2) {
                 WinoParams wp{p.in, wd + h->off_c2b_u16[i], p.bias, p.addend, p.resid, p.out, H, W, T, 1, F, nullptr};
                 HIPCHK(launch_conv_wino16(wp, s));
-            } else if (h->conv_algo == 1) {
+            } else if (h->conv_algo == 1 || h->conv_algo == 3) {
                 WinoParams wp{p.in, wd + h->off_c2b_u[i], p.bias, p.addend, p.resid, p.out, H, W, T, 1, F, nullptr};
-                HIPCHK(launch_conv_wino(wp, s));
+                HIPCHK(h->conv_algo == 3 ? launch_conv_wino_ws(wp, s) : launch_conv_wino(wp, s));
             } else {
                 HIPCHK(launch_conv_mfma(p, 3, F, s));
             }
@@ -314,7 +314,7 @@ int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
     h->cfg = *cfg;
     if (const char* e = std::getenv("PFNL_CONV3X3")) {
         const std::string v(e);
-        h->conv_algo = v == "direct" ? 0 : (v == "winograd16" ? 2 : 1);
+        h->conv_algo = v == "direct" ? 0 : (v == "winograd16" ? 2 : (v == "winograd_ws" ? 3 : 1));
     }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
@@ -376,8 +376,9 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
     if (k == "conv3x3") {
         if (v == "winograd") h->conv_algo = 1;
         else if (v == "winograd16") h->conv_algo = 2;
+        else if (v == "winograd_ws") h->conv_algo = 3;
         else if (v == "direct") h->conv_algo = 0;
-        else return fail(PFNL_ERR_INVALID, "conv3x3 must be winograd, winograd16 or direct");
+        else return fail(PFNL_ERR_INVALID, "conv3x3 must be winograd, winograd_ws, winograd16 or direct");
         return 0;
     }
     return fail(PFNL_ERR_INVALID, "unknown option " + k);
@@ -648,9 +649,9 @@ int pfnl_op_conv2d(const float* in, const float* kernel_host, const float* bias_
     return 0;
 }
 
-int pfnl_op_conv3x3_winograd(const float* in, const float* kernel_host, const float* bias_host,
-                             const float* addend, int add_div, const float* resid, float* out, int items, int H,
-                             int W, int act, void* stream) {
+static int op_conv3x3_wino(bool ws, const float* in, const float* kernel_host, const float* bias_host,
+                           const float* addend, int add_div, const float* resid, float* out, int items, int H,
+                           int W, int act, void* stream) {
     if (!in || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
     if (items < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return fail(PFNL_ERR_INVALID, "winograd conv needs even H, W");
     if ((addend != nullptr) != (resid != nullptr))
@@ -674,7 +675,7 @@ int pfnl_op_conv3x3_winograd(const float* in, const float* kernel_host, const fl
             wp.dbg = dbg;
         }
 #endif
-        e = pfnl::launch_conv_wino(wp, s);
+        e = ws ? pfnl::launch_conv_wino_ws(wp, s) : pfnl::launch_conv_wino(wp, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
 #ifdef PFNL_WINO_TIMING
         if (dbg) {
@@ -693,6 +694,18 @@ int pfnl_op_conv3x3_winograd(const float* in, const float* kernel_host, const fl
     (void)hipFree(dw);
     if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("winograd conv op: ") + hipGetErrorString(e));
     return 0;
+}
+
+int pfnl_op_conv3x3_winograd(const float* in, const float* kernel_host, const float* bias_host,
+                             const float* addend, int add_div, const float* resid, float* out, int items, int H,
+                             int W, int act, void* stream) {
+    return op_conv3x3_wino(false, in, kernel_host, bias_host, addend, add_div, resid, out, items, H, W, act, stream);
+}
+
+int pfnl_op_conv3x3_winograd_ws(const float* in, const float* kernel_host, const float* bias_host,
+                                const float* addend, int add_div, const float* resid, float* out, int items, int H,
+                                int W, int act, void* stream) {
+    return op_conv3x3_wino(true, in, kernel_host, bias_host, addend, add_div, resid, out, items, H, W, act, stream);
 }
 
 int pfnl_op_conv3x3_winograd16(const float* in, const float* kernel_host, const float* bias_host,

@@ -29,7 +29,7 @@ __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, 0.2f * v); }  
 // ---- MFMA implicit-GEMM convolution (conv_mfma.hip) ------------------------------------------
 // Output tile of one workgroup: 8 rows x 32 columns x 64 output channels of one item.
 constexpr int CONV_TW = 32;
-constexpr int CONV_TH = 8;
+constexpr int CONV_TH = 8;        // rows per workgroup at MT = 2 (conv_mfma.hip)
 constexpr int CONV_CK = 16;       // input channels per K-chunk of the 3x3 kernel (conv_ck(): 32 for 1x1)
 constexpr int CONV_NPAD = 64;     // output channels are padded to 64 in the packed weights
 
@@ -73,6 +73,7 @@ struct WinoParams {
     long long* dbg;        // PFNL_WINO_TIMING builds only: 64 clock64() stamps per workgroup (else null)
 };
 hipError_t launch_conv_wino(const WinoParams& p, hipStream_t s);
+hipError_t launch_conv_wino_ws(const WinoParams& p, hipStream_t s);  // persistent wave-specialised variant (conv_wino_ws.hip), same packed U
 hipError_t launch_conv_wino16(const WinoParams& p, hipStream_t s);   // one-wave-per-SIMD variant (conv_wino16.hip)
 void wino16_pack_weights(const float* hwio, int cin_total, int cin_begin, float* dst);
 size_t wino_pack_floats();

@@ -11,16 +11,19 @@
 // column) and the B operand (lane = output channel, weights [tap][c][64]) are conflict-free
 // ds_read_b32; the next chunk's global loads are issued before the current chunk's MFMAs and
 // written to LDS after them (register staging), and two workgroups per CU interleave.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace pfnl {
 
-template <int KS, int CK_>
+template <int KS, int CK_, int MT>
 struct ConvGeom {
     static constexpr int CK = CK_;
     static constexpr int HALO = KS - 1;
+    static constexpr int TH = 4 * MT;                              // output rows per workgroup (MT per wave)
     static constexpr int IW = CONV_TW + HALO;
-    static constexpr int IH = CONV_TH + HALO;
+    static constexpr int IH = TH + HALO;
     static constexpr int IPIX = IW * IH;
     static constexpr int PS = (IPIX % 2 == 0) ? IPIX + 1 : IPIX;  // odd: planes hit distinct banks
     static constexpr int W_FLOATS = KS * KS * CK * CONV_NPAD;
@@ -36,9 +39,11 @@ struct ConvGeom {
 };
 
 // FUSE = false: out = act(conv + bias);  FUSE = true: out = act(conv + bias + addend) + resid.
-template <int KS, int CK_, bool FUSE>
+// MT = M-tiles (output rows) per wave: 2 for the 64->64 3x3 (B operand reused twice); 1 where the grid
+// would otherwise be <= one workgroup per CU (conv10, convmerge1: 256 tiles of 8x32 at 4 x 128 x 128).
+template <int KS, int CK_, int MT, bool FUSE>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
-    using G = ConvGeom<KS, CK_>;
+    using G = ConvGeom<KS, CK_, MT>;
     constexpr int CK = G::CK, IW = G::IW, PS = G::PS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sw = smem;                    // [KS*KS][CK][64]
@@ -51,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     const int kh = lane >> 5;
     const int item = blockIdx.z;
     const int tx0 = blockIdx.x * CONV_TW;
-    const int ty0 = blockIdx.y * CONV_TH;
+    const int ty0 = blockIdx.y * G::TH;
     const int H = p.H, W = p.W;
 
     // Per-thread staging descriptors (identical for every chunk).
@@ -112,16 +117,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
             reinterpret_cast<f32x4*>(sw)[tid + i * 256] = rw[i];                                   \
     } while (0)
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     // lane-dependent bases: A = pixel (row 2*wave(+1), column xl), channel half kh; B = channel xl.
-    const float* abase = s_in + kh * PS + (2 * wave) * IW + xl;
+    const float* abase = s_in + kh * PS + (MT * wave) * IW + xl;
     const float* bbase = sw + kh * CONV_NPAD + xl;
 
     PFNL_LOAD_CHUNK(0);
@@ -138,14 +143,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
                 const float* bp = bbase + (dy * KS + dx) * CK * CONV_NPAD;
 #pragma unroll
                 for (int kk = 0; kk < CK / 2; ++kk) {
-                    const float a0 = ap[(2 * kk) * PS];
-                    const float a1 = ap[(2 * kk) * PS + IW];
                     const float b0 = bp[(2 * kk) * CONV_NPAD];
                     const float b1 = bp[(2 * kk) * CONV_NPAD + 32];
-                    acc[0][0] = mfma32(a0, b0, acc[0][0]);
-                    acc[0][1] = mfma32(a0, b1, acc[0][1]);
-                    acc[1][0] = mfma32(a1, b0, acc[1][0]);
-                    acc[1][1] = mfma32(a1, b1, acc[1][1]);
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi) {
+                        const float a = ap[(2 * kk) * PS + mi * IW];
+                        acc[mi][0] = mfma32(a, b0, acc[mi][0]);
+                        acc[mi][1] = mfma32(a, b1, acc[mi][1]);
+                    }
                 }
             }
         }
@@ -165,8 +170,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     const float slope = p.act ? 0.2f : 1.0f;                 // max(v, slope*v): lrelu or identity
     const int aitem = FUSE ? item / p.add_div : 0;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int y = ty0 + 2 * wave + mi;
+    for (int mi = 0; mi < MT; ++mi) {
+        const int y = ty0 + MT * wave + mi;
         const bool live = y < H && cvalid;
         const int yc = y < H ? y : H - 1;
         const size_t rowpix = ((size_t)item * H + yc) * W;
@@ -205,20 +210,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     }
 }
 
-template <int KS, int CK_, bool FUSE>
-static hipError_t launch_variant(const ConvParams& p, dim3 grid, hipStream_t s) {
+template <int KS, int CK_, int MT, bool FUSE>
+static hipError_t launch_variant(const ConvParams& p, int items, hipStream_t s) {
+    const dim3 grid((p.W + CONV_TW - 1) / CONV_TW, (p.H + 4 * MT - 1) / (4 * MT), items);
     static bool attr_set[64] = {false};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<KS, CK_, FUSE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ConvGeom<KS, CK_>::LDS_BYTES);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<KS, CK_, MT, FUSE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ConvGeom<KS, CK_, MT>::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
-    constexpr size_t lds_bytes = ConvGeom<KS, CK_>::LDS_BYTES;
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, CK_, FUSE>), grid, dim3(256), lds_bytes, s, p);
+    constexpr size_t lds_bytes = ConvGeom<KS, CK_, MT>::LDS_BYTES;
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, CK_, MT, FUSE>), grid, dim3(256), lds_bytes, s, p);
     return hipGetLastError();
 }
 
@@ -234,9 +240,21 @@ hipError_t launch_conv_mfma(const ConvParams& p0, int ksize, int items, hipStrea
     ConvParams p = p0;
     p.chunks_per_frame = p.in_cstride / conv_ck(ksize);
     p.nchunks = p.frames_per_item * p.chunks_per_frame;
-    dim3 grid((p.W + CONV_TW - 1) / CONV_TW, (p.H + CONV_TH - 1) / CONV_TH, items);
-    if (ksize == 3) return fuse ? launch_variant<3, 16, true>(p, grid, s) : launch_variant<3, 16, false>(p, grid, s);
-    if (ksize == 1) return fuse ? launch_variant<1, 32, true>(p, grid, s) : launch_variant<1, 32, false>(p, grid, s);
+    // 8-row tiles unless that leaves the chip with fewer than two workgroups per CU
+    const long tiles8 = (long)((p.W + CONV_TW - 1) / CONV_TW) * ((p.H + 7) / 8) * items;
+    bool small = tiles8 < 3 * 256;
+    if (const char* e = getenv("PFNL_CONV_MT")) {                 // test hook: force the tile height
+        if (e[0] == '1') small = true;
+        if (e[0] == '2') small = false;
+    }
+    if (ksize == 3) {
+        if (fuse) return launch_variant<3, 16, 2, true>(p, items, s);
+        return small ? launch_variant<3, 16, 1, false>(p, items, s) : launch_variant<3, 16, 2, false>(p, items, s);
+    }
+    if (ksize == 1) {
+        if (fuse) return launch_variant<1, 32, 2, true>(p, items, s);
+        return small ? launch_variant<1, 32, 1, false>(p, items, s) : launch_variant<1, 32, 2, false>(p, items, s);
+    }
     return hipErrorInvalidValue;
 }
 

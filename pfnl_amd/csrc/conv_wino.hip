@@ -31,73 +31,9 @@
 #include <string>
 
 #include "common.h"
+#include "wino_geom.h"
 
 namespace pfnl {
-
-constexpr int WN_TX = 16, WN_TY = 2;              // Winograd tiles per workgroup tile (x, y)
-constexpr int WN_IW = 2 * WN_TX + 2;              // 34 input columns
-constexpr int WN_IH = 2 * WN_TY + 2;              // 6 input rows
-constexpr int WN_HALF = 20;                       // floats per column-parity half row (17 used)
-constexpr int WN_RP = 2 * WN_HALF;                // row pitch 40: two tile rows are 80 = 16 mod 32 banks apart
-constexpr int WN_PS = WN_IH * WN_RP + 1;          // plane stride 241 (odd)
-constexpr int WN_CK = 16;
-constexpr int WN_NCHUNK = 64 / WN_CK;
-constexpr int WN_BUF = WN_CK * WN_PS;             // floats per raw buffer (3856)
-constexpr int WN_ES = 36;                         // slab row stride (floats): 32 couts + 4, 16-byte aligned rows
-constexpr int WN_SLAB = 4 * 2 * 32 * WN_ES;       // [xi][j][tile][cout]  (9216 floats, aliases the raw buffers)
-constexpr int WN_LDS_FLOATS = (2 * WN_BUF > WN_SLAB) ? 2 * WN_BUF : WN_SLAB;
-constexpr size_t WN_LDS_BYTES = size_t(WN_LDS_FLOATS) * sizeof(float);   // 36 864 B -> 4 workgroups / CU
-constexpr int WN_THREADS = 256;
-constexpr int WN_IN_ITEMS = WN_IH * WN_IW * (WN_CK / 4);                 // 816 float4 pieces
-constexpr int WN_IN_ITERS = (WN_IN_ITEMS + WN_THREADS - 1) / WN_THREADS; // 4
-constexpr int WN_UDEPTH = PFNL_WINO_UDEPTH;       // K-steps of U kept in flight
-constexpr int WN_NSTEP = WN_NCHUNK * (WN_CK / 2); // 32 K-steps
-constexpr int wino_pack_floats_c = 16 * 64 * 64;
-
-
-// One K-step (2 input channels) of one wave, hand-ordered: the SIMD issues VALU and MFMA through one
-// port, and VALU work is only hidden under a 64-cycle f32 MFMA when it sits between two MFMAs of the
-// SAME wave in program order - hipcc clumps the four MFMAs together, so the order is fixed here.
-//   current step : acc[nu] += V_cur[nu] (x) U[nu]                      (4 MFMAs)
-//   next step    : 8 LDS reads (immediate offsets from two row bases), t[b] = dA[b] + sgn*dB[b],
-//                  V_nxt = Bt * t                                       (8 VALU, in the MFMA shadows)
-// Row selection / sign per Winograd row xi: (A,B,sgn) = (0,2,-1) (1,2,+1) (1,2,-1)* (1,3,-1);
-// * xi = 2 needs d2 - d1 = -(d1 - d2): the minus sign is folded into U on the host.
-template <int OFF>     // byte offset of (buffer, channel pair) inside the raw LDS tile
-__device__ __forceinline__ void wn_kstep_asm(f32x16& a0, f32x16& a1, f32x16& a2, f32x16& a3, const float (&vc)[4],
-                                             float (&vn)[4], const f32x4 bc, unsigned pa, unsigned pb, float sgn) {
-    float x0, x1, x2, x3, y0, y1, y2, y3;
-    asm volatile(
-        "ds_read_b32 %[x0], %[pa] offset:%c[o0]\n\t"
-        "ds_read_b32 %[y0], %[pb] offset:%c[o0]\n\t"
-        "ds_read_b32 %[x2], %[pa] offset:%c[o2]\n\t"
-        "ds_read_b32 %[y2], %[pb] offset:%c[o2]\n\t"
-        "v_mfma_f32_32x32x2_f32 %[a0], %[c0], %[bx], %[a0]\n\t"
-        "ds_read_b32 %[x1], %[pa] offset:%c[o1]\n\t"
-        "ds_read_b32 %[y1], %[pb] offset:%c[o1]\n\t"
-        "ds_read_b32 %[x3], %[pa] offset:%c[o3]\n\t"
-        "ds_read_b32 %[y3], %[pb] offset:%c[o3]\n\t"
-        "v_mfma_f32_32x32x2_f32 %[a1], %[c1], %[by], %[a1]\n\t"
-        "s_waitcnt lgkmcnt(4)\n\t"
-        "v_fmac_f32 %[x0], %[sg], %[y0]\n\t"          // t0
-        "v_fmac_f32 %[x2], %[sg], %[y2]\n\t"          // t2
-        "v_sub_f32 %[n0], %[x0], %[x2]\n\t"           // V0 = t0 - t2
-        "v_mfma_f32_32x32x2_f32 %[a2], %[c2], %[bz], %[a2]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_fmac_f32 %[x1], %[sg], %[y1]\n\t"          // t1
-        "v_fmac_f32 %[x3], %[sg], %[y3]\n\t"          // t3
-        "v_add_f32 %[n1], %[x1], %[x2]\n\t"           // V1 = t1 + t2
-        "v_sub_f32 %[n2], %[x2], %[x1]\n\t"           // V2 = t2 - t1
-        "v_sub_f32 %[n3], %[x1], %[x3]\n\t"           // V3 = t1 - t3
-        "v_mfma_f32_32x32x2_f32 %[a3], %[c3], %[bw], %[a3]\n\t"
-        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [n0] "=&v"(vn[0]), [n1] "=&v"(vn[1]),
-          [n2] "=&v"(vn[2]), [n3] "=&v"(vn[3]), [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3),
-          [y0] "=&v"(y0), [y1] "=&v"(y1), [y2] "=&v"(y2), [y3] "=&v"(y3)
-        : [c0] "v"(vc[0]), [c1] "v"(vc[1]), [c2] "v"(vc[2]), [c3] "v"(vc[3]), [bx] "v"(bc.x), [by] "v"(bc.y),
-          [bz] "v"(bc.z), [bw] "v"(bc.w), [pa] "v"(pa), [pb] "v"(pb), [sg] "v"(sgn), [o0] "i"(OFF),
-          [o1] "i"(OFF + WN_HALF * 4), [o2] "i"(OFF + 4), [o3] "i"(OFF + WN_HALF * 4 + 4)
-        : "memory");
-}
 
 template <bool FUSE>
 __global__ __launch_bounds__(WN_THREADS, PFNL_WINO_WPS) void conv_wino_kernel(WinoParams p) {

@@ -64,7 +64,9 @@ def _conv_case(rng, items, fpi, H, W, ks, cout, act, fused):
     (1, 5, 6, 8, 1, 64, True, False),        # T = 5
     (1, 1, 1, 1, 3, 64, True, False),        # a single pixel: everything is halo
 ])
-def test_conv_mfma(items, fpi, H, W, ks, cout, act, fused):
+@pytest.mark.parametrize("mt", ["1", "2"])     # rows per wave: the launcher picks by grid size, both are forced here
+def test_conv_mfma(items, fpi, H, W, ks, cout, act, fused, mt, monkeypatch):
+    monkeypatch.setenv("PFNL_CONV_MT", mt)
     rng = np.random.default_rng(items * 1000 + H * 10 + W + ks)
     got, ref = _conv_case(rng, items, fpi, H, W, ks, cout, act, fused)
     assert got.shape == ref.shape
@@ -80,7 +82,7 @@ def test_conv_mfma(items, fpi, H, W, ks, cout, act, fused):
     (1, 2, 2, True, False),         # a single 2x2 tile: everything is halo
     (4, 64, 64, True, True),
 ])
-@pytest.mark.parametrize("variant", ["winograd", "winograd16"])
+@pytest.mark.parametrize("variant", ["winograd", "winograd_ws", "winograd16"])
 def test_conv3x3_winograd(items, H, W, act, fused, variant):
     rng = np.random.default_rng(items * 1000 + H * 10 + W)
     x = rng.normal(size=(items, H, W, 64)).astype(np.float32)
