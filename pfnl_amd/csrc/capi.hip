@@ -681,6 +681,15 @@ static int op_conv3x3_wino(bool ws, const float* in, const float* kernel_host, c
         if (dbg) {
             std::vector<long long> hst(dbg_n);
             (void)hipMemcpy(hst.data(), dbg, dbg_n * sizeof(long long), hipMemcpyDeviceToHost);
+            if (ws) {
+                for (int b : {0, 8, 101, 300, 511})
+                    for (int role = 0; role < 2; ++role) {
+                        const long long* t = &hst[(size_t)b * 128 + role * 64];
+                        std::fprintf(stderr, "WS_TIMING wg %d %s:", b, role ? "helper" : "matrix");
+                        for (int i = 1; i < 64 && t[i]; ++i) std::fprintf(stderr, " %lld", t[i] - t[i - 1]);
+                        std::fprintf(stderr, " | t0-t0[wg0] %lld\n", t[0] - hst[0]);
+                    }
+            } else
             for (int b : {0, 8, 16, 1024, 2048, 4096, 7000}) {
                 std::fprintf(stderr, "WINO_TIMING wg %d:", b);
                 for (int i = 1; i < 16 && hst[(size_t)b * 16 + i]; ++i)

@@ -28,7 +28,7 @@
 namespace pfnl {
 
 constexpr int WS_THREADS = 512;
-constexpr int WS_RAW_FLOATS = 2 * WN_BUF;                                  // two raw halo buffers
+constexpr int WS_RAW_FLOATS = 2 * WP_BUF;                                  // two raw halo buffers
 constexpr int WS_LDS_FLOATS = WS_RAW_FLOATS + WN_SLAB;
 constexpr size_t WS_LDS_BYTES = size_t(WS_LDS_FLOATS) * sizeof(float);     // 67 712 B
 constexpr int WS_MAX_WG_PER_XCD = 64;                                      // 32 CUs x 2 workgroups
@@ -68,9 +68,23 @@ __global__ __launch_bounds__(WS_THREADS, 2) void conv_wino_ws_kernel(WinoParams 
         x0_ = (rem_ - by_ * tiles_x) * (2 * WN_TX);                   \
     } while (0)
 
+#ifdef PFNL_WINO_TIMING
+    long long* dbg = p.dbg ? p.dbg + (size_t)blockIdx.x * 128 + (wave < 4 ? 0 : 64) : nullptr;
+    int dbg_n = 0;
+    const bool dbg_on = dbg && (lane == 0) && (wave == 0 || wave == 4);
+#define WS_STAMP() do { if (dbg_on && dbg_n < 64) dbg[dbg_n++] = clock64(); } while (0)
+#else
+#define WS_STAMP() do {} while (0)
+#endif
     if (wave < 4) {
         // =================================== matrix waves ===========================================
-        __builtin_amdgcn_s_setprio(2);
+#ifndef PFNL_WS_MPRIO
+#define PFNL_WS_MPRIO 0
+#endif
+#ifndef PFNL_WS_HPRIO
+#define PFNL_WS_HPRIO 3
+#endif
+        __builtin_amdgcn_s_setprio(PFNL_WS_MPRIO);
         const int xi = wave;
         const int tx = lane & 15;
         const int ty = (lane >> 4) & 1;
@@ -87,75 +101,96 @@ __global__ __launch_bounds__(WS_THREADS, 2) void conv_wino_ws_kernel(WinoParams 
         f32x4 ring[WN_UDEPTH];
 #pragma unroll
         for (int d = 0; d < WN_UDEPTH; ++d) ring[d] = WS_USTEP(d);
+#ifdef PFNL_WS_NO_U     /* timing experiment only: wrong results */
+#define WS_RING_REFILL(s_) do {} while (0)
+#else
+#define WS_RING_REFILL(s_) ring[(s_) % WN_UDEPTH] = WS_USTEP((s_) + WN_UDEPTH)
+#endif
 
         const int rowA = (xi == 0) ? 0 : 1;
         const int rowB = (xi == 3) ? 3 : 2;
         const float sgn = (xi == 1) ? 1.f : -1.f;
+        const f32x2 sg2 = {sgn, sgn};
         const unsigned lds0 = (unsigned)(uintptr_t)smem;
-        const unsigned lane_off = (unsigned)(kh * WN_PS + (2 * ty) * WN_RP + tx) * 4u;
-        const unsigned pa = lds0 + lane_off + rowA * WN_RP * 4;
-        const unsigned pb = lds0 + lane_off + rowB * WN_RP * 4;
+        const int lane_a = kh * WP_PS + (2 * ty + rowA) * WP_RP + 2 * tx;          // floats
+        const int lane_b = kh * WP_PS + (2 * ty + rowB) * WP_RP + 2 * tx;
+        const unsigned pa = lds0 + (unsigned)lane_a * 4u;
+        const unsigned pb = lds0 + (unsigned)lane_b * 4u;
         float* const slab = slabm + xi * (2 * 32 * WN_ES);
 
         f32x16 acc[4];
-#define WS_VFIRST(q_, v_)                                                                        \
+#define WS_VFIRST(q_, v03_, v12_)                                                                \
     do {                                                                                         \
-        const float* cA_ = smem + ((q_) & 1) * WN_BUF + (lane_off >> 2) + rowA * WN_RP;          \
-        const float* cB_ = smem + ((q_) & 1) * WN_BUF + (lane_off >> 2) + rowB * WN_RP;          \
-        const float t0_ = fmaf(sgn, cB_[0], cA_[0]);                                             \
-        const float t1_ = fmaf(sgn, cB_[WN_HALF], cA_[WN_HALF]);                                 \
-        const float t2_ = fmaf(sgn, cB_[1], cA_[1]);                                             \
-        const float t3_ = fmaf(sgn, cB_[WN_HALF + 1], cA_[WN_HALF + 1]);                         \
-        (v_)[0] = t0_ - t2_;                                                                     \
-        (v_)[1] = t1_ + t2_;                                                                     \
-        (v_)[2] = t2_ - t1_;                                                                     \
-        (v_)[3] = t1_ - t3_;                                                                     \
+        const f32x2* cA_ = reinterpret_cast<const f32x2*>(smem + ((q_) & 1) * WP_BUF + lane_a);   \
+        const f32x2* cB_ = reinterpret_cast<const f32x2*>(smem + ((q_) & 1) * WP_BUF + lane_b);   \
+        const f32x2 t01_ = cA_[0] + sg2 * cB_[0];                                                \
+        const f32x2 t23_ = cA_[1] + sg2 * cB_[1];                                                \
+        (v03_) = t01_ - t23_;                                    /* (t0 - t2, t1 - t3) */        \
+        (v12_).x = t01_.y + t23_.x;                                                              \
+        (v12_).y = t23_.x - t01_.y;                                                              \
     } while (0)
-#define WS_KSTEP(q_, kk_, vcur_, vnxt_)                                                          \
+#define WS_KSTEP(q_, kk_, c03_, c12_, n03_, n12_)                                                \
     do {                                                                                         \
         constexpr int s_ = (q_) * (WN_CK / 2) + (kk_);                                           \
         const f32x4 bc_ = ring[s_ % WN_UDEPTH];                                                  \
-        ring[s_ % WN_UDEPTH] = WS_USTEP(s_ + WN_UDEPTH);        /* wraps into the next unit */   \
-        constexpr int off_ = (((q_) & 1) * WN_BUF + 2 * ((kk_) + 1) * WN_PS) * 4;                \
+        WS_RING_REFILL(s_);                                     /* wraps into the next unit */   \
+        constexpr int off_ = (((q_) & 1) * WP_BUF + 2 * ((kk_) + 1) * WP_PS) * 4;                \
         if ((q_) == 0 && (kk_) == 0) {                                                           \
-            wn_kstep_asm_zero<off_>(acc[0], acc[1], acc[2], acc[3], vcur_, vnxt_, bc_, pa, pb, sgn); \
+            wp_kstep_asm_zero<off_>(acc[0], acc[1], acc[2], acc[3], (c03_).x, (c12_).x, (c12_).y, (c03_).y, n03_, \
+                                    n12_, bc_, pa, pb, sg2);                                     \
         } else if ((kk_) + 1 < WN_CK / 2) {                                                      \
-            wn_kstep_asm<off_>(acc[0], acc[1], acc[2], acc[3], vcur_, vnxt_, bc_, pa, pb, sgn);  \
+            wp_kstep_asm<off_>(acc[0], acc[1], acc[2], acc[3], (c03_).x, (c12_).x, (c12_).y, (c03_).y, n03_, n12_, \
+                               bc_, pa, pb, sg2);                                                \
         } else {                                                                                 \
-            acc[0] = mfma32((vcur_)[0], bc_.x, acc[0]);                                          \
-            acc[1] = mfma32((vcur_)[1], bc_.y, acc[1]);                                          \
-            acc[2] = mfma32((vcur_)[2], bc_.z, acc[2]);                                          \
-            acc[3] = mfma32((vcur_)[3], bc_.w, acc[3]);                                          \
+            acc[0] = mfma32((c03_).x, bc_.x, acc[0]);                                            \
+            acc[1] = mfma32((c12_).x, bc_.y, acc[1]);                                            \
+            acc[2] = mfma32((c12_).y, bc_.z, acc[2]);                                            \
+            acc[3] = mfma32((c03_).y, bc_.w, acc[3]);                                            \
         }                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                       \
     } while (0)
 #define WS_MCHUNK(q_)                                                                            \
     do {                                                                                         \
-        float va[4], vb[4];                                                                      \
-        WS_VFIRST(q_, va);                                                                       \
+        f32x2 pA_, pB_, pC_, pD_;                               /* (V0,V3) and (V1,V2), two sets */ \
+        WS_VFIRST(q_, pA_, pB_);                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        WS_KSTEP(q_, 0, va, vb); WS_KSTEP(q_, 1, vb, va); WS_KSTEP(q_, 2, va, vb); WS_KSTEP(q_, 3, vb, va); \
-        WS_KSTEP(q_, 4, va, vb); WS_KSTEP(q_, 5, vb, va); WS_KSTEP(q_, 6, va, vb); WS_KSTEP(q_, 7, vb, va); \
+        WS_KSTEP(q_, 0, pA_, pB_, pC_, pD_); WS_KSTEP(q_, 1, pC_, pD_, pA_, pB_);                \
+        WS_KSTEP(q_, 2, pA_, pB_, pC_, pD_); WS_KSTEP(q_, 3, pC_, pD_, pA_, pB_);                \
+        WS_KSTEP(q_, 4, pA_, pB_, pC_, pD_); WS_KSTEP(q_, 5, pC_, pD_, pA_, pB_);                \
+        WS_KSTEP(q_, 6, pA_, pB_, pC_, pD_); WS_KSTEP(q_, 7, pC_, pD_, pA_, pB_);                \
     } while (0)
         static_assert(WN_CK == 16 && WN_NCHUNK == 4, "written out for 8 K-steps x 4 chunks");
 
+        WS_STAMP();
         __syncthreads();                                            // B0: chunk 0 of the first unit is in LDS
         for (int i = 0; i < nu; ++i) {
+            WS_STAMP();
             WS_MCHUNK(0);
+            WS_STAMP();
             __syncthreads();
+            WS_STAMP();
             WS_MCHUNK(1);
+            WS_STAMP();
             __syncthreads();
+            WS_STAMP();
             WS_MCHUNK(2);
+            WS_STAMP();
             __syncthreads();
+            WS_STAMP();
             WS_MCHUNK(3);
+            WS_STAMP();
             // column transform over nu in registers (At = [[1,1,1,0],[0,1,-1,-1]]) -> slab[xi][j][tile][cout]
+            {
+                const f32x16 s0 = acc[0] + acc[1] + acc[2];     // whole-vector form: packed-f32 adds
+                const f32x16 s1 = acc[1] - acc[2] - acc[3];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r];
-                const int etile = drow(r, lane);
-                slab[(0 * 32 + etile) * WN_ES + xl] = m0 + m1 + m2;
-                slab[(1 * 32 + etile) * WN_ES + xl] = m1 - m2 - m3;
+                for (int r = 0; r < 16; ++r) {
+                    const int etile = drow(r, lane);
+                    slab[(0 * 32 + etile) * WN_ES + xl] = s0[r];
+                    slab[(1 * 32 + etile) * WN_ES + xl] = s1[r];
+                }
             }
+            WS_STAMP();
             __syncthreads();
         }
 #undef WS_MCHUNK
@@ -166,6 +201,10 @@ __global__ __launch_bounds__(WS_THREADS, 2) void conv_wino_ws_kernel(WinoParams 
     }
 
     // ====================================== helper waves =============================================
+    // The helpers issue few instructions but every one of them is on the barrier-critical path; at
+    // equal or lower priority they only got an issue slot about once per MFMA (measured: 16 LDS stores
+    // + selects took ~4.5k cycles), so they run at the highest priority.
+    __builtin_amdgcn_s_setprio(PFNL_WS_HPRIO);
     const int ht = tid - 4 * 64;                                    // 0..255
     // unit-independent part of the staging descriptors
     int loff[WN_IN_ITERS], pyx[WN_IN_ITERS];
@@ -179,45 +218,47 @@ __global__ __launch_bounds__(WS_THREADS, 2) void conv_wino_ws_kernel(WinoParams 
             const int pix = it >> 2, c4 = it & 3;
             const int py = pix / WN_IW, px = pix - py * WN_IW;
             stmask |= 1u << i;
-            loff[i] = (c4 * 4) * WN_PS + py * WN_RP + (px & 1) * WN_HALF + (px >> 1);
+            loff[i] = (c4 * 4) * WP_PS + py * WP_RP + px;
             pyx[i] = (py << 16) | (px << 4) | (c4 * 4);
         }
     }
-    // descriptors of the unit whose chunks are being loaded
+    // descriptors of the unit whose chunks are being loaded: one buffer resource per item (its range
+    // check returns 0 for the voffset of halo pixels outside the image: no selects, no masks) and a
+    // byte offset per staged piece; the chunk's channel offset goes in the scalar offset.
     int goff[WN_IN_ITERS];
-    unsigned maskL = 0;
-    const float* finL = p.in;
+    __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, 0, 0x00020000);
+    const int item_bytes = H * W * 64 * (int)sizeof(float);
 #define WS_DESC(i_)                                                                              \
     do {                                                                                         \
         int item_, y0_, x0_;                                                                     \
         WS_UNIT(i_, item_, y0_, x0_);                                                            \
-        finL = p.in + (size_t)item_ * H * W * 64;                                                \
-        maskL = 0;                                                                               \
+        rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (size_t)item_ * H * W * 64, 0, item_bytes, \
+                                                0x00020000);                                     \
         _Pragma("unroll") for (int k_ = 0; k_ < WN_IN_ITERS; ++k_) {                             \
             const int gy_ = y0_ + (pyx[k_] >> 16) - 1, gx_ = x0_ + ((pyx[k_] >> 4) & 0xfff) - 1; \
-            const bool in_ = ((stmask >> k_) & 1u) && gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W; \
-            goff[k_] = in_ ? (gy_ * W + gx_) * 64 + (pyx[k_] & 15) : 0;                          \
-            maskL |= in_ ? (1u << k_) : 0u;                                                      \
+            const bool in_ = gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W;                         \
+            goff[k_] = in_ ? ((gy_ * W + gx_) * 64 + (pyx[k_] & 15)) * 4 : 0x7fffffff;           \
         }                                                                                        \
     } while (0)
     f32x4 rin0[WN_IN_ITERS], rin1[WN_IN_ITERS];
-    unsigned mask0 = 0, mask1 = 0;
-#define WS_LOAD(q_, rin, mask_)                                                                  \
+#ifdef PFNL_WS_NO_HALO  /* timing experiment only: wrong results */
+#define WS_LOAD(q_, rin) do {} while (0)
+#else
+#define WS_LOAD(q_, rin)                                                                         \
     do {                                                                                         \
         _Pragma("unroll") for (int k_ = 0; k_ < WN_IN_ITERS; ++k_)                               \
-            rin[k_] = *reinterpret_cast<const f32x4*>(finL + (q_) * WN_CK + goff[k_]);           \
-        mask_ = maskL;                                                                           \
+            rin[k_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsL, goff[k_], (q_) * WN_CK * 4, 0)); \
     } while (0)
-#define WS_STORE(buf_, rin, mask_)                                                               \
+#endif
+#define WS_STORE(buf_, rin)                                                                      \
     do {                                                                                         \
         _Pragma("unroll") for (int k_ = 0; k_ < WN_IN_ITERS; ++k_) {                             \
             if ((stmask >> k_) & 1u) {                                                           \
-                const f32x4 v_ = ((mask_ >> k_) & 1u) ? rin[k_] : f32x4{0.f, 0.f, 0.f, 0.f};     \
-                float* d_ = smem + (buf_) * WN_BUF + loff[k_];                                   \
-                d_[0] = v_.x;                                                                    \
-                d_[WN_PS] = v_.y;                                                                \
-                d_[2 * WN_PS] = v_.z;                                                            \
-                d_[3 * WN_PS] = v_.w;                                                            \
+                float* d_ = smem + (buf_) * WP_BUF + loff[k_];                                   \
+                d_[0] = rin[k_].x;                                                               \
+                d_[WP_PS] = rin[k_].y;                                                           \
+                d_[2 * WP_PS] = rin[k_].z;                                                       \
+                d_[3 * WP_PS] = rin[k_].w;                                                       \
             }                                                                                    \
         }                                                                                        \
     } while (0)
@@ -271,35 +312,58 @@ __global__ __launch_bounds__(WS_THREADS, 2) void conv_wino_ws_kernel(WinoParams 
         }                                                                                        \
     } while (0)
 
+#ifdef PFNL_WS_NO_EPI   /* timing experiment only: wrong results */
+#undef WS_EPI
+#undef WS_EPI_LOAD
+#define WS_EPI(k_) do {} while (0)
+#define WS_EPI_LOAD(k_) do {} while (0)
+#endif
     // prologue: chunks 0,1 of unit 0 requested; chunk 0 stored; chunk 2 requested
     WS_DESC(0);
-    WS_LOAD(0, rin0, mask0);
-    WS_LOAD(1, rin1, mask1);
-    WS_STORE(0, rin0, mask0);
-    WS_LOAD(2, rin0, mask0);
+    WS_LOAD(0, rin0);
+    WS_LOAD(1, rin1);
+    WS_STORE(0, rin0);
+    WS_LOAD(2, rin0);
+    WS_STAMP();
     __syncthreads();                                                // B0
     for (int i = 0; i < nu; ++i) {
+        WS_STAMP();
         // phase 0: chunk 1 -> buffer 1; request chunk 3; first half of the previous unit's epilogue
-        WS_STORE(1, rin1, mask1);
-        WS_LOAD(3, rin1, mask1);
+#ifdef PFNL_WINO_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WS_STAMP();
+#endif
+        WS_STORE(1, rin1);
+        WS_STAMP();
+        WS_LOAD(3, rin1);
+        WS_STAMP();
         if (i > 0) WS_EPI(0);
+        WS_STAMP();
         __syncthreads();
+        WS_STAMP();
         // phase 1: chunk 2 -> buffer 0; request chunk 0 of the next unit; second half of that epilogue
-        WS_STORE(0, rin0, mask0);
+        WS_STORE(0, rin0);
+        WS_STAMP();
         WS_DESC(min(i + 1, nu - 1));                                // past the end: harmless re-read of the last unit
-        WS_LOAD(0, rin0, mask0);
+        WS_LOAD(0, rin0);
+        WS_STAMP();
         if (i > 0) WS_EPI(1);
+        WS_STAMP();
         __syncthreads();
+        WS_STAMP();
         // phase 2: chunk 3 -> buffer 1; request chunk 1 of the next unit; addend / residual of THIS unit, first half
-        WS_STORE(1, rin1, mask1);
-        WS_LOAD(1, rin1, mask1);
+        WS_STORE(1, rin1);
+        WS_LOAD(1, rin1);
         WS_UNIT(i, e_item, e_y0, e_x0);
         WS_EPI_LOAD(0);
+        WS_STAMP();
         __syncthreads();
+        WS_STAMP();
         // phase 3: next unit's chunk 0 -> buffer 0; request its chunk 2; second half of the addend / residual loads
-        WS_STORE(0, rin0, mask0);
-        WS_LOAD(2, rin0, mask0);
+        WS_STORE(0, rin0);
+        WS_LOAD(2, rin0);
         WS_EPI_LOAD(1);
+        WS_STAMP();
         __syncthreads();                                            // the matrix waves have filled the slab
     }
     WS_EPI(0);

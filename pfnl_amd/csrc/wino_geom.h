@@ -107,4 +107,70 @@ __device__ __forceinline__ void wn_kstep_asm_zero(f32x16& a0, f32x16& a1, f32x16
         : "memory");
 }
 
+
+
+// ---- packed-math K-step (natural column order in LDS) --------------------------------------------
+// Measured on gfx950 (tools/ubench/): while a SIMD's matrix pipe is saturated with f32 MFMAs, VALU
+// instructions get ~1 issue slot per MFMA, and inside a wave every VALU / LDS instruction between two
+// MFMAs delays the next MFMA (~14 cycles per group + ~4 per instruction).  Instruction COUNT is the
+// currency, so this K-step does the same transform with 4 ds_read_b64 + 4 packed-f32 VALU instead of
+// 8 ds_read_b32 + 8 VALU:  lane (tile column tx) reads columns 2tx..2tx+3 of rows A and B as two
+// 8-byte pairs each,  T01 = X01 + sgn*Y01,  T23 = X23 + sgn*Y23,
+// (V0,V3) = T01 - T23,  (V1,V2) = (t1 + t2, t2 - t1) via op_sel.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int WP_RP = 40;                          // row pitch (floats), even: 8-byte aligned pairs
+constexpr int WP_PS = WN_IH * WP_RP + 2;           // plane stride 242 (even)
+constexpr int WP_BUF = WN_CK * WP_PS;              // floats per raw buffer (3872)
+
+template <int OFF>     // byte offset of (buffer, channel pair of the NEXT step) inside the raw LDS tile
+__device__ __forceinline__ void wp_kstep_asm(f32x16& a0, f32x16& a1, f32x16& a2, f32x16& a3, const float c0,
+                                             const float c1, const float c2, const float c3, f32x2& n03, f32x2& n12,
+                                             const f32x4 bc, unsigned pa, unsigned pb, f32x2 sg) {
+    f32x2 x01, x23, y01, y23;
+    asm volatile(
+        "v_mfma_f32_32x32x2_f32 %[a0], %[c0], %[bx], %[a0]\n\t"
+        "ds_read_b64 %[x01], %[pa] offset:%c[o0]\n\t"
+        "ds_read_b64 %[y01], %[pb] offset:%c[o0]\n\t"
+        "ds_read_b64 %[x23], %[pa] offset:%c[o2]\n\t"
+        "ds_read_b64 %[y23], %[pb] offset:%c[o2]\n\t"
+        "v_mfma_f32_32x32x2_f32 %[a1], %[c1], %[by], %[a1]\n\t"
+        "v_mfma_f32_32x32x2_f32 %[a2], %[c2], %[bz], %[a2]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_pk_fma_f32 %[x01], %[y01], %[sg], %[x01]\n\t"                              // (t0, t1)
+        "v_pk_fma_f32 %[x23], %[y23], %[sg], %[x23]\n\t"                              // (t2, t3)
+        "v_pk_add_f32 %[n03], %[x01], %[x23] neg_lo:[0,1] neg_hi:[0,1]\n\t"           // (t0 - t2, t1 - t3)
+        "v_pk_add_f32 %[n12], %[x01], %[x23] op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"  // (t1 + t2, t2 - t1)
+        "v_mfma_f32_32x32x2_f32 %[a3], %[c3], %[bw], %[a3]\n\t"
+        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [n03] "=&v"(n03), [n12] "=&v"(n12),
+          [x01] "=&v"(x01), [x23] "=&v"(x23), [y01] "=&v"(y01), [y23] "=&v"(y23)
+        : [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [bx] "v"(bc.x), [by] "v"(bc.y), [bz] "v"(bc.z),
+          [bw] "v"(bc.w), [pa] "v"(pa), [pb] "v"(pb), [sg] "v"(sg), [o0] "i"(OFF), [o2] "i"(OFF + 8)
+        : "memory");
+}
+// First K-step of a tile: accumulators written (C = 0), not read.
+template <int OFF>
+__device__ __forceinline__ void wp_kstep_asm_zero(f32x16& a0, f32x16& a1, f32x16& a2, f32x16& a3, const float c0,
+                                             const float c1, const float c2, const float c3, f32x2& n03, f32x2& n12,
+                                             const f32x4 bc, unsigned pa, unsigned pb, f32x2 sg) {
+    f32x2 x01, x23, y01, y23;
+    asm volatile(
+        "v_mfma_f32_32x32x2_f32 %[a0], %[c0], %[bx], 0\n\t"
+        "ds_read_b64 %[x01], %[pa] offset:%c[o0]\n\t"
+        "ds_read_b64 %[y01], %[pb] offset:%c[o0]\n\t"
+        "ds_read_b64 %[x23], %[pa] offset:%c[o2]\n\t"
+        "ds_read_b64 %[y23], %[pb] offset:%c[o2]\n\t"
+        "v_mfma_f32_32x32x2_f32 %[a1], %[c1], %[by], 0\n\t"
+        "v_mfma_f32_32x32x2_f32 %[a2], %[c2], %[bz], 0\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_pk_fma_f32 %[x01], %[y01], %[sg], %[x01]\n\t"                              // (t0, t1)
+        "v_pk_fma_f32 %[x23], %[y23], %[sg], %[x23]\n\t"                              // (t2, t3)
+        "v_pk_add_f32 %[n03], %[x01], %[x23] neg_lo:[0,1] neg_hi:[0,1]\n\t"           // (t0 - t2, t1 - t3)
+        "v_pk_add_f32 %[n12], %[x01], %[x23] op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"  // (t1 + t2, t2 - t1)
+        "v_mfma_f32_32x32x2_f32 %[a3], %[c3], %[bw], 0\n\t"
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [n03] "=&v"(n03), [n12] "=&v"(n12),
+          [x01] "=&v"(x01), [x23] "=&v"(x23), [y01] "=&v"(y01), [y23] "=&v"(y23)
+        : [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [bx] "v"(bc.x), [by] "v"(bc.y), [bz] "v"(bc.z),
+          [bw] "v"(bc.w), [pa] "v"(pa), [pb] "v"(pb), [sg] "v"(sg), [o0] "i"(OFF), [o2] "i"(OFF + 8)
+        : "memory");
+}
 }  // namespace pfnl
