@@ -1,25 +1,28 @@
 // Fused Winograd F(2x2,3x3) convolution, 64 -> 64 channels, f32 MFMA - persistent, wave-specialised.
 //
-// Same arithmetic, packed U and tile geometry as conv_wino_kernel (conv_wino.hip; reference
-// model/pfnl.py:49-51 applied at :66-71); what changes is who does what.  conv_wino.hip measured its
-// own limit: a wave spends ~40 % of its life in the prologue (first halo chunk from HBM), the slab
-// exchange and the NHWC epilogue, so on average only ~1.5 of the 3 resident waves per SIMD are inside
-// the K-loop.  Here a workgroup is 8 waves that never change roles:
+// Same arithmetic and packed U as conv_wino_kernel (conv_wino.hip; reference model/pfnl.py:49-51 applied
+// at :66-71).  What shapes this kernel is a property of the gfx950 SIMD measured in tools/ubench/:
+// while the matrix pipe is busy with f32 MFMAs, every VALU / LDS instruction a wave issues between its
+// own MFMAs delays the next MFMA (~14 cycles per group + ~4 per instruction), and other waves on that
+// SIMD get about ONE VALU issue slot per MFMA.  Non-MFMA instruction COUNT per MFMA is therefore the
+// currency, not latency.  So:
 //
-//   waves 0-3  (matrix waves, Winograd row xi = wave): nothing but the K-loop.  Their only vector-
-//              memory traffic is the L2-resident U stream, so no HBM-latency load ever sits in front
-//              of it in the in-order vmcnt queue.  At the end of a unit they drop the column-transformed
-//              accumulators into an LDS slab and go straight on to the next unit.
-//   waves 4-7  (helper waves): stage the raw halo chunks global -> registers -> LDS two phases ahead,
-//              and run the previous unit's row transform + fused bias / addend / leaky-relu / residual
-//              epilogue out of the slab while the matrix waves are already computing.
+//   * one workgroup (8 waves) per CU, roles fixed for the life of the kernel;
+//   * waves 0-3, matrix waves (Winograd row xi = wave): 8 accumulators = BOTH 32-channel N-tiles of a
+//     2x16-tile spatial tile, so the input transform (4 ds_read_b64 + 4 packed-f32 VALU per K-step) is
+//     paid once per 8 MFMAs.  Their only vector-memory traffic is the L2-resident U stream (4 K-steps
+//     in flight), so no HBM-latency load ever sits in front of it in the in-order vmcnt queue.  Every
+//     K-step is the same asm block: it multiplies step s and prefetches + transforms step s+1; the
+//     chunk barrier sits between K-step 6 and 7 of a chunk (by then the last raw values of the chunk
+//     are in registers and the next chunk's tile is in LDS), so there is no per-chunk restart bubble;
+//   * waves 4-7, helper waves: stage the raw halo chunks global -> registers -> LDS FOUR phases ahead
+//     (buffer loads whose range check zero-fills the image border: no selects), and run the previous
+//     tile's row transform + fused bias / addend / leaky-relu / residual epilogue out of an LDS slab,
+//     with buffer stores whose range check drops the out-of-image lanes (no branches).
 //
-// Unit = (spatial tile of 2x16 Winograd tiles, 32-channel N-tile); a workgroup walks a strided list of
-// units of its XCD's contiguous tile range (the two N-tiles of a tile run at the same time on
-// neighbouring workgroups, so the second halo read hits L2).  One barrier per 16-channel chunk is the
-// only synchronisation: in phase c the matrix waves read raw buffer c&1 while the helpers fill buffer
-// (c+1)&1; the slab is written at the end of a unit's 4th phase and read during the next unit's first two.
-// 67.7 KB LDS and <= 128 VGPRs -> two workgroups per CU = per SIMD two matrix waves + two helpers.
+// Phase c = [barrier c-1, barrier c): the matrix waves read raw buffer c&1 (chunk c) while the helpers
+// fill buffer (c+1)&1; a tile's accumulators are dropped into the slab right after its 32nd K-step and
+// are read by the helpers in phases 1..3 of the next tile.  100.6 KB LDS, <= 256 VGPRs.
 #include <cstdint>
 
 #include "common.h"
@@ -29,13 +32,18 @@ namespace pfnl {
 
 constexpr int WS_THREADS = 512;
 constexpr int WS_RAW_FLOATS = 2 * WP_BUF;                                  // two raw halo buffers
-constexpr int WS_LDS_FLOATS = WS_RAW_FLOATS + WN_SLAB;
-constexpr size_t WS_LDS_BYTES = size_t(WS_LDS_FLOATS) * sizeof(float);     // 67 712 B
-constexpr int WS_MAX_WG_PER_XCD = 64;                                      // 32 CUs x 2 workgroups
+constexpr int WS_ES = 68;                                                  // slab row stride: 64 couts + 4
+constexpr int WS_SLAB_XI = 2 * 32 * WS_ES;                                 // floats per Winograd row: [j][tile][cout]
+constexpr int WS_LDS_FLOATS = WS_RAW_FLOATS + 4 * WS_SLAB_XI;
+constexpr size_t WS_LDS_BYTES = size_t(WS_LDS_FLOATS) * sizeof(float);     // 100 608 B
+constexpr int WS_MAX_WG_PER_XCD = 32;                                      // one workgroup per CU
+constexpr int WS_UD = 4;                                                   // K-steps of U in flight (divides 32)
 static_assert((WS_RAW_FLOATS * sizeof(float)) % 16 == 0, "slab must stay 16-byte aligned");
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 template <bool FUSE>
-__global__ __launch_bounds__(WS_THREADS, 2) void conv_wino_ws_kernel(WinoParams p) {
+__global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const slabm = smem + WS_RAW_FLOATS;
     const int tid = threadIdx.x;
@@ -43,8 +51,8 @@ __global__ __launch_bounds__(WS_THREADS, 2) void conv_wino_ws_kernel(WinoParams 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = p.H, W = p.W;
 
-    // ---- this workgroup's unit list: XCD b&7 owns tiles [xcd*rs, xcd*rs+rs); its workgroup j takes
-    // units j, j+wpx, ... of (tile, N-tile) pairs, N-tile minor.  wpx is even, so the N-tile is fixed.
+    // ---- this workgroup's tile list: XCD b&7 owns tiles [xcd*rs, xcd*rs+rs); workgroup j of the XCD
+    // takes tiles j, j+wpx, ...  (placement only affects L2 reuse, never results)
     const int tiles_x = (W + 2 * WN_TX - 1) / (2 * WN_TX);
     const int tiles_y = (H + 2 * WN_TY - 1) / (2 * WN_TY);
     const int per_item = tiles_x * tiles_y;
@@ -54,13 +62,12 @@ __global__ __launch_bounds__(WS_THREADS, 2) void conv_wino_ws_kernel(WinoParams 
     const int j = blockIdx.x >> 3;
     const int wpx = gridDim.x >> 3;
     const int tbeg = xcd * rs;
-    const int nux = 2 * min(rs, ntiles - tbeg);
-    if (j >= nux) return;
-    const int nu = (nux - j + wpx - 1) / wpx;
-    const int ng = j & 1;
+    const int tcnt = min(rs, ntiles - tbeg);
+    if (j >= tcnt) return;
+    const int nu = (tcnt - j + wpx - 1) / wpx;
 #define WS_UNIT(i_, item_, y0_, x0_)                                  \
     do {                                                              \
-        const int t_ = tbeg + ((j + (i_) * wpx) >> 1);                \
+        const int t_ = tbeg + j + (i_) * wpx;                         \
         item_ = t_ / per_item;                                        \
         const int rem_ = t_ - item_ * per_item;                       \
         const int by_ = rem_ / tiles_x;                               \
@@ -68,23 +75,8 @@ __global__ __launch_bounds__(WS_THREADS, 2) void conv_wino_ws_kernel(WinoParams 
         x0_ = (rem_ - by_ * tiles_x) * (2 * WN_TX);                   \
     } while (0)
 
-#ifdef PFNL_WINO_TIMING
-    long long* dbg = p.dbg ? p.dbg + (size_t)blockIdx.x * 128 + (wave < 4 ? 0 : 64) : nullptr;
-    int dbg_n = 0;
-    const bool dbg_on = dbg && (lane == 0) && (wave == 0 || wave == 4);
-#define WS_STAMP() do { if (dbg_on && dbg_n < 64) dbg[dbg_n++] = clock64(); } while (0)
-#else
-#define WS_STAMP() do {} while (0)
-#endif
     if (wave < 4) {
         // =================================== matrix waves ===========================================
-#ifndef PFNL_WS_MPRIO
-#define PFNL_WS_MPRIO 0
-#endif
-#ifndef PFNL_WS_HPRIO
-#define PFNL_WS_HPRIO 3
-#endif
-        __builtin_amdgcn_s_setprio(PFNL_WS_MPRIO);
         const int xi = wave;
         const int tx = lane & 15;
         const int ty = (lane >> 4) & 1;
@@ -95,17 +87,15 @@ __global__ __launch_bounds__(WS_THREADS, 2) void conv_wino_ws_kernel(WinoParams 
         constexpr int UP_CHUNK_F4 = 4 * 2 * 8 * KS_F4;
         const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(p.upack), 0, (int)(wino_pack_floats_c * sizeof(float)), 0x00020000);
-        const int uvoff = (((xi * 2 + ng) * 8) * KS_F4 + lane) * 16;
-#define WS_USTEP(s_) \
-    __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, uvoff, ((((s_) & 31) >> 3) * UP_CHUNK_F4 + ((s_) & 7) * KS_F4) * 16, 0))
-        f32x4 ring[WN_UDEPTH];
+        const int uvoff = ((xi * 2 * 8) * KS_F4 + lane) * 16;
+#define WS_USTEP(s_, g_) \
+    __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, uvoff, ((((s_) & 31) >> 3) * UP_CHUNK_F4 + ((g_) * 8 + ((s_) & 7)) * KS_F4) * 16, 0))
+        f32x4 ring0[WS_UD], ring1[WS_UD];
 #pragma unroll
-        for (int d = 0; d < WN_UDEPTH; ++d) ring[d] = WS_USTEP(d);
-#ifdef PFNL_WS_NO_U     /* timing experiment only: wrong results */
-#define WS_RING_REFILL(s_) do {} while (0)
-#else
-#define WS_RING_REFILL(s_) ring[(s_) % WN_UDEPTH] = WS_USTEP((s_) + WN_UDEPTH)
-#endif
+        for (int d = 0; d < WS_UD; ++d) {
+            ring0[d] = WS_USTEP(d, 0);
+            ring1[d] = WS_USTEP(d, 1);
+        }
 
         const int rowA = (xi == 0) ? 0 : 1;
         const int rowB = (xi == 3) ? 3 : 2;
@@ -116,95 +106,92 @@ __global__ __launch_bounds__(WS_THREADS, 2) void conv_wino_ws_kernel(WinoParams 
         const int lane_b = kh * WP_PS + (2 * ty + rowB) * WP_RP + 2 * tx;
         const unsigned pa = lds0 + (unsigned)lane_a * 4u;
         const unsigned pb = lds0 + (unsigned)lane_b * 4u;
-        float* const slab = slabm + xi * (2 * 32 * WN_ES);
+        float* const slab = slabm + xi * WS_SLAB_XI;
 
-        f32x16 acc[4];
-#define WS_VFIRST(q_, v03_, v12_)                                                                \
+        f32x16 acc[8];                                              // [N-tile g][nu]
+        f32x2 vA, vB, vC, vD;                                       // (V0,V3), (V1,V2): current / next step
+
+        // step s: 8 MFMAs on V_s; raw values of step s+1 read from buffer ((s+1)>>3)&1 and transformed
+#define WS_STEP(s_, c03_, c12_, n03_, n12_)                                                      \
     do {                                                                                         \
-        const f32x2* cA_ = reinterpret_cast<const f32x2*>(smem + ((q_) & 1) * WP_BUF + lane_a);   \
-        const f32x2* cB_ = reinterpret_cast<const f32x2*>(smem + ((q_) & 1) * WP_BUF + lane_b);   \
-        const f32x2 t01_ = cA_[0] + sg2 * cB_[0];                                                \
-        const f32x2 t23_ = cA_[1] + sg2 * cB_[1];                                                \
-        (v03_) = t01_ - t23_;                                    /* (t0 - t2, t1 - t3) */        \
-        (v12_).x = t01_.y + t23_.x;                                                              \
-        (v12_).y = t23_.x - t01_.y;                                                              \
-    } while (0)
-#define WS_KSTEP(q_, kk_, c03_, c12_, n03_, n12_)                                                \
-    do {                                                                                         \
-        constexpr int s_ = (q_) * (WN_CK / 2) + (kk_);                                           \
-        const f32x4 bc_ = ring[s_ % WN_UDEPTH];                                                  \
-        WS_RING_REFILL(s_);                                     /* wraps into the next unit */   \
-        constexpr int off_ = (((q_) & 1) * WP_BUF + 2 * ((kk_) + 1) * WP_PS) * 4;                \
-        if ((q_) == 0 && (kk_) == 0) {                                                           \
-            wp_kstep_asm_zero<off_>(acc[0], acc[1], acc[2], acc[3], (c03_).x, (c12_).x, (c12_).y, (c03_).y, n03_, \
-                                    n12_, bc_, pa, pb, sg2);                                     \
-        } else if ((kk_) + 1 < WN_CK / 2) {                                                      \
-            wp_kstep_asm<off_>(acc[0], acc[1], acc[2], acc[3], (c03_).x, (c12_).x, (c12_).y, (c03_).y, n03_, n12_, \
-                               bc_, pa, pb, sg2);                                                \
-        } else {                                                                                 \
-            acc[0] = mfma32((c03_).x, bc_.x, acc[0]);                                            \
-            acc[1] = mfma32((c12_).x, bc_.y, acc[1]);                                            \
-            acc[2] = mfma32((c12_).y, bc_.z, acc[2]);                                            \
-            acc[3] = mfma32((c03_).y, bc_.w, acc[3]);                                            \
-        }                                                                                        \
+        constexpr int d_ = (s_) % WS_UD;                                                         \
+        const f32x4 b0_ = ring0[d_], b1_ = ring1[d_];                                            \
+        ring0[d_] = WS_USTEP((s_) + WS_UD, 0);                  /* wraps into the next tile */   \
+        ring1[d_] = WS_USTEP((s_) + WS_UD, 1);                                                   \
+        constexpr int n_ = ((s_) + 1) & 31;                                                      \
+        constexpr int off_ = (((n_ >> 3) & 1) * WP_BUF + 2 * (n_ & 7) * WP_PS) * 4;              \
+        f32x2 x01_, y01_, x23_, y23_;                                                            \
+        wq_kstep_a<off_, (s_) == 0>(acc[0], acc[1], acc[2], acc[3], (c03_).x, (c12_).x, (c12_).y, (c03_).y, b0_, \
+                                    x01_, y01_, x23_, y23_, pa, pb);                             \
+        wq_kstep_b<(s_) == 0>(acc[4], acc[5], acc[6], acc[7], (c03_).x, (c12_).x, (c12_).y, (c03_).y, b1_, x01_, \
+                              y01_, x23_, y23_, n03_, n12_, sg2);                                \
         __builtin_amdgcn_sched_barrier(0);                                                       \
     } while (0)
-#define WS_MCHUNK(q_)                                                                            \
-    do {                                                                                         \
-        f32x2 pA_, pB_, pC_, pD_;                               /* (V0,V3) and (V1,V2), two sets */ \
-        WS_VFIRST(q_, pA_, pB_);                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-        WS_KSTEP(q_, 0, pA_, pB_, pC_, pD_); WS_KSTEP(q_, 1, pC_, pD_, pA_, pB_);                \
-        WS_KSTEP(q_, 2, pA_, pB_, pC_, pD_); WS_KSTEP(q_, 3, pC_, pD_, pA_, pB_);                \
-        WS_KSTEP(q_, 4, pA_, pB_, pC_, pD_); WS_KSTEP(q_, 5, pC_, pD_, pA_, pB_);                \
-        WS_KSTEP(q_, 6, pA_, pB_, pC_, pD_); WS_KSTEP(q_, 7, pC_, pD_, pA_, pB_);                \
-    } while (0)
-        static_assert(WN_CK == 16 && WN_NCHUNK == 4, "written out for 8 K-steps x 4 chunks");
+#define WS_STEP2(s_)                       \
+    WS_STEP(s_, vA, vB, vC, vD);           \
+    WS_STEP((s_) + 1, vC, vD, vA, vB)
 
-        WS_STAMP();
-        __syncthreads();                                            // B0: chunk 0 of the first unit is in LDS
+        __syncthreads();                                            // chunk 0 of the first tile is in LDS
+        {   // V of the very first K-step (every later one comes out of the asm step before it)
+            const f32x2* cA = reinterpret_cast<const f32x2*>(smem + lane_a);
+            const f32x2* cB = reinterpret_cast<const f32x2*>(smem + lane_b);
+            const f32x2 t01 = cA[0] + sg2 * cB[0];
+            const f32x2 t23 = cA[1] + sg2 * cB[1];
+            vA = t01 - t23;
+            vB.x = t01.y + t23.x;
+            vB.y = t23.x - t01.y;
+            asm volatile("s_nop 4" ::: "memory");                   // VALU write -> MFMA read inside the asm block
+        }
         for (int i = 0; i < nu; ++i) {
-            WS_STAMP();
-            WS_MCHUNK(0);
-            WS_STAMP();
+            WS_STEP2(0);
+            WS_STEP2(2);
+            WS_STEP2(4);
+            WS_STEP(6, vA, vB, vC, vD);
+            __syncthreads();                                        // chunk 1 ready / chunk 0's buffer free
+            WS_STEP(7, vC, vD, vA, vB);
+            WS_STEP2(8);
+            WS_STEP2(10);
+            WS_STEP2(12);
+            WS_STEP(14, vA, vB, vC, vD);
             __syncthreads();
-            WS_STAMP();
-            WS_MCHUNK(1);
-            WS_STAMP();
+            WS_STEP(15, vC, vD, vA, vB);
+            WS_STEP2(16);
+            WS_STEP2(18);
+            WS_STEP2(20);
+            WS_STEP(22, vA, vB, vC, vD);
             __syncthreads();
-            WS_STAMP();
-            WS_MCHUNK(2);
-            WS_STAMP();
-            __syncthreads();
-            WS_STAMP();
-            WS_MCHUNK(3);
-            WS_STAMP();
-            // column transform over nu in registers (At = [[1,1,1,0],[0,1,-1,-1]]) -> slab[xi][j][tile][cout]
-            {
-                const f32x16 s0 = acc[0] + acc[1] + acc[2];     // whole-vector form: packed-f32 adds
-                const f32x16 s1 = acc[1] - acc[2] - acc[3];
+            WS_STEP(23, vC, vD, vA, vB);
+            WS_STEP2(24);
+            WS_STEP2(26);
+            WS_STEP2(28);
+            WS_STEP(30, vA, vB, vC, vD);
+            __syncthreads();                                        // next tile's chunk 0 ready
+            WS_STEP(31, vC, vD, vA, vB);
+            // column transform over nu (At = [[1,1,1,0],[0,1,-1,-1]]) -> slab[xi][j][tile][cout]
+            asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");       // MFMA results of the asm blocks -> VALU reads
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x16 s0 = acc[4 * g] + acc[4 * g + 1] + acc[4 * g + 2];
+                const f32x16 s1 = acc[4 * g + 1] - acc[4 * g + 2] - acc[4 * g + 3];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int etile = drow(r, lane);
-                    slab[(0 * 32 + etile) * WN_ES + xl] = s0[r];
-                    slab[(1 * 32 + etile) * WN_ES + xl] = s1[r];
+                    slab[(0 * 32 + etile) * WS_ES + g * 32 + xl] = s0[r];
+                    slab[(1 * 32 + etile) * WS_ES + g * 32 + xl] = s1[r];
                 }
             }
-            WS_STAMP();
-            __syncthreads();
         }
-#undef WS_MCHUNK
-#undef WS_KSTEP
-#undef WS_VFIRST
+        __syncthreads();                                            // the last tile's slab is complete
+#undef WS_STEP2
+#undef WS_STEP
 #undef WS_USTEP
         return;
     }
 
     // ====================================== helper waves =============================================
-    // The helpers issue few instructions but every one of them is on the barrier-critical path; at
-    // equal or lower priority they only got an issue slot about once per MFMA (measured: 16 LDS stores
-    // + selects took ~4.5k cycles), so they run at the highest priority.
-    __builtin_amdgcn_s_setprio(PFNL_WS_HPRIO);
+    // Few instructions, but every one is on the barrier-critical path and only gets an issue slot when the
+    // matrix wave of its SIMD leaves one: highest priority.
+    __builtin_amdgcn_s_setprio(3);
     const int ht = tid - 4 * 64;                                    // 0..255
     // unit-independent part of the staging descriptors
     int loff[WN_IN_ITERS], pyx[WN_IN_ITERS];
@@ -222,12 +209,12 @@ __global__ __launch_bounds__(WS_THREADS, 2) void conv_wino_ws_kernel(WinoParams 
             pyx[i] = (py << 16) | (px << 4) | (c4 * 4);
         }
     }
-    // descriptors of the unit whose chunks are being loaded: one buffer resource per item (its range
-    // check returns 0 for the voffset of halo pixels outside the image: no selects, no masks) and a
-    // byte offset per staged piece; the chunk's channel offset goes in the scalar offset.
-    int goff[WN_IN_ITERS];
-    __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, 0, 0x00020000);
+    // descriptors of the tile whose chunks are being loaded: one buffer resource per item (its range
+    // check returns 0 for the voffset given to halo pixels outside the image) and a byte offset per
+    // staged piece; the chunk's channel offset goes in the scalar offset.
     const int item_bytes = H * W * 64 * (int)sizeof(float);
+    int goff[WN_IN_ITERS];
+    __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, item_bytes, 0x00020000);
 #define WS_DESC(i_)                                                                              \
     do {                                                                                         \
         int item_, y0_, x0_;                                                                     \
@@ -236,140 +223,150 @@ __global__ __launch_bounds__(WS_THREADS, 2) void conv_wino_ws_kernel(WinoParams 
                                                 0x00020000);                                     \
         _Pragma("unroll") for (int k_ = 0; k_ < WN_IN_ITERS; ++k_) {                             \
             const int gy_ = y0_ + (pyx[k_] >> 16) - 1, gx_ = x0_ + ((pyx[k_] >> 4) & 0xfff) - 1; \
-            const bool in_ = gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W;                         \
+            const bool in_ = (unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W;         \
             goff[k_] = in_ ? ((gy_ * W + gx_) * 64 + (pyx[k_] & 15)) * 4 : 0x7fffffff;           \
         }                                                                                        \
     } while (0)
-    f32x4 rin0[WN_IN_ITERS], rin1[WN_IN_ITERS];
-#ifdef PFNL_WS_NO_HALO  /* timing experiment only: wrong results */
-#define WS_LOAD(q_, rin) do {} while (0)
-#else
-#define WS_LOAD(q_, rin)                                                                         \
+    f32x4 rin[WN_NCHUNK][WN_IN_ITERS];                              // one register set per chunk index
+#define WS_LOAD(q_)                                                                              \
     do {                                                                                         \
         _Pragma("unroll") for (int k_ = 0; k_ < WN_IN_ITERS; ++k_)                               \
-            rin[k_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsL, goff[k_], (q_) * WN_CK * 4, 0)); \
+            rin[q_][k_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsL, goff[k_], (q_) * WN_CK * 4, 0)); \
     } while (0)
-#endif
-#define WS_STORE(buf_, rin)                                                                      \
+#define WS_STORE(q_)                                                                             \
     do {                                                                                         \
         _Pragma("unroll") for (int k_ = 0; k_ < WN_IN_ITERS; ++k_) {                             \
             if ((stmask >> k_) & 1u) {                                                           \
-                float* d_ = smem + (buf_) * WP_BUF + loff[k_];                                   \
-                d_[0] = rin[k_].x;                                                               \
-                d_[WP_PS] = rin[k_].y;                                                           \
-                d_[2 * WP_PS] = rin[k_].z;                                                       \
-                d_[3 * WP_PS] = rin[k_].w;                                                       \
+                float* d_ = smem + ((q_) & 1) * WP_BUF + loff[k_];                               \
+                d_[0] = rin[q_][k_].x;                                                           \
+                d_[WP_PS] = rin[q_][k_].y;                                                       \
+                d_[2 * WP_PS] = rin[q_][k_].z;                                                   \
+                d_[3 * WP_PS] = rin[q_][k_].w;                                                   \
             }                                                                                    \
         }                                                                                        \
     } while (0)
 
-    // epilogue state: E = the unit whose addend/residual loads are in flight / whose slab is read
-    const int c4 = ht & 7;
-    const int cbase = ng * 32 + c4 * 4;
-    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + cbase);
+    // epilogue state: E = the tile whose addend / residual loads are in flight and whose slab is read.
+    // Item id = k*256 + ht -> channel quad c4 (16), column parity jj, Winograd tile et (32); two output rows.
+    const int c4 = ht & 15;
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + c4 * 4);
     const float slope = p.act ? 0.2f : 1.0f;
-    int e_item = 0, e_y0 = 0, e_x0 = 0;
-    f32x4 av[2][2], rv[2][2];
+    int e_y0 = 0, e_x0 = 0;
+    __amdgpu_buffer_rsrc_t rsOut = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, item_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsRes = rsOut, rsAdd = rsOut;
+    f32x4 av[4][2], rv[4][2];
+#define WS_EPI_UNIT(i_)                                                                          \
+    do {                                                                                         \
+        int item_;                                                                               \
+        WS_UNIT(i_, item_, e_y0, e_x0);                                                          \
+        rsOut = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)item_ * H * W * 64, 0, item_bytes, 0x00020000); \
+        if (FUSE) {                                                                              \
+            rsRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid) + (size_t)item_ * H * W * 64, 0, \
+                                                      item_bytes, 0x00020000);                   \
+            rsAdd = __builtin_amdgcn_make_buffer_rsrc(                                           \
+                const_cast<float*>(p.addend) + (size_t)(item_ / p.add_div) * H * W * 64, 0, item_bytes, 0x00020000); \
+        }                                                                                        \
+    } while (0)
+    // byte offset of (row r_ of item k_) inside the item, or out of range for pixels outside the image
+#define WS_EPI_OFF(k_, r_, off_)                                                                 \
+    do {                                                                                         \
+        const int id_ = (k_) * 256 + ht;                                                         \
+        const int et_ = id_ >> 5;                                                                \
+        const int ox_ = e_x0 + 2 * (et_ & 15) + ((id_ >> 4) & 1);                                \
+        const int oy_ = e_y0 + 2 * (et_ >> 4) + (r_);                                            \
+        off_ = (ox_ < W && oy_ < H) ? ((oy_ * W + ox_) * 64 + c4 * 4) * 4 : 0x7fffffff;          \
+    } while (0)
 #define WS_EPI_LOAD(k_)                                                                          \
     do {                                                                                         \
         if (FUSE) {                                                                              \
-            const int id_ = (k_) * 256 + ht;                                                     \
-            const int j_ = (id_ >> 3) & 1, et_ = id_ >> 4;                                       \
-            const int ox_ = min(e_x0 + 2 * (et_ & 15) + j_, W - 1);                              \
-            const int ai_ = e_item / p.add_div;                                                  \
             _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                                   \
-                const int yc_ = min(e_y0 + 2 * (et_ >> 4) + r_, H - 1);                          \
-                av[k_][r_] = *reinterpret_cast<const f32x4*>(p.addend + (((size_t)ai_ * H + yc_) * W + ox_) * 64 + cbase); \
-                rv[k_][r_] = *reinterpret_cast<const f32x4*>(p.resid + (((size_t)e_item * H + yc_) * W + ox_) * 64 + cbase); \
+                int off_;                                                                        \
+                WS_EPI_OFF(k_, r_, off_);                                                        \
+                av[k_][r_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAdd, off_, 0, 0)); \
+                rv[k_][r_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsRes, off_, 0, 0)); \
             }                                                                                    \
         }                                                                                        \
     } while (0)
 #define WS_EPI(k_)                                                                               \
     do {                                                                                         \
         const int id_ = (k_) * 256 + ht;                                                         \
-        const int j_ = (id_ >> 3) & 1, et_ = id_ >> 4;                                           \
-        const int oy_ = e_y0 + 2 * (et_ >> 4);                                                   \
-        const int ox_ = e_x0 + 2 * (et_ & 15) + j_;                                              \
-        const float* sp_ = slabm + (j_ * 32 + et_) * WN_ES + c4 * 4;                             \
+        const float* sp_ = slabm + (((id_ >> 4) & 1) * 32 + (id_ >> 5)) * WS_ES + c4 * 4;        \
         const f32x4 r0_ = *reinterpret_cast<const f32x4*>(sp_);                                  \
-        const f32x4 r1_ = *reinterpret_cast<const f32x4*>(sp_ + 1 * 2 * 32 * WN_ES);             \
-        const f32x4 r2_ = *reinterpret_cast<const f32x4*>(sp_ + 2 * 2 * 32 * WN_ES);             \
-        const f32x4 r3_ = *reinterpret_cast<const f32x4*>(sp_ + 3 * 2 * 32 * WN_ES);             \
+        const f32x4 r1_ = *reinterpret_cast<const f32x4*>(sp_ + 1 * WS_SLAB_XI);                 \
+        const f32x4 r2_ = *reinterpret_cast<const f32x4*>(sp_ + 2 * WS_SLAB_XI);                 \
+        const f32x4 r3_ = *reinterpret_cast<const f32x4*>(sp_ + 3 * WS_SLAB_XI);                 \
         f32x4 yv_[2];                                                                            \
-        yv_[0] = r0_ + r1_ + r2_;                                                                \
-        yv_[1] = r1_ - r2_ - r3_;                                                                \
+        yv_[0] = r0_ + r1_ + r2_;                               /* row transform over xi */      \
+        yv_[1] = r1_ - (r2_ + r3_);                                                              \
         _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                                       \
-            const int y_ = oy_ + r_;                                                             \
+            int off_;                                                                            \
+            WS_EPI_OFF(k_, r_, off_);                                                            \
             f32x4 o_ = yv_[r_] + bias4;                                                          \
             if (FUSE) o_ += av[k_][r_];                                                          \
-            o_.x = fmaxf(o_.x, slope * o_.x);                                                    \
-            o_.y = fmaxf(o_.y, slope * o_.y);                                                    \
-            o_.z = fmaxf(o_.z, slope * o_.z);                                                    \
-            o_.w = fmaxf(o_.w, slope * o_.w);                                                    \
+            const f32x4 so_ = o_ * slope;                                                        \
+            o_.x = fmaxf(o_.x, so_.x);                                                           \
+            o_.y = fmaxf(o_.y, so_.y);                                                           \
+            o_.z = fmaxf(o_.z, so_.z);                                                           \
+            o_.w = fmaxf(o_.w, so_.w);                                                           \
             if (FUSE) o_ += rv[k_][r_];                                                          \
-            if (ox_ < W && y_ < H)                                                               \
-                *reinterpret_cast<f32x4*>(p.out + (((size_t)e_item * H + y_) * W + ox_) * 64 + cbase) = o_; \
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o_), rsOut, off_, 0, 0); \
         }                                                                                        \
     } while (0)
 
-#ifdef PFNL_WS_NO_EPI   /* timing experiment only: wrong results */
-#undef WS_EPI
-#undef WS_EPI_LOAD
-#define WS_EPI(k_) do {} while (0)
-#define WS_EPI_LOAD(k_) do {} while (0)
-#endif
-    // prologue: chunks 0,1 of unit 0 requested; chunk 0 stored; chunk 2 requested
+    // prologue: all four chunks of tile 0 requested; chunk 0 stored; chunk 0 of tile 1 requested
     WS_DESC(0);
-    WS_LOAD(0, rin0);
-    WS_LOAD(1, rin1);
-    WS_STORE(0, rin0);
-    WS_LOAD(2, rin0);
-    WS_STAMP();
-    __syncthreads();                                                // B0
+    WS_LOAD(0);
+    WS_LOAD(1);
+    WS_LOAD(2);
+    WS_LOAD(3);
+    WS_STORE(0);
+    WS_DESC(min(1, nu - 1));                                        // past the end: harmless re-read of the last tile
+    WS_LOAD(0);
+    __syncthreads();
     for (int i = 0; i < nu; ++i) {
-        WS_STAMP();
-        // phase 0: chunk 1 -> buffer 1; request chunk 3; first half of the previous unit's epilogue
-#ifdef PFNL_WINO_TIMING
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        WS_STAMP();
-#endif
-        WS_STORE(1, rin1);
-        WS_STAMP();
-        WS_LOAD(3, rin1);
-        WS_STAMP();
-        if (i > 0) WS_EPI(0);
-        WS_STAMP();
+        // phase 0: chunk 1 -> buffer 1; request chunk 1 of the next tile; rest of the previous tile's addend / residual
+        WS_STORE(1);
+        WS_LOAD(1);
+        if (i > 0) {
+            WS_EPI_LOAD(2);
+            WS_EPI_LOAD(3);
+        }
+        __syncthreads();                                            // the matrix waves have filled the slab (tile i-1)
+        // phase 1: chunk 2 -> buffer 0; half of the previous tile's epilogue
+        WS_STORE(2);
+        WS_LOAD(2);
+        if (i > 0) {
+            WS_EPI(0);
+            WS_EPI(1);
+        }
         __syncthreads();
-        WS_STAMP();
-        // phase 1: chunk 2 -> buffer 0; request chunk 0 of the next unit; second half of that epilogue
-        WS_STORE(0, rin0);
-        WS_STAMP();
-        WS_DESC(min(i + 1, nu - 1));                                // past the end: harmless re-read of the last unit
-        WS_LOAD(0, rin0);
-        WS_STAMP();
-        if (i > 0) WS_EPI(1);
-        WS_STAMP();
+        // phase 2: chunk 3 -> buffer 1
+        WS_STORE(3);
+        WS_LOAD(3);
+        if (i > 0) WS_EPI(2);
         __syncthreads();
-        WS_STAMP();
-        // phase 2: chunk 3 -> buffer 1; request chunk 1 of the next unit; addend / residual of THIS unit, first half
-        WS_STORE(1, rin1);
-        WS_LOAD(1, rin1);
-        WS_UNIT(i, e_item, e_y0, e_x0);
+        // phase 3: next tile's chunk 0 -> buffer 0; request chunk 0 of the tile after; last quarter of the
+        // epilogue, then the addend / residual of THIS tile (first half)
+        WS_STORE(0);
+        WS_DESC(min(i + 2, nu - 1));
+        WS_LOAD(0);
+        if (i > 0) WS_EPI(3);
+        WS_EPI_UNIT(i);
         WS_EPI_LOAD(0);
-        WS_STAMP();
-        __syncthreads();
-        WS_STAMP();
-        // phase 3: next unit's chunk 0 -> buffer 0; request its chunk 2; second half of the addend / residual loads
-        WS_STORE(0, rin0);
-        WS_LOAD(2, rin0);
         WS_EPI_LOAD(1);
-        WS_STAMP();
-        __syncthreads();                                            // the matrix waves have filled the slab
+        __syncthreads();
     }
+    WS_EPI_LOAD(2);
+    WS_EPI_LOAD(3);
+    __syncthreads();                                                // the last tile's slab is complete
     WS_EPI(0);
     WS_EPI(1);
+    WS_EPI(2);
+    WS_EPI(3);
 #undef WS_EPI
 #undef WS_EPI_LOAD
+#undef WS_EPI_OFF
+#undef WS_EPI_UNIT
 #undef WS_STORE
 #undef WS_LOAD
 #undef WS_DESC
@@ -397,9 +394,10 @@ hipError_t launch_conv_wino_ws(const WinoParams& p, hipStream_t s) {
     const bool fuse = p.addend != nullptr || p.resid != nullptr;
     if (fuse && (!p.addend || !p.resid || p.add_div < 1)) return hipErrorInvalidValue;
     if ((p.H & 1) || (p.W & 1)) return hipErrorInvalidValue;
+    if ((long long)p.H * p.W * 256 >= 0x7fffffffLL) return hipErrorInvalidValue;   // 32-bit buffer offsets per item
     const int ntiles = ((p.W + 2 * WN_TX - 1) / (2 * WN_TX)) * ((p.H + 2 * WN_TY - 1) / (2 * WN_TY)) * p.items;
     const int rs = (ntiles + 7) / 8;
-    const int wpx = 2 * rs < WS_MAX_WG_PER_XCD ? 2 * rs : WS_MAX_WG_PER_XCD;    // even
+    const int wpx = rs < WS_MAX_WG_PER_XCD ? rs : WS_MAX_WG_PER_XCD;
     return fuse ? launch_ws_variant<true>(p, 8 * wpx, s) : launch_ws_variant<false>(p, 8 * wpx, s);
 }
 

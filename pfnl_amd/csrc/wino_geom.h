@@ -173,4 +173,69 @@ __device__ __forceinline__ void wp_kstep_asm_zero(f32x16& a0, f32x16& a1, f32x16
           [bw] "v"(bc.w), [pa] "v"(pa), [pb] "v"(pb), [sg] "v"(sg), [o0] "i"(OFF), [o2] "i"(OFF + 8)
         : "memory");
 }
+
+// ---- 8-MFMA K-step (both 32-channel N-tiles per wave): two asm blocks, 4 LDS + 4 packed VALU per 8 MFMAs
+// block A: N-tile 0's four MFMAs + the raw reads of the NEXT step;  block B: N-tile 1's four MFMAs with
+// the transform of the next step's V between them.  ZERO: first step of a tile, C = 0.
+#define PFNL_WQ_A(C0, C1, C2, C3)                                                                       \
+    asm volatile("v_mfma_f32_32x32x2_f32 %[a0], %[c0], %[bx], " C0 "\n\t"                               \
+                 "ds_read_b64 %[x01], %[pa] offset:%c[o0]\n\t"                                          \
+                 "ds_read_b64 %[y01], %[pb] offset:%c[o0]\n\t"                                          \
+                 "ds_read_b64 %[x23], %[pa] offset:%c[o2]\n\t"                                          \
+                 "ds_read_b64 %[y23], %[pb] offset:%c[o2]\n\t"                                          \
+                 "v_mfma_f32_32x32x2_f32 %[a1], %[c1], %[by], " C1 "\n\t"                               \
+                 "v_mfma_f32_32x32x2_f32 %[a2], %[c2], %[bz], " C2 "\n\t"                               \
+                 "v_mfma_f32_32x32x2_f32 %[a3], %[c3], %[bw], " C3 "\n\t"
+#define PFNL_WQ_A_IN                                                                                    \
+    [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [bx] "v"(bc.x), [by] "v"(bc.y), [bz] "v"(bc.z), \
+        [bw] "v"(bc.w), [pa] "v"(pa), [pb] "v"(pb), [o0] "i"(OFF), [o2] "i"(OFF + 8)
+template <int OFF, bool ZERO>
+__device__ __forceinline__ void wq_kstep_a(f32x16& a0, f32x16& a1, f32x16& a2, f32x16& a3, const float c0, const float c1,
+                                           const float c2, const float c3, const f32x4 bc, f32x2& x01, f32x2& y01,
+                                           f32x2& x23, f32x2& y23, unsigned pa, unsigned pb) {
+    if constexpr (ZERO) {
+        PFNL_WQ_A("0", "0", "0", "0")
+                     : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [x01] "=&v"(x01), [y01] "=&v"(y01),
+                       [x23] "=&v"(x23), [y23] "=&v"(y23)
+                     : PFNL_WQ_A_IN
+                     : "memory");
+    } else {
+        PFNL_WQ_A("%[a0]", "%[a1]", "%[a2]", "%[a3]")
+                     : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [x01] "=&v"(x01), [y01] "=&v"(y01),
+                       [x23] "=&v"(x23), [y23] "=&v"(y23)
+                     : PFNL_WQ_A_IN
+                     : "memory");
+    }
+}
+#define PFNL_WQ_B(C0, C1, C2, C3)                                                                       \
+    asm volatile("v_mfma_f32_32x32x2_f32 %[a0], %[c0], %[bx], " C0 "\n\t"                               \
+                 "v_mfma_f32_32x32x2_f32 %[a1], %[c1], %[by], " C1 "\n\t"                               \
+                 "s_waitcnt lgkmcnt(0)\n\t"                                                             \
+                 "v_pk_fma_f32 %[x01], %[y01], %[sg], %[x01]\n\t"                                       \
+                 "v_pk_fma_f32 %[x23], %[y23], %[sg], %[x23]\n\t"                                       \
+                 "v_pk_add_f32 %[n03], %[x01], %[x23] neg_lo:[0,1] neg_hi:[0,1]\n\t"                    \
+                 "v_pk_add_f32 %[n12], %[x01], %[x23] op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"    \
+                 "v_mfma_f32_32x32x2_f32 %[a2], %[c2], %[bz], " C2 "\n\t"                               \
+                 "v_mfma_f32_32x32x2_f32 %[a3], %[c3], %[bw], " C3 "\n\t"
+#define PFNL_WQ_B_IN                                                                                    \
+    [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [bx] "v"(bc.x), [by] "v"(bc.y), [bz] "v"(bc.z), \
+        [bw] "v"(bc.w), [y01] "v"(y01), [y23] "v"(y23), [sg] "v"(sg)
+template <bool ZERO>
+__device__ __forceinline__ void wq_kstep_b(f32x16& a0, f32x16& a1, f32x16& a2, f32x16& a3, const float c0, const float c1,
+                                           const float c2, const float c3, const f32x4 bc, f32x2& x01, const f32x2 y01,
+                                           f32x2& x23, const f32x2 y23, f32x2& n03, f32x2& n12, const f32x2 sg) {
+    if constexpr (ZERO) {
+        PFNL_WQ_B("0", "0", "0", "0")
+                     : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [x01] "+v"(x01), [x23] "+v"(x23),
+                       [n03] "=&v"(n03), [n12] "=&v"(n12)
+                     : PFNL_WQ_B_IN
+                     : "memory");
+    } else {
+        PFNL_WQ_B("%[a0]", "%[a1]", "%[a2]", "%[a3]")
+                     : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [x01] "+v"(x01), [x23] "+v"(x23),
+                       [n03] "=&v"(n03), [n12] "=&v"(n12)
+                     : PFNL_WQ_B_IN
+                     : "memory");
+    }
+}
 }  // namespace pfnl
