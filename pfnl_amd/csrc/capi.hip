@@ -682,7 +682,7 @@ static int op_conv3x3_wino(bool ws, const float* in, const float* kernel_host, c
             std::vector<long long> hst(dbg_n);
             (void)hipMemcpy(hst.data(), dbg, dbg_n * sizeof(long long), hipMemcpyDeviceToHost);
             if (ws) {
-                for (int b : {0, 8, 101, 300, 511})
+                for (int b : {0, 8, 101, 200, 255})
                     for (int role = 0; role < 2; ++role) {
                         const long long* t = &hst[(size_t)b * 128 + role * 64];
                         std::fprintf(stderr, "WS_TIMING wg %d %s:", b, role ? "helper" : "matrix");

@@ -37,7 +37,7 @@ constexpr int WS_SLAB_XI = 2 * 32 * WS_ES;                                 // fl
 constexpr int WS_LDS_FLOATS = WS_RAW_FLOATS + 4 * WS_SLAB_XI;
 constexpr size_t WS_LDS_BYTES = size_t(WS_LDS_FLOATS) * sizeof(float);     // 100 608 B
 constexpr int WS_MAX_WG_PER_XCD = 32;                                      // one workgroup per CU
-constexpr int WS_UD = 4;                                                   // K-steps of U in flight (divides 32)
+constexpr int WS_UD = 8;                                                   // K-steps of U in flight (divides 32)
 static_assert((WS_RAW_FLOATS * sizeof(float)) % 16 == 0, "slab must stay 16-byte aligned");
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -75,6 +75,14 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
         x0_ = (rem_ - by_ * tiles_x) * (2 * WN_TX);                   \
     } while (0)
 
+#ifdef PFNL_WINO_TIMING
+    long long* dbg = p.dbg ? p.dbg + (size_t)blockIdx.x * 128 + (wave < 4 ? 0 : 64) : nullptr;
+    int dbg_n = 0;
+    const bool dbg_on = dbg && (lane == 0) && (wave == 0 || wave == 4);
+#define WS_STAMP() do { if (dbg_on && dbg_n < 64) dbg[dbg_n++] = clock64(); } while (0)
+#else
+#define WS_STAMP() do {} while (0)
+#endif
     if (wave < 4) {
         // =================================== matrix waves ===========================================
         const int xi = wave;
@@ -147,39 +155,53 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
             WS_STEP2(2);
             WS_STEP2(4);
             WS_STEP(6, vA, vB, vC, vD);
+            WS_STAMP();
             __syncthreads();                                        // chunk 1 ready / chunk 0's buffer free
+            WS_STAMP();
             WS_STEP(7, vC, vD, vA, vB);
             WS_STEP2(8);
             WS_STEP2(10);
             WS_STEP2(12);
             WS_STEP(14, vA, vB, vC, vD);
+            WS_STAMP();
             __syncthreads();
+            WS_STAMP();
             WS_STEP(15, vC, vD, vA, vB);
             WS_STEP2(16);
             WS_STEP2(18);
             WS_STEP2(20);
             WS_STEP(22, vA, vB, vC, vD);
+            WS_STAMP();
             __syncthreads();
+            WS_STAMP();
             WS_STEP(23, vC, vD, vA, vB);
             WS_STEP2(24);
             WS_STEP2(26);
             WS_STEP2(28);
             WS_STEP(30, vA, vB, vC, vD);
+            WS_STAMP();
             __syncthreads();                                        // next tile's chunk 0 ready
+            WS_STAMP();
             WS_STEP(31, vC, vD, vA, vB);
+            WS_STAMP();
             // column transform over nu (At = [[1,1,1,0],[0,1,-1,-1]]) -> slab[xi][j][tile][cout]
             asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");       // MFMA results of the asm blocks -> VALU reads
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                const f32x16 s0 = acc[4 * g] + acc[4 * g + 1] + acc[4 * g + 2];
-                const f32x16 s1 = acc[4 * g + 1] - acc[4 * g + 2] - acc[4 * g + 3];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int etile = drow(r, lane);
-                    slab[(0 * 32 + etile) * WS_ES + g * 32 + xl] = s0[r];
-                    slab[(1 * 32 + etile) * WS_ES + g * 32 + xl] = s1[r];
+                for (int r = 0; r < 16; r += 2) {               // register pairs: packed-f32 adds
+                    const f32x2 m0 = {acc[4 * g][r], acc[4 * g][r + 1]}, m1 = {acc[4 * g + 1][r], acc[4 * g + 1][r + 1]};
+                    const f32x2 m2 = {acc[4 * g + 2][r], acc[4 * g + 2][r + 1]}, m3 = {acc[4 * g + 3][r], acc[4 * g + 3][r + 1]};
+                    const f32x2 s0 = m0 + m1 + m2;
+                    const f32x2 s1 = m1 - (m2 + m3);
+                    const int e0 = drow(r, lane), e1 = drow(r + 1, lane);
+                    slab[(0 * 32 + e0) * WS_ES + g * 32 + xl] = s0.x;
+                    slab[(1 * 32 + e0) * WS_ES + g * 32 + xl] = s1.x;
+                    slab[(0 * 32 + e1) * WS_ES + g * 32 + xl] = s0.y;
+                    slab[(1 * 32 + e1) * WS_ES + g * 32 + xl] = s1.y;
                 }
             }
+            WS_STAMP();
         }
         __syncthreads();                                            // the last tile's slab is complete
 #undef WS_STEP2
@@ -209,23 +231,38 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
             pyx[i] = (py << 16) | (px << 4) | (c4 * 4);
         }
     }
+    int relk[WN_IN_ITERS];                                          // byte offset relative to the tile origin pixel
+#pragma unroll
+    for (int i = 0; i < WN_IN_ITERS; ++i)
+        relk[i] = ((((pyx[i] >> 16) - 1) * W + ((pyx[i] >> 4) & 0xfff) - 1) * 64 + (pyx[i] & 15)) * 4;
     // descriptors of the tile whose chunks are being loaded: one buffer resource per item (its range
     // check returns 0 for the voffset given to halo pixels outside the image) and a byte offset per
     // staged piece; the chunk's channel offset goes in the scalar offset.
     const int item_bytes = H * W * 64 * (int)sizeof(float);
-    int goff[WN_IN_ITERS];
+    int goff[WN_IN_ITERS], goffN[WN_IN_ITERS];                     // current / next (computed a phase early)
     __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, item_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsLN = rsL;
 #define WS_DESC(i_)                                                                              \
     do {                                                                                         \
         int item_, y0_, x0_;                                                                     \
         WS_UNIT(i_, item_, y0_, x0_);                                                            \
-        rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (size_t)item_ * H * W * 64, 0, item_bytes, \
+        rsLN = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (size_t)item_ * H * W * 64, 0, item_bytes, \
                                                 0x00020000);                                     \
-        _Pragma("unroll") for (int k_ = 0; k_ < WN_IN_ITERS; ++k_) {                             \
-            const int gy_ = y0_ + (pyx[k_] >> 16) - 1, gx_ = x0_ + ((pyx[k_] >> 4) & 0xfff) - 1; \
-            const bool in_ = (unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W;         \
-            goff[k_] = in_ ? ((gy_ * W + gx_) * 64 + (pyx[k_] & 15)) * 4 : 0x7fffffff;           \
+        const int org_ = (y0_ * W + x0_) * 256;                                                  \
+        if (y0_ > 0 && y0_ + WN_IH - 1 <= H && x0_ > 0 && x0_ + WN_IW - 1 <= W) {   /* interior tile: uniform branch */ \
+            _Pragma("unroll") for (int k_ = 0; k_ < WN_IN_ITERS; ++k_) goffN[k_] = org_ + relk[k_]; \
+        } else {                                                                                 \
+            _Pragma("unroll") for (int k_ = 0; k_ < WN_IN_ITERS; ++k_) {                         \
+                const int gy_ = y0_ + (pyx[k_] >> 16) - 1, gx_ = x0_ + ((pyx[k_] >> 4) & 0xfff) - 1; \
+                const bool in_ = (unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W;     \
+                goffN[k_] = in_ ? org_ + relk[k_] : 0x7fffffff;                                   \
+            }                                                                                    \
         }                                                                                        \
+    } while (0)
+#define WS_DESC_COMMIT()                                                                         \
+    do {                                                                                         \
+        rsL = rsLN;                                                                              \
+        _Pragma("unroll") for (int k_ = 0; k_ < WN_IN_ITERS; ++k_) goff[k_] = goffN[k_];         \
     } while (0)
     f32x4 rin[WN_NCHUNK][WN_IN_ITERS];                              // one register set per chunk index
 #define WS_LOAD(q_)                                                                              \
@@ -251,39 +288,54 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
     const int c4 = ht & 15;
     const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + c4 * 4);
     const float slope = p.act ? 0.2f : 1.0f;
-    int e_y0 = 0, e_x0 = 0;
+    int n_y0 = 0, n_x0 = 0;
     __amdgpu_buffer_rsrc_t rsOut = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, item_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsRes = rsOut, rsAdd = rsOut;
+    __amdgpu_buffer_rsrc_t rsRes = rsOut, rsAdd = rsOut, rsOutN = rsOut, rsResN = rsOut, rsAddN = rsOut;
     f32x4 av[4][2], rv[4][2];
 #define WS_EPI_UNIT(i_)                                                                          \
     do {                                                                                         \
         int item_;                                                                               \
-        WS_UNIT(i_, item_, e_y0, e_x0);                                                          \
-        rsOut = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)item_ * H * W * 64, 0, item_bytes, 0x00020000); \
+        WS_UNIT(i_, item_, n_y0, n_x0);                                                          \
+        rsOutN = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)item_ * H * W * 64, 0, item_bytes, 0x00020000); \
         if (FUSE) {                                                                              \
-            rsRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid) + (size_t)item_ * H * W * 64, 0, \
+            rsResN = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid) + (size_t)item_ * H * W * 64, 0, \
                                                       item_bytes, 0x00020000);                   \
-            rsAdd = __builtin_amdgcn_make_buffer_rsrc(                                           \
+            rsAddN = __builtin_amdgcn_make_buffer_rsrc(                                           \
                 const_cast<float*>(p.addend) + (size_t)(item_ / p.add_div) * H * W * 64, 0, item_bytes, 0x00020000); \
         }                                                                                        \
     } while (0)
-    // byte offset of (row r_ of item k_) inside the item, or out of range for pixels outside the image
-#define WS_EPI_OFF(k_, r_, off_)                                                                 \
+#define WS_EPI_COMMIT()                                                                          \
     do {                                                                                         \
-        const int id_ = (k_) * 256 + ht;                                                         \
-        const int et_ = id_ >> 5;                                                                \
-        const int ox_ = e_x0 + 2 * (et_ & 15) + ((id_ >> 4) & 1);                                \
-        const int oy_ = e_y0 + 2 * (et_ >> 4) + (r_);                                            \
-        off_ = (ox_ < W && oy_ < H) ? ((oy_ * W + ox_) * 64 + c4 * 4) * 4 : 0x7fffffff;          \
+        rsOut = rsOutN;                                                                          \
+        if (FUSE) {                                                                              \
+            rsRes = rsResN;                                                                      \
+            rsAdd = rsAddN;                                                                      \
+        }                                                                                        \
+        _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) eoff[k_] = eoffN[k_];                   \
+    } while (0)
+    // Byte offsets of this thread's four items (row 0) inside the item, computed once per tile; out of
+    // range for pixels outside the image (H, W even: row 1 is valid iff row 0 is, and it is reached
+    // through the scalar offset `rowb`, which the range check ignores).  Item k sits 16*(k&1) columns and
+    // 2*(k>>1) rows from item 0.
+    int eoff[4] = {0, 0, 0, 0}, eoffN[4] = {0, 0, 0, 0};
+    const int rowb = W * 256;
+    const int h5 = ht >> 5;
+#define WS_EPI_OFFS()                                                                            \
+    do {                                                                                         \
+        const int ox_ = n_x0 + 2 * h5 + ((ht >> 4) & 1), oy_ = n_y0;                             \
+        const int o0_ = ((oy_ * W + ox_) * 64 + c4 * 4) * 4;                                     \
+        const bool vx0_ = ox_ < W, vx1_ = ox_ + 16 < W, vy0_ = oy_ < H, vy1_ = oy_ + 2 < H;      \
+        eoffN[0] = (vx0_ && vy0_) ? o0_ : 0x7fffffff;                                             \
+        eoffN[1] = (vx1_ && vy0_) ? o0_ + 16 * 256 : 0x7fffffff;                                  \
+        eoffN[2] = (vx0_ && vy1_) ? o0_ + 2 * rowb : 0x7fffffff;                                  \
+        eoffN[3] = (vx1_ && vy1_) ? o0_ + 2 * rowb + 16 * 256 : 0x7fffffff;                       \
     } while (0)
 #define WS_EPI_LOAD(k_)                                                                          \
     do {                                                                                         \
         if (FUSE) {                                                                              \
             _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                                   \
-                int off_;                                                                        \
-                WS_EPI_OFF(k_, r_, off_);                                                        \
-                av[k_][r_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAdd, off_, 0, 0)); \
-                rv[k_][r_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsRes, off_, 0, 0)); \
+                av[k_][r_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAdd, eoff[k_], r_ * rowb, 0)); \
+                rv[k_][r_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsRes, eoff[k_], r_ * rowb, 0)); \
             }                                                                                    \
         }                                                                                        \
     } while (0)
@@ -299,8 +351,6 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
         yv_[0] = r0_ + r1_ + r2_;                               /* row transform over xi */      \
         yv_[1] = r1_ - (r2_ + r3_);                                                              \
         _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                                       \
-            int off_;                                                                            \
-            WS_EPI_OFF(k_, r_, off_);                                                            \
             f32x4 o_ = yv_[r_] + bias4;                                                          \
             if (FUSE) o_ += av[k_][r_];                                                          \
             const f32x4 so_ = o_ * slope;                                                        \
@@ -309,29 +359,38 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
             o_.z = fmaxf(o_.z, so_.z);                                                           \
             o_.w = fmaxf(o_.w, so_.w);                                                           \
             if (FUSE) o_ += rv[k_][r_];                                                          \
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o_), rsOut, off_, 0, 0); \
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o_), rsOut, eoff[k_], r_ * rowb, 0); \
         }                                                                                        \
     } while (0)
 
     // prologue: all four chunks of tile 0 requested; chunk 0 stored; chunk 0 of tile 1 requested
     WS_DESC(0);
+    WS_DESC_COMMIT();
     WS_LOAD(0);
     WS_LOAD(1);
     WS_LOAD(2);
     WS_LOAD(3);
     WS_STORE(0);
     WS_DESC(min(1, nu - 1));                                        // past the end: harmless re-read of the last tile
+    WS_DESC_COMMIT();
     WS_LOAD(0);
     __syncthreads();
     for (int i = 0; i < nu; ++i) {
-        // phase 0: chunk 1 -> buffer 1; request chunk 1 of the next tile; rest of the previous tile's addend / residual
+        // phase 0 (the matrix waves also drop the previous tile's accumulators here, so it has slack):
+        // chunk 1 -> buffer 1; request chunk 1 of the next tile; rest of the previous tile's addend /
+        // residual; descriptors of the tile after next and this tile's epilogue offsets, into shadow sets
         WS_STORE(1);
         WS_LOAD(1);
         if (i > 0) {
             WS_EPI_LOAD(2);
             WS_EPI_LOAD(3);
         }
+        WS_DESC(min(i + 2, nu - 1));
+        WS_EPI_UNIT(i);
+        WS_EPI_OFFS();
+        WS_STAMP();
         __syncthreads();                                            // the matrix waves have filled the slab (tile i-1)
+        WS_STAMP();
         // phase 1: chunk 2 -> buffer 0; half of the previous tile's epilogue
         WS_STORE(2);
         WS_LOAD(2);
@@ -339,22 +398,28 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
             WS_EPI(0);
             WS_EPI(1);
         }
+        WS_STAMP();
         __syncthreads();
+        WS_STAMP();
         // phase 2: chunk 3 -> buffer 1
         WS_STORE(3);
         WS_LOAD(3);
         if (i > 0) WS_EPI(2);
+        WS_STAMP();
         __syncthreads();
+        WS_STAMP();
         // phase 3: next tile's chunk 0 -> buffer 0; request chunk 0 of the tile after; last quarter of the
         // epilogue, then the addend / residual of THIS tile (first half)
         WS_STORE(0);
-        WS_DESC(min(i + 2, nu - 1));
+        WS_DESC_COMMIT();
         WS_LOAD(0);
         if (i > 0) WS_EPI(3);
-        WS_EPI_UNIT(i);
+        WS_EPI_COMMIT();
         WS_EPI_LOAD(0);
         WS_EPI_LOAD(1);
+        WS_STAMP();
         __syncthreads();
+        WS_STAMP();
     }
     WS_EPI_LOAD(2);
     WS_EPI_LOAD(3);
@@ -363,9 +428,11 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
     WS_EPI(1);
     WS_EPI(2);
     WS_EPI(3);
+#undef WS_EPI_COMMIT
+#undef WS_DESC_COMMIT
 #undef WS_EPI
 #undef WS_EPI_LOAD
-#undef WS_EPI_OFF
+#undef WS_EPI_OFFS
 #undef WS_EPI_UNIT
 #undef WS_STORE
 #undef WS_LOAD
