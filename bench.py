@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--conv3x3", choices=["winograd", "winograd_ws", "winograd16", "direct"], default=None, help="override the 3x3 conv algorithm")
+    ap.add_argument("--conv3x3", choices=["winograd", "winograd_tile", "winograd16", "direct"], default=None, help="override the 3x3 conv algorithm")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to exercise the N>1 plumbing on a 1-GPU box)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events (no roofline object)")
@@ -177,7 +177,8 @@ def main():
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                 "kernel": ("conv_wino16_kernel<*> (fused Winograd F(2x2,3x3), one wave per SIMD)" if algo == "winograd16" else
-                           "conv_wino_kernel<*> (fused Winograd F(2x2,3x3) 64->64, f32 MFMA)" if algo == "winograd"
+                           "conv_wino_kernel<*> (fused Winograd F(2x2,3x3) 64->64, f32 MFMA, one workgroup per tile)" if algo == "winograd_tile" else
+                           "conv_wino_ws_kernel<*> (fused Winograd F(2x2,3x3) 64->64, f32 MFMA, persistent wave-specialised)" if algo == "winograd"
                            else "conv_mfma_kernel<3,16,*> (3x3 64->64 f32 MFMA implicit GEMM)"),
                 "avg_launch_ms": round(avg_ms, 4), "launches": k["launches"],
                 "gflop_per_launch": round(flops_per_launch / 1e9, 3),

@@ -73,10 +73,13 @@ int pfnl_missing_weights(pfnl_handle* h, int* count);
  * Wg*Ww of the non-local block, chunks the implicit-GEMM weights. */
 int pfnl_finalize_weights(pfnl_handle* h);
 
-/* Tuning knobs (all parity-tested):  key "conv3x3" = "winograd" (default: fused Winograd F(2x2,3x3),
- * f32 MFMA, 2.25x fewer multiplies) | "winograd16" (same maths, one wave per SIMD owning all 16
- * positions) | "direct" (implicit-GEMM f32 MFMA).  The default can also be
- * set with the environment variable PFNL_CONV3X3 read by pfnl_create. */
+/* Tuning knobs (all parity-tested):  key "conv3x3" =
+ *   "winograd"      (default) fused Winograd F(2x2,3x3) on f32 MFMA (2.25x fewer multiplies), persistent
+ *                   wave-specialised kernel: matrix waves + helper waves (conv_wino_ws.hip);
+ *   "winograd_tile" same maths, one 4-wave workgroup per tile (conv_wino.hip);
+ *   "winograd16"    same maths, one wave per SIMD owning all 16 positions (experimental, slower);
+ *   "direct"        implicit-GEMM f32 MFMA (conv_mfma.hip).
+ * The default can also be set with the environment variable PFNL_CONV3X3 read by pfnl_create. */
 int pfnl_set_option(pfnl_handle* h, const char* key, const char* value);
 
 /* ---- the hot path ------------------------------------------------------------------------ */

@@ -59,7 +59,7 @@ struct pfnl_handle {
     std::map<std::string, std::vector<int64_t>> expected;   // tf name -> shape
     std::map<std::string, HostTensor> host;                  // tensors received so far
     bool finalized = false;
-    int conv_algo = 1;                                        // conv3x3: 0 direct, 1 winograd (4 waves / tile), 2 winograd16 (1 wave / SIMD), 3 winograd_ws (persistent, wave-specialised)
+    int conv_algo = 3;                                        // conv3x3: 0 direct, 1 winograd (4 waves / tile), 2 winograd16 (1 wave / SIMD), 3 winograd_ws (persistent, wave-specialised)
 
     // device weights (offsets in floats into `wdev`)
     DevBuf wdev;
@@ -314,7 +314,7 @@ int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
     h->cfg = *cfg;
     if (const char* e = std::getenv("PFNL_CONV3X3")) {
         const std::string v(e);
-        h->conv_algo = v == "direct" ? 0 : (v == "winograd16" ? 2 : (v == "winograd_ws" ? 3 : 1));
+        h->conv_algo = v == "direct" ? 0 : (v == "winograd16" ? 2 : (v == "winograd_tile" ? 1 : 3));
     }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
@@ -374,11 +374,11 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
     if (!h || !key || !value) return fail(PFNL_ERR_INVALID, "NULL argument");
     const std::string k(key), v(value);
     if (k == "conv3x3") {
-        if (v == "winograd") h->conv_algo = 1;
+        if (v == "winograd" || v == "winograd_ws") h->conv_algo = 3;
+        else if (v == "winograd_tile") h->conv_algo = 1;
         else if (v == "winograd16") h->conv_algo = 2;
-        else if (v == "winograd_ws") h->conv_algo = 3;
         else if (v == "direct") h->conv_algo = 0;
-        else return fail(PFNL_ERR_INVALID, "conv3x3 must be winograd, winograd_ws, winograd16 or direct");
+        else return fail(PFNL_ERR_INVALID, "conv3x3 must be winograd, winograd_tile, winograd16 or direct");
         return 0;
     }
     return fail(PFNL_ERR_INVALID, "unknown option " + k);

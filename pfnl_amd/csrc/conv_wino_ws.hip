@@ -85,6 +85,9 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
 #endif
     if (wave < 4) {
         // =================================== matrix waves ===========================================
+#ifdef PFNL_WS_MPRIO
+        __builtin_amdgcn_s_setprio(PFNL_WS_MPRIO);
+#endif
         const int xi = wave;
         const int tx = lane & 15;
         const int ty = (lane >> 4) & 1;
@@ -213,7 +216,10 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
     // ====================================== helper waves =============================================
     // Few instructions, but every one is on the barrier-critical path and only gets an issue slot when the
     // matrix wave of its SIMD leaves one: highest priority.
-    __builtin_amdgcn_s_setprio(3);
+#ifndef PFNL_WS_HPRIO
+#define PFNL_WS_HPRIO 3
+#endif
+    __builtin_amdgcn_s_setprio(PFNL_WS_HPRIO);
     const int ht = tid - 4 * 64;                                    // 0..255
     // unit-independent part of the staging descriptors
     int loff[WN_IN_ITERS], pyx[WN_IN_ITERS];
@@ -461,7 +467,7 @@ hipError_t launch_conv_wino_ws(const WinoParams& p, hipStream_t s) {
     const bool fuse = p.addend != nullptr || p.resid != nullptr;
     if (fuse && (!p.addend || !p.resid || p.add_div < 1)) return hipErrorInvalidValue;
     if ((p.H & 1) || (p.W & 1)) return hipErrorInvalidValue;
-    if ((long long)p.H * p.W * 256 >= 0x7fffffffLL) return hipErrorInvalidValue;   // 32-bit buffer offsets per item
+    if ((long long)p.H * p.W * 256 >= 0x7fffffffLL) return launch_conv_wino(p, s);   // 32-bit buffer offsets per item: per-tile kernel instead
     const int ntiles = ((p.W + 2 * WN_TX - 1) / (2 * WN_TX)) * ((p.H + 2 * WN_TY - 1) / (2 * WN_TY)) * p.items;
     const int rs = (ntiles + 7) / 8;
     const int wpx = rs < WS_MAX_WG_PER_XCD ? rs : WS_MAX_WG_PER_XCD;

@@ -238,4 +238,69 @@ __device__ __forceinline__ void wq_kstep_b(f32x16& a0, f32x16& a1, f32x16& a2, f
                      : "memory");
     }
 }
+
+// ---- 8-MFMA K-step split at the ONE place where compiler-issued instructions may land -------------------
+// head = first MFMA + the 4 raw reads of the next step; the caller then issues the two U loads of step
+// s+UD (plain builtins: the compiler keeps vmcnt and register liveness right) and whatever s_waitcnt the
+// operands of `rest` need; rest = the other 7 MFMAs with the 4 packed-VALU transform before the last two.
+// Non-MFMA instructions thus form two groups per K-step instead of four.  ZERO: first step of a tile (C = 0).
+template <int OFF, bool ZERO>
+__device__ __forceinline__ void wr_kstep_head(f32x16& a0, const float c0, const float b0x, f32x2& x01, f32x2& y01,
+                                              f32x2& x23, f32x2& y23, unsigned pa, unsigned pb) {
+#define PFNL_WR_HEAD(C0)                                                        \
+    asm volatile("v_mfma_f32_32x32x2_f32 %[a0], %[c0], %[bx], " C0 "\n\t"       \
+                 "ds_read_b64 %[x01], %[pa] offset:%c[o0]\n\t"                  \
+                 "ds_read_b64 %[y01], %[pb] offset:%c[o0]\n\t"                  \
+                 "ds_read_b64 %[x23], %[pa] offset:%c[o2]\n\t"                  \
+                 "ds_read_b64 %[y23], %[pb] offset:%c[o2]\n\t"
+    if constexpr (ZERO) {
+        PFNL_WR_HEAD("0")
+                     : [a0] "=&v"(a0), [x01] "=&v"(x01), [y01] "=&v"(y01), [x23] "=&v"(x23), [y23] "=&v"(y23)
+                     : [c0] "v"(c0), [bx] "v"(b0x), [pa] "v"(pa), [pb] "v"(pb), [o0] "i"(OFF), [o2] "i"(OFF + 8)
+                     : "memory");
+    } else {
+        PFNL_WR_HEAD("%[a0]")
+                     : [a0] "+v"(a0), [x01] "=&v"(x01), [y01] "=&v"(y01), [x23] "=&v"(x23), [y23] "=&v"(y23)
+                     : [c0] "v"(c0), [bx] "v"(b0x), [pa] "v"(pa), [pb] "v"(pb), [o0] "i"(OFF), [o2] "i"(OFF + 8)
+                     : "memory");
+    }
+#undef PFNL_WR_HEAD
+}
+template <bool ZERO>
+__device__ __forceinline__ void wr_kstep_rest(f32x16& a1, f32x16& a2, f32x16& a3, f32x16& a4, f32x16& a5, f32x16& a6,
+                                              f32x16& a7, const float c0, const float c1, const float c2, const float c3,
+                                              const f32x4 b0, const f32x4 b1, f32x2& x01, const f32x2 y01, f32x2& x23,
+                                              const f32x2 y23, f32x2& n03, f32x2& n12, const f32x2 sg) {
+#define PFNL_WR_REST(C1, C2, C3, C4, C5, C6, C7)                                                        \
+    asm volatile("v_mfma_f32_32x32x2_f32 %[a1], %[c1], %[py], " C1 "\n\t"                               \
+                 "v_mfma_f32_32x32x2_f32 %[a2], %[c2], %[pz], " C2 "\n\t"                               \
+                 "v_mfma_f32_32x32x2_f32 %[a3], %[c3], %[pw], " C3 "\n\t"                               \
+                 "v_mfma_f32_32x32x2_f32 %[a4], %[c0], %[qx], " C4 "\n\t"                               \
+                 "v_mfma_f32_32x32x2_f32 %[a5], %[c1], %[qy], " C5 "\n\t"                               \
+                 "s_waitcnt lgkmcnt(0)\n\t"                                                             \
+                 "v_pk_fma_f32 %[x01], %[y01], %[sg], %[x01]\n\t"                                       \
+                 "v_pk_fma_f32 %[x23], %[y23], %[sg], %[x23]\n\t"                                       \
+                 "v_pk_add_f32 %[n03], %[x01], %[x23] neg_lo:[0,1] neg_hi:[0,1]\n\t"                    \
+                 "v_pk_add_f32 %[n12], %[x01], %[x23] op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"    \
+                 "v_mfma_f32_32x32x2_f32 %[a6], %[c2], %[qz], " C6 "\n\t"                               \
+                 "v_mfma_f32_32x32x2_f32 %[a7], %[c3], %[qw], " C7 "\n\t"
+#define PFNL_WR_REST_IN                                                                                  \
+    [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [py] "v"(b0.y), [pz] "v"(b0.z), [pw] "v"(b0.w),  \
+        [qx] "v"(b1.x), [qy] "v"(b1.y), [qz] "v"(b1.z), [qw] "v"(b1.w), [y01] "v"(y01), [y23] "v"(y23), [sg] "v"(sg)
+    if constexpr (ZERO) {
+        PFNL_WR_REST("0", "0", "0", "0", "0", "0", "0")
+                     : [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [a4] "=&v"(a4), [a5] "=&v"(a5), [a6] "=&v"(a6),
+                       [a7] "=&v"(a7), [x01] "+v"(x01), [x23] "+v"(x23), [n03] "=&v"(n03), [n12] "=&v"(n12)
+                     : PFNL_WR_REST_IN
+                     : "memory");
+    } else {
+        PFNL_WR_REST("%[a1]", "%[a2]", "%[a3]", "%[a4]", "%[a5]", "%[a6]", "%[a7]")
+                     : [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6),
+                       [a7] "+v"(a7), [x01] "+v"(x01), [x23] "+v"(x23), [n03] "=&v"(n03), [n12] "=&v"(n12)
+                     : PFNL_WR_REST_IN
+                     : "memory");
+    }
+#undef PFNL_WR_REST
+#undef PFNL_WR_REST_IN
+}
 }  // namespace pfnl

@@ -69,10 +69,13 @@ def test_winograd_and_direct_paths_agree():
     eng = engine_for(geometry_of(gd["meta"]))
     eng.set_option("conv3x3", "direct")
     y_d = eng.forward(gd["x"])
-    eng.set_option("conv3x3", "winograd")
+    eng.set_option("conv3x3", "winograd")                     # default: persistent wave-specialised kernel
     y_w = eng.forward(gd["x"])
+    eng.set_option("conv3x3", "winograd_tile")                # one workgroup per tile: same arithmetic, same bits
+    y_t = eng.forward(gd["x"])
     assert np.abs(y_d - gd["y"]).max() < ABS_TOL and np.abs(y_w - gd["y"]).max() < ABS_TOL
     assert np.abs(y_d - y_w).max() < 5e-5
+    assert np.abs(y_t - y_w).max() < 2e-6
     with pytest.raises(Exception):
         eng.set_option("conv3x3", "fft")
 
@@ -185,7 +188,7 @@ def test_random_geometry_fuzz(seed):
     eng = PFNLEngine(geom)
     eng.load_weights(w)
     ref = pfnl_fast.FastOracle(w, T, scale, nb).forward(x)
-    for algo in ("winograd", "direct"):
+    for algo in ("winograd", "winograd_tile", "direct"):
         eng.set_option("conv3x3", algo)
         y = eng.forward(x)
         assert y.shape == ref.shape
