@@ -79,6 +79,7 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *   "winograd_tile" same maths, one 4-wave workgroup per tile (conv_wino.hip);
  *   "winograd16"    same maths, one wave per SIMD owning all 16 positions (experimental, slower);
  *   "direct"        implicit-GEMM f32 MFMA (conv_mfma.hip).
+ * key "conv1x1" = "stream" (default, conv1x1.hip) | "tiled" (conv_mfma.hip).
  * The default can also be set with the environment variable PFNL_CONV3X3 read by pfnl_create. */
 int pfnl_set_option(pfnl_handle* h, const char* key, const char* value);
 
@@ -121,6 +122,11 @@ int pfnl_op_conv2d(const float* in, const float* kernel_host, const float* bias_
                    const float* addend, int add_div, const float* resid, float* out,
                    int items, int frames_per_item, int H, int W, int ksize, int cout, int act,
                    void* stream);
+/* conv10_i (reference model/pfnl.py:50, :67-68): the 1x1, (frames_per_item*64) -> 64 convolution through
+ * the streaming kernel that reads its A operand straight from HBM (no LDS; conv1x1.hip).
+ * in [items*frames_per_item, HW, 64], kernel_host HWIO [1,1,64*fpi,64], out [items, HW, 64]. */
+int pfnl_op_conv1x1_stream(const float* in, const float* kernel_host, const float* bias_host, float* out,
+                           int items, int frames_per_item, int HW, int act, void* stream);
 /* The same 3x3 64->64 convolution (frames_per_item = 1, cout = 64) through the fused Winograd
  * F(2x2,3x3) kernel; H and W must be even. */
 int pfnl_op_conv3x3_winograd(const float* in, const float* kernel_host, const float* bias_host,

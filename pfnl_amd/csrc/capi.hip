@@ -59,12 +59,13 @@ struct pfnl_handle {
     std::map<std::string, std::vector<int64_t>> expected;   // tf name -> shape
     std::map<std::string, HostTensor> host;                  // tensors received so far
     bool finalized = false;
+    int conv1x1_algo = 1;                                     // conv10: 1 streaming kernel (conv1x1.hip), 0 LDS-tiled implicit GEMM
     int conv_algo = 3;                                        // conv3x3: 0 direct, 1 winograd (4 waves / tile), 2 winograd16 (1 wave / SIMD), 3 winograd_ws (persistent, wave-specialised)
 
     // device weights (offsets in floats into `wdev`)
     DevBuf wdev;
     size_t off_conv0_w = 0, off_conv0_b = 0;
-    std::vector<size_t> off_c1_w, off_c1_b, off_c10_w, off_c10_b, off_c2a_w, off_c2b_w, off_c2_b;
+    std::vector<size_t> off_c1_w, off_c1_b, off_c10_w, off_c10_b, off_c10_s, off_c2a_w, off_c2b_w, off_c2_b;
     std::vector<size_t> off_c1_u, off_c2a_u, off_c2b_u;       // Winograd-packed variants
     std::vector<size_t> off_c1_u16, off_c2a_u16, off_c2b_u16; // ... for conv_wino16_kernel
     size_t off_m1_w = 0, off_m1_b = 0, off_m2_w = 0, off_m2_b = 0, off_nl_w = 0, off_nl_b = 0, off_zero = 0;
@@ -221,7 +222,10 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             p.out = h->base.p;
             p.frames_per_item = T;
             p.nchunks = T * p.chunks_per_frame;
-            HIPCHK(launch_conv_mfma(p, 1, B, s));
+            if (h->conv1x1_algo == 1)
+                HIPCHK(launch_conv1x1_stream(p.in, wd + h->off_c10_s[i], p.bias, p.out, B, T, H * W, 1, s));
+            else
+                HIPCHK(launch_conv_mfma(p, 1, B, s));
         }
         {   // conv2_i, shared half: 3x3 over `base` (kernel rows 0..63), once per clip, raw
             ProfScope ps(h, s, PFNL_K_CONV3X3);
@@ -381,6 +385,12 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         else return fail(PFNL_ERR_INVALID, "conv3x3 must be winograd, winograd_tile, winograd16 or direct");
         return 0;
     }
+    if (k == "conv1x1") {
+        if (v == "stream") h->conv1x1_algo = 1;
+        else if (v == "tiled") h->conv1x1_algo = 0;
+        else return fail(PFNL_ERR_INVALID, "conv1x1 must be stream or tiled");
+        return 0;
+    }
     return fail(PFNL_ERR_INVALID, "unknown option " + k);
 }
 
@@ -436,6 +446,7 @@ int pfnl_finalize_weights(pfnl_handle* h) {
     h->off_c1_b.assign(nb, 0);
     h->off_c10_w.assign(nb, 0);
     h->off_c10_b.assign(nb, 0);
+    h->off_c10_s.assign(nb, 0);
     h->off_c2a_w.assign(nb, 0);
     h->off_c2b_w.assign(nb, 0);
     h->off_c2_b.assign(nb, 0);
@@ -451,6 +462,8 @@ int pfnl_finalize_weights(pfnl_handle* h) {
         h->off_c1_b[i] = put_bias(Bv("conv1_" + s));
         h->off_c10_w[i] = put_pack(W("conv10_" + s), 1, 64 * T, 0, 64 * T, 64);
         h->off_c10_b[i] = put_bias(Bv("conv10_" + s));
+        h->off_c10_s[i] = reserve(pfnl::conv1x1_pack_floats(T));
+        pfnl::conv1x1_pack_weights(W("conv10_" + s).data(), T, &blob[h->off_c10_s[i]]);
         // conv2_i input = concat([base, inp1_t]) (model/pfnl.py:69): rows 0..63 see `base`.
         h->off_c2a_w[i] = put_pack(W("conv2_" + s), 3, 128, 0, 64, 64);
         h->off_c2b_w[i] = put_pack(W("conv2_" + s), 3, 128, 64, 64, 64);
@@ -646,6 +659,26 @@ int pfnl_op_conv2d(const float* in, const float* kernel_host, const float* bias_
     }
     hipFree(dw);
     if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv op: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int pfnl_op_conv1x1_stream(const float* in, const float* kernel_host, const float* bias_host, float* out, int items,
+                           int frames_per_item, int HW, int act, void* stream) {
+    if (!in || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (items < 1 || frames_per_item < 1 || HW < 1) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
+    hipStream_t s = (hipStream_t)stream;
+    const int T = frames_per_item;
+    std::vector<float> pack(pfnl::conv1x1_pack_floats(T) + 64, 0.f);
+    pfnl::conv1x1_pack_weights(kernel_host, T, pack.data());
+    const size_t boff = pack.size() - 64;
+    if (bias_host) std::memcpy(&pack[boff], bias_host, 64 * sizeof(float));
+    float* dw = nullptr;
+    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(float)));
+    hipError_t e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = pfnl::launch_conv1x1_stream(in, dw, dw + boff, out, items, T, HW, act, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dw);
+    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv1x1 op: ") + hipGetErrorString(e));
     return 0;
 }
 

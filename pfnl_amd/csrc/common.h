@@ -59,6 +59,12 @@ void conv_pack_weights(const float* hwio, int ksize, int cin_total, int cin_begi
                        int cout, float* dst);
 
 // ---- fused Winograd F(2x2,3x3) 64->64 convolution (conv_wino.hip) -------------------------------
+// conv10_i: streaming 1x1 over the concat of T frames, T*64 -> 64 (conv1x1.hip)
+hipError_t launch_conv1x1_stream(const float* in, const float* wpack, const float* bias, float* out, int items, int T,
+                                 int HW, int act, hipStream_t s);
+size_t conv1x1_pack_floats(int T);
+void conv1x1_pack_weights(const float* hwio, int T, float* dst);   // HWIO [1,1,T*64,64]
+
 struct WinoParams {
     const float* in;       // [items][H][W][64]
     const float* upack;    // U = G g G^T, packed [chunk][xi][kk][lane][nu*2+nt] (wino_pack_weights)

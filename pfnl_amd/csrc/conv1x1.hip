@@ -1,0 +1,164 @@
+// conv10_i of the reference (model/pfnl.py:50 applied at :67-68): 1x1 convolution over the channel
+// concatenation of the T frames of a clip, T*64 -> 64 channels, + bias, leaky_relu(0.2) -> `base`.
+//
+// A 1x1 convolution has no spatial reuse, so nothing needs to go through LDS: the GEMM's A operand
+// (M = pixels, K = T*64 input channels) is read straight from HBM as 16-byte pieces, and - the order
+// of a contraction being free - the K order is chosen so that a float4 of 4 CONSECUTIVE channels held by
+// one lane feeds 4 consecutive v_mfma_f32_32x32x2_f32:  lane (pixel = l&31, kh = l>>5) loads channels
+// [32M + 16kh + 4t, +4) of frame f; MFMA (t, e) then contracts the channel pair (32M + 4t + e,
+// 32M + 16 + 4t + e).  The weights are packed on the host in exactly that order, 16 bytes per lane per
+// 4 MFMAs.  Per 8 MFMAs the wave issues one global load, two LDS reads and no VALU instruction at all,
+// which is what a saturated gfx950 matrix pipe wants (tools/ubench/).  The four float4 of one pixel's
+// 32-channel half (one 128-byte line) are requested back to back.
+//
+// The weights (16 KB per frame) go through LDS, one frame ahead of the MFMAs, double-buffered: the B
+// operand is one ds_read_b128 per lane per 4 MFMAs, and they are shared by the 8 waves of a workgroup (a
+// first version that streamed B per wave from L2 stalled behind the HBM-latency A pieces in the in-order
+// vmcnt queue; a second one that copied all T*16 KB up front paid that copy as a serial prologue, which
+// matters when a wave only lives for T*64 MFMAs).  Wave = 32 consecutive pixels of one clip x all 64
+// output channels (2 accumulators); the next two frames' A pieces and the next frame's weights are in flight while
+// the current frame's 64 MFMAs run; the frame barrier sits between steps 6 and 7, so that step 7 can
+// already prefetch the next frame's first B.  The epilogue adds the bias, applies the activation on the
+// accumulators and stores 128-byte channel-contiguous segments per pixel.
+#include <cstdint>
+
+#include "common.h"
+
+namespace pfnl {
+
+constexpr int C1_THREADS = 512;
+constexpr int C1_WF = 16 * 64;                                     // f32x4 of weights per frame (16 KB)
+
+__global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_stream_kernel(const float* __restrict__ in,
+                                                                       const float* __restrict__ wpack,
+                                                                       const float* __restrict__ bias,
+                                                                       float* __restrict__ out, int HW, int T, int items,
+                                                                       int act) {
+    __shared__ __attribute__((aligned(16))) f32x4 sw[2][C1_WF];     // [frame parity][M][t][g][lane] x e
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xl = lane & 31;
+    const int kh = lane >> 5;
+    const int gpi = (HW + 31) >> 5;                                 // pixel groups per clip
+    const int ngroups = gpi * items;
+    const int g = min(blockIdx.x * 8 + wave, ngroups - 1);          // surplus waves redo the last group (same values)
+    const int item = g / gpi;
+    const int p0 = (g - item * gpi) * 32;
+
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(wpack) + tid;   // + f*C1_WF (+512)
+    f32x4 wr0 = wsrc[0], wr1 = wsrc[C1_THREADS];
+    // A: this lane's pixel (clamped; masked at the store), 16-byte pieces at channel 16*kh + 4*t of half M
+    const f32x4* ap = reinterpret_cast<const f32x4*>(in) + (((size_t)item * T * HW + min(p0 + xl, HW - 1)) * 16 + kh * 4);
+    const size_t aframe = (size_t)HW * 16;                          // f32x4 per frame
+#ifdef PFNL_C1_NO_A   /* timing experiment only: wrong results */
+#define C1_LOAD_A(dst, ap_) do { (void)(ap_); } while (0)
+#else
+#define C1_LOAD_A(dst, ap_)                                                                            \
+    do {                                                                                               \
+        _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) dst[q_] = (ap_)[(q_ >> 2) * 8 + (q_ & 3)];     \
+    } while (0)
+#endif
+    f32x4 a0[8] = {}, a1[8] = {}, a2[8] = {};                                    // rotating sets: [M*4 + t] of one frame
+    C1_LOAD_A(a0, ap);
+    C1_LOAD_A(a1, ap + (size_t)min(1, T - 1) * aframe);
+    sw[0][tid] = wr0;
+    sw[0][tid + C1_THREADS] = wr1;
+    const float bias0 = bias[xl], bias1 = bias[32 + xl];
+    __syncthreads();
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc0[r] = 0.f;
+        acc1[r] = 0.f;
+    }
+    f32x4 w0[2], w1[2];                                             // B double buffer: [step parity]
+    w0[0] = sw[0][lane];
+    w1[0] = sw[0][64 + lane];
+
+    // one frame: request the A pieces two frames ahead and the next frame's weights, 64 MFMAs
+#define C1_FRAME(cur, far, f_)                                                                         \
+    do {                                                                                               \
+        const int fn_ = min((f_) + 1, T - 1);                   /* past the end: harmless re-read */   \
+        C1_LOAD_A(far, ap + (size_t)min((f_) + 2, T - 1) * aframe);                                    \
+        wr0 = wsrc[(size_t)fn_ * C1_WF];                                                               \
+        wr1 = wsrc[(size_t)fn_ * C1_WF + C1_THREADS];                                                  \
+        __builtin_amdgcn_sched_barrier(0);                      /* the streams stay a whole frame ahead */ \
+        const f32x4* wl_ = &sw[(f_) & 1][lane];                                                        \
+        const f32x4* wn_ = &sw[((f_) + 1) & 1][lane];                                                  \
+        _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                             \
+            if (q_ == 6) {                                      /* next frame's weights -> the other buffer */ \
+                sw[((f_) + 1) & 1][tid] = wr0;                                                         \
+                sw[((f_) + 1) & 1][tid + C1_THREADS] = wr1;                                            \
+            }                                                                                          \
+            if (q_ == 7) __syncthreads();                                                              \
+            /* B of the next step (next frame's first step after the last) lands during this step's MFMAs */ \
+            const f32x4* wq_ = q_ < 7 ? wl_ + ((q_ + 1) * 2) * 64 : wn_;                               \
+            w0[(q_ + 1) & 1] = wq_[0];                                                                 \
+            w1[(q_ + 1) & 1] = wq_[64];                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+            const f32x4 w0_ = w0[q_ & 1], w1_ = w1[q_ & 1];                                            \
+            acc0 = mfma32(cur[q_].x, w0_.x, acc0);                                                     \
+            acc1 = mfma32(cur[q_].x, w1_.x, acc1);                                                     \
+            acc0 = mfma32(cur[q_].y, w0_.y, acc0);                                                     \
+            acc1 = mfma32(cur[q_].y, w1_.y, acc1);                                                     \
+            acc0 = mfma32(cur[q_].z, w0_.z, acc0);                                                     \
+            acc1 = mfma32(cur[q_].z, w1_.z, acc1);                                                     \
+            acc0 = mfma32(cur[q_].w, w0_.w, acc0);                                                     \
+            acc1 = mfma32(cur[q_].w, w1_.w, acc1);                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+        }                                                                                              \
+    } while (0)
+    for (int f = 0; f < T; f += 3) {
+        C1_FRAME(a0, a2, f);
+        if (f + 1 < T) C1_FRAME(a1, a0, f + 1);
+        if (f + 2 < T) C1_FRAME(a2, a1, f + 2);
+    }
+#undef C1_FRAME
+#undef C1_LOAD_A
+
+    // epilogue: lane holds output channel xl (acc0) and 32 + xl (acc1) of pixels drow(r, lane)
+    if ((int)(blockIdx.x * 8 + wave) >= ngroups) return;
+    const float slope = act ? 0.2f : 1.0f;
+    float* ob = out + ((size_t)item * HW + p0) * 64 + xl;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int px = drow(r, lane);
+        float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+        v0 = fmaxf(v0, slope * v0);
+        v1 = fmaxf(v1, slope * v1);
+        if (p0 + px < HW) {
+            ob[(size_t)px * 64] = v0;
+            ob[(size_t)px * 64 + 32] = v1;
+        }
+    }
+}
+
+hipError_t launch_conv1x1_stream(const float* in, const float* wpack, const float* bias, float* out, int items, int T,
+                                 int HW, int act, hipStream_t s) {
+    if (!in || !wpack || !bias || !out || items < 1 || T < 1 || HW < 1) return hipErrorInvalidValue;
+    const int ngroups = ((HW + 31) / 32) * items;
+    hipLaunchKernelGGL(conv1x1_stream_kernel, dim3((ngroups + 7) / 8), dim3(C1_THREADS), 0, s, in, wpack, bias, out, HW, T,
+                       items, act);
+    return hipGetLastError();
+}
+
+size_t conv1x1_pack_floats(int T) { return (size_t)T * 64 * 64; }
+
+// HWIO [1,1,T*64,64] -> [f][M][t][g][lane][e], value W[f*64 + 32M + 16*(lane>>5) + 4t + e][32g + (lane&31)]
+void conv1x1_pack_weights(const float* hwio, int T, float* dst) {
+    for (int f = 0; f < T; ++f)
+        for (int M = 0; M < 2; ++M)
+            for (int t = 0; t < 4; ++t)
+                for (int g = 0; g < 2; ++g)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int ci = f * 64 + 32 * M + 16 * (lane >> 5) + 4 * t + e;
+                            const int co = 32 * g + (lane & 31);
+                            dst[((((((size_t)f * 2 + M) * 4 + t) * 2 + g) * 64 + lane) * 4) + e] =
+                                hwio[(size_t)ci * 64 + co];
+                        }
+}
+
+}  // namespace pfnl

@@ -52,6 +52,24 @@ def conv2d(x, kernel, bias=None, act=True, frames_per_item=1, addend=None, add_d
     return out
 
 
+def conv1x1_stream(x, kernel, bias=None, act=True, frames_per_item=1):
+    """conv10_i: 1x1 over the concat of `frames_per_item` frames, (64*fpi) -> 64, streaming kernel.
+    x: [items*fpi, H, W, 64] (cuda); kernel HWIO [1,1,64*fpi,64].  Reference: model/pfnl.py:50, :67-68."""
+    import torch
+    lib = _capi.load_library()
+    k = _host(kernel, "kernel")
+    b = _host(bias, "bias")
+    F, H, W, c = x.shape
+    if k.shape != (1, 1, 64 * frames_per_item, 64) or c != 64 or F % frames_per_item:
+        raise ValueError("conv1x1_stream: geometry mismatch")
+    items = F // frames_per_item
+    out = torch.empty((items, H, W, 64), dtype=torch.float32, device=x.device)
+    _capi.check(lib.pfnl_op_conv1x1_stream(
+        _req(x, "x"), k.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p) if b is not None else None,
+        _req(out, "out"), items, frames_per_item, H * W, 1 if act else 0, _stream(x)))
+    return out
+
+
 def conv3x3_winograd(x, kernel, bias=None, act=True, addend=None, add_div=1, resid=None, variant="winograd"):
     """The 3x3 64->64 'same' convolution through the fused Winograd F(2x2,3x3) kernel (even H, W)."""
     import torch

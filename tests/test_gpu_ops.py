@@ -74,6 +74,27 @@ def test_conv_mfma(items, fpi, H, W, ks, cout, act, fused, mt, monkeypatch):
     assert err < 5e-6 * max(1.0, np.abs(ref).max()), err
 
 
+@pytest.mark.parametrize("items,fpi,H,W,act", [
+    (2, 7, 16, 40, True),        # conv10 at T = 7
+    (1, 5, 6, 8, True),          # T = 5, 48 pixels: one full + one ragged wave
+    (3, 3, 5, 7, False),         # T = 3, 35 pixels, no activation
+    (1, 7, 1, 1, True),          # a single pixel
+    (4, 7, 32, 36, True),        # several workgroups per clip
+])
+def test_conv1x1_stream(items, fpi, H, W, act):
+    rng = np.random.default_rng(items * 100 + fpi * 10 + H + W)
+    x = rng.normal(size=(items * fpi, H, W, 64)).astype(np.float32)
+    k = (rng.normal(size=(1, 1, 64 * fpi, 64)) / np.sqrt(64 * fpi)).astype(np.float32)
+    b = rng.normal(size=64).astype(np.float32)
+    xin = x.reshape(items, fpi, H, W, 64).transpose(0, 2, 3, 1, 4).reshape(items, H, W, 64 * fpi)
+    ref = pfnl_spec.conv2d_same(xin.astype(np.float64), k.astype(np.float64), b.astype(np.float64))
+    if act:
+        ref = pfnl_spec.lrelu(ref)
+    got = ops.conv1x1_stream(dev(x), k, b, act=act, frames_per_item=fpi).cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 5e-6 * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize("items,H,W,act,fused", [
     (2, 4, 32, True, False),        # exactly one workgroup tile
     (3, 20, 36, True, False),       # ragged in both directions
