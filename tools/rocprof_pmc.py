@@ -7,14 +7,29 @@ import sys
 def main():
     for db in sys.argv[1:]:
         c = sqlite3.connect(db)
-        rows = c.execute("select kernel_name, grid_size, counter_name, count(*), avg(value), avg(duration) "
-                         "from counters_collection group by kernel_name, grid_size, counter_name").fetchall()
-        table = {}
-        for name, grid, ctr, n, val, dur in rows:
+        raw = c.execute("select kernel_name, grid_size, counter_name, value, duration from counters_collection").fetchall()
+        # the persistent Winograd kernel uses one grid for 28-item and 4-item launches: split a (kernel, grid)
+        # group whose durations span more than 3x at the geometric mean of its extremes
+        span = {}
+        for name, grid, ctr, val, dur in raw:
+            lo, hi = span.get((name, grid), (dur, dur))
+            span[(name, grid)] = (min(lo, dur), max(hi, dur))
+        acc = {}
+        for name, grid, ctr, val, dur in raw:
             if "pfnl::" not in name:
                 continue
-            key = (name.split("(")[0].replace("void ", ""), grid)
-            table.setdefault(key, {"n": n, "dur_us": dur / 1e3})[ctr] = val
+            lo, hi = span[(name, grid)]
+            cls = ""
+            if hi > 3 * lo:
+                cls = " [long]" if dur * dur > lo * hi else " [short]"
+            key = (name.split("(")[0].replace("void ", "") + cls, grid)
+            a = acc.setdefault((key, ctr), [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += val
+            a[2] += dur
+        table = {}
+        for (key, ctr), (n, sv, sd) in acc.items():
+            table.setdefault(key, {"n": n, "dur_us": sd / n / 1e3})[ctr] = sv / n
         ctrs = sorted({k for v in table.values() for k in v if k not in ("n", "dur_us")})
         print("\n### %s\n" % db)
         print("| kernel | grid | dispatches | avg us | " + " | ".join(ctrs) + " |")
