@@ -59,6 +59,7 @@ struct pfnl_handle {
     std::map<std::string, std::vector<int64_t>> expected;   // tf name -> shape
     std::map<std::string, HostTensor> host;                  // tensors received so far
     bool finalized = false;
+    int merge_cstride = 48;                                   // floats per pixel of `merge` as written by the last forward
     int conv1x1_algo = 1;                                     // conv10: 1 streaming kernel (conv1x1.hip), 0 LDS-tiled implicit GEMM
     int conv_algo = 3;                                        // conv3x3: 0 direct, 1 winograd (4 waves / tile), 2 winograd16 (1 wave / SIMD), 3 winograd_ws (persistent, wave-specialised)
 
@@ -68,6 +69,7 @@ struct pfnl_handle {
     std::vector<size_t> off_c1_w, off_c1_b, off_c10_w, off_c10_b, off_c10_s, off_c2a_w, off_c2b_w, off_c2_b;
     std::vector<size_t> off_c1_u, off_c2a_u, off_c2b_u;       // Winograd-packed variants
     std::vector<size_t> off_c1_u16, off_c2a_u16, off_c2b_u16; // ... for conv_wino16_kernel
+    std::vector<size_t> off_m1_u;                             // convmerge1 per frame, Winograd pack (cout 48 padded to 64)
     size_t off_m1_w = 0, off_m1_b = 0, off_m2_w = 0, off_m2_b = 0, off_nl_w = 0, off_nl_b = 0, off_zero = 0;
 
     // workspace
@@ -165,7 +167,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
         h->nlp.ensure(nl_partial_floats(B, N, C)) ||
         h->inp0.ensure((size_t)F * P * 64) || h->inp1.ensure((size_t)F * P * 64) ||
         h->base.ensure((size_t)B * P * 64) || h->pb.ensure((size_t)B * P * 64) ||
-        h->merge.ensure((size_t)B * P * 48))
+        h->merge.ensure((size_t)B * P * 64))
         return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
     h->lastB = B;
     h->lastH = H;
@@ -267,7 +269,36 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             }
         }
     }
-    {   // convmerge1: 3x3 over the concat of T frames -> 48 + lrelu        (:73-74)
+    const bool m1_wino = h->conv_algo == 3 && (long long)H * W * 256 < 0x7fffffffLL;
+    const int mstride = m1_wino ? 64 : 48;
+    h->merge_cstride = mstride;
+    if (m1_wino) {
+        // convmerge1 (:73-74) = sum over the T frames of a 3x3 64->48 convolution: T launches of the Winograd
+        // kernel (cout zero-padded to 64) accumulating in `base` (free after the last block) through the fused
+        // epilogue: frames 1..T-2 add the running sum after the (identity) activation, the last frame adds it
+        // BEFORE bias + leaky-relu.  `pb` (also free) is cleared and serves as the zero operand.
+        ProfScope ps(h, s, PFNL_K_MERGE1);
+        HIPCHK(hipMemsetAsync(h->pb.p, 0, (size_t)B * P * 64 * sizeof(float), s));
+        for (int f = 0; f < T; ++f) {
+            WinoParams wp{};
+            wp.in = h->inp0.p + (size_t)f * P * 64;
+            wp.in_item_stride = (long long)T * P * 64;
+            wp.upack = wd + h->off_m1_u[f];
+            wp.H = H;
+            wp.W = W;
+            wp.items = B;
+            wp.add_div = 1;
+            const bool last = f == T - 1;
+            wp.bias = last ? wd + h->off_m1_b : wd + h->off_zero;
+            wp.act = last ? 1 : 0;
+            wp.out = last ? h->merge.p : h->base.p;
+            if (f > 0) {
+                wp.addend = last ? h->base.p : h->pb.p;
+                wp.resid = last ? h->pb.p : h->base.p;
+            }
+            HIPCHK(launch_conv_wino_ws(wp, s));
+        }
+    } else {   // convmerge1: 3x3 over the concat of T frames -> 48 + lrelu        (:73-74)
         ProfScope ps(h, s, PFNL_K_MERGE1);
         p.in = h->inp0.p;
         p.wpack = wd + h->off_m1_w;
@@ -285,7 +316,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
     }
     {   // model/pfnl.py:63,76-80
         ProfScope ps(h, s, PFNL_K_TAIL);
-        HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, H, W, c.scale, s));
+        HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, H, W, c.scale, mstride, s));
     }
     h->chain_open = false;
     return 0;
@@ -477,6 +508,11 @@ int pfnl_finalize_weights(pfnl_handle* h) {
     }
     h->off_m1_w = put_pack(W("convmerge1"), 3, 64 * T, 0, 64 * T, 48);
     h->off_m1_b = put_bias(Bv("convmerge1"));
+    h->off_m1_u.assign(T, 0);
+    for (int f = 0; f < T; ++f) {
+        h->off_m1_u[f] = reserve(pfnl::wino_pack_floats());
+        pfnl::wino_pack_weights(W("convmerge1").data(), 64 * T, 64 * f, &blob[h->off_m1_u[f]], 48);
+    }
     {
         const auto& k = W("convmerge2");
         h->off_m2_w = reserve(k.size());
@@ -606,7 +642,10 @@ int pfnl_debug_tap(pfnl_handle* h, const char* name, float* host_dst, size_t cou
         src = h->inp0.p;
     } else if (n == "merge1") {
         need = (size_t)B * H * W * 48;
-        src = h->merge.p;
+        if (count != need) return fail(PFNL_ERR_INVALID, "tap size mismatch");
+        HIPCHK(hipMemcpy2D(host_dst, 48 * sizeof(float), h->merge.p, h->merge_cstride * sizeof(float), 48 * sizeof(float),
+                           (size_t)B * H * W, hipMemcpyDeviceToHost));
+        return 0;
     } else {
         return fail(PFNL_ERR_INVALID, "unknown tap " + n);
     }

@@ -77,13 +77,14 @@ struct WinoParams {
     int act;
     int items;
     long long* dbg;        // PFNL_WINO_TIMING builds only: 64 clock64() stamps per workgroup (else null)
+    long long in_item_stride;   // floats between consecutive input items; 0 = H*W*64 (conv_wino_ws only)
 };
 hipError_t launch_conv_wino(const WinoParams& p, hipStream_t s);
 hipError_t launch_conv_wino_ws(const WinoParams& p, hipStream_t s);  // persistent wave-specialised variant (conv_wino_ws.hip), same packed U
 hipError_t launch_conv_wino16(const WinoParams& p, hipStream_t s);   // one-wave-per-SIMD variant (conv_wino16.hip)
 void wino16_pack_weights(const float* hwio, int cin_total, int cin_begin, float* dst);
 size_t wino_pack_floats();
-void wino_pack_weights(const float* hwio, int cin_total, int cin_begin, float* dst);
+void wino_pack_weights(const float* hwio, int cin_total, int cin_begin, float* dst, int cout = 64);
 
 // ---- non-local block (nonlocal.hip) ----------------------------------------------------------
 int nl_padded_ch(int C);                                      // 32*ceil(C/32)
@@ -97,7 +98,7 @@ hipError_t launch_nl_unpack(const float* Xo, float* out, int B, int T, int H, in
 hipError_t launch_conv0(const float* Xo, const float* w75x64, const float* bias, float* out, int B,
                         int T, int H, int W, hipStream_t s);
 hipError_t launch_tail(const float* merge, const float* x, const float* w2, const float* b2,
-                       float* out, int B, int T, int H, int W, int scale, hipStream_t s);
+                       float* out, int B, int T, int H, int W, int scale, int merge_cstride, hipStream_t s);
 hipError_t launch_blur_decimate(const float* hr, float* lr, int F, int H, int W, int scale, hipStream_t s);
 hipError_t launch_bicubic(const float* x, float* out, int B, int H, int W, int scale, hipStream_t s);
 hipError_t run_mfma_selftest(int* mismatches);

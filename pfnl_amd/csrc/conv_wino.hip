@@ -288,9 +288,9 @@ hipError_t launch_conv_wino(const WinoParams& p, hipStream_t s) {
 
 size_t wino_pack_floats() { return (size_t)wino_pack_floats_c; }
 
-// HWIO [3,3,cin_total,64] rows [cin_begin, cin_begin+64) -> U = G g G^T packed as
+// HWIO [3,3,cin_total,cout<=64] rows [cin_begin, cin_begin+64) -> U = G g G^T packed as
 // [chunk q][xi][N-tile g][kk][lane][nu], value U[xi][nu][cin = 16q + 2kk + (lane>>5)][cout = 32g + (lane&31)].
-void wino_pack_weights(const float* hwio, int cin_total, int cin_begin, float* dst) {
+void wino_pack_weights(const float* hwio, int cin_total, int cin_begin, float* dst, int cout) {
     static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     for (int q = 0; q < 4; ++q)
         for (int x = 0; x < 4; ++x)
@@ -301,10 +301,10 @@ void wino_pack_weights(const float* hwio, int cin_total, int cin_begin, float* d
                             const int ci = cin_begin + q * 16 + 2 * kk + (lane >> 5);
                             const int co = g * 32 + (lane & 31);
                             double u = 0.0;
-                            for (int a = 0; a < 3; ++a)
+                            for (int a = 0; a < 3 && co < cout; ++a)      // output channels >= cout: zero weights
                                 for (int b = 0; b < 3; ++b)
                                     u += G[x][a] * G[nu][b] *
-                                         (double)hwio[(((size_t)a * 3 + b) * cin_total + ci) * 64 + co];
+                                         (double)hwio[(((size_t)a * 3 + b) * cin_total + ci) * cout + co];
                             if (x == 2) u = -u;   // the kernel computes d1 - d2 for this row (see wn_kstep_asm)
                             dst[(((((size_t)q * 4 + x) * 2 + g) * 8 + kk) * 64 + lane) * 4 + nu] = (float)u;
                         }

@@ -252,6 +252,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
     // check returns 0 for the voffset given to halo pixels outside the image) and a byte offset per
     // staged piece; the chunk's channel offset goes in the scalar offset.
     const int item_bytes = H * W * 64 * (int)sizeof(float);
+    const size_t in_stride = p.in_item_stride ? (size_t)p.in_item_stride : (size_t)H * W * 64;
     int goff[WN_IN_ITERS], goffN[WN_IN_ITERS];                     // current / next (computed a phase early)
     __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, item_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsLN = rsL;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
     do {                                                                                         \
         int item_, y0_, x0_;                                                                     \
         WS_UNIT(i_, item_, y0_, x0_);                                                            \
-        rsLN = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (size_t)item_ * H * W * 64, 0, item_bytes, \
+        rsLN = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (size_t)item_ * in_stride, 0, item_bytes, \
                                                 0x00020000);                                     \
         const int org_ = (y0_ * W + x0_) * 256;                                                  \
         if (y0_ > 0 && y0_ + WN_IH - 1 <= H && x0_ > 0 && x0_ + WN_IW - 1 <= W) {   /* interior tile: uniform branch */ \
@@ -474,7 +475,7 @@ hipError_t launch_conv_wino_ws(const WinoParams& p, hipStream_t s) {
     const bool fuse = p.addend != nullptr || p.resid != nullptr;
     if (fuse && (!p.addend || !p.resid || p.add_div < 1)) return hipErrorInvalidValue;
     if ((p.H & 1) || (p.W & 1)) return hipErrorInvalidValue;
-    if ((long long)p.H * p.W * 256 >= 0x7fffffffLL) return launch_conv_wino(p, s);   // 32-bit buffer offsets per item: per-tile kernel instead
+    if ((long long)p.H * p.W * 256 >= 0x7fffffffLL && !p.in_item_stride) return launch_conv_wino(p, s);   // 32-bit buffer offsets per item: per-tile kernel instead
     const int ntiles = ((p.W + 2 * WN_TX - 1) / (2 * WN_TX)) * ((p.H + 2 * WN_TY - 1) / (2 * WN_TY)) * p.items;
     const int rs = (ntiles + 7) / 8;
     const int wpx = rs < WS_MAX_WG_PER_XCD ? rs : WS_MAX_WG_PER_XCD;

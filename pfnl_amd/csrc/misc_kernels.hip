@@ -152,14 +152,14 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ mer
                                                    const float* __restrict__ x,   // [B][T][H][W][3]
                                                    const float* __restrict__ w2,  // [3][3][12][CO]
                                                    const float* __restrict__ b2,  // [CO]
-                                                   float* __restrict__ out, int B, int T, int H, int W) {
+                                                   float* __restrict__ out, int B, int T, int H, int W, int MS) {   // MS = floats per merge pixel (48 or 64)
     constexpr int SCALE = (CO == 12) ? 4 : 2;
     const int H2 = 2 * H, W2 = 2 * W;
     const int X = blockIdx.x * 32 + (threadIdx.x & 31);
     const int Y = blockIdx.y * 8 + (threadIdx.x >> 5);
     const int b = blockIdx.z;
     if (X >= W2 || Y >= H2) return;
-    const float* mb = merge + (size_t)b * H * W * 48;
+    const float* mb = merge + (size_t)b * H * W * MS;
 
     float acc[CO];
 #pragma unroll
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ mer
             if (xx < 0 || xx >= W2) continue;
             // large1[yy][xx][k] = merge[yy/2][xx/2][((yy&1)*2+(xx&1))*12 + k]   (model/pfnl.py:76)
             const float4* src = reinterpret_cast<const float4*>(
-                mb + ((size_t)(yy >> 1) * W + (xx >> 1)) * 48 + ((yy & 1) * 2 + (xx & 1)) * 12);
+                mb + ((size_t)(yy >> 1) * W + (xx >> 1)) * MS + ((yy & 1) * 2 + (xx & 1)) * 12);
             const float4 v0 = src[0], v1 = src[1], v2 = src[2];
             const float v[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
             const float* wp = w2 + (dy * 3 + dx) * 12 * CO;
@@ -210,12 +210,13 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ mer
 }
 
 hipError_t launch_tail(const float* merge, const float* x, const float* w2, const float* b2, float* out,
-                       int B, int T, int H, int W, int scale, hipStream_t s) {
+                       int B, int T, int H, int W, int scale, int merge_cstride, hipStream_t s) {
+    if (merge_cstride != 48 && merge_cstride != 64) return hipErrorInvalidValue;
     dim3 grid((2 * W + 31) / 32, (2 * H + 7) / 8, B);
     if (scale == 4)
-        hipLaunchKernelGGL(tail_kernel<12>, grid, dim3(256), 0, s, merge, x, w2, b2, out, B, T, H, W);
+        hipLaunchKernelGGL(tail_kernel<12>, grid, dim3(256), 0, s, merge, x, w2, b2, out, B, T, H, W, merge_cstride);
     else if (scale == 2)
-        hipLaunchKernelGGL(tail_kernel<3>, grid, dim3(256), 0, s, merge, x, w2, b2, out, B, T, H, W);
+        hipLaunchKernelGGL(tail_kernel<3>, grid, dim3(256), 0, s, merge, x, w2, b2, out, B, T, H, W, merge_cstride);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
