@@ -37,6 +37,8 @@ def main():
     tot_b = 0.0
     tot_n = 0
     for k in f:
+        if "<true> [short]" in k:      # convmerge1's accumulating launches (4 items, fused): not the conv3x3 class of bench.py
+            continue
         n = f[k][0]
         fb = f[k][1] / n * 1024 * 2
         wb = w[k][1] / w[k][0] * 1024
