@@ -94,9 +94,12 @@ int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes);
 int pfnl_sync(pfnl_handle* h);
 
 /* ---- measurement ------------------------------------------------------------------------- */
-/* Per-kernel-class HIP-event timing on the launch stream.  enable!=0: every launch of the
- * classes below is bracketed by hipEvents until disabled; pfnl_profile_read synchronises and
- * returns accumulated milliseconds and launch counts since the last reset. */
+/* Per-kernel-class HIP-event timing on the launch stream.  enable = 1: every launch of the classes
+ * below is bracketed by hipEvents until disabled; enable = 2: the same for the launches outside the
+ * progressive-fusion blocks and for every 4th block (blocks are identical, so average launch durations
+ * are unbiased; ~30 instead of ~95 events per forward - each event costs the stream ~2 us);
+ * pfnl_profile_read synchronises and returns accumulated milliseconds and the number of TIMED launches
+ * since the last reset. */
 enum {
     PFNL_K_NL_PACK = 0, PFNL_K_NL_ATTN = 1, PFNL_K_CONV0 = 2, PFNL_K_CONV3X3 = 3,
     PFNL_K_CONV1X1 = 4, PFNL_K_MERGE1 = 5, PFNL_K_TAIL = 6, PFNL_K_COUNT = 7

@@ -79,6 +79,8 @@ struct pfnl_handle {
     // profiling: boundary events.  One event after every kernel launch (plus one at the start of a
     // forward); a launch's time = its event - the previous event, i.e. kernel + the gap before it.
     bool prof = false;
+    int prof_mode = 0;                // 1: every launch; 2: every launch outside the PF blocks + every 4th PF block
+    bool prof_gate = true;            // events are recorded for the launches issued now
     bool chain_open = false;          // an event has been recorded in the current forward
     std::vector<hipEvent_t> evs;
     std::vector<int> ev_cls;          // class of the interval ENDING at event i (-1: chain start)
@@ -107,13 +109,13 @@ struct ProfScope {
     hipStream_t s;
     int cls;
     ProfScope(pfnl_handle* h_, hipStream_t s_, int cls_) : h(h_), s(s_), cls(cls_) {
-        if (h && h->prof && !h->chain_open) {
+        if (h && h->prof && h->prof_gate && !h->chain_open) {
             prof_mark(h, s, -1);
             h->chain_open = true;
         }
     }
     ~ProfScope() {
-        if (h && h->prof) prof_mark(h, s, cls);
+        if (h && h->prof && h->prof_gate) prof_mark(h, s, cls);
     }
 };
 
@@ -192,6 +194,10 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
     p.in_cstride = 64;
     p.chunks_per_frame = 64 / CONV_CK;
     for (int i = 0; i < c.num_block; ++i) {   // model/pfnl.py:65-71
+        if (h->prof_mode == 2) {          // sampled profiling: blocks 0, 4, 8, ... each with a fresh event chain
+            h->prof_gate = (i & 3) == 0;
+            h->chain_open = false;
+        }
         {   // conv1_i: per frame 3x3 64->64 + lrelu                       (:66)
             ProfScope ps(h, s, PFNL_K_CONV3X3);
             p.in = h->inp0.p;
@@ -269,6 +275,8 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             }
         }
     }
+    h->prof_gate = true;
+    if (h->prof_mode == 2) h->chain_open = false;
     const bool m1_wino = h->conv_algo == 3 && (long long)H * W * 256 < 0x7fffffffLL;
     const int mstride = m1_wino ? 64 : 48;
     h->merge_cstride = mstride;
@@ -599,6 +607,8 @@ int pfnl_profile_enable(pfnl_handle* h, int enable) {
         if (prof_collect(h)) return fail(PFNL_ERR_HIP, "event collection failed");
     }
     h->prof = enable != 0;
+    h->prof_mode = enable == 2 ? 2 : (enable ? 1 : 0);
+    h->prof_gate = true;
     return 0;
 }
 

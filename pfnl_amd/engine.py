@@ -126,8 +126,9 @@ class PFNLEngine:
         return n.value
 
     # ---- measurement / debugging ---------------------------------------------------------------
-    def profile(self, enable: bool) -> None:
-        _capi.check(self._lib.pfnl_profile_enable(self._h, 1 if enable else 0))
+    def profile(self, enable) -> None:
+        """False/0: off; True/1: HIP events around every launch; 2: sampled (every 4th PF block)."""
+        _capi.check(self._lib.pfnl_profile_enable(self._h, int(enable)))
 
     def profile_reset(self) -> None:
         _capi.check(self._lib.pfnl_profile_reset(self._h))

@@ -207,3 +207,24 @@ def test_1080p_single_clip_runs():
     assert abs(float(y.mean()) - float(x[:, 3].mean())) < 0.2
     # batch independence at this size: a 64x480 strip cannot be compared (non-local is global), so compare determinism
     assert np.array_equal(eng.forward(x), y)
+
+
+def test_profile_counts_full_and_sampled():
+    """pfnl_profile_*: mode 1 brackets every launch (3 conv3x3-class and 1 conv10 launch per PF block),
+    mode 2 only every 4th block; outputs are unaffected."""
+    geom = PFNLGeometry(num_block=6)
+    eng = engine_for(geom)
+    x = synth.uniform_clips(1, 7, 16, 32, seed=5)
+    y0 = eng.forward(x)
+    for mode, blocks in ((1, 6), (2, 2)):            # blocks 0 and 4 are timed in sampled mode
+        eng.profile_reset()
+        eng.profile(mode)
+        y = eng.forward(x)
+        eng.profile(0)
+        p = eng.profile_read()
+        assert np.array_equal(y, y0)
+        assert p["conv3x3"]["launches"] == 3 * blocks and p["conv1x1"]["launches"] == blocks
+        assert p["tail"]["launches"] == 1 and p["conv0"]["launches"] == 1
+        assert all(v["ms"] > 0 for k, v in p.items() if v["launches"])
+    eng.profile_reset()
+    assert sum(v["launches"] for v in eng.profile_read().values()) == 0
