@@ -170,7 +170,9 @@ def main():
     roof = None
     if k["launches"]:
         avg_ms = k["ms"] / k["launches"]                              # over the launches that were timed
-        launches_per_step = 3 * geom.num_block                        # conv1_i, conv2_i shared half, conv2_i per-frame half
+        # conv1_i + conv2_i: the default kernel runs the whole of conv2_i as one grouped launch; the others
+        # launch its shared half and its per-frame half separately
+        launches_per_step = (2 if algo == "winograd" else 3) * geom.num_block
         flops_per_launch = flops3 / launches_per_step
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         executed = achieved / 2.25 if algo.startswith("winograd") else achieved

@@ -80,6 +80,7 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *   "winograd16"    same maths, one wave per SIMD owning all 16 positions (experimental, slower);
  *   "direct"        implicit-GEMM f32 MFMA (conv_mfma.hip).
  * key "conv1x1" = "stream" (default, conv1x1.hip) | "tiled" (conv_mfma.hip).
+ * key "conv2"   = "grouped" (default with conv3x3=winograd: one launch per block, shared half in LDS) | "split".
  * The default can also be set with the environment variable PFNL_CONV3X3 read by pfnl_create. */
 int pfnl_set_option(pfnl_handle* h, const char* key, const char* value);
 
@@ -125,6 +126,13 @@ int pfnl_op_conv2d(const float* in, const float* kernel_host, const float* bias_
                    const float* addend, int add_div, const float* resid, float* out,
                    int items, int frames_per_item, int H, int W, int ksize, int cout, int act,
                    void* stream);
+/* The whole of conv2_i (reference model/pfnl.py:51, :69-71) in one launch of the persistent Winograd kernel:
+ * out[c*T+t] = resid[c*T+t] + act(conv3x3(concat([base[c], in[c*T+t]]); kernel) + bias), the base half computed
+ * once per clip and tile and kept in LDS.  in/resid/out [clips*T, H, W, 64], base [clips, H, W, 64],
+ * kernel_host HWIO [3,3,128,64]; out may alias resid. */
+int pfnl_op_conv2_grouped(const float* in, const float* base, const float* kernel_host, const float* bias_host,
+                          const float* resid, float* out, int clips, int frames_per_clip, int H, int W, int act,
+                          void* stream);
 /* conv10_i (reference model/pfnl.py:50, :67-68): the 1x1, (frames_per_item*64) -> 64 convolution through
  * the streaming kernel that reads its A operand straight from HBM (no LDS; conv1x1.hip).
  * in [items*frames_per_item, HW, 64], kernel_host HWIO [1,1,64*fpi,64], out [items, HW, 64]. */

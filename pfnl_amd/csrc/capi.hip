@@ -59,6 +59,7 @@ struct pfnl_handle {
     std::map<std::string, std::vector<int64_t>> expected;   // tf name -> shape
     std::map<std::string, HostTensor> host;                  // tensors received so far
     bool finalized = false;
+    bool conv2_grouped = true;                                // winograd: conv2_i as one grouped launch (option conv2=grouped|split)
     int merge_cstride = 48;                                   // floats per pixel of `merge` as written by the last forward
     int conv1x1_algo = 1;                                     // conv10: 1 streaming kernel (conv1x1.hip), 0 LDS-tiled implicit GEMM
     int conv_algo = 3;                                        // conv3x3: 0 direct, 1 winograd (4 waves / tile), 2 winograd16 (1 wave / SIMD), 3 winograd_ws (persistent, wave-specialised)
@@ -234,6 +235,26 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
                 HIPCHK(launch_conv1x1_stream(p.in, wd + h->off_c10_s[i], p.bias, p.out, B, T, H * W, 1, s));
             else
                 HIPCHK(launch_conv_mfma(p, 1, B, s));
+        }
+        const bool conv2_grouped = h->conv_algo == 3 && h->conv2_grouped && (long long)H * W * 256 < 0x7fffffffLL;
+        if (conv2_grouped) {
+            // the whole of conv2_i in one launch: per (clip, tile) the shared half stays in LDS (conv_wino_ws MODE 2)
+            ProfScope ps(h, s, PFNL_K_CONV3X3);
+            WinoParams wp{};
+            wp.in = h->inp1.p;
+            wp.in2 = h->base.p;
+            wp.upack = wd + h->off_c2b_u[i];
+            wp.upack2 = wd + h->off_c2a_u[i];
+            wp.bias = wd + h->off_c2_b[i];
+            wp.resid = h->inp0.p;
+            wp.out = h->inp0.p;
+            wp.H = H;
+            wp.W = W;
+            wp.add_div = T;
+            wp.act = 1;
+            wp.items = F;
+            HIPCHK(launch_conv_wino_ws(wp, s));
+            continue;
         }
         {   // conv2_i, shared half: 3x3 over `base` (kernel rows 0..63), once per clip, raw
             ProfScope ps(h, s, PFNL_K_CONV3X3);
@@ -422,6 +443,12 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         else if (v == "winograd16") h->conv_algo = 2;
         else if (v == "direct") h->conv_algo = 0;
         else return fail(PFNL_ERR_INVALID, "conv3x3 must be winograd, winograd_tile, winograd16 or direct");
+        return 0;
+    }
+    if (k == "conv2") {
+        if (v == "grouped") h->conv2_grouped = true;
+        else if (v == "split") h->conv2_grouped = false;
+        else return fail(PFNL_ERR_INVALID, "conv2 must be grouped or split");
         return 0;
     }
     if (k == "conv1x1") {
@@ -708,6 +735,44 @@ int pfnl_op_conv2d(const float* in, const float* kernel_host, const float* bias_
     }
     hipFree(dw);
     if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv op: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int pfnl_op_conv2_grouped(const float* in, const float* base, const float* kernel_host, const float* bias_host,
+                          const float* resid, float* out, int clips, int frames_per_clip, int H, int W, int act,
+                          void* stream) {
+    if (!in || !base || !kernel_host || !resid || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (clips < 1 || frames_per_clip < 1 || H < 2 || W < 2 || (H & 1) || (W & 1))
+        return fail(PFNL_ERR_INVALID, "grouped conv2 needs even H, W");
+    if ((long long)H * W * 256 >= 0x7fffffffLL) return fail(PFNL_ERR_INVALID, "frame too large for the grouped kernel");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t pf = pfnl::wino_pack_floats();
+    std::vector<float> pack(2 * pf + 64, 0.f);
+    pfnl::wino_pack_weights(kernel_host, 128, 0, pack.data());            // rows 0..63 multiply `base`
+    pfnl::wino_pack_weights(kernel_host, 128, 64, pack.data() + pf);      // rows 64..127 multiply the frame
+    if (bias_host) std::memcpy(&pack[2 * pf], bias_host, 64 * sizeof(float));
+    float* dw = nullptr;
+    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(float)));
+    hipError_t e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        pfnl::WinoParams wp{};
+        wp.in = in;
+        wp.in2 = base;
+        wp.upack = dw + pf;
+        wp.upack2 = dw;
+        wp.bias = dw + 2 * pf;
+        wp.resid = resid;
+        wp.out = out;
+        wp.H = H;
+        wp.W = W;
+        wp.add_div = frames_per_clip;
+        wp.act = act;
+        wp.items = clips * frames_per_clip;
+        e = pfnl::launch_conv_wino_ws(wp, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    (void)hipFree(dw);
+    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("grouped conv2 op: ") + hipGetErrorString(e));
     return 0;
 }
 

@@ -42,10 +42,17 @@ static_assert((WS_RAW_FLOATS * sizeof(float)) % 16 == 0, "slab must stay 16-byte
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool FUSE>
+// MODE 0: out = act(conv + bias).   MODE 1: out = act(conv + bias + addend[item / add_div]) + resid.
+// MODE 2 (the whole of conv2_i, reference model/pfnl.py:69-71): per clip and spatial tile one workgroup runs
+//   unit 0      : raw 3x3 conv of `in2` (= base, kernel rows 0..63 = upack2) -> kept in LDS (`pbl`)
+//   units 1..T  : 3x3 conv of frame t of `in` (kernel rows 64..127 = upack) + pbl + bias, act, + resid -> out
+// so the shared half never goes to HBM and needs no launch of its own (T = add_div).
+template <int MODE>
 __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams p) {
+    constexpr bool FUSE = MODE >= 1, GROUPED = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const slabm = smem + WS_RAW_FLOATS;
+    float* const pbl = slabm + 4 * WS_SLAB_XI;                      // MODE 2: [4 rows][32 cols][64] addend tile
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -56,7 +63,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
     const int tiles_x = (W + 2 * WN_TX - 1) / (2 * WN_TX);
     const int tiles_y = (H + 2 * WN_TY - 1) / (2 * WN_TY);
     const int per_item = tiles_x * tiles_y;
-    const int ntiles = per_item * p.items;
+    const int gT = GROUPED ? p.add_div : 0;                         // frames per clip (units per group = gT + 1)
+    const int ntiles = GROUPED ? per_item * (p.items / p.add_div) : per_item * p.items;   // MODE 2: (clip, tile) groups
     const int rs = (ntiles + 7) >> 3;
     const int xcd = blockIdx.x & 7;
     const int j = blockIdx.x >> 3;
@@ -64,19 +72,32 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
     const int tbeg = xcd * rs;
     const int tcnt = min(rs, ntiles - tbeg);
     if (j >= tcnt) return;
-    const int nu = (tcnt - j + wpx - 1) / wpx;
+    const int nu = ((tcnt - j + wpx - 1) / wpx) * (gT + 1);
     // Tile order.  Plain launches: item-major.  Fused launches (conv2): the add_div frames of a clip at the
     // same spatial tile are consecutive, so the shared addend tile (`pb`, one per clip) is read from HBM once
     // and then from L2 (measured before: 359 MB fetched per launch against 252 MB compulsory).
-    const int grp = (FUSE && p.add_div > 1 && p.items % p.add_div == 0) ? p.add_div : 1;
+    const int grp = (MODE == 1 && p.add_div > 1 && p.items % p.add_div == 0) ? p.add_div : 1;
     const int per_grp = per_item * grp;
-#define WS_UNIT(i_, item_, y0_, x0_)                                  \
+    // unit i of this workgroup -> (input item, tile origin, is it the shared-half unit of MODE 2)
+#define WS_UNIT(i_, item_, y0_, x0_, pb_)                             \
     do {                                                              \
-        const int t_ = tbeg + j + (i_) * wpx;                         \
-        const int c_ = t_ / per_grp;                                  \
-        const int r_ = t_ - c_ * per_grp;                             \
-        const int sp_ = r_ / grp;                                     \
-        item_ = c_ * grp + (r_ - sp_ * grp);                          \
+        int sp_;                                                      \
+        if (GROUPED) {                                                \
+            const int gi_ = (i_) / (gT + 1);                          \
+            const int u_ = (i_) - gi_ * (gT + 1);                     \
+            const int t_ = tbeg + j + gi_ * wpx;                      \
+            const int c_ = t_ / per_item;                             \
+            sp_ = t_ - c_ * per_item;                                 \
+            pb_ = u_ == 0;                                            \
+            item_ = pb_ ? c_ : c_ * gT + u_ - 1;                      \
+        } else {                                                      \
+            const int t_ = tbeg + j + (i_) * wpx;                     \
+            const int c_ = t_ / per_grp;                              \
+            const int r_ = t_ - c_ * per_grp;                         \
+            sp_ = r_ / grp;                                           \
+            item_ = c_ * grp + (r_ - sp_ * grp);                      \
+            pb_ = false;                                              \
+        }                                                             \
         const int by_ = sp_ / tiles_x;                                \
         y0_ = by_ * (2 * WN_TY);                                      \
         x0_ = (sp_ - by_ * tiles_x) * (2 * WN_TX);                    \
@@ -103,11 +124,22 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
 
         constexpr int KS_F4 = 64;                                   // float4 per (chunk, xi, N-tile, kk)
         constexpr int UP_CHUNK_F4 = 4 * 2 * 8 * KS_F4;
+        // one descriptor over both weight packs of MODE 2 (they live in one blob); the pack is chosen per
+        // unit through the scalar offset
+        const float* ubase = (GROUPED && p.upack2 < p.upack) ? p.upack2 : p.upack;
+        const int uoffB = (int)((p.upack - ubase) * sizeof(float));
+        const int uoffA = GROUPED ? (int)((p.upack2 - ubase) * sizeof(float)) : uoffB;
         const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(p.upack), 0, (int)(wino_pack_floats_c * sizeof(float)), 0x00020000);
+            const_cast<float*>(ubase), 0, max(uoffA, uoffB) + (int)(wino_pack_floats_c * sizeof(float)), 0x00020000);
+        int mu = 0;                                                 // MODE 2: position of the current unit in its group
+        int uoff_cur = GROUPED ? uoffA : uoffB, uoff_nxt = uoffB;
         const int uvoff = ((xi * 2 * 8) * KS_F4 + lane) * 16;
-#define WS_USTEP(s_, g_) \
-    __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, uvoff, ((((s_) & 31) >> 3) * UP_CHUNK_F4 + ((g_) * 8 + ((s_) & 7)) * KS_F4) * 16, 0))
+#define WS_USTEP(s_, g_)                                                                          \
+    __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                              \
+                                  urs, uvoff,                                                     \
+                                  ((s_) < 32 ? uoff_cur : uoff_nxt) +                             \
+                                      ((((s_) & 31) >> 3) * UP_CHUNK_F4 + ((g_) * 8 + ((s_) & 7)) * KS_F4) * 16, \
+                                  0))
         f32x4 ring0[WS_UD], ring1[WS_UD];
 #pragma unroll
         for (int d = 0; d < WS_UD; ++d) {
@@ -212,6 +244,11 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
                 }
             }
             WS_STAMP();
+            if (GROUPED) {                                          // weight pack of the next unit / the one after
+                mu = mu == gT ? 0 : mu + 1;
+                uoff_cur = uoff_nxt;
+                uoff_nxt = mu == gT ? uoffA : uoffB;
+            }
         }
         __syncthreads();                                            // the last tile's slab is complete
 #undef WS_STEP2
@@ -259,9 +296,10 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
 #define WS_DESC(i_)                                                                              \
     do {                                                                                         \
         int item_, y0_, x0_;                                                                     \
-        WS_UNIT(i_, item_, y0_, x0_);                                                            \
-        rsLN = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (size_t)item_ * in_stride, 0, item_bytes, \
-                                                0x00020000);                                     \
+        bool pb_;                                                                                \
+        WS_UNIT(i_, item_, y0_, x0_, pb_);                                                       \
+        rsLN = __builtin_amdgcn_make_buffer_rsrc(                                                \
+            const_cast<float*>(pb_ ? p.in2 : p.in) + (size_t)item_ * in_stride, 0, item_bytes, 0x00020000); \
         const int org_ = (y0_ * W + x0_) * 256;                                                  \
         if (y0_ > 0 && y0_ + WN_IH - 1 <= H && x0_ > 0 && x0_ + WN_IW - 1 <= W) {   /* interior tile: uniform branch */ \
             _Pragma("unroll") for (int k_ = 0; k_ < WN_IN_ITERS; ++k_) goffN[k_] = org_ + relk[k_]; \
@@ -303,27 +341,31 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
     const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + c4 * 4);
     const float slope = p.act ? 0.2f : 1.0f;
     int n_y0 = 0, n_x0 = 0;
+    bool e_pb = false, n_pb = false;                                // MODE 2: the epilogue tile is the shared-half unit
     __amdgpu_buffer_rsrc_t rsOut = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, item_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsRes = rsOut, rsAdd = rsOut, rsOutN = rsOut, rsResN = rsOut, rsAddN = rsOut;
     f32x4 av[4][2], rv[4][2];
 #define WS_EPI_UNIT(i_)                                                                          \
     do {                                                                                         \
         int item_;                                                                               \
-        WS_UNIT(i_, item_, n_y0, n_x0);                                                          \
+        WS_UNIT(i_, item_, n_y0, n_x0, n_pb);                                                    \
+        if (n_pb) item_ = 0;                                    /* its result stays in LDS */     \
         rsOutN = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)item_ * H * W * 64, 0, item_bytes, 0x00020000); \
         if (FUSE) {                                                                              \
             rsResN = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid) + (size_t)item_ * H * W * 64, 0, \
                                                       item_bytes, 0x00020000);                   \
-            rsAddN = __builtin_amdgcn_make_buffer_rsrc(                                           \
-                const_cast<float*>(p.addend) + (size_t)(item_ / p.add_div) * H * W * 64, 0, item_bytes, 0x00020000); \
+            if (!GROUPED)                                                                        \
+                rsAddN = __builtin_amdgcn_make_buffer_rsrc(                                      \
+                    const_cast<float*>(p.addend) + (size_t)(item_ / p.add_div) * H * W * 64, 0, item_bytes, 0x00020000); \
         }                                                                                        \
     } while (0)
 #define WS_EPI_COMMIT()                                                                          \
     do {                                                                                         \
         rsOut = rsOutN;                                                                          \
+        e_pb = n_pb;                                                                             \
         if (FUSE) {                                                                              \
             rsRes = rsResN;                                                                      \
-            rsAdd = rsAddN;                                                                      \
+            if (!GROUPED) rsAdd = rsAddN;                                                        \
         }                                                                                        \
         _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) eoff[k_] = eoffN[k_];                   \
     } while (0)
@@ -346,9 +388,10 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
     } while (0)
 #define WS_EPI_LOAD(k_)                                                                          \
     do {                                                                                         \
-        if (FUSE) {                                                                              \
+        if (FUSE && !(GROUPED && e_pb)) {                                                        \
             _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                                   \
-                av[k_][r_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAdd, eoff[k_], r_ * rowb, 0)); \
+                if (!GROUPED)                                                                    \
+                    av[k_][r_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAdd, eoff[k_], r_ * rowb, 0)); \
                 rv[k_][r_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsRes, eoff[k_], r_ * rowb, 0)); \
             }                                                                                    \
         }                                                                                        \
@@ -364,9 +407,16 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
         f32x4 yv_[2];                                                                            \
         yv_[0] = r0_ + r1_ + r2_;                               /* row transform over xi */      \
         yv_[1] = r1_ - (r2_ + r3_);                                                              \
+        /* MODE 2: this item's two pixels in the LDS addend tile [row][col][64] */               \
+        f32x4* pl_ = reinterpret_cast<f32x4*>(pbl + ((2 * ((id_ >> 5) >> 4)) * 32 + 2 * ((id_ >> 5) & 15) + ((id_ >> 4) & 1)) * 64 + c4 * 4); \
+        if (GROUPED && e_pb) {                                  /* shared-half unit: raw result -> LDS, nothing else */ \
+            pl_[0] = yv_[0];                                                                     \
+            pl_[32 * 16] = yv_[1];                                                               \
+        } else                                                                                   \
         _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                                       \
             f32x4 o_ = yv_[r_] + bias4;                                                          \
-            if (FUSE) o_ += av[k_][r_];                                                          \
+            if (GROUPED) o_ += pl_[r_ * 32 * 16];                                                \
+            else if (FUSE) o_ += av[k_][r_];                                                     \
             const f32x4 so_ = o_ * slope;                                                        \
             o_.x = fmaxf(o_.x, so_.x);                                                           \
             o_.y = fmaxf(o_.y, so_.y);                                                           \
@@ -454,32 +504,37 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
 #undef WS_UNIT
 }
 
-template <bool FUSE>
+template <int MODE>
 static hipError_t launch_ws_variant(const WinoParams& p, int nblocks, hipStream_t s) {
+    constexpr size_t WS_LDS = WS_LDS_BYTES + (MODE == 2 ? 4 * 32 * 64 * sizeof(float) : 0);
     static bool attr_set[64] = {false};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_ws_kernel<FUSE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_ws_kernel<MODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS);
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((conv_wino_ws_kernel<FUSE>), dim3(nblocks), dim3(WS_THREADS), WS_LDS_BYTES, s, p);
+    hipLaunchKernelGGL((conv_wino_ws_kernel<MODE>), dim3(nblocks), dim3(WS_THREADS), WS_LDS, s, p);
     return hipGetLastError();
 }
 
 hipError_t launch_conv_wino_ws(const WinoParams& p, hipStream_t s) {
     if (!p.bias || !p.in || !p.upack || !p.out || p.items < 1) return hipErrorInvalidValue;
     const bool fuse = p.addend != nullptr || p.resid != nullptr;
-    if (fuse && (!p.addend || !p.resid || p.add_div < 1)) return hipErrorInvalidValue;
+    if (fuse && !p.in2 && (!p.addend || !p.resid || p.add_div < 1)) return hipErrorInvalidValue;
     if ((p.H & 1) || (p.W & 1)) return hipErrorInvalidValue;
     if ((long long)p.H * p.W * 256 >= 0x7fffffffLL && !p.in_item_stride) return launch_conv_wino(p, s);   // 32-bit buffer offsets per item: per-tile kernel instead
-    const int ntiles = ((p.W + 2 * WN_TX - 1) / (2 * WN_TX)) * ((p.H + 2 * WN_TY - 1) / (2 * WN_TY)) * p.items;
+    const bool grouped = p.in2 != nullptr;
+    if (grouped && (!p.upack2 || !p.resid || p.addend || p.add_div < 1 || p.items % p.add_div)) return hipErrorInvalidValue;
+    const int per_item = ((p.W + 2 * WN_TX - 1) / (2 * WN_TX)) * ((p.H + 2 * WN_TY - 1) / (2 * WN_TY));
+    const int ntiles = per_item * (grouped ? p.items / p.add_div : p.items);        // MODE 2: (clip, tile) groups
     const int rs = (ntiles + 7) / 8;
     const int wpx = rs < WS_MAX_WG_PER_XCD ? rs : WS_MAX_WG_PER_XCD;
-    return fuse ? launch_ws_variant<true>(p, 8 * wpx, s) : launch_ws_variant<false>(p, 8 * wpx, s);
+    if (grouped) return launch_ws_variant<2>(p, 8 * wpx, s);
+    return fuse ? launch_ws_variant<1>(p, 8 * wpx, s) : launch_ws_variant<0>(p, 8 * wpx, s);
 }
 
 }  // namespace pfnl

@@ -52,6 +52,25 @@ def conv2d(x, kernel, bias=None, act=True, frames_per_item=1, addend=None, add_d
     return out
 
 
+def conv2_grouped(x, base, kernel, bias, resid, frames_per_clip, act=True):
+    """conv2_i of the reference in one launch: resid + act(conv3x3(concat([base[clip], x[frame]])) + bias).
+    x/resid [clips*T, H, W, 64], base [clips, H, W, 64] (cuda); kernel HWIO [3,3,128,64].
+    Reference: model/pfnl.py:51, :69-71."""
+    import torch
+    lib = _capi.load_library()
+    k = _host(kernel, "kernel")
+    b = _host(bias, "bias")
+    F, H, W, c = x.shape
+    if k.shape != (3, 3, 128, 64) or c != 64 or F % frames_per_clip or base.shape != (F // frames_per_clip, H, W, 64):
+        raise ValueError("conv2_grouped: geometry mismatch")
+    out = torch.empty_like(x)
+    _capi.check(lib.pfnl_op_conv2_grouped(
+        _req(x, "x"), _req(base, "base"), k.ctypes.data_as(C.c_void_p),
+        b.ctypes.data_as(C.c_void_p) if b is not None else None, _req(resid, "resid"), _req(out, "out"),
+        F // frames_per_clip, frames_per_clip, H, W, 1 if act else 0, _stream(x)))
+    return out
+
+
 def conv1x1_stream(x, kernel, bias=None, act=True, frames_per_item=1):
     """conv10_i: 1x1 over the concat of `frames_per_item` frames, (64*fpi) -> 64, streaming kernel.
     x: [items*fpi, H, W, 64] (cuda); kernel HWIO [1,1,64*fpi,64].  Reference: model/pfnl.py:50, :67-68."""

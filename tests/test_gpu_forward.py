@@ -188,8 +188,9 @@ def test_random_geometry_fuzz(seed):
     eng = PFNLEngine(geom)
     eng.load_weights(w)
     ref = pfnl_fast.FastOracle(w, T, scale, nb).forward(x)
-    for algo in ("winograd", "winograd_tile", "direct"):
-        eng.set_option("conv3x3", algo)
+    for algo in ("winograd", "winograd_split", "winograd_tile", "direct"):
+        eng.set_option("conv3x3", "winograd" if algo == "winograd_split" else algo)
+        eng.set_option("conv2", "split" if algo == "winograd_split" else "grouped")
         y = eng.forward(x)
         assert y.shape == ref.shape
         assert np.abs(y - ref).max() < ABS_TOL, (algo, T, scale, nb, B, H, W, np.abs(y - ref).max())
@@ -210,8 +211,8 @@ def test_1080p_single_clip_runs():
 
 
 def test_profile_counts_full_and_sampled():
-    """pfnl_profile_*: mode 1 brackets every launch (3 conv3x3-class and 1 conv10 launch per PF block),
-    mode 2 only every 4th block; outputs are unaffected."""
+    """pfnl_profile_*: mode 1 brackets every launch (conv1_i + grouped conv2_i = 2 conv3x3-class launches and
+    1 conv10 launch per PF block), mode 2 only every 4th block; outputs are unaffected."""
     geom = PFNLGeometry(num_block=6)
     eng = engine_for(geom)
     x = synth.uniform_clips(1, 7, 16, 32, seed=5)
@@ -223,7 +224,7 @@ def test_profile_counts_full_and_sampled():
         eng.profile(0)
         p = eng.profile_read()
         assert np.array_equal(y, y0)
-        assert p["conv3x3"]["launches"] == 3 * blocks and p["conv1x1"]["launches"] == blocks
+        assert p["conv3x3"]["launches"] == 2 * blocks and p["conv1x1"]["launches"] == blocks
         assert p["tail"]["launches"] == 1 and p["conv0"]["launches"] == 1
         assert all(v["ms"] > 0 for k, v in p.items() if v["launches"])
     eng.profile_reset()

@@ -74,6 +74,28 @@ def test_conv_mfma(items, fpi, H, W, ks, cout, act, fused, mt, monkeypatch):
     assert err < 5e-6 * max(1.0, np.abs(ref).max()), err
 
 
+@pytest.mark.parametrize("clips,T,H,W", [
+    (1, 7, 4, 32),        # one tile, one group
+    (2, 7, 20, 36),       # ragged tiles, two clips
+    (3, 3, 6, 70),        # T = 3
+    (1, 5, 2, 2),         # a single 2x2 tile: everything is halo
+    (4, 7, 64, 64),       # several groups per workgroup
+])
+def test_conv2_grouped(clips, T, H, W):
+    """conv2_i as written in the reference: conv over concat([base, frame]) (model/pfnl.py:69-71)."""
+    rng = np.random.default_rng(clips * 100 + T * 10 + H + W)
+    x = rng.normal(size=(clips * T, H, W, 64)).astype(np.float32)
+    base = rng.normal(size=(clips, H, W, 64)).astype(np.float32)
+    res = rng.normal(size=(clips * T, H, W, 64)).astype(np.float32)
+    k = (rng.normal(size=(3, 3, 128, 64)) / 34).astype(np.float32)
+    b = rng.normal(size=64).astype(np.float32)
+    cat = np.concatenate([np.repeat(base, T, axis=0), x], axis=-1)
+    ref = res + pfnl_spec.lrelu(pfnl_spec.conv2d_same(cat.astype(np.float64), k.astype(np.float64), b.astype(np.float64)))
+    got = ops.conv2_grouped(dev(x), dev(base), k, b, dev(res), T).cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize("items,fpi,H,W,act", [
     (2, 7, 16, 40, True),        # conv10 at T = 7
     (1, 5, 6, 8, True),          # T = 5, 48 pixels: one full + one ragged wave
