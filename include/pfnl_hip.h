@@ -133,6 +133,11 @@ int pfnl_op_conv2d(const float* in, const float* kernel_host, const float* bias_
 int pfnl_op_conv2_grouped(const float* in, const float* base, const float* kernel_host, const float* bias_host,
                           const float* resid, float* out, int clips, int frames_per_clip, int H, int W, int act,
                           void* stream);
+/* convmerge1 (reference model/pfnl.py:52, :73-74): 3x3 convolution over the concat of frames_per_clip frames,
+ * (64*fpc) -> cout <= 64, as ONE launch of the persistent Winograd kernel in its accumulating mode.
+ * in [clips*fpc, H, W, 64], kernel_host HWIO [3,3,64*fpc,cout], out [clips, H, W, 64] (channels >= cout: act(0)). */
+int pfnl_op_conv3x3_accum(const float* in, const float* kernel_host, const float* bias_host, float* out, int clips,
+                          int frames_per_clip, int H, int W, int cout, int act, void* stream);
 /* conv10_i (reference model/pfnl.py:50, :67-68): the 1x1, (frames_per_item*64) -> 64 convolution through
  * the streaming kernel that reads its A operand straight from HBM (no LDS; conv1x1.hip).
  * in [items*frames_per_item, HW, 64], kernel_host HWIO [1,1,64*fpi,64], out [items, HW, 64]. */

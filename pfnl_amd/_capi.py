@@ -52,6 +52,7 @@ SIGNATURES = {
     "pfnl_debug_tap": (_i, [_vp, C.c_char_p, _vp, C.c_size_t]),
     "pfnl_op_conv2d": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv2_grouped": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "pfnl_op_conv3x3_accum": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv1x1_stream": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv3x3_winograd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv3x3_winograd_ws": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),

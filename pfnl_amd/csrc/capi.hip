@@ -302,31 +302,23 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
     const int mstride = m1_wino ? 64 : 48;
     h->merge_cstride = mstride;
     if (m1_wino) {
-        // convmerge1 (:73-74) = sum over the T frames of a 3x3 64->48 convolution: T launches of the Winograd
-        // kernel (cout zero-padded to 64) accumulating in `base` (free after the last block) through the fused
-        // epilogue: frames 1..T-2 add the running sum after the (identity) activation, the last frame adds it
-        // BEFORE bias + leaky-relu.  `pb` (also free) is cleared and serves as the zero operand.
+        // convmerge1 (:73-74) = sum over the T frames of a 3x3 64->48 convolution: one launch of the persistent
+        // Winograd kernel in its accumulating mode (cout zero-padded to 64; the T frame tiles of a clip add into
+        // the same accumulators, one epilogue per clip tile)
         ProfScope ps(h, s, PFNL_K_MERGE1);
-        HIPCHK(hipMemsetAsync(h->pb.p, 0, (size_t)B * P * 64 * sizeof(float), s));
-        for (int f = 0; f < T; ++f) {
-            WinoParams wp{};
-            wp.in = h->inp0.p + (size_t)f * P * 64;
-            wp.in_item_stride = (long long)T * P * 64;
-            wp.upack = wd + h->off_m1_u[f];
-            wp.H = H;
-            wp.W = W;
-            wp.items = B;
-            wp.add_div = 1;
-            const bool last = f == T - 1;
-            wp.bias = last ? wd + h->off_m1_b : wd + h->off_zero;
-            wp.act = last ? 1 : 0;
-            wp.out = last ? h->merge.p : h->base.p;
-            if (f > 0) {
-                wp.addend = last ? h->base.p : h->pb.p;
-                wp.resid = last ? h->pb.p : h->base.p;
-            }
-            HIPCHK(launch_conv_wino_ws(wp, s));
-        }
+        WinoParams wp{};
+        wp.in = h->inp0.p;
+        wp.upack = wd + h->off_m1_u[0];
+        wp.upack_stride = T > 1 ? (long long)(h->off_m1_u[1] - h->off_m1_u[0]) : 0;
+        wp.accum = 1;
+        wp.bias = wd + h->off_m1_b;
+        wp.out = h->merge.p;
+        wp.H = H;
+        wp.W = W;
+        wp.items = F;
+        wp.add_div = T;
+        wp.act = 1;
+        HIPCHK(launch_conv_wino_ws(wp, s));
     } else {   // convmerge1: 3x3 over the concat of T frames -> 48 + lrelu        (:73-74)
         ProfScope ps(h, s, PFNL_K_MERGE1);
         p.in = h->inp0.p;
@@ -773,6 +765,42 @@ int pfnl_op_conv2_grouped(const float* in, const float* base, const float* kerne
     }
     (void)hipFree(dw);
     if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("grouped conv2 op: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int pfnl_op_conv3x3_accum(const float* in, const float* kernel_host, const float* bias_host, float* out, int clips,
+                          int frames_per_clip, int H, int W, int cout, int act, void* stream) {
+    if (!in || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (clips < 1 || frames_per_clip < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || cout < 1 || cout > 64)
+        return fail(PFNL_ERR_INVALID, "accumulating conv needs even H, W and cout <= 64");
+    if ((long long)H * W * 256 >= 0x7fffffffLL) return fail(PFNL_ERR_INVALID, "frame too large for the persistent kernel");
+    hipStream_t s = (hipStream_t)stream;
+    const int T = frames_per_clip;
+    const size_t pf = pfnl::wino_pack_floats();
+    std::vector<float> pack(T * pf + 64, 0.f);
+    for (int f = 0; f < T; ++f) pfnl::wino_pack_weights(kernel_host, 64 * T, 64 * f, pack.data() + f * pf, cout);
+    if (bias_host) std::memcpy(&pack[T * pf], bias_host, cout * sizeof(float));
+    float* dw = nullptr;
+    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(float)));
+    hipError_t e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        pfnl::WinoParams wp{};
+        wp.in = in;
+        wp.upack = dw;
+        wp.upack_stride = (long long)pf;
+        wp.accum = 1;
+        wp.bias = dw + T * pf;
+        wp.out = out;
+        wp.H = H;
+        wp.W = W;
+        wp.add_div = T;
+        wp.act = act;
+        wp.items = clips * T;
+        e = pfnl::launch_conv_wino_ws(wp, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    (void)hipFree(dw);
+    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("accumulating conv op: ") + hipGetErrorString(e));
     return 0;
 }
 

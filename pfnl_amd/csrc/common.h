@@ -80,6 +80,8 @@ struct WinoParams {
     long long in_item_stride;   // floats between consecutive input items; 0 = H*W*64 (conv_wino_ws only)
     const float* in2;      // conv_wino_ws MODE 2 (whole conv2_i): base [items/add_div][H][W][64]; else null
     const float* upack2;   // ... and the packed U of the kernel rows that multiply it
+    int accum;             // conv_wino_ws MODE 3 (convmerge1): sum over the add_div frames of a clip, one output per clip
+    long long upack_stride;   // ... floats between the packed U of consecutive frames
 };
 hipError_t launch_conv_wino(const WinoParams& p, hipStream_t s);
 hipError_t launch_conv_wino_ws(const WinoParams& p, hipStream_t s);  // persistent wave-specialised variant (conv_wino_ws.hip), same packed U

@@ -47,9 +47,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 //   unit 0      : raw 3x3 conv of `in2` (= base, kernel rows 0..63 = upack2) -> kept in LDS (`pbl`)
 //   units 1..T  : 3x3 conv of frame t of `in` (kernel rows 64..127 = upack) + pbl + bias, act, + resid -> out
 // so the shared half never goes to HBM and needs no launch of its own (T = add_div).
+// MODE 3 (convmerge1, model/pfnl.py:73-74: a 3x3 conv over the concat of T frames): per clip and spatial tile
+//   units 0..T-1 : frame t of `in` with the weight pack upack + t*upack_stride, all into the SAME accumulators;
+//   only the last unit drops the slab and gets an epilogue: out[clip] = act(sum + bias).
 template <int MODE>
 __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams p) {
-    constexpr bool FUSE = MODE >= 1, GROUPED = MODE == 2;
+    constexpr bool FUSE = MODE == 1 || MODE == 2, GROUPED = MODE == 2, ACCUM = MODE == 3;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const slabm = smem + WS_RAW_FLOATS;
     float* const pbl = slabm + 4 * WS_SLAB_XI;                      // MODE 2: [4 rows][32 cols][64] addend tile
@@ -63,8 +66,9 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
     const int tiles_x = (W + 2 * WN_TX - 1) / (2 * WN_TX);
     const int tiles_y = (H + 2 * WN_TY - 1) / (2 * WN_TY);
     const int per_item = tiles_x * tiles_y;
-    const int gT = GROUPED ? p.add_div : 0;                         // frames per clip (units per group = gT + 1)
-    const int ntiles = GROUPED ? per_item * (p.items / p.add_div) : per_item * p.items;   // MODE 2: (clip, tile) groups
+    const int gT = (GROUPED || ACCUM) ? p.add_div : 0;              // frames per clip
+    const int upg = GROUPED ? gT + 1 : (ACCUM ? gT : 1);            // units per (clip, tile) group
+    const int ntiles = (GROUPED || ACCUM) ? per_item * (p.items / p.add_div) : per_item * p.items;   // MODE 2/3: (clip, tile) groups
     const int rs = (ntiles + 7) >> 3;
     const int xcd = blockIdx.x & 7;
     const int j = blockIdx.x >> 3;
@@ -72,24 +76,26 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
     const int tbeg = xcd * rs;
     const int tcnt = min(rs, ntiles - tbeg);
     if (j >= tcnt) return;
-    const int nu = ((tcnt - j + wpx - 1) / wpx) * (gT + 1);
+    const int nu = ((tcnt - j + wpx - 1) / wpx) * upg;
     // Tile order.  Plain launches: item-major.  Fused launches (conv2): the add_div frames of a clip at the
     // same spatial tile are consecutive, so the shared addend tile (`pb`, one per clip) is read from HBM once
     // and then from L2 (measured before: 359 MB fetched per launch against 252 MB compulsory).
     const int grp = (MODE == 1 && p.add_div > 1 && p.items % p.add_div == 0) ? p.add_div : 1;
     const int per_grp = per_item * grp;
     // unit i of this workgroup -> (input item, tile origin, is it the shared-half unit of MODE 2)
-#define WS_UNIT(i_, item_, y0_, x0_, pb_)                             \
+#define WS_UNIT(i_, item_, y0_, x0_, pb_, fin_)                       \
     do {                                                              \
         int sp_;                                                      \
-        if (GROUPED) {                                                \
-            const int gi_ = (i_) / (gT + 1);                          \
-            const int u_ = (i_) - gi_ * (gT + 1);                     \
+        fin_ = true;                                                  \
+        if (GROUPED || ACCUM) {                                       \
+            const int gi_ = (i_) / upg;                               \
+            const int u_ = (i_) - gi_ * upg;                          \
             const int t_ = tbeg + j + gi_ * wpx;                      \
             const int c_ = t_ / per_item;                             \
             sp_ = t_ - c_ * per_item;                                 \
-            pb_ = u_ == 0;                                            \
-            item_ = pb_ ? c_ : c_ * gT + u_ - 1;                      \
+            pb_ = GROUPED && u_ == 0;                                 \
+            item_ = GROUPED ? (pb_ ? c_ : c_ * gT + u_ - 1) : c_ * gT + u_; \
+            if (ACCUM) fin_ = u_ == gT - 1;                           \
         } else {                                                      \
             const int t_ = tbeg + j + (i_) * wpx;                     \
             const int c_ = t_ / per_grp;                              \
@@ -130,9 +136,13 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
         const int uoffB = (int)((p.upack - ubase) * sizeof(float));
         const int uoffA = GROUPED ? (int)((p.upack2 - ubase) * sizeof(float)) : uoffB;
         const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(ubase), 0, max(uoffA, uoffB) + (int)(wino_pack_floats_c * sizeof(float)), 0x00020000);
+            const_cast<float*>(ubase), 0,
+            max(uoffA, uoffB) + (ACCUM ? (gT - 1) * (int)(p.upack_stride * sizeof(float)) : 0) + (int)(wino_pack_floats_c * sizeof(float)),
+            0x00020000);
         int mu = 0;                                                 // MODE 2: position of the current unit in its group
         int uoff_cur = GROUPED ? uoffA : uoffB, uoff_nxt = uoffB;
+        const int ustride = ACCUM ? (int)(p.upack_stride * sizeof(float)) : 0;
+        if (ACCUM) uoff_nxt = gT > 1 ? ustride : 0;
         const int uvoff = ((xi * 2 * 8) * KS_F4 + lane) * 16;
 #define WS_USTEP(s_, g_)                                                                          \
     __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                              \
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
         f32x2 vA, vB, vC, vD;                                       // (V0,V3), (V1,V2): current / next step
 
         // step s: 8 MFMAs on V_s; raw values of step s+1 read from buffer ((s+1)>>3)&1 and transformed
-#define WS_STEP(s_, c03_, c12_, n03_, n12_)                                                      \
+#define WS_STEPX(s_, z_, c03_, c12_, n03_, n12_)                                                 \
     do {                                                                                         \
         constexpr int d_ = (s_) % WS_UD;                                                         \
         const f32x4 b0_ = ring0[d_], b1_ = ring1[d_];                                            \
@@ -171,12 +181,13 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
         constexpr int n_ = ((s_) + 1) & 31;                                                      \
         constexpr int off_ = (((n_ >> 3) & 1) * WP_BUF + 2 * (n_ & 7) * WP_PS) * 4;              \
         f32x2 x01_, y01_, x23_, y23_;                                                            \
-        wq_kstep_a<off_, (s_) == 0>(acc[0], acc[1], acc[2], acc[3], (c03_).x, (c12_).x, (c12_).y, (c03_).y, b0_, \
+        wq_kstep_a<off_, z_>(acc[0], acc[1], acc[2], acc[3], (c03_).x, (c12_).x, (c12_).y, (c03_).y, b0_, \
                                     x01_, y01_, x23_, y23_, pa, pb);                             \
-        wq_kstep_b<(s_) == 0>(acc[4], acc[5], acc[6], acc[7], (c03_).x, (c12_).x, (c12_).y, (c03_).y, b1_, x01_, \
+        wq_kstep_b<z_>(acc[4], acc[5], acc[6], acc[7], (c03_).x, (c12_).x, (c12_).y, (c03_).y, b1_, x01_, \
                               y01_, x23_, y23_, n03_, n12_, sg2);                                \
         __builtin_amdgcn_sched_barrier(0);                                                       \
     } while (0)
+#define WS_STEP(s_, c03_, c12_, n03_, n12_) WS_STEPX(s_, false, c03_, c12_, n03_, n12_)
 #define WS_STEP2(s_)                       \
     WS_STEP(s_, vA, vB, vC, vD);           \
     WS_STEP((s_) + 1, vC, vD, vA, vB)
@@ -193,7 +204,12 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
             asm volatile("s_nop 4" ::: "memory");                   // VALU write -> MFMA read inside the asm block
         }
         for (int i = 0; i < nu; ++i) {
-            WS_STEP2(0);
+            if (!ACCUM || mu == 0) {                                // first K-step of a tile: C = 0
+                WS_STEPX(0, true, vA, vB, vC, vD);
+            } else {                                                // MODE 3: later frames add to the same accumulators
+                WS_STEPX(0, false, vA, vB, vC, vD);
+            }
+            WS_STEP(1, vC, vD, vA, vB);
             WS_STEP2(2);
             WS_STEP2(4);
             WS_STEP(6, vA, vB, vC, vD);
@@ -228,6 +244,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
             WS_STAMP();
             // column transform over nu (At = [[1,1,1,0],[0,1,-1,-1]]) -> slab[xi][j][tile][cout]
             asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");       // MFMA results of the asm blocks -> VALU reads
+            if (!ACCUM || mu == gT - 1)
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
 #pragma unroll
@@ -248,6 +265,11 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
                 mu = mu == gT ? 0 : mu + 1;
                 uoff_cur = uoff_nxt;
                 uoff_nxt = mu == gT ? uoffA : uoffB;
+            }
+            if (ACCUM) {
+                mu = mu == gT - 1 ? 0 : mu + 1;
+                uoff_cur = uoff_nxt;
+                uoff_nxt = (mu == gT - 1 ? 0 : mu + 1) * ustride;
             }
         }
         __syncthreads();                                            // the last tile's slab is complete
@@ -296,8 +318,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
 #define WS_DESC(i_)                                                                              \
     do {                                                                                         \
         int item_, y0_, x0_;                                                                     \
-        bool pb_;                                                                                \
-        WS_UNIT(i_, item_, y0_, x0_, pb_);                                                       \
+        bool pb_, fin_;                                                                          \
+        WS_UNIT(i_, item_, y0_, x0_, pb_, fin_);                                                 \
         rsLN = __builtin_amdgcn_make_buffer_rsrc(                                                \
             const_cast<float*>(pb_ ? p.in2 : p.in) + (size_t)item_ * in_stride, 0, item_bytes, 0x00020000); \
         const int org_ = (y0_ * W + x0_) * 256;                                                  \
@@ -342,14 +364,16 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
     const float slope = p.act ? 0.2f : 1.0f;
     int n_y0 = 0, n_x0 = 0;
     bool e_pb = false, n_pb = false;                                // MODE 2: the epilogue tile is the shared-half unit
+    bool e_fin = true, n_fin = true;                                // MODE 3: the unit completes its tile (has an epilogue)
     __amdgpu_buffer_rsrc_t rsOut = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, item_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsRes = rsOut, rsAdd = rsOut, rsOutN = rsOut, rsResN = rsOut, rsAddN = rsOut;
     f32x4 av[4][2], rv[4][2];
 #define WS_EPI_UNIT(i_)                                                                          \
     do {                                                                                         \
         int item_;                                                                               \
-        WS_UNIT(i_, item_, n_y0, n_x0, n_pb);                                                    \
+        WS_UNIT(i_, item_, n_y0, n_x0, n_pb, n_fin);                                             \
         if (n_pb) item_ = 0;                                    /* its result stays in LDS */     \
+        if (ACCUM) item_ /= gT;                                 /* one output tile per clip */    \
         rsOutN = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)item_ * H * W * 64, 0, item_bytes, 0x00020000); \
         if (FUSE) {                                                                              \
             rsResN = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid) + (size_t)item_ * H * W * 64, 0, \
@@ -363,6 +387,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
     do {                                                                                         \
         rsOut = rsOutN;                                                                          \
         e_pb = n_pb;                                                                             \
+        e_fin = n_fin;                                                                           \
         if (FUSE) {                                                                              \
             rsRes = rsResN;                                                                      \
             if (!GROUPED) rsAdd = rsAddN;                                                        \
@@ -445,7 +470,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
         // residual; descriptors of the tile after next and this tile's epilogue offsets, into shadow sets
         WS_STORE(1);
         WS_LOAD(1);
-        if (i > 0) {
+        if (i > 0 && e_fin) {
             WS_EPI_LOAD(2);
             WS_EPI_LOAD(3);
         }
@@ -458,7 +483,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
         // phase 1: chunk 2 -> buffer 0; half of the previous tile's epilogue
         WS_STORE(2);
         WS_LOAD(2);
-        if (i > 0) {
+        if (i > 0 && e_fin) {
             WS_EPI(0);
             WS_EPI(1);
         }
@@ -468,7 +493,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
         // phase 2: chunk 3 -> buffer 1
         WS_STORE(3);
         WS_LOAD(3);
-        if (i > 0) WS_EPI(2);
+        if (i > 0 && e_fin) WS_EPI(2);
         WS_STAMP();
         __syncthreads();
         WS_STAMP();
@@ -477,7 +502,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
         WS_STORE(0);
         WS_DESC_COMMIT();
         WS_LOAD(0);
-        if (i > 0) WS_EPI(3);
+        if (i > 0 && e_fin) WS_EPI(3);
         WS_EPI_COMMIT();
         WS_EPI_LOAD(0);
         WS_EPI_LOAD(1);
@@ -528,12 +553,15 @@ hipError_t launch_conv_wino_ws(const WinoParams& p, hipStream_t s) {
     if ((p.H & 1) || (p.W & 1)) return hipErrorInvalidValue;
     if ((long long)p.H * p.W * 256 >= 0x7fffffffLL && !p.in_item_stride) return launch_conv_wino(p, s);   // 32-bit buffer offsets per item: per-tile kernel instead
     const bool grouped = p.in2 != nullptr;
+    const bool accum = p.accum != 0;
+    if (accum && (grouped || fuse || p.add_div < 1 || p.items % p.add_div || p.upack_stride < 0)) return hipErrorInvalidValue;
     if (grouped && (!p.upack2 || !p.resid || p.addend || p.add_div < 1 || p.items % p.add_div)) return hipErrorInvalidValue;
     const int per_item = ((p.W + 2 * WN_TX - 1) / (2 * WN_TX)) * ((p.H + 2 * WN_TY - 1) / (2 * WN_TY));
-    const int ntiles = per_item * (grouped ? p.items / p.add_div : p.items);        // MODE 2: (clip, tile) groups
+    const int ntiles = per_item * ((grouped || accum) ? p.items / p.add_div : p.items);   // MODE 2/3: (clip, tile) groups
     const int rs = (ntiles + 7) / 8;
     const int wpx = rs < WS_MAX_WG_PER_XCD ? rs : WS_MAX_WG_PER_XCD;
     if (grouped) return launch_ws_variant<2>(p, 8 * wpx, s);
+    if (accum) return launch_ws_variant<3>(p, 8 * wpx, s);
     return fuse ? launch_ws_variant<1>(p, 8 * wpx, s) : launch_ws_variant<0>(p, 8 * wpx, s);
 }
 

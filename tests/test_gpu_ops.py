@@ -96,6 +96,25 @@ def test_conv2_grouped(clips, T, H, W):
     assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("clips,T,H,W,cout", [
+    (1, 7, 12, 34, 48),     # convmerge1: 448 -> 48, ragged tiles
+    (2, 5, 4, 32, 48),      # T = 5, exactly one tile per clip
+    (3, 3, 6, 70, 64),      # T = 3, full 64 outputs
+    (4, 7, 32, 64, 48),     # several groups per workgroup
+    (1, 1, 2, 2, 48),       # degenerate: a single frame, a single 2x2 tile
+])
+def test_conv3x3_accum(clips, T, H, W, cout):
+    rng = np.random.default_rng(clips * 100 + T * 10 + H + W)
+    x = rng.normal(size=(clips * T, H, W, 64)).astype(np.float32)
+    k = (rng.normal(size=(3, 3, 64 * T, cout)) / np.sqrt(9 * 64 * T)).astype(np.float32)
+    b = rng.normal(size=cout).astype(np.float32)
+    xin = x.reshape(clips, T, H, W, 64).transpose(0, 2, 3, 1, 4).reshape(clips, H, W, 64 * T)
+    ref = pfnl_spec.lrelu(pfnl_spec.conv2d_same(xin.astype(np.float64), k.astype(np.float64), b.astype(np.float64)))
+    got = ops.conv3x3_accum(dev(x), k, b, act=True, frames_per_clip=T).cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize("items,fpi,H,W,act", [
     (2, 7, 16, 40, True),        # conv10 at T = 7
     (1, 5, 6, 8, True),          # T = 5, 48 pixels: one full + one ragged wave
