@@ -37,7 +37,7 @@ constexpr int WS_SLAB_XI = 2 * 32 * WS_ES;                                 // fl
 constexpr int WS_LDS_FLOATS = WS_RAW_FLOATS + 4 * WS_SLAB_XI;
 constexpr size_t WS_LDS_BYTES = size_t(WS_LDS_FLOATS) * sizeof(float);     // 100 608 B
 constexpr int WS_MAX_WG_PER_XCD = 32;                                      // one workgroup per CU
-constexpr int WS_UD = 8;                                                   // K-steps of U in flight (divides 32)
+constexpr int WS_UD_MAX = 8;                                               // K-steps of U in flight (divides 32)
 static_assert((WS_RAW_FLOATS * sizeof(float)) % 16 == 0, "slab must stay 16-byte aligned");
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -53,6 +53,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int MODE>
 __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams p) {
     constexpr bool FUSE = MODE == 1 || MODE == 2, GROUPED = MODE == 2, ACCUM = MODE == 3;
+    constexpr int WS_UD = ACCUM ? 4 : WS_UD_MAX;                    // (the accumulating mode is short of registers)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const slabm = smem + WS_RAW_FLOATS;
     float* const pbl = slabm + 4 * WS_SLAB_XI;                      // MODE 2: [4 rows][32 cols][64] addend tile
@@ -204,10 +205,16 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
             asm volatile("s_nop 4" ::: "memory");                   // VALU write -> MFMA read inside the asm block
         }
         for (int i = 0; i < nu; ++i) {
-            if (!ACCUM || mu == 0) {                                // first K-step of a tile: C = 0
-                WS_STEPX(0, true, vA, vB, vC, vD);
-            } else {                                                // MODE 3: later frames add to the same accumulators
+            if (ACCUM) {                                            // MODE 3: frames add into the same accumulators;
+                if (mu == 0) {                                      // cleared in place before a tile's first frame
+#pragma unroll
+                    for (int n = 0; n < 8; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+                }
                 WS_STEPX(0, false, vA, vB, vC, vD);
+            } else {                                                // first K-step of a tile: C = 0
+                WS_STEPX(0, true, vA, vB, vC, vD);
             }
             WS_STEP(1, vC, vD, vA, vB);
             WS_STEP2(2);

@@ -37,7 +37,7 @@ def main():
     tot_b = 0.0
     tot_n = 0
     for k in f:
-        if "<true> [short]" in k:      # convmerge1's accumulating launches (4 items, fused): not the conv3x3 class of bench.py
+        if "ws_kernel<3>" in k:        # convmerge1 (accumulating mode): not the conv3x3 class of bench.py
             continue
         n = f[k][0]
         fb = f[k][1] / n * 1024 * 2
