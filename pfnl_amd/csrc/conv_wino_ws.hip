@@ -402,8 +402,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
         _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) eoff[k_] = eoffN[k_];                   \
     } while (0)
     // Byte offsets of this thread's four items (row 0) inside the item, computed once per tile; out of
-    // range for pixels outside the image (H, W even: row 1 is valid iff row 0 is, and it is reached
-    // through the scalar offset `rowb`, which the range check ignores).  Item k sits 16*(k&1) columns and
+    // range for pixels outside the image (H, W even: row 1 is valid iff row 0 is; it is reached through the
+    // scalar offset `rowb` - the range check covers voffset + soffset, and 0x7fffffff + rowb stays out of range).  Item k sits 16*(k&1) columns and
     // 2*(k>>1) rows from item 0.
     int eoff[4] = {0, 0, 0, 0}, eoffN[4] = {0, 0, 0, 0};
     const int rowb = W * 256;
