@@ -80,7 +80,11 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *   "winograd16"    same maths, one wave per SIMD owning all 16 positions (experimental, slower);
  *   "direct"        implicit-GEMM f32 MFMA (conv_mfma.hip).
  * key "conv1x1" = "stream" (default, conv1x1.hip) | "tiled" (conv_mfma.hip).
- * key "conv2"   = "grouped" (default with conv3x3=winograd: one launch per block, shared half in LDS) | "split".
+ * key "graph"   = "off" (default) | "on" (every shape is captured into a hipGraph on its second call and replayed
+ *                 between the staging buffers) | "auto" (only shapes with frames*H*W <= 65536 pixels).  Measured: no
+ *                 gain - the small shapes are bound by per-kernel latency, not by launch gaps.
+ * key "conv2"   = "grouped" (default with conv3x3=winograd: one launch per block, shared half in LDS; taken when there
+ *                 are at least 224 (clip, 4x32-pixel tile) groups, like the accumulating convmerge1) | "split".
  * The default can also be set with the environment variable PFNL_CONV3X3 read by pfnl_create. */
 int pfnl_set_option(pfnl_handle* h, const char* key, const char* value);
 

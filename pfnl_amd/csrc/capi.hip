@@ -27,11 +27,14 @@ int fail(int code, const std::string& msg) {
             return fail(PFNL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
     } while (0)
 
+static unsigned long long g_alloc_gen = 0;   // bumped whenever a device buffer moves: captured graphs hold raw pointers
+
 struct DevBuf {
     float* p = nullptr;
     size_t n = 0;   // floats
     int ensure(size_t count) {
         if (count <= n) return 0;
+        ++g_alloc_gen;
         if (p) hipFree(p);
         p = nullptr;
         n = 0;
@@ -59,6 +62,18 @@ struct pfnl_handle {
     std::map<std::string, std::vector<int64_t>> expected;   // tf name -> shape
     std::map<std::string, HostTensor> host;                  // tensors received so far
     bool finalized = false;
+    // launch-bound shapes (e.g. BASELINE.json configs[0], 1x7x32x32: ~95 launches of a few us each): the whole
+    // forward is captured once per (B, H, W) into a hipGraph between the staging buffers and replayed
+    struct GraphEntry {
+        int B, H, W, seen;
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+        unsigned long long alloc_gen, cfg_gen;
+    };
+    std::vector<GraphEntry> graphs;
+    unsigned long long cfg_gen = 0;                           // bumped by finalize_weights / set_option
+    hipEvent_t gev = nullptr;                                  // ordering with the legacy default stream around a replay
+    int graph_mode = 0;                                       // 0 off (default: measured slower), 1 auto (frames*H*W <= 65536 pixels), 2 on
     bool conv2_grouped = true;                                // winograd: conv2_i as one grouped launch (option conv2=grouped|split)
     int merge_cstride = 48;                                   // floats per pixel of `merge` as written by the last forward
     int conv1x1_algo = 1;                                     // conv10: 1 streaming kernel (conv1x1.hip), 0 LDS-tiled implicit GEMM
@@ -194,6 +209,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
     p.W = W;
     p.in_cstride = 64;
     p.chunks_per_frame = 64 / CONV_CK;
+    const int wino_groups = B * ((W + 31) / 32) * ((H + 3) / 4);   // (clip, 4x32-pixel tile) groups of conv_wino_ws
     for (int i = 0; i < c.num_block; ++i) {   // model/pfnl.py:65-71
         if (h->prof_mode == 2) {          // sampled profiling: blocks 0, 4, 8, ... each with a fresh event chain
             h->prof_gate = (i & 3) == 0;
@@ -236,7 +252,9 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             else
                 HIPCHK(launch_conv_mfma(p, 1, B, s));
         }
-        const bool conv2_grouped = h->conv_algo == 3 && h->conv2_grouped && (long long)H * W * 256 < 0x7fffffffLL;
+        // grouped / accumulating modes chain T(+1) units inside one workgroup: only worth it when there are enough
+        // (clip, tile) groups to occupy the chip (below ~220 the split launches finish sooner)
+        const bool conv2_grouped = h->conv_algo == 3 && h->conv2_grouped && wino_groups >= 224 && (long long)H * W * 256 < 0x7fffffffLL;
         if (conv2_grouped) {
             // the whole of conv2_i in one launch: per (clip, tile) the shared half stays in LDS (conv_wino_ws MODE 2)
             ProfScope ps(h, s, PFNL_K_CONV3X3);
@@ -298,7 +316,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
     }
     h->prof_gate = true;
     if (h->prof_mode == 2) h->chain_open = false;
-    const bool m1_wino = h->conv_algo == 3 && (long long)H * W * 256 < 0x7fffffffLL;
+    const bool m1_wino = h->conv_algo == 3 && wino_groups >= 224 && (long long)H * W * 256 < 0x7fffffffLL;
     const int mstride = m1_wino ? 64 : 48;
     h->merge_cstride = mstride;
     if (m1_wino) {
@@ -399,6 +417,11 @@ int pfnl_destroy(pfnl_handle* h) {
         hipStreamDestroy(h->stream);
     }
     for (auto& e : h->evs) hipEventDestroy(e);
+    if (h->gev) hipEventDestroy(h->gev);
+    for (auto& g : h->graphs) {
+        if (g.exec) hipGraphExecDestroy(g.exec);
+        if (g.graph) hipGraphDestroy(g.graph);
+    }
     for (DevBuf* b : {&h->wdev, &h->X, &h->Xo, &h->nlp, &h->inp0, &h->inp1, &h->base, &h->pb, &h->merge,
                       &h->stage_in, &h->stage_out, &h->scratch})
         b->release();
@@ -429,6 +452,14 @@ int pfnl_set_weight(pfnl_handle* h, const char* tf_name, const float* host, cons
 int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
     if (!h || !key || !value) return fail(PFNL_ERR_INVALID, "NULL argument");
     const std::string k(key), v(value);
+    ++h->cfg_gen;
+    if (k == "graph") {
+        if (v == "auto") h->graph_mode = 1;
+        else if (v == "on") h->graph_mode = 2;
+        else if (v == "off") h->graph_mode = 0;
+        else return fail(PFNL_ERR_INVALID, "graph must be auto, on or off");
+        return 0;
+    }
     if (k == "conv3x3") {
         if (v == "winograd" || v == "winograd_ws") h->conv_algo = 3;
         else if (v == "winograd_tile") h->conv_algo = 1;
@@ -568,6 +599,7 @@ int pfnl_finalize_weights(pfnl_handle* h) {
     if (h->wdev.ensure(blob.size())) return fail(PFNL_ERR_NOMEM, "weight allocation failed");
     HIPCHK(hipMemcpy(h->wdev.p, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
     h->finalized = true;
+    ++h->cfg_gen;
     return 0;
 }
 
@@ -594,6 +626,69 @@ int pfnl_forward(pfnl_handle* h, const void* in, int in_is_device, void* out, in
     const size_t n_in = (size_t)B * T * H * W * 3, n_out = (size_t)B * H * W * sc * sc * 3;
     const float* din = (const float*)in;
     float* dout = (float*)out;
+    const bool want_graph = !h->prof && (h->graph_mode == 2 || (h->graph_mode == 1 && (size_t)B * T * H * W <= 65536));
+    if (want_graph) {
+        if (h->stage_in.ensure(n_in) || h->stage_out.ensure(n_out)) return fail(PFNL_ERR_NOMEM, "staging allocation failed");
+        pfnl_handle::GraphEntry* ge = nullptr;
+        for (auto& g : h->graphs)
+            if (g.B == B && g.H == H && g.W == W) ge = &g;
+        if (!ge) {
+            h->graphs.push_back({B, H, W, 0, nullptr, nullptr, 0, 0});
+            ge = &h->graphs.back();
+        }
+        if (ge->exec && (ge->alloc_gen != g_alloc_gen || ge->cfg_gen != h->cfg_gen)) {   // buffers moved / weights or options changed
+            hipGraphExecDestroy(ge->exec);
+            hipGraphDestroy(ge->graph);
+            ge->exec = nullptr;
+            ge->graph = nullptr;
+            ge->seen = 0;
+        }
+        if (!ge->exec && ge->seen >= 1) {
+            // second call with this shape (the first one ran eagerly: workspaces allocated, kernel attributes set)
+            HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            const int fe = forward_device(h, h->stage_in.p, h->stage_out.p, B, H, W, s);
+            hipGraph_t g = nullptr;
+            const hipError_t ce = hipStreamEndCapture(s, &g);
+            if (fe) return fe;
+            if (ce != hipSuccess || !g) return fail(PFNL_ERR_HIP, std::string("graph capture: ") + hipGetErrorString(ce));
+            hipGraphExec_t ex = nullptr;
+            const hipError_t ie = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+            if (ie != hipSuccess) {
+                hipGraphDestroy(g);
+                return fail(PFNL_ERR_HIP, std::string("graph instantiate: ") + hipGetErrorString(ie));
+            }
+            ge->graph = g;
+            ge->exec = ex;
+            ge->alloc_gen = g_alloc_gen;
+            ge->cfg_gen = h->cfg_gen;
+        }
+        if (ge->exec) {
+            // No stream given: the eager path relies on the legacy default stream's implicit ordering with the handle's
+            // (blocking) stream; a graph launch does not take part in it, so order explicitly in both directions.
+            if (!stream) {
+                if (!h->gev && hipEventCreateWithFlags(&h->gev, hipEventDisableTiming) != hipSuccess)
+                    return fail(PFNL_ERR_HIP, "event creation failed");
+                HIPCHK(hipEventRecord(h->gev, nullptr));
+                HIPCHK(hipStreamWaitEvent(s, h->gev, 0));
+            }
+            HIPCHK(hipMemcpyAsync(h->stage_in.p, in, n_in * sizeof(float),
+                                  in_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+            HIPCHK(hipGraphLaunch(ge->exec, s));
+            HIPCHK(hipMemcpyAsync(out, h->stage_out.p, n_out * sizeof(float),
+                                  out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+            if (!in_is_device || !out_is_device) {
+                HIPCHK(hipStreamSynchronize(s));
+            } else if (!stream) {
+                HIPCHK(hipEventRecord(h->gev, s));
+                HIPCHK(hipStreamWaitEvent(nullptr, h->gev, 0));
+            }
+            h->lastB = B;
+            h->lastH = H;
+            h->lastW = W;
+            return 0;
+        }
+        ge->seen++;
+    }
     if (!in_is_device) {
         if (h->stage_in.ensure(n_in)) return fail(PFNL_ERR_NOMEM, "staging allocation failed");
         HIPCHK(hipMemcpyAsync(h->stage_in.p, in, n_in * sizeof(float), hipMemcpyHostToDevice, s));

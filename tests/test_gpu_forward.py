@@ -211,8 +211,9 @@ def test_1080p_single_clip_runs():
 
 
 def test_profile_counts_full_and_sampled():
-    """pfnl_profile_*: mode 1 brackets every launch (conv1_i + grouped conv2_i = 2 conv3x3-class launches and
-    1 conv10 launch per PF block), mode 2 only every 4th block; outputs are unaffected."""
+    """pfnl_profile_*: mode 1 brackets every launch (conv1_i + the two halves of conv2_i = 3 conv3x3-class launches -
+    this shape is too small for the grouped conv2_i - and 1 conv10 launch per PF block), mode 2 only every 4th block;
+    outputs are unaffected."""
     geom = PFNLGeometry(num_block=6)
     eng = engine_for(geom)
     x = synth.uniform_clips(1, 7, 16, 32, seed=5)
@@ -224,8 +225,33 @@ def test_profile_counts_full_and_sampled():
         eng.profile(0)
         p = eng.profile_read()
         assert np.array_equal(y, y0)
-        assert p["conv3x3"]["launches"] == 2 * blocks and p["conv1x1"]["launches"] == blocks
+        assert p["conv3x3"]["launches"] == 3 * blocks and p["conv1x1"]["launches"] == blocks
         assert p["tail"]["launches"] == 1 and p["conv0"]["launches"] == 1
         assert all(v["ms"] > 0 for k, v in p.items() if v["launches"])
     eng.profile_reset()
     assert sum(v["launches"] for v in eng.profile_read().values()) == 0
+
+
+def test_graph_replay_matches_eager():
+    """Small shapes are captured into a hipGraph on their second call (pfnl_set_option "graph"): eager, capturing and
+    replayed calls give the same bits, for host and device containers, and survive an option change."""
+    import torch
+    gd = load_golden("cfg1_7x32x32")
+    eng = engine_for(geometry_of(gd["meta"]))
+    eng.set_option("graph", "off")
+    y_off = eng.forward(gd["x"])
+    eng.set_option("graph", "auto")
+    ys = [eng.forward(gd["x"]) for _ in range(4)]              # eager, capture + replay, replay, replay
+    assert all(np.array_equal(y, y_off) for y in ys)
+    xd = torch.from_numpy(gd["x"]).cuda()
+    assert np.array_equal(eng.forward(xd).cpu().numpy(), y_off)
+    eng.set_option("conv3x3", "direct")                       # invalidates the captured graph
+    y_dir = [eng.forward(gd["x"]) for _ in range(3)]
+    assert np.array_equal(y_dir[0], y_dir[1]) and np.array_equal(y_dir[1], y_dir[2])
+    assert np.abs(y_dir[0] - y_off).max() < 5e-5 and not np.array_equal(y_dir[0], y_off)
+    eng.set_option("conv3x3", "winograd")
+    eng.set_option("graph", "on")
+    x2 = synth.uniform_clips(2, 7, 20, 36, seed=9)            # another shape: its own graph
+    y2 = [eng.forward(x2) for _ in range(3)]
+    assert np.array_equal(y2[0], y2[2])
+    assert np.array_equal(eng.forward(gd["x"]), y_off)
