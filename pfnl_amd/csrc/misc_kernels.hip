@@ -42,9 +42,11 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ Xo
     __syncthreads();
 
     const int ty = tid / C0_T, tx = tid % C0_T;
-    float acc[64];
+    // 64 output channels as 32 packed pairs: v_pk_fma_f32 does two channels per VALU issue
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc[32];
 #pragma unroll
-    for (int o = 0; o < 64; ++o) acc[o] = bias[o];
+    for (int o = 0; o < 32; ++o) acc[o] = f32x2{bias[2 * o], bias[2 * o + 1]};
     for (int ky = 0; ky < 5; ++ky) {
         for (int kx = 0; kx < 5; ++kx) {
             const float* ip = s_in + ((ty + ky) * C0_IN + tx + kx) * 3;
@@ -52,13 +54,12 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ Xo
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float a = ip[c];
+                const f32x2 a2 = {a, a};
 #pragma unroll
                 for (int o4 = 0; o4 < 16; ++o4) {
-                    const float4 wv = *reinterpret_cast<const float4*>(wp + c * 64 + o4 * 4);
-                    acc[o4 * 4 + 0] = fmaf(a, wv.x, acc[o4 * 4 + 0]);
-                    acc[o4 * 4 + 1] = fmaf(a, wv.y, acc[o4 * 4 + 1]);
-                    acc[o4 * 4 + 2] = fmaf(a, wv.z, acc[o4 * 4 + 2]);
-                    acc[o4 * 4 + 3] = fmaf(a, wv.w, acc[o4 * 4 + 3]);
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + c * 64 + o4 * 4);
+                    acc[o4 * 2 + 0] = __builtin_elementwise_fma(a2, f32x2{wv.x, wv.y}, acc[o4 * 2 + 0]);
+                    acc[o4 * 2 + 1] = __builtin_elementwise_fma(a2, f32x2{wv.z, wv.w}, acc[o4 * 2 + 1]);
                 }
             }
         }
@@ -68,8 +69,8 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ Xo
         float4* dst = reinterpret_cast<float4*>(out + (((size_t)f * H + y) * W + x) * 64);
 #pragma unroll
         for (int o4 = 0; o4 < 16; ++o4)
-            dst[o4] = make_float4(lrelu(acc[o4 * 4]), lrelu(acc[o4 * 4 + 1]), lrelu(acc[o4 * 4 + 2]),
-                                  lrelu(acc[o4 * 4 + 3]));
+            dst[o4] = make_float4(lrelu(acc[o4 * 2].x), lrelu(acc[o4 * 2].y), lrelu(acc[o4 * 2 + 1].x),
+                                  lrelu(acc[o4 * 2 + 1].y));
     }
 }
 
