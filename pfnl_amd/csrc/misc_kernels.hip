@@ -20,8 +20,9 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ Xo
                                                     const float* __restrict__ bias,  // [64]
                                                     float* __restrict__ out, int T, int H, int W,
                                                     int CP) {
-    __shared__ __attribute__((aligned(16))) float sw[75 * 64];
-    __shared__ float s_in[C0_IN * C0_IN * 3];
+    __shared__ __attribute__((aligned(16))) float smem0[256 * 36];   // weights [75][64] | input tile, later the store slab
+    float* const sw = smem0;
+    float* const s_in = smem0 + 75 * 64;
     const int tid = threadIdx.x;
     const int f = blockIdx.z;
     const int b = f / T, t = f % T;
@@ -64,13 +65,31 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ Xo
             }
         }
     }
-    const int y = y0 + ty, x = x0 + tx;
-    if (y < H && x < W) {
-        float4* dst = reinterpret_cast<float4*>(out + (((size_t)f * H + y) * W + x) * 64);
+    // Stores: a thread owns one pixel's 64 channels (256 B); stored directly, every instruction would scatter 64
+    // 16-byte pieces over 64 cache lines.  Two passes of 32 channels through an LDS slab (aliasing the weights and
+    // the input tile) turn them into instructions that write 8 whole 128-byte lines.
+    constexpr int SS = 36;                                          // slab row stride (floats): 32 channels + 4
+    float* slab = smem0;
+    static_assert(75 * 64 + C0_IN * C0_IN * 3 <= 256 * SS, "weights + input tile must fit the slab they share LDS with");
 #pragma unroll
-        for (int o4 = 0; o4 < 16; ++o4)
-            dst[o4] = make_float4(lrelu(acc[o4 * 2].x), lrelu(acc[o4 * 2].y), lrelu(acc[o4 * 2 + 1].x),
-                                  lrelu(acc[o4 * 2 + 1].y));
+    for (int hp = 0; hp < 2; ++hp) {
+        __syncthreads();                                            // weights / input tile (or the previous pass) no longer needed
+#pragma unroll
+        for (int o4 = 0; o4 < 8; ++o4) {
+            const int o = hp * 16 + o4 * 2;
+            *reinterpret_cast<f32x4*>(slab + tid * SS + o4 * 4) =
+                f32x4{lrelu(acc[o].x), lrelu(acc[o].y), lrelu(acc[o + 1].x), lrelu(acc[o + 1].y)};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int id = it * 256 + tid;
+            const int pix = id >> 3, q = id & 7;
+            const int y = y0 + pix / C0_T, x = x0 + pix % C0_T;
+            if (y < H && x < W)
+                *reinterpret_cast<f32x4*>(out + (((size_t)f * H + y) * W + x) * 64 + hp * 32 + q * 4) =
+                    *reinterpret_cast<const f32x4*>(slab + pix * SS + q * 4);
+        }
     }
 }
 
