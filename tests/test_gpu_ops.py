@@ -1,10 +1,13 @@
 """Per-op parity on a real MI355X: each HIP kernel class against the fp64 spec oracle
 (oracle/pfnl_spec.py), through the C-ABI op hooks.  Tolerances: f32 MFMA is an exact fmaf chain
 (cdna guide §3), so differences are summation-order round-off: |err| <= 2e-6 * sum|a*b| scale."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 torch = pytest.importorskip("torch")
 
@@ -237,3 +240,14 @@ def test_blur_decimate(F, H, W, scale):
     ref = synth.blur_decimate(hr.astype(np.float64), scale)        # numpy restatement of utils.py:169-192
     assert got.shape == ref.shape == (F, -(-H // scale), -(-W // scale), 3)
     assert np.abs(got - ref).max() < 2e-6
+
+
+def test_ws_modes_random_geometries():
+    """Short run of tools/stress_ws.py: modes 0 / 2 / 3 of the persistent Winograd kernel against the per-tile and
+    direct kernels over random (T, clips, H, W), and bit-exact repeatability of every call."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("stress_ws", os.path.join(os.path.dirname(HERE), "tools", "stress_ws.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, worst = mod.run(seed=7, seconds=60.0, max_iters=25)
+    assert n == 25 and worst < 3e-5
