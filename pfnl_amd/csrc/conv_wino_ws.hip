@@ -327,6 +327,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
         int item_, y0_, x0_;                                                                     \
         bool pb_, fin_;                                                                          \
         WS_UNIT(i_, item_, y0_, x0_, pb_, fin_);                                                 \
+        (void)fin_;                                                                              \
         rsLN = __builtin_amdgcn_make_buffer_rsrc(                                                \
             const_cast<float*>(pb_ ? p.in2 : p.in) + (size_t)item_ * in_stride, 0, item_bytes, 0x00020000); \
         const int org_ = (y0_ * W + x0_) * 256;                                                  \
