@@ -91,18 +91,25 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
     const int q = blockIdx.x * 128 + wave * 32 + xl;       // this lane's query
     const int qc = q < N ? q : N - 1;
 
-    // B operand of S^T = Xk Xq^T: lane holds Xq[q][2s + kh].
+    // B operand of S^T = Xk Xq^T: lane holds Xq[q][2s + kh], pre-scaled by log2(e) so that the logits come out
+    // of the MFMA in base-2 units and the softmax needs one v_exp_f32 per element (expf expands to ~8 VALU, and
+    // VALU issued between a wave's MFMAs is matrix-pipe time: tools/ubench).
+    constexpr float LOG2E = 1.4426950408889634f;
     float bq[KSTEPS];
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) bq[s] = Xb[(size_t)qc * CP + 2 * s + kh];
+    for (int s = 0; s < KSTEPS; ++s) bq[s] = Xb[(size_t)qc * CP + 2 * s + kh] * LOG2E;
+    // The running sum l of the probabilities is not kept in VALU: pad channel C of the key tile in LDS is set to 1,
+    // so row C of O^T = V^T P^T accumulates sum_k P (and is rescaled with O).  Where that row lives in the D layout:
+    constexpr int LCT = C / 32, LI = C % 32;
+    constexpr int LKH = (LI % 8) >= 4 ? 1 : 0, LR = (LI / 8) * 4 + (LI % 8) % 4;
+    static_assert(C < CP, "needs a pad channel");
 
     f32x16 o[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
-    float m = -INFINITY;   // running max of the logits of this lane's query
-    float l = 0.f;         // running sum over this lane's half of the keys
+    float m = -INFINITY;   // running max of the (base-2) logits of this lane's query
 
     constexpr int TILE_F4 = NL_KT * CP / 4;
     constexpr int LD_ITERS = (TILE_F4 + 255) / 256;
@@ -130,6 +137,7 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
                 d[1] = rk[i].y;
                 d[2] = rk[i].z;
                 d[3] = rk[i].w;
+                if (c4 == C / 4) d[C % 4] = 1.0f;          // the "ones" channel (see LCT / LR above)
             }
         }
     };
@@ -158,22 +166,19 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
             for (int s = 0; s < KSTEPS; ++s) st = mfma32(ka[2 * s], bq[s], st);
 
             // online softmax; register r of this lane is key kbase + drow(r, lane).
-            float tmax = -INFINITY;
+            if (kbase + 32 > N) {                          // wave-uniform: only the last, partial key tile
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (kbase + drow(r, lane) >= N) st[r] = -INFINITY;
-                tmax = fmaxf(tmax, st[r]);
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + drow(r, lane) >= N) st[r] = -INFINITY;
             }
+            float tmax = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
+#pragma unroll
+            for (int r = 4; r < 16; r += 4) tmax = fmaxf(tmax, fmaxf(fmaxf(st[r], st[r + 1]), fmaxf(st[r + 2], st[r + 3])));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
             const float mn = fmaxf(m, tmax);
-            const float alpha = expf(m - mn);              // m = -inf on the first tile -> 0
-            float psum = 0.f;
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);   // m = -inf on the first tile -> 0
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                st[r] = expf(st[r] - mn);
-                psum += st[r];
-            }
-            l = l * alpha + psum;
+            for (int r = 0; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r] - mn);
             m = mn;
             if (!__all(alpha == 1.0f)) {
 #pragma unroll
@@ -193,8 +198,13 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
         }
     }
 
-    // normalise: both halves of a query's keys (partial results stay un-normalised: the projection is linear)
-    l += __shfl_xor(l, 32);
+    // normalise (partial results stay un-normalised: the projection is linear); l = row C of O^T, held by the
+    // lanes of half LKH in register LR
+    float l = o[LCT][LR];
+    {
+        const float lo = __shfl_xor(l, 32);
+        if (kh != LKH) l = lo;
+    }
     const float inv = (ks == 1) ? 1.0f / l : 1.0f;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -255,7 +265,7 @@ __global__ void nl_merge_kernel(const float* __restrict__ X, const float* __rest
         float num = 0.f, den = 0.f;
         for (int p = 0; p < ks; ++p) {
             const float* ml = ML + ((b * ks + p) * N + qn) * 2;
-            const float w = expf(ml[0] - m);
+            const float w = exp2f(ml[0] - m);                 // the partial maxima are base-2 logits
             num = fmaf(w, Zp[((b * ks + p) * N + qn) * CP + co], num);
             den = fmaf(w, ml[1], den);
         }
