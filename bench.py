@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv3x3", choices=["winograd", "winograd_tile", "winograd16", "direct"], default=None, help="override the 3x3 conv algorithm")
+    ap.add_argument("--conv1x1", choices=["stream", "tiled"], default=None, help="override the conv10_i algorithm")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to exercise the N>1 plumbing on a 1-GPU box)")
     ap.add_argument("--full-profile", action="store_true",
@@ -119,6 +120,8 @@ def main():
     eng.load_weights(weights)
     if args.conv3x3:
         eng.set_option("conv3x3", args.conv3x3)
+    if args.conv1x1:
+        eng.set_option("conv1x1", args.conv1x1)
     x = torch.from_numpy(synth.uniform_clips(B_PER_GPU, T, H, W, seed=1234 + rank)).to(dev)   # resident in HBM
     out = torch.empty(eng.out_shape(B_PER_GPU, H, W), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
