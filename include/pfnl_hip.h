@@ -85,6 +85,10 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *                 gain - the small shapes are bound by per-kernel latency, not by launch gaps.
  * key "conv2"   = "grouped" (default with conv3x3=winograd: one launch per block, shared half in LDS; taken when there
  *                 are at least 224 (clip, 4x32-pixel tile) groups, like the accumulating convmerge1) | "split".
+ * key "precision" = "fp32" (default: the reference's arithmetic, |dPSNR| <= 0.01 dB) | "bf16" (BASELINE.json configs[3]:
+ *                 the 20 progressive-fusion blocks keep their activations and weights in bf16 and accumulate in fp32 on
+ *                 bf16 MFMA (conv_bf16.hip); the non-local block, its logits, conv0's arithmetic, convmerge1, the tail and
+ *                 the bicubic skip stay fp32; the interface tensors stay float32.  Tolerance: DESIGN.md section 4).
  * The default can also be set with the environment variable PFNL_CONV3X3 read by pfnl_create. */
 int pfnl_set_option(pfnl_handle* h, const char* key, const char* value);
 
@@ -147,6 +151,16 @@ int pfnl_op_conv3x3_accum(const float* in, const float* kernel_host, const float
  * in [items*frames_per_item, HW, 64], kernel_host HWIO [1,1,64*fpi,64], out [items, HW, 64]. */
 int pfnl_op_conv1x1_stream(const float* in, const float* kernel_host, const float* bias_host, float* out,
                            int items, int frames_per_item, int HW, int act, void* stream);
+/* bf16 trunk (option precision=bf16; BASELINE.json configs[3]): the 3x3 64->64 convolution of a progressive-fusion
+ * block (reference model/pfnl.py:49,51,66,69-71) on bf16 MFMA with fp32 accumulation.  Tensors are bf16 (uint16_t
+ * bit patterns) [items, H, W, 64]; kernel_host fp32 HWIO [3,3,64,64] (rounded to bf16 inside), bias fp32.
+ * out = act(conv + bias + addend[item / add_div]) + resid; addend and resid both NULL or both given; out may alias resid. */
+int pfnl_op_conv3x3_bf16(const uint16_t* in, const float* kernel_host, const float* bias_host, const uint16_t* addend,
+                         int add_div, const uint16_t* resid, uint16_t* out, int items, int H, int W, int act, void* stream);
+/* ... and conv10_i (reference model/pfnl.py:50, :67-68): in [items*fpi, HW, 64] bf16, kernel_host fp32 HWIO
+ * [1,1,64*fpi,64], out [items, HW, 64] bf16; fpi in {3,5,7}. */
+int pfnl_op_conv1x1_bf16(const uint16_t* in, const float* kernel_host, const float* bias_host, uint16_t* out, int items,
+                         int frames_per_item, int HW, int act, void* stream);
 /* The same 3x3 64->64 convolution (frames_per_item = 1, cout = 64) through the fused Winograd
  * F(2x2,3x3) kernel; H and W must be even. */
 int pfnl_op_conv3x3_winograd(const float* in, const float* kernel_host, const float* bias_host,

@@ -51,8 +51,14 @@ class FastOracle:
     """Weights are converted once (HWIO -> OIHW); ``forward`` is the timed CPU baseline."""
 
     def __init__(self, weights: Dict[str, np.ndarray], num_frames: int = 7, scale: int = 4,
-                 num_block: int = 20):
+                 num_block: int = 20, trunk_dtype: str = "fp32"):
+        """trunk_dtype="bf16": the build-defined arithmetic of BASELINE.json configs[3] (not expressible in the
+        reference, which is fp32 throughout): inside the progressive-fusion blocks every activation and kernel is
+        rounded to bfloat16 (round-to-nearest-even), products are accumulated in fp32, biases stay fp32; everything
+        outside the blocks is the fp32 graph.  Rounding points = the stores of pfnl_amd/csrc/conv_bf16.hip."""
+        assert trunk_dtype in ("fp32", "bf16")
         self.T, self.scale, self.num_block = num_frames, scale, num_block
+        self.trunk_bf16 = trunk_dtype == "bf16"
         self.w = {}
         for k, v in weights.items():
             t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
@@ -64,6 +70,20 @@ class FastOracle:
         k = self.w[f"nlvsr/{name}/kernel"]
         y = F.conv2d(x, k, self.w[f"nlvsr/{name}/bias"], padding=k.shape[-1] // 2)
         return F.leaky_relu(y, 0.2) if act else y
+
+    def _trunk_bf16(self, fr, B, T, mf, H, W):
+        r = lambda t: t.to(torch.bfloat16).to(torch.float32)              # noqa: E731  (RNE)
+        fr = r(fr)
+        for i in range(self.num_block):                                   # pfnl.py:65-71 with bf16 stores
+            k1, b1 = r(self.w[f"nlvsr/conv1_{i}/kernel"]), self.w[f"nlvsr/conv1_{i}/bias"]
+            k10, b10 = r(self.w[f"nlvsr/conv10_{i}/kernel"]), self.w[f"nlvsr/conv10_{i}/bias"]
+            k2, b2 = r(self.w[f"nlvsr/conv2_{i}/kernel"]), self.w[f"nlvsr/conv2_{i}/bias"]
+            a = r(F.leaky_relu(F.conv2d(fr, k1, b1, padding=1), 0.2))
+            base = r(F.leaky_relu(F.conv2d(a.reshape(B, T * mf, H, W), k10, b10), 0.2))
+            pb = r(F.conv2d(base, k2[:, :mf], None, padding=1))          # shared half, raw, stored in bf16
+            pre = F.conv2d(a, k2[:, mf:], b2, padding=1).reshape(B, T, mf, H, W) + pb[:, None]
+            fr = r(fr + F.leaky_relu(pre, 0.2).reshape(B * T, mf, H, W))
+        return fr
 
     @torch.no_grad()
     def forward(self, x) -> np.ndarray:
@@ -86,7 +106,9 @@ class FastOracle:
         cen = x[:, T // 2].permute(0, 3, 1, 2)                            # :63
         My, Mx = _bicubic_matrix(H, self.scale), _bicubic_matrix(W, self.scale)
         bic = torch.einsum("oh,bchw->bcow", My, torch.einsum("pw,bchw->bchp", Mx, cen))
-        for i in range(self.num_block):                                   # :65-71
+        if self.trunk_bf16:
+            fr = self._trunk_bf16(fr, B, T, mf, H, W)
+        for i in range(0 if self.trunk_bf16 else self.num_block):         # :65-71
             a = self._conv(f"conv1_{i}", fr)
             base = self._conv(f"conv10_{i}", a.reshape(B, T * mf, H, W))
             cat = torch.cat([base[:, None].expand(B, T, mf, H, W), a.reshape(B, T, mf, H, W)], 2)

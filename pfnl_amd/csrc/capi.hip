@@ -10,6 +10,7 @@
 
 #include "../../include/pfnl_hip.h"
 #include "common.h"
+#include "conv_bf16.h"
 
 namespace {
 
@@ -77,6 +78,9 @@ struct pfnl_handle {
     bool conv2_grouped = true;                                // winograd: conv2_i as one grouped launch (option conv2=grouped|split)
     int merge_cstride = 48;                                   // floats per pixel of `merge` as written by the last forward
     int conv1x1_algo = 1;                                     // conv10: 1 streaming kernel (conv1x1.hip), 0 LDS-tiled implicit GEMM
+    bool bf16 = false;                                        // option precision=bf16: progressive-fusion trunk in bf16 (conv_bf16.hip); NL, conv0 maths, merge, tail stay fp32
+    DevBuf wdev16;                                            // bf16 packs (offsets in 16-bit elements)
+    std::vector<size_t> off16_c1, off16_c10, off16_c2a, off16_c2b;
     int conv_algo = 3;                                        // conv3x3: 0 direct, 1 winograd (4 waves / tile), 2 winograd16 (1 wave / SIMD), 3 winograd_ws (persistent, wave-specialised)
 
     // device weights (offsets in floats into `wdev`)
@@ -201,7 +205,50 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
     }
     {   // model/pfnl.py:61-62
         ProfScope ps(h, s, PFNL_K_CONV0);
-        HIPCHK(launch_conv0(h->Xo.p, wd + h->off_conv0_w, wd + h->off_conv0_b, h->inp0.p, B, T, H, W, s));
+        if (h->bf16)
+            HIPCHK(launch_conv0_bf16(h->Xo.p, wd + h->off_conv0_w, wd + h->off_conv0_b, reinterpret_cast<uint16_t*>(h->inp0.p), B, T, H, W, s));
+        else
+            HIPCHK(launch_conv0(h->Xo.p, wd + h->off_conv0_w, wd + h->off_conv0_b, h->inp0.p, B, T, H, W, s));
+    }
+    const float* merge_in = h->inp0.p;
+    if (h->bf16) {
+        // bf16 trunk (conv_bf16.hip): activations bf16 in the same workspace buffers, fp32 accumulation and biases
+        if ((long long)T * H * W * 128 >= 0x7fffffffLL) return fail(PFNL_ERR_INVALID, "frame too large for the bf16 trunk");
+        uint16_t* const a0 = reinterpret_cast<uint16_t*>(h->inp0.p);
+        uint16_t* const a1 = reinterpret_cast<uint16_t*>(h->inp1.p);
+        uint16_t* const ab = reinterpret_cast<uint16_t*>(h->base.p);
+        uint16_t* const ap = reinterpret_cast<uint16_t*>(h->pb.p);
+        const uint16_t* const w16 = reinterpret_cast<const uint16_t*>(h->wdev16.p);
+        for (int i = 0; i < c.num_block; ++i) {   // model/pfnl.py:65-71
+            if (h->prof_mode == 2) {
+                h->prof_gate = (i & 3) == 0;
+                h->chain_open = false;
+            }
+            {   // conv1_i
+                ProfScope ps(h, s, PFNL_K_CONV3X3);
+                ConvBf16Params q{a0, w16 + h->off16_c1[i], wd + h->off_c1_b[i], nullptr, nullptr, a1, H, W, F, 1, 1};
+                HIPCHK(launch_conv3x3_bf16(q, s));
+            }
+            {   // conv10_i
+                ProfScope ps(h, s, PFNL_K_CONV1X1);
+                HIPCHK(launch_conv1x1_bf16(a1, w16 + h->off16_c10[i], wd + h->off_c10_b[i], ab, B, T, H * W, 1, s));
+            }
+            {   // conv2_i, shared half (raw, once per clip)
+                ProfScope ps(h, s, PFNL_K_CONV3X3);
+                ConvBf16Params q{ab, w16 + h->off16_c2a[i], wd + h->off_zero, nullptr, nullptr, ap, H, W, B, 1, 0};
+                HIPCHK(launch_conv3x3_bf16(q, s));
+            }
+            {   // conv2_i, per-frame half + shared half + bias, lrelu, residual
+                ProfScope ps(h, s, PFNL_K_CONV3X3);
+                ConvBf16Params q{a1, w16 + h->off16_c2b[i], wd + h->off_c2_b[i], ap, a0, a0, H, W, F, T, 1};
+                HIPCHK(launch_conv3x3_bf16(q, s));
+            }
+        }
+        {   // back to fp32 for convmerge1 (1.2 % of the FLOPs) and the tail
+            ProfScope ps(h, s, PFNL_K_MERGE1);
+            HIPCHK(launch_cast_bf16_f32(a0, h->inp1.p, (size_t)F * P * 64, s));
+        }
+        merge_in = h->inp1.p;
     }
 
     ConvParams p{};
@@ -210,7 +257,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
     p.in_cstride = 64;
     p.chunks_per_frame = 64 / CONV_CK;
     const int wino_groups = B * ((W + 31) / 32) * ((H + 3) / 4);   // (clip, 4x32-pixel tile) groups of conv_wino_ws
-    for (int i = 0; i < c.num_block; ++i) {   // model/pfnl.py:65-71
+    for (int i = 0; i < (h->bf16 ? 0 : c.num_block); ++i) {   // model/pfnl.py:65-71
         if (h->prof_mode == 2) {          // sampled profiling: blocks 0, 4, 8, ... each with a fresh event chain
             h->prof_gate = (i & 3) == 0;
             h->chain_open = false;
@@ -325,7 +372,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
         // the same accumulators, one epilogue per clip tile)
         ProfScope ps(h, s, PFNL_K_MERGE1);
         WinoParams wp{};
-        wp.in = h->inp0.p;
+        wp.in = merge_in;
         wp.upack = wd + h->off_m1_u[0];
         wp.upack_stride = T > 1 ? (long long)(h->off_m1_u[1] - h->off_m1_u[0]) : 0;
         wp.accum = 1;
@@ -339,7 +386,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
         HIPCHK(launch_conv_wino_ws(wp, s));
     } else {   // convmerge1: 3x3 over the concat of T frames -> 48 + lrelu        (:73-74)
         ProfScope ps(h, s, PFNL_K_MERGE1);
-        p.in = h->inp0.p;
+        p.in = merge_in;
         p.wpack = wd + h->off_m1_w;
         p.bias = wd + h->off_m1_b;
         p.addend = nullptr;
@@ -422,7 +469,7 @@ int pfnl_destroy(pfnl_handle* h) {
         if (g.exec) hipGraphExecDestroy(g.exec);
         if (g.graph) hipGraphDestroy(g.graph);
     }
-    for (DevBuf* b : {&h->wdev, &h->X, &h->Xo, &h->nlp, &h->inp0, &h->inp1, &h->base, &h->pb, &h->merge,
+    for (DevBuf* b : {&h->wdev, &h->wdev16, &h->X, &h->Xo, &h->nlp, &h->inp0, &h->inp1, &h->base, &h->pb, &h->merge,
                       &h->stage_in, &h->stage_out, &h->scratch})
         b->release();
     delete h;
@@ -472,6 +519,12 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         if (v == "grouped") h->conv2_grouped = true;
         else if (v == "split") h->conv2_grouped = false;
         else return fail(PFNL_ERR_INVALID, "conv2 must be grouped or split");
+        return 0;
+    }
+    if (k == "precision") {
+        if (v == "bf16") h->bf16 = true;
+        else if (v == "fp32") h->bf16 = false;
+        else return fail(PFNL_ERR_INVALID, "precision must be fp32 or bf16");
         return 0;
     }
     if (k == "conv1x1") {
@@ -595,6 +648,32 @@ int pfnl_finalize_weights(pfnl_handle* h) {
             for (int cm = 0; cm < C; ++cm) acc += (double)bg[cm] * (double)ww[(size_t)cm * C + co];
             blob[h->off_nl_b + co] = (float)acc;
         }
+    }
+    {   // bf16 packs of the trunk (precision=bf16)
+        std::vector<uint16_t> b16;
+        auto reserve16 = [&](size_t n) {
+            size_t off = (b16.size() + 127) / 128 * 128;
+            b16.resize(off + n, 0);
+            return off;
+        };
+        h->off16_c1.assign(nb, 0);
+        h->off16_c10.assign(nb, 0);
+        h->off16_c2a.assign(nb, 0);
+        h->off16_c2b.assign(nb, 0);
+        for (int i = 0; i < nb; ++i) {
+            const std::string s = std::to_string(i);
+            h->off16_c1[i] = reserve16(pfnl::conv3x3_bf16_pack_halfs());
+            pfnl::conv3x3_bf16_pack_weights(W("conv1_" + s).data(), 64, 0, &b16[h->off16_c1[i]]);
+            h->off16_c10[i] = reserve16(pfnl::conv1x1_bf16_pack_halfs(T));
+            pfnl::conv1x1_bf16_pack_weights(W("conv10_" + s).data(), T, &b16[h->off16_c10[i]]);
+            h->off16_c2a[i] = reserve16(pfnl::conv3x3_bf16_pack_halfs());
+            pfnl::conv3x3_bf16_pack_weights(W("conv2_" + s).data(), 128, 0, &b16[h->off16_c2a[i]]);
+            h->off16_c2b[i] = reserve16(pfnl::conv3x3_bf16_pack_halfs());
+            pfnl::conv3x3_bf16_pack_weights(W("conv2_" + s).data(), 128, 64, &b16[h->off16_c2b[i]]);
+        }
+        b16.resize((b16.size() + 1) / 2 * 2 + 2, 0);
+        if (h->wdev16.ensure(b16.size() / 2)) return fail(PFNL_ERR_NOMEM, "weight allocation failed");
+        HIPCHK(hipMemcpy(h->wdev16.p, b16.data(), b16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     if (h->wdev.ensure(blob.size())) return fail(PFNL_ERR_NOMEM, "weight allocation failed");
     HIPCHK(hipMemcpy(h->wdev.p, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -763,7 +842,7 @@ int pfnl_debug_tap(pfnl_handle* h, const char* name, float* host_dst, size_t cou
         src = h->scratch.p;
     } else if (n == "trunk") {
         need = (size_t)B * T * H * W * 64;
-        src = h->inp0.p;
+        src = h->bf16 ? h->inp1.p : h->inp0.p;                      // bf16 trunk: the fp32 copy made for convmerge1
     } else if (n == "merge1") {
         need = (size_t)B * H * W * 48;
         if (count != need) return fail(PFNL_ERR_INVALID, "tap size mismatch");
@@ -896,6 +975,46 @@ int pfnl_op_conv3x3_accum(const float* in, const float* kernel_host, const float
     }
     (void)hipFree(dw);
     if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("accumulating conv op: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int pfnl_op_conv3x3_bf16(const uint16_t* in, const float* kernel_host, const float* bias_host, const uint16_t* addend,
+                         int add_div, const uint16_t* resid, uint16_t* out, int items, int H, int W, int act, void* stream) {
+    if (!in || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (items < 1 || H < 1 || W < 1 || (addend == nullptr) != (resid == nullptr)) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nh = pfnl::conv3x3_bf16_pack_halfs();
+    std::vector<uint16_t> pack(nh + 128, 0);
+    pfnl::conv3x3_bf16_pack_weights(kernel_host, 64, 0, pack.data());
+    if (bias_host) std::memcpy(&pack[nh], bias_host, 64 * sizeof(float));
+    uint16_t* dw = nullptr;
+    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(uint16_t)));
+    hipError_t e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    pfnl::ConvBf16Params q{in, dw, reinterpret_cast<const float*>(dw + nh), addend, resid, out, H, W, items, add_div < 1 ? 1 : add_div, act};
+    if (e == hipSuccess) e = pfnl::launch_conv3x3_bf16(q, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dw);
+    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv3x3 bf16 op: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int pfnl_op_conv1x1_bf16(const uint16_t* in, const float* kernel_host, const float* bias_host, uint16_t* out, int items,
+                         int frames_per_item, int HW, int act, void* stream) {
+    if (!in || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    const int T = frames_per_item;
+    if (items < 1 || (T != 3 && T != 5 && T != 7) || HW < 1) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nh = pfnl::conv1x1_bf16_pack_halfs(T);
+    std::vector<uint16_t> pack(nh + 128, 0);
+    pfnl::conv1x1_bf16_pack_weights(kernel_host, T, pack.data());
+    if (bias_host) std::memcpy(&pack[nh], bias_host, 64 * sizeof(float));
+    uint16_t* dw = nullptr;
+    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(uint16_t)));
+    hipError_t e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = pfnl::launch_conv1x1_bf16(in, dw, reinterpret_cast<const float*>(dw + nh), out, items, T, HW, act, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dw);
+    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv1x1 bf16 op: ") + hipGetErrorString(e));
     return 0;
 }
 

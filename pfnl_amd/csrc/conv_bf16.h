@@ -1,0 +1,32 @@
+// bf16 trunk kernels (conv_bf16.hip): declarations shared with capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace pfnl {
+
+struct ConvBf16Params {
+    const uint16_t* in;      // [items][H][W][64] bf16
+    const uint16_t* wpack;   // conv3x3_bf16_pack_weights
+    const float* bias;       // [64] f32; never null
+    const uint16_t* addend;  // [items/add_div][H][W][64] bf16, added before the activation \ both or
+    const uint16_t* resid;   // [items][H][W][64] bf16, added after the activation           / neither
+    uint16_t* out;           // [items][H][W][64] bf16 (may alias resid)
+    int H, W, items, add_div, act;
+};
+hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s);
+hipError_t launch_conv1x1_bf16(const uint16_t* in, const uint16_t* wpack, const float* bias, uint16_t* out, int items, int T,
+                               int HW, int act, hipStream_t s);
+hipError_t launch_cast_bf16_f32(const uint16_t* in, float* out, size_t n, hipStream_t s);   // n % 8 == 0
+hipError_t launch_cast_f32_bf16(const float* in, uint16_t* out, size_t n, hipStream_t s);
+uint16_t bf16_rne(float f);
+size_t conv3x3_bf16_pack_halfs();
+void conv3x3_bf16_pack_weights(const float* hwio, int cin_total, int cin_begin, uint16_t* dst);
+size_t conv1x1_bf16_pack_halfs(int T);
+void conv1x1_bf16_pack_weights(const float* hwio, int T, uint16_t* dst);
+// conv0 writing the bf16 trunk input (misc_kernels.hip)
+hipError_t launch_conv0_bf16(const float* Xo, const float* w75x64, const float* bias, uint16_t* out, int B, int T, int H,
+                             int W, hipStream_t s);
+
+}  // namespace pfnl

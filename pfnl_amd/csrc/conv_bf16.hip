@@ -1,0 +1,413 @@
+// bf16 trunk (BASELINE.json configs[3]: 1080p, bf16 activations + weights, fp32 accumulation): the 3x3 64->64
+// convolutions of the progressive-fusion blocks (conv1_i, both halves of conv2_i; reference model/pfnl.py:49-51,
+// 66-71) and conv10_i (1x1, T*64 -> 64; :50, :67-68) on v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate.
+//
+// At that rate the matrix pipe is no longer what bounds the block: layer by layer the trunk moves 5.6 KB per LR
+// pixel and block in bf16, i.e. ~15 GB per 1080p forward against 3 TFLOP of DIRECT 3x3 work (1.2 ms at the 2.5
+// PFLOP/s dense peak, ~3 ms at 5 TB/s).  So this kernel is the direct algorithm (a Winograd transform would cost
+// more VALU time than the multiplies it saves), written so that HBM streams while the MFMAs run:
+//
+//   * persistent workgroup per CU (512 threads = 2 waves per SIMD); the launch's packed weights (9 taps x 64 x 64
+//     bf16 = 72 KB) are copied into LDS once and stay there;
+//   * output tile 16 rows x 32 columns x 64 channels; its 18 x 34-pixel halo tile (128 B per pixel, 76.5 KB)
+//     lives in LDS next to the weights (148.7 of 160 KB), 16-byte channel chunks XOR-swizzled by (column >> 1) & 7
+//     so that a ds_read_b128 of one chunk of 32 consecutive pixels is bank-conflict free;
+//   * MFMA roles: A = weights (rows = 32 output channels), B = pixels (columns = 32 pixels of a tile row), so
+//     that an accumulator lane owns ONE pixel and 4 consecutive output channels per register quad: the epilogue
+//     (bias, shared-half addend, leaky_relu, residual) works on 8-byte pieces of a pixel's 128-byte line;
+//   * wave w owns tile rows 2w, 2w+1 (2 pixel tiles x 2 channel tiles = 4 accumulators).  For a fixed column tap
+//     kx and 16-channel step, the 4 halo rows 2w..2w+3 serve all 3 row taps of both output rows: 4 pixel reads +
+//     6 weight reads feed 12 MFMAs;
+//   * the next tile's halo is requested into registers (10 x 16 B per thread, buffer loads whose range check
+//     zero-fills the border) before the 432 MFMAs of the current tile start, and written to LDS after them.
+//
+// conv2_i keeps the shared-`base` split of the fp32 path (`SURVEY.md` §8(a)-G): one launch over `base` produces
+// the raw shared half per clip, the per-frame launch adds it before the activation.
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+#include "conv_bf16.h"
+
+namespace pfnl {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int CB_THREADS = 512;
+constexpr int CB_TH = 16, CB_TW = 32;
+constexpr int CB_IH = CB_TH + 2, CB_IW = CB_TW + 2;
+constexpr int CB_TILE_BYTES = CB_IH * CB_IW * 128;                  // 78 336
+constexpr int CB_W_BYTES = 9 * 4 * 2 * 1024;                        // 73 728: [tap][kstep][channel tile][lane] x 16 B
+constexpr int CB_LDS_BYTES = CB_TILE_BYTES + CB_W_BYTES + 64 * 4;   // + bias
+constexpr int CB_CHUNKS = CB_IH * CB_IW * 8;                        // 16-byte pieces of a halo tile
+constexpr int CB_ITERS = (CB_CHUNKS + CB_THREADS - 1) / CB_THREADS; // 10
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 bf16x4_to_f32(u32x2 v) {
+    return f32x4{__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xffff0000u),
+                 __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xffff0000u)};
+}
+__device__ __forceinline__ u32x2 f32x4_to_bf16(f32x4 v) {         // round to nearest even (v_cvt_pk_bf16_f32)
+    const bf16x4 b = __builtin_convertvector(v, bf16x4);
+    return __builtin_bit_cast(u32x2, b);
+}
+
+template <bool FUSE>
+__global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cb_smem[];
+    unsigned char* const tile = cb_smem;
+    unsigned char* const wl = cb_smem + CB_TILE_BYTES;
+    float* const bl = reinterpret_cast<float*>(cb_smem + CB_TILE_BYTES + CB_W_BYTES);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, W = p.W;
+    const int tiles_x = (W + CB_TW - 1) / CB_TW, tiles_y = (H + CB_TH - 1) / CB_TH;
+    const int per_item = tiles_x * tiles_y;
+    const int ntiles = per_item * p.items;
+    const int item_bytes = H * W * 128;
+
+    // weights + bias -> LDS (once per workgroup)
+#pragma unroll
+    for (int k = 0; k < CB_W_BYTES / 16 / CB_THREADS; ++k)
+        reinterpret_cast<u32x4*>(wl)[k * CB_THREADS + tid] = reinterpret_cast<const u32x4*>(p.wpack)[k * CB_THREADS + tid];
+    if (tid < 64) bl[tid] = p.bias[tid];
+
+    // staging map: piece id = k*512 + tid -> halo pixel id >> 3, channel chunk id & 7
+    int soff[CB_ITERS], srel[CB_ITERS], spyx[CB_ITERS];
+#pragma unroll
+    for (int k = 0; k < CB_ITERS; ++k) {
+        const int id = min(k * CB_THREADS + tid, CB_CHUNKS - 1);    // surplus threads redo the last piece (same value)
+        const int pix = id >> 3, c = id & 7;
+        const int py = pix / CB_IW, px = pix - py * CB_IW;
+        soff[k] = pix * 128 + ((c ^ ((px >> 1) & 7)) << 4);
+        srel[k] = ((py - 1) * W + (px - 1)) * 128 + c * 16;
+        spyx[k] = (py << 16) | px;
+    }
+    u32x4 stg[CB_ITERS];
+#define CB_REQUEST(t_)                                                                           \
+    do {                                                                                         \
+        const int it_ = (t_) / per_item, sp_ = (t_) - it_ * per_item;                            \
+        const int ty_ = sp_ / tiles_x;                                                           \
+        const int y0_ = ty_ * CB_TH, x0_ = (sp_ - ty_ * tiles_x) * CB_TW;                        \
+        const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                    \
+            const_cast<uint16_t*>(p.in) + (size_t)it_ * H * W * 64, 0, item_bytes, 0x00020000);  \
+        const int org_ = (y0_ * W + x0_) * 128;                                                  \
+        if (y0_ > 0 && y0_ + CB_IH - 1 <= H && x0_ > 0 && x0_ + CB_IW - 1 <= W) {                \
+            _Pragma("unroll") for (int k_ = 0; k_ < CB_ITERS; ++k_)                              \
+                stg[k_] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, org_ + srel[k_], 0, 0)); \
+        } else {                                                                                 \
+            _Pragma("unroll") for (int k_ = 0; k_ < CB_ITERS; ++k_) {                            \
+                const int gy_ = y0_ + (spyx[k_] >> 16) - 1, gx_ = x0_ + (spyx[k_] & 0xffff) - 1; \
+                const bool in_ = (unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W;     \
+                stg[k_] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, in_ ? org_ + srel[k_] : 0x7fffffff, 0, 0)); \
+            }                                                                                    \
+        }                                                                                        \
+    } while (0)
+
+    // operand addresses: pixel operand of (column tap kx, k-step ks) = chunk 2*ks + (lane >> 5) of halo pixel
+    // (row 2*wave + ..., column (lane & 31) + kx); weights: 16 bytes per lane
+    int paddr[3][4];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int col = (lane & 31) + kx;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            paddr[kx][ks] = ((2 * wave) * CB_IW + col) * 128 + (((2 * ks + (lane >> 5)) ^ ((col >> 1) & 7)) << 4);
+    }
+    const unsigned char* const wlane = wl + lane * 16;
+
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    CB_REQUEST(t);
+    for (; t < ntiles; t += gridDim.x) {
+        __syncthreads();                                            // the previous tile's operands have been read (and the weights written)
+#pragma unroll
+        for (int k = 0; k < CB_ITERS; ++k) *reinterpret_cast<u32x4*>(tile + soff[k]) = stg[k];
+        __syncthreads();
+        const int tn = t + gridDim.x;
+        CB_REQUEST(min(tn, ntiles - 1));                            // past the end: harmless re-read
+        __builtin_amdgcn_sched_barrier(0);
+
+        const int item = t / per_item, sp = t - item * per_item;
+        const int ty = sp / tiles_x;
+        const int y0 = ty * CB_TH, x0 = (sp - ty * tiles_x) * CB_TW;
+
+        f32x16 acc[2][2];                                           // [channel tile][output row]
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+        // epilogue inputs: this lane's pixel of output row n; 8-byte pieces at channels 32m + 8g + 4(lane>>5)
+        const int ox = x0 + (lane & 31);
+        const int ech = 4 * (lane >> 5);
+        int eoff[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int oy = y0 + 2 * wave + n;
+            eoff[n] = (ox < W && oy < H) ? ((oy * W + ox) * 64 + ech) * 2 : 0x7fffffff;
+        }
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)item * H * W * 64, 0, item_bytes, 0x00020000);
+        u32x2 rres[2][2][4], radd[2][2][4];
+
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (FUSE && kx == 2 && ks == 0) {                   // addend / residual: requested 4 groups before the epilogue
+                    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<uint16_t*>(p.resid) + (size_t)item * H * W * 64, 0, item_bytes, 0x00020000);
+                    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<uint16_t*>(p.addend) + (size_t)(item / p.add_div) * H * W * 64, 0, item_bytes, 0x00020000);
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                radd[m][n][g] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsA, eoff[n], (32 * m + 8 * g) * 2, 0));
+                                rres[m][n][g] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsR, eoff[n], (32 * m + 8 * g) * 2, 0));
+                            }
+                }
+                bf16x8 px[4], wv[3][2];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    px[r] = *reinterpret_cast<const bf16x8*>(tile + paddr[kx][ks] + r * (CB_IW * 128));
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        wv[ky][m] = *reinterpret_cast<const bf16x8*>(wlane + ((((ky * 3 + kx) * 4 + ks) * 2 + m) << 10));
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) acc[m][n] = mfma_bf16(wv[ky][m], px[n + ky], acc[m][n]);
+            }
+        }
+
+        // epilogue: register r of acc[m][n] = channel 32m + (r&3) + 8(r>>2) + 4(lane>>5) of this lane's pixel
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + 32 * m + 8 * g + ech);
+                    f32x4 v = f32x4{acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]} + b4;
+                    if (FUSE) v += bf16x4_to_f32(radd[m][n][g]);
+                    if (p.act) {
+                        v.x = lrelu(v.x);
+                        v.y = lrelu(v.y);
+                        v.z = lrelu(v.z);
+                        v.w = lrelu(v.w);
+                    }
+                    if (FUSE) v += bf16x4_to_f32(rres[m][n][g]);
+                    __builtin_amdgcn_raw_buffer_store_b64(f32x4_to_bf16(v), rsO, eoff[n], (32 * m + 8 * g) * 2, 0);
+                }
+    }
+#undef CB_REQUEST
+}
+
+hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s) {
+    if (!p.in || !p.wpack || !p.bias || !p.out || p.items < 1 || p.H < 1 || p.W < 1) return hipErrorInvalidValue;
+    if ((p.addend == nullptr) != (p.resid == nullptr) || (p.addend && (p.add_div < 1 || p.items % p.add_div))) return hipErrorInvalidValue;
+    if ((long long)p.H * p.W * 128 >= 0x7fffffffLL) return hipErrorInvalidValue;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        ncu = prop.multiProcessorCount;
+    }
+    const int ntiles = ((p.W + CB_TW - 1) / CB_TW) * ((p.H + CB_TH - 1) / CB_TH) * p.items;
+    const int grid = ntiles < ncu ? ntiles : ncu;
+    static bool attr[2] = {false, false};
+    if (p.addend) {
+        if (!attr[1]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS_BYTES);
+            if (e != hipSuccess) return e;
+            attr[1] = true;
+        }
+        hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, dim3(grid), dim3(CB_THREADS), CB_LDS_BYTES, s, p);
+    } else {
+        if (!attr[0]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS_BYTES);
+            if (e != hipSuccess) return e;
+            attr[0] = true;
+        }
+        hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, dim3(grid), dim3(CB_THREADS), CB_LDS_BYTES, s, p);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv10_i in bf16: T*64 -> 64 over the concat of the T frames of a clip.  HBM-bound by a wide margin (896 B read
+// per pixel for 57 kFLOP): the packed weights (T x 8 KB) sit in LDS, a wave takes 32 consecutive pixels, requests
+// all T*4 16-byte pieces of its lanes' pixels at once and runs the 8T MFMAs as they arrive.
+template <int T>
+__global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wpack,
+                                                              const float* __restrict__ bias, uint16_t* __restrict__ out,
+                                                              int HW, int items, int act) {
+    __shared__ __attribute__((aligned(16))) unsigned char wl[T * 8192 + 256];
+    float* const bl = reinterpret_cast<float*>(wl + T * 8192);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int k = tid; k < T * 512; k += 256) reinterpret_cast<u32x4*>(wl)[k] = reinterpret_cast<const u32x4*>(wpack)[k];
+    if (tid < 64) bl[tid] = bias[tid];
+    __syncthreads();
+    const int gpi = (HW + 31) >> 5;
+    const int ngroups = gpi * items;
+    const int frame_bytes = HW * 128;
+    const unsigned char* const wlane = wl + lane * 16;
+    const int ech = 4 * (lane >> 5);
+    for (int g = blockIdx.x * 4 + wave; g < ngroups; g += gridDim.x * 4) {
+        const int item = g / gpi;
+        const int p0 = (g - item * gpi) * 32;
+        const int px = p0 + (lane & 31);
+        const int voff = px < HW ? px * 128 + (lane >> 5) * 16 : 0x7fffffff;
+        const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint16_t*>(in) + (size_t)item * T * HW * 64, 0, T * frame_bytes, 0x00020000);
+        bf16x8 b[T][4];
+#pragma unroll
+        for (int f = 0; f < T; ++f)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                b[f][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsI, voff, f * frame_bytes + ks * 32, 0));
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[0][r] = 0.f;
+            acc[1][r] = 0.f;
+        }
+#pragma unroll
+        for (int f = 0; f < T; ++f) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    acc[m] = mfma_bf16(*reinterpret_cast<const bf16x8*>(wlane + (((f * 4 + ks) * 2 + m) << 10)), b[f][ks], acc[m]);
+            __builtin_amdgcn_sched_barrier(0);                      // keep the weight reads next to their MFMAs (registers)
+        }
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)item * HW * 64, 0, frame_bytes, 0x00020000);
+        const int ooff = px < HW ? px * 128 + ech * 2 : 0x7fffffff;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + 32 * m + 8 * q + ech);
+                f32x4 v = f32x4{acc[m][4 * q], acc[m][4 * q + 1], acc[m][4 * q + 2], acc[m][4 * q + 3]} + b4;
+                if (act) {
+                    v.x = lrelu(v.x);
+                    v.y = lrelu(v.y);
+                    v.z = lrelu(v.z);
+                    v.w = lrelu(v.w);
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(f32x4_to_bf16(v), rsO, ooff, (32 * m + 8 * q) * 2, 0);
+            }
+    }
+}
+
+hipError_t launch_conv1x1_bf16(const uint16_t* in, const uint16_t* wpack, const float* bias, uint16_t* out, int items, int T,
+                               int HW, int act, hipStream_t s) {
+    if (!in || !wpack || !bias || !out || items < 1 || HW < 1) return hipErrorInvalidValue;
+    if ((long long)T * HW * 128 >= 0x7fffffffLL) return hipErrorInvalidValue;
+    const int ngroups = ((HW + 31) / 32) * items;
+    const int grid = (ngroups + 3) / 4 < 512 ? (ngroups + 3) / 4 : 512;
+    switch (T) {
+        case 3: hipLaunchKernelGGL(conv1x1_bf16_kernel<3>, dim3(grid), dim3(256), 0, s, in, wpack, bias, out, HW, items, act); break;
+        case 5: hipLaunchKernelGGL(conv1x1_bf16_kernel<5>, dim3(grid), dim3(256), 0, s, in, wpack, bias, out, HW, items, act); break;
+        case 7: hipLaunchKernelGGL(conv1x1_bf16_kernel<7>, dim3(grid), dim3(256), 0, s, in, wpack, bias, out, HW, items, act); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// element casts between the bf16 trunk and the fp32 kernels either side of it
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const u32x4* __restrict__ in, f32x4* __restrict__ out, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const u32x4 v = in[i];
+        out[2 * i] = bf16x4_to_f32(u32x2{v.x, v.y});
+        out[2 * i + 1] = bf16x4_to_f32(u32x2{v.z, v.w});
+    }
+}
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const f32x4* __restrict__ in, u32x4* __restrict__ out, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const u32x2 a = f32x4_to_bf16(in[2 * i]), b = f32x4_to_bf16(in[2 * i + 1]);
+        out[i] = u32x4{a.x, a.y, b.x, b.y};
+    }
+}
+
+hipError_t launch_cast_bf16_f32(const uint16_t* in, float* out, size_t n, hipStream_t s) {
+    if (n % 8) return hipErrorInvalidValue;
+    const size_t n8 = n / 8;
+    const int grid = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid ? grid : 1), dim3(256), 0, s, reinterpret_cast<const u32x4*>(in),
+                       reinterpret_cast<f32x4*>(out), n8);
+    return hipGetLastError();
+}
+hipError_t launch_cast_f32_bf16(const float* in, uint16_t* out, size_t n, hipStream_t s) {
+    if (n % 8) return hipErrorInvalidValue;
+    const size_t n8 = n / 8;
+    const int grid = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid ? grid : 1), dim3(256), 0, s, reinterpret_cast<const f32x4*>(in),
+                       reinterpret_cast<u32x4*>(out), n8);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side packing (round to nearest even, like the device conversion)
+uint16_t bf16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+size_t conv3x3_bf16_pack_halfs() { return CB_W_BYTES / 2; }
+
+// HWIO [3,3,cin_total,64] rows [cin_begin, cin_begin+64) -> [tap][ks][m][lane][e]:
+// W[ky][kx][cin_begin + 16 ks + 8 (lane>>5) + e][32 m + (lane&31)]
+void conv3x3_bf16_pack_weights(const float* hwio, int cin_total, int cin_begin, uint16_t* dst) {
+    for (int tap = 0; tap < 9; ++tap)
+        for (int ks = 0; ks < 4; ++ks)
+            for (int m = 0; m < 2; ++m)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int ci = cin_begin + 16 * ks + 8 * (lane >> 5) + e;
+                        const int co = 32 * m + (lane & 31);
+                        dst[((((size_t)tap * 4 + ks) * 2 + m) * 64 + lane) * 8 + e] = bf16_rne(hwio[((size_t)tap * cin_total + ci) * 64 + co]);
+                    }
+}
+
+size_t conv1x1_bf16_pack_halfs(int T) { return (size_t)T * 4096; }
+
+// HWIO [1,1,T*64,64] -> [f][ks][m][lane][e]: W[64 f + 16 ks + 8 (lane>>5) + e][32 m + (lane&31)]
+void conv1x1_bf16_pack_weights(const float* hwio, int T, uint16_t* dst) {
+    for (int f = 0; f < T; ++f)
+        for (int ks = 0; ks < 4; ++ks)
+            for (int m = 0; m < 2; ++m)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int ci = 64 * f + 16 * ks + 8 * (lane >> 5) + e;
+                        const int co = 32 * m + (lane & 31);
+                        dst[((((size_t)f * 4 + ks) * 2 + m) * 64 + lane) * 8 + e] = bf16_rne(hwio[(size_t)ci * 64 + co]);
+                    }
+}
+
+}  // namespace pfnl

@@ -5,6 +5,7 @@
 //   bicubic : TF1.12 legacy ResizeBicubic (align_corners=False, no half-pixel centres, A=-0.75,
 //             clamped taps, no renormalisation)                           (model/pfnl.py:63)
 #include "common.h"
+#include "conv_bf16.h"
 
 namespace pfnl {
 
@@ -15,6 +16,7 @@ namespace pfnl {
 constexpr int C0_T = 16;
 constexpr int C0_IN = C0_T + 4;
 
+template <bool BF16OUT>                                             // bf16 trunk: `out` is [F][H][W][64] bf16
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ Xo,
                                                     const float* __restrict__ w,     // [75][64]
                                                     const float* __restrict__ bias,  // [64]
@@ -86,9 +88,16 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ Xo
             const int id = it * 256 + tid;
             const int pix = id >> 3, q = id & 7;
             const int y = y0 + pix / C0_T, x = x0 + pix % C0_T;
-            if (y < H && x < W)
-                *reinterpret_cast<f32x4*>(out + (((size_t)f * H + y) * W + x) * 64 + hp * 32 + q * 4) =
-                    *reinterpret_cast<const f32x4*>(slab + pix * SS + q * 4);
+            if (y < H && x < W) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(slab + pix * SS + q * 4);
+                if (BF16OUT) {
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<uint16_t*>(out) + (((size_t)f * H + y) * W + x) * 64 + hp * 32 + q * 4) =
+                        __builtin_convertvector(v, bf16x4);
+                } else {
+                    *reinterpret_cast<f32x4*>(out + (((size_t)f * H + y) * W + x) * 64 + hp * 32 + q * 4) = v;
+                }
+            }
         }
     }
 }
@@ -96,7 +105,15 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ Xo
 hipError_t launch_conv0(const float* Xo, const float* w75x64, const float* bias, float* out, int B,
                         int T, int H, int W, hipStream_t s) {
     dim3 grid((W + C0_T - 1) / C0_T, (H + C0_T - 1) / C0_T, B * T);
-    hipLaunchKernelGGL(conv0_kernel, grid, dim3(256), 0, s, Xo, w75x64, bias, out, T, H, W,
+    hipLaunchKernelGGL(conv0_kernel<false>, grid, dim3(256), 0, s, Xo, w75x64, bias, out, T, H, W,
+                       nl_padded_ch(12 * T));
+    return hipGetLastError();
+}
+
+hipError_t launch_conv0_bf16(const float* Xo, const float* w75x64, const float* bias, uint16_t* out, int B, int T, int H,
+                             int W, hipStream_t s) {
+    dim3 grid((W + C0_T - 1) / C0_T, (H + C0_T - 1) / C0_T, B * T);
+    hipLaunchKernelGGL(conv0_kernel<true>, grid, dim3(256), 0, s, Xo, w75x64, bias, reinterpret_cast<float*>(out), T, H, W,
                        nl_padded_ch(12 * T));
     return hipGetLastError();
 }

@@ -18,6 +18,13 @@ def _req(t, name):
     return C.c_void_p(t.data_ptr())
 
 
+def _req16(t, name):
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()):
+        raise TypeError(f"{name} must be a contiguous bfloat16 tensor on the GPU")
+    return C.c_void_p(t.data_ptr())
+
+
 def _host(a, name) -> Optional[np.ndarray]:
     if a is None:
         return None
@@ -88,6 +95,41 @@ def conv3x3_accum(x, kernel, bias=None, act=True, frames_per_clip=1):
         _req(x, "x"), k.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p) if b is not None else None,
         _req(out, "out"), F // frames_per_clip, frames_per_clip, H, W, cout, 1 if act else 0, _stream(x)))
     return out[..., :cout]
+
+
+def conv3x3_bf16(x, kernel, bias=None, act=True, addend=None, add_div=1, resid=None):
+    """bf16 trunk: 3x3 64->64 'same' convolution on bf16 MFMA, fp32 accumulation; out = act(conv + bias + addend) + resid.
+    x / addend / resid / result: bfloat16 [items, H, W, 64] (cuda); kernel fp32 HWIO [3,3,64,64] (rounded inside).
+    Reference: model/pfnl.py:49,51 applied at :66,69-71."""
+    import torch
+    lib = _capi.load_library()
+    k, b = _host(kernel, "kernel"), _host(bias, "bias")
+    F, H, W, c = x.shape
+    if k.shape != (3, 3, 64, 64) or c != 64 or (addend is None) != (resid is None):
+        raise ValueError("conv3x3_bf16: geometry mismatch")
+    out = torch.empty_like(x)
+    _capi.check(lib.pfnl_op_conv3x3_bf16(
+        _req16(x, "x"), k.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p) if b is not None else None,
+        _req16(addend, "addend") if addend is not None else None, add_div,
+        _req16(resid, "resid") if resid is not None else None, _req16(out, "out"), F, H, W, 1 if act else 0, _stream(x)))
+    return out
+
+
+def conv1x1_bf16(x, kernel, bias=None, act=True, frames_per_item=7):
+    """bf16 trunk: conv10_i, 1x1 over the concat of `frames_per_item` frames.  x bfloat16 [items*fpi, H, W, 64];
+    kernel fp32 HWIO [1,1,64*fpi,64].  Reference: model/pfnl.py:50, :67-68."""
+    import torch
+    lib = _capi.load_library()
+    k, b = _host(kernel, "kernel"), _host(bias, "bias")
+    F, H, W, c = x.shape
+    if k.shape != (1, 1, 64 * frames_per_item, 64) or c != 64 or F % frames_per_item:
+        raise ValueError("conv1x1_bf16: geometry mismatch")
+    items = F // frames_per_item
+    out = torch.empty((items, H, W, 64), dtype=torch.bfloat16, device=x.device)
+    _capi.check(lib.pfnl_op_conv1x1_bf16(
+        _req16(x, "x"), k.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p) if b is not None else None,
+        _req16(out, "out"), items, frames_per_item, H * W, 1 if act else 0, _stream(x)))
+    return out
 
 
 def conv1x1_stream(x, kernel, bias=None, act=True, frames_per_item=1):

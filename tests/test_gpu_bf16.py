@@ -1,0 +1,107 @@
+"""bf16 trunk (option precision=bf16, BASELINE.json configs[3]) on a real MI355X: the bf16 kernels against a torch-CPU
+restatement with the same rounding points (bf16 operands, fp32 accumulation, bf16 stores), through the C-ABI.
+
+Tolerances.  A bf16 store rounds to nearest even: |error| <= 2^-9 |v| per element; the fp32 accumulation order of
+the MFMA differs from the CPU's, which can move a value across a rounding boundary, i.e. up to one bf16 ulp
+(2^-8 |v|) on isolated elements.  Ops: |d| <= 2^-7 |ref| + 1e-5 element-wise and a mean error far below one ulp.
+Whole forward (20 blocks of such stores, then the fp32 merge / tail): PSNR against the equally-rounded oracle
+> 55 dB and |dPSNR| against ground truth vs the fp32 oracle reported and bounded at 0.1 dB (NOT the fp32 bar)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+import torch.nn.functional as F  # noqa: E402
+
+from oracle import pfnl_fast  # noqa: E402
+from pfnl_amd import ops, synth  # noqa: E402
+from pfnl_amd.engine import PFNLEngine  # noqa: E402
+from pfnl_amd.spec import PFNLGeometry  # noqa: E402
+
+
+def r16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def close_bf16(out, ref32):
+    d = (out.float().cpu() - ref32).abs()
+    bound = ref32.abs() * 2.0 ** -7 + 1e-5
+    assert bool((d <= bound).all()), float((d - bound).max())
+    assert float(d.mean()) <= float(ref32.abs().mean()) * 2.0 ** -9 + 1e-6
+
+
+def ref_conv3(x, k, b, act, addend=None, add_div=1, resid=None):
+    y = F.conv2d(x.permute(0, 3, 1, 2), r16(torch.from_numpy(k)).permute(3, 2, 0, 1), torch.from_numpy(b), padding=1)
+    y = y.permute(0, 2, 3, 1)
+    if addend is not None:
+        y = y + addend.repeat_interleave(add_div, 0)
+    if act:
+        y = F.leaky_relu(y, 0.2)
+    if resid is not None:
+        y = y + resid
+    return y
+
+
+@pytest.mark.parametrize("shape", [(3, 20, 36), (2, 16, 32), (1, 50, 70), (2, 2, 2), (1, 33, 95), (7, 18, 34)])
+@pytest.mark.parametrize("act", [True, False])
+def test_conv3x3_bf16_plain(shape, act):
+    Fr, H, W = shape
+    g = torch.Generator().manual_seed(Fr * 1000 + H)
+    x = r16(torch.randn(Fr, H, W, 64, generator=g))
+    k = (torch.randn(3, 3, 64, 64, generator=g) * 0.05).numpy()
+    b = (torch.randn(64, generator=g) * 0.1).numpy()
+    out = ops.conv3x3_bf16(x.to(torch.bfloat16).cuda(), k, b, act=act)
+    close_bf16(out, ref_conv3(x, k, b, act))
+
+
+@pytest.mark.parametrize("clips,T,H,W", [(2, 7, 20, 36), (1, 5, 32, 64), (3, 3, 17, 33)])
+def test_conv3x3_bf16_fused(clips, T, H, W):
+    g = torch.Generator().manual_seed(clips * 100 + T)
+    Fr = clips * T
+    x = r16(torch.randn(Fr, H, W, 64, generator=g))
+    addend = r16(torch.randn(clips, H, W, 64, generator=g))
+    resid = r16(torch.randn(Fr, H, W, 64, generator=g))
+    k = (torch.randn(3, 3, 64, 64, generator=g) * 0.05).numpy()
+    b = (torch.randn(64, generator=g) * 0.1).numpy()
+    out = ops.conv3x3_bf16(x.to(torch.bfloat16).cuda(), k, b, act=True, addend=addend.to(torch.bfloat16).cuda(), add_div=T,
+                           resid=resid.to(torch.bfloat16).cuda())
+    close_bf16(out, ref_conv3(x, k, b, True, addend, T, resid))
+
+
+@pytest.mark.parametrize("items,T,H,W", [(2, 7, 20, 36), (3, 5, 9, 31), (1, 3, 64, 64), (2, 7, 1, 5)])
+def test_conv1x1_bf16(items, T, H, W):
+    g = torch.Generator().manual_seed(items * 10 + T)
+    x = r16(torch.randn(items * T, H, W, 64, generator=g))
+    k = (torch.randn(1, 1, 64 * T, 64, generator=g) * 0.05).numpy()
+    b = (torch.randn(64, generator=g) * 0.1).numpy()
+    out = ops.conv1x1_bf16(x.to(torch.bfloat16).cuda(), k, b, act=True, frames_per_item=T)
+    cat = x.reshape(items, T, H, W, 64).permute(0, 2, 3, 1, 4).reshape(items, H, W, T * 64)
+    ref = F.leaky_relu(cat @ r16(torch.from_numpy(k[0, 0])) + torch.from_numpy(b), 0.2)
+    close_bf16(out, ref)
+
+
+@pytest.mark.parametrize("geom,B,H,W", [(PFNLGeometry(num_frames=7, scale=4, num_block=20), 1, 32, 32),
+                                        (PFNLGeometry(num_frames=7, scale=4, num_block=3), 2, 20, 36),
+                                        (PFNLGeometry(num_frames=5, scale=2, num_block=2), 1, 16, 24),
+                                        (PFNLGeometry(num_frames=3, scale=4, num_block=2), 2, 34, 70)])
+def test_forward_bf16_matches_rounded_oracle(geom, B, H, W):
+    w = synth.synthetic_weights(geom, seed=0)
+    eng = PFNLEngine(geom, device=0)
+    eng.load_weights(w)
+    eng.set_option("precision", "bf16")
+    x, gt = synth.moving_field_clips(B, geom.num_frames, H, W, geom.scale, seed=5)
+    y = eng.forward(x)
+    o16 = pfnl_fast.FastOracle(w, geom.num_frames, geom.scale, geom.num_block, trunk_dtype="bf16").forward(x)
+    o32 = pfnl_fast.FastOracle(w, geom.num_frames, geom.scale, geom.num_block).forward(x)
+    assert y.shape == o16.shape and y.dtype == np.float32
+    p_same = synth.psnr(y, o16)
+    p_fp32 = synth.psnr(y, o32)
+    d_gt = abs(synth.psnr(y[:, 0], gt) - synth.psnr(o32[:, 0], gt))
+    print(f"bf16 forward {B}x{geom.num_frames}x{H}x{W} nb{geom.num_block}: PSNR vs bf16 oracle {p_same:.1f} dB, "
+          f"vs fp32 oracle {p_fp32:.1f} dB, |dPSNR(GT)| {d_gt:.4f} dB, max|d| {np.abs(y - o16).max():.2e}")
+    assert p_same > 55.0, p_same
+    assert d_gt <= 0.1, d_gt
+    eng.set_option("precision", "fp32")                                   # and back: the fp32 path is untouched
+    assert np.abs(eng.forward(x) - o32).max() < 2e-4
+    eng.close()
