@@ -46,6 +46,10 @@ constexpr int CB_CHUNKS = CB_IH * CB_IW * 8;                        // 16-byte p
 constexpr int CB_ITERS = (CB_CHUNKS + CB_THREADS - 1) / CB_THREADS; // 10
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+#ifdef CB_X_NOMFMA
+    c[0] += (float)a[0] * (float)b[0];
+    return c;
+#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
@@ -80,16 +84,17 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
     if (tid < 64) bl[tid] = p.bias[tid];
 
     // staging map: piece id = k*512 + tid -> halo pixel id >> 3, channel chunk id & 7
-    int soff[CB_ITERS], srel[CB_ITERS], spyx[CB_ITERS];
+    // (kept as one packed word per piece: LDS and global offsets are recomputed per tile, ~100 VALU per thread
+    // against a tile's 4.6k MFMA cycles per wave - the registers are worth more)
+    int spk[CB_ITERS];                                              // py << 16 | px << 3 | chunk
 #pragma unroll
     for (int k = 0; k < CB_ITERS; ++k) {
         const int id = min(k * CB_THREADS + tid, CB_CHUNKS - 1);    // surplus threads redo the last piece (same value)
         const int pix = id >> 3, c = id & 7;
         const int py = pix / CB_IW, px = pix - py * CB_IW;
-        soff[k] = pix * 128 + ((c ^ ((px >> 1) & 7)) << 4);
-        srel[k] = ((py - 1) * W + (px - 1)) * 128 + c * 16;
-        spyx[k] = (py << 16) | px;
+        spk[k] = (py << 16) | (px << 3) | c;
     }
+    const int wbytes = W * 128;
     u32x4 stg[CB_ITERS];
 #define CB_REQUEST(t_)                                                                           \
     do {                                                                                         \
@@ -98,15 +103,17 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
         const int y0_ = ty_ * CB_TH, x0_ = (sp_ - ty_ * tiles_x) * CB_TW;                        \
         const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                    \
             const_cast<uint16_t*>(p.in) + (size_t)it_ * H * W * 64, 0, item_bytes, 0x00020000);  \
-        const int org_ = (y0_ * W + x0_) * 128;                                                  \
+        const int org_ = ((y0_ - 1) * W + x0_ - 1) * 128;       /* halo origin */                \
         if (y0_ > 0 && y0_ + CB_IH - 1 <= H && x0_ > 0 && x0_ + CB_IW - 1 <= W) {                \
             _Pragma("unroll") for (int k_ = 0; k_ < CB_ITERS; ++k_)                              \
-                stg[k_] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, org_ + srel[k_], 0, 0)); \
+                stg[k_] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(       \
+                    rs_, org_ + (spk[k_] >> 16) * wbytes + (spk[k_] & 0xffff) * 16, 0, 0));       \
         } else {                                                                                 \
             _Pragma("unroll") for (int k_ = 0; k_ < CB_ITERS; ++k_) {                            \
-                const int gy_ = y0_ + (spyx[k_] >> 16) - 1, gx_ = x0_ + (spyx[k_] & 0xffff) - 1; \
+                const int gy_ = y0_ + (spk[k_] >> 16) - 1, gx_ = x0_ + ((spk[k_] >> 3) & 0x1fff) - 1; \
                 const bool in_ = (unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W;     \
-                stg[k_] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, in_ ? org_ + srel[k_] : 0x7fffffff, 0, 0)); \
+                stg[k_] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(       \
+                    rs_, in_ ? org_ + (spk[k_] >> 16) * wbytes + (spk[k_] & 0xffff) * 16 : 0x7fffffff, 0, 0)); \
             }                                                                                    \
         }                                                                                        \
     } while (0)
@@ -123,23 +130,98 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
     }
     const unsigned char* const wlane = wl + lane * 16;
 
+    // Accumulator rows: the MFMA row index is free to name any output channel (it only fixes which weight row sits
+    // in which lane), so row i of channel tile m is channel 32m + 16((i>>2)&1) + 4(i>>3) + (i&3): register r of a
+    // lane is then channel 32m + 16(lane>>5) + r - 16 consecutive channels, two 16-byte pieces per (m, row).
+    const int ech = 16 * (lane >> 5);
+    f32x16 acc[2][2];                                               // [channel tile][output row]
+    u32x4 rres[2][2][2], radd[2][2][2];                             // FUSE: residual / addend pieces of the tile in flight
+    int eoff[2] = {0x7fffffff, 0x7fffffff};                         // this lane's pixel of output row n (bytes into the item)
+    int eitem = 0;
+    bool pending = false;                                           // a computed tile waits for its epilogue
+
+    // The epilogue of tile t runs at the start of iteration t+1, after the LDS tile has been refilled: its stores
+    // are then OLDER in the (in-order) vmcnt queue than the next halo request, so waiting for that halo never
+    // waits for store acknowledgements, and they drain under the next tile's MFMAs.
+    auto epilogue = [&]() {
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)eitem * H * W * 64, 0, item_bytes, 0x00020000);
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 v[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + 32 * m + ech + 8 * h + 4 * q);
+                        const int r0 = 8 * h + 4 * q;
+                        v[q] = f32x4{acc[m][n][r0], acc[m][n][r0 + 1], acc[m][n][r0 + 2], acc[m][n][r0 + 3]} + b4;
+                        if (FUSE) v[q] += bf16x4_to_f32(u32x2{radd[m][n][h][2 * q], radd[m][n][h][2 * q + 1]});
+                        if (p.act) {
+                            v[q].x = lrelu(v[q].x);
+                            v[q].y = lrelu(v[q].y);
+                            v[q].z = lrelu(v[q].z);
+                            v[q].w = lrelu(v[q].w);
+                        }
+                        if (FUSE) v[q] += bf16x4_to_f32(u32x2{rres[m][n][h][2 * q], rres[m][n][h][2 * q + 1]});
+                    }
+                    const u32x2 lo = f32x4_to_bf16(v[0]), hi = f32x4_to_bf16(v[1]);
+#ifdef CB_X_NOSTORE   /* timing experiments only */
+                    if (v[0].x == 12345.678f)
+#endif
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, rsO, eoff[n], (32 * m + 8 * h) * 2, 0);
+                }
+    };
+
     int t = blockIdx.x;
     if (t >= ntiles) return;
     CB_REQUEST(t);
     for (; t < ntiles; t += gridDim.x) {
         __syncthreads();                                            // the previous tile's operands have been read (and the weights written)
 #pragma unroll
-        for (int k = 0; k < CB_ITERS; ++k) *reinterpret_cast<u32x4*>(tile + soff[k]) = stg[k];
+        for (int k = 0; k < CB_ITERS; ++k) asm volatile("" : "+v"(spk[k]));   // opaque: nothing derived from it is hoisted into registers
+#pragma unroll
+        for (int k = 0; k < CB_ITERS; ++k) {
+            const int py = spk[k] >> 16, px = (spk[k] >> 3) & 0x1fff, c = spk[k] & 7;
+            *reinterpret_cast<u32x4*>(tile + (py * CB_IW + px) * 128 + ((c ^ ((px >> 1) & 7)) << 4)) = stg[k];
+        }
         __syncthreads();
-        const int tn = t + gridDim.x;
-        CB_REQUEST(min(tn, ntiles - 1));                            // past the end: harmless re-read
+        if (pending) epilogue();
+        pending = true;
         __builtin_amdgcn_sched_barrier(0);
 
         const int item = t / per_item, sp = t - item * per_item;
         const int ty = sp / tiles_x;
         const int y0 = ty * CB_TH, x0 = (sp - ty * tiles_x) * CB_TW;
+        const int ox = x0 + (lane & 31);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int oy = y0 + 2 * wave + n;
+            eoff[n] = (ox < W && oy < H) ? ((oy * W + ox) * 64 + ech) * 2 : 0x7fffffff;
+        }
+        eitem = item;
+        if (FUSE) {                                                 // this tile's addend / residual pieces, then the next halo
+            const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint16_t*>(p.resid) + (size_t)item * H * W * 64, 0, item_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint16_t*>(p.addend) + (size_t)(item / p.add_div) * H * W * 64, 0, item_bytes, 0x00020000);
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        radd[m][n][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, eoff[n], (32 * m + 8 * h) * 2, 0));
+                        rres[m][n][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, eoff[n], (32 * m + 8 * h) * 2, 0));
+                    }
+        }
+        const int tn = t + gridDim.x;
+#ifndef CB_X_NOLOAD   /* timing experiments only */
+        CB_REQUEST(min(tn, ntiles - 1));                            // past the end: harmless re-read
+#endif
+        __builtin_amdgcn_sched_barrier(0);
 
-        f32x16 acc[2][2];                                           // [channel tile][output row]
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -147,75 +229,50 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-        // epilogue inputs: this lane's pixel of output row n; 8-byte pieces at channels 32m + 8g + 4(lane>>5)
-        const int ox = x0 + (lane & 31);
-        const int ech = 4 * (lane >> 5);
-        int eoff[2];
+        // 12 groups (column tap kx, k-step ks), software-pipelined in two stages so that no MFMA waits for LDS:
+        //   stage A: request the weights of row taps 1, 2;       4 MFMAs of row tap 0
+        //   stage B: request the next group's 4 pixel rows and its row-tap-0 weights;   8 MFMAs of row taps 1, 2
+        bf16x8 px[2][4], wa[2], wb[2][2];
+#define CB_PX(g_, r_) (*reinterpret_cast<const bf16x8*>(tile + paddr[(g_) >> 2][(g_) & 3] + (r_) * (CB_IW * 128)))
+#define CB_WT(g_, ky_, m_) (*reinterpret_cast<const bf16x8*>(wlane + (((((ky_) * 3 + ((g_) >> 2)) * 4 + ((g_) & 3)) * 2 + (m_)) << 10)))
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int oy = y0 + 2 * wave + n;
-            eoff[n] = (ox < W && oy < H) ? ((oy * W + ox) * 64 + ech) * 2 : 0x7fffffff;
-        }
-        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)item * H * W * 64, 0, item_bytes, 0x00020000);
-        u32x2 rres[2][2][4], radd[2][2][4];
-
+        for (int r = 0; r < 4; ++r) px[0][r] = CB_PX(0, r);
+        wa[0] = CB_WT(0, 0, 0);
+        wa[1] = CB_WT(0, 0, 1);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
+        for (int g = 0; g < 12; ++g) {
+            const int cur = g & 1;
+            // stage A
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if (FUSE && kx == 2 && ks == 0) {                   // addend / residual: requested 4 groups before the epilogue
-                    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
-                        const_cast<uint16_t*>(p.resid) + (size_t)item * H * W * 64, 0, item_bytes, 0x00020000);
-                    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-                        const_cast<uint16_t*>(p.addend) + (size_t)(item / p.add_div) * H * W * 64, 0, item_bytes, 0x00020000);
+            for (int ky = 1; ky < 3; ++ky)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n)
+                for (int m = 0; m < 2; ++m) wb[ky - 1][m] = CB_WT(g, ky, m);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int m = 0; m < 2; ++m)
+            for (int n = 0; n < 2; ++n)
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                radd[m][n][g] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsA, eoff[n], (32 * m + 8 * g) * 2, 0));
-                                rres[m][n][g] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsR, eoff[n], (32 * m + 8 * g) * 2, 0));
-                            }
-                }
-                bf16x8 px[4], wv[3][2];
+                for (int m = 0; m < 2; ++m) acc[m][n] = mfma_bf16(wa[m], px[cur][n], acc[m][n]);
+            __builtin_amdgcn_sched_barrier(0);
+            // stage B
+            if (g < 11) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    px[r] = *reinterpret_cast<const bf16x8*>(tile + paddr[kx][ks] + r * (CB_IW * 128));
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-                        wv[ky][m] = *reinterpret_cast<const bf16x8*>(wlane + ((((ky * 3 + kx) * 4 + ks) * 2 + m) << 10));
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) acc[m][n] = mfma_bf16(wv[ky][m], px[n + ky], acc[m][n]);
+                for (int r = 0; r < 4; ++r) px[cur ^ 1][r] = CB_PX(g + 1, r);
+                wa[0] = CB_WT(g + 1, 0, 0);
+                wa[1] = CB_WT(g + 1, 0, 1);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ky = 1; ky < 3; ++ky)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m][n] = mfma_bf16(wb[ky - 1][m], px[cur][n + ky], acc[m][n]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-
-        // epilogue: register r of acc[m][n] = channel 32m + (r&3) + 8(r>>2) + 4(lane>>5) of this lane's pixel
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + 32 * m + 8 * g + ech);
-                    f32x4 v = f32x4{acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]} + b4;
-                    if (FUSE) v += bf16x4_to_f32(radd[m][n][g]);
-                    if (p.act) {
-                        v.x = lrelu(v.x);
-                        v.y = lrelu(v.y);
-                        v.z = lrelu(v.z);
-                        v.w = lrelu(v.w);
-                    }
-                    if (FUSE) v += bf16x4_to_f32(rres[m][n][g]);
-                    __builtin_amdgcn_raw_buffer_store_b64(f32x4_to_bf16(v), rsO, eoff[n], (32 * m + 8 * g) * 2, 0);
-                }
+#undef CB_PX
+#undef CB_WT
     }
+    epilogue();
 #undef CB_REQUEST
 }
 
@@ -273,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(const uint16_t* __
     const int ngroups = gpi * items;
     const int frame_bytes = HW * 128;
     const unsigned char* const wlane = wl + lane * 16;
-    const int ech = 4 * (lane >> 5);
+    const int ech = 16 * (lane >> 5);
     for (int g = blockIdx.x * 4 + wave; g < ngroups; g += gridDim.x * 4) {
         const int item = g / gpi;
         const int p0 = (g - item * gpi) * 32;
@@ -307,16 +364,22 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(const uint16_t* __
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + 32 * m + 8 * q + ech);
-                f32x4 v = f32x4{acc[m][4 * q], acc[m][4 * q + 1], acc[m][4 * q + 2], acc[m][4 * q + 3]} + b4;
-                if (act) {
-                    v.x = lrelu(v.x);
-                    v.y = lrelu(v.y);
-                    v.z = lrelu(v.z);
-                    v.w = lrelu(v.w);
+            for (int h = 0; h < 2; ++h) {                           // register r = channel 32m + 16(lane>>5) + r
+                f32x4 v[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int r0 = 8 * h + 4 * q;
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + 32 * m + ech + r0);
+                    v[q] = f32x4{acc[m][r0], acc[m][r0 + 1], acc[m][r0 + 2], acc[m][r0 + 3]} + b4;
+                    if (act) {
+                        v[q].x = lrelu(v[q].x);
+                        v[q].y = lrelu(v[q].y);
+                        v[q].z = lrelu(v[q].z);
+                        v[q].w = lrelu(v[q].w);
+                    }
                 }
-                __builtin_amdgcn_raw_buffer_store_b64(f32x4_to_bf16(v), rsO, ooff, (32 * m + 8 * q) * 2, 0);
+                const u32x2 lo = f32x4_to_bf16(v[0]), hi = f32x4_to_bf16(v[1]);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, rsO, ooff, (32 * m + 8 * h) * 2, 0);
             }
     }
 }
@@ -379,10 +442,13 @@ uint16_t bf16_rne(float f) {
     return (uint16_t)(u >> 16);
 }
 
+// MFMA row i of a channel tile -> channel within the tile (see the kernel: 16 consecutive channels per lane)
+static int bf16_row_channel(int i) { return 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3); }
+
 size_t conv3x3_bf16_pack_halfs() { return CB_W_BYTES / 2; }
 
 // HWIO [3,3,cin_total,64] rows [cin_begin, cin_begin+64) -> [tap][ks][m][lane][e]:
-// W[ky][kx][cin_begin + 16 ks + 8 (lane>>5) + e][32 m + (lane&31)]
+// W[ky][kx][cin_begin + 16 ks + 8 (lane>>5) + e][32 m + bf16_row_channel(lane&31)]
 void conv3x3_bf16_pack_weights(const float* hwio, int cin_total, int cin_begin, uint16_t* dst) {
     for (int tap = 0; tap < 9; ++tap)
         for (int ks = 0; ks < 4; ++ks)
@@ -390,14 +456,14 @@ void conv3x3_bf16_pack_weights(const float* hwio, int cin_total, int cin_begin, 
                 for (int lane = 0; lane < 64; ++lane)
                     for (int e = 0; e < 8; ++e) {
                         const int ci = cin_begin + 16 * ks + 8 * (lane >> 5) + e;
-                        const int co = 32 * m + (lane & 31);
+                        const int co = 32 * m + bf16_row_channel(lane & 31);
                         dst[((((size_t)tap * 4 + ks) * 2 + m) * 64 + lane) * 8 + e] = bf16_rne(hwio[((size_t)tap * cin_total + ci) * 64 + co]);
                     }
 }
 
 size_t conv1x1_bf16_pack_halfs(int T) { return (size_t)T * 4096; }
 
-// HWIO [1,1,T*64,64] -> [f][ks][m][lane][e]: W[64 f + 16 ks + 8 (lane>>5) + e][32 m + (lane&31)]
+// HWIO [1,1,T*64,64] -> [f][ks][m][lane][e]: W[64 f + 16 ks + 8 (lane>>5) + e][32 m + bf16_row_channel(lane&31)]
 void conv1x1_bf16_pack_weights(const float* hwio, int T, uint16_t* dst) {
     for (int f = 0; f < T; ++f)
         for (int ks = 0; ks < 4; ++ks)
@@ -405,7 +471,7 @@ void conv1x1_bf16_pack_weights(const float* hwio, int T, uint16_t* dst) {
                 for (int lane = 0; lane < 64; ++lane)
                     for (int e = 0; e < 8; ++e) {
                         const int ci = 64 * f + 16 * ks + 8 * (lane >> 5) + e;
-                        const int co = 32 * m + (lane & 31);
+                        const int co = 32 * m + bf16_row_channel(lane & 31);
                         dst[((((size_t)f * 4 + ks) * 2 + m) * 64 + lane) * 8 + e] = bf16_rne(hwio[(size_t)ci * 64 + co]);
                     }
 }
