@@ -24,6 +24,7 @@
 // conv2_i keeps the shared-`base` split of the fp32 path (`SURVEY.md` §8(a)-G): one launch over `base` produces
 // the raw shared half per clip, the per-frame launch adds it before the activation.
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -36,14 +37,17 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef CB_LATEPOS
+#define CB_LATEPOS 1
+#endif
 constexpr int CB_THREADS = 512;
-constexpr int CB_TH = 16, CB_TW = 32;
+constexpr int CB_TH = 8, CB_TW = 32;
 constexpr int CB_IH = CB_TH + 2, CB_IW = CB_TW + 2;
-constexpr int CB_TILE_BYTES = CB_IH * CB_IW * 128;                  // 78 336
+constexpr int CB_TILE_BYTES = CB_IH * CB_IW * 128;                  // 43 520, two buffers
 constexpr int CB_W_BYTES = 9 * 4 * 2 * 1024;                        // 73 728: [tap][kstep][channel tile][lane] x 16 B
-constexpr int CB_LDS_BYTES = CB_TILE_BYTES + CB_W_BYTES + 64 * 4;   // + bias
+constexpr int CB_LDS_BYTES = 2 * CB_TILE_BYTES + CB_W_BYTES + 64 * 4;   // 161 024 of 163 840
 constexpr int CB_CHUNKS = CB_IH * CB_IW * 8;                        // 16-byte pieces of a halo tile
-constexpr int CB_ITERS = (CB_CHUNKS + CB_THREADS - 1) / CB_THREADS; // 10
+constexpr int CB_ITERS = (CB_CHUNKS + CB_THREADS - 1) / CB_THREADS; // 6
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 #ifdef CB_X_NOMFMA
@@ -62,20 +66,54 @@ __device__ __forceinline__ u32x2 f32x4_to_bf16(f32x4 v) {         // round to ne
     return __builtin_bit_cast(u32x2, b);
 }
 
+#ifdef PFNL_BF16_TIMING   /* phase timeline of the kernel (tools/bf16_timing.py); not part of the product build */
+__device__ long long cb_dbg[256 * 8 * 64];
+#define CB_STAMP() do { if (lane == 0 && dbg_n < 64) cb_dbg[(blockIdx.x * 8 + wave) * 64 + dbg_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CB_STAMP() do {} while (0)
+#endif
+
 template <bool FUSE>
 __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cb_smem[];
-    unsigned char* const tile = cb_smem;
-    unsigned char* const wl = cb_smem + CB_TILE_BYTES;
-    float* const bl = reinterpret_cast<float*>(cb_smem + CB_TILE_BYTES + CB_W_BYTES);
+    unsigned char* const wl = cb_smem + 2 * CB_TILE_BYTES;
+    float* const bl = reinterpret_cast<float*>(cb_smem + 2 * CB_TILE_BYTES + CB_W_BYTES);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef PFNL_BF16_TIMING
+    int dbg_n = 0;
+#endif
+    const int rp = wave >> 1;                                       // rows 2rp, 2rp+1 of the tile
+    const int mt = wave & 1;                                        // output channels 32mt .. 32mt+31
+    const bool late = wave >= 4;                                    // waves w and w+4 share a SIMD: their memory bursts are half a tile apart
+    constexpr bool LATEPOS = CB_LATEPOS && !FUSE;                   // (the fused variant has no registers left for the second copy of the burst)
     const int H = p.H, W = p.W;
     const int tiles_x = (W + CB_TW - 1) / CB_TW, tiles_y = (H + CB_TH - 1) / CB_TH;
     const int per_item = tiles_x * tiles_y;
-    const int ntiles = per_item * p.items;
     const int item_bytes = H * W * 128;
+    // Work order.  A unit = one spatial tile of one item; the fused launch (conv2_i's per-frame half) chains the gT
+    // frames of a clip at the same spatial tile, so the shared-half addend pieces are fetched once per chain.  Chains
+    // are dealt out XCD by XCD (blockIdx & 7 = XCD): the 32 workgroups of an XCD walk a contiguous run of spatial
+    // tiles together, so the halo rows two tiles share come from that XCD's L2 instead of HBM a second time
+    // (measured before: 1.31x the compulsory reads, and the addend 7x).
+    const int gT = FUSE ? p.add_div : 1;
+    const int nchains = per_item * (p.items / gT);
+    const int xcd = blockIdx.x & 7, xj = blockIdx.x >> 3, cpx = gridDim.x >> 3;
+    const int per_xcd = (nchains + 7) >> 3;
+    const int cbeg = xcd * per_xcd;
+    const int ccnt = min(per_xcd, nchains - cbeg);
+    if (xj >= ccnt) return;
+    const int nu = ((ccnt - xj + cpx - 1) / cpx) * gT;              // units of this workgroup
+    // unit u -> (item, spatial tile)
+#define CB_UNIT(u_, item_, sp_)                                                                  \
+    do {                                                                                         \
+        const int ci_ = (u_) / gT, f_ = (u_) - ci_ * gT;                                         \
+        const int ch_ = cbeg + xj + ci_ * cpx;                                                   \
+        const int cl_ = ch_ / per_item;                                                          \
+        sp_ = ch_ - cl_ * per_item;                                                              \
+        item_ = cl_ * gT + f_;                                                                   \
+    } while (0)
 
     // weights + bias -> LDS (once per workgroup)
 #pragma unroll
@@ -83,9 +121,9 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
         reinterpret_cast<u32x4*>(wl)[k * CB_THREADS + tid] = reinterpret_cast<const u32x4*>(p.wpack)[k * CB_THREADS + tid];
     if (tid < 64) bl[tid] = p.bias[tid];
 
-    // staging map: piece id = k*512 + tid -> halo pixel id >> 3, channel chunk id & 7
-    // (kept as one packed word per piece: LDS and global offsets are recomputed per tile, ~100 VALU per thread
-    // against a tile's 4.6k MFMA cycles per wave - the registers are worth more)
+    // staging map: piece id = k*512 + tid -> halo pixel id >> 3, channel chunk id & 7, kept as one packed word per
+    // piece (LDS and global offsets are recomputed per tile: ~60 VALU per thread against a tile's 2.3k MFMA cycles
+    // per wave - the registers are worth more)
     int spk[CB_ITERS];                                              // py << 16 | px << 3 | chunk
 #pragma unroll
     for (int k = 0; k < CB_ITERS; ++k) {
@@ -96,9 +134,10 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
     }
     const int wbytes = W * 128;
     u32x4 stg[CB_ITERS];
-#define CB_REQUEST(t_)                                                                           \
+#define CB_REQUEST(u_)                                                                           \
     do {                                                                                         \
-        const int it_ = (t_) / per_item, sp_ = (t_) - it_ * per_item;                            \
+        int it_, sp_;                                                                            \
+        CB_UNIT(u_, it_, sp_);                                                                   \
         const int ty_ = sp_ / tiles_x;                                                           \
         const int y0_ = ty_ * CB_TH, x0_ = (sp_ - ty_ * tiles_x) * CB_TW;                        \
         const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                    \
@@ -107,7 +146,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
         if (y0_ > 0 && y0_ + CB_IH - 1 <= H && x0_ > 0 && x0_ + CB_IW - 1 <= W) {                \
             _Pragma("unroll") for (int k_ = 0; k_ < CB_ITERS; ++k_)                              \
                 stg[k_] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(       \
-                    rs_, org_ + (spk[k_] >> 16) * wbytes + (spk[k_] & 0xffff) * 16, 0, 0));       \
+                    rs_, org_ + (spk[k_] >> 16) * wbytes + (spk[k_] & 0xffff) * 16, 0, 0));      \
         } else {                                                                                 \
             _Pragma("unroll") for (int k_ = 0; k_ < CB_ITERS; ++k_) {                            \
                 const int gy_ = y0_ + (spk[k_] >> 16) - 1, gx_ = x0_ + ((spk[k_] >> 3) & 0x1fff) - 1; \
@@ -117,163 +156,219 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
             }                                                                                    \
         }                                                                                        \
     } while (0)
+#define CB_COMMIT(buf_)                                                                          \
+    do {                                                                                         \
+        _Pragma("unroll") for (int k_ = 0; k_ < CB_ITERS; ++k_) {                                \
+            const int py_ = spk[k_] >> 16, px_ = (spk[k_] >> 3) & 0x1fff, c_ = spk[k_] & 7;      \
+            *reinterpret_cast<u32x4*>(cb_smem + (buf_) * CB_TILE_BYTES + (py_ * CB_IW + px_) * 128 + ((c_ ^ ((px_ >> 1) & 7)) << 4)) = stg[k_]; \
+        }                                                                                        \
+    } while (0)
 
     // operand addresses: pixel operand of (column tap kx, k-step ks) = chunk 2*ks + (lane >> 5) of halo pixel
-    // (row 2*wave + ..., column (lane & 31) + kx); weights: 16 bytes per lane
+    // (row 2*rp + ..., column (lane & 31) + kx); weights: 16 bytes per lane
     int paddr[3][4];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
         const int col = (lane & 31) + kx;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-            paddr[kx][ks] = ((2 * wave) * CB_IW + col) * 128 + (((2 * ks + (lane >> 5)) ^ ((col >> 1) & 7)) << 4);
+            paddr[kx][ks] = ((2 * rp) * CB_IW + col) * 128 + (((2 * ks + (lane >> 5)) ^ ((col >> 1) & 7)) << 4);
     }
-    const unsigned char* const wlane = wl + lane * 16;
+    const unsigned char* const wlane = wl + mt * 1024 + lane * 16;
 
     // Accumulator rows: the MFMA row index is free to name any output channel (it only fixes which weight row sits
-    // in which lane), so row i of channel tile m is channel 32m + 16((i>>2)&1) + 4(i>>3) + (i&3): register r of a
-    // lane is then channel 32m + 16(lane>>5) + r - 16 consecutive channels, two 16-byte pieces per (m, row).
-    const int ech = 16 * (lane >> 5);
-    f32x16 acc[2][2];                                               // [channel tile][output row]
-    u32x4 rres[2][2][2], radd[2][2][2];                             // FUSE: residual / addend pieces of the tile in flight
-    int eoff[2] = {0x7fffffff, 0x7fffffff};                         // this lane's pixel of output row n (bytes into the item)
-    int eitem = 0;
-    bool pending = false;                                           // a computed tile waits for its epilogue
+    // in which lane), so row i of a channel tile is channel 16((i>>2)&1) + 4(i>>3) + (i&3): register r of a lane is
+    // then channel 32mt + 16(lane>>5) + r - 16 consecutive channels, two 16-byte pieces per output row.
+    const int ech = 32 * mt + 16 * (lane >> 5);
+    f32x16 acc[2], accp[2];                                         // [output row]: the tile being computed / awaiting its epilogue
+    u32x4 rres[2][2], radd[2][2];                                   // FUSE: residual / addend pieces of the tile awaiting its epilogue
+    int eoff[2] = {0x7fffffff, 0x7fffffff}, eoffp[2] = {0x7fffffff, 0x7fffffff};   // this lane's pixel of output row n (bytes into the item)
+    int eitem = 0, eitemp = 0;
+    bool pending = false;
 
-    // The epilogue of tile t runs at the start of iteration t+1, after the LDS tile has been refilled: its stores
-    // are then OLDER in the (in-order) vmcnt queue than the next halo request, so waiting for that halo never
-    // waits for store acknowledgements, and they drain under the next tile's MFMAs.
-    auto epilogue = [&]() {
-        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)eitem * H * W * 64, 0, item_bytes, 0x00020000);
+    // Stores.  A lane owns 32 contiguous bytes of its pixel (two 16-byte pieces), lane + 32 the next 32: stored as
+    // they sit, every instruction would send 64 separate 16-byte writes to L2 (measured: 2.3-3.9k cycles per tile in
+    // the epilogue, the L2 request rate, not bytes, was the bound).  The pieces are first exchanged through the LDS
+    // crossbar (ds_bpermute, no LDS memory) so that 4 ADJACENT lanes hold the 4 pieces of one pixel's 64-byte half
+    // line: instruction i of a row stores pixels 16i .. 16i+15, one 64-byte request each.
+    const int sq = lane & 3;                                        // piece of the half line this lane stores
+    const int ssrc = (((lane >> 2) + 32 * (sq >> 1)) << 2);         // + 64 i: bpermute address of the lane that holds it
+    int soffp[2][2] = {{0x7fffffff, 0x7fffffff}, {0x7fffffff, 0x7fffffff}};   // [row][i]: store offsets of the tile awaiting its epilogue
+    auto epilogue = [&]() {                                         // bias, addend, leaky_relu, residual, bf16, store: tile `p`
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)eitemp * H * W * 64, 0, item_bytes, 0x00020000);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            u32x4 pc[2];                                            // this lane's two pieces of row n
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 v[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int r0 = 8 * h + 4 * q;
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + ech + r0);
+                    v[q] = f32x4{accp[n][r0], accp[n][r0 + 1], accp[n][r0 + 2], accp[n][r0 + 3]} + b4;
+                    if (FUSE) v[q] += bf16x4_to_f32(u32x2{radd[n][h][2 * q], radd[n][h][2 * q + 1]});
+                    if (p.act) {
+                        v[q].x = lrelu(v[q].x);
+                        v[q].y = lrelu(v[q].y);
+                        v[q].z = lrelu(v[q].z);
+                        v[q].w = lrelu(v[q].w);
+                    }
+                    if (FUSE) v[q] += bf16x4_to_f32(u32x2{rres[n][h][2 * q], rres[n][h][2 * q + 1]});
+                }
+                const u32x2 lo = f32x4_to_bf16(v[0]), hi = f32x4_to_bf16(v[1]);
+                pc[h] = u32x4{lo.x, lo.y, hi.x, hi.y};
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                u32x4 o;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const unsigned a0 = __builtin_amdgcn_ds_bpermute(ssrc + 64 * i, pc[0][d]);
+                    const unsigned a1 = __builtin_amdgcn_ds_bpermute(ssrc + 64 * i, pc[1][d]);
+                    o[d] = (sq & 1) ? a1 : a0;
+                }
+#ifdef CB_X_NOSTORE   /* timing experiments only */
+                if (o.x == 0x12345678u)
+#endif
+                __builtin_amdgcn_raw_buffer_store_b128(o, rsO, soffp[n][i], 0, 0);
+            }
+        }
+    };
+    auto fuse_request = [&](bool with_addend) {                     // addend / residual pieces of the tile just described by eoff / eitem
+        const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint16_t*>(p.resid) + (size_t)eitem * H * W * 64, 0, item_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint16_t*>(p.addend) + (size_t)(eitem / p.add_div) * H * W * 64, 0, item_bytes, 0x00020000);
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    f32x4 v[2];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + 32 * m + ech + 8 * h + 4 * q);
-                        const int r0 = 8 * h + 4 * q;
-                        v[q] = f32x4{acc[m][n][r0], acc[m][n][r0 + 1], acc[m][n][r0 + 2], acc[m][n][r0 + 3]} + b4;
-                        if (FUSE) v[q] += bf16x4_to_f32(u32x2{radd[m][n][h][2 * q], radd[m][n][h][2 * q + 1]});
-                        if (p.act) {
-                            v[q].x = lrelu(v[q].x);
-                            v[q].y = lrelu(v[q].y);
-                            v[q].z = lrelu(v[q].z);
-                            v[q].w = lrelu(v[q].w);
-                        }
-                        if (FUSE) v[q] += bf16x4_to_f32(u32x2{rres[m][n][h][2 * q], rres[m][n][h][2 * q + 1]});
-                    }
-                    const u32x2 lo = f32x4_to_bf16(v[0]), hi = f32x4_to_bf16(v[1]);
-#ifdef CB_X_NOSTORE   /* timing experiments only */
-                    if (v[0].x == 12345.678f)
-#endif
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, rsO, eoff[n], (32 * m + 8 * h) * 2, 0);
-                }
+            for (int h = 0; h < 2; ++h) {
+                if (with_addend)                                    // (same pixels for every frame of the chain)
+                    radd[n][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, eoff[n], (ech + 8 * h) * 2, 0));
+                rres[n][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, eoff[n], (ech + 8 * h) * 2, 0));
+            }
     };
 
-    int t = blockIdx.x;
-    if (t >= ntiles) return;
-    CB_REQUEST(t);
-    for (; t < ntiles; t += gridDim.x) {
-        __syncthreads();                                            // the previous tile's operands have been read (and the weights written)
-#pragma unroll
-        for (int k = 0; k < CB_ITERS; ++k) asm volatile("" : "+v"(spk[k]));   // opaque: nothing derived from it is hoisted into registers
-#pragma unroll
-        for (int k = 0; k < CB_ITERS; ++k) {
-            const int py = spk[k] >> 16, px = (spk[k] >> 3) & 0x1fff, c = spk[k] & 7;
-            *reinterpret_cast<u32x4*>(tile + (py * CB_IW + px) * 128 + ((c ^ ((px >> 1) & 7)) << 4)) = stg[k];
-        }
-        __syncthreads();
-        if (pending) epilogue();
-        pending = true;
-        __builtin_amdgcn_sched_barrier(0);
-
-        const int item = t / per_item, sp = t - item * per_item;
+    CB_REQUEST(0);
+    CB_COMMIT(0);
+    CB_REQUEST(min(1, nu - 1));                                     // past the end: harmless re-read
+    __syncthreads();
+    for (int u = 0; u < nu; ++u) {
+        const int cb = u & 1;                                       // LDS buffer of this tile; the other one receives the next tile
+        const unsigned char* const tile = cb_smem + cb * CB_TILE_BYTES;
+        int item, sp;
+        CB_UNIT(u, item, sp);
+        const bool chain_head = !FUSE || item % gT == 0;            // first frame of a chain: fetch the addend pieces
         const int ty = sp / tiles_x;
         const int y0 = ty * CB_TH, x0 = (sp - ty * tiles_x) * CB_TW;
         const int ox = x0 + (lane & 31);
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            const int oy = y0 + 2 * wave + n;
-            eoff[n] = (ox < W && oy < H) ? ((oy * W + ox) * 64 + ech) * 2 : 0x7fffffff;
+            const int oy = y0 + 2 * rp + n;
+            eoff[n] = (ox < W && oy < H) ? (oy * W + ox) * 128 : 0x7fffffff;
         }
         eitem = item;
-        if (FUSE) {                                                 // this tile's addend / residual pieces, then the next halo
-            const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<uint16_t*>(p.resid) + (size_t)item * H * W * 64, 0, item_bytes, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<uint16_t*>(p.addend) + (size_t)(item / p.add_div) * H * W * 64, 0, item_bytes, 0x00020000);
+        int soff[2][2];
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+            for (int i = 0; i < 2; ++i) {
+                const int sx = x0 + 16 * i + (lane >> 2), sy = y0 + 2 * rp + n;
+                soff[n][i] = (sx < W && sy < H) ? (sy * W + sx) * 128 + 64 * mt + 16 * sq : 0x7fffffff;
+            }
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        radd[m][n][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, eoff[n], (32 * m + 8 * h) * 2, 0));
-                        rres[m][n][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, eoff[n], (32 * m + 8 * h) * 2, 0));
-                    }
-        }
-        const int tn = t + gridDim.x;
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+        // The memory burst of an iteration, once per wave, at group 3 (waves 0-3) or 9 (waves 4-7) of the 12: the halo
+        // requested one burst ago goes to the other LDS buffer (nobody reads it during this iteration), the previous
+        // tile's epilogue runs from its copied accumulators, then this tile's addend / residual pieces and the halo
+        // after next are requested.  Every wait in here is for the NEWEST request in the in-order vmcnt queue, issued
+        // a whole tile period earlier - stores and loads drain under the MFMAs of both waves of the SIMD.
+        auto burst = [&]() {
+            CB_STAMP();
+#pragma unroll
+            for (int k = 0; k < CB_ITERS; ++k) asm volatile("" : "+v"(spk[k]));   // opaque: nothing derived from it is hoisted into registers
+            CB_COMMIT(cb ^ 1);
+            CB_STAMP();
+            if (pending) epilogue();
+            CB_STAMP();
+            if (FUSE) fuse_request(chain_head);
 #ifndef CB_X_NOLOAD   /* timing experiments only */
-        CB_REQUEST(min(tn, ntiles - 1));                            // past the end: harmless re-read
+            CB_REQUEST(min(u + 2, nu - 1));
 #endif
-        __builtin_amdgcn_sched_barrier(0);
+            CB_STAMP();
+        };
 
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
-        // 12 groups (column tap kx, k-step ks), software-pipelined in two stages so that no MFMA waits for LDS:
-        //   stage A: request the weights of row taps 1, 2;       4 MFMAs of row tap 0
-        //   stage B: request the next group's 4 pixel rows and its row-tap-0 weights;   8 MFMAs of row taps 1, 2
-        bf16x8 px[2][4], wa[2], wb[2][2];
+        // 12 groups (column tap kx, k-step ks): the 4 halo rows 2rp..2rp+3 serve the 3 row taps of both output rows -
+        // 4 pixel reads + 3 weight reads feed 6 MFMAs; the operands of group g+1 are requested before the MFMAs of g
+        bf16x8 px[2][4], wv[2][3];
 #define CB_PX(g_, r_) (*reinterpret_cast<const bf16x8*>(tile + paddr[(g_) >> 2][(g_) & 3] + (r_) * (CB_IW * 128)))
-#define CB_WT(g_, ky_, m_) (*reinterpret_cast<const bf16x8*>(wlane + (((((ky_) * 3 + ((g_) >> 2)) * 4 + ((g_) & 3)) * 2 + (m_)) << 10)))
+#define CB_WT(g_, ky_) (*reinterpret_cast<const bf16x8*>(wlane + ((((ky_) * 3 + ((g_) >> 2)) * 4 + ((g_) & 3)) << 11)))
 #pragma unroll
         for (int r = 0; r < 4; ++r) px[0][r] = CB_PX(0, r);
-        wa[0] = CB_WT(0, 0, 0);
-        wa[1] = CB_WT(0, 0, 1);
 #pragma unroll
-        for (int g = 0; g < 12; ++g) {
-            const int cur = g & 1;
-            // stage A
-#pragma unroll
-            for (int ky = 1; ky < 3; ++ky)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) wb[ky - 1][m] = CB_WT(g, ky, m);
+        for (int ky = 0; ky < 3; ++ky) wv[0][ky] = CB_WT(0, ky);
+        // (written out through a generic lambda over integral constants: a `#pragma unroll` loop of this size can be
+        // left rolled by the optimizer, which silently turns the operand arrays into scratch memory - 60x slower)
+        auto group = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int cur = g & 1;
+            if constexpr (g == 3) {
+                if (!(late && LATEPOS)) burst();
+            }
+            if constexpr (g == 9 && LATEPOS) {
+                if (late) burst();
+            }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) acc[m][n] = mfma_bf16(wa[m], px[cur][n], acc[m][n]);
-            __builtin_amdgcn_sched_barrier(0);
-            // stage B
-            if (g < 11) {
+            if constexpr (g < 11) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) px[cur ^ 1][r] = CB_PX(g + 1, r);
-                wa[0] = CB_WT(g + 1, 0, 0);
-                wa[1] = CB_WT(g + 1, 0, 1);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) wv[cur ^ 1][ky] = CB_WT(g + 1, ky);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ky = 1; ky < 3; ++ky)
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) acc[m][n] = mfma_bf16(wb[ky - 1][m], px[cur][n + ky], acc[m][n]);
+                for (int n = 0; n < 2; ++n) acc[n] = mfma_bf16(wv[cur][ky], px[cur][n + ky], acc[n]);
             __builtin_amdgcn_sched_barrier(0);
-        }
+        };
+        group(std::integral_constant<int, 0>{});
+        group(std::integral_constant<int, 1>{});
+        group(std::integral_constant<int, 2>{});
+        group(std::integral_constant<int, 3>{});
+        group(std::integral_constant<int, 4>{});
+        group(std::integral_constant<int, 5>{});
+        group(std::integral_constant<int, 6>{});
+        group(std::integral_constant<int, 7>{});
+        group(std::integral_constant<int, 8>{});
+        group(std::integral_constant<int, 9>{});
+        group(std::integral_constant<int, 10>{});
+        group(std::integral_constant<int, 11>{});
 #undef CB_PX
 #undef CB_WT
+        accp[0] = acc[0];
+        accp[1] = acc[1];
+        eoffp[0] = eoff[0];
+        eoffp[1] = eoff[1];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) soffp[n][i] = soff[n][i];
+        eitemp = eitem;
+        pending = true;
+        CB_STAMP();
+        __syncthreads();                                            // this tile's buffer is free, the next tile's is complete
+        CB_STAMP();
     }
+    // the last tile: its addend / residual pieces were requested in its own burst
     epilogue();
+#undef CB_COMMIT
 #undef CB_REQUEST
+#undef CB_UNIT
 }
 
 hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s) {
@@ -287,8 +382,7 @@ hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
         ncu = prop.multiProcessorCount;
     }
-    const int ntiles = ((p.W + CB_TW - 1) / CB_TW) * ((p.H + CB_TH - 1) / CB_TH) * p.items;
-    const int grid = ntiles < ncu ? ntiles : ncu;
+    const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;                    // whole XCDs; surplus workgroups exit at once
     static bool attr[2] = {false, false};
     if (p.addend) {
         if (!attr[1]) {
@@ -477,3 +571,9 @@ void conv1x1_bf16_pack_weights(const float* hwio, int T, uint16_t* dst) {
 }
 
 }  // namespace pfnl
+
+#ifdef PFNL_BF16_TIMING
+extern "C" int pfnl_debug_read_bf16_stamps(long long* host, size_t n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(pfnl::cb_dbg), n * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif
