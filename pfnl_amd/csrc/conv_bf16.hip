@@ -1,28 +1,37 @@
-// bf16 trunk (BASELINE.json configs[3]: 1080p, bf16 activations + weights, fp32 accumulation): the 3x3 64->64
-// convolutions of the progressive-fusion blocks (conv1_i, both halves of conv2_i; reference model/pfnl.py:49-51,
-// 66-71) and conv10_i (1x1, T*64 -> 64; :50, :67-68) on v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate.
+// bf16 trunk (option precision=bf16; BASELINE.json configs[3]: 1080p, bf16 activations + weights, fp32 accumulation):
+// the 3x3 64->64 convolutions of the progressive-fusion blocks (conv1_i, both halves of conv2_i; reference
+// model/pfnl.py:49-51, 66-71) and conv10_i (1x1, T*64 -> 64; :50, :67-68) on v_mfma_f32_32x32x16_bf16, 16x the f32
+// MFMA rate.
 //
-// At that rate the matrix pipe is no longer what bounds the block: layer by layer the trunk moves 5.6 KB per LR
-// pixel and block in bf16, i.e. ~15 GB per 1080p forward against 3 TFLOP of DIRECT 3x3 work (1.2 ms at the 2.5
-// PFLOP/s dense peak, ~3 ms at 5 TB/s).  So this kernel is the direct algorithm (a Winograd transform would cost
-// more VALU time than the multiplies it saves), written so that HBM streams while the MFMAs run:
+// At that rate the matrix pipe no longer bounds the block: layer by layer the trunk moves 5.8 KB per LR pixel and
+// block in bf16 (15 GB per 1080p forward) against 3 TFLOP of DIRECT 3x3 work - 1.2 ms at the 2.5 PFLOP/s dense peak,
+// ~3 ms at the 4-5 TB/s this traffic mix reaches.  So the 3x3 kernel is the direct algorithm (a Winograd transform
+// would cost more VALU time than the multiplies it saves) built around the memory stream:
 //
 //   * persistent workgroup per CU (512 threads = 2 waves per SIMD); the launch's packed weights (9 taps x 64 x 64
 //     bf16 = 72 KB) are copied into LDS once and stay there;
-//   * output tile 16 rows x 32 columns x 64 channels; its 18 x 34-pixel halo tile (128 B per pixel, 76.5 KB)
-//     lives in LDS next to the weights (148.7 of 160 KB), 16-byte channel chunks XOR-swizzled by (column >> 1) & 7
-//     so that a ds_read_b128 of one chunk of 32 consecutive pixels is bank-conflict free;
-//   * MFMA roles: A = weights (rows = 32 output channels), B = pixels (columns = 32 pixels of a tile row), so
-//     that an accumulator lane owns ONE pixel and 4 consecutive output channels per register quad: the epilogue
-//     (bias, shared-half addend, leaky_relu, residual) works on 8-byte pieces of a pixel's 128-byte line;
-//   * wave w owns tile rows 2w, 2w+1 (2 pixel tiles x 2 channel tiles = 4 accumulators).  For a fixed column tap
-//     kx and 16-channel step, the 4 halo rows 2w..2w+3 serve all 3 row taps of both output rows: 4 pixel reads +
-//     6 weight reads feed 12 MFMAs;
-//   * the next tile's halo is requested into registers (10 x 16 B per thread, buffer loads whose range check
-//     zero-fills the border) before the 432 MFMAs of the current tile start, and written to LDS after them.
+//   * output tile 8 rows x 32 columns x 64 channels; its 10 x 34-pixel halo tile (128 B per pixel, 42.5 KB) is
+//     double-buffered in LDS next to the weights (157 of 160 KB), 16-byte channel chunks XOR-swizzled by
+//     (column >> 1) & 7 so that a ds_read_b128 of one chunk of 32 consecutive pixels is bank-conflict free
+//     (SQ_LDS_BANK_CONFLICT = 0);
+//   * MFMA roles: A = weights (rows = 32 output channels), B = pixels (columns = 32 pixels of a tile row): an
+//     accumulator lane owns ONE pixel, and - the row -> channel map being free - 16 consecutive output channels;
+//   * wave = (row pair, channel tile): 2 accumulators.  For a fixed column tap and 16-channel step the 4 halo rows of
+//     the pair serve all 3 row taps of both output rows: 4 pixel reads + 3 weight reads feed 6 MFMAs, requested one
+//     group ahead of the MFMAs that use them;
+//   * work order: chains of the T frames of a clip at one spatial tile (fused launch: the shared-half addend pieces
+//     are fetched once per chain), dealt out XCD by XCD so that neighbouring tiles share their halo rows in that
+//     XCD's L2 - HBM reads went from 1.31x (conv1_i) / 1.55x (conv2_i) of the compulsory bytes to 1.02x;
+//   * everything that is not an MFMA is sliced over the 12 groups of a tile (see the loop): the previous tile's
+//     epilogue from copied accumulators into an LDS scratch, its stores as whole 128-byte lines, the next halo's
+//     commit to the other LDS buffer, the requests for the halo after next - each wait is for a request issued most of
+//     a tile period earlier, and the in-order vmcnt queue never has a store in front of a load that is waited for.
 //
-// conv2_i keeps the shared-`base` split of the fp32 path (`SURVEY.md` §8(a)-G): one launch over `base` produces
-// the raw shared half per clip, the per-frame launch adds it before the activation.
+// conv2_i keeps the shared-`base` split of the fp32 path: one launch over `base` produces
+// the raw shared half per clip (stored in bf16), the per-frame launch adds it before the activation.
+// Measured (1x7x270x480, rocprofv3): conv1_i 72 us, conv2_i per-frame half 87 us, shared half 16 us, conv10_i 29 us
+// per block; 3.2-4.3 TB/s of HBM traffic; matrix pipe 38 % busy.  -DCB_X_NOMFMA / NOSTORE / NOLOAD are timing
+// experiments (wrong results on purpose) used to find what bounds the kernel; -DPFNL_BF16_TIMING adds phase stamps.
 #include <cstring>
 #include <type_traits>
 #include <vector>
@@ -37,9 +46,6 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-#ifndef CB_LATEPOS
-#define CB_LATEPOS 1
-#endif
 constexpr int CB_THREADS = 512;
 constexpr int CB_TH = 8, CB_TW = 32;
 constexpr int CB_IH = CB_TH + 2, CB_IW = CB_TW + 2;
@@ -86,8 +92,6 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
 #endif
     const int rp = wave >> 1;                                       // rows 2rp, 2rp+1 of the tile
     const int mt = wave & 1;                                        // output channels 32mt .. 32mt+31
-    const bool late = wave >= 4;                                    // waves w and w+4 share a SIMD: their memory bursts are half a tile apart
-    constexpr bool LATEPOS = CB_LATEPOS && !FUSE;                   // (the fused variant has no registers left for the second copy of the burst)
     const int H = p.H, W = p.W;
     const int tiles_x = (W + CB_TW - 1) / CB_TW, tiles_y = (H + CB_TH - 1) / CB_TH;
     const int per_item = tiles_x * tiles_y;
@@ -182,72 +186,59 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
     const int ech = 32 * mt + 16 * (lane >> 5);
     f32x16 acc[2], accp[2];                                         // [output row]: the tile being computed / awaiting its epilogue
     u32x4 rres[2][2], radd[2][2];                                   // FUSE: residual / addend pieces of the tile awaiting its epilogue
-    int eoff[2] = {0x7fffffff, 0x7fffffff}, eoffp[2] = {0x7fffffff, 0x7fffffff};   // this lane's pixel of output row n (bytes into the item)
+    int eoff[2] = {0x7fffffff, 0x7fffffff};                         // this lane's pixel of output row n (bytes into the item): addend / residual pieces
     int eitem = 0, eitemp = 0;
     bool pending = false;
 
-    // Stores.  A lane owns 32 contiguous bytes of its pixel (two 16-byte pieces), lane + 32 the next 32: stored as
-    // they sit, every instruction would send 64 separate 16-byte writes to L2 (measured: 2.3-3.9k cycles per tile in
-    // the epilogue, the L2 request rate, not bytes, was the bound).  The pieces are first exchanged through the LDS
-    // crossbar (ds_bpermute, no LDS memory) so that 4 ADJACENT lanes hold the 4 pieces of one pixel's 64-byte half
-    // line: instruction i of a row stores pixels 16i .. 16i+15, one 64-byte request each.
-    const int sq = lane & 3;                                        // piece of the half line this lane stores
-    const int ssrc = (((lane >> 2) + 32 * (sq >> 1)) << 2);         // + 64 i: bpermute address of the lane that holds it
-    int soffp[2][2] = {{0x7fffffff, 0x7fffffff}, {0x7fffffff, 0x7fffffff}};   // [row][i]: store offsets of the tile awaiting its epilogue
-    auto epilogue = [&]() {                                         // bias, addend, leaky_relu, residual, bf16, store: tile `p`
-        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)eitemp * H * W * 64, 0, item_bytes, 0x00020000);
+    // Stores.  A lane owns 32 contiguous bytes of its pixel (two 16-byte pieces), lane + 32 the next 32, the partner
+    // wave (other channel tile) the other half line: stored as they sit, a wave instruction sends 64 separate 16-byte
+    // writes to L2, and HBM sees half-written lines.  Measured on the 1080p launches (rocprofv3, t = a R + b W over
+    // the conv1_i / conv2_i launches): reads ~10 TB/s, such writes 1.8 TB/s - against 4 TB/s for the fully coalesced
+    // stores of the cast kernel.  So the finished tile (bias, addend, activation, residual applied, rounded to bf16)
+    // goes through LDS: every wave drops its pieces into a pixel-major scratch (the OTHER halo buffer, free until the
+    // next halo is committed; 16-byte pieces XOR-swizzled by pixel & 7, conflict-free both ways), and after a
+    // barrier the workgroup stores it as whole 128-byte lines, 8 pixels per wave instruction.
+    int ex0p = 0, ey0p = 0;                                         // origin of the tile awaiting its epilogue
+    auto epilogue_unit = [&](unsigned char* scratch, int n, int h) __attribute__((always_inline)) {   // bias, addend, leaky_relu, residual, bf16
+        f32x4 v[2];                                                 // of row n, channels ech + 8h .. + 7 of the tile awaiting its epilogue
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            u32x4 pc[2];                                            // this lane's two pieces of row n
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                f32x4 v[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int r0 = 8 * h + 4 * q;
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + ech + r0);
-                    v[q] = f32x4{accp[n][r0], accp[n][r0 + 1], accp[n][r0 + 2], accp[n][r0 + 3]} + b4;
-                    if (FUSE) v[q] += bf16x4_to_f32(u32x2{radd[n][h][2 * q], radd[n][h][2 * q + 1]});
-                    if (p.act) {
-                        v[q].x = lrelu(v[q].x);
-                        v[q].y = lrelu(v[q].y);
-                        v[q].z = lrelu(v[q].z);
-                        v[q].w = lrelu(v[q].w);
-                    }
-                    if (FUSE) v[q] += bf16x4_to_f32(u32x2{rres[n][h][2 * q], rres[n][h][2 * q + 1]});
-                }
-                const u32x2 lo = f32x4_to_bf16(v[0]), hi = f32x4_to_bf16(v[1]);
-                pc[h] = u32x4{lo.x, lo.y, hi.x, hi.y};
+        for (int q = 0; q < 2; ++q) {
+            const int r0 = 8 * h + 4 * q;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + ech + r0);
+            v[q] = f32x4{accp[n][r0], accp[n][r0 + 1], accp[n][r0 + 2], accp[n][r0 + 3]} + b4;
+            if (FUSE) v[q] += bf16x4_to_f32(u32x2{radd[n][h][2 * q], radd[n][h][2 * q + 1]});
+            if (p.act) {
+                v[q].x = lrelu(v[q].x);
+                v[q].y = lrelu(v[q].y);
+                v[q].z = lrelu(v[q].z);
+                v[q].w = lrelu(v[q].w);
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                u32x4 o;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const unsigned a0 = __builtin_amdgcn_ds_bpermute(ssrc + 64 * i, pc[0][d]);
-                    const unsigned a1 = __builtin_amdgcn_ds_bpermute(ssrc + 64 * i, pc[1][d]);
-                    o[d] = (sq & 1) ? a1 : a0;
-                }
-#ifdef CB_X_NOSTORE   /* timing experiments only */
-                if (o.x == 0x12345678u)
-#endif
-                __builtin_amdgcn_raw_buffer_store_b128(o, rsO, soffp[n][i], 0, 0);
-            }
+            if (FUSE) v[q] += bf16x4_to_f32(u32x2{rres[n][h][2 * q], rres[n][h][2 * q + 1]});
         }
+        const u32x2 lo = f32x4_to_bf16(v[0]), hi = f32x4_to_bf16(v[1]);
+        const int j = lane & 31;
+        const int c = 4 * mt + 2 * (lane >> 5) + h;                 // piece of the pixel's line
+        *reinterpret_cast<u32x4*>(scratch + ((2 * rp + n) * 32 + j) * 128 + ((c ^ (j & 7)) << 4)) = u32x4{lo.x, lo.y, hi.x, hi.y};
     };
-    auto fuse_request = [&](bool with_addend) {                     // addend / residual pieces of the tile just described by eoff / eitem
+    auto store_piece = [&](const unsigned char* scratch, int k) __attribute__((always_inline)) {   // 2048 pieces, 4 per thread, whole lines per instruction
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)eitemp * H * W * 64, 0, item_bytes, 0x00020000);
+        const int id = k * CB_THREADS + tid;
+        const int pp = id >> 3, c = id & 7;
+        const int sx = ex0p + (pp & 31), sy = ey0p + (pp >> 5);
+        const u32x4 o = *reinterpret_cast<const u32x4*>(scratch + pp * 128 + ((c ^ (pp & 7)) << 4));
+#ifdef CB_X_NOSTORE   /* timing experiments only */
+        if (o.x == 0x12345678u)
+#endif
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsO, (sx < W && sy < H) ? (sy * W + sx) * 128 + c * 16 : 0x7fffffff, 0, 0);
+    };
+    auto fuse_request = [&](bool with_addend, int n, int h) __attribute__((always_inline)) {   // addend / residual piece (n, h) of the tile described by eoff / eitem
         const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<uint16_t*>(p.resid) + (size_t)eitem * H * W * 64, 0, item_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<uint16_t*>(p.addend) + (size_t)(eitem / p.add_div) * H * W * 64, 0, item_bytes, 0x00020000);
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (with_addend)                                    // (same pixels for every frame of the chain)
-                    radd[n][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, eoff[n], (ech + 8 * h) * 2, 0));
-                rres[n][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, eoff[n], (ech + 8 * h) * 2, 0));
-            }
+        if (with_addend)                                            // (same pixels for every frame of the chain)
+            radd[n][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, eoff[n], (ech + 8 * h) * 2, 0));
+        rres[n][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, eoff[n], (ech + 8 * h) * 2, 0));
     };
 
     CB_REQUEST(0);
@@ -269,38 +260,21 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
             eoff[n] = (ox < W && oy < H) ? (oy * W + ox) * 128 : 0x7fffffff;
         }
         eitem = item;
-        int soff[2][2];
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int sx = x0 + 16 * i + (lane >> 2), sy = y0 + 2 * rp + n;
-                soff[n][i] = (sx < W && sy < H) ? (sy * W + sx) * 128 + 64 * mt + 16 * sq : 0x7fffffff;
-            }
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
-        // The memory burst of an iteration, once per wave, at group 3 (waves 0-3) or 9 (waves 4-7) of the 12: the halo
-        // requested one burst ago goes to the other LDS buffer (nobody reads it during this iteration), the previous
-        // tile's epilogue runs from its copied accumulators, then this tile's addend / residual pieces and the halo
-        // after next are requested.  Every wait in here is for the NEWEST request in the in-order vmcnt queue, issued
-        // a whole tile period earlier - stores and loads drain under the MFMAs of both waves of the SIMD.
-        auto burst = [&]() {
-            CB_STAMP();
-#pragma unroll
-            for (int k = 0; k < CB_ITERS; ++k) asm volatile("" : "+v"(spk[k]));   // opaque: nothing derived from it is hoisted into registers
-            CB_COMMIT(cb ^ 1);
-            CB_STAMP();
-            if (pending) epilogue();
-            CB_STAMP();
-            if (FUSE) fuse_request(chain_head);
-#ifndef CB_X_NOLOAD   /* timing experiments only */
-            CB_REQUEST(min(u + 2, nu - 1));
-#endif
-            CB_STAMP();
-        };
+        // Everything that is not an MFMA is spread over the 12 groups of the tile, a slice per group, so that it issues
+        // in the shadow of the matrix pipe (both waves of a SIMD run the same phase at the same time - work done in a
+        // block of its own is added to the MFMA time, not hidden by it: measured 9.2k cycles per tile with the MFMAs,
+        // loads and stores compiled out).  Every wait is for a request issued most of a tile period earlier.
+        //   groups 0-3:  epilogue unit (row, channel half) of the previous tile into the scratch, then that unit's
+        //                addend / residual pieces of THIS tile are requested into the registers just consumed
+        //   group 4:     barrier;  groups 4-7: a quarter of the previous tile's stores each, whole lines
+        //   group 8:     barrier (scratch read);  the halo requested a tile ago -> the other LDS buffer (over the scratch)
+        //   group 10:    the halo after next is requested
+        unsigned char* const other = cb_smem + (cb ^ 1) * CB_TILE_BYTES;
 
         // 12 groups (column tap kx, k-step ks): the 4 halo rows 2rp..2rp+3 serve the 3 row taps of both output rows -
         // 4 pixel reads + 3 weight reads feed 6 MFMAs; the operands of group g+1 are requested before the MFMAs of g
@@ -316,11 +290,26 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
         auto group = [&](auto gc) {
             constexpr int g = decltype(gc)::value;
             constexpr int cur = g & 1;
-            if constexpr (g == 3) {
-                if (!(late && LATEPOS)) burst();
+            if constexpr (g < 4) {
+                if (pending) epilogue_unit(other, g >> 1, g & 1);
+                if (FUSE) fuse_request(chain_head, g >> 1, g & 1);
             }
-            if constexpr (g == 9 && LATEPOS) {
-                if (late) burst();
+            if constexpr (g == 4) __syncthreads();
+            if constexpr (g >= 4 && g < 8) {
+                if (pending) store_piece(other, g - 4);
+            }
+            if constexpr (g == 8) {
+                __syncthreads();                                       // the scratch has been read
+                CB_STAMP();
+#pragma unroll
+                for (int k = 0; k < CB_ITERS; ++k) asm volatile("" : "+v"(spk[k]));   // opaque: nothing derived from it is hoisted into registers
+                CB_COMMIT(cb ^ 1);
+                CB_STAMP();
+            }
+            if constexpr (g == 10) {
+#ifndef CB_X_NOLOAD   /* timing experiments only */
+                CB_REQUEST(min(u + 2, nu - 1));
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (g < 11) {
@@ -352,20 +341,20 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
 #undef CB_WT
         accp[0] = acc[0];
         accp[1] = acc[1];
-        eoffp[0] = eoff[0];
-        eoffp[1] = eoff[1];
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) soffp[n][i] = soff[n][i];
+        ex0p = x0;
+        ey0p = y0;
         eitemp = eitem;
         pending = true;
         CB_STAMP();
-        __syncthreads();                                            // this tile's buffer is free, the next tile's is complete
+        __syncthreads();                                               // this tile's buffer is free, the next tile's is complete
         CB_STAMP();
     }
-    // the last tile: its addend / residual pieces were requested in its own burst
-    epilogue();
+    // the last tile (its addend / residual pieces were requested in its own iteration); any buffer is free now
+#pragma unroll
+    for (int k = 0; k < 4; ++k) epilogue_unit(cb_smem, k >> 1, k & 1);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) store_piece(cb_smem, k);
 #undef CB_COMMIT
 #undef CB_REQUEST
 #undef CB_UNIT

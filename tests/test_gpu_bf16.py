@@ -105,3 +105,29 @@ def test_forward_bf16_matches_rounded_oracle(geom, B, H, W):
     eng.set_option("precision", "fp32")                                   # and back: the fp32 path is untouched
     assert np.abs(eng.forward(x) - o32).max() < 2e-4
     eng.close()
+
+
+@pytest.mark.parametrize("B,H,W", [(4, 128, 128), (1, 270, 480)])
+def test_forward_bf16_full_size_against_fp32_build(B, H, W):
+    """BASELINE.json configs[1] / configs[3] sizes: the CPU oracle needs minutes there, so the bf16 trunk is held against
+    the fp32 build of the same forward (itself pinned to the oracle: test_gpu_forward.py, tools/check_1080p.py), plus
+    determinism and batch-permutation equivariance (clips are independent units)."""
+    geom = PFNLGeometry()
+    eng = PFNLEngine(geom, device=0)
+    eng.load_weights(synth.synthetic_weights(geom, seed=0))
+    x, gt = synth.moving_field_clips(B, 7, H, W, 4, seed=11) if H <= 128 else (synth.uniform_clips(B, 7, H, W, seed=11), None)
+    y32 = eng.forward(x)
+    eng.set_option("precision", "bf16")
+    y16 = eng.forward(x)
+    assert y16.shape == y32.shape and np.isfinite(y16).all()
+    p = synth.psnr(y16, y32)
+    print(f"bf16 vs fp32 build at {B}x7x{H}x{W}: PSNR {p:.1f} dB, max|d| {np.abs(y16 - y32).max():.2e}")
+    assert p > 55.0, p
+    if gt is not None:
+        d = abs(synth.psnr(y16[:, 0], gt) - synth.psnr(y32[:, 0], gt))
+        assert d <= 0.1, d
+    assert np.array_equal(eng.forward(x), y16)
+    if B > 1:
+        perm = np.arange(B)[::-1].copy()
+        assert np.array_equal(eng.forward(np.ascontiguousarray(x[perm])), y16[perm])
+    eng.close()
