@@ -178,6 +178,11 @@ int pfnl_op_conv3x3_winograd16(const float* in, const float* kernel_host, const 
 int pfnl_op_nonlocal(const float* x, const float* wg_host, const float* bg_host,
                      const float* ww_host, const float* bw_host, float* out,
                      int B, int T, int H, int W, void* stream);
+/* The same block on bf16 MFMA with split (hi + lo) operands and fp32 softmax state (option precision=bf16,
+ * nonlocal_bf16.hip): same arguments, fp32 in and out. */
+int pfnl_op_nonlocal_bf16(const float* x, const float* wg_host, const float* bg_host,
+                     const float* ww_host, const float* bw_host, float* out,
+                     int B, int T, int H, int W, void* stream);
 /* tf.image.resize_images(method=2) of TF1.12 (model/pfnl.py:63): x [B,H,W,3] -> [B,sH,sW,3]. */
 int pfnl_op_bicubic(const float* x, float* out, int B, int H, int W, int scale, void* stream);
 /* The step before the path in test_video_truth / eval (reference utils.py:95-105,169-192:

@@ -93,6 +93,7 @@ struct pfnl_handle {
     size_t off_m1_w = 0, off_m1_b = 0, off_m2_w = 0, off_m2_b = 0, off_nl_w = 0, off_nl_b = 0, off_zero = 0;
 
     // workspace
+    DevBuf nl16;                                              // bf16 non-local: split K / V^T operands
     DevBuf X, Xo, nlp, inp0, inp1, base, pb, merge, stage_in, stage_out, scratch;
     int lastB = 0, lastH = 0, lastW = 0;
 
@@ -201,7 +202,13 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
     }
     {
         ProfScope ps(h, s, PFNL_K_NL_ATTN);
-        HIPCHK(launch_nl_attn(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p, B, N, C, s));
+        if (h->bf16) {
+            if (h->nl16.ensure((nl_bf16_scratch_halfs(B, N) + 1) / 2)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
+            HIPCHK(launch_nl_attn_bf16(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p,
+                                       reinterpret_cast<uint16_t*>(h->nl16.p), B, N, C, s));
+        } else {
+            HIPCHK(launch_nl_attn(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p, B, N, C, s));
+        }
     }
     {   // model/pfnl.py:61-62
         ProfScope ps(h, s, PFNL_K_CONV0);
@@ -469,7 +476,7 @@ int pfnl_destroy(pfnl_handle* h) {
         if (g.exec) hipGraphExecDestroy(g.exec);
         if (g.graph) hipGraphDestroy(g.graph);
     }
-    for (DevBuf* b : {&h->wdev, &h->wdev16, &h->X, &h->Xo, &h->nlp, &h->inp0, &h->inp1, &h->base, &h->pb, &h->merge,
+    for (DevBuf* b : {&h->wdev, &h->wdev16, &h->nl16, &h->X, &h->Xo, &h->nlp, &h->inp0, &h->inp1, &h->base, &h->pb, &h->merge,
                       &h->stage_in, &h->stage_out, &h->scratch})
         b->release();
     delete h;
@@ -1153,8 +1160,8 @@ int pfnl_op_conv3x3_winograd16(const float* in, const float* kernel_host, const 
     return 0;
 }
 
-int pfnl_op_nonlocal(const float* x, const float* wg, const float* bg, const float* ww, const float* bw,
-                     float* out, int B, int T, int H, int W, void* stream) {
+static int op_nonlocal(bool bf16, const float* x, const float* wg, const float* bg, const float* ww, const float* bw,
+                       float* out, int B, int T, int H, int W, void* stream) {
     if (!x || !wg || !bg || !ww || !bw || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
     if ((T != 3 && T != 5 && T != 7) || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1))
         return fail(PFNL_ERR_INVALID, "unsupported non-local geometry");
@@ -1175,18 +1182,32 @@ int pfnl_op_nonlocal(const float* x, const float* wg, const float* bg, const flo
     float* d = nullptr;
     const size_t nX = (size_t)B * N * CP;
     const size_t nP = pfnl::nl_partial_floats(B, N, C);
-    HIPCHK(hipMalloc(&d, (blob.size() + 2 * nX + nP) * sizeof(float)));
+    const size_t n16 = bf16 ? (pfnl::nl_bf16_scratch_halfs(B, N) + 1) / 2 : 0;   // in floats
+    HIPCHK(hipMalloc(&d, (blob.size() + 2 * nX + nP + n16 + 64) * sizeof(float)));
     float* dX = d + blob.size();
     float* dXo = dX + nX;
     float* dP = nP ? dXo + nX : nullptr;
+    uint16_t* d16 = reinterpret_cast<uint16_t*>(d + (blob.size() + 2 * nX + nP + 63) / 64 * 64);
     hipError_t e = hipMemcpy(d, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = pfnl::launch_nl_pack(x, dX, B, T, H, W, s);
-    if (e == hipSuccess) e = pfnl::launch_nl_attn(dX, dXo, d, d + (size_t)CP * CP, dP, B, N, C, s);
+    if (e == hipSuccess)
+        e = bf16 ? pfnl::launch_nl_attn_bf16(dX, dXo, d, d + (size_t)CP * CP, dP, d16, B, N, C, s)
+                 : pfnl::launch_nl_attn(dX, dXo, d, d + (size_t)CP * CP, dP, B, N, C, s);
     if (e == hipSuccess) e = pfnl::launch_nl_unpack(dXo, out, B, T, H, W, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     hipFree(d);
     if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("nonlocal op: ") + hipGetErrorString(e));
     return 0;
+}
+
+int pfnl_op_nonlocal(const float* x, const float* wg, const float* bg, const float* ww, const float* bw,
+                     float* out, int B, int T, int H, int W, void* stream) {
+    return op_nonlocal(false, x, wg, bg, ww, bw, out, B, T, H, W, stream);
+}
+
+int pfnl_op_nonlocal_bf16(const float* x, const float* wg, const float* bg, const float* ww, const float* bw,
+                          float* out, int B, int T, int H, int W, void* stream) {
+    return op_nonlocal(true, x, wg, bg, ww, bw, out, B, T, H, W, stream);
 }
 
 int pfnl_op_bicubic(const float* x, float* out, int B, int H, int W, int scale, void* stream) {

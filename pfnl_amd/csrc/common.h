@@ -96,6 +96,9 @@ hipError_t launch_nl_pack(const float* x, float* X, int B, int T, int H, int W, 
 size_t nl_partial_floats(int B, int N, int C);               // scratch for the key-split partials (0 if unsplit)
 hipError_t launch_nl_attn(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, int B,
                           int N, int C, hipStream_t s);
+int nl_key_splits(int B, int N);
+hipError_t launch_nl_merge(const float* X, const float* Zp, const float* ML, const float* bp, float* Xo, int B, int N, int C, int ks,
+                           hipStream_t s);
 hipError_t launch_nl_unpack(const float* Xo, float* out, int B, int T, int H, int W, hipStream_t s);
 
 // ---- head / tail (misc_kernels.hip) ----------------------------------------------------------

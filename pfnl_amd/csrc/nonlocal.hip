@@ -319,6 +319,12 @@ hipError_t launch_nl_attn(const float* X, float* Xo, const float* Wp, const floa
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ks == 1) return e;
+    return launch_nl_merge(X, Zp, ML, bp, Xo, B, N, C, ks, s);
+}
+
+hipError_t launch_nl_merge(const float* X, const float* Zp, const float* ML, const float* bp, float* Xo, int B, int N, int C, int ks,
+                           hipStream_t s) {
+    const int CP = nl_padded_ch(C);
     const size_t total = (size_t)B * N * CP;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(nl_merge_kernel, dim3(blocks), dim3(256), 0, s, X, Zp, ML, bp, Xo, B, N, C, CP, ks);

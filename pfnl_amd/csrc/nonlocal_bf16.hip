@@ -1,0 +1,295 @@
+// Non-local block on bf16 MFMA (option precision=bf16; BASELINE.json configs[3]: at 1080p the affinity is
+// N = 32400 squared, 354 GFLOP - 3.3 ms on the f32 matrix pipe, more than the whole bf16 trunk).
+//
+// Same streaming-softmax structure as nonlocal.hip (reference utils.py:18-71, nltype=1), with the two contractions on
+// v_mfma_f32_32x32x16_bf16 and fp32 everywhere a bf16 value would be visible in the result:
+//   * logits S = X X^T (|S| <= 84, exp(S) needs ~1e-4 absolute): bf16 inputs alone would be wrong by ~16 %
+//     (SURVEY.md section 7), so X is split into hi + lo bf16 parts and S = hi hi + hi lo + lo hi accumulated in fp32
+//     (the dropped lo lo term is < 84 * 2^-18): 18 MFMAs of 32 cycles per 32x32 tile against 42 f32 MFMAs of 64;
+//   * P = exp2(S' - running max) in fp32, rounded to bf16 only as the MFMA operand; the row sum accumulates the SAME
+//     rounded values through the "ones" channel, so the normalisation is exact for what was summed;
+//   * V = X also as hi + lo (12 MFMAs per tile): a query dominated by one key returns that key's fp32 value;
+//   * running max / rescale, normalisation, the folded 1x1 projection (f32 MFMA) and the residual as in nonlocal.hip.
+// Operand layouts (lane = (l & 31, kh = l >> 5), 8 bf16 per lane and MFMA):
+//   K tile in LDS  [key][96 ch] (+ pad to 208 B: conflict-free b128 reads), hi and lo: A of S^T = K Q^T;
+//   Q in registers [6 k-steps] hi and lo, pre-scaled by log2(e): B of S^T;
+//   P^T straight from the S^T accumulator: register r of lane (query, kh) is key (r&3) + 8(r>>2) + 4kh, registers
+//   8t..8t+7 form the B operand of k-step t - the contraction order over keys is free, so V^T is stored by nl_pack_bf16
+//   with the keys of every 32-block permuted to exactly that order ([ch][block][t][kh][e]).
+#include "common.h"
+#include "conv_bf16.h"
+
+namespace pfnl {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NB_KT = 64;                  // keys per LDS tile
+constexpr int NB_KROW = 208;               // bytes per key row of the K tiles (96 ch * 2 B + 16)
+constexpr int NB_VROW = 144;               // bytes per channel row of the V^T tiles (64 keys * 2 B + 16)
+constexpr int NB_CP = 96;
+
+__device__ __forceinline__ unsigned short bf16_bits(float f) {   // round to nearest even
+    const __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf16_float(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+
+// X [B][N][CP] fp32 (nl_pack_kernel) -> Khi, Klo [B][N][96] bf16;  Vthi, Vtlo [B][96][Npad] bf16, keys permuted per
+// 32-block, channel C = 1 (the row-sum channel), channels > C = 0
+__global__ void nl_pack_bf16_kernel(const float* __restrict__ X, uint16_t* __restrict__ Khi, uint16_t* __restrict__ Klo,
+                                    uint16_t* __restrict__ Vthi, uint16_t* __restrict__ Vtlo, int B, int N, int Npad, int C,
+                                    int CPin) {
+    const size_t total = (size_t)B * Npad * NB_CP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % NB_CP);
+        const int n = (int)((i / NB_CP) % Npad);
+        const int b = (int)(i / ((size_t)NB_CP * Npad));
+        const float v = (n < N && c < C) ? X[((size_t)b * N + n) * CPin + c] : 0.f;
+        const unsigned short hi = bf16_bits(v);
+        const unsigned short lo = bf16_bits(v - bf16_float(hi));
+        if (n < N) {
+            Khi[((size_t)b * N + n) * NB_CP + c] = hi;
+            Klo[((size_t)b * N + n) * NB_CP + c] = lo;
+        }
+        // position of key n inside its 32-block: key = (e&3) + 8(2t + (e>>2)) + 4kh  ->  pos = 16t + 8kh + e
+        const int kb = n & 31;
+        const int e = (kb & 3) | (((kb >> 3) & 1) << 2), kh = (kb >> 2) & 1, t = kb >> 4;
+        const size_t vp = ((size_t)b * NB_CP + c) * Npad + (n & ~31) + 16 * t + 8 * kh + e;
+        Vthi[vp] = c == C ? (unsigned short)0x3f80 : hi;             // 1.0
+        Vtlo[vp] = c == C ? (unsigned short)0 : lo;
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void nl_attn_bf16_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Khi,
+                                                              const uint16_t* __restrict__ Klo, const uint16_t* __restrict__ Vthi,
+                                                              const uint16_t* __restrict__ Vtlo, float* __restrict__ Xo,
+                                                              const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                              float* __restrict__ Zp, float* __restrict__ ML, int N, int Npad) {
+    constexpr int CT = 3;
+    constexpr int CP = (C + 31) / 32 * 32;                          // row stride of X / Xo / Wp (nl_padded_ch)
+    static_assert(C < NB_CP && C % 2 == 0, "needs a pad channel inside 96");
+    __shared__ __attribute__((aligned(16))) unsigned char sm[2 * NB_KT * NB_KROW + 2 * NB_CP * NB_VROW];
+    unsigned char* const skh = sm;
+    unsigned char* const skl = sm + NB_KT * NB_KROW;
+    unsigned char* const svh = sm + 2 * NB_KT * NB_KROW;
+    unsigned char* const svl = svh + NB_CP * NB_VROW;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int xl = lane & 31;
+    const int kh = lane >> 5;
+    const int b = blockIdx.y;
+    const float* Xb = X + (size_t)b * N * CP;
+    float* Xob = Xo + (size_t)b * N * CP;
+    const int q = blockIdx.x * 128 + wave * 32 + xl;                // this lane's query
+    const int qc = q < N ? q : N - 1;
+
+    // B operand of S^T = K Q^T: this lane's query, channels 16ks + 8kh .. +7, scaled by log2(e), split hi + lo
+    constexpr float LOG2E = 1.4426950408889634f;
+    bf16x8 qh[6], ql[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 16 * ks + 8 * kh + e;
+            const float v = c < C ? Xb[(size_t)qc * CP + c] * LOG2E : 0.f;
+            const __bf16 h = (__bf16)v;
+            qh[ks][e] = h;
+            ql[ks][e] = (__bf16)(v - (float)h);
+        }
+    constexpr int LCT = C / 32, LI = C % 32;                        // where the row-sum channel C lives in the D layout
+    constexpr int LKH = (LI % 8) >= 4 ? 1 : 0, LR = (LI / 8) * 4 + (LI % 8) % 4;
+
+    f32x16 o[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
+    float m = -INFINITY;
+
+    // staging: 4 x 768 16-byte pieces per 64-key tile, 12 per thread
+    const uint16_t* const Khb = Khi + (size_t)b * N * NB_CP;
+    const uint16_t* const Klb = Klo + (size_t)b * N * NB_CP;
+    const uint16_t* const Vhb = Vthi + (size_t)b * NB_CP * Npad;
+    const uint16_t* const Vlb = Vtlo + (size_t)b * NB_CP * Npad;
+    u32x4 rk[12];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int id = tid + i * 256;                           // 0..767
+            const int key = id / 12, c16 = id - key * 12;
+            const bool ok = k0 + key < N;
+            const size_t ko = ((size_t)(k0 + (ok ? key : 0)) * NB_CP + c16 * 8);
+            rk[i] = ok ? *reinterpret_cast<const u32x4*>(Khb + ko) : u32x4{0, 0, 0, 0};
+            rk[3 + i] = ok ? *reinterpret_cast<const u32x4*>(Klb + ko) : u32x4{0, 0, 0, 0};
+            const int ch = id >> 3, kc = id & 7;                    // V^T: 96 rows x 8 pieces (k0 + 64 <= Npad + 32: rows are padded)
+            const bool vok = k0 + kc * 8 < Npad;
+            const size_t vo = (size_t)ch * Npad + k0 + (vok ? kc * 8 : 0);
+            rk[6 + i] = vok ? *reinterpret_cast<const u32x4*>(Vhb + vo) : u32x4{0, 0, 0, 0};
+            rk[9 + i] = vok ? *reinterpret_cast<const u32x4*>(Vlb + vo) : u32x4{0, 0, 0, 0};
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int id = tid + i * 256;
+            const int key = id / 12, c16 = id - key * 12;
+            *reinterpret_cast<u32x4*>(skh + key * NB_KROW + c16 * 16) = rk[i];
+            *reinterpret_cast<u32x4*>(skl + key * NB_KROW + c16 * 16) = rk[3 + i];
+            const int ch = id >> 3, kc = id & 7;
+            *reinterpret_cast<u32x4*>(svh + ch * NB_VROW + kc * 16) = rk[6 + i];
+            *reinterpret_cast<u32x4*>(svl + ch * NB_VROW + kc * 16) = rk[9 + i];
+        }
+    };
+
+    const int ntiles = (N + NB_KT - 1) / NB_KT;
+    const int ksp = gridDim.z, sp = blockIdx.z;
+    const int kt0 = (int)((long long)ntiles * sp / ksp), kt1 = (int)((long long)ntiles * (sp + 1) / ksp);
+    load_tile(kt0 * NB_KT);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        if (kt > kt0) __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < kt1) load_tile((kt + 1) * NB_KT);
+#pragma unroll
+        for (int sub = 0; sub < NB_KT / 32; ++sub) {
+            const int kbase = kt * NB_KT + sub * 32;
+            if (kbase >= N) break;                                  // wave-uniform
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+            const unsigned char* const kah = skh + (sub * 32 + xl) * NB_KROW + kh * 16;
+            const unsigned char* const kal = skl + (sub * 32 + xl) * NB_KROW + kh * 16;
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(kah + ks * 32);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(kal + ks * 32);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[ks], st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[ks], st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[ks], st, 0, 0, 0);
+            }
+            if (kbase + 32 > N) {                                   // wave-uniform: only the last, partial key block
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + drow(r, lane) >= N) st[r] = -INFINITY;
+            }
+            float tmax = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
+#pragma unroll
+            for (int r = 4; r < 16; r += 4) tmax = fmaxf(tmax, fmaxf(fmaxf(st[r], st[r + 1]), fmaxf(st[r + 2], st[r + 3])));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float mn = fmaxf(m, tmax);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            bf16x8 pt[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pt[r >> 3][r & 7] = (__bf16)__builtin_amdgcn_exp2f(st[r] - mn);
+            m = mn;
+            if (!__all(alpha == 1.0f)) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+            }
+            // O^T[ch][query] += V^T[ch][keys] P^T[keys][query], keys in the accumulator's own order
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const unsigned char* const vah = svh + (ct * 32 + xl) * NB_VROW + sub * 64 + kh * 16;
+                const unsigned char* const val = svl + (ct * 32 + xl) * NB_VROW + sub * 64 + kh * 16;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(vah + t * 32), pt[t], o[ct], 0, 0, 0);
+                    o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(val + t * 32), pt[t], o[ct], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    float l = o[LCT][LR];
+    {
+        const float lo = __shfl_xor(l, 32);
+        if (kh != LKH) l = lo;
+    }
+    const float inv = (ksp == 1) ? 1.0f / l : 1.0f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] *= inv;
+
+    // Z^T = W'^T O^T on the f32 matrix pipe, as in nonlocal.hip (pad rows of W' are zero: the row-sum channel drops out)
+    constexpr int CTW = CP / 32;
+#pragma unroll
+    for (int cot = 0; cot < CTW; ++cot) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) {
+            const float* wa = Wp + (size_t)(ct * 32 + 4 * kh) * CP + cot * 32 + xl;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) z = mfma32(wa[((s & 3) + 8 * (s >> 2)) * CP], o[ct][s], z);
+        }
+        if (q < N) {
+            if (ksp == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cot * 32 + drow(r, lane);
+                    if (co < C) {
+                        const size_t idx = (size_t)q * CP + co;
+                        Xob[idx] = Xb[idx] + z[r] + bp[co];            // residual, model/pfnl.py:60
+                    }
+                }
+            } else {
+                float* zp = Zp + (((size_t)b * ksp + sp) * N + q) * CP;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zp[cot * 32 + drow(r, lane)] = z[r];
+            }
+        }
+    }
+    if (ksp > 1 && q < N && kh == 0) {
+        float* ml = ML + (((size_t)b * ksp + sp) * N + q) * 2;
+        ml[0] = m;
+        ml[1] = l;
+    }
+}
+
+size_t nl_bf16_scratch_halfs(int B, int N) {                        // Khi, Klo, Vthi, Vtlo
+    const size_t npad = (size_t)(N + 31) / 32 * 32 + 64;            // + one tile of slack for the last tile's V^T pieces
+    return 2 * (size_t)B * N * NB_CP + 2 * (size_t)B * NB_CP * npad;
+}
+
+// X, Xo as in launch_nl_attn; scratch16: nl_bf16_scratch_halfs(B, N) 16-bit elements; partial: nl_partial_floats
+hipError_t launch_nl_attn_bf16(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, uint16_t* scratch16,
+                               int B, int N, int C, hipStream_t s) {
+    if (C != 84 && C != 60 && C != 36) return hipErrorInvalidValue;
+    const int CP = nl_padded_ch(C);
+    const int npad = (N + 31) / 32 * 32 + 64;
+    uint16_t* Khi = scratch16;
+    uint16_t* Klo = Khi + (size_t)B * N * NB_CP;
+    uint16_t* Vthi = Klo + (size_t)B * N * NB_CP;
+    uint16_t* Vtlo = Vthi + (size_t)B * NB_CP * npad;
+    {
+        const size_t total = (size_t)B * npad * NB_CP;
+        const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        hipLaunchKernelGGL(nl_pack_bf16_kernel, dim3(blocks), dim3(256), 0, s, X, Khi, Klo, Vthi, Vtlo, B, N, npad, C, CP);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    const int ks = nl_key_splits(B, N);
+    if (ks > 1 && !partial) return hipErrorInvalidValue;
+    float* Zp = partial;
+    float* ML = partial ? partial + (size_t)B * ks * N * CP : nullptr;
+    dim3 grid((N + 127) / 128, B, ks);
+    dim3 block(256);
+    switch (C) {
+        case 84: hipLaunchKernelGGL(nl_attn_bf16_kernel<84>, grid, block, 0, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad); break;
+        case 60: hipLaunchKernelGGL(nl_attn_bf16_kernel<60>, grid, block, 0, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad); break;
+        case 36: hipLaunchKernelGGL(nl_attn_bf16_kernel<36>, grid, block, 0, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || ks == 1) return e;
+    return launch_nl_merge(X, Zp, ML, bp, Xo, B, N, C, ks, s);
+}
+
+}  // namespace pfnl

@@ -169,7 +169,7 @@ def conv3x3_winograd(x, kernel, bias=None, act=True, addend=None, add_div=1, res
     return out
 
 
-def nonlocal_residual(x, wg, bg, ww, bw):
+def nonlocal_residual(x, wg, bg, ww, bw, precision="fp32"):
     """x [B,T,H,W,3] (cuda) -> [B,H,W,3T] = stack + depth_to_space(NonLocalBlock(space_to_depth(stack)))
     (reference utils.py:18-71 with nltype=1, model/pfnl.py:55-60)."""
     import torch
@@ -180,7 +180,8 @@ def nonlocal_residual(x, wg, bg, ww, bw):
     if arrs[0].size != C_ * C_ or arrs[2].size != C_ * C_ or arrs[1].size != C_ or arrs[3].size != C_:
         raise ValueError("nonlocal: weight shapes do not match 12*T channels")
     out = torch.empty((B, H, W, 3 * T), dtype=torch.float32, device=x.device)
-    _capi.check(lib.pfnl_op_nonlocal(_req(x, "x"), *[a.ctypes.data_as(C.c_void_p) for a in arrs],
+    fn = lib.pfnl_op_nonlocal_bf16 if precision == "bf16" else lib.pfnl_op_nonlocal   # bf16: split-operand bf16 MFMA variant
+    _capi.check(fn(_req(x, "x"), *[a.ctypes.data_as(C.c_void_p) for a in arrs],
                                      _req(out, "out"), B, T, H, W, _stream(x)))
     return out
 
