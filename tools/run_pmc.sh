@@ -6,5 +6,5 @@ for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST
             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM" \
             "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $pass --kernel-trace -d gpurun_out/pmc_${tag}_$i -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2>&1
+  rocprofv3 --pmc $pass --kernel-trace -d gpurun_out/pmc_${tag}_$i -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile $BENCH_ARGS > /dev/null 2>&1
 done
