@@ -89,6 +89,7 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *                 the 20 progressive-fusion blocks keep their activations and weights in bf16 and accumulate in fp32 on
  *                 bf16 MFMA (conv_bf16.hip); the non-local block, its logits, conv0's arithmetic, convmerge1, the tail and
  *                 the bicubic skip stay fp32; the interface tensors stay float32.  Tolerance: DESIGN.md section 4).
+ * key "bf16_conv10" = "fused" (default: conv10_i runs inside the conv1_i launch of the bf16 trunk) | "separate".
  * The default can also be set with the environment variable PFNL_CONV3X3 read by pfnl_create. */
 int pfnl_set_option(pfnl_handle* h, const char* key, const char* value);
 
@@ -157,6 +158,12 @@ int pfnl_op_conv1x1_stream(const float* in, const float* kernel_host, const floa
  * out = act(conv + bias + addend[item / add_div]) + resid; addend and resid both NULL or both given; out may alias resid. */
 int pfnl_op_conv3x3_bf16(const uint16_t* in, const float* kernel_host, const float* bias_host, const uint16_t* addend,
                          int add_div, const uint16_t* resid, uint16_t* out, int items, int H, int W, int act, void* stream);
+/* conv1_i and conv10_i of a progressive-fusion block (reference model/pfnl.py:66-68) in ONE launch of the bf16 3x3 kernel:
+ * out1 = lrelu(conv3x3(in) + b1) [clips*fpc, H, W, 64], base = lrelu(conv1x1(concat_t out1_t) + b10) [clips, H, W, 64];
+ * the 1x1 contraction reads every finished tile from LDS.  fpc in {3,5,7}. */
+int pfnl_op_conv1_conv10_bf16(const uint16_t* in, const float* k1_host, const float* b1_host, const float* k10_host,
+                              const float* b10_host, uint16_t* out1, uint16_t* base, int clips, int frames_per_clip, int H, int W,
+                              void* stream);
 /* ... and conv10_i (reference model/pfnl.py:50, :67-68): in [items*fpi, HW, 64] bf16, kernel_host fp32 HWIO
  * [1,1,64*fpi,64], out [items, HW, 64] bf16; fpi in {3,5,7}. */
 int pfnl_op_conv1x1_bf16(const uint16_t* in, const float* kernel_host, const float* bias_host, uint16_t* out, int items,

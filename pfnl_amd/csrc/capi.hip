@@ -78,6 +78,7 @@ struct pfnl_handle {
     bool conv2_grouped = true;                                // winograd: conv2_i as one grouped launch (option conv2=grouped|split)
     int merge_cstride = 48;                                   // floats per pixel of `merge` as written by the last forward
     int conv1x1_algo = 1;                                     // conv10: 1 streaming kernel (conv1x1.hip), 0 LDS-tiled implicit GEMM
+    bool bf16_fuse10 = true;                                  // bf16 trunk: conv10_i inside the conv1_i launch (option bf16_conv10=fused|separate)
     bool bf16 = false;                                        // option precision=bf16: progressive-fusion trunk in bf16 (conv_bf16.hip); NL, conv0 maths, merge, tail stay fp32
     DevBuf wdev16;                                            // bf16 packs (offsets in 16-bit elements)
     std::vector<size_t> off16_c1, off16_c10, off16_c2a, off16_c2b;
@@ -231,12 +232,18 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
                 h->prof_gate = (i & 3) == 0;
                 h->chain_open = false;
             }
-            {   // conv1_i
+            {   // conv1_i (+ conv10_i from the LDS scratch its tiles pass through: conv_bf16.hip MODE 2)
                 ProfScope ps(h, s, PFNL_K_CONV3X3);
                 ConvBf16Params q{a0, w16 + h->off16_c1[i], wd + h->off_c1_b[i], nullptr, nullptr, a1, H, W, F, 1, 1};
+                if (h->bf16_fuse10) {
+                    q.add_div = T;
+                    q.x_w = w16 + h->off16_c10[i];
+                    q.x_bias = wd + h->off_c10_b[i];
+                    q.x_out = ab;
+                }
                 HIPCHK(launch_conv3x3_bf16(q, s));
             }
-            {   // conv10_i
+            if (!h->bf16_fuse10) {   // conv10_i as a launch of its own
                 ProfScope ps(h, s, PFNL_K_CONV1X1);
                 HIPCHK(launch_conv1x1_bf16(a1, w16 + h->off16_c10[i], wd + h->off_c10_b[i], ab, B, T, H * W, 1, s));
             }
@@ -526,6 +533,12 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         if (v == "grouped") h->conv2_grouped = true;
         else if (v == "split") h->conv2_grouped = false;
         else return fail(PFNL_ERR_INVALID, "conv2 must be grouped or split");
+        return 0;
+    }
+    if (k == "bf16_conv10") {
+        if (v == "fused") h->bf16_fuse10 = true;
+        else if (v == "separate") h->bf16_fuse10 = false;
+        else return fail(PFNL_ERR_INVALID, "bf16_conv10 must be fused or separate");
         return 0;
     }
     if (k == "precision") {
@@ -1002,6 +1015,31 @@ int pfnl_op_conv3x3_bf16(const uint16_t* in, const float* kernel_host, const flo
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(dw);
     if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv3x3 bf16 op: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int pfnl_op_conv1_conv10_bf16(const uint16_t* in, const float* k1_host, const float* b1_host, const float* k10_host,
+                              const float* b10_host, uint16_t* out1, uint16_t* base, int clips, int frames_per_clip, int H, int W,
+                              void* stream) {
+    if (!in || !k1_host || !k10_host || !out1 || !base) return fail(PFNL_ERR_INVALID, "NULL argument");
+    const int T = frames_per_clip;
+    if (clips < 1 || (T != 3 && T != 5 && T != 7) || H < 1 || W < 1) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n3 = pfnl::conv3x3_bf16_pack_halfs(), n1 = pfnl::conv1x1_bf16_pack_halfs(T);
+    std::vector<uint16_t> pack(n3 + n1 + 256, 0);
+    pfnl::conv3x3_bf16_pack_weights(k1_host, 64, 0, pack.data());
+    pfnl::conv1x1_bf16_pack_weights(k10_host, T, pack.data() + n3);
+    if (b1_host) std::memcpy(&pack[n3 + n1], b1_host, 64 * sizeof(float));
+    if (b10_host) std::memcpy(&pack[n3 + n1 + 128], b10_host, 64 * sizeof(float));
+    uint16_t* dw = nullptr;
+    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(uint16_t)));
+    hipError_t e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    pfnl::ConvBf16Params q{in, dw, reinterpret_cast<const float*>(dw + n3 + n1), nullptr, nullptr, out1, H, W, clips * T, T, 1,
+                           dw + n3, reinterpret_cast<const float*>(dw + n3 + n1 + 128), base};
+    if (e == hipSuccess) e = pfnl::launch_conv3x3_bf16(q, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dw);
+    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv1+conv10 bf16 op: ") + hipGetErrorString(e));
     return 0;
 }
 

@@ -14,6 +14,11 @@ struct ConvBf16Params {
     const uint16_t* resid;   // [items][H][W][64] bf16, added after the activation           / neither
     uint16_t* out;           // [items][H][W][64] bf16 (may alias resid)
     int H, W, items, add_div, act;
+    // conv1_i + conv10_i in one launch (addend == resid == nullptr): per chain of add_div frames
+    // x_out[clip] = leaky_relu(sum_t W10_t out_t + x_bias)
+    const uint16_t* x_w;     // conv1x1_bf16_pack_weights (add_div frames); nullptr = plain launch
+    const float* x_bias;     // [64]
+    uint16_t* x_out;         // [items/add_div][H][W][64] bf16
 };
 hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s);
 hipError_t launch_conv1x1_bf16(const uint16_t* in, const uint16_t* wpack, const float* bias, uint16_t* out, int items, int T,

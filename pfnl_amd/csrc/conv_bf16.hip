@@ -79,8 +79,14 @@ __device__ long long cb_dbg[256 * 8 * 64];
 #define CB_STAMP() do {} while (0)
 #endif
 
-template <bool FUSE>
+// MODE 0: out = act(conv + bias).  MODE 1 (conv2_i per-frame half): out = act(conv + bias + addend[item / add_div]) + resid.
+// MODE 2 (conv1_i + conv10_i): MODE 0, and per chain of add_div frames x_out = act(sum_t W10_t out_t + x_bias), the 1x1
+// contraction running from the LDS scratch each finished tile passes through anyway (conv10_i costs no launch and
+// no second read of conv1_i's output: -116 MB of 763 MB per block at 1080p).
+template <int MODE>
 __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Params p) {
+    constexpr bool FUSE = MODE == 1;
+    constexpr bool WITH10 = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char cb_smem[];
     unsigned char* const wl = cb_smem + 2 * CB_TILE_BYTES;
     float* const bl = reinterpret_cast<float*>(cb_smem + 2 * CB_TILE_BYTES + CB_W_BYTES);
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
     // are dealt out XCD by XCD (blockIdx & 7 = XCD): the 32 workgroups of an XCD walk a contiguous run of spatial
     // tiles together, so the halo rows two tiles share come from that XCD's L2 instead of HBM a second time
     // (measured before: 1.31x the compulsory reads, and the addend 7x).
-    const int gT = FUSE ? p.add_div : 1;
+    const int gT = (FUSE || WITH10) ? p.add_div : 1;
     const int nchains = per_item * (p.items / gT);
     const int xcd = blockIdx.x & 7, xj = blockIdx.x >> 3, cpx = gridDim.x >> 3;
     const int per_xcd = (nchains + 7) >> 3;
@@ -196,7 +202,8 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
     // the conv1_i / conv2_i launches): reads ~10 TB/s, such writes 1.8 TB/s - against 4 TB/s for the fully coalesced
     // stores of the cast kernel.  So the finished tile (bias, addend, activation, residual applied, rounded to bf16)
     // goes through LDS: every wave drops its pieces into a pixel-major scratch (the OTHER halo buffer, free until the
-    // next halo is committed; 16-byte pieces XOR-swizzled by pixel & 7, conflict-free both ways), and after a
+    // next halo is committed; 16-byte pieces XOR-swizzled by (pixel >> 1) & 7 like the halo tiles, conflict-free for the
+    // writes, the read-back and the 1x1 operand reads of MODE 2), and after a
     // barrier the workgroup stores it as whole 128-byte lines, 8 pixels per wave instruction.
     int ex0p = 0, ey0p = 0;                                         // origin of the tile awaiting its epilogue
     auto epilogue_unit = [&](unsigned char* scratch, int n, int h) __attribute__((always_inline)) {   // bias, addend, leaky_relu, residual, bf16
@@ -218,14 +225,14 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
         const u32x2 lo = f32x4_to_bf16(v[0]), hi = f32x4_to_bf16(v[1]);
         const int j = lane & 31;
         const int c = 4 * mt + 2 * (lane >> 5) + h;                 // piece of the pixel's line
-        *reinterpret_cast<u32x4*>(scratch + ((2 * rp + n) * 32 + j) * 128 + ((c ^ (j & 7)) << 4)) = u32x4{lo.x, lo.y, hi.x, hi.y};
+        *reinterpret_cast<u32x4*>(scratch + ((2 * rp + n) * 32 + j) * 128 + ((c ^ ((j >> 1) & 7)) << 4)) = u32x4{lo.x, lo.y, hi.x, hi.y};
     };
     auto store_piece = [&](const unsigned char* scratch, int k) __attribute__((always_inline)) {   // 2048 pieces, 4 per thread, whole lines per instruction
         const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)eitemp * H * W * 64, 0, item_bytes, 0x00020000);
         const int id = k * CB_THREADS + tid;
         const int pp = id >> 3, c = id & 7;
         const int sx = ex0p + (pp & 31), sy = ey0p + (pp >> 5);
-        const u32x4 o = *reinterpret_cast<const u32x4*>(scratch + pp * 128 + ((c ^ (pp & 7)) << 4));
+        const u32x4 o = *reinterpret_cast<const u32x4*>(scratch + pp * 128 + ((c ^ ((pp >> 1) & 7)) << 4));
 #ifdef CB_X_NOSTORE   /* timing experiments only */
         if (o.x == 0x12345678u)
 #endif
@@ -239,6 +246,54 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
         if (with_addend)                                            // (same pixels for every frame of the chain)
             radd[n][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, eoff[n], (ech + 8 * h) * 2, 0));
         rres[n][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, eoff[n], (ech + 8 * h) * 2, 0));
+    };
+
+    // MODE 2: the 1x1 over the chain's frames.  Wave (rp, mt) accumulates rows 2rp, 2rp+1 x output channels 32mt..+31
+    // of `base`; per finished frame tile: 4 k-steps x 2 rows = 8 MFMAs, B = the tile in the scratch, A = W10 of that
+    // frame from L2 (16 bytes per lane and k-step, requested a few groups ahead).
+    f32x16 bacc[2];
+    u32x4 xw[4];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bacc[n][r] = 0.f;
+    const __amdgpu_buffer_rsrc_t rsXW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x_w), 0, WITH10 ? gT * 8192 : 0, 0x00020000);
+    auto x_request = [&](int ks) __attribute__((always_inline)) {  // W10[frame of the pending tile][k-step ks][channel tile mt]
+        xw[ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsXW, lane * 16 + mt * 1024, ((eitemp % gT) * 4 + ks) * 2048, 0));
+    };
+    auto x_step = [&](const unsigned char* scratch, int ks) __attribute__((always_inline)) {
+        const int j = lane & 31;
+        const unsigned char* bp = scratch + ((2 * rp) * 32 + j) * 128 + (((2 * ks + (lane >> 5)) ^ ((j >> 1) & 7)) << 4);
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            bacc[n] = mfma_bf16(__builtin_bit_cast(bf16x8, xw[ks]), *reinterpret_cast<const bf16x8*>(bp + n * 32 * 128), bacc[n]);
+    };
+    auto x_epilogue = [&]() __attribute__((always_inline)) {        // chain complete: bias, leaky_relu, bf16, store; clear
+        const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(p.x_out + (size_t)(eitemp / gT) * H * W * 64, 0, item_bytes, 0x00020000);
+        const int sx = ex0p + (lane & 31);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int sy = ey0p + 2 * rp + n;
+            const int off = (sx < W && sy < H) ? ((sy * W + sx) * 64 + ech) * 2 : 0x7fffffff;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 v[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int r0 = 8 * h + 4 * q;
+                    v[q] = f32x4{bacc[n][r0], bacc[n][r0 + 1], bacc[n][r0 + 2], bacc[n][r0 + 3]} +
+                           *reinterpret_cast<const f32x4*>(p.x_bias + ech + r0);
+                    v[q].x = lrelu(v[q].x);
+                    v[q].y = lrelu(v[q].y);
+                    v[q].z = lrelu(v[q].z);
+                    v[q].w = lrelu(v[q].w);
+                }
+                const u32x2 lo = f32x4_to_bf16(v[0]), hi = f32x4_to_bf16(v[1]);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, rsX, off, 16 * h, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bacc[n][r] = 0.f;
+        }
     };
 
     CB_REQUEST(0);
@@ -293,13 +348,16 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
             if constexpr (g < 4) {
                 if (pending) epilogue_unit(other, g >> 1, g & 1);
                 if (FUSE) fuse_request(chain_head, g >> 1, g & 1);
+                if (WITH10 && pending) x_request(g);
             }
             if constexpr (g == 4) __syncthreads();
             if constexpr (g >= 4 && g < 8) {
                 if (pending) store_piece(other, g - 4);
+                if (WITH10 && pending) x_step(other, g - 4);
             }
             if constexpr (g == 8) {
                 __syncthreads();                                       // the scratch has been read
+                if (WITH10 && pending && eitemp % gT == gT - 1) x_epilogue();   // the pending tile closed its chain
                 CB_STAMP();
 #pragma unroll
                 for (int k = 0; k < CB_ITERS; ++k) asm volatile("" : "+v"(spk[k]));   // opaque: nothing derived from it is hoisted into registers
@@ -351,10 +409,17 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
     }
     // the last tile (its addend / residual pieces were requested in its own iteration); any buffer is free now
 #pragma unroll
-    for (int k = 0; k < 4; ++k) epilogue_unit(cb_smem, k >> 1, k & 1);
+    for (int k = 0; k < 4; ++k) {
+        epilogue_unit(cb_smem, k >> 1, k & 1);
+        if (WITH10) x_request(k);
+    }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) store_piece(cb_smem, k);
+    for (int k = 0; k < 4; ++k) {
+        store_piece(cb_smem, k);
+        if (WITH10) x_step(cb_smem, k);
+    }
+    if (WITH10) x_epilogue();                                       // (a workgroup's units are whole chains)
 #undef CB_COMMIT
 #undef CB_REQUEST
 #undef CB_UNIT
@@ -372,24 +437,20 @@ hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s) {
         ncu = prop.multiProcessorCount;
     }
     const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;                    // whole XCDs; surplus workgroups exit at once
-    static bool attr[2] = {false, false};
-    if (p.addend) {
-        if (!attr[1]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16_kernel<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS_BYTES);
-            if (e != hipSuccess) return e;
-            attr[1] = true;
-        }
-        hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, dim3(grid), dim3(CB_THREADS), CB_LDS_BYTES, s, p);
-    } else {
-        if (!attr[0]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16_kernel<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS_BYTES);
-            if (e != hipSuccess) return e;
-            attr[0] = true;
-        }
-        hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, dim3(grid), dim3(CB_THREADS), CB_LDS_BYTES, s, p);
+    const bool with10 = p.x_out != nullptr;
+    if (with10 && (p.addend || !p.x_w || !p.x_bias || p.add_div < 1 || p.add_div > 7 || p.items % p.add_div)) return hipErrorInvalidValue;
+    const int mode = p.addend ? 1 : (with10 ? 2 : 0);
+    static bool attr[3] = {false, false, false};
+    const void* fn = mode == 1 ? reinterpret_cast<const void*>(conv3x3_bf16_kernel<1>)
+                               : (mode == 2 ? reinterpret_cast<const void*>(conv3x3_bf16_kernel<2>) : reinterpret_cast<const void*>(conv3x3_bf16_kernel<0>));
+    if (!attr[mode]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr[mode] = true;
     }
+    if (mode == 1) hipLaunchKernelGGL(conv3x3_bf16_kernel<1>, dim3(grid), dim3(CB_THREADS), CB_LDS_BYTES, s, p);
+    else if (mode == 2) hipLaunchKernelGGL(conv3x3_bf16_kernel<2>, dim3(grid), dim3(CB_THREADS), CB_LDS_BYTES, s, p);
+    else hipLaunchKernelGGL(conv3x3_bf16_kernel<0>, dim3(grid), dim3(CB_THREADS), CB_LDS_BYTES, s, p);
     return hipGetLastError();
 }
 

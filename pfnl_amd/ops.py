@@ -115,6 +115,25 @@ def conv3x3_bf16(x, kernel, bias=None, act=True, addend=None, add_div=1, resid=N
     return out
 
 
+def conv1_conv10_bf16(x, k1, b1, k10, b10, frames_per_clip):
+    """bf16 trunk: conv1_i + conv10_i in one launch.  x bfloat16 [clips*T, H, W, 64] -> (lrelu(conv3x3(x)+b1) bfloat16,
+    lrelu(conv1x1 over the T outputs + b10) bfloat16 [clips, H, W, 64]).  Reference: model/pfnl.py:66-68."""
+    import torch
+    lib = _capi.load_library()
+    k1h, b1h, k10h, b10h = _host(k1, "k1"), _host(b1, "b1"), _host(k10, "k10"), _host(b10, "b10")
+    F, H, W, c = x.shape
+    T = frames_per_clip
+    if k1h.shape != (3, 3, 64, 64) or k10h.shape != (1, 1, 64 * T, 64) or c != 64 or F % T:
+        raise ValueError("conv1_conv10_bf16: geometry mismatch")
+    out1 = torch.empty_like(x)
+    base = torch.empty((F // T, H, W, 64), dtype=torch.bfloat16, device=x.device)
+    _capi.check(lib.pfnl_op_conv1_conv10_bf16(
+        _req16(x, "x"), k1h.ctypes.data_as(C.c_void_p), b1h.ctypes.data_as(C.c_void_p) if b1h is not None else None,
+        k10h.ctypes.data_as(C.c_void_p), b10h.ctypes.data_as(C.c_void_p) if b10h is not None else None,
+        _req16(out1, "out1"), _req16(base, "base"), F // T, T, H, W, _stream(x)))
+    return out1, base
+
+
 def conv1x1_bf16(x, kernel, bias=None, act=True, frames_per_item=7):
     """bf16 trunk: conv10_i, 1x1 over the concat of `frames_per_item` frames.  x bfloat16 [items*fpi, H, W, 64];
     kernel fp32 HWIO [1,1,64*fpi,64].  Reference: model/pfnl.py:50, :67-68."""

@@ -195,3 +195,24 @@ def test_bf16_kernels_random_geometries_short():
     import stress_bf16
     n, worst = stress_bf16.run(seed=7, seconds=8.0, max_iters=60)
     assert n >= 5 and worst < 2.0 ** -7 + 1e-3
+
+
+@pytest.mark.parametrize("clips,T,H,W", [(2, 7, 20, 36), (1, 5, 32, 64), (3, 3, 17, 33), (1, 7, 8, 32), (2, 7, 70, 100)])
+def test_conv1_conv10_bf16_one_launch(clips, T, H, W):
+    """MODE 2 of the bf16 3x3 kernel: conv1_i's output identical (bit for bit) to the plain launch, `base` within one
+    bf16 ulp of the 1x1 computed from that (already rounded) output with fp32 accumulation."""
+    g = torch.Generator().manual_seed(clips * 100 + T + H)
+    Fr = clips * T
+    x = r16(torch.randn(Fr, H, W, 64, generator=g))
+    k1 = (torch.randn(3, 3, 64, 64, generator=g) * 0.05).numpy()
+    b1 = (torch.randn(64, generator=g) * 0.1).numpy()
+    k10 = (torch.randn(1, 1, 64 * T, 64, generator=g) * 0.05).numpy()
+    b10 = (torch.randn(64, generator=g) * 0.1).numpy()
+    xb = x.to(torch.bfloat16).cuda()
+    out1, base = ops.conv1_conv10_bf16(xb, k1, b1, k10, b10, T)
+    ref1 = ops.conv3x3_bf16(xb, k1, b1, act=True)
+    assert torch.equal(out1, ref1)
+    o = out1.float().cpu()
+    cat = o.reshape(clips, T, H, W, 64).permute(0, 2, 3, 1, 4).reshape(clips, H, W, T * 64)
+    close_bf16(base, F.leaky_relu(cat @ r16(torch.from_numpy(k10[0, 0])) + torch.from_numpy(b10), 0.2))
+    assert torch.equal(base, ops.conv1_conv10_bf16(xb, k1, b1, k10, b10, T)[1])
