@@ -216,8 +216,13 @@ def main():
         launches_per_step = 3 * geom.num_block
         bytes_per_launch = P * 128.0 * (5 * F + 3 * B_PER_GPU) / 3.0
         gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_bf16.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic = tj.get("hbm_bytes_per_launch_avg", {}).get(args.workload)
         roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
-                "traffic": None, "kernel": "conv3x3_bf16_kernel<*> (direct 3x3 64->64, bf16 MFMA, fp32 accumulation, persistent)",
+                "traffic": traffic, "kernel": "conv3x3_bf16_kernel<*> (direct 3x3 64->64, bf16 MFMA, fp32 accumulation, persistent)",
                 "avg_launch_ms": round(avg_ms, 4), "launches_timed": k["launches"], "launches_per_step": launches_per_step,
                 "mbytes_per_launch": round(bytes_per_launch / 1e6, 2),
                 "mfma_tflops": round(flops3 / launches_per_step / (avg_ms * 1e-3) / 1e12, 1), "mfma_peak_bf16_tflops": 2500.0}
