@@ -101,6 +101,11 @@ class VSR(object):
                 self._weights = synthetic_weights(self.geometry(), seed=0)
             eng = PFNLEngine(self.geometry(), device=self.device)
             eng.load_weights(self._weights)
+            # build-side knob (the reference has none): PFNL_PRECISION=bf16 runs main.py unchanged on the bf16 path of
+            # BASELINE.json configs[3]; default = the reference's fp32 arithmetic
+            prec = getattr(self, "precision", None) or os.environ.get("PFNL_PRECISION", "fp32")
+            if prec != "fp32":
+                eng.set_option("precision", prec)
             self._engine = eng
         return self._engine
 

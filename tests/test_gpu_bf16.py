@@ -216,3 +216,28 @@ def test_conv1_conv10_bf16_one_launch(clips, T, H, W):
     cat = o.reshape(clips, T, H, W, 64).permute(0, 2, 3, 1, 4).reshape(clips, H, W, T * 64)
     close_bf16(base, F.leaky_relu(cat @ r16(torch.from_numpy(k10[0, 0])) + torch.from_numpy(b10), 0.2))
     assert torch.equal(base, ops.conv1_conv10_bf16(xb, k1, b1, k10, b10, T)[1])
+
+
+def test_dropin_class_on_the_bf16_path(tmp_path):
+    """PFNL().test_video_lr with `precision = "bf16"` (or PFNL_PRECISION=bf16) on a tiny PNG sequence: uint8 frames within
+    one grey level of the fp32 golden frames (the harness clips and rounds, reference model/pfnl.py:255-257)."""
+    from PIL import Image
+    from conftest import load_golden
+    from model.pfnl import PFNL
+    gd = load_golden("harness_5x16x24_nb1")
+    seq = tmp_path / "seq0"
+    (seq / "blur4").mkdir(parents=True)
+    for i, im in enumerate(gd["lr_u8"]):
+        Image.fromarray(im).save(seq / "blur4" / f"{i:04d}.png")
+    m = PFNL()
+    m.num_block = 1
+    m.precision = "bf16"
+    m.set_weights(synth.synthetic_weights(PFNLGeometry(num_block=1), seed=0))
+    m.save_dir = str(tmp_path / "ckpt")
+    m.save(None, m.save_dir, 1000)
+    m.test_video_lr(str(seq), name="result", part=2)
+    outs = sorted((seq / "result").glob("*.png"))
+    assert [p.name for p in outs] == [f"{i:04d}.png" for i in range(5)]
+    got = np.stack([np.asarray(Image.open(p)) for p in outs])
+    diff = np.abs(got.astype(np.int32) - gd["sr_u8"].astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.05
