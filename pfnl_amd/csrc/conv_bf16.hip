@@ -440,7 +440,10 @@ hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s) {
     const bool with10 = p.x_out != nullptr;
     if (with10 && (p.addend || !p.x_w || !p.x_bias || p.add_div < 1 || p.add_div > 7 || p.items % p.add_div)) return hipErrorInvalidValue;
     const int mode = p.addend ? 1 : (with10 ? 2 : 0);
-    static bool attr[3] = {false, false, false};
+    static bool attr_dev[64][3] = {};                               // the attribute is per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    bool* const attr = attr_dev[dev];
     const void* fn = mode == 1 ? reinterpret_cast<const void*>(conv3x3_bf16_kernel<1>)
                                : (mode == 2 ? reinterpret_cast<const void*>(conv3x3_bf16_kernel<2>) : reinterpret_cast<const void*>(conv3x3_bf16_kernel<0>));
     if (!attr[mode]) {

@@ -192,6 +192,72 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
 #define WS_STEP2(s_)                       \
     WS_STEP(s_, vA, vB, vC, vD);           \
     WS_STEP((s_) + 1, vC, vD, vA, vB)
+        // column transform over nu (At = [[1,1,1,0],[0,1,-1,-1]]) of registers 4q..4q+3 (= channels 32g + 8q + 4kh + 0..3
+        // of tile xl) of N-tile g -> slab[xi][j][tile][cout], 16 bytes per store
+#define WS_DUMP(g_, q_)                                                                          \
+    do {                                                                                         \
+        const f32x4 m0_ = {acc[4 * (g_)][4 * (q_)], acc[4 * (g_)][4 * (q_) + 1], acc[4 * (g_)][4 * (q_) + 2], acc[4 * (g_)][4 * (q_) + 3]}; \
+        const f32x4 m1_ = {acc[4 * (g_) + 1][4 * (q_)], acc[4 * (g_) + 1][4 * (q_) + 1], acc[4 * (g_) + 1][4 * (q_) + 2], acc[4 * (g_) + 1][4 * (q_) + 3]}; \
+        const f32x4 m2_ = {acc[4 * (g_) + 2][4 * (q_)], acc[4 * (g_) + 2][4 * (q_) + 1], acc[4 * (g_) + 2][4 * (q_) + 2], acc[4 * (g_) + 2][4 * (q_) + 3]}; \
+        const f32x4 m3_ = {acc[4 * (g_) + 3][4 * (q_)], acc[4 * (g_) + 3][4 * (q_) + 1], acc[4 * (g_) + 3][4 * (q_) + 2], acc[4 * (g_) + 3][4 * (q_) + 3]}; \
+        float* const d_ = slab + xl * WS_ES + (g_) * 32 + 8 * (q_) + 4 * kh;                      \
+        *reinterpret_cast<f32x4*>(d_) = m0_ + m1_ + m2_;                                          \
+        *reinterpret_cast<f32x4*>(d_ + 32 * WS_ES) = m1_ - (m2_ + m3_);                           \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    } while (0)
+        // K-step 31 of a tile: block B (N-tile 1) split into its MFMAs, N-tile 0's finished accumulators transformed
+        // and stored between them
+#define WS_STEP31_D0(c03_, c12_, n03_, n12_)                                                     \
+    do {                                                                                         \
+        constexpr int d_ = 31 % WS_UD;                                                           \
+        const f32x4 b0_ = ring0[d_], b1_ = ring1[d_];                                            \
+        ring0[d_] = WS_USTEP(31 + WS_UD, 0);                                                     \
+        ring1[d_] = WS_USTEP(31 + WS_UD, 1);                                                     \
+        f32x2 x01_, y01_, x23_, y23_;                                                            \
+        wq_kstep_a<0, false>(acc[0], acc[1], acc[2], acc[3], (c03_).x, (c12_).x, (c12_).y, (c03_).y, b0_, \
+                             x01_, y01_, x23_, y23_, pa, pb);       /* next step = 0 of the next tile: buffer 0, kk 0 */ \
+        wq_mfma1<false>(acc[4], b1_.x, (c03_).x);                                                \
+        wq_results_ready(acc[0], acc[1], acc[2], acc[3]);                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        WS_DUMP(0, 0);                                                                           \
+        wq_mfma1<false>(acc[5], b1_.y, (c12_).x);                                                \
+        wq_b_transform(x01_, y01_, x23_, y23_, n03_, n12_, sg2);                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        WS_DUMP(0, 1);                                                                           \
+        wq_mfma1<false>(acc[6], b1_.z, (c12_).y);                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        WS_DUMP(0, 2);                                                                           \
+        wq_mfma1<false>(acc[7], b1_.w, (c03_).y);                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        WS_DUMP(0, 3);                                                                           \
+    } while (0)
+        // K-step 0 of the NEXT tile (C = 0): block A (N-tile 0) split, the previous tile's N-tile 1 transformed and
+        // stored between its MFMAs; then block B as usual
+#define WS_STEP0_D1(c03_, c12_, n03_, n12_)                                                      \
+    do {                                                                                         \
+        constexpr int d_ = 0;                                                                    \
+        const f32x4 b0_ = ring0[d_], b1_ = ring1[d_];                                            \
+        ring0[d_] = WS_USTEP(WS_UD, 0);                                                          \
+        ring1[d_] = WS_USTEP(WS_UD, 1);                                                          \
+        constexpr int off_ = (2 * 1 * WP_PS) * 4;                   /* next step = 1: buffer 0, kk 1 */ \
+        f32x2 x01_, y01_, x23_, y23_;                                                            \
+        wq_a_head<off_, true>(acc[0], b0_.x, (c03_).x, x01_, y01_, x23_, y23_, pa, pb);          \
+        wq_results_ready(acc[4], acc[5], acc[6], acc[7]);                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        WS_DUMP(1, 0);                                                                           \
+        wq_mfma1<true>(acc[1], b0_.y, (c12_).x);                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        WS_DUMP(1, 1);                                                                           \
+        wq_mfma1<true>(acc[2], b0_.z, (c12_).y);                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        WS_DUMP(1, 2);                                                                           \
+        wq_mfma1<true>(acc[3], b0_.w, (c03_).y);                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        WS_DUMP(1, 3);                                                                           \
+        wq_kstep_b<true>(acc[4], acc[5], acc[6], acc[7], (c03_).x, (c12_).x, (c12_).y, (c03_).y, b1_, x01_, \
+                         y01_, x23_, y23_, n03_, n12_, sg2);                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    } while (0)
 
         __syncthreads();                                            // chunk 0 of the first tile is in LDS
         {   // V of the very first K-step (every later one comes out of the asm step before it)
@@ -213,7 +279,9 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
                         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
                 }
                 WS_STEPX(0, false, vA, vB, vC, vD);
-            } else {                                                // first K-step of a tile: C = 0
+            } else if (i > 0) {                                     // first K-step of a tile: C = 0; the previous tile's N-tile 1 leaves
+                WS_STEP0_D1(vA, vB, vC, vD);
+            } else {
                 WS_STEPX(0, true, vA, vB, vC, vD);
             }
             WS_STEP(1, vC, vD, vA, vB);
@@ -247,25 +315,20 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
             WS_STAMP();
             __syncthreads();                                        // next tile's chunk 0 ready
             WS_STAMP();
-            WS_STEP(31, vC, vD, vA, vB);
-            WS_STAMP();
-            // column transform over nu (At = [[1,1,1,0],[0,1,-1,-1]]) -> slab[xi][j][tile][cout]
-            asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");       // MFMA results of the asm blocks -> VALU reads
-            if (!ACCUM || mu == gT - 1)
+            if (ACCUM) {
+                WS_STEP(31, vC, vD, vA, vB);
+                WS_STAMP();
+                // MODE 3: only a clip's last frame leaves the accumulators; both N-tiles after the last MFMA
+                asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA results of the asm blocks -> VALU reads
+                if (mu == gT - 1) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+                    for (int g = 0; g < 2; ++g)
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {               // register pairs: packed-f32 adds
-                    const f32x2 m0 = {acc[4 * g][r], acc[4 * g][r + 1]}, m1 = {acc[4 * g + 1][r], acc[4 * g + 1][r + 1]};
-                    const f32x2 m2 = {acc[4 * g + 2][r], acc[4 * g + 2][r + 1]}, m3 = {acc[4 * g + 3][r], acc[4 * g + 3][r + 1]};
-                    const f32x2 s0 = m0 + m1 + m2;
-                    const f32x2 s1 = m1 - (m2 + m3);
-                    const int e0 = drow(r, lane), e1 = drow(r + 1, lane);
-                    slab[(0 * 32 + e0) * WS_ES + g * 32 + xl] = s0.x;
-                    slab[(1 * 32 + e0) * WS_ES + g * 32 + xl] = s1.x;
-                    slab[(0 * 32 + e1) * WS_ES + g * 32 + xl] = s0.y;
-                    slab[(1 * 32 + e1) * WS_ES + g * 32 + xl] = s1.y;
+                        for (int q = 0; q < 4; ++q) WS_DUMP(g, q);
                 }
+            } else {
+                WS_STEP31_D0(vC, vD, vA, vB);                       // N-tile 0 leaves here, N-tile 1 in the next tile's K-step 0
+                WS_STAMP();
             }
             WS_STAMP();
             if (GROUPED) {                                          // weight pack of the next unit / the one after
@@ -279,7 +342,16 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
                 uoff_nxt = (mu == gT - 1 ? 0 : mu + 1) * ustride;
             }
         }
+        if (!ACCUM) {                                               // the last tile's N-tile 1
+            wq_results_ready(acc[4], acc[5], acc[6], acc[7]);
+            asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) WS_DUMP(1, q);
+        }
         __syncthreads();                                            // the last tile's slab is complete
+#undef WS_STEP0_D1
+#undef WS_STEP31_D0
+#undef WS_DUMP
 #undef WS_STEP2
 #undef WS_STEP
 #undef WS_USTEP

@@ -175,17 +175,20 @@ __device__ __forceinline__ void wp_kstep_asm_zero(f32x16& a0, f32x16& a1, f32x16
 }
 
 // ---- 8-MFMA K-step (both 32-channel N-tiles per wave): two asm blocks, 4 LDS + 4 packed VALU per 8 MFMAs
+// Operand roles: srcA = U (rows = the N-tile's 32 output channels), srcB = V (columns = the wave's 32 Winograd tiles),
+// so that an accumulator lane owns ONE tile and 4 consecutive registers are 4 consecutive channels: the column
+// transform's results go to the slab as 16-byte stores (the per-lane data of both operands is the same either way).
 // block A: N-tile 0's four MFMAs + the raw reads of the NEXT step;  block B: N-tile 1's four MFMAs with
 // the transform of the next step's V between them.  ZERO: first step of a tile, C = 0.
 #define PFNL_WQ_A(C0, C1, C2, C3)                                                                       \
-    asm volatile("v_mfma_f32_32x32x2_f32 %[a0], %[c0], %[bx], " C0 "\n\t"                               \
+    asm volatile("v_mfma_f32_32x32x2_f32 %[a0], %[bx], %[c0], " C0 "\n\t"                               \
                  "ds_read_b64 %[x01], %[pa] offset:%c[o0]\n\t"                                          \
                  "ds_read_b64 %[y01], %[pb] offset:%c[o0]\n\t"                                          \
                  "ds_read_b64 %[x23], %[pa] offset:%c[o2]\n\t"                                          \
                  "ds_read_b64 %[y23], %[pb] offset:%c[o2]\n\t"                                          \
-                 "v_mfma_f32_32x32x2_f32 %[a1], %[c1], %[by], " C1 "\n\t"                               \
-                 "v_mfma_f32_32x32x2_f32 %[a2], %[c2], %[bz], " C2 "\n\t"                               \
-                 "v_mfma_f32_32x32x2_f32 %[a3], %[c3], %[bw], " C3 "\n\t"
+                 "v_mfma_f32_32x32x2_f32 %[a1], %[by], %[c1], " C1 "\n\t"                               \
+                 "v_mfma_f32_32x32x2_f32 %[a2], %[bz], %[c2], " C2 "\n\t"                               \
+                 "v_mfma_f32_32x32x2_f32 %[a3], %[bw], %[c3], " C3 "\n\t"
 #define PFNL_WQ_A_IN                                                                                    \
     [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [bx] "v"(bc.x), [by] "v"(bc.y), [bz] "v"(bc.z), \
         [bw] "v"(bc.w), [pa] "v"(pa), [pb] "v"(pb), [o0] "i"(OFF), [o2] "i"(OFF + 8)
@@ -208,15 +211,15 @@ __device__ __forceinline__ void wq_kstep_a(f32x16& a0, f32x16& a1, f32x16& a2, f
     }
 }
 #define PFNL_WQ_B(C0, C1, C2, C3)                                                                       \
-    asm volatile("v_mfma_f32_32x32x2_f32 %[a0], %[c0], %[bx], " C0 "\n\t"                               \
-                 "v_mfma_f32_32x32x2_f32 %[a1], %[c1], %[by], " C1 "\n\t"                               \
+    asm volatile("v_mfma_f32_32x32x2_f32 %[a0], %[bx], %[c0], " C0 "\n\t"                               \
+                 "v_mfma_f32_32x32x2_f32 %[a1], %[by], %[c1], " C1 "\n\t"                               \
                  "s_waitcnt lgkmcnt(0)\n\t"                                                             \
                  "v_pk_fma_f32 %[x01], %[y01], %[sg], %[x01]\n\t"                                       \
                  "v_pk_fma_f32 %[x23], %[y23], %[sg], %[x23]\n\t"                                       \
                  "v_pk_add_f32 %[n03], %[x01], %[x23] neg_lo:[0,1] neg_hi:[0,1]\n\t"                    \
                  "v_pk_add_f32 %[n12], %[x01], %[x23] op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"    \
-                 "v_mfma_f32_32x32x2_f32 %[a2], %[c2], %[bz], " C2 "\n\t"                               \
-                 "v_mfma_f32_32x32x2_f32 %[a3], %[c3], %[bw], " C3 "\n\t"
+                 "v_mfma_f32_32x32x2_f32 %[a2], %[bz], %[c2], " C2 "\n\t"                               \
+                 "v_mfma_f32_32x32x2_f32 %[a3], %[bw], %[c3], " C3 "\n\t"
 #define PFNL_WQ_B_IN                                                                                    \
     [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [bx] "v"(bc.x), [by] "v"(bc.y), [bz] "v"(bc.z), \
         [bw] "v"(bc.w), [y01] "v"(y01), [y23] "v"(y23), [sg] "v"(sg)
@@ -237,6 +240,56 @@ __device__ __forceinline__ void wq_kstep_b(f32x16& a0, f32x16& a1, f32x16& a2, f
                      : PFNL_WQ_B_IN
                      : "memory");
     }
+}
+
+// ---- pieces of the two blocks above as separate statements, for the two K-steps around a tile boundary: the column
+// transform + slab stores of one N-tile's accumulators are issued between the MFMAs of the OTHER N-tile
+// (conv_wino_ws.hip), instead of after the last MFMA with the matrix pipe idle.
+template <bool ZERO>
+__device__ __forceinline__ void wq_mfma1(f32x16& a, const float u, const float v) {
+    if constexpr (ZERO) asm volatile("v_mfma_f32_32x32x2_f32 %[a], %[u], %[v], 0" : [a] "=&v"(a) : [u] "v"(u), [v] "v"(v) : "memory");
+    else asm volatile("v_mfma_f32_32x32x2_f32 %[a], %[u], %[v], %[a]" : [a] "+v"(a) : [u] "v"(u), [v] "v"(v) : "memory");
+}
+// first MFMA of block A + the 4 raw reads of the next step
+template <int OFF, bool ZERO>
+__device__ __forceinline__ void wq_a_head(f32x16& a0, const float u, const float v, f32x2& x01, f32x2& y01, f32x2& x23, f32x2& y23,
+                                          unsigned pa, unsigned pb) {
+#define PFNL_WQ_AH(C0)                                                          \
+    asm volatile("v_mfma_f32_32x32x2_f32 %[a0], %[u], %[v], " C0 "\n\t"          \
+                 "ds_read_b64 %[x01], %[pa] offset:%c[o0]\n\t"                  \
+                 "ds_read_b64 %[y01], %[pb] offset:%c[o0]\n\t"                  \
+                 "ds_read_b64 %[x23], %[pa] offset:%c[o2]\n\t"                  \
+                 "ds_read_b64 %[y23], %[pb] offset:%c[o2]\n\t"
+    if constexpr (ZERO) {
+        PFNL_WQ_AH("0")
+                     : [a0] "=&v"(a0), [x01] "=&v"(x01), [y01] "=&v"(y01), [x23] "=&v"(x23), [y23] "=&v"(y23)
+                     : [u] "v"(u), [v] "v"(v), [pa] "v"(pa), [pb] "v"(pb), [o0] "i"(OFF), [o2] "i"(OFF + 8)
+                     : "memory");
+    } else {
+        PFNL_WQ_AH("%[a0]")
+                     : [a0] "+v"(a0), [x01] "=&v"(x01), [y01] "=&v"(y01), [x23] "=&v"(x23), [y23] "=&v"(y23)
+                     : [u] "v"(u), [v] "v"(v), [pa] "v"(pa), [pb] "v"(pb), [o0] "i"(OFF), [o2] "i"(OFF + 8)
+                     : "memory");
+    }
+#undef PFNL_WQ_AH
+}
+// the transform of the next step's V that sits between the 2nd and 3rd MFMA of block B
+__device__ __forceinline__ void wq_b_transform(f32x2& x01, const f32x2 y01, f32x2& x23, const f32x2 y23, f32x2& n03, f32x2& n12,
+                                               const f32x2 sg) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 "v_pk_fma_f32 %[x01], %[y01], %[sg], %[x01]\n\t"
+                 "v_pk_fma_f32 %[x23], %[y23], %[sg], %[x23]\n\t"
+                 "v_pk_add_f32 %[n03], %[x01], %[x23] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_add_f32 %[n12], %[x01], %[x23] op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
+                 : [x01] "+v"(x01), [x23] "+v"(x23), [n03] "=&v"(n03), [n12] "=&v"(n12)
+                 : [y01] "v"(y01), [y23] "v"(y23), [sg] "v"(sg)
+                 : "memory");
+}
+// "the four accumulators of an N-tile are complete and may be read by VALU from here on": a few wait states after the
+// MFMA issued just before (which targets the other N-tile), and a data dependence that keeps the compiler from
+// scheduling the reads any earlier
+__device__ __forceinline__ void wq_results_ready(f32x16& a0, f32x16& a1, f32x16& a2, f32x16& a3) {
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)::"memory");
 }
 
 // ---- 8-MFMA K-step split at the ONE place where compiler-issued instructions may land -------------------
