@@ -28,6 +28,12 @@ constexpr int NB_KT = 64;                  // keys per LDS tile
 constexpr int NB_KROW = 208;               // bytes per key row of the K tiles (96 ch * 2 B + 16)
 constexpr int NB_VROW = 144;               // bytes per channel row of the V^T tiles (64 keys * 2 B + 16)
 constexpr int NB_CP = 96;
+constexpr int NB_THREADS = 512;           // 8 waves x 32 queries share every key tile: the K / V^T stream (48 KB per 64 keys) is what
+                                          // bounds this kernel - with 128 queries per workgroup it ran at 6.6 TB/s of L2 -> CU traffic
+                                          // (11 B/clk/CU) and 43 % matrix-pipe use, whatever was done to its instruction schedule
+constexpr int NB_QB = NB_THREADS / 2;     // queries per workgroup
+constexpr int NB_TILE_BYTES = 2 * NB_KT * NB_KROW + 2 * NB_CP * NB_VROW;   // 54 272: K hi, K lo, V^T hi, V^T lo
+constexpr int NB_LDS_BYTES = 2 * NB_TILE_BYTES;                             // double-buffered: one barrier per tile
 
 __device__ __forceinline__ unsigned short bf16_bits(float f) {   // round to nearest even
     const __bf16 b = (__bf16)f;
@@ -62,7 +68,7 @@ __global__ void nl_pack_bf16_kernel(const float* __restrict__ X, uint16_t* __res
 }
 
 template <int C>
-__global__ __launch_bounds__(256, 2) void nl_attn_bf16_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Khi,
+__global__ __launch_bounds__(NB_THREADS, 2) void nl_attn_bf16_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Khi,
                                                               const uint16_t* __restrict__ Klo, const uint16_t* __restrict__ Vthi,
                                                               const uint16_t* __restrict__ Vtlo, float* __restrict__ Xo,
                                                               const float* __restrict__ Wp, const float* __restrict__ bp,
@@ -70,11 +76,7 @@ __global__ __launch_bounds__(256, 2) void nl_attn_bf16_kernel(const float* __res
     constexpr int CT = 3;
     constexpr int CP = (C + 31) / 32 * 32;                          // row stride of X / Xo / Wp (nl_padded_ch)
     static_assert(C < NB_CP && C % 2 == 0, "needs a pad channel inside 96");
-    __shared__ __attribute__((aligned(16))) unsigned char sm[2 * NB_KT * NB_KROW + 2 * NB_CP * NB_VROW];
-    unsigned char* const skh = sm;
-    unsigned char* const skl = sm + NB_KT * NB_KROW;
-    unsigned char* const svh = sm + 2 * NB_KT * NB_KROW;
-    unsigned char* const svl = svh + NB_CP * NB_VROW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];   // two tiles: K hi | K lo | V^T hi | V^T lo
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void nl_attn_bf16_kernel(const float* __res
     const int b = blockIdx.y;
     const float* Xb = X + (size_t)b * N * CP;
     float* Xob = Xo + (size_t)b * N * CP;
-    const int q = blockIdx.x * 128 + wave * 32 + xl;                // this lane's query
+    const int q = blockIdx.x * NB_QB + wave * 32 + xl;              // this lane's query
     const int qc = q < N ? q : N - 1;
 
     // B operand of S^T = K Q^T: this lane's query, channels 16ks + 8kh .. +7, scaled by log2(e), split hi + lo
@@ -110,38 +112,39 @@ __global__ __launch_bounds__(256, 2) void nl_attn_bf16_kernel(const float* __res
         for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
     float m = -INFINITY;
 
-    // staging: 4 x 768 16-byte pieces per 64-key tile, 12 per thread
+    // staging: 4 x 768 16-byte pieces per 64-key tile, 6 per thread (8 slots: the second pass covers pieces 512..767)
     const uint16_t* const Khb = Khi + (size_t)b * N * NB_CP;
     const uint16_t* const Klb = Klo + (size_t)b * N * NB_CP;
     const uint16_t* const Vhb = Vthi + (size_t)b * NB_CP * Npad;
     const uint16_t* const Vlb = Vtlo + (size_t)b * NB_CP * Npad;
-    u32x4 rk[12];
+    constexpr int NI = 2;
+    u32x4 rk[4 * NI];
     auto load_tile = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int id = tid + i * 256;                           // 0..767
+        for (int i = 0; i < NI; ++i) {
+            const int id = min(tid + i * NB_THREADS, 767);          // 0..767 (surplus threads redo the last piece)
             const int key = id / 12, c16 = id - key * 12;
             const bool ok = k0 + key < N;
             const size_t ko = ((size_t)(k0 + (ok ? key : 0)) * NB_CP + c16 * 8);
             rk[i] = ok ? *reinterpret_cast<const u32x4*>(Khb + ko) : u32x4{0, 0, 0, 0};
-            rk[3 + i] = ok ? *reinterpret_cast<const u32x4*>(Klb + ko) : u32x4{0, 0, 0, 0};
+            rk[NI + i] = ok ? *reinterpret_cast<const u32x4*>(Klb + ko) : u32x4{0, 0, 0, 0};
             const int ch = id >> 3, kc = id & 7;                    // V^T: 96 rows x 8 pieces (k0 + 64 <= Npad + 32: rows are padded)
             const bool vok = k0 + kc * 8 < Npad;
             const size_t vo = (size_t)ch * Npad + k0 + (vok ? kc * 8 : 0);
-            rk[6 + i] = vok ? *reinterpret_cast<const u32x4*>(Vhb + vo) : u32x4{0, 0, 0, 0};
-            rk[9 + i] = vok ? *reinterpret_cast<const u32x4*>(Vlb + vo) : u32x4{0, 0, 0, 0};
+            rk[2 * NI + i] = vok ? *reinterpret_cast<const u32x4*>(Vhb + vo) : u32x4{0, 0, 0, 0};
+            rk[3 * NI + i] = vok ? *reinterpret_cast<const u32x4*>(Vlb + vo) : u32x4{0, 0, 0, 0};
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](unsigned char* buf) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int id = tid + i * 256;
+        for (int i = 0; i < NI; ++i) {
+            const int id = min(tid + i * NB_THREADS, 767);
             const int key = id / 12, c16 = id - key * 12;
-            *reinterpret_cast<u32x4*>(skh + key * NB_KROW + c16 * 16) = rk[i];
-            *reinterpret_cast<u32x4*>(skl + key * NB_KROW + c16 * 16) = rk[3 + i];
+            *reinterpret_cast<u32x4*>(buf + key * NB_KROW + c16 * 16) = rk[i];
+            *reinterpret_cast<u32x4*>(buf + NB_KT * NB_KROW + key * NB_KROW + c16 * 16) = rk[NI + i];
             const int ch = id >> 3, kc = id & 7;
-            *reinterpret_cast<u32x4*>(svh + ch * NB_VROW + kc * 16) = rk[6 + i];
-            *reinterpret_cast<u32x4*>(svl + ch * NB_VROW + kc * 16) = rk[9 + i];
+            *reinterpret_cast<u32x4*>(buf + 2 * NB_KT * NB_KROW + ch * NB_VROW + kc * 16) = rk[2 * NI + i];
+            *reinterpret_cast<u32x4*>(buf + 2 * NB_KT * NB_KROW + NB_CP * NB_VROW + ch * NB_VROW + kc * 16) = rk[3 * NI + i];
         }
     };
 
@@ -149,61 +152,109 @@ __global__ __launch_bounds__(256, 2) void nl_attn_bf16_kernel(const float* __res
     const int ksp = gridDim.z, sp = blockIdx.z;
     const int kt0 = (int)((long long)ntiles * sp / ksp), kt1 = (int)((long long)ntiles * (sp + 1) / ksp);
     load_tile(kt0 * NB_KT);
+    store_tile(sm);
+    if (kt0 + 1 < kt1) load_tile((kt0 + 1) * NB_KT);
+    __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
-        if (kt > kt0) __syncthreads();
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < kt1) load_tile((kt + 1) * NB_KT);
+        unsigned char* const cur = sm + ((kt - kt0) & 1) * NB_TILE_BYTES;
+        unsigned char* const nxt = sm + (((kt - kt0) & 1) ^ 1) * NB_TILE_BYTES;
+        const unsigned char* const skh = cur;
+        const unsigned char* const skl = cur + NB_KT * NB_KROW;
+        const unsigned char* const svh = cur + 2 * NB_KT * NB_KROW;
+        const unsigned char* const svl = svh + NB_CP * NB_VROW;
+        // S^T for both 32-key halves of the tile (two independent accumulators), ONE running-max / rescale update for
+        // the 64 keys, then P V: the softmax bookkeeping (max tree, alpha, rescale test) is paid once per 64 keys
+        const int kbase = kt * NB_KT;
+        f32x16 st[2];
 #pragma unroll
-        for (int sub = 0; sub < NB_KT / 32; ++sub) {
-            const int kbase = kt * NB_KT + sub * 32;
-            if (kbase >= N) break;                                  // wave-uniform
-            f32x16 st;
+        for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[r] = 0.f;
-            const unsigned char* const kah = skh + (sub * 32 + xl) * NB_KROW + kh * 16;
-            const unsigned char* const kal = skl + (sub * 32 + xl) * NB_KROW + kh * 16;
+            for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
+        // operands one step ahead of the MFMAs that use them (left to itself the compiler issues each ds_read right in
+        // front of its MFMA, and the matrix pipe waits out the LDS latency 60 times per tile): ob[step & 1] holds
+        // K hi/lo of both halves for S^T step ks, then V^T hi/lo of the 3 channel tiles for P V step j = (half, t)
+        bf16x8 ob[2][6];
+        const unsigned char* const kah = skh + xl * NB_KROW + kh * 16;
+        const unsigned char* const kal = skl + xl * NB_KROW + kh * 16;
+        const unsigned char* const vah = svh + xl * NB_VROW + kh * 16;
+        const unsigned char* const val = svl + xl * NB_VROW + kh * 16;
+#define NB_LOAD_QK(ks_, d_)                                                                                     \
+    do {                                                                                                        \
+        ob[d_][0] = *reinterpret_cast<const bf16x8*>(kah + (ks_) * 32);                                         \
+        ob[d_][1] = *reinterpret_cast<const bf16x8*>(kah + 32 * NB_KROW + (ks_) * 32);                          \
+        ob[d_][2] = *reinterpret_cast<const bf16x8*>(kal + (ks_) * 32);                                         \
+        ob[d_][3] = *reinterpret_cast<const bf16x8*>(kal + 32 * NB_KROW + (ks_) * 32);                          \
+    } while (0)
+#define NB_LOAD_PV(j_, d_)                                                                                      \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_) {                                                  \
+            ob[d_][ct_] = *reinterpret_cast<const bf16x8*>(vah + ct_ * 32 * NB_VROW + ((j_) >> 1) * 64 + ((j_) & 1) * 32);     \
+            ob[d_][3 + ct_] = *reinterpret_cast<const bf16x8*>(val + ct_ * 32 * NB_VROW + ((j_) >> 1) * 64 + ((j_) & 1) * 32); \
+        }                                                                                                       \
+    } while (0)
+        NB_LOAD_QK(0, 0);
 #pragma unroll
-            for (int ks = 0; ks < 6; ++ks) {
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(kah + ks * 32);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(kal + ks * 32);
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[ks], st, 0, 0, 0);
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[ks], st, 0, 0, 0);
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[ks], st, 0, 0, 0);
-            }
-            if (kbase + 32 > N) {                                   // wave-uniform: only the last, partial key block
+        for (int ks = 0; ks < 6; ++ks) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks < 5) NB_LOAD_QK(ks + 1, (ks + 1) & 1);
+            else NB_LOAD_PV(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const int d = ks & 1;                                   // the two halves alternate: no MFMA waits for its predecessor
+            st[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ob[d][0], qh[ks], st[0], 0, 0, 0);
+            st[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ob[d][1], qh[ks], st[1], 0, 0, 0);
+            st[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ob[d][0], ql[ks], st[0], 0, 0, 0);
+            st[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ob[d][1], ql[ks], st[1], 0, 0, 0);
+            st[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ob[d][2], qh[ks], st[0], 0, 0, 0);
+            st[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ob[d][3], qh[ks], st[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < kt1) {                                         // next tile (requested a tile ago) -> the other buffer; the one after requested
+            store_tile(nxt);
+            if (kt + 2 < kt1) load_tile((kt + 2) * NB_KT);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kbase + NB_KT > N) {                                    // wave-uniform: only the last, partial key tile
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (kbase + drow(r, lane) >= N) st[r] = -INFINITY;
-            }
-            float tmax = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
-#pragma unroll
-            for (int r = 4; r < 16; r += 4) tmax = fmaxf(tmax, fmaxf(fmaxf(st[r], st[r + 1]), fmaxf(st[r + 2], st[r + 3])));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            const float mn = fmaxf(m, tmax);
-            const float alpha = __builtin_amdgcn_exp2f(m - mn);
-            bf16x8 pt[2];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) pt[r >> 3][r & 7] = (__bf16)__builtin_amdgcn_exp2f(st[r] - mn);
-            m = mn;
-            if (!__all(alpha == 1.0f)) {
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
-            }
-            // O^T[ch][query] += V^T[ch][keys] P^T[keys][query], keys in the accumulator's own order
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const unsigned char* const vah = svh + (ct * 32 + xl) * NB_VROW + sub * 64 + kh * 16;
-                const unsigned char* const val = svl + (ct * 32 + xl) * NB_VROW + sub * 64 + kh * 16;
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(vah + t * 32), pt[t], o[ct], 0, 0, 0);
-                    o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(val + t * 32), pt[t], o[ct], 0, 0, 0);
-                }
-            }
+                    if (kbase + sub * 32 + drow(r, lane) >= N) st[sub][r] = -INFINITY;
         }
+        float tmax = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[1][0], st[1][1]));
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) tmax = fmaxf(tmax, fmaxf(fmaxf(st[0][r], st[0][r + 1]), fmaxf(st[1][r], st[1][r + 1])));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float mn = fmaxf(m, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);         // m = -inf on the first tile -> 0
+        bf16x8 pt[2][2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pt[sub][r >> 3][r & 7] = (__bf16)__builtin_amdgcn_exp2f(st[sub][r] - mn);
+        m = mn;
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+        }
+        // O^T[ch][query] += V^T[ch][keys] P^T[keys][query], keys in the accumulator's own order; channel tile innermost
+        // (consecutive MFMAs go to different accumulators)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (j < 3) NB_LOAD_PV(j + 1, (j + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int d = j & 1;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ob[d][ct], pt[j >> 1][j & 1], o[ct], 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ob[d][3 + ct], pt[j >> 1][j & 1], o[ct], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#undef NB_LOAD_PV
+#undef NB_LOAD_QK
+        __syncthreads();                                            // this tile's buffer is free, the next tile's is complete
     }
 
     float l = o[LCT][LR];
@@ -276,16 +327,42 @@ hipError_t launch_nl_attn_bf16(const float* X, float* Xo, const float* Wp, const
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    const int ks = nl_key_splits(B, N);
+    // key splits: this kernel runs 1 workgroup per CU (LDS), so the grid should fill a whole number of 256-workgroup
+    // rounds: time ~ ceil(query blocks * B * ks / 256) / ks.  (1080p: 127 blocks -> ks = 2 is one full round.)  Bounded
+    // by the fp32 kernel's choice, which sized the partial-result buffer.
+    const int ks_max = nl_key_splits(B, N);
+    int ks = 1;
+    {
+        const long long qb = (long long)((N + NB_QB - 1) / NB_QB) * B;
+        double best = 1e30;
+        for (int k = 1; k <= ks_max; ++k) {
+            const double t = (double)((qb * k + 255) / 256) / k;
+            if (t < best - 1e-9) {
+                best = t;
+                ks = k;
+            }
+        }
+    }
     if (ks > 1 && !partial) return hipErrorInvalidValue;
     float* Zp = partial;
     float* ML = partial ? partial + (size_t)B * ks * N * CP : nullptr;
-    dim3 grid((N + 127) / 128, B, ks);
-    dim3 block(256);
+    dim3 grid((N + NB_QB - 1) / NB_QB, B, ks);
+    dim3 block(NB_THREADS);
+    static bool attr_dev[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_dev[dev]) {
+        for (const void* fn : {reinterpret_cast<const void*>(nl_attn_bf16_kernel<84>), reinterpret_cast<const void*>(nl_attn_bf16_kernel<60>),
+                               reinterpret_cast<const void*>(nl_attn_bf16_kernel<36>)}) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NB_LDS_BYTES);
+            if (e != hipSuccess) return e;
+        }
+        attr_dev[dev] = true;
+    }
     switch (C) {
-        case 84: hipLaunchKernelGGL(nl_attn_bf16_kernel<84>, grid, block, 0, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad); break;
-        case 60: hipLaunchKernelGGL(nl_attn_bf16_kernel<60>, grid, block, 0, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad); break;
-        case 36: hipLaunchKernelGGL(nl_attn_bf16_kernel<36>, grid, block, 0, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad); break;
+        case 84: hipLaunchKernelGGL(nl_attn_bf16_kernel<84>, grid, block, NB_LDS_BYTES, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad); break;
+        case 60: hipLaunchKernelGGL(nl_attn_bf16_kernel<60>, grid, block, NB_LDS_BYTES, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad); break;
+        case 36: hipLaunchKernelGGL(nl_attn_bf16_kernel<36>, grid, block, NB_LDS_BYTES, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad); break;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ks == 1) return e;
