@@ -33,7 +33,7 @@ constexpr int NB_THREADS = 512;           // 8 waves x 32 queries share every ke
                                           // (11 B/clk/CU) and 43 % matrix-pipe use, whatever was done to its instruction schedule
 constexpr int NB_QB = NB_THREADS / 2;     // queries per workgroup
 constexpr int NB_TILE_BYTES = 2 * NB_KT * NB_KROW + 2 * NB_CP * NB_VROW;   // 54 272: K hi, K lo, V^T hi, V^T lo
-constexpr int NB_LDS_BYTES = 2 * NB_TILE_BYTES;                             // double-buffered: one barrier per tile
+constexpr int NB_LDS_BYTES = 3 * NB_TILE_BYTES;                             // 162 816 of 163 840: tiles t-1 (late waves' P V), t, t+1 (being filled)
 
 __device__ __forceinline__ unsigned short bf16_bits(float f) {   // round to nearest even
     const __bf16 b = (__bf16)f;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(NB_THREADS, 2) void nl_attn_bf16_kernel(const float
     constexpr int CT = 3;
     constexpr int CP = (C + 31) / 32 * 32;                          // row stride of X / Xo / Wp (nl_padded_ch)
     static_assert(C < NB_CP && C % 2 == 0, "needs a pad channel inside 96");
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];   // two tiles: K hi | K lo | V^T hi | V^T lo
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];   // three tiles: K hi | K lo | V^T hi | V^T lo
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -155,29 +155,15 @@ __global__ __launch_bounds__(NB_THREADS, 2) void nl_attn_bf16_kernel(const float
     store_tile(sm);
     if (kt0 + 1 < kt1) load_tile((kt0 + 1) * NB_KT);
     __syncthreads();
-    for (int kt = kt0; kt < kt1; ++kt) {
-        unsigned char* const cur = sm + ((kt - kt0) & 1) * NB_TILE_BYTES;
-        unsigned char* const nxt = sm + (((kt - kt0) & 1) ^ 1) * NB_TILE_BYTES;
-        const unsigned char* const skh = cur;
-        const unsigned char* const skl = cur + NB_KT * NB_KROW;
-        const unsigned char* const svh = cur + 2 * NB_KT * NB_KROW;
-        const unsigned char* const svl = svh + NB_CP * NB_VROW;
-        // S^T for both 32-key halves of the tile (two independent accumulators), ONE running-max / rescale update for
-        // the 64 keys, then P V: the softmax bookkeeping (max tree, alpha, rescale test) is paid once per 64 keys
-        const int kbase = kt * NB_KT;
-        f32x16 st[2];
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
-        // operands one step ahead of the MFMAs that use them (left to itself the compiler issues each ds_read right in
-        // front of its MFMA, and the matrix pipe waits out the LDS latency 60 times per tile): ob[step & 1] holds
-        // K hi/lo of both halves for S^T step ks, then V^T hi/lo of the 3 channel tiles for P V step j = (half, t)
-        bf16x8 ob[2][6];
-        const unsigned char* const kah = skh + xl * NB_KROW + kh * 16;
-        const unsigned char* const kal = skl + xl * NB_KROW + kh * 16;
-        const unsigned char* const vah = svh + xl * NB_VROW + kh * 16;
-        const unsigned char* const val = svl + xl * NB_VROW + kh * 16;
+    // The two waves of a SIMD are half a tile apart: waves 0-3 run S^T, softmax, P V of tile t; waves 4-7 run P V of
+    // tile t-1 (its P^T kept in registers, its V^T in the third LDS buffer), then S^T and softmax of tile t.  Next to
+    // a wave that keeps the matrix pipe busy a partner's VALU gets one issue slot per MFMA (tools/ubench) - phase-aligned,
+    // the two waves' softmax blocks (150 VALU, 32 of them quarter-rate v_exp_f32) simply add to the MFMA time; skewed,
+    // and with the softmax at raised priority, one wave's VALU runs under the other's MFMAs.
+    const bool late = wave >= 4;
+    bf16x8 pt[2][2];                                                // P^T of the tile whose P V is still to come
+    bf16x8 ob[2][6];                                                // operands one MFMA step ahead (the compiler alone issues each
+                                                                    // ds_read right in front of its MFMA: 60 LDS latencies per tile)
 #define NB_LOAD_QK(ks_, d_)                                                                                     \
     do {                                                                                                        \
         ob[d_][0] = *reinterpret_cast<const bf16x8*>(kah + (ks_) * 32);                                         \
@@ -185,21 +171,55 @@ __global__ __launch_bounds__(NB_THREADS, 2) void nl_attn_bf16_kernel(const float
         ob[d_][2] = *reinterpret_cast<const bf16x8*>(kal + (ks_) * 32);                                         \
         ob[d_][3] = *reinterpret_cast<const bf16x8*>(kal + 32 * NB_KROW + (ks_) * 32);                          \
     } while (0)
-#define NB_LOAD_PV(j_, d_)                                                                                      \
+#define NB_LOAD_PV(vah_, val_, j_, d_)                                                                          \
     do {                                                                                                        \
         _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_) {                                                  \
-            ob[d_][ct_] = *reinterpret_cast<const bf16x8*>(vah + ct_ * 32 * NB_VROW + ((j_) >> 1) * 64 + ((j_) & 1) * 32);     \
-            ob[d_][3 + ct_] = *reinterpret_cast<const bf16x8*>(val + ct_ * 32 * NB_VROW + ((j_) >> 1) * 64 + ((j_) & 1) * 32); \
+            ob[d_][ct_] = *reinterpret_cast<const bf16x8*>((vah_) + ct_ * 32 * NB_VROW + ((j_) >> 1) * 64 + ((j_) & 1) * 32);     \
+            ob[d_][3 + ct_] = *reinterpret_cast<const bf16x8*>((val_) + ct_ * 32 * NB_VROW + ((j_) >> 1) * 64 + ((j_) & 1) * 32); \
         }                                                                                                       \
     } while (0)
+    // O^T[ch][query] += V^T[ch][keys] P^T[keys][query] for the tile in `buf`, keys in the accumulator's own order;
+    // channel tile innermost (consecutive MFMAs go to different accumulators)
+#define NB_PV(buf_)                                                                                             \
+    do {                                                                                                        \
+        const unsigned char* const vah_ = (buf_) + 2 * NB_KT * NB_KROW + xl * NB_VROW + kh * 16;                \
+        const unsigned char* const val_ = vah_ + NB_CP * NB_VROW;                                               \
+        NB_LOAD_PV(vah_, val_, 0, 0);                                                                           \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+            if (j_ < 3) NB_LOAD_PV(vah_, val_, j_ + 1, (j_ + 1) & 1);                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+            _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_)                                                \
+                o[ct_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ob[j_ & 1][ct_], pt[j_ >> 1][j_ & 1], o[ct_], 0, 0, 0);     \
+            _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_)                                                \
+                o[ct_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ob[j_ & 1][3 + ct_], pt[j_ >> 1][j_ & 1], o[ct_], 0, 0, 0); \
+        }                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+    } while (0)
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int bi = (kt - kt0) % 3;
+        unsigned char* const cur = sm + bi * NB_TILE_BYTES;
+        unsigned char* const nxt = sm + (bi == 2 ? 0 : bi + 1) * NB_TILE_BYTES;   // held tile kt-2: read by nobody any more
+        const unsigned char* const prv = sm + (bi == 0 ? 2 : bi - 1) * NB_TILE_BYTES;
+        if (late && kt > kt0) NB_PV(prv);
+        // S^T for both 32-key halves of the tile (two independent accumulators, alternating: no MFMA waits for its
+        // predecessor), then ONE running-max / rescale update for the 64 keys
+        const int kbase = kt * NB_KT;
+        f32x16 st[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
+        const unsigned char* const kah = cur + xl * NB_KROW + kh * 16;
+        const unsigned char* const kal = kah + NB_KT * NB_KROW;
         NB_LOAD_QK(0, 0);
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) {
             __builtin_amdgcn_sched_barrier(0);
             if (ks < 5) NB_LOAD_QK(ks + 1, (ks + 1) & 1);
-            else NB_LOAD_PV(0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            const int d = ks & 1;                                   // the two halves alternate: no MFMA waits for its predecessor
+            const int d = ks & 1;
             st[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ob[d][0], qh[ks], st[0], 0, 0, 0);
             st[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ob[d][1], qh[ks], st[1], 0, 0, 0);
             st[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ob[d][0], ql[ks], st[0], 0, 0, 0);
@@ -208,11 +228,7 @@ __global__ __launch_bounds__(NB_THREADS, 2) void nl_attn_bf16_kernel(const float
             st[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ob[d][3], qh[ks], st[1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < kt1) {                                         // next tile (requested a tile ago) -> the other buffer; the one after requested
-            store_tile(nxt);
-            if (kt + 2 < kt1) load_tile((kt + 2) * NB_KT);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(2);                              // the softmax VALU goes ahead of the partner wave's MFMAs
         if (kbase + NB_KT > N) {                                    // wave-uniform: only the last, partial key tile
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
@@ -226,7 +242,6 @@ __global__ __launch_bounds__(NB_THREADS, 2) void nl_attn_bf16_kernel(const float
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float mn = fmaxf(m, tmax);
         const float alpha = __builtin_amdgcn_exp2f(m - mn);         // m = -inf on the first tile -> 0
-        bf16x8 pt[2][2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -238,24 +253,19 @@ __global__ __launch_bounds__(NB_THREADS, 2) void nl_attn_bf16_kernel(const float
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
         }
-        // O^T[ch][query] += V^T[ch][keys] P^T[keys][query], keys in the accumulator's own order; channel tile innermost
-        // (consecutive MFMAs go to different accumulators)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (j < 3) NB_LOAD_PV(j + 1, (j + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-            const int d = j & 1;
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ob[d][ct], pt[j >> 1][j & 1], o[ct], 0, 0, 0);
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ob[d][3 + ct], pt[j >> 1][j & 1], o[ct], 0, 0, 0);
-        }
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+        if (!late) NB_PV(cur);
+        if (kt + 1 < kt1) {                                         // next tile (requested a tile ago) -> the third buffer; the tile
+            store_tile(nxt);                                        // after it requested
+            if (kt + 2 < kt1) load_tile((kt + 2) * NB_KT);
+        }
+        __syncthreads();                                            // this tile's S^T operands are free, the next tile is complete
+    }
+    if (late) NB_PV(sm + ((kt1 - 1 - kt0) % 3) * NB_TILE_BYTES);    // the late waves' last P V
+#undef NB_PV
 #undef NB_LOAD_PV
 #undef NB_LOAD_QK
-        __syncthreads();                                            // this tile's buffer is free, the next tile's is complete
-    }
 
     float l = o[LCT][LR];
     {
