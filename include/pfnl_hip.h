@@ -164,6 +164,12 @@ int pfnl_op_conv3x3_bf16(const uint16_t* in, const float* kernel_host, const flo
 int pfnl_op_conv1_conv10_bf16(const uint16_t* in, const float* k1_host, const float* b1_host, const float* k10_host,
                               const float* b10_host, uint16_t* out1, uint16_t* base, int clips, int frames_per_clip, int H, int W,
                               void* stream);
+/* convmerge1 (reference model/pfnl.py:52, :73-74) from the bf16 trunk: 3x3 over the concat of frames_per_clip frames,
+ * (64*fpc) -> cout <= 64, as ONE launch of the bf16 3x3 kernel in its accumulating mode (the weight pack in LDS is replaced
+ * between the frames of a chain).  in bf16 [clips*fpc, H, W, 64]; kernel_host fp32 HWIO [3,3,64*fpc,cout]; out fp32
+ * [clips, H, W, 64] (channels >= cout: act(0)). */
+int pfnl_op_conv3x3_accum_bf16(const uint16_t* in, const float* kernel_host, const float* bias_host, float* out, int clips,
+                               int frames_per_clip, int H, int W, int cout, int act, void* stream);
 /* ... and conv10_i (reference model/pfnl.py:50, :67-68): in [items*fpi, HW, 64] bf16, kernel_host fp32 HWIO
  * [1,1,64*fpi,64], out [items, HW, 64] bf16; fpi in {3,5,7}. */
 int pfnl_op_conv1x1_bf16(const uint16_t* in, const float* kernel_host, const float* bias_host, uint16_t* out, int items,

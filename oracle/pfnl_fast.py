@@ -54,8 +54,8 @@ class FastOracle:
                  num_block: int = 20, trunk_dtype: str = "fp32"):
         """trunk_dtype="bf16": the build-defined arithmetic of BASELINE.json configs[3] (not expressible in the
         reference, which is fp32 throughout): inside the progressive-fusion blocks every activation and kernel is
-        rounded to bfloat16 (round-to-nearest-even), products are accumulated in fp32, biases stay fp32; everything
-        outside the blocks is the fp32 graph.  Rounding points = the stores of pfnl_amd/csrc/conv_bf16.hip."""
+        rounded to bfloat16 (round-to-nearest-even), products are accumulated in fp32, biases stay fp32; convmerge1 reads
+        the bf16 trunk with a bf16-rounded kernel and produces fp32; everything else is the fp32 graph.  Rounding points = the stores of pfnl_amd/csrc/conv_bf16.hip."""
         assert trunk_dtype in ("fp32", "bf16")
         self.T, self.scale, self.num_block = num_frames, scale, num_block
         self.trunk_bf16 = trunk_dtype == "bf16"
@@ -113,7 +113,11 @@ class FastOracle:
             base = self._conv(f"conv10_{i}", a.reshape(B, T * mf, H, W))
             cat = torch.cat([base[:, None].expand(B, T, mf, H, W), a.reshape(B, T, mf, H, W)], 2)
             fr = fr + self._conv(f"conv2_{i}", cat.reshape(B * T, 2 * mf, H, W))
-        m = self._conv("convmerge1", fr.reshape(B, T * mf, H, W))        # :73-74
+        if self.trunk_bf16:                                               # bf16 build: the merge kernel is rounded too, fp32 out
+            km = self.w["nlvsr/convmerge1/kernel"].to(torch.bfloat16).to(torch.float32)
+            m = F.leaky_relu(F.conv2d(fr.reshape(B, T * mf, H, W), km, self.w["nlvsr/convmerge1/bias"], padding=1), 0.2)
+        else:
+            m = self._conv("convmerge1", fr.reshape(B, T * mf, H, W))    # :73-74
         o = self._conv("convmerge2", _d2s(m), act=False)                  # :76-77
         if self.scale == 4:
             o = _d2s(o)                                                   # :78

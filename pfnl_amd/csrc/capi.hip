@@ -82,6 +82,7 @@ struct pfnl_handle {
     bool bf16 = false;                                        // option precision=bf16: progressive-fusion trunk in bf16 (conv_bf16.hip); NL, conv0 maths, merge, tail stay fp32
     DevBuf wdev16;                                            // bf16 packs (offsets in 16-bit elements)
     std::vector<size_t> off16_c1, off16_c10, off16_c2a, off16_c2b;
+    size_t off16_m1 = 0;                                      // convmerge1: T consecutive packs (cout 48 zero-padded to 64)
     int conv_algo = 3;                                        // conv3x3: 0 direct, 1 winograd (4 waves / tile), 2 winograd16 (1 wave / SIMD), 3 winograd_ws (persistent, wave-specialised)
 
     // device weights (offsets in floats into `wdev`)
@@ -258,11 +259,20 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
                 HIPCHK(launch_conv3x3_bf16(q, s));
             }
         }
-        {   // back to fp32 for convmerge1 (1.2 % of the FLOPs) and the tail
+        {   // convmerge1 (:73-74): the accumulating mode of the bf16 3x3 kernel, fp32 out for the tail
             ProfScope ps(h, s, PFNL_K_MERGE1);
-            HIPCHK(launch_cast_bf16_f32(a0, h->inp1.p, (size_t)F * P * 64, s));
+            ConvBf16Params q{a0, w16 + h->off16_m1, wd + h->off_m1_b, nullptr, nullptr, nullptr, H, W, F, T, 1};
+            q.out_f32 = h->merge.p;
+            HIPCHK(launch_conv3x3_bf16(q, s));
         }
-        merge_in = h->inp1.p;
+        h->merge_cstride = 64;
+        {   // model/pfnl.py:63,76-80
+            ProfScope ps(h, s, PFNL_K_TAIL);
+            HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, H, W, c.scale, 64, s));
+        }
+        h->prof_gate = true;
+        h->chain_open = false;
+        return 0;
     }
 
     ConvParams p{};
@@ -691,6 +701,9 @@ int pfnl_finalize_weights(pfnl_handle* h) {
             h->off16_c2b[i] = reserve16(pfnl::conv3x3_bf16_pack_halfs());
             pfnl::conv3x3_bf16_pack_weights(W("conv2_" + s).data(), 128, 64, &b16[h->off16_c2b[i]]);
         }
+        h->off16_m1 = reserve16((size_t)T * pfnl::conv3x3_bf16_pack_halfs());
+        for (int f = 0; f < T; ++f)
+            pfnl::conv3x3_bf16_pack_weights(W("convmerge1").data(), 64 * T, 64 * f, &b16[h->off16_m1 + (size_t)f * pfnl::conv3x3_bf16_pack_halfs()], 48);
         b16.resize((b16.size() + 1) / 2 * 2 + 2, 0);
         if (h->wdev16.ensure(b16.size() / 2)) return fail(PFNL_ERR_NOMEM, "weight allocation failed");
         HIPCHK(hipMemcpy(h->wdev16.p, b16.data(), b16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -862,7 +875,13 @@ int pfnl_debug_tap(pfnl_handle* h, const char* name, float* host_dst, size_t cou
         src = h->scratch.p;
     } else if (n == "trunk") {
         need = (size_t)B * T * H * W * 64;
-        src = h->bf16 ? h->inp1.p : h->inp0.p;                      // bf16 trunk: the fp32 copy made for convmerge1
+        src = h->inp0.p;
+        if (h->bf16) {                                              // bf16 trunk: cast on demand
+            if (h->scratch.ensure(need)) return fail(PFNL_ERR_NOMEM, "scratch allocation failed");
+            HIPCHK(pfnl::launch_cast_bf16_f32(reinterpret_cast<const uint16_t*>(h->inp0.p), h->scratch.p, need, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            src = h->scratch.p;
+        }
     } else if (n == "merge1") {
         need = (size_t)B * H * W * 48;
         if (count != need) return fail(PFNL_ERR_INVALID, "tap size mismatch");
@@ -1040,6 +1059,28 @@ int pfnl_op_conv1_conv10_bf16(const uint16_t* in, const float* k1_host, const fl
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(dw);
     if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv1+conv10 bf16 op: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int pfnl_op_conv3x3_accum_bf16(const uint16_t* in, const float* kernel_host, const float* bias_host, float* out, int clips,
+                               int frames_per_clip, int H, int W, int cout, int act, void* stream) {
+    if (!in || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    const int T = frames_per_clip;
+    if (clips < 1 || T < 1 || T > 7 || H < 1 || W < 1 || cout < 1 || cout > 64) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nh = pfnl::conv3x3_bf16_pack_halfs();
+    std::vector<uint16_t> pack((size_t)T * nh + 128, 0);
+    for (int f = 0; f < T; ++f) pfnl::conv3x3_bf16_pack_weights(kernel_host, 64 * T, 64 * f, &pack[(size_t)f * nh], cout);
+    if (bias_host) std::memcpy(&pack[(size_t)T * nh], bias_host, cout * sizeof(float));
+    uint16_t* dw = nullptr;
+    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(uint16_t)));
+    hipError_t e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    pfnl::ConvBf16Params q{in, dw, reinterpret_cast<const float*>(dw + (size_t)T * nh), nullptr, nullptr, nullptr, H, W, clips * T, T, act};
+    q.out_f32 = out;
+    if (e == hipSuccess) e = pfnl::launch_conv3x3_bf16(q, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dw);
+    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv3x3 accum bf16 op: ") + hipGetErrorString(e));
     return 0;
 }
 

@@ -19,6 +19,9 @@ struct ConvBf16Params {
     const uint16_t* x_w;     // conv1x1_bf16_pack_weights (add_div frames); nullptr = plain launch
     const float* x_bias;     // [64]
     uint16_t* x_out;         // [items/add_div][H][W][64] bf16
+    // convmerge1 (accumulating mode; out == addend == x_out == nullptr): wpack = add_div consecutive packs (one per frame of
+    // a clip), out_f32[clip] = act(sum_t conv(in[clip*add_div + t]; W_t) + bias), fp32 [items/add_div][H][W][64]
+    float* out_f32;
 };
 hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s);
 hipError_t launch_conv1x1_bf16(const uint16_t* in, const uint16_t* wpack, const float* bias, uint16_t* out, int items, int T,
@@ -27,7 +30,7 @@ hipError_t launch_cast_bf16_f32(const uint16_t* in, float* out, size_t n, hipStr
 hipError_t launch_cast_f32_bf16(const float* in, uint16_t* out, size_t n, hipStream_t s);
 uint16_t bf16_rne(float f);
 size_t conv3x3_bf16_pack_halfs();
-void conv3x3_bf16_pack_weights(const float* hwio, int cin_total, int cin_begin, uint16_t* dst);
+void conv3x3_bf16_pack_weights(const float* hwio, int cin_total, int cin_begin, uint16_t* dst, int cout = 64);   // cout < 64: zero-padded
 size_t conv1x1_bf16_pack_halfs(int T);
 void conv1x1_bf16_pack_weights(const float* hwio, int T, uint16_t* dst);
 // non-local block on bf16 MFMA with split (hi + lo) operands (nonlocal_bf16.hip)

@@ -83,10 +83,14 @@ __device__ long long cb_dbg[256 * 8 * 64];
 // MODE 2 (conv1_i + conv10_i): MODE 0, and per chain of add_div frames x_out = act(sum_t W10_t out_t + x_bias), the 1x1
 // contraction running from the LDS scratch each finished tile passes through anyway (conv10_i costs no launch and
 // no second read of conv1_i's output: -116 MB of 763 MB per block at 1080p).
+// MODE 3 (convmerge1, reference model/pfnl.py:52, :73-74): out_f32[clip] = act(sum_t conv(in[clip*T + t]; W_t) + bias) - the
+// accumulators run through the chain's add_div frames, the 72 KB weight pack in LDS is replaced between frames (requested
+// into registers during a tile, written after its last MFMA), one fp32 epilogue per chain.
 template <int MODE>
 __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Params p) {
     constexpr bool FUSE = MODE == 1;
     constexpr bool WITH10 = MODE == 2;
+    constexpr bool ACCUM = MODE == 3;
     extern __shared__ __attribute__((aligned(16))) unsigned char cb_smem[];
     unsigned char* const wl = cb_smem + 2 * CB_TILE_BYTES;
     float* const bl = reinterpret_cast<float*>(cb_smem + 2 * CB_TILE_BYTES + CB_W_BYTES);
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
     // are dealt out XCD by XCD (blockIdx & 7 = XCD): the 32 workgroups of an XCD walk a contiguous run of spatial
     // tiles together, so the halo rows two tiles share come from that XCD's L2 instead of HBM a second time
     // (measured before: 1.31x the compulsory reads, and the addend 7x).
-    const int gT = (FUSE || WITH10) ? p.add_div : 1;
+    const int gT = (FUSE || WITH10 || ACCUM) ? p.add_div : 1;
     const int nchains = per_item * (p.items / gT);
     const int xcd = blockIdx.x & 7, xj = blockIdx.x >> 3, cpx = gridDim.x >> 3;
     const int per_xcd = (nchains + 7) >> 3;
@@ -207,6 +211,24 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
     // barrier the workgroup stores it as whole 128-byte lines, 8 pixels per wave instruction.
     int ex0p = 0, ey0p = 0;                                         // origin of the tile awaiting its epilogue
     auto epilogue_unit = [&](unsigned char* scratch, int n, int h) __attribute__((always_inline)) {   // bias, addend, leaky_relu, residual, bf16
+        if constexpr (ACCUM) {                                      // fp32 out, straight from the accumulators (one tile in T, 48 of 64 channels used)
+            const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(p.out_f32 + (size_t)(eitemp / gT) * H * W * 64, 0, 2 * item_bytes, 0x00020000);
+            const int sx = ex0p + (lane & 31), sy = ey0p + 2 * rp + n;
+            const int off = (sx < W && sy < H) ? ((sy * W + sx) * 64 + ech + 8 * h) * 4 : 0x7fffffff;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r0 = 8 * h + 4 * q;
+                f32x4 v = f32x4{accp[n][r0], accp[n][r0 + 1], accp[n][r0 + 2], accp[n][r0 + 3]} + *reinterpret_cast<const f32x4*>(bl + ech + r0);
+                if (p.act) {
+                    v.x = lrelu(v.x);
+                    v.y = lrelu(v.y);
+                    v.z = lrelu(v.z);
+                    v.w = lrelu(v.w);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsF, off, 16 * q, 0);
+            }
+            return;
+        }
         f32x4 v[2];                                                 // of row n, channels ech + 8h .. + 7 of the tile awaiting its epilogue
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -228,6 +250,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
         *reinterpret_cast<u32x4*>(scratch + ((2 * rp + n) * 32 + j) * 128 + ((c ^ ((j >> 1) & 7)) << 4)) = u32x4{lo.x, lo.y, hi.x, hi.y};
     };
     auto store_piece = [&](const unsigned char* scratch, int k) __attribute__((always_inline)) {   // 2048 pieces, 4 per thread, whole lines per instruction
+        if constexpr (ACCUM) return;                                // (stored by epilogue_unit)
         const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)eitemp * H * W * 64, 0, item_bytes, 0x00020000);
         const int id = k * CB_THREADS + tid;
         const int pp = id >> 3, c = id & 7;
@@ -296,6 +319,8 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
         }
     };
 
+    u32x4 wnx[CB_W_BYTES / 16 / CB_THREADS];                        // MODE 3: the next frame's weight pack on its way to LDS
+
     CB_REQUEST(0);
     CB_COMMIT(0);
     CB_REQUEST(min(1, nu - 1));                                     // past the end: harmless re-read
@@ -315,10 +340,12 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
             eoff[n] = (ox < W && oy < H) ? (oy * W + ox) * 128 : 0x7fffffff;
         }
         eitem = item;
+        if (!ACCUM || item % gT == 0) {                             // (MODE 3: the accumulators run through the chain)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+        }
 
         // Everything that is not an MFMA is spread over the 12 groups of the tile, a slice per group, so that it issues
         // in the shadow of the matrix pipe (both waves of a SIMD run the same phase at the same time - work done in a
@@ -368,6 +395,11 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
 #ifndef CB_X_NOLOAD   /* timing experiments only */
                 CB_REQUEST(min(u + 2, nu - 1));
 #endif
+                if constexpr (ACCUM) {                              // weights of the next unit's frame (units are whole chains: frame + 1 mod T)
+                    const size_t wo = (size_t)((item % gT + 1) % gT) * (CB_W_BYTES / 16);
+#pragma unroll
+                    for (int k = 0; k < CB_W_BYTES / 16 / CB_THREADS; ++k) wnx[k] = reinterpret_cast<const u32x4*>(p.wpack)[wo + k * CB_THREADS + tid];
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (g < 11) {
@@ -397,20 +429,31 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
         group(std::integral_constant<int, 11>{});
 #undef CB_PX
 #undef CB_WT
-        accp[0] = acc[0];
-        accp[1] = acc[1];
-        ex0p = x0;
-        ey0p = y0;
-        eitemp = eitem;
-        pending = true;
+        if (!ACCUM || item % gT == gT - 1) {                        // (MODE 3: only the chain's last frame leaves the accumulators)
+            accp[0] = acc[0];
+            accp[1] = acc[1];
+            ex0p = x0;
+            ey0p = y0;
+            eitemp = eitem;
+            pending = true;
+        } else {
+            pending = false;
+        }
         CB_STAMP();
         __syncthreads();                                               // this tile's buffer is free, the next tile's is complete
         CB_STAMP();
+        if constexpr (ACCUM) {                                      // every wave is past its last MFMA with the old weights
+            if (gT > 1) {
+#pragma unroll
+                for (int k = 0; k < CB_W_BYTES / 16 / CB_THREADS; ++k) reinterpret_cast<u32x4*>(wl)[k * CB_THREADS + tid] = wnx[k];
+                __syncthreads();
+            }
+        }
     }
     // the last tile (its addend / residual pieces were requested in its own iteration); any buffer is free now
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        epilogue_unit(cb_smem, k >> 1, k & 1);
+        if (!ACCUM || pending) epilogue_unit(cb_smem, k >> 1, k & 1);
         if (WITH10) x_request(k);
     }
     __syncthreads();
@@ -426,7 +469,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
 }
 
 hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s) {
-    if (!p.in || !p.wpack || !p.bias || !p.out || p.items < 1 || p.H < 1 || p.W < 1) return hipErrorInvalidValue;
+    if (!p.in || !p.wpack || !p.bias || (!p.out && !p.out_f32) || p.items < 1 || p.H < 1 || p.W < 1) return hipErrorInvalidValue;
     if ((p.addend == nullptr) != (p.resid == nullptr) || (p.addend && (p.add_div < 1 || p.items % p.add_div))) return hipErrorInvalidValue;
     if ((long long)p.H * p.W * 128 >= 0x7fffffffLL) return hipErrorInvalidValue;
     static int ncu = 0;
@@ -437,15 +480,18 @@ hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s) {
         ncu = prop.multiProcessorCount;
     }
     const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;                    // whole XCDs; surplus workgroups exit at once
+    const bool accum = p.out_f32 != nullptr;
+    if (accum && (p.addend || p.x_out || p.add_div < 1 || p.items % p.add_div)) return hipErrorInvalidValue;
     const bool with10 = p.x_out != nullptr;
     if (with10 && (p.addend || !p.x_w || !p.x_bias || p.add_div < 1 || p.add_div > 7 || p.items % p.add_div)) return hipErrorInvalidValue;
-    const int mode = p.addend ? 1 : (with10 ? 2 : 0);
-    static bool attr_dev[64][3] = {};                               // the attribute is per device
+    const int mode = accum ? 3 : (p.addend ? 1 : (with10 ? 2 : 0));
+    static bool attr_dev[64][4] = {};                               // the attribute is per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     bool* const attr = attr_dev[dev];
     const void* fn = mode == 1 ? reinterpret_cast<const void*>(conv3x3_bf16_kernel<1>)
-                               : (mode == 2 ? reinterpret_cast<const void*>(conv3x3_bf16_kernel<2>) : reinterpret_cast<const void*>(conv3x3_bf16_kernel<0>));
+                   : mode == 2 ? reinterpret_cast<const void*>(conv3x3_bf16_kernel<2>)
+                   : mode == 3 ? reinterpret_cast<const void*>(conv3x3_bf16_kernel<3>) : reinterpret_cast<const void*>(conv3x3_bf16_kernel<0>);
     if (!attr[mode]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -453,6 +499,7 @@ hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s) {
     }
     if (mode == 1) hipLaunchKernelGGL(conv3x3_bf16_kernel<1>, dim3(grid), dim3(CB_THREADS), CB_LDS_BYTES, s, p);
     else if (mode == 2) hipLaunchKernelGGL(conv3x3_bf16_kernel<2>, dim3(grid), dim3(CB_THREADS), CB_LDS_BYTES, s, p);
+    else if (mode == 3) hipLaunchKernelGGL(conv3x3_bf16_kernel<3>, dim3(grid), dim3(CB_THREADS), CB_LDS_BYTES, s, p);
     else hipLaunchKernelGGL(conv3x3_bf16_kernel<0>, dim3(grid), dim3(CB_THREADS), CB_LDS_BYTES, s, p);
     return hipGetLastError();
 }
@@ -596,7 +643,7 @@ size_t conv3x3_bf16_pack_halfs() { return CB_W_BYTES / 2; }
 
 // HWIO [3,3,cin_total,64] rows [cin_begin, cin_begin+64) -> [tap][ks][m][lane][e]:
 // W[ky][kx][cin_begin + 16 ks + 8 (lane>>5) + e][32 m + bf16_row_channel(lane&31)]
-void conv3x3_bf16_pack_weights(const float* hwio, int cin_total, int cin_begin, uint16_t* dst) {
+void conv3x3_bf16_pack_weights(const float* hwio, int cin_total, int cin_begin, uint16_t* dst, int cout) {
     for (int tap = 0; tap < 9; ++tap)
         for (int ks = 0; ks < 4; ++ks)
             for (int m = 0; m < 2; ++m)
@@ -604,7 +651,8 @@ void conv3x3_bf16_pack_weights(const float* hwio, int cin_total, int cin_begin, 
                     for (int e = 0; e < 8; ++e) {
                         const int ci = cin_begin + 16 * ks + 8 * (lane >> 5) + e;
                         const int co = 32 * m + bf16_row_channel(lane & 31);
-                        dst[((((size_t)tap * 4 + ks) * 2 + m) * 64 + lane) * 8 + e] = bf16_rne(hwio[((size_t)tap * cin_total + ci) * 64 + co]);
+                        dst[((((size_t)tap * 4 + ks) * 2 + m) * 64 + lane) * 8 + e] =
+                            co < cout ? bf16_rne(hwio[((size_t)tap * cin_total + ci) * cout + co]) : (uint16_t)0;
                     }
 }
 

@@ -242,10 +242,17 @@ __global__ __launch_bounds__(NB_THREADS, 2) void nl_attn_bf16_kernel(const float
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float mn = fmaxf(m, tmax);
         const float alpha = __builtin_amdgcn_exp2f(m - mn);         // m = -inf on the first tile -> 0
+#ifdef NB_X_NOSOFTMAX   /* timing experiment only: wrong results */
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; r += 8) pt[sub][r >> 3] = __builtin_bit_cast(bf16x8, u32x4{__builtin_bit_cast(unsigned, st[sub][r]), __builtin_bit_cast(unsigned, st[sub][r + 1]), __builtin_bit_cast(unsigned, st[sub][r + 2]), __builtin_bit_cast(unsigned, st[sub][r + 3])});
+#else
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; ++r) pt[sub][r >> 3][r & 7] = (__bf16)__builtin_amdgcn_exp2f(st[sub][r] - mn);
+#endif
         m = mn;
         if (!__all(alpha == 1.0f)) {
 #pragma unroll

@@ -134,6 +134,24 @@ def conv1_conv10_bf16(x, k1, b1, k10, b10, frames_per_clip):
     return out1, base
 
 
+def conv3x3_accum_bf16(x, kernel, bias=None, act=True, frames_per_clip=7):
+    """bf16 trunk -> convmerge1: 3x3 over the concat of `frames_per_clip` frames, (64*fpc) -> cout <= 64, fp32 out
+    [clips, H, W, 64] (channels >= cout hold act(0)).  x bfloat16 [clips*fpc, H, W, 64]; kernel fp32 HWIO [3,3,64*fpc,cout].
+    Reference: model/pfnl.py:52, :73-74."""
+    import torch
+    lib = _capi.load_library()
+    k, b = _host(kernel, "kernel"), _host(bias, "bias")
+    F, H, W, c = x.shape
+    T = frames_per_clip
+    if k.shape[:3] != (3, 3, 64 * T) or k.shape[3] > 64 or c != 64 or F % T:
+        raise ValueError("conv3x3_accum_bf16: geometry mismatch")
+    out = torch.empty((F // T, H, W, 64), dtype=torch.float32, device=x.device)
+    _capi.check(lib.pfnl_op_conv3x3_accum_bf16(
+        _req16(x, "x"), k.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p) if b is not None else None,
+        _req(out, "out"), F // T, T, H, W, int(k.shape[3]), 1 if act else 0, _stream(x)))
+    return out
+
+
 def conv1x1_bf16(x, kernel, bias=None, act=True, frames_per_item=7):
     """bf16 trunk: conv10_i, 1x1 over the concat of `frames_per_item` frames.  x bfloat16 [items*fpi, H, W, 64];
     kernel fp32 HWIO [1,1,64*fpi,64].  Reference: model/pfnl.py:50, :67-68."""

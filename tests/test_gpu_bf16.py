@@ -241,3 +241,19 @@ def test_dropin_class_on_the_bf16_path(tmp_path):
     got = np.stack([np.asarray(Image.open(p)) for p in outs])
     diff = np.abs(got.astype(np.int32) - gd["sr_u8"].astype(np.int32))
     assert diff.max() <= 1 and (diff > 0).mean() < 0.05
+
+
+@pytest.mark.parametrize("clips,T,H,W,cout", [(2, 7, 20, 36, 48), (1, 5, 32, 64, 48), (3, 3, 17, 33, 64), (1, 7, 8, 32, 48), (2, 7, 70, 100, 48)])
+def test_conv3x3_accum_bf16(clips, T, H, W, cout):
+    """convmerge1 in the accumulating mode of the bf16 3x3 kernel (weight pack swapped in LDS between the frames of a chain):
+    fp32 accumulation over all T*576 products, fp32 output -> close to an fp32 conv over the same bf16-rounded operands."""
+    g = torch.Generator().manual_seed(clips * 100 + T + H)
+    x = r16(torch.randn(clips * T, H, W, 64, generator=g))
+    k = (torch.randn(3, 3, 64 * T, cout, generator=g) / np.sqrt(576 * T))
+    b = torch.randn(cout, generator=g) * 0.1
+    out = ops.conv3x3_accum_bf16(x.to(torch.bfloat16).cuda(), k.numpy(), b.numpy(), act=True, frames_per_clip=T).cpu()
+    cat = x.reshape(clips, T, H, W, 64).permute(0, 2, 3, 1, 4).reshape(clips, H, W, T * 64)
+    ref = F.leaky_relu(F.conv2d(cat.permute(0, 3, 1, 2), r16(k).permute(3, 2, 0, 1), b, padding=1), 0.2).permute(0, 2, 3, 1)
+    assert float((out[..., :cout] - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert float(out[..., cout:].abs().max()) == 0.0 if cout < 64 else True
+    assert torch.equal(out, ops.conv3x3_accum_bf16(x.to(torch.bfloat16).cuda(), k.numpy(), b.numpy(), act=True, frames_per_clip=T).cpu())
