@@ -259,6 +259,8 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
                 HIPCHK(launch_conv3x3_bf16(q, s));
             }
         }
+        h->prof_gate = true;
+        if (h->prof_mode == 2) h->chain_open = false;
         {   // convmerge1 (:73-74): the accumulating mode of the bf16 3x3 kernel, fp32 out for the tail
             ProfScope ps(h, s, PFNL_K_MERGE1);
             ConvBf16Params q{a0, w16 + h->off16_m1, wd + h->off_m1_b, nullptr, nullptr, nullptr, H, W, F, T, 1};
@@ -270,7 +272,6 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             ProfScope ps(h, s, PFNL_K_TAIL);
             HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, H, W, c.scale, 64, s));
         }
-        h->prof_gate = true;
         h->chain_open = false;
         return 0;
     }
