@@ -28,7 +28,9 @@
 //     a tile period earlier, and the in-order vmcnt queue never has a store in front of a load that is waited for.
 //
 // conv2_i keeps the shared-`base` split of the fp32 path: one launch over `base` produces
-// the raw shared half per clip (stored in bf16), the per-frame launch adds it before the activation.
+// the raw shared half per clip (stored in bf16), the per-frame launch adds it before the activation.  The same kernel
+// also runs conv10_i inside the conv1_i launch (mode 2) and convmerge1 (mode 3, accumulating over the frames of a clip
+// with the weight pack replaced in LDS between frames): see the mode list above the kernel.
 // Measured (1x7x270x480, rocprofv3): conv1_i 72 us, conv2_i per-frame half 87 us, shared half 16 us, conv10_i 29 us
 // per block; 3.2-4.3 TB/s of HBM traffic; matrix pipe 38 % busy.  -DCB_X_NOMFMA / NOSTORE / NOLOAD are timing
 // experiments (wrong results on purpose) used to find what bounds the kernel; -DPFNL_BF16_TIMING adds phase stamps.
