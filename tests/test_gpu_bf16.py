@@ -6,6 +6,8 @@ the MFMA differs from the CPU's, which can move a value across a rounding bounda
 (2^-8 |v|) on isolated elements.  Ops: |d| <= 2^-7 |ref| + 1e-5 element-wise and a mean error far below one ulp.
 Whole forward (20 blocks of such stores, then the fp32 merge / tail): PSNR against the equally-rounded oracle
 > 55 dB and |dPSNR| against ground truth vs the fp32 oracle reported and bounded at 0.1 dB (NOT the fp32 bar)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -257,3 +259,20 @@ def test_conv3x3_accum_bf16(clips, T, H, W, cout):
     assert float((out[..., :cout] - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
     assert float(out[..., cout:].abs().max()) == 0.0 if cout < 64 else True
     assert torch.equal(out, ops.conv3x3_accum_bf16(x.to(torch.bfloat16).cuda(), k.numpy(), b.numpy(), act=True, frames_per_clip=T).cpu())
+
+
+@pytest.mark.parametrize("name", ["ragged_7x20x36_nb2", "x2_5x16x24_nb2"])
+def test_forward_bf16_against_committed_golden(name):
+    """The bf16 path against committed fixtures (tests/golden/bf16_outputs.npz, written by tools/make_golden.py from the fast
+    oracle's bf16 mode in the build container): PSNR > 60 dB, element-wise within 2e-3 on [0,1]-scale outputs."""
+    from conftest import geometry_of, load_golden
+    gd = load_golden(name)
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_outputs.npz"))[name]
+    geom = geometry_of(gd["meta"])
+    eng = PFNLEngine(geom, device=0)
+    eng.load_weights(synth.synthetic_weights(geom, seed=0))
+    eng.set_option("precision", "bf16")
+    y = eng.forward(gd["x"])
+    assert y.shape == ref.shape
+    assert synth.psnr(y, ref) > 60.0 and np.abs(y - ref).max() < 2e-3
+    eng.close()

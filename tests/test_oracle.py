@@ -185,3 +185,16 @@ def test_bf16_trunk_mode_of_the_fast_oracle():
     fr = torch.rand(7, 64, 8, 8)
     out = fo16._trunk_bf16(fr, 1, 7, 64, 8, 8)
     assert torch.equal(out, out.to(torch.bfloat16).to(torch.float32))
+
+
+def test_bf16_golden_outputs_reproduce():
+    """tests/golden/bf16_outputs.npz is what the fast oracle's bf16 mode produces today (guards against silent drift)."""
+    import os
+    from oracle import pfnl_fast
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_outputs.npz"))
+    for name in ("ragged_7x20x36_nb2", "x2_5x16x24_nb2"):
+        gd = load_golden(name)
+        geom = geometry_of(gd["meta"])
+        w = synth.synthetic_weights(geom, seed=0)
+        y = pfnl_fast.FastOracle(w, geom.num_frames, geom.scale, geom.num_block, trunk_dtype="bf16").forward(gd["x"])
+        assert np.abs(y - ref[name]).max() < 1e-5

@@ -64,6 +64,20 @@ def main():
                         sr_u8=pfnl_spec.quantise(sr[:, 0]), sr=sr.astype(np.float32))
     print("harness", sr.shape)
 
+    # bf16 path (BASELINE.json configs[3]'s arithmetic, build-defined): outputs of the fast oracle's trunk_dtype="bf16"
+    # mode for two existing cases (inputs are the cases' x; only y is stored)
+    from oracle import pfnl_fast
+    rec = {}
+    for name, T, scale, nb, B, H, W, kind, seed in CASES:
+        if name not in ("ragged_7x20x36_nb2", "x2_5x16x24_nb2"):
+            continue
+        geom = PFNLGeometry(num_frames=T, scale=scale, num_block=nb)
+        w = synth.synthetic_weights(geom, seed=0)
+        x = np.load(os.path.join(OUT, name + ".npz"))["x"]
+        rec[name] = pfnl_fast.FastOracle(w, T, scale, nb, trunk_dtype="bf16").forward(x).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "bf16_outputs.npz"), **rec)
+    print("bf16", {k: v.shape for k, v in rec.items()})
+
 
 if __name__ == "__main__":
     main()
