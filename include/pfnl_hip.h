@@ -18,7 +18,8 @@
  * available from pfnl_last_error().  A handle is bound to one device and is not re-entrant;
  * distinct handles are independent.  "device pointer" = memory accessible from that device
  * (e.g. a torch-ROCm tensor's data_ptr()); "stream" = a hipStream_t passed as void* (NULL = the
- * handle's own stream).  All tensors are float32, contiguous, NHWC-style as in the reference:
+ * handle's own stream).  All tensors are float32 (the *_bf16 single-op hooks alone take bfloat16 bit patterns as
+ * uint16_t), contiguous, NHWC-style as in the reference:
  *   input  [B, T, H, W, 3]      values nominally in [0,1]
  *   output [B, 1, s*H, s*W, 3]  not clipped (the harness clips, reference model/pfnl.py:255-257)
  */
