@@ -8,14 +8,19 @@ Workload = BASELINE.json configs[1]: PFNL 4xSR, 7 LR frames 128x128 -> one 512x5
 batch 4 clips per GPU, fp32, synthetic U[0,1) clips and seeded Xavier weights (no checkpoint/dataset
 can be fetched).  A "step" = one pfnl_forward over the rank's batch with the input already resident in
 HBM.  Clips are independent, so ranks share nothing on the data path (weak scaling: 4 clips per GPU);
-RCCL is used for the weight broadcast, the barriers and the max-over-ranks time only.
+RCCL carries the weight replica (pfnl_comm_bcast_weights), the barriers and the max-over-ranks time only.
 
-Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel class: the
-3x3 64->64 MFMA implicit-GEMM conv, timed live with HIP events on the launch stream) and, at N=1,
-`cpu_baseline` (the torch-CPU fp32 oracle = the stand-in for the reference's TF1 CPU path, timed on a
-bounded sample of the same workload).
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline      dominant kernel class (the 3x3 64->64 convolutions), timed live with HIP events on the launch stream;
+                frac = matrix-pipe FLOPs the kernel EXECUTES / the dense MFMA peak of its instruction (<= 1)
+  sustained     >= 2 s of back-to-back steps (no events): ms/step, so clock droop is visible
+  secondary     measured in the same process after the headline: configs[3] (1080p bf16), configs[0], configs[4]
+                (2x, T=5, 64x64) and the HOST-pointer configs[1] path (H2D + D2H inside, what the reference's
+                sess.run timing covers, model/pfnl.py:249-253)
+  cpu_baseline  (N=1) the torch-CPU fp32 oracle = the stand-in for the reference's TF1 CPU path, on a bounded sample.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -26,10 +31,32 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, no xf32 on gfx950
-B_PER_GPU, T, H, W = 4, 7, 128, 128
+PEAK_F16_MFMA_TFLOPS = 2500.0     # dense bf16 / f16 MFMA (no sparsity)
+PEAK_HBM_GBS = 8000.0
+T = 7
+
+CONV3X3_KERNELS = {
+    "winograd": ("conv_wino_ws_kernel<*> (fused Winograd F(2x2,3x3) 64->64, f32 MFMA, persistent wave-specialised)",
+                 ["conv_wino_ws.hip", "wino_geom.h"]),
+    "winograd_tile": ("conv_wino_kernel<*> (fused Winograd F(2x2,3x3) 64->64, f32 MFMA, one workgroup per tile)",
+                      ["conv_wino.hip", "wino_geom.h"]),
+    "winograd16": ("conv_wino16_kernel<*> (fused Winograd F(2x2,3x3), one wave per SIMD)", ["conv_wino16.hip", "wino_geom.h"]),
+    "direct": ("conv_mfma_kernel<3,16,*> (3x3 64->64 f32 MFMA implicit GEMM)", ["conv_mfma.hip"]),
+    "bf16": ("conv3x3_bf16_kernel<*> (direct 3x3 64->64, bf16 MFMA, fp32 accumulation, persistent)", ["conv_bf16.hip"]),
+}
 
 
-def cpu_baseline(weights, sample_clips, budget_s=24.0):
+def kernel_source_sha(files):
+    """sha256 over the sources of a kernel: `roofline.traffic` (PMC bytes measured offline) is only reported while the
+    kernel it was measured on is the kernel that is being timed."""
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, "pfnl_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(weights, sample_clips, H, W, budget_s=24.0):
     """Times oracle/pfnl_fast.py (the CPU port of the reference graph) on this host."""
     import numpy as np
     import torch
@@ -49,7 +76,7 @@ def cpu_baseline(weights, sample_clips, budget_s=24.0):
 
     ncpu = os.cpu_count() or 1
     default_thr = torch.get_num_threads()
-    cands = sorted({c for c in (8, 16, 32, 64, default_thr) if 1 <= c <= max(ncpu, 1)})
+    cands = sorted({c for c in (8, 16, 32, default_thr) if 1 <= c <= max(ncpu, 1)})
     per_run_budget = max(3.0, budget_s / len(cands))
     results = {}
     for c in cands:                                   # oversubscription hurts oneDNN: report the best
@@ -64,12 +91,94 @@ def cpu_baseline(weights, sample_clips, budget_s=24.0):
             "by_threads": {str(c): round(v[0], 4) for c, v in results.items()}}
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on stdout when a communicator is created; the contract is ONE JSON line there."""
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
+def timed_steps(step, fence, steps):
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    return time.perf_counter() - t0
+
+
+def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
+    """`roofline` of the dominant kernel class from the live HIP-event timing (k = prof["conv3x3"])."""
+    k = prof["conv3x3"]
+    if not k["launches"]:
+        return None
+    P, F = H * W, B * geom.num_frames
+    avg_ms = k["ms"] / k["launches"]                                   # over the launches that were timed
+    flops3 = geom.num_block * (2 * F + B) * P * 9 * 64 * 64 * 2.0      # direct-convolution FLOPs, shared-base split (DESIGN.md 3)
+    if bf16:
+        # bf16 trunk: the 3x3 launches are bound by HBM, not by the matrix pipe (DESIGN.md section 3.4): algorithmic bytes
+        # per PF block = conv1_i (read F, write F tiles of 128 B per pixel) + shared half (read B, write B) + per-frame
+        # half (read F + residual F + addend B, write F), over 3 launches
+        launches_per_step = 3 * geom.num_block
+        bytes_per_launch = P * 128.0 * (5 * F + 3 * B) / 3.0
+        gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        name, files = CONV3X3_KERNELS["bf16"]
+        traffic = stamped_traffic("traffic_bf16.json", files, workload)
+        return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                "traffic": traffic, "kernel": name, "avg_launch_ms": round(avg_ms, 4), "launches_timed": k["launches"],
+                "launches_per_step": launches_per_step, "mbytes_per_launch": round(bytes_per_launch / 1e6, 2),
+                "mfma_tflops": round(flops3 / launches_per_step / (avg_ms * 1e-3) / 1e12, 1), "mfma_peak_bf16_tflops": PEAK_F16_MFMA_TFLOPS}
+    # fp32: conv1_i + conv2_i; the default kernel runs the whole of conv2_i as one grouped launch, the others launch its
+    # shared half and its per-frame half separately
+    launches_per_step = (2 if algo == "winograd" else 3) * geom.num_block
+    flops_per_launch = flops3 / launches_per_step
+    direct_tflops = flops_per_launch / (avg_ms * 1e-3) / 1e12
+    wino = algo.startswith("winograd")
+    executed = direct_tflops / 2.25 if wino else direct_tflops          # F(2x2,3x3): 16 multiplies instead of 36 per 2x2 outputs
+    name, files = CONV3X3_KERNELS[algo]
+    return {"bound": "mfma", "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
+            "traffic": stamped_traffic("traffic.json", files, algo),
+            "kernel": name, "avg_launch_ms": round(avg_ms, 4), "launches_timed": k["launches"],
+            "launches_per_step": launches_per_step,
+            "gflop_per_launch_executed": round(flops_per_launch / (2.25 if wino else 1.0) / 1e9, 3),
+            "gflop_per_launch_direct": round(flops_per_launch / 1e9, 3),
+            "algorithmic_direct_tflops": round(direct_tflops, 2),
+            "algorithmic_vs_direct_roof": round(direct_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+            "note": ("achieved = matrix-pipe FLOPs the kernel executes (Winograd F(2x2,3x3): direct-conv FLOPs / 2.25) / time, "
+                     "against the dense f32 MFMA peak; algorithmic_* = the direct convolution's FLOPs / time, which a Winograd "
+                     "kernel can take past the direct algorithm's roof") if wino else "achieved = executed = algorithmic (direct convolution)"}
+
+
+def stamped_traffic(suffix, files, key):
+    """HBM bytes per launch from the rocprofv3 --pmc passes kept under profiles/ (the newest r<NN>_<suffix>), or None when
+    the kernel sources have changed since they were measured (the file records the sha of the sources it was measured on)."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    if not cands:
+        return None
+    tj = json.load(open(cands[-1]))
+    if tj.get("kernel_src_sha") != kernel_source_sha(files):
+        return None
+    v = tj.get("hbm_bytes_per_launch_avg")
+    if isinstance(v, dict):
+        return v.get(key)
+    return v if tj.get("algo", key) == key else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads and the sustained run")
     ap.add_argument("--conv3x3", choices=["winograd", "winograd_tile", "winograd16", "direct"], default=None, help="override the 3x3 conv algorithm")
     ap.add_argument("--conv1x1", choices=["stream", "tiled"], default=None, help="override the conv10_i algorithm")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
@@ -82,9 +191,7 @@ def main():
                     help="HIP events around every launch (default: every 4th progressive-fusion block is timed)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events (no roofline object)")
     args = ap.parse_args()
-    global B_PER_GPU, H, W
-    if args.workload == "cfg4":
-        B_PER_GPU, H, W = 1, 270, 480
+    B_PER_GPU, H, W = (1, 270, 480) if args.workload == "cfg4" else (4, 128, 128)
 
     import numpy as np
     import torch
@@ -109,22 +216,32 @@ def main():
     geom = PFNLGeometry()
 
     use_dist = world > 1
+    comm = None
+    eng = PFNLEngine(geom, device=local_dev)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+            # torch.distributed is the launcher (rendezvous + the contract's barrier); the weight replica and the
+            # max-over-ranks time go through the library's own RCCL communicator (pfnl_comm_*, include/pfnl_hip.h)
+            from pfnl_amd.comm import Comm
+            with stdout_to_stderr():
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+                dist.barrier()                                         # creates torch's communicator now, not inside the timed region
+                comm = Comm.from_torch_distributed(local_dev)
+                weights = synth.synthetic_weights(geom, seed=0) if rank == 0 else None
+                if rank == 0:
+                    eng.load_weights(weights)
+                comm.bcast_weights(eng, root=0)                        # ncclBroadcast of the packed device blobs, once
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-        cdev = dev if args.backend == "nccl" else None                # where collective tensors live
-        weights = pd.broadcast_weights(geom, synth.synthetic_weights(geom, seed=0) if rank == 0 else None,
-                                       src=0, device=cdev)           # RCCL broadcast, 12 MB, once
+            weights = pd.broadcast_weights(geom, synth.synthetic_weights(geom, seed=0) if rank == 0 else None, src=0)
+            eng.load_weights(weights)
     else:
         weights = synth.synthetic_weights(geom, seed=0)
+        eng.load_weights(weights)
 
-    eng = PFNLEngine(geom, device=local_dev)
-    eng.load_weights(weights)
     if args.conv3x3:
         eng.set_option("conv3x3", args.conv3x3)
     if args.conv1x1:
@@ -153,79 +270,25 @@ def main():
     # of every 4th of the 20 identical PF blocks plus everything outside the blocks (an event costs ~2 us)
     prof_mode = 0 if args.no_profile else (1 if args.full_profile else 2)
     eng.profile(prof_mode)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed_steps(step, fence, args.steps)
     eng.profile(False)
     prof = eng.profile_read()
 
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev or "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+        if comm is not None:
+            elapsed = float(comm.allreduce([elapsed], "max")[0])
+        else:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t[0])
     assert torch.isfinite(out).all().item(), "non-finite output"
 
     clips_total = world * B_PER_GPU * args.steps
     value = clips_total / elapsed                                     # 1 HR frame per clip
     ms_per_step = 1e3 * elapsed / args.steps
 
-    # dominant kernel class (PFNL_K_CONV3X3): the 3x3 64->64 convs conv1_i and both halves of conv2_i
-    #  = conv_wino_kernel<*> (default) or conv_mfma_kernel<3,16,*> (--conv3x3 direct).
-    # ALGORITHMIC flops = direct-convolution flops with the shared-base split; the Winograd
-    # kernel executes 2.25x fewer MFMA flops, reported separately as mfma_executed / mfma_util.
-    P = H * W
-    F = B_PER_GPU * T
-    flops3 = geom.num_block * (2 * F + B_PER_GPU) * P * 9 * 64 * 64 * 2.0         # per forward
     algo = args.conv3x3 or os.environ.get("PFNL_CONV3X3", "winograd")
-    k = prof["conv3x3"]
-    roof = None
-    if k["launches"]:
-        avg_ms = k["ms"] / k["launches"]                              # over the launches that were timed
-        # conv1_i + conv2_i: the default kernel runs the whole of conv2_i as one grouped launch; the others
-        # launch its shared half and its per-frame half separately
-        launches_per_step = (2 if algo == "winograd" else 3) * geom.num_block
-        flops_per_launch = flops3 / launches_per_step
-        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        executed = achieved / 2.25 if algo.startswith("winograd") else achieved
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj.get("algo") == algo:
-                traffic = tj.get("hbm_bytes_per_launch_avg")
-        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                "kernel": ("conv_wino16_kernel<*> (fused Winograd F(2x2,3x3), one wave per SIMD)" if algo == "winograd16" else
-                           "conv_wino_kernel<*> (fused Winograd F(2x2,3x3) 64->64, f32 MFMA, one workgroup per tile)" if algo == "winograd_tile" else
-                           "conv_wino_ws_kernel<*> (fused Winograd F(2x2,3x3) 64->64, f32 MFMA, persistent wave-specialised)" if algo == "winograd"
-                           else "conv_mfma_kernel<3,16,*> (3x3 64->64 f32 MFMA implicit GEMM)"),
-                "avg_launch_ms": round(avg_ms, 4), "launches_timed": k["launches"],
-                "launches_per_step": launches_per_step,
-                "gflop_per_launch": round(flops_per_launch / 1e9, 3),
-                "mfma_executed_tflops": round(executed, 2),
-                "mfma_util": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
-                "note": "achieved = algorithmic (direct-conv) FLOPs / time; Winograd executes 1/2.25 of them on the matrix pipe"
-                        if algo.startswith("winograd") else "achieved = executed = algorithmic"}
-    if bf16 and k["launches"]:
-        # bf16 trunk: the 3x3 launches are bound by HBM, not by the matrix pipe: algorithmic bytes
-        # per PF block = conv1_i (read F, write F tiles of 128 B per pixel) + shared half (read B, write B) + per-frame
-        # half (read F + residual F + addend B, write F), over 3 launches
-        avg_ms = k["ms"] / k["launches"]
-        launches_per_step = 3 * geom.num_block
-        bytes_per_launch = P * 128.0 * (5 * F + 3 * B_PER_GPU) / 3.0
-        gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic_bf16.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            traffic = tj.get("hbm_bytes_per_launch_avg", {}).get(args.workload)
-        roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
-                "traffic": traffic, "kernel": "conv3x3_bf16_kernel<*> (direct 3x3 64->64, bf16 MFMA, fp32 accumulation, persistent)",
-                "avg_launch_ms": round(avg_ms, 4), "launches_timed": k["launches"], "launches_per_step": launches_per_step,
-                "mbytes_per_launch": round(bytes_per_launch / 1e6, 2),
-                "mfma_tflops": round(flops3 / launches_per_step / (avg_ms * 1e-3) / 1e12, 1), "mfma_peak_bf16_tflops": 2500.0}
+    roof = conv3x3_roofline(geom, prof, B_PER_GPU, H, W, algo, bf16, args.workload)
     f_ref = geom.flops_per_clip(H, W) * B_PER_GPU
     f_exec = geom.flops_per_clip(H, W, shared_base=True) * B_PER_GPU
     # sampled mode: the two classes inside the PF blocks were timed in ceil(nb/4) of the nb blocks
@@ -244,18 +307,103 @@ def main():
                    "weights": "synthetic Xavier (seed 0)", "input": "resident in HBM"},
         "roofline": roof,
         "whole_forward": {"tflops_ref_graph": round(f_ref / (ms_per_step * 1e-3) / 1e12, 2),
-                          "tflops_executed": round(f_exec / (ms_per_step * 1e-3) / 1e12, 2),
-                          "frac_of_f32_mfma_peak_executed": round(f_exec / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                          "tflops_direct_shared_base": round(f_exec / (ms_per_step * 1e-3) / 1e12, 2),
                           "kernel_ms_per_step": breakdown},
     }
+
+    if not args.no_secondary:
+        # ---- sustained: >= 2 s of back-to-back steps, no events (clock droop shows up as ms/step above the headline's)
+        n_sus = max(args.steps, int(2.2e3 / max(ms_per_step, 1e-3)) + 1)
+        el = timed_steps(step, fence, n_sus)
+        if use_dist:
+            el = float(comm.allreduce([el], "max")[0]) if comm is not None else el
+        res["sustained"] = {"steps": n_sus, "seconds": round(el, 3), "ms_per_step": round(1e3 * el / n_sus, 4),
+                            "value": round(world * B_PER_GPU * n_sus / el, 3)}
+    if rank == 0 and world == 1 and not args.no_secondary and args.workload == "cfg2" and not bf16:
+        res["secondary"] = secondary_workloads(eng, geom, weights, local_dev, dev, x, out)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":   # (the 1080p oracle needs minutes per pass)
         sample = synth.uniform_clips(1, T, H, W, seed=1234)
-        res["cpu_baseline"] = cpu_baseline(weights, sample)
+        res["cpu_baseline"] = cpu_baseline(weights, sample, H, W)
         res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
     if rank == 0:
         print(json.dumps(res), flush=True)
+    if comm is not None:
+        comm.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def secondary_workloads(eng, geom, weights, local_dev, dev, x_cfg2, out_cfg2):
+    """The other BASELINE.json configurations and the host-pointer path, each: 2 warm-up + K timed steps bracketed by
+    synchronize, its own HIP-event breakdown; N=1 only.  Not the judged `value` - driver-visible evidence."""
+    import numpy as np
+    import torch
+    from pfnl_amd import synth
+    from pfnl_amd.engine import PFNLEngine
+    from pfnl_amd.spec import PFNLGeometry
+
+    def sync():
+        torch.cuda.synchronize()
+
+    def run(e, g, B, H, W, steps, seed, bf16=False, label=""):
+        xs = torch.from_numpy(synth.uniform_clips(B, g.num_frames, H, W, seed=seed)).to(dev)
+        o = torch.empty(e.out_shape(B, H, W), dtype=torch.float32, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        fwd = lambda: e.forward_device(xs.data_ptr(), o.data_ptr(), B, H, W, st)    # noqa: E731
+        for _ in range(2):
+            fwd()
+        sync()
+        e.profile_reset()
+        e.profile(2)
+        el = timed_steps(fwd, sync, steps)
+        e.profile(False)
+        prof = e.profile_read()
+        nb = g.num_block
+        sc = nb / float((nb + 3) // 4) if nb else 1.0
+        ms = 1e3 * el / steps
+        rec = {"workload": label, "dtype": "bf16" if bf16 else "f32", "clips": B, "steps": steps, "ms_per_step": round(ms, 4),
+               "value": round(B * steps / el, 3), "unit": "HR frames/s", "input": "resident in HBM",
+               "kernel_ms_per_step": {n: round(v["ms"] / steps * (sc if n in ("conv3x3", "conv1x1") else 1.0), 4) for n, v in prof.items()}}
+        assert torch.isfinite(o).all().item(), "non-finite output (%s)" % label
+        return rec, prof
+
+    out = []
+    # configs[3]: 1080p, bf16 trunk
+    eng.set_option("precision", "bf16")
+    rec, prof = run(eng, geom, 1, 270, 480, 10, 4040, bf16=True, label="BASELINE.json configs[3]: 4xSR 7x270x480 -> 1080x1920, batch 1, bf16 trunk")
+    rec["roofline"] = conv3x3_roofline(geom, prof, 1, 270, 480, "bf16", True, "cfg4")
+    out.append(rec)
+    eng.set_option("precision", "fp32")
+    # configs[3] geometry in fp32 (the reference's arithmetic at 1080p)
+    rec, prof = run(eng, geom, 1, 270, 480, 5, 4040, label="configs[3] geometry in fp32: 7x270x480 -> 1080x1920, batch 1")
+    rec["roofline"] = conv3x3_roofline(geom, prof, 1, 270, 480, os.environ.get("PFNL_CONV3X3", "winograd"), False, "cfg4")
+    out.append(rec)
+    # configs[0]: 7x32x32, batch 1 (the reference's CPU-runnable plumbing case; latency-bound on a GPU)
+    rec, _ = run(eng, geom, 1, 32, 32, 50, 1234, label="BASELINE.json configs[0]: 4xSR 7x32x32 -> 128x128, batch 1, fp32")
+    out.append(rec)
+    # configs[4]: 2x, 5 frames, 64x64 (build-defined tail; 20 blocks)
+    g5 = PFNLGeometry(num_frames=5, scale=2, num_block=20)
+    e5 = PFNLEngine(g5, device=local_dev)
+    e5.load_weights(synth.synthetic_weights(g5, seed=0))
+    rec, _ = run(e5, g5, 1, 64, 64, 50, 55, label="BASELINE.json configs[4]: 2xSR 5x64x64 -> 128x128, batch 1, fp32")
+    out.append(rec)
+    e5.close()
+    # configs[1] through HOST pointers: numpy in -> numpy out, H2D + kernels + D2H inside pfnl_forward
+    xh = np.ascontiguousarray(x_cfg2.cpu().numpy())
+    for _ in range(2):
+        eng.forward(xh)
+    sync()
+    steps = 10
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        yh = eng.forward(xh)
+    el = time.perf_counter() - t0
+    assert np.isfinite(yh).all()
+    out.append({"workload": "BASELINE.json configs[1] through HOST pointers (pageable numpy in/out: 5.5 MB H2D + 12.6 MB D2H inside pfnl_forward; "
+                            "what the reference's sess.run timing covers, model/pfnl.py:249-253)",
+                "dtype": "f32", "clips": int(xh.shape[0]), "steps": steps, "ms_per_step": round(1e3 * el / steps, 4),
+                "value": round(xh.shape[0] * steps / el, 3), "unit": "HR frames/s", "input": "host memory (PCIe-inclusive)"})
+    return out
 
 
 if __name__ == "__main__":

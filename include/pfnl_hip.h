@@ -41,7 +41,8 @@ typedef enum pfnl_status {
     PFNL_ERR_STATE = -2,       /* e.g. forward before finalize_weights, missing weights        */
     PFNL_ERR_HIP = -3,         /* a HIP runtime call failed                                    */
     PFNL_ERR_NOMEM = -4,
-    PFNL_ERR_NODEVICE = -5     /* no gfx950-capable device visible                             */
+    PFNL_ERR_NODEVICE = -5,    /* no gfx950-capable device visible                             */
+    PFNL_ERR_COMM = -6         /* an RCCL call failed / RCCL could not be loaded               */
 } pfnl_status;
 
 /* Mirrors the constants hard-coded in the reference (model/pfnl.py:21-23, 40-43). */
@@ -55,7 +56,7 @@ typedef struct pfnl_config {
 } pfnl_config;
 
 const char* pfnl_last_error(void);
-int pfnl_version(void);                        /* ABI version, currently 1 */
+int pfnl_version(void);                        /* ABI version, currently 2 */
 int pfnl_device_count(int* count);
 
 /* ---- model lifetime ---------------------------------------------------------------------- */
@@ -68,7 +69,10 @@ int pfnl_destroy(pfnl_handle* h);
  * and stays owned by the caller; the library keeps its own repacked device copies. */
 int pfnl_set_weight(pfnl_handle* h, const char* tf_name, const float* host,
                     const int64_t* shape, int rank);
-/* Number of variables still missing (0 = complete). */
+/* Optional: "nlvsr/nlblock_0/theta/theta/{kernel,bias}" and ".../phi/phi/{kernel,bias}" ([1,1,C,C] / [C], C = 12T) switch
+ * the non-local block to the embedded-Gaussian form (reference utils.py:31-42 with nltype 0: theta = conv(x), phi = conv(x));
+ * all four or none.  PFNL itself calls the block with nltype 1 (model/pfnl.py:58), where these scopes hold no variables.
+ * Number of variables still missing (0 = complete; the optional ones never count). */
 int pfnl_missing_weights(pfnl_handle* h, int* count);
 /* Repack + upload: splits conv2_i into its shared-`base` half and per-frame half, folds
  * Wg*Ww of the non-local block, chunks the implicit-GEMM weights. */
@@ -103,6 +107,32 @@ int pfnl_forward(pfnl_handle* h, const void* in, int in_is_device, void* out, in
                  int B, int H, int W, void* stream);
 int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes);
 int pfnl_sync(pfnl_handle* h);
+
+/* ---- multi-GPU (RCCL over xGMI) ------------------------------------ */
+/* Clips are independent (reference model/pfnl.py:44,55: the batch is only the leading dimension), so ranks share NOTHING on
+ * the data path; these entry points carry what the reference's single-GPU session (main.py:10) has no counterpart for:
+ * the weight replica, the statistics, and an optional gather.  RCCL is loaded at run time (dlopen; PFNL_RCCL_LIB overrides
+ * the search) - a single-GPU caller never needs it.  One communicator per process: rank 0 calls pfnl_comm_get_unique_id,
+ * moves the PFNL_COMM_ID_BYTES bytes to the other ranks through any host channel, every rank calls pfnl_comm_init_rank
+ * (collective).  One process driving several devices: pfnl_comm_init_all (comms[i] on devs[i], devs NULL = 0..ndev-1). */
+typedef struct pfnl_comm pfnl_comm;
+#define PFNL_COMM_ID_BYTES 128
+enum { PFNL_COMM_SUM = 0, PFNL_COMM_MAX = 1 };
+int pfnl_comm_get_unique_id(void* id /*[PFNL_COMM_ID_BYTES]*/);
+int pfnl_comm_init_rank(int nranks, int rank, const void* id, int device_id, pfnl_comm** out);
+int pfnl_comm_init_all(int ndev, const int* devs, pfnl_comm** comms /*[ndev]*/);
+int pfnl_comm_destroy(pfnl_comm* c);
+int pfnl_comm_rank(pfnl_comm* c, int* rank, int* nranks);
+/* ncclBroadcast of the packed DEVICE weight blobs of `h` (what pfnl_finalize_weights built on `root`) to every rank's
+ * handle of the same geometry; a non-root handle needs no pfnl_set_weight calls at all.  Replaces nothing in the reference
+ * (tf.train.Saver.restore per process, model/base_model.py:231-243): one read of the checkpoint instead of one per GPU. */
+int pfnl_comm_bcast_weights(pfnl_comm* c, pfnl_handle* h, int root);
+int pfnl_comm_bcast(pfnl_comm* c, void* dev_buf, size_t bytes, int root);                 /* in place, synchronous */
+/* all-reduce of n <= 64 HOST doubles in place (squared error / frame counts: PFNL_COMM_SUM; elapsed time: PFNL_COMM_MAX) */
+int pfnl_comm_allreduce_f64(pfnl_comm* c, double* vals, int n, int op);
+int pfnl_comm_barrier(pfnl_comm* c);
+/* gather of equal per-rank shards of SR frames (device pointers): recv_dev [nranks][count_per_rank]; stream NULL = synchronous */
+int pfnl_comm_allgather(pfnl_comm* c, const float* send_dev, float* recv_dev, size_t count_per_rank, void* stream);
 
 /* ---- measurement ------------------------------------------------------------------------- */
 /* Per-kernel-class HIP-event timing on the launch stream.  enable = 1: every launch of the classes
@@ -197,6 +227,25 @@ int pfnl_op_nonlocal(const float* x, const float* wg_host, const float* bg_host,
 int pfnl_op_nonlocal_bf16(const float* x, const float* wg_host, const float* bg_host,
                      const float* ww_host, const float* bw_host, float* out,
                      int B, int T, int H, int W, void* stream);
+/* The embedded-Gaussian form of the block (reference utils.py:18-71 with nltype 0): same contract as pfnl_op_nonlocal plus
+ * theta / phi 1x1 projections wt, wp [C,C] (row = input channel), bt, bp [C]. */
+int pfnl_op_nonlocal_embedded(const float* x, const float* wg_host, const float* bg_host, const float* ww_host,
+                              const float* bw_host, const float* wt_host, const float* bt_host, const float* wp_host,
+                              const float* bp_host, float* out, int B, int T, int H, int W, void* stream);
+/* conv0 (reference model/pfnl.py:48,61-62): lrelu(conv5x5 'same' 3 -> 64 + b) of every frame.
+ * x [B,T,H,W,3] (device), kernel_host HWIO [5,5,3,64], bias_host [64] or NULL, out [B*T,H,W,64] (device). */
+int pfnl_op_conv0(const float* x, const float* kernel_host, const float* bias_host, float* out, int B, int T, int H, int W,
+                  void* stream);
+/* The tail (reference model/pfnl.py:53,63,76-80): depth_to_space(2) -> convmerge2 3x3 (no activation) -> depth_to_space(2)
+ * (scale 4 only) -> + ResizeBicubic(x[:, T/2]) -> [B,1,sH,sW,3].  merge [B,H,W,48] (device, the output of convmerge1),
+ * x [B,T,H,W,3] (device), kernel_host HWIO [3,3,12,12] (scale 4) or [3,3,12,3] (scale 2), bias_host or NULL. */
+int pfnl_op_tail(const float* merge, const float* x, const float* kernel_host, const float* bias_host, float* out, int B,
+                 int T, int H, int W, int scale, void* stream);
+/* Harness helpers (reference model/pfnl.py:238-242, 254-257), device pointers, async on stream:
+ * windows: frames [F,H,W,3] -> win [count,T,H,W,3], window w slot t = frame clip(first + w + t - T/2, 0, F-1);
+ * quantise: uint8(np.round(np.clip(sr * 255, 0, 255))) (round half to even), n % 4 == 0. */
+int pfnl_op_gather_windows(const float* frames, float* win, int F, int first, int count, int T, int H, int W, void* stream);
+int pfnl_op_quantise_u8(const float* sr, uint8_t* out, size_t n, void* stream);
 /* tf.image.resize_images(method=2) of TF1.12 (model/pfnl.py:63): x [B,H,W,3] -> [B,sH,sW,3]. */
 int pfnl_op_bicubic(const float* x, float* out, int B, int H, int W, int scale, void* stream);
 /* The step before the path in test_video_truth / eval (reference utils.py:95-105,169-192:

@@ -100,13 +100,17 @@ def resize_bicubic_tf1(x: np.ndarray, scale: int) -> np.ndarray:
     return out
 
 
-def nonlocal_block(x: np.ndarray, wg, bg, ww, bw, stabilise: bool = False) -> np.ndarray:
-    """utils.py:18-71 with nltype=1, sub_sample=1.  x [B,h,w,C] -> [B,h,w,C] (no residual, :70)."""
+def nonlocal_block(x: np.ndarray, wg, bg, ww, bw, stabilise: bool = False, theta=None, phi=None) -> np.ndarray:
+    """utils.py:18-71, sub_sample=1.  x [B,h,w,C] -> [B,h,w,C] (no residual, :70).
+    nltype=1 (PFNL's call, model/pfnl.py:58): theta = phi = x.  nltype=0 (embedded Gaussian; the option north_star
+    names): ``theta`` / ``phi`` = (kernel [1,1,C,C], bias [C]) of the two extra 1x1 convs (:31-32, :39-40)."""
     B, h, w, C = x.shape
     g = conv2d_same(x, wg, bg)                           # utils.py:26
     g_x = g.reshape(B, -1, C)                            # :44
-    theta_x = x.reshape(B, -1, C)                        # :34, :45
-    phi_x = x.reshape(B, -1, C).transpose(0, 2, 1)       # :42, :49-50
+    th = x if theta is None else conv2d_same(x, theta[0], theta[1])      # :39-42
+    ph = x if phi is None else conv2d_same(x, phi[0], phi[1])            # :31-34
+    theta_x = th.reshape(B, -1, C)                       # :45
+    phi_x = ph.reshape(B, -1, C).transpose(0, 2, 1)      # :49-50
     f = theta_x @ phi_x                                  # :53
     if stabilise:
         f = f - f.max(axis=-1, keepdims=True)
@@ -132,9 +136,13 @@ def forward(x: np.ndarray, weights: Dict[str, np.ndarray], scale: int = 4, num_b
 
     inp0 = np.concatenate([x[:, i] for i in range(T)], axis=-1)          # :55-56
     inp1 = space_to_depth2(inp0)                                          # :57
+    tp = [None, None]                                                     # nltype 0 option: theta / phi variables present
+    for j, n in enumerate(("theta/theta", "phi/phi")):
+        if f"nlvsr/nlblock_0/{n}/kernel" in Wt:
+            tp[j] = (Wt[f"nlvsr/nlblock_0/{n}/kernel"], Wt[f"nlvsr/nlblock_0/{n}/bias"])
     inp1 = nonlocal_block(inp1, Wt["nlvsr/nlblock_0/g/g/kernel"], Wt["nlvsr/nlblock_0/g/g/bias"],
                           Wt["nlvsr/nlblock_0/w/w/kernel"], Wt["nlvsr/nlblock_0/w/w/bias"],
-                          stabilise=stabilise)                            # :58
+                          stabilise=stabilise, theta=tp[0], phi=tp[1])    # :58
     inp1 = depth_to_space2(inp1)                                          # :59
     inp0 = inp0 + inp1                                                    # :60
     if taps is not None:

@@ -66,7 +66,24 @@ SIGNATURES = {
     "pfnl_op_bicubic": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_blur_decimate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_selftest_mfma": (_i, [_i]),
+    "pfnl_op_nonlocal_embedded": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pfnl_op_conv0": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pfnl_op_tail": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "pfnl_op_gather_windows": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "pfnl_op_quantise_u8": (_i, [_vp, _vp, C.c_size_t, _vp]),
+    "pfnl_comm_get_unique_id": (_i, [_vp]),
+    "pfnl_comm_init_rank": (_i, [_i, _i, _vp, _i, C.POINTER(_vp)]),
+    "pfnl_comm_init_all": (_i, [_i, C.POINTER(_i), C.POINTER(_vp)]),
+    "pfnl_comm_destroy": (_i, [_vp]),
+    "pfnl_comm_rank": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "pfnl_comm_bcast_weights": (_i, [_vp, _vp, _i]),
+    "pfnl_comm_bcast": (_i, [_vp, _vp, C.c_size_t, _i]),
+    "pfnl_comm_allreduce_f64": (_i, [_vp, C.POINTER(C.c_double), _i, _i]),
+    "pfnl_comm_barrier": (_i, [_vp]),
+    "pfnl_comm_allgather": (_i, [_vp, _vp, _vp, C.c_size_t, _vp]),
 }
+COMM_ID_BYTES = 128
+COMM_SUM, COMM_MAX = 0, 1
 
 _lib: Optional[C.CDLL] = None
 
@@ -81,6 +98,10 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
                              f"(make -C pfnl_amd/csrc); there is no CPU fallback")
     try:  # share torch's HIP runtime (same soname) when torch is present
         import torch  # noqa: F401
+        # ... and, for pfnl_comm_*, torch's RCCL build (it is linked against that same runtime); comm.hip dlopens it lazily
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(cand):
+            os.environ.setdefault("PFNL_RCCL_LIB", cand)
     except Exception:  # pragma: no cover - torch is plumbing, not a requirement of the C-ABI
         pass
     lib = C.CDLL(path, mode=C.RTLD_GLOBAL)

@@ -81,10 +81,15 @@ def load_checkpoint(checkpoint_dir: str, geom: PFNLGeometry, step: Optional[int]
     if base is None:
         return None
     prefix = os.path.join(checkpoint_dir, base)
-    if os.path.isfile(prefix + ".npz"):
+    has_npz, has_tf = os.path.isfile(prefix + ".npz"), os.path.isfile(prefix + ".index")
+    # The TF bundle is the reference's format and wins; the .npz sibling is this build's cache of it and is only
+    # preferred when it is at least as new (a re-downloaded checkpoint must not be shadowed by a stale cache).
+    if has_npz and has_tf and os.path.getmtime(prefix + ".npz") < os.path.getmtime(prefix + ".index"):
+        has_npz = False
+    if has_npz:
         with np.load(prefix + ".npz") as z:
             tensors = {k: z[k] for k in z.files}
-    elif os.path.isfile(prefix + ".index"):
+    elif has_tf:
         from . import tfbundle
         tensors = tfbundle.read_bundle(prefix)
     else:
@@ -97,10 +102,16 @@ def save_checkpoint(checkpoint_dir: str, weights: Dict[str, np.ndarray], step: i
     os.makedirs(checkpoint_dir, exist_ok=True)
     base = "{}-{}".format(model_name, int(step))
     prefix = os.path.join(checkpoint_dir, base)
-    if fmt in ("npz", "both"):
-        np.savez(prefix + ".npz", **{k: np.asarray(v, np.float32) for k, v in weights.items()})
     if fmt in ("tf", "both"):
         from . import tfbundle
         tfbundle.write_bundle(prefix, {k: np.asarray(v, np.float32) for k, v in weights.items()})
+    elif os.path.isfile(prefix + ".index"):                   # writing only the cache: drop a stale bundle of the same step
+        for suffix in (".index", ".data-00000-of-00001"):
+            if os.path.isfile(prefix + suffix):
+                os.remove(prefix + suffix)
+    if fmt in ("npz", "both"):                                 # written last: never older than its bundle
+        np.savez(prefix + ".npz", **{k: np.asarray(v, np.float32) for k, v in weights.items()})
+    elif os.path.isfile(prefix + ".npz"):
+        os.remove(prefix + ".npz")
     write_state_file(checkpoint_dir, base)
     return prefix

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/pfnl_hip.h"
+#include "capi_internal.h"
 #include "common.h"
 #include "conv_bf16.h"
 
@@ -20,6 +21,11 @@ int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+}  // namespace
+
+int pfnl_internal_fail(int code, const std::string& msg) { return fail(code, msg); }
+
+namespace {
 
 #define HIPCHK(expr)                                                                         \
     do {                                                                                     \
@@ -70,6 +76,7 @@ struct pfnl_handle {
         hipGraph_t graph;
         hipGraphExec_t exec;
         unsigned long long alloc_gen, cfg_gen;
+        unsigned long long seen_cfg_gen;                          // cfg_gen at the eager run that `seen` counts
     };
     std::vector<GraphEntry> graphs;
     unsigned long long cfg_gen = 0;                           // bumped by finalize_weights / set_option
@@ -93,6 +100,12 @@ struct pfnl_handle {
     std::vector<size_t> off_c1_u16, off_c2a_u16, off_c2b_u16; // ... for conv_wino16_kernel
     std::vector<size_t> off_m1_u;                             // convmerge1 per frame, Winograd pack (cout 48 padded to 64)
     size_t off_m1_w = 0, off_m1_b = 0, off_m2_w = 0, off_m2_b = 0, off_nl_w = 0, off_nl_b = 0, off_zero = 0;
+
+    // embedded-Gaussian option of the non-local block (utils.py nltype 0): optional theta / phi projections
+    std::map<std::string, std::vector<int64_t>> optional;    // tf name -> shape (all four or none)
+    bool nl_theta = false;
+    size_t off_nl_m = 0, off_nl_c = 0;                        // M = Wt Wp^T [CP][CP], c = bt Wp^T [CP]
+    DevBuf Q;                                                 // projected queries [B][N][CP]
 
     // workspace
     DevBuf nl16;                                              // bf16 non-local: split K / V^T operands
@@ -204,7 +217,11 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
     }
     {
         ProfScope ps(h, s, PFNL_K_NL_ATTN);
-        if (h->bf16) {
+        if (h->nl_theta) {   // nltype 0: queries X M + c, keys / values X (fp32 kernel in both precisions)
+            if (h->Q.ensure((size_t)B * N * CP)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
+            HIPCHK(launch_nl_qproj(h->X.p, wd + h->off_nl_m, wd + h->off_nl_c, h->Q.p, B, N, C, s));
+            HIPCHK(launch_nl_attn(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p, B, N, C, s, h->Q.p));
+        } else if (h->bf16) {
             if (h->nl16.ensure((nl_bf16_scratch_halfs(B, N) + 1) / 2)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
             HIPCHK(launch_nl_attn_bf16(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p,
                                        reinterpret_cast<uint16_t*>(h->nl16.p), B, N, C, s));
@@ -438,7 +455,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
 extern "C" {
 
 const char* pfnl_last_error(void) { return g_err.c_str(); }
-int pfnl_version(void) { return 1; }
+int pfnl_version(void) { return 2; }
 
 int pfnl_device_count(int* count) {
     if (!count) return fail(PFNL_ERR_INVALID, "count is NULL");
@@ -462,7 +479,9 @@ int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
         const std::string v(e);
         h->conv_algo = v == "direct" ? 0 : (v == "winograd16" ? 2 : (v == "winograd_tile" ? 1 : 3));
     }
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    // A BLOCKING stream: it is implicitly ordered with the legacy null stream (= torch's default stream) in both
+    // directions, so host-pointer calls and graph replays on it are ordered with the caller's default-stream work.
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamDefault) != hipSuccess) {
         delete h;
         return fail(PFNL_ERR_HIP, "hipStreamCreate failed");
     }
@@ -477,6 +496,12 @@ int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
     add_expected(h, "convmerge2", 3, 12, cfg->scale == 4 ? 12 : 3);
     add_expected(h, "nlblock_0/g/g", 1, C, C);
     add_expected(h, "nlblock_0/w/w", 1, C, C);
+    // utils.py:31-42: nltype 0 / 2 create theta and phi 1x1 convs; PFNL calls the block with nltype 1, where they hold
+    // no variables - accepted when a caller supplies all four (embedded Gaussian), absent otherwise
+    for (const char* n : {"theta/theta", "phi/phi"}) {
+        h->optional[std::string("nlvsr/nlblock_0/") + n + "/kernel"] = {1, 1, C, C};
+        h->optional[std::string("nlvsr/nlblock_0/") + n + "/bias"] = {C};
+    }
     *out = h;
     return 0;
 }
@@ -494,7 +519,7 @@ int pfnl_destroy(pfnl_handle* h) {
         if (g.exec) hipGraphExecDestroy(g.exec);
         if (g.graph) hipGraphDestroy(g.graph);
     }
-    for (DevBuf* b : {&h->wdev, &h->wdev16, &h->nl16, &h->X, &h->Xo, &h->nlp, &h->inp0, &h->inp1, &h->base, &h->pb, &h->merge,
+    for (DevBuf* b : {&h->Q, &h->wdev, &h->wdev16, &h->nl16, &h->X, &h->Xo, &h->nlp, &h->inp0, &h->inp1, &h->base, &h->pb, &h->merge,
                       &h->stage_in, &h->stage_out, &h->scratch})
         b->release();
     delete h;
@@ -509,7 +534,11 @@ int pfnl_set_weight(pfnl_handle* h, const char* tf_name, const float* host, cons
     if (name.size() > 2 && name.compare(name.size() - 2, 2, ":0") == 0) name.resize(name.size() - 2);
     auto it = h->expected.find(name);
     if (it == h->expected.end()) it = h->expected.find("nlvsr/" + name);
-    if (it == h->expected.end()) return fail(PFNL_ERR_INVALID, "unknown tensor name: " + name);
+    if (it == h->expected.end()) {
+        it = h->optional.find(name);
+        if (it == h->optional.end()) it = h->optional.find("nlvsr/" + name);
+        if (it == h->optional.end()) return fail(PFNL_ERR_INVALID, "unknown tensor name: " + name);
+    }
     if ((int)it->second.size() != rank) return fail(PFNL_ERR_INVALID, "rank mismatch for " + name);
     for (int i = 0; i < rank; ++i)
         if (shape[i] != it->second[i]) return fail(PFNL_ERR_INVALID, "shape mismatch for " + name);
@@ -680,6 +709,31 @@ int pfnl_finalize_weights(pfnl_handle* h) {
             blob[h->off_nl_b + co] = (float)acc;
         }
     }
+    {   // optional embedded-Gaussian projections: M = Wt Wp^T, c = bt Wp^T (see nl_qproj_kernel)
+        int have = 0;
+        for (auto& kv : h->optional) have += (int)h->host.count(kv.first);
+        if (have != 0 && have != (int)h->optional.size())
+            return fail(PFNL_ERR_STATE, "nlblock_0 theta/phi: all four tensors (two kernels, two biases) or none");
+        h->nl_theta = have != 0;
+        if (h->nl_theta) {
+            const auto& wt = W("nlblock_0/theta/theta");   // [C][C] (ci, cm)
+            const auto& wp = W("nlblock_0/phi/phi");
+            const auto& bt = Bv("nlblock_0/theta/theta");
+            h->off_nl_m = reserve((size_t)CP * CP);
+            h->off_nl_c = reserve(CP);
+            for (int ci = 0; ci < C; ++ci)
+                for (int cj = 0; cj < C; ++cj) {
+                    double acc = 0.0;
+                    for (int cm = 0; cm < C; ++cm) acc += (double)wt[(size_t)ci * C + cm] * (double)wp[(size_t)cj * C + cm];
+                    blob[h->off_nl_m + (size_t)ci * CP + cj] = (float)acc;
+                }
+            for (int cj = 0; cj < C; ++cj) {
+                double acc = 0.0;
+                for (int cm = 0; cm < C; ++cm) acc += (double)bt[cm] * (double)wp[(size_t)cj * C + cm];
+                blob[h->off_nl_c + cj] = (float)acc;
+            }
+        }
+    }
     {   // bf16 packs of the trunk (precision=bf16)
         std::vector<uint16_t> b16;
         auto reserve16 = [&](size_t n) {
@@ -719,9 +773,18 @@ int pfnl_finalize_weights(pfnl_handle* h) {
 int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes) {
     if (!h || !bytes) return fail(PFNL_ERR_INVALID, "NULL argument");
     if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return fail(PFNL_ERR_INVALID, "bad shape");
-    const size_t T = h->cfg.num_frames, P = (size_t)H * W, N = P / 4;
-    const size_t CP = pfnl::nl_padded_ch(12 * (int)T);
-    size_t f = 2 * B * N * CP + 2 * B * T * P * 64 + 2 * B * P * 64 + B * P * 48;
+    // the same expressions forward_device / pfnl_forward allocate with (every buffer a call with these arguments can
+    // touch under the current options, the host-pointer staging pair included)
+    const size_t T = h->cfg.num_frames, P = (size_t)H * W, N = P / 4, sc = h->cfg.scale;
+    const int C = 12 * (int)T;
+    const size_t CP = pfnl::nl_padded_ch(C);
+    size_t f = 2 * B * N * CP                                   // X, Xo
+             + pfnl::nl_partial_floats(B, (int)N, C)            // nlp
+             + 2 * B * T * P * 64                               // inp0, inp1
+             + 3 * B * P * 64                                   // base, pb, merge (64 floats per pixel)
+             + (size_t)B * T * P * 3 + (size_t)B * P * sc * sc * 3;   // stage_in, stage_out
+    if (h->bf16) f += (pfnl::nl_bf16_scratch_halfs(B, (int)N) + 1) / 2;
+    if (h->nl_theta) f += (size_t)B * N * CP;                   // projected queries (nltype 0)
     *bytes = f * sizeof(float);
     return 0;
 }
@@ -734,19 +797,22 @@ int pfnl_forward(pfnl_handle* h, const void* in, int in_is_device, void* out, in
     if ((H & 1) || (W & 1))
         return fail(PFNL_ERR_INVALID, "H and W must be even (space_to_depth(2), reference model/pfnl.py:57)");
     HIPCHK(hipSetDevice(h->cfg.device_id));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     const int T = h->cfg.num_frames, sc = h->cfg.scale;
     const size_t n_in = (size_t)B * T * H * W * 3, n_out = (size_t)B * H * W * sc * sc * 3;
     const float* din = (const float*)in;
     float* dout = (float*)out;
     const bool want_graph = !h->prof && (h->graph_mode == 2 || (h->graph_mode == 1 && (size_t)B * T * H * W <= 65536));
+    // stream == NULL: device-pointer calls are launched on the LEGACY NULL STREAM itself (what a caller that passes
+    // torch.cuda.current_stream().cuda_stream == 0 means: same-stream ordering with everything it has enqueued and will
+    // enqueue); host-pointer calls and graph replays (a capture cannot run on the null stream) use the handle's stream.
+    hipStream_t s = stream ? (hipStream_t)stream : ((in_is_device && out_is_device && !want_graph) ? (hipStream_t) nullptr : h->stream);
     if (want_graph) {
         if (h->stage_in.ensure(n_in) || h->stage_out.ensure(n_out)) return fail(PFNL_ERR_NOMEM, "staging allocation failed");
         pfnl_handle::GraphEntry* ge = nullptr;
         for (auto& g : h->graphs)
             if (g.B == B && g.H == H && g.W == W) ge = &g;
         if (!ge) {
-            h->graphs.push_back({B, H, W, 0, nullptr, nullptr, 0, 0});
+            h->graphs.push_back({B, H, W, 0, nullptr, nullptr, 0, 0, h->cfg_gen});
             ge = &h->graphs.back();
         }
         if (ge->exec && (ge->alloc_gen != g_alloc_gen || ge->cfg_gen != h->cfg_gen)) {   // buffers moved / weights or options changed
@@ -755,6 +821,10 @@ int pfnl_forward(pfnl_handle* h, const void* in, int in_is_device, void* out, in
             ge->exec = nullptr;
             ge->graph = nullptr;
             ge->seen = 0;
+        }
+        if (!ge->exec && ge->seen_cfg_gen != h->cfg_gen) {   // options / weights changed since the eager run: the path to be
+            ge->seen = 0;                                     // captured has not allocated its workspaces / set its attributes yet
+            ge->seen_cfg_gen = h->cfg_gen;
         }
         if (!ge->exec && ge->seen >= 1) {
             // second call with this shape (the first one ran eagerly: workspaces allocated, kernel attributes set)
@@ -825,6 +895,34 @@ int pfnl_sync(pfnl_handle* h) {
     if (!h) return fail(PFNL_ERR_INVALID, "NULL handle");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(nullptr));                     // device-pointer calls with stream == NULL run on the null stream
+    return 0;
+}
+
+// Weight replica over RCCL (comm.hip holds the communicator): the packed device blobs root -> all.
+int pfnl_comm_bcast_weights(pfnl_comm* c, pfnl_handle* h, int root) {
+    if (!c || !h) return fail(PFNL_ERR_INVALID, "NULL argument");
+    int rank = 0, nranks = 0;
+    if (int e = pfnl_comm_rank(c, &rank, &nranks)) return e;
+    if (root < 0 || root >= nranks) return fail(PFNL_ERR_INVALID, "bad root");
+    if (rank == root && !h->finalized) return fail(PFNL_ERR_STATE, "root has no finalized weights");
+    if (rank != root && !h->finalized) {
+        // the blob layout depends on the geometry only: build it from zeros, then receive root's bytes over it
+        for (auto& kv : h->expected)
+            if (!h->host.count(kv.first)) {
+                HostTensor t;
+                t.shape = kv.second;
+                t.data.assign(numel(t.shape), 0.f);
+                h->host[kv.first] = std::move(t);
+            }
+        if (int e = pfnl_finalize_weights(h)) return e;
+    }
+    double v[4] = {(double)h->wdev.n, -(double)h->wdev.n, (double)h->wdev16.n, -(double)h->wdev16.n};
+    if (int e = pfnl_comm_allreduce_f64(c, v, 4, PFNL_COMM_MAX)) return e;
+    if (v[0] != -v[1] || v[2] != -v[3]) return fail(PFNL_ERR_STATE, "ranks disagree on the weight blob size (geometry / theta-phi option)");
+    if (int e = pfnl_comm_bcast(c, h->wdev.p, h->wdev.n * sizeof(float), root)) return e;
+    if (int e = pfnl_comm_bcast(c, h->wdev16.p, h->wdev16.n * sizeof(float), root)) return e;
+    ++h->cfg_gen;
     return 0;
 }
 

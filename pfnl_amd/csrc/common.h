@@ -95,7 +95,8 @@ int nl_padded_ch(int C);                                      // 32*ceil(C/32)
 hipError_t launch_nl_pack(const float* x, float* X, int B, int T, int H, int W, hipStream_t s);
 size_t nl_partial_floats(int B, int N, int C);               // scratch for the key-split partials (0 if unsplit)
 hipError_t launch_nl_attn(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, int B,
-                          int N, int C, hipStream_t s);
+                          int N, int C, hipStream_t s, const float* Q = nullptr);   // Q: projected queries (nltype 0) or null = X
+hipError_t launch_nl_qproj(const float* X, const float* M, const float* c, float* Q, int B, int N, int C, hipStream_t s);
 int nl_key_splits(int B, int N);
 hipError_t launch_nl_merge(const float* X, const float* Zp, const float* ML, const float* bp, float* Xo, int B, int N, int C, int ks,
                            hipStream_t s);
@@ -109,5 +110,8 @@ hipError_t launch_tail(const float* merge, const float* x, const float* w2, cons
 hipError_t launch_blur_decimate(const float* hr, float* lr, int F, int H, int W, int scale, hipStream_t s);
 hipError_t launch_bicubic(const float* x, float* out, int B, int H, int W, int scale, hipStream_t s);
 hipError_t run_mfma_selftest(int* mismatches);
+hipError_t launch_gather_windows(const float* frames, float* win, int F, int first, int count, int T, size_t frame_floats,
+                                 hipStream_t s);
+hipError_t launch_quantise_u8(const float* sr, uint8_t* out, size_t n, hipStream_t s);
 
 }  // namespace pfnl

@@ -355,3 +355,55 @@ hipError_t run_mfma_selftest(int* mismatches) {
 }
 
 }  // namespace pfnl
+
+// ------------------------------------------------------------------------------------------------
+// Harness helpers (reference model/pfnl.py:238-242, 254-257): the LR sequence is uploaded once; the clamped T-frame
+// windows of a batch are gathered on the device, and the SR frames are quantised to uint8 there (a quarter of the D2H).
+namespace pfnl {
+
+// frames [F][frame_f4 float4] -> win [count][T][frame_f4]: window w, slot t = frame clamp(first + w + t - T/2, 0, F-1)
+__global__ __launch_bounds__(256) void gather_windows_kernel(const f32x4* __restrict__ frames, f32x4* __restrict__ win, int F,
+                                                             int first, int count, int T, size_t frame_f4) {
+    const size_t total = (size_t)count * T * frame_f4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t e = i % frame_f4;
+        const int wt = (int)(i / frame_f4);
+        const int w = wt / T, t = wt - w * T;
+        int f = first + w + t - T / 2;
+        f = f < 0 ? 0 : (f > F - 1 ? F - 1 : f);
+        win[i] = frames[(size_t)f * frame_f4 + e];
+    }
+}
+
+hipError_t launch_gather_windows(const float* frames, float* win, int F, int first, int count, int T, size_t frame_floats,
+                                 hipStream_t s) {
+    if (frame_floats % 4) return hipErrorInvalidValue;
+    const size_t total = (size_t)count * T * (frame_floats / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(gather_windows_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, reinterpret_cast<const f32x4*>(frames),
+                       reinterpret_cast<f32x4*>(win), F, first, count, T, frame_floats / 4);
+    return hipGetLastError();
+}
+
+// uint8(np.round(np.clip(sr * 255, 0, 255))): rintf = round half to even, like np.round
+__global__ __launch_bounds__(256) void quantise_u8_kernel(const f32x4* __restrict__ sr, uint32_t* __restrict__ out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = sr[i];
+        const uint32_t a = (uint32_t)rintf(fminf(fmaxf(v.x * 255.0f, 0.f), 255.f));
+        const uint32_t b = (uint32_t)rintf(fminf(fmaxf(v.y * 255.0f, 0.f), 255.f));
+        const uint32_t c = (uint32_t)rintf(fminf(fmaxf(v.z * 255.0f, 0.f), 255.f));
+        const uint32_t d = (uint32_t)rintf(fminf(fmaxf(v.w * 255.0f, 0.f), 255.f));
+        out[i] = a | (b << 8) | (c << 16) | (d << 24);
+    }
+}
+
+hipError_t launch_quantise_u8(const float* sr, uint8_t* out, size_t n, hipStream_t s) {
+    if (n % 4) return hipErrorInvalidValue;
+    const size_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(quantise_u8_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, reinterpret_cast<const f32x4*>(sr),
+                       reinterpret_cast<uint32_t*>(out), n4);
+    return hipGetLastError();
+}
+
+}  // namespace pfnl

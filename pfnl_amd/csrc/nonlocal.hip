@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
                                                          const float* __restrict__ bp,   // [CP]
                                                          float* __restrict__ Zp,         // [B][ks][N][CP] partial W'^T O (ks > 1)
                                                          float* __restrict__ ML,         // [B][ks][N][2]  partial (max, sum)
+                                                         const float* __restrict__ Q,    // [B][N][CP] queries (nltype 0: X M + c), or X
                                                          int N) {
     constexpr int CT = (C + 31) / 32;
     constexpr int CP = CT * 32;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
     constexpr float LOG2E = 1.4426950408889634f;
     float bq[KSTEPS];
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) bq[s] = Xb[(size_t)qc * CP + 2 * s + kh] * LOG2E;
+    for (int s = 0; s < KSTEPS; ++s) bq[s] = Q[((size_t)b * N + qc) * CP + 2 * s + kh] * LOG2E;
     // The running sum l of the probabilities is not kept in VALU: pad channel C of the key tile in LDS is set to 1,
     // so row C of O^T = V^T P^T accumulates sum_k P (and is rescaled with O).  Where that row lives in the D layout:
     constexpr int LCT = C / 32, LI = C % 32;
@@ -302,8 +303,36 @@ hipError_t launch_nl_unpack(const float* Xo, float* out, int B, int T, int H, in
     return hipGetLastError();
 }
 
+// Embedded-Gaussian option (utils.py nltype 0: theta = X Wt + bt, phi = X Wp + bp): the logits
+//   (X_i Wt + bt) . (X_j Wp + bp) = (X_i M + c) . X_j + (terms constant in j, which cancel in the softmax over j),
+//   M = Wt Wp^T, c = bt Wp^T (folded on the host in fp64) - so only the QUERIES are projected; keys and values stay X.
+__global__ void nl_qproj_kernel(const float* __restrict__ X, const float* __restrict__ M, const float* __restrict__ c,
+                                float* __restrict__ Q, size_t rows, int C, int CP) {
+    const size_t total = rows * CP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % CP);
+        const size_t n = i / CP;
+        float acc = 0.f;
+        if (co < C) {
+            acc = c[co];
+            const float* xr = X + n * CP;
+            for (int ci = 0; ci < C; ++ci) acc = fmaf(xr[ci], M[(size_t)ci * CP + co], acc);
+        }
+        Q[i] = acc;
+    }
+}
+
+hipError_t launch_nl_qproj(const float* X, const float* M, const float* c, float* Q, int B, int N, int C, hipStream_t s) {
+    const int CP = nl_padded_ch(C);
+    const size_t total = (size_t)B * N * CP;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(nl_qproj_kernel, dim3(blocks), dim3(256), 0, s, X, M, c, Q, (size_t)B * N, C, CP);
+    return hipGetLastError();
+}
+
 hipError_t launch_nl_attn(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, int B, int N,
-                          int C, hipStream_t s) {
+                          int C, hipStream_t s, const float* Q) {
+    if (!Q) Q = X;
     const int ks = nl_key_splits(B, N);
     const int CP = nl_padded_ch(C);
     if (ks > 1 && !partial) return hipErrorInvalidValue;
@@ -312,9 +341,9 @@ hipError_t launch_nl_attn(const float* X, float* Xo, const float* Wp, const floa
     dim3 grid((N + 127) / 128, B, ks);
     dim3 block(256);
     switch (C) {
-        case 84: hipLaunchKernelGGL(nl_attn_kernel<84>, grid, block, 0, s, X, Xo, Wp, bp, Zp, ML, N); break;
-        case 60: hipLaunchKernelGGL(nl_attn_kernel<60>, grid, block, 0, s, X, Xo, Wp, bp, Zp, ML, N); break;
-        case 36: hipLaunchKernelGGL(nl_attn_kernel<36>, grid, block, 0, s, X, Xo, Wp, bp, Zp, ML, N); break;
+        case 84: hipLaunchKernelGGL(nl_attn_kernel<84>, grid, block, 0, s, X, Xo, Wp, bp, Zp, ML, Q, N); break;
+        case 60: hipLaunchKernelGGL(nl_attn_kernel<60>, grid, block, 0, s, X, Xo, Wp, bp, Zp, ML, Q, N); break;
+        case 36: hipLaunchKernelGGL(nl_attn_kernel<36>, grid, block, 0, s, X, Xo, Wp, bp, Zp, ML, Q, N); break;
         default: return hipErrorInvalidValue;
     }
     hipError_t e = hipGetLastError();

@@ -75,18 +75,40 @@ def allreduce_stats(sq_err: float, count: float, seconds: float, device: Optiona
 
 
 def sharded_forward(forward_fn: Callable[[np.ndarray], np.ndarray], clips: np.ndarray,
-                    gather_to: Optional[int] = 0) -> Optional[np.ndarray]:
+                    gather_to: Optional[int] = 0, device: Optional[str] = None) -> Optional[np.ndarray]:
     """Run ``forward_fn`` on this rank's contiguous share of ``clips`` [B,T,H,W,3] (every rank holds the
     same array or at least its own slice) and gather the [B,1,sH,sW,3] result on ``gather_to``
-    (None: leave outputs sharded, return the local part)."""
+    (None: leave outputs sharded, return the local part).  The gather is a tensor all_gather of equal-size
+    (zero-padded) shards - RCCL with backend nccl (``device`` = the rank's GPU), gloo on the host."""
+    import torch
     dist = _dist()
     rank, world = dist.get_rank(), dist.get_world_size()
-    lo, hi = shard_range(clips.shape[0], rank, world)
+    B = clips.shape[0]
+    lo, hi = shard_range(B, rank, world)
     local = forward_fn(np.ascontiguousarray(clips[lo:hi])) if hi > lo else None
     if gather_to is None:
         return local
-    parts: List = [None] * world
-    dist.all_gather_object(parts, local)
+    # every rank needs the frame shape to size its (possibly empty) shard: it is a function of the input alone
+    per = max(shard_range(B, r, world)[1] - shard_range(B, r, world)[0] for r in range(world))
+    shape = torch.zeros(4, dtype=torch.int64)
+    if local is not None:
+        shape = torch.tensor(local.shape[1:], dtype=torch.int64)
+    if device is not None:
+        shape = shape.to(device)
+    dist.all_reduce(shape, op=dist.ReduceOp.MAX)
+    frame = tuple(int(v) for v in shape.cpu())
+    pad = torch.zeros((per,) + frame, dtype=torch.float32)
+    if local is not None:
+        pad[:hi - lo] = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32))
+    if device is not None:
+        pad = pad.to(device)
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
     if rank != gather_to:
         return None
-    return np.concatenate([p for p in parts if p is not None], axis=0)
+    outs = []
+    for r in range(world):
+        a, b = shard_range(B, r, world)
+        if b > a:
+            outs.append(parts[r][:b - a].cpu().numpy())
+    return np.concatenate(outs, axis=0)

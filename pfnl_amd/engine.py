@@ -46,7 +46,8 @@ class PFNLEngine:
     # ---- weights (TF names, HWIO float32) --------------------------------
     def load_weights(self, weights: Dict[str, np.ndarray]) -> None:
         check_weights(self.geom, weights)
-        for name, shape in self.geom.weight_shapes():
+        opt = [(n, s) for n, s in self.geom.optional_weight_shapes() if n in weights]    # theta / phi (nltype 0)
+        for name, shape in list(self.geom.weight_shapes()) + opt:
             arr = np.ascontiguousarray(weights[name], dtype=np.float32)
             shp = (C.c_int64 * len(shape))(*shape)
             _capi.check(self._lib.pfnl_set_weight(self._h, name.encode(), arr.ctypes.data_as(C.c_void_p),

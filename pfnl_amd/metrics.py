@@ -53,7 +53,8 @@ def avg_psnr(vid_true, vid_pred, vmin=0.0, vmax=1.0, t_border=2, sp_border=8) ->
     yp = np.stack([rgb2ycbcr(to_uint8(f, vmin, vmax))[..., 0] for f in vid_pred])
     T = yp.shape[0]
     d = (yt - yp)[t_border:T - t_border, sp_border:yp.shape[1] - sp_border, sp_border:yp.shape[2] - sp_border]
-    ps = [20.0 * np.log10(255.0 / np.sqrt(np.mean(f ** 2))) for f in d]
+    with np.errstate(divide="ignore"):                            # identical frames: +inf, like the reference's log10(255/0)
+        ps = [20.0 * np.log10(255.0 / np.sqrt(np.mean(f ** 2))) for f in d]
     return float(np.mean(ps))
 
 

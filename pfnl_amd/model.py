@@ -7,13 +7,22 @@ What is kept:  ``PFNL()`` no-arg ctor and its attributes (:21-37); ``forward(x)`
 ``test_video_truth`` (:203-262), ``test_video_lr`` (:264-320), ``testvideos`` (:322-332) incl. the
 sliding 7-frame window with clamped indices, ``part``/``num_once`` batching, uint8 quantisation and
 the timing print that excludes the first call; ``load`` returning a bool instead of raising
-(base_model.py:231-243); ``save``.  ``train``/``eval``/``build`` exist (so `main.py` imports) but
-raise NotImplementedError — training is out of scope.
+(base_model.py:231-243); ``save``.  ``eval`` runs the reference's validation protocol (model/pfnl.py:94-149) on the
+GPU path; ``train``/``build`` exist (so `main.py` imports) but raise NotImplementedError — training is out of scope
+(SURVEY.md §2).
+
+Weights: the reference initialises every variable randomly and then restores a checkpoint if one exists
+(model/pfnl.py:229-232); a missing checkpoint therefore yields obvious garbage.  Here a model without weights REFUSES to
+run (RuntimeError) unless ``allow_random_init = True`` (or PFNL_ALLOW_RANDOM_INIT=1) opts into a seeded random
+initialisation; a checkpoint that exists but cannot be read or does not match the geometry raises, it is never replaced
+by anything else.
 """
 from __future__ import annotations
 
 import glob
+import json
 import os
+import re
 import time
 from os.path import join
 from typing import Dict, Optional
@@ -23,6 +32,9 @@ import numpy as np
 from . import checkpoint as ckpt
 from .spec import PFNLGeometry
 from .synth import synthetic_weights
+
+
+_STEP_RE = re.compile(r"-(\d+)$")
 
 
 def automkdir(path):                       # reference utils.py:84-86
@@ -92,14 +104,24 @@ class VSR(object):
         if self._engine is not None:
             self._engine.load_weights(self._weights)
 
+    allow_random_init = False      # opt-in: run without a checkpoint on a seeded random initialisation
+    loaded_step: Optional[int] = None
+
     def _get_engine(self):
         if self._engine is None:
             from .engine import PFNLEngine      # raises if libpfnl_hip.so is missing: no CPU path
+            eng = PFNLEngine(self.geometry(), device=self.device)     # raises without a HIP device
             if self._weights is None:
-                # the reference runs tf.global_variables_initializer() before (and regardless of)
-                # load(): model/pfnl.py:229-232.  Same here: Xavier-uniform random init.
+                # the reference runs tf.global_variables_initializer() before (and regardless of) load():
+                # model/pfnl.py:229-232 - its output without a checkpoint is visibly random.  The seeded synthetic set
+                # here is scaled to look like a trained model, so it is only used on explicit request.
+                if not (self.allow_random_init or os.environ.get("PFNL_ALLOW_RANDOM_INIT") == "1"):
+                    eng.close()
+                    raise RuntimeError(
+                        "PFNL has no weights: no checkpoint was loaded from {!r}; call load()/set_weights(), or set "
+                        "allow_random_init = True (PFNL_ALLOW_RANDOM_INIT=1) to run on a seeded random initialisation"
+                        .format(self.save_dir))
                 self._weights = synthetic_weights(self.geometry(), seed=0)
-            eng = PFNLEngine(self.geometry(), device=self.device)
             eng.load_weights(self._weights)
             # build-side knob (the reference has none): PFNL_PRECISION=bf16 runs main.py unchanged on the bf16 path of
             # BASELINE.json configs[3]; default = the reference's fp32 arithmetic
@@ -116,18 +138,21 @@ class VSR(object):
         ckpt.save_checkpoint(checkpoint_dir, self._weights, step, model_name="VSR")
 
     def load(self, sess, checkpoint_dir, step=None):
-        """base_model.py:231-243: prints and returns True/False, never raises on a missing checkpoint."""
+        """base_model.py:231-243: prints and returns True/False; False only when there is NO checkpoint to restore.
+        A checkpoint that is present but unreadable / of another geometry raises (as tf.train.Saver.restore does)."""
         print(" [*] Reading SR checkpoints...")
         try:
             found = ckpt.load_checkpoint(checkpoint_dir, self.geometry(), step=step)
-        except Exception as e:  # corrupt / unreadable files: the reference would also just fail to restore
+        except Exception as e:
             print(" [*] Reading checkpoints... ERROR ({})".format(e))
-            return False
+            raise
         if found is None:
             print(" [*] Reading checkpoints... ERROR")
             return False
         name, weights = found
         self.set_weights(weights)
+        m = _STEP_RE.search(name)
+        self.loaded_step = int(m.group(1)) if m else None
         print(" [*] Reading checkpoints...{} Success".format(name))
         return True
 
@@ -163,42 +188,121 @@ class PFNL(VSR):
         raise NotImplementedError("training graph (model/pfnl.py:82-92) is out of scope of the MI355X inference build")
 
     def eval(self):
-        raise NotImplementedError("validation loop (model/pfnl.py:94-149) is out of scope of the MI355X inference build")
+        """The reference's validation protocol (model/pfnl.py:94-149) on the HIP path: every sequence listed in
+        ``eval_dir`` (one directory per line, HR frames in ``<dir>/truth/*.png``), centre frames 15, 47, 79, ...,
+        clamped 7-frame windows, crop ``[8:8+4*128, 8:8+4*240]``, blur + decimate on the GPU (utils.py:169-192),
+        batches of ``eval_basz`` (a trailing partial batch is dropped, as in the reference), RGB MSE of the SR centre
+        frame against the HR centre frame, ``PSNR = 10 log10(1/mse)`` per clip; prints the averages and appends one JSON
+        line to ``log_dir``.  Returns {"psnr": [...], "mse": [...], "clips": n} (the reference returns None)."""
+        print('Evaluating ...')
+        if self._weights is None:
+            self.load(None, self.save_dir)
+        import torch
+        from . import ops
+        eng = self._get_engine()
+        dev = "cuda:%d" % self.device
+        border = 8
+        in_h, in_w = self.eval_in_size
+        out_h, out_w = in_h * self.scale, in_w * self.scale
+        T = self.num_frames
+        with open(self.eval_dir, 'rt') as f:
+            filenames = f.read().splitlines()
+        gt_list = [sorted(glob.glob(join(f, 'truth', '*.png'))) for f in filenames if f.strip()]
+        center = 15
+        batch_gt, batch_cnt, mse_acc = [], 0, []
+        for gtlist in gt_list:
+            max_frame = len(gtlist)
+            for idx0 in range(center, max_frame, 32):
+                index = np.clip(np.arange(idx0 - T // 2, idx0 + T // 2 + 1), 0, max_frame - 1).tolist()
+                gt = [imread_rgb(gtlist[i]) for i in index]
+                gt = [i[border:out_h + border, border:out_w + border, :].astype(np.float32) / 255.0 for i in gt]
+                if any(g.shape != (out_h, out_w, 3) for g in gt):
+                    raise ValueError("eval frames must be at least {}x{} (crop [{b}:{}+{b}, {b}:{}+{b}]): {}".format(
+                        out_h + border, out_w + border, out_h, out_w, gtlist[index[0]], b=border))
+                batch_gt.append(np.stack(gt, axis=0))
+                if len(batch_gt) == self.eval_basz:
+                    bg = np.stack(batch_gt, 0)                                        # [basz,T,out_h,out_w,3]
+                    hr = torch.from_numpy(bg.reshape((-1,) + bg.shape[2:])).to(dev)
+                    lr = ops.blur_decimate(hr, self.scale).reshape(bg.shape[0], T, in_h, in_w, 3)
+                    sr = eng.forward(lr.contiguous()).cpu().numpy()                   # [basz,1,out_h,out_w,3]
+                    d = sr.astype(np.float64) - bg[:, T // 2:T // 2 + 1].astype(np.float64)
+                    mse_acc.append(np.mean(d * d, axis=(2, 3, 4)))                    # [basz,1]  (model/pfnl.py:90)
+                    batch_gt = []
+                    print('\tEval batch {} - {} ...'.format(batch_cnt, batch_cnt + self.eval_basz))
+                    batch_cnt += self.eval_basz
+        if not mse_acc:
+            raise ValueError("eval: no full batch of {} clips (sequences need > {} frames)".format(self.eval_basz, center))
+        mse_acc = np.concatenate(mse_acc, axis=0)
+        psnr_acc = 10 * np.log10(1.0 / mse_acc)
+        mse_avg = np.mean(mse_acc, axis=0)
+        psnr_avg = np.mean(psnr_acc, axis=0)
+        print('Eval PSNR: {}, MSE: {}'.format(psnr_avg, mse_avg))
+        with open(self.log_dir, 'a+') as f:
+            mse_w = (mse_avg * 1e6).astype(np.int64) / (1e6)
+            psnr_w = (psnr_avg * 1e6).astype(np.int64) / (1e6)
+            f.write('{' + '"Iter": {} , "PSNR": {}, "MSE": {}'.format(self.loaded_step or 0, psnr_w.tolist(), mse_w.tolist()) + '}\n')
+        return {"psnr": psnr_avg.tolist(), "mse": mse_avg.tolist(), "clips": int(mse_acc.shape[0])}
 
     def train(self):
         raise NotImplementedError("training loop (model/pfnl.py:151-199) is out of scope of the MI355X inference build")
 
     # ---- inference harness ------------------------------------------------------------------------
-    def _run_sequence(self, lrs: np.ndarray, save_path: str, part: int):
-        """Shared tail of test_video_truth / test_video_lr (model/pfnl.py:236-262, 293-320)."""
-        max_frame = lrs.shape[0]
+    encode_threads = 4             # PNG encoders running while the GPU works on the next batch
+
+    def _run_sequence(self, lrs, save_path: str, part: int):
+        """Shared tail of test_video_truth / test_video_lr (model/pfnl.py:236-262, 293-320).  ``lrs`` [F,H,W,3] float32:
+        numpy (uploaded ONCE) or already a cuda tensor.  Per batch, all on the device: gather of the clamped T-frame
+        windows (pfnl_op_gather_windows), pfnl_forward, uint8 quantisation (pfnl_op_quantise_u8); the uint8 frames
+        come back over PCIe (a quarter of the float bytes) and are PNG-encoded on worker threads while the next batch
+        runs.  The timed span (H2D-resident input -> quantised frames on the host) is what the reference times around
+        sess.run (:249-253), first batch excluded from the average."""
+        max_frame = int(lrs.shape[0])
         if max_frame == 0:
             print('Save at {}'.format(save_path))
             return
+        import torch
+        from concurrent.futures import ThreadPoolExecutor
+        from . import ops
         if part > max_frame:
             part = max_frame
         num_once = max_frame // part if max_frame % part == 0 else max_frame // part + 1
-        lr_list = sliding_windows(lrs, self.num_frames)
+        eng = self._get_engine()
+        if torch.is_tensor(lrs):
+            frames = lrs.contiguous()
+        else:
+            frames = torch.from_numpy(np.ascontiguousarray(lrs, dtype=np.float32)).to("cuda:%d" % self.device)
         print('Save at {}'.format(save_path))
-        print('{} Inputs With Shape {}'.format(lrs.shape[0], lrs.shape[1:]))
+        print('{} Inputs With Shape {}'.format(max_frame, tuple(frames.shape[1:])))
         all_time = []
-        for i in range(part):
-            batch = lr_list[i * num_once:(i + 1) * num_once]
-            if batch.shape[0] == 0:
-                break
-            st_time = time.time()
-            sr = self.forward(np.ascontiguousarray(batch, dtype=np.float32))
-            all_time.append(time.time() - st_time)
-            for j in range(sr.shape[0]):
-                imsave_rgb(join(save_path, '{:0>4}.png'.format(i * num_once + j)), quantise(sr[j][0]))
+        jobs = []
+        with ThreadPoolExecutor(max_workers=max(1, int(self.encode_threads))) as pool:
+            for i in range(part):
+                first = i * num_once
+                count = min(num_once, max_frame - first)
+                if count <= 0:
+                    break
+                st_time = time.time()
+                win = ops.gather_windows(frames, first, count, self.num_frames)
+                sr = eng.forward(win)
+                u8 = ops.quantise_u8(sr).cpu().numpy()               # synchronises
+                all_time.append(time.time() - st_time)
+                for j in range(count):
+                    jobs.append(pool.submit(imsave_rgb, join(save_path, '{:0>4}.png'.format(first + j)), u8[j][0]))
+            for j in jobs:
+                j.result()
         all_time = np.array(all_time)
-        if max_frame > 0:
-            avg = np.mean(all_time[1:]) if len(all_time) > 1 else float('nan')
-            print('spent {} s in total and {} s in average'.format(np.sum(all_time), avg))
+        avg = np.mean(all_time[1:]) if len(all_time) > 1 else float('nan')
+        print('spent {} s in total and {} s in average'.format(np.sum(all_time), avg))
 
     def _ensure_loaded(self, reuse):
+        """model/pfnl.py:229-232: restore the checkpoint unless the session is being reused.  load() returning False
+        (no checkpoint in save_dir) is tolerated here only if weights were installed some other way - otherwise the
+        first forward raises (see _get_engine)."""
         if not reuse:
-            self.load(None, self.save_dir)
+            if not self.load(None, self.save_dir) and self._weights is None and not (
+                    self.allow_random_init or os.environ.get("PFNL_ALLOW_RANDOM_INIT") == "1"):
+                raise RuntimeError("no checkpoint in {!r} and no weights installed (set_weights / allow_random_init)"
+                                   .format(self.save_dir))
 
     def test_video_truth(self, path, name='result', reuse=False, part=50):
         """HR pngs in <path>/truth -> blur + decimate (utils.py:169-192) -> SR pngs in <path>/<name>."""
@@ -214,7 +318,7 @@ class PFNL(VSR):
         from . import ops
         self._get_engine()                       # fails loudly without a device
         dev = "cuda:%d" % self.device
-        lrs = ops.blur_decimate(torch.from_numpy(np.ascontiguousarray(hr, np.float32)).to(dev), self.scale).cpu().numpy()
+        lrs = ops.blur_decimate(torch.from_numpy(np.ascontiguousarray(hr, np.float32)).to(dev), self.scale)   # stays on the device
         self._run_sequence(lrs, save_path, part)
 
     def test_video_lr(self, path, name='result', reuse=False, part=50):

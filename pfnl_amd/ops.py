@@ -249,3 +249,72 @@ def blur_decimate(hr, scale: int = 4):
 
 def selftest_mfma(device: int = 0) -> None:
     _capi.check(_capi.load_library().pfnl_selftest_mfma(device))
+
+
+def _hp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def nonlocal_embedded(x, wg, bg, ww, bw, wt, bt, wp, bp):
+    """The embedded-Gaussian form (reference utils.py:18-71 with nltype=0: theta = conv(x; wt, bt), phi = conv(x; wp, bp)):
+    x [B,T,H,W,3] (cuda) -> [B,H,W,3T] = stack + depth_to_space(NonLocalBlock_0(space_to_depth(stack)))."""
+    import torch
+    lib = _capi.load_library()
+    B, T, H, W, c = x.shape
+    C_ = 12 * T
+    arrs = [_host(a, "w") for a in (wg, bg, ww, bw, wt, bt, wp, bp)]
+    for a, n in zip(arrs, (C_ * C_, C_) * 4):
+        if a.size != n:
+            raise ValueError("nonlocal_embedded: weight shapes do not match 12*T channels")
+    out = torch.empty((B, H, W, 3 * T), dtype=torch.float32, device=x.device)
+    _capi.check(lib.pfnl_op_nonlocal_embedded(_req(x, "x"), *[_hp(a) for a in arrs], _req(out, "out"), B, T, H, W, _stream(x)))
+    return out
+
+
+def conv0(x, kernel, bias=None):
+    """conv0 (reference model/pfnl.py:48,61-62): x [B,T,H,W,3] (cuda) -> lrelu(conv5x5(frame) + b) [B*T,H,W,64]."""
+    import torch
+    lib = _capi.load_library()
+    B, T, H, W, c = x.shape
+    k, b = _host(kernel, "kernel"), _host(bias, "bias")
+    if k.shape != (5, 5, 3, 64) or c != 3:
+        raise ValueError("conv0: geometry mismatch")
+    out = torch.empty((B * T, H, W, 64), dtype=torch.float32, device=x.device)
+    _capi.check(lib.pfnl_op_conv0(_req(x, "x"), _hp(k), _hp(b), _req(out, "out"), B, T, H, W, _stream(x)))
+    return out
+
+
+def tail(merge, x, kernel, bias, scale: int):
+    """The tail (reference model/pfnl.py:53,63,76-80): merge [B,H,W,48] (cuda), x [B,T,H,W,3] (cuda) -> [B,1,sH,sW,3]."""
+    import torch
+    lib = _capi.load_library()
+    B, T, H, W, c = x.shape
+    k, b = _host(kernel, "kernel"), _host(bias, "bias")
+    if merge.shape != (B, H, W, 48) or k.shape != (3, 3, 12, 12 if scale == 4 else 3):
+        raise ValueError("tail: geometry mismatch")
+    out = torch.empty((B, 1, scale * H, scale * W, 3), dtype=torch.float32, device=x.device)
+    _capi.check(lib.pfnl_op_tail(_req(merge, "merge"), _req(x, "x"), _hp(k), _hp(b), _req(out, "out"), B, T, H, W, scale, _stream(x)))
+    return out
+
+
+def gather_windows(frames, first: int, count: int, num_frames: int):
+    """frames [F,H,W,3] (cuda) -> [count,T,H,W,3]: the clamped sliding windows of frames first..first+count-1
+    (reference model/pfnl.py:238-242)."""
+    import torch
+    lib = _capi.load_library()
+    F, H, W, c = frames.shape
+    if c != 3:
+        raise ValueError("gather_windows expects [F,H,W,3]")
+    out = torch.empty((count, num_frames, H, W, 3), dtype=torch.float32, device=frames.device)
+    _capi.check(lib.pfnl_op_gather_windows(_req(frames, "frames"), _req(out, "out"), F, first, count, num_frames, H, W, _stream(frames)))
+    return out
+
+
+def quantise_u8(sr):
+    """uint8(np.round(np.clip(sr * 255, 0, 255))) on the device (reference model/pfnl.py:254-257)."""
+    import torch
+    lib = _capi.load_library()
+    _req(sr, "sr")
+    out = torch.empty(sr.shape, dtype=torch.uint8, device=sr.device)
+    _capi.check(lib.pfnl_op_quantise_u8(C.c_void_p(sr.data_ptr()), C.c_void_p(out.data_ptr()), sr.numel(), _stream(sr)))
+    return out

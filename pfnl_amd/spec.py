@@ -71,6 +71,16 @@ class PFNLGeometry:
         add("nlblock_0/w/w", 1, self.nl_ch, self.nl_ch)
         return out
 
+    def optional_weight_shapes(self) -> List[Tuple[str, Tuple[int, ...]]]:
+        """theta / phi 1x1 projections of the non-local block (reference utils.py:31-42: created for nltype 0 / 2 only;
+        PFNL's nltype 1 checkpoint has none).  All four present = embedded-Gaussian block, none = the reference's."""
+        C = self.nl_ch
+        out: List[Tuple[str, Tuple[int, ...]]] = []
+        for n in ("theta/theta", "phi/phi"):
+            out.append((f"nlvsr/nlblock_0/{n}/kernel", (1, 1, C, C)))
+            out.append((f"nlvsr/nlblock_0/{n}/bias", (C,)))
+        return out
+
     def num_params(self) -> int:
         n = 0
         for _, s in self.weight_shapes():
@@ -106,5 +116,11 @@ def check_weights(geom: PFNLGeometry, weights: Dict[str, "object"]) -> None:
     for name, shape in geom.weight_shapes():
         if name not in weights:
             raise KeyError(f"missing tensor {name}")
+        if tuple(weights[name].shape) != tuple(shape):
+            raise ValueError(f"{name}: expected shape {shape}, got {tuple(weights[name].shape)}")
+    opt = [(n, s) for n, s in geom.optional_weight_shapes() if n in weights]
+    if opt and len(opt) != len(geom.optional_weight_shapes()):
+        raise KeyError("nlblock_0 theta/phi: all four tensors or none")
+    for name, shape in opt:
         if tuple(weights[name].shape) != tuple(shape):
             raise ValueError(f"{name}: expected shape {shape}, got {tuple(weights[name].shape)}")

@@ -49,6 +49,8 @@ def _worker(rank, world, port, q):
         oracle = pfnl_fast.FastOracle(w, num_block=1)
         clips = synth.uniform_clips(3, 7, 8, 12, seed=5)           # 3 clips over 2 ranks: 2 + 1
         out = pd.sharded_forward(oracle.forward, clips, gather_to=0)
+        one = pd.sharded_forward(oracle.forward, clips[:1], gather_to=0)   # 1 clip over 2 ranks: rank 1's shard is empty
+        assert (one is None) == (rank != 0) and (rank != 0 or np.abs(one - out[:1]).max() < 1e-6)   # (oneDNN: batch-size dependent round-off)
         lo, hi = pd.shard_range(3, rank, world)
         sq, cnt, tmax = pd.allreduce_stats(float(hi - lo), float(hi - lo), 0.1 * (rank + 1))
         q.put((rank, None if out is None else out, sq, cnt, tmax, float(w["nlvsr/conv0/kernel"].sum())))

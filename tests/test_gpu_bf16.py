@@ -109,6 +109,28 @@ def test_forward_bf16_matches_rounded_oracle(geom, B, H, W):
     eng.close()
 
 
+def test_forward_bf16_1080p_against_oracle_subsample():
+    """BASELINE.json configs[3] (1080p, bf16) against the ORACLE with the same rounding points
+    (oracle/pfnl_fast.py trunk_dtype="bf16"): every 8th HR pixel + a dense 64x64 crop, generated once in the build
+    container (tools/make_golden_1080p.py); and against the fp32 oracle subsample."""
+    from conftest import load_golden
+    gd = load_golden("cfg4_1080p_stride8")
+    seed, stride, cy, cx, cs = (int(v) for v in gd["meta"])
+    geom = PFNLGeometry()
+    eng = PFNLEngine(geom, device=0)
+    eng.load_weights(synth.synthetic_weights(geom, seed=0))
+    eng.set_option("precision", "bf16")
+    y = eng.forward(synth.uniform_clips(1, 7, 270, 480, seed=seed))[0, 0]
+    sub, crop = y[::stride, ::stride], y[cy:cy + cs, cx:cx + cs]
+    p_same = min(synth.psnr(sub, gd["y_bf16mode"]), synth.psnr(crop, gd["y_bf16mode_crop"]))
+    p_fp32 = min(synth.psnr(sub, gd["y_fp32"]), synth.psnr(crop, gd["y_fp32_crop"]))
+    print(f"1080p bf16: PSNR vs bf16-mode oracle {p_same:.1f} dB, vs fp32 oracle {p_fp32:.1f} dB, "
+          f"max|d| {np.abs(sub - gd['y_bf16mode']).max():.2e}")
+    assert p_same > 60.0, p_same
+    assert p_fp32 > 55.0, p_fp32
+    eng.close()
+
+
 @pytest.mark.parametrize("B,H,W", [(4, 128, 128), (1, 270, 480)])
 def test_forward_bf16_full_size_against_fp32_build(B, H, W):
     """BASELINE.json configs[1] / configs[3] sizes: the CPU oracle needs minutes there, so the bf16 trunk is held against

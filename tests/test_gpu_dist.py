@@ -1,0 +1,164 @@
+"""The N > 1 path with the REAL per-rank compute (PFNLEngine on the GPU) and the RCCL entry points of the C-ABI.
+
+A 1-GPU box cannot give two RCCL ranks a device each (RCCL rejects duplicate devices), so
+  * the two-rank tests stack both ranks on the one GPU and move bytes over gloo (the sharding, gather, weight replica and
+    bench.py's N>1 branch are exactly the code the 8-GPU run uses; only the transport differs), and
+  * pfnl_comm_* is exercised on RCCL itself with a single-rank communicator (every entry point makes its real RCCL call),
+    plus a two-rank RCCL test that runs when two devices are visible.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from pfnl_amd import dist as pd  # noqa: E402
+from pfnl_amd import synth  # noqa: E402
+from pfnl_amd.spec import PFNLGeometry  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from pfnl_amd.engine import PFNLEngine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = PFNLGeometry(num_block=2)
+        w = pd.broadcast_weights(g, synth.synthetic_weights(g, seed=3) if rank == 0 else None, src=0)
+        eng = PFNLEngine(g, device=0)                                  # both ranks on the one visible GPU
+        eng.load_weights(w)
+        clips = synth.uniform_clips(5, 7, 16, 24, seed=5)              # 5 clips over 2 ranks: 3 + 2
+        out = pd.sharded_forward(eng.forward, clips, gather_to=0)
+        one = pd.sharded_forward(eng.forward, clips[:1], gather_to=0)  # 1 clip over 2 ranks: rank 1 has an empty shard
+        q.put((rank, out, one))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_engine_sharded_equals_unsharded():
+    import torch.multiprocessing as mp
+    from pfnl_amd.engine import PFNLEngine
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = PFNLGeometry(num_block=2)
+    eng = PFNLEngine(g, device=0)
+    eng.load_weights(synth.synthetic_weights(g, seed=3))
+    clips = synth.uniform_clips(5, 7, 16, 24, seed=5)
+    ref = eng.forward(clips)
+    assert res[1][1] is None and res[1][2] is None
+    assert np.array_equal(res[0][1], ref)                               # sharded == unsharded, bit for bit
+    assert np.array_equal(res[0][2], ref[:1])
+    eng.close()
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N>1 branch end to end (torch.distributed.run, two ranks, gloo transport): one JSON line, n_gpus 2."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--no-secondary"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8 and rec["scaling"] == "weak"
+    assert rec["value"] > 0 and rec["steps"] == 2 and "cpu_baseline" not in rec
+
+
+def test_comm_single_rank_rccl():
+    """pfnl_comm_* on RCCL itself (one rank): unique id, init, weight broadcast into a handle that never saw
+    pfnl_set_weight, scalar reductions, gather, barrier."""
+    from pfnl_amd.comm import Comm
+    from pfnl_amd.engine import PFNLEngine
+    g = PFNLGeometry(num_block=1)
+    uid = Comm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    c = Comm(1, 0, 0, uid)
+    eng = PFNLEngine(g, device=0)
+    eng.load_weights(synth.synthetic_weights(g, seed=1))
+    x = synth.uniform_clips(1, 7, 8, 12, seed=2)
+    y0 = eng.forward(x)
+    c.bcast_weights(eng, root=0)                                        # root == self: weights unchanged
+    assert np.array_equal(eng.forward(x), y0)
+    v = c.allreduce([1.5, -2.0, 7.0], "sum")
+    assert np.array_equal(v, [1.5, -2.0, 7.0])
+    assert np.array_equal(c.allreduce([3.25], "max"), [3.25])
+    c.barrier()
+    t = torch.arange(24, dtype=torch.float32, device="cuda").reshape(2, 12)
+    got = c.allgather(t)
+    assert got.shape == (1, 2, 12) and torch.equal(got[0], t)
+    with pytest.raises(Exception):
+        c.allreduce(np.zeros(65), "sum")                                # n <= 64
+    c.close()
+    eng.close()
+
+
+def _rccl_worker(rank, world, uid, q):
+    sys.path.insert(0, ROOT)
+    from pfnl_amd.comm import Comm
+    from pfnl_amd.engine import PFNLEngine
+    g = PFNLGeometry(num_block=1)
+    torch.cuda.set_device(rank)
+    c = Comm(world, rank, rank, uid)
+    eng = PFNLEngine(g, device=rank)
+    if rank == 0:
+        eng.load_weights(synth.synthetic_weights(g, seed=1))
+    c.bcast_weights(eng, root=0)                                        # rank 1 never calls pfnl_set_weight
+    x = synth.uniform_clips(2, 7, 8, 12, seed=2)
+    y = eng.forward(x[rank:rank + 1])
+    s = c.allreduce([float(rank + 1), 1.0], "sum")
+    m = c.allreduce([0.1 * (rank + 1)], "max")
+    q.put((rank, y, s.tolist(), m.tolist()))
+    c.close()
+    eng.close()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="two RCCL ranks need two devices")
+def test_comm_two_ranks_rccl():
+    import torch.multiprocessing as mp
+    from pfnl_amd.comm import Comm
+    from pfnl_amd.engine import PFNLEngine
+    uid = Comm.unique_id()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, uid, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = PFNLGeometry(num_block=1)
+    eng = PFNLEngine(g, device=0)
+    eng.load_weights(synth.synthetic_weights(g, seed=1))
+    ref = eng.forward(synth.uniform_clips(2, 7, 8, 12, seed=2))
+    for r in res:
+        assert np.array_equal(r[1], ref[r[0]:r[0] + 1])
+        assert r[2] == [3.0, 2.0] and abs(r[3][0] - 0.2) < 1e-12

@@ -1,6 +1,8 @@
 """End-to-end parity of pfnl_forward (through the C-ABI / PFNLEngine / the drop-in PFNL class) on a
 real MI355X against the committed golden vectors and the oracle, plus size-independent properties at
 BASELINE.json's full single-GPU size (7x128x128 -> 512x512, batch 4)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -15,7 +17,7 @@ from pfnl_amd.engine import PFNLEngine  # noqa: E402
 from pfnl_amd.spec import PFNLGeometry  # noqa: E402
 
 PSNR_TOL_DB = 0.01          # BASELINE.json: |dPSNR| <= 0.01 dB (fp32)
-ABS_TOL = 2e-4              # direct element-wise bound on [0,1]-scale outputs (expect ~1e-5)
+ABS_TOL = 5e-5              # direct element-wise bound on [0,1]-scale outputs (observed ~1e-5)
 
 _engines = {}
 
@@ -156,10 +158,96 @@ def test_test_video_truth_harness(tmp_path):
     assert diff.max() <= 1 and (diff > 0).mean() < 2e-3
 
 
-def test_full_size_properties_and_sampled_parity():
-    """BASELINE.json configs[1]: 7x128x128 -> 512x512, batch 4.  The fp64 oracle is too slow here; use
-    (a) the fp32 fast oracle on ONE clip, (b) batch independence, (c) bic[::4,::4] anchoring through
-    zeroed tail weights is covered above; here: determinism + permutation equivariance over clips."""
+def test_harness_on_device_is_byte_identical(tmp_path):
+    """The device-side harness (frames uploaded once, windows gathered and frames quantised on the GPU, PNGs encoded on
+    worker threads) writes exactly the bytes of the host restatement of model/pfnl.py:236-258 around the same forward."""
+    from PIL import Image
+    from model.pfnl import PFNL
+    from pfnl_amd import model as M
+    rng = np.random.default_rng(12)
+    lr_u8 = rng.integers(0, 256, size=(9, 12, 20, 3), dtype=np.uint8)
+    seq = tmp_path / "seqB"
+    (seq / "blur4").mkdir(parents=True)
+    for i, im in enumerate(lr_u8):
+        Image.fromarray(im).save(seq / "blur4" / f"{i:04d}.png")
+    geom = PFNLGeometry(num_block=1)
+    m = PFNL()
+    m.num_block = 1
+    m.save_dir = str(tmp_path / "none")
+    m.set_weights(synth.synthetic_weights(geom, seed=0))
+    m.test_video_lr(str(seq), name="out", part=4)                  # 9 frames, part 4 -> num_once 3
+    got = np.stack([np.asarray(Image.open(p)) for p in sorted((seq / "out").glob("*.png"))])
+    lrs = (lr_u8 / 255.).astype(np.float32)
+    want = M.quantise(engine_for(geom).forward(np.ascontiguousarray(M.sliding_windows(lrs, 7)))[:, 0])
+    assert got.shape == want.shape == (9, 48, 80, 3)
+    assert np.array_equal(got, want)
+    m3 = PFNL()
+    m3.num_block = 1
+    m3.save_dir = str(tmp_path / "none")
+    with pytest.raises(RuntimeError, match="no checkpoint"):      # ADVICE r1: no silent trained-looking weights
+        m3.test_video_lr(str(seq), name="out2")
+    m3.allow_random_init = True                                   # ... unless asked for
+    m3.test_video_lr(str(seq), name="out2", part=100)
+    assert len(list((seq / "out2").glob("*.png"))) == 9
+
+
+def test_eval_protocol(tmp_path):
+    """PFNL.eval (reference model/pfnl.py:94-149): centre frames 15 + 32k, clamped windows, crop [8:8+4h, 8:8+4w], GPU
+    blur + decimate, batches of eval_basz (partial batch dropped), RGB PSNR, one JSON line appended to log_dir - against
+    the same chain through the oracle."""
+    import json
+    from PIL import Image
+    from model.pfnl import PFNL
+    rng = np.random.default_rng(99)
+    geom = PFNLGeometry(num_block=1)
+    w = synth.synthetic_weights(geom, seed=0)
+    seqs = []
+    for sname, nfr in (("a", 17), ("b", 50), ("c", 16)):          # clips at 15 | 15, 47 | 15  -> 4 clips, eval_basz 2 -> 2 batches
+        d = tmp_path / sname / "truth"
+        d.mkdir(parents=True)
+        yy, xx = np.mgrid[0:80, 0:112]
+        fr = []
+        for i in range(nfr):
+            img = 127 + 90 * np.sin(0.11 * (yy + i) + rng.random()) * np.cos(0.07 * (xx - 2 * i))
+            img = np.stack([img, img[::-1], img[:, ::-1]], -1) + rng.normal(0, 6, size=(80, 112, 3))
+            fr.append(np.clip(img, 0, 255).astype(np.uint8))
+            Image.fromarray(fr[-1]).save(d / f"{i:03d}.png")
+        seqs.append((str(tmp_path / sname), np.stack(fr)))
+    lst = tmp_path / "val.txt"
+    lst.write_text("\n".join(p for p, _ in seqs) + "\n")
+    m = PFNL()
+    m.num_block = 1
+    m.eval_in_size = [16, 24]                                      # crop 64 x 96 out of 80 x 112 frames
+    m.eval_basz = 2
+    m.eval_dir = str(lst)
+    m.log_dir = str(tmp_path / "log.txt")
+    m.save_dir = str(tmp_path / "ck")
+    m.set_weights(w)
+    m.save(None, m.save_dir, 4321)
+    m2 = PFNL()
+    for k in ("num_block", "eval_in_size", "eval_basz", "eval_dir", "log_dir", "save_dir"):
+        setattr(m2, k, getattr(m, k))
+    res = m2.eval()                                                # loads VSR-4321 itself, like the reference
+    assert res["clips"] == 4
+    mses = []
+    for _, fr in seqs:
+        for idx0 in range(15, fr.shape[0], 32):
+            idx = np.clip(np.arange(idx0 - 3, idx0 + 4), 0, fr.shape[0] - 1)
+            gt = fr[idx][:, 8:72, 8:104].astype(np.float32) / 255.0
+            lr = synth.blur_decimate(gt, 4)
+            sr = pfnl_spec.forward(lr[None], w, num_block=1)[0, 0]
+            mses.append(np.mean((sr - gt[3].astype(np.float64)) ** 2))
+    mses = np.array(mses)
+    assert abs(res["mse"][0] - mses.mean()) < 1e-7
+    assert abs(res["psnr"][0] - np.mean(10 * np.log10(1 / mses))) < 1e-3
+    line = json.loads(open(m.log_dir).read().strip().splitlines()[-1])
+    assert line["Iter"] == 4321 and abs(line["PSNR"][0] - res["psnr"][0]) < 2e-6 and len(line["MSE"]) == 1
+
+
+def test_full_size_all_clips_against_oracle():
+    """BASELINE.json configs[1]: 7x128x128 -> 512x512, batch 4 - EVERY clip against the fp32 oracle (16 host threads,
+    a few seconds per clip), plus determinism and permutation equivariance over clips (clips are independent units)."""
+    import torch as _t
     geom = PFNLGeometry()
     eng = engine_for(geom)
     lr, gt = synth.moving_field_clips(2, 7, 128, 128, seed=4321)
@@ -167,10 +255,96 @@ def test_full_size_properties_and_sampled_parity():
     y = eng.forward(x)
     assert y.shape == (4, 1, 512, 512, 3) and np.isfinite(y).all()
     assert np.array_equal(eng.forward(x[::-1].copy()), y[::-1])
-    ref = pfnl_fast.FastOracle(synth.synthetic_weights(geom, 0)).forward(x[:1])
-    assert np.abs(y[:1] - ref).max() < ABS_TOL
-    d = abs(synth.psnr(y[0, 0], gt[0]) - synth.psnr(ref[0, 0], gt[0]))
-    assert d <= PSNR_TOL_DB, d
+    nthr = _t.get_num_threads()
+    _t.set_num_threads(min(16, os.cpu_count() or 1))
+    try:
+        ref = pfnl_fast.FastOracle(synth.synthetic_weights(geom, 0)).forward(x)
+    finally:
+        _t.set_num_threads(nthr)
+    err = np.abs(y - ref).max(axis=(1, 2, 3, 4))
+    print("configs[1] max|hip - oracle| per clip:", err)
+    assert err.max() < ABS_TOL, err
+    for b in range(2):
+        d = abs(synth.psnr(y[b, 0], gt[b]) - synth.psnr(ref[b, 0], gt[b]))
+        assert d <= PSNR_TOL_DB, d
+
+
+def test_configs4_geometry_full_size():
+    """BASELINE.json configs[4]: 2x SR, 5 frames, 64x64 -> 128x128, 20 blocks (N = 1024, C = 60: MFMA tile edges of the
+    non-local block; build-defined tail, pfnl_amd/spec.py) against the fp32 oracle, both conv2_i schedules."""
+    geom = PFNLGeometry(num_frames=5, scale=2, num_block=20)
+    w = synth.synthetic_weights(geom, seed=0)
+    eng = PFNLEngine(geom, device=0)
+    eng.load_weights(w)
+    x = np.concatenate([synth.moving_field_clips(1, 5, 64, 64, scale=2, seed=31)[0], synth.uniform_clips(1, 5, 64, 64, seed=32)], 0)
+    ref = pfnl_fast.FastOracle(w, 5, 2, 20).forward(x)
+    for B in (1, 2):
+        y = eng.forward(x[:B])
+        assert y.shape == (B, 1, 128, 128, 3)
+        assert np.abs(y - ref[:B]).max() < ABS_TOL, (B, np.abs(y - ref[:B]).max())
+    eng.close()
+
+
+def test_1080p_fp32_against_oracle_subsample():
+    """BASELINE.json configs[3] geometry in fp32 against the ORACLE: tests/golden/cfg4_1080p_stride8.npz holds every 8th
+    HR pixel (and a dense 64x64 crop) of oracle/pfnl_fast.py's 1080p output, generated once in the build container
+    (tools/make_golden_1080p.py: the oracle needs minutes at this size)."""
+    gd = load_golden("cfg4_1080p_stride8")
+    seed, stride, cy, cx, cs = (int(v) for v in gd["meta"])
+    geom = PFNLGeometry()
+    eng = engine_for(geom)
+    x = synth.uniform_clips(1, 7, 270, 480, seed=seed)
+    y = eng.forward(x)[0, 0]
+    assert y.shape == (1080, 1920, 3) and np.isfinite(y).all()
+    e1 = np.abs(y[::stride, ::stride] - gd["y_fp32"]).max()
+    e2 = np.abs(y[cy:cy + cs, cx:cx + cs] - gd["y_fp32_crop"]).max()
+    print("1080p fp32 max|hip - oracle|: subsample %.3g, crop %.3g" % (e1, e2))
+    assert e1 < ABS_TOL and e2 < ABS_TOL, (e1, e2)
+
+
+def test_embedded_gaussian_option_forward():
+    """The theta/phi option north_star names (reference utils.py:31-42, nltype 0): optional nlblock_0/{theta,phi} variables
+    switch the non-local block to theta(x) phi(x)^T logits; whole forward against the fp64 spec written as the reference."""
+    geom = PFNLGeometry(num_block=1)
+    w = synth.synthetic_weights(geom, seed=0)
+    rng = np.random.default_rng(5)
+    C = geom.nl_ch
+    for n, sc in (("theta/theta", 0.12), ("phi/phi", 0.12)):
+        w[f"nlvsr/nlblock_0/{n}/kernel"] = (rng.normal(size=(1, 1, C, C)) * sc).astype(np.float32)
+        w[f"nlvsr/nlblock_0/{n}/bias"] = (rng.normal(size=C) * 0.05).astype(np.float32)
+    eng = PFNLEngine(geom, device=0)
+    eng.load_weights(w)
+    x = synth.uniform_clips(2, 7, 12, 20, seed=3)
+    y = eng.forward(x)
+    taps = {}
+    ref = pfnl_spec.forward(x, w, num_block=1, taps=taps)
+    assert np.abs(eng.tap("nl_out", 2, 12, 20) - taps["nl_out"]).max() < 5e-5
+    assert np.abs(y - ref).max() < ABS_TOL
+    w1 = {k: v for k, v in w.items() if "theta" not in k and "phi" not in k}
+    assert np.abs(pfnl_spec.forward(x, w1, num_block=1) - ref).max() > 1e-4       # the option changes the result
+    bad = dict(w1)
+    bad["nlvsr/nlblock_0/theta/theta/kernel"] = w["nlvsr/nlblock_0/theta/theta/kernel"]
+    with pytest.raises(KeyError):
+        eng.load_weights(bad)                                                       # all four or none
+    eng.close()
+
+
+def test_default_stream_ordering_without_synchronize():
+    """a device-tensor forward on torch's default stream (cuda_stream == 0 -> stream NULL in the ABI)
+    must be ordered with the caller's stream in both directions: producer kernel -> forward -> .cpu(), no explicit
+    synchronize anywhere, graph off (the eager path)."""
+    geom = PFNLGeometry(num_block=2)
+    eng = engine_for(geom)
+    eng.set_option("graph", "off")
+    x = synth.uniform_clips(2, 7, 64, 96, seed=21)
+    want = eng.forward(x)
+    xd = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    for _ in range(5):
+        big = torch.empty(64 << 20, device="cuda").normal_()         # keeps the default stream busy before the input exists
+        xin = (xd + big[:xd.numel()].view_as(xd) * 0.0).contiguous()  # input produced on the default stream, not yet complete
+        got = eng.forward(xin).cpu().numpy()                          # .cpu() is ordered on the default stream only
+        assert np.array_equal(got, want)
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
@@ -195,19 +369,6 @@ def test_random_geometry_fuzz(seed):
         assert y.shape == ref.shape
         assert np.abs(y - ref).max() < ABS_TOL, (algo, T, scale, nb, B, H, W, np.abs(y - ref).max())
     eng.close()
-
-
-def test_1080p_single_clip_runs():
-    """BASELINE.json configs[3] geometry in fp32: 7x270x480 -> 1080x1920, batch 1 (N = 32400: 16 | N, 32 !| N)."""
-    geom = PFNLGeometry()
-    eng = engine_for(geom)
-    x = synth.uniform_clips(1, 7, 270, 480, seed=77)
-    y = eng.forward(x)
-    assert y.shape == (1, 1, 1080, 1920, 3) and np.isfinite(y).all()
-    # bicubic anchor: with the trunk residual removed the skip is exact at ::4; here just a sanity band
-    assert abs(float(y.mean()) - float(x[:, 3].mean())) < 0.2
-    # batch independence at this size: a 64x480 strip cannot be compared (non-local is global), so compare determinism
-    assert np.array_equal(eng.forward(x), y)
 
 
 def test_profile_counts_full_and_sampled():

@@ -251,3 +251,81 @@ def test_ws_modes_random_geometries():
     spec.loader.exec_module(mod)
     n, worst = mod.run(seed=7, seconds=60.0, max_iters=25)
     assert n == 25 and worst < 3e-5
+
+
+# ---- round 2: op hooks for the head and the tail, the embedded-Gaussian block, the harness helpers ------------------
+
+@pytest.mark.parametrize("B,T,H,W", [(1, 7, 16, 24), (2, 3, 10, 38), (1, 5, 34, 18), (1, 7, 2, 2)])
+def test_conv0_op(B, T, H, W):
+    """conv0 (reference model/pfnl.py:48,61-62): lrelu(conv5x5 'same' 3->64 + b) per frame vs the fp64 spec."""
+    rng = np.random.default_rng(B * 1000 + H * 10 + W)
+    x = rng.random((B, T, H, W, 3), dtype=np.float32)
+    k = (rng.normal(size=(5, 5, 3, 64)) / np.sqrt(75.0)).astype(np.float32)
+    b = (rng.normal(size=64) * 0.1).astype(np.float32)
+    got = ops.conv0(dev(x), k, b).cpu().numpy()
+    ref = pfnl_spec.lrelu(pfnl_spec.conv2d_same(x.reshape(B * T, H, W, 3).astype(np.float64), k.astype(np.float64), b.astype(np.float64)))
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 2e-6 * max(1.0, np.abs(ref).max())
+    delta = np.zeros((5, 5, 3, 64), np.float32)                       # pure data movement: a shifted delta kernel is bit-exact
+    delta[1, 3, 2, 7] = 1.0
+    got = ops.conv0(dev(x), delta, None).cpu().numpy()
+    xp = np.pad(x.reshape(B * T, H, W, 3), ((0, 0), (2, 2), (2, 2), (0, 0)))
+    assert np.array_equal(got[..., 7], xp[:, 1:1 + H, 3:3 + W, 2])
+    assert not got[..., :7].any() and not got[..., 8:].any()
+
+
+@pytest.mark.parametrize("B,T,H,W,scale", [(1, 7, 8, 12, 4), (2, 5, 6, 20, 2), (1, 3, 17, 5, 4), (1, 7, 1, 1, 4)])
+def test_tail_op(B, T, H, W, scale):
+    """d2s -> convmerge2 (no activation) -> d2s (4x) -> + legacy bicubic of the centre frame (reference model/pfnl.py:53,63,
+    76-80) vs the fp64 spec, op for op."""
+    rng = np.random.default_rng(H * 31 + W)
+    merge = rng.normal(size=(B, H, W, 48)).astype(np.float32)
+    x = rng.random((B, T, H, W, 3), dtype=np.float32)
+    co = 12 if scale == 4 else 3
+    k = (rng.normal(size=(3, 3, 12, co)) / np.sqrt(108.0)).astype(np.float32)
+    b = (rng.normal(size=co) * 0.1).astype(np.float32)
+    got = ops.tail(dev(merge), dev(x), k, b, scale).cpu().numpy()
+    o = pfnl_spec.conv2d_same(pfnl_spec.depth_to_space2(merge.astype(np.float64)), k.astype(np.float64), b.astype(np.float64))
+    if scale == 4:
+        o = pfnl_spec.depth_to_space2(o)
+    ref = (o + pfnl_spec.resize_bicubic_tf1(x[:, T // 2].astype(np.float64), scale))[:, None]
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 5e-6
+
+
+@pytest.mark.parametrize("B,T,H,W", [(1, 7, 16, 16), (2, 3, 6, 10), (1, 5, 12, 22)])
+def test_nonlocal_embedded_gaussian(B, T, H, W):
+    """reference utils.py:18-71 with nltype=0 (theta / phi 1x1 projections in front of the affinity) + the residual of
+    model/pfnl.py:55-60, against the fp64 spec written as the reference (two convs, full N x N affinity)."""
+    rng = np.random.default_rng(T * 7 + H)
+    C = 12 * T
+    x = rng.random((B, T, H, W, 3), dtype=np.float32)
+    mk = lambda sc: (rng.normal(size=(1, 1, C, C)) * sc).astype(np.float32)      # noqa: E731
+    mb = lambda: (rng.normal(size=C) * 0.05).astype(np.float32)                  # noqa: E731
+    wg, ww, wt, wp = mk(0.1), mk(0.1), mk(0.15), mk(0.15)
+    bg, bw, bt, bp = mb(), mb(), mb(), mb()
+    got = ops.nonlocal_embedded(dev(x), wg, bg, ww, bw, wt, bt, wp, bp).cpu().numpy()
+    stack = np.concatenate([x[:, t] for t in range(T)], -1).astype(np.float64)
+    x1 = pfnl_spec.space_to_depth2(stack)
+    f = lambda a: a.astype(np.float64)                                           # noqa: E731
+    z = pfnl_spec.nonlocal_block(x1, f(wg), f(bg), f(ww), f(bw), theta=(f(wt), f(bt)), phi=(f(wp), f(bp)))
+    ref = stack + pfnl_spec.depth_to_space2(z)
+    assert np.abs(got - ref).max() < 2e-5
+    plain = ops.nonlocal_residual(dev(x), wg, bg, ww, bw).cpu().numpy()
+    assert np.abs(plain - ref).max() > 1e-4                                      # theta/phi matter
+
+
+def test_gather_windows_and_quantise():
+    """reference model/pfnl.py:238-242 (clamped windows) and :254-257 (uint8 quantisation) on the device: bit-exact
+    against the host restatements."""
+    from pfnl_amd import model as M
+    rng = np.random.default_rng(9)
+    for F, T, H, W in ((5, 7, 4, 6), (1, 7, 2, 2), (9, 3, 6, 10), (12, 5, 8, 2)):
+        fr = rng.random((F, H, W, 3), dtype=np.float32)
+        want = M.sliding_windows(fr, T)
+        for first, count in ((0, F), (F // 2, F - F // 2), (F - 1, 1)):
+            got = ops.gather_windows(dev(fr), first, count, T).cpu().numpy()
+            assert np.array_equal(got, want[first:first + count])
+    sr = (rng.random((2, 1, 8, 12, 3), dtype=np.float32) * 1.4 - 0.2)
+    sr.ravel()[:8] = [0.5 / 255, 1.5 / 255, 2.5 / 255, 254.5 / 255, 1.0, 0.0, -1.0, 2.0]      # ties, ends, out of range
+    assert np.array_equal(ops.quantise_u8(dev(sr)).cpu().numpy(), M.quantise(sr))

@@ -31,9 +31,10 @@ def test_class_surface_matches_reference():
     assert [(k, p.default) for k, p in sig(m.testvideos)][1:] == [('start', 0), ('name', 'pfnl')]
     assert [k for k, _ in sig(m.load)] == ['sess', 'checkpoint_dir', 'step']
     assert [k for k, _ in sig(m.save)] == ['sess', 'checkpoint_dir', 'step']
-    for fn in (m.train, m.eval, m.build):
+    for fn in (m.train, m.build):
         with pytest.raises(NotImplementedError):
             fn()
+    assert [k for k, _ in sig(m.eval)] == []                     # eval() takes no arguments (model/pfnl.py:94)
     assert PFNL.testvideo is PFNL.test_video_lr
 
 
@@ -147,3 +148,152 @@ def test_metrics_known_answers():
     vp[:2] += 0.5                                   # spatial / temporal borders only
     assert mt.avg_psnr(vt, np.clip(vp, 0, 2)) == float("inf") or mt.avg_psnr(vt, np.clip(vp, 0, 2)) > 100
     assert mt.ssim(a[..., 0], 255 - a[..., 0]) < 0.1
+
+
+# ---- round 2 -------------------------------------------------------------------------------------------------------
+
+def test_ssim_matches_the_reference_implementation():
+    """metrics.ssim against outputs of the REFERENCE's own modules/SSIM_Index.compute_ssim, generated in the build
+    container by tools/make_metric_golden.py (the one piece of the reference that imports without TF1)."""
+    from conftest import load_golden
+    from pfnl_amd import metrics
+    gd = load_golden("ssim_ref")
+    for a, b, (h, w, s255, s1) in zip(gd["a"], gd["b"], gd["hw_ssim255_ssim1"]):
+        h, w = int(h), int(w)
+        assert abs(metrics.ssim(a[:h, :w], b[:h, :w]) - s255) < 1e-12
+        assert abs(metrics.ssim(a[:h, :w] / 255.0, b[:h, :w] / 255.0, L=1.0) - s1) < 1e-12
+    assert gd["hw_ssim255_ssim1"][0, 2] == 1.0                      # identical images
+
+
+def _crc32c_bitwise(data: bytes) -> int:                            # independent of tfbundle's table-driven version
+    c = 0xFFFFFFFF
+    for byte in data:
+        c ^= byte
+        for _ in range(8):
+            c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+    return c ^ 0xFFFFFFFF
+
+
+def test_tfbundle_reader_on_a_hand_assembled_bundle(tmp_path):
+    """The reader against bytes assembled HERE from the published layouts (LevelDB table_format: prefix-compressed
+    entries, restart arrays, block trailers with masked crc32c, index block of separator keys, 48-byte footer;
+    tensor_bundle.proto: BundleHeaderProto / BundleEntryProto) - nothing of write_bundle is involved.  Two data blocks,
+    restart interval 2, optimizer slots and scalars mixed in, as tf.train.Saver writes a training checkpoint."""
+    import struct
+
+    def varint(n):
+        out = b""
+        while n >= 0x80:
+            out += bytes([(n & 0x7f) | 0x80])
+            n >>= 7
+        return out + bytes([n])
+
+    def mask(c):
+        return ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xa282ead8) & 0xFFFFFFFF
+
+    def entry(dtype, shape, offset, size, crc):
+        dims = b"".join(b"\x12" + varint(len(b"\x08" + varint(d))) + b"\x08" + varint(d) for d in shape)
+        msg = b"\x08" + varint(dtype)                               # dtype = 1
+        if dims:
+            msg += b"\x12" + varint(len(dims)) + dims               # shape = 2 { dim = 2 { size = 1 } }
+        if offset:
+            msg += b"\x20" + varint(offset)                         # offset = 4 (shard_id = 3 omitted: 0)
+        return msg + b"\x28" + varint(size) + b"\x35" + struct.pack("<I", crc)   # size = 5, crc32c = 6 (fixed32)
+
+    def block(items, interval):
+        out, restarts, prev = b"", [], b""
+        for i, (k, v) in enumerate(items):
+            shared = 0
+            if i % interval == 0:
+                restarts.append(len(out))
+            else:
+                while shared < min(len(prev), len(k)) and prev[shared] == k[shared]:
+                    shared += 1
+            out += varint(shared) + varint(len(k) - shared) + varint(len(v)) + k[shared:] + v
+            prev = k
+        restarts = restarts or [0]
+        return out + b"".join(struct.pack("<I", r) for r in restarts) + struct.pack("<I", len(restarts))
+
+    def with_trailer(b):
+        return b + b"\x00" + struct.pack("<I", mask(_crc32c_bitwise(b + b"\x00")))
+
+    g = PFNLGeometry(num_block=1)
+    w = synth.synthetic_weights(g, seed=4)
+    tensors = dict(w)
+    tensors["nlvsr/conv0/kernel/Adam"] = np.ones((5, 5, 3, 64), np.float32)
+    tensors["nlvsr/conv0/kernel/Adam_1"] = np.full((5, 5, 3, 64), 2, np.float32)
+    tensors["Variable"] = np.array(1500, dtype=np.int64)           # global_step (model/pfnl.py:153)
+    tensors["beta1_power"] = np.array(0.9, dtype=np.float32)
+    codes = {np.dtype("float32"): 1, np.dtype("int64"): 9}
+    data, items = b"", [(b"", b"\x08\x01\x1a\x02\x08\x01")]         # header: num_shards = 1, version { producer = 1 }
+    for name in sorted(tensors):
+        raw = tensors[name].tobytes()
+        items.append((name.encode(), entry(codes[tensors[name].dtype], tensors[name].shape, len(data), len(raw),
+                                           mask(_crc32c_bitwise(raw) if len(raw) < 65536 else tfbundle.crc32c(raw)))))   # (big tensors: the table-driven crc, itself pinned by known answers)
+        data += raw
+    split = len(items) // 2
+    f, handles = b"", []
+    for chunk in (items[:split], items[split:]):
+        b = block(chunk, 2)
+        handles.append(varint(len(f)) + varint(len(b)))
+        f += with_trailer(b)
+    meta = block([], 1)
+    mh = varint(len(f)) + varint(len(meta))
+    f += with_trailer(meta)
+    idx = block([(items[split - 1][0] + b"\x00", handles[0]), (items[-1][0] + b"\xff", handles[1])], 1)   # separators >= last key
+    ih = varint(len(f)) + varint(len(idx))
+    f += with_trailer(idx)
+    foot = mh + ih
+    f += foot + b"\x00" * (40 - len(foot)) + struct.pack("<Q", 0xdb4775248b80fb57)
+    (tmp_path / "VSR-1500.index").write_bytes(f)
+    (tmp_path / "VSR-1500.data-00000-of-00001").write_bytes(data)
+    (tmp_path / "checkpoint").write_text('model_checkpoint_path: "VSR-1500"\nall_model_checkpoint_paths: "VSR-1500"\n')
+    got = tfbundle.read_bundle(str(tmp_path / "VSR-1500"), verify_data=True)
+    assert set(got) == set(tensors)
+    assert all(np.array_equal(got[k], tensors[k]) for k in tensors)
+    m = M.PFNL()
+    m.num_block = 1
+    assert m.load(None, str(tmp_path)) is True and m.loaded_step == 1500
+    assert all(np.array_equal(m._weights[k], w[k]) for k in w)
+    bad = bytearray(f)
+    bad[10] ^= 0x40                                                  # a flipped bit inside the first data block
+    (tmp_path / "VSR-1500.index").write_bytes(bytes(bad))
+    with pytest.raises(ValueError):
+        tfbundle.read_index(str(tmp_path / "VSR-1500"))
+    with pytest.raises(ValueError):                                  # present but unreadable: raises, never "random weights"
+        M.PFNL().load(None, str(tmp_path))
+
+
+def test_checkpoint_format_preference_and_mismatch(tmp_path):
+    g = PFNLGeometry(num_block=1)
+    w_old, w_new = synth.synthetic_weights(g, seed=1), synth.synthetic_weights(g, seed=2)
+    checkpoint.save_checkpoint(str(tmp_path), w_old, 10, fmt="npz")
+    import time
+    time.sleep(0.05)
+    tfbundle.write_bundle(str(tmp_path / "VSR-10"), w_new)          # a (re)downloaded TF checkpoint next to a stale cache
+    os.utime(tmp_path / "VSR-10.index", (time.time() + 5, time.time() + 5))
+    got = checkpoint.load_checkpoint(str(tmp_path), g, step=10)
+    assert np.array_equal(got[1]["nlvsr/conv0/kernel"], w_new["nlvsr/conv0/kernel"])
+    checkpoint.save_checkpoint(str(tmp_path), w_old, 10, fmt="npz")  # writing only the cache drops the stale bundle
+    assert not (tmp_path / "VSR-10.index").exists()
+    got = checkpoint.load_checkpoint(str(tmp_path), g, step=10)
+    assert np.array_equal(got[1]["nlvsr/conv0/kernel"], w_old["nlvsr/conv0/kernel"])
+    m = M.PFNL()                                                     # default geometry (20 blocks) vs a 1-block checkpoint
+    with pytest.raises(KeyError):
+        m.load(None, str(tmp_path), step=10)
+    m1 = M.PFNL()
+    m1.save_dir = str(tmp_path / "empty")
+    with pytest.raises(RuntimeError, match="no checkpoint"):
+        m1._ensure_loaded(False)
+
+
+def test_optional_theta_phi_layout():
+    g = PFNLGeometry(num_block=1)
+    w = synth.synthetic_weights(g)
+    names = [n for n, _ in g.optional_weight_shapes()]
+    assert names == ["nlvsr/nlblock_0/theta/theta/kernel", "nlvsr/nlblock_0/theta/theta/bias",
+                     "nlvsr/nlblock_0/phi/phi/kernel", "nlvsr/nlblock_0/phi/phi/bias"]
+    check_weights(g, w)
+    w[names[0]] = np.zeros((1, 1, 84, 84), np.float32)
+    with pytest.raises(KeyError):
+        check_weights(g, w)

@@ -34,5 +34,10 @@ for i in range(0, len(args) - 1, 3):
         tot_n += f[k][0]
     res["hbm_bytes_per_launch_avg"][wl] = round(tot_b / tot_n)
     res["per_kernel"][wl] = per
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (the sha of the kernel sources the passes were measured on)
+res["kernel_src_files"] = bench.CONV3X3_KERNELS["bf16"][1]
+res["kernel_src_sha"] = bench.kernel_source_sha(res["kernel_src_files"])
 json.dump(res, open(dst, "w"), indent=1)
 print(json.dumps(res["hbm_bytes_per_launch_avg"]))

@@ -45,7 +45,12 @@ def main():
         per[k] = {"dispatches": n, "fetch_bytes": round(fb, 1), "write_bytes": round(wb, 1)}
         tot_b += (fb + wb) * n
         tot_n += n
-    json.dump({"algo": algo, "hbm_bytes_per_launch_avg": int(tot_b / tot_n),
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench                                             # the sha of the kernel sources the passes were measured on
+    files = bench.CONV3X3_KERNELS[algo][1]
+    json.dump({"algo": algo, "kernel_src_sha": bench.kernel_source_sha(files), "kernel_src_files": files,
+               "hbm_bytes_per_launch_avg": int(tot_b / tot_n),
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) on "
                          "`python bench.py --steps 1 --warmup 1`; FETCH_SIZE x1024 x2 (gfx950 correction), WRITE_SIZE x1024",
                "per_kernel": per}, open(dst, "w"), indent=1)
