@@ -83,7 +83,9 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *                   wave-specialised kernel: matrix waves + helper waves (conv_wino_ws.hip);
  *   "winograd_tile" same maths, one 4-wave workgroup per tile (conv_wino.hip);
  *   "winograd16"    same maths, one wave per SIMD owning all 16 positions (experimental, slower);
- *   "direct"        implicit-GEMM f32 MFMA (conv_mfma.hip).
+ *   "direct"        implicit-GEMM f32 MFMA (conv_mfma.hip);
+ *   "split16"       direct 3x3 on the f16 matrix pipe with exactly split fp32 operands (3 f16 MFMAs per product block,
+ *                   fp32 accumulation, >= 22 mantissa bits per product: conv_split16.hip).
  * key "conv1x1" = "stream" (default, conv1x1.hip) | "tiled" (conv_mfma.hip).
  * key "graph"   = "off" (default) | "on" (every shape is captured into a hipGraph on its second call and replayed
  *                 between the staging buffers) | "auto" (only shapes with frames*H*W <= 65536 pixels).  Measured: no
@@ -189,6 +191,11 @@ int pfnl_op_conv1x1_stream(const float* in, const float* kernel_host, const floa
  * out = act(conv + bias + addend[item / add_div]) + resid; addend and resid both NULL or both given; out may alias resid. */
 int pfnl_op_conv3x3_bf16(const uint16_t* in, const float* kernel_host, const float* bias_host, const uint16_t* addend,
                          int add_div, const uint16_t* resid, uint16_t* out, int items, int H, int W, int act, void* stream);
+/* The fp32 3x3 64->64 convolution on the f16 matrix pipe with split operands (option conv3x3=split16, conv_split16.hip): fp32
+ * tensors in and out, fp32 accumulation, every operand taken as f16(x) + f16((x - f16(x)) 2^11) 2^-11 (>= 22 mantissa bits per
+ * product).  Same contract as pfnl_op_conv3x3_winograd (any H, W); out may alias resid. */
+int pfnl_op_conv3x3_split16(const float* in, const float* kernel_host, const float* bias_host, const float* addend, int add_div,
+                            const float* resid, float* out, int items, int H, int W, int act, void* stream);
 /* conv1_i and conv10_i of a progressive-fusion block (reference model/pfnl.py:66-68) in ONE launch of the bf16 3x3 kernel:
  * out1 = lrelu(conv3x3(in) + b1) [clips*fpc, H, W, 64], base = lrelu(conv1x1(concat_t out1_t) + b10) [clips, H, W, 64];
  * the 1x1 contraction reads every finished tile from LDS.  fpc in {3,5,7}. */

@@ -12,6 +12,7 @@
 #include "capi_internal.h"
 #include "common.h"
 #include "conv_bf16.h"
+#include "conv_split16.h"
 
 namespace {
 
@@ -90,7 +91,9 @@ struct pfnl_handle {
     DevBuf wdev16;                                            // bf16 packs (offsets in 16-bit elements)
     std::vector<size_t> off16_c1, off16_c10, off16_c2a, off16_c2b;
     size_t off16_m1 = 0;                                      // convmerge1: T consecutive packs (cout 48 zero-padded to 64)
-    int conv_algo = 3;                                        // conv3x3: 0 direct, 1 winograd (4 waves / tile), 2 winograd16 (1 wave / SIMD), 3 winograd_ws (persistent, wave-specialised)
+    int conv_algo = 3;                                        // conv3x3: 0 direct, 1 winograd (4 waves / tile), 2 winograd16 (1 wave / SIMD), 3 winograd_ws (persistent, wave-specialised), 4 split16 (f16 MFMA, split fp32 operands)
+    DevBuf wdev16s;                                           // split-f16 packs of the 3x3 kernels (offsets in 16-bit elements)
+    std::vector<size_t> off16s_c1, off16s_c2a, off16s_c2b;
 
     // device weights (offsets in floats into `wdev`)
     DevBuf wdev;
@@ -318,7 +321,10 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             p.nchunks = p.chunks_per_frame;
             p.add_div = 1;
             p.act = 1;
-            if (h->conv_algo == 2) {
+            if (h->conv_algo == 4) {
+                ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_c1[i], p.bias, nullptr, nullptr, p.out, H, W, F, 1, 1};
+                HIPCHK(launch_conv3x3_split16(q, s));
+            } else if (h->conv_algo == 2) {
                 WinoParams wp{p.in, wd + h->off_c1_u16[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 1, F, nullptr};
                 HIPCHK(launch_conv_wino16(wp, s));
             } else if (h->conv_algo == 1 || h->conv_algo == 3) {
@@ -372,7 +378,10 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             p.frames_per_item = 1;
             p.nchunks = p.chunks_per_frame;
             p.act = 0;
-            if (h->conv_algo == 2) {
+            if (h->conv_algo == 4) {
+                ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_c2a[i], p.bias, nullptr, nullptr, p.out, H, W, B, 1, 0};
+                HIPCHK(launch_conv3x3_split16(q, s));
+            } else if (h->conv_algo == 2) {
                 WinoParams wp{p.in, wd + h->off_c2a_u16[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 0, B, nullptr};
                 HIPCHK(launch_conv_wino16(wp, s));
             } else if (h->conv_algo == 1 || h->conv_algo == 3) {
@@ -392,7 +401,10 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             p.resid = h->inp0.p;
             p.out = h->inp0.p;
             p.act = 1;
-            if (h->conv_algo == 2) {
+            if (h->conv_algo == 4) {
+                ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_c2b[i], p.bias, p.addend, p.resid, p.out, H, W, F, T, 1};
+                HIPCHK(launch_conv3x3_split16(q, s));
+            } else if (h->conv_algo == 2) {
                 WinoParams wp{p.in, wd + h->off_c2b_u16[i], p.bias, p.addend, p.resid, p.out, H, W, T, 1, F, nullptr};
                 HIPCHK(launch_conv_wino16(wp, s));
             } else if (h->conv_algo == 1 || h->conv_algo == 3) {
@@ -477,7 +489,7 @@ int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
     h->cfg = *cfg;
     if (const char* e = std::getenv("PFNL_CONV3X3")) {
         const std::string v(e);
-        h->conv_algo = v == "direct" ? 0 : (v == "winograd16" ? 2 : (v == "winograd_tile" ? 1 : 3));
+        h->conv_algo = v == "direct" ? 0 : (v == "winograd16" ? 2 : (v == "winograd_tile" ? 1 : (v == "split16" ? 4 : 3)));
     }
     // A BLOCKING stream: it is implicitly ordered with the legacy null stream (= torch's default stream) in both
     // directions, so host-pointer calls and graph replays on it are ordered with the caller's default-stream work.
@@ -519,7 +531,7 @@ int pfnl_destroy(pfnl_handle* h) {
         if (g.exec) hipGraphExecDestroy(g.exec);
         if (g.graph) hipGraphDestroy(g.graph);
     }
-    for (DevBuf* b : {&h->Q, &h->wdev, &h->wdev16, &h->nl16, &h->X, &h->Xo, &h->nlp, &h->inp0, &h->inp1, &h->base, &h->pb, &h->merge,
+    for (DevBuf* b : {&h->Q, &h->wdev16s, &h->wdev, &h->wdev16, &h->nl16, &h->X, &h->Xo, &h->nlp, &h->inp0, &h->inp1, &h->base, &h->pb, &h->merge,
                       &h->stage_in, &h->stage_out, &h->scratch})
         b->release();
     delete h;
@@ -566,7 +578,8 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         else if (v == "winograd_tile") h->conv_algo = 1;
         else if (v == "winograd16") h->conv_algo = 2;
         else if (v == "direct") h->conv_algo = 0;
-        else return fail(PFNL_ERR_INVALID, "conv3x3 must be winograd, winograd_tile, winograd16 or direct");
+        else if (v == "split16") h->conv_algo = 4;
+        else return fail(PFNL_ERR_INVALID, "conv3x3 must be winograd, winograd_tile, winograd16, direct or split16");
         return 0;
     }
     if (k == "conv2") {
@@ -763,6 +776,25 @@ int pfnl_finalize_weights(pfnl_handle* h) {
         if (h->wdev16.ensure(b16.size() / 2)) return fail(PFNL_ERR_NOMEM, "weight allocation failed");
         HIPCHK(hipMemcpy(h->wdev16.p, b16.data(), b16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
+    {   // split-f16 packs of the 3x3 64->64 kernels (conv3x3=split16)
+        std::vector<uint16_t> b16;
+        const size_t n3 = pfnl::conv3x3_split16_pack_halfs();
+        h->off16s_c1.assign(nb, 0);
+        h->off16s_c2a.assign(nb, 0);
+        h->off16s_c2b.assign(nb, 0);
+        b16.resize((size_t)3 * nb * n3 + 2, 0);
+        for (int i = 0; i < nb; ++i) {
+            const std::string s = std::to_string(i);
+            h->off16s_c1[i] = (size_t)(3 * i) * n3;
+            h->off16s_c2a[i] = (size_t)(3 * i + 1) * n3;
+            h->off16s_c2b[i] = (size_t)(3 * i + 2) * n3;
+            pfnl::conv3x3_split16_pack_weights(W("conv1_" + s).data(), 64, 0, &b16[h->off16s_c1[i]]);
+            pfnl::conv3x3_split16_pack_weights(W("conv2_" + s).data(), 128, 0, &b16[h->off16s_c2a[i]]);
+            pfnl::conv3x3_split16_pack_weights(W("conv2_" + s).data(), 128, 64, &b16[h->off16s_c2b[i]]);
+        }
+        if (h->wdev16s.ensure(b16.size() / 2)) return fail(PFNL_ERR_NOMEM, "weight allocation failed");
+        HIPCHK(hipMemcpy(h->wdev16s.p, b16.data(), b16.size() / 2 * 2 * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     if (h->wdev.ensure(blob.size())) return fail(PFNL_ERR_NOMEM, "weight allocation failed");
     HIPCHK(hipMemcpy(h->wdev.p, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
     h->finalized = true;
@@ -922,6 +954,7 @@ int pfnl_comm_bcast_weights(pfnl_comm* c, pfnl_handle* h, int root) {
     if (v[0] != -v[1] || v[2] != -v[3]) return fail(PFNL_ERR_STATE, "ranks disagree on the weight blob size (geometry / theta-phi option)");
     if (int e = pfnl_comm_bcast(c, h->wdev.p, h->wdev.n * sizeof(float), root)) return e;
     if (int e = pfnl_comm_bcast(c, h->wdev16.p, h->wdev16.n * sizeof(float), root)) return e;
+    if (int e = pfnl_comm_bcast(c, h->wdev16s.p, h->wdev16s.n * sizeof(float), root)) return e;
     ++h->cfg_gen;
     return 0;
 }
@@ -1133,6 +1166,27 @@ int pfnl_op_conv3x3_bf16(const uint16_t* in, const float* kernel_host, const flo
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(dw);
     if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv3x3 bf16 op: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int pfnl_op_conv3x3_split16(const float* in, const float* kernel_host, const float* bias_host, const float* addend, int add_div,
+                            const float* resid, float* out, int items, int H, int W, int act, void* stream) {
+    if (!in || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (items < 1 || H < 1 || W < 1 || (addend == nullptr) != (resid == nullptr)) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
+    if (addend && (add_div < 1 || items % add_div)) return fail(PFNL_ERR_INVALID, "items must be a multiple of add_div");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nh = pfnl::conv3x3_split16_pack_halfs();
+    std::vector<uint16_t> pack(nh + 128, 0);
+    pfnl::conv3x3_split16_pack_weights(kernel_host, 64, 0, pack.data());
+    if (bias_host) std::memcpy(&pack[nh], bias_host, 64 * sizeof(float));
+    uint16_t* dw = nullptr;
+    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(uint16_t)));
+    hipError_t e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    pfnl::ConvSplitParams q{in, dw, reinterpret_cast<const float*>(dw + nh), addend, resid, out, H, W, items, add_div < 1 ? 1 : add_div, act};
+    if (e == hipSuccess) e = pfnl::launch_conv3x3_split16(q, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dw);
+    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv3x3 split16 op: ") + hipGetErrorString(e));
     return 0;
 }
 

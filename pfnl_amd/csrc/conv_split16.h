@@ -1,0 +1,22 @@
+// fp32 convolution on the f16 matrix pipe with split operands (conv_split16.hip): declarations shared with capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace pfnl {
+
+struct ConvSplitParams {
+    const float* in;         // [items][H][W][64] fp32
+    const uint16_t* wpack;   // conv3x3_split16_pack_weights (both channel halves)
+    const float* bias;       // [64] f32; never null
+    const float* addend;     // [items/add_div][H][W][64] f32, added before the activation \ both or
+    const float* resid;      // [items][H][W][64] f32, added after the activation           / neither
+    float* out;              // [items][H][W][64] f32 (may alias resid)
+    int H, W, items, add_div, act;
+};
+hipError_t launch_conv3x3_split16(const ConvSplitParams& p, hipStream_t s);
+size_t conv3x3_split16_pack_halfs();                                  // 16-bit elements per packed 3x3 64->64 kernel
+void conv3x3_split16_pack_weights(const float* hwio, int cin_total, int cin_begin, uint16_t* dst, int cout = 64);   // cout < 64: zero-padded
+
+}  // namespace pfnl

@@ -1,0 +1,533 @@
+// fp32 3x3 64->64 convolution on the f16 matrix pipe with SPLIT operands (option conv3x3=split16): the 3x3 convolutions of
+// the progressive-fusion blocks (conv1_i, both halves of conv2_i; reference model/pfnl.py:49-51, 66-71).
+//
+// gfx950 has no xf32 MFMA; v_mfma_f32_32x32x2_f32 peaks at 157 TFLOP/s while v_mfma_f32_32x32x16_f16 runs at 16x that rate
+// with fp32 accumulation.  Every fp32 operand is therefore split exactly into two binary16 numbers
+//     x = hi + lo' * 2^-11,   hi = f16(x),  lo' = f16((x - hi) * 2^11)        (x - hi is exact in fp32; |lo'| <= |x|)
+// and a product is taken as  x w = hi_x hi_w + (hi_x lo'_w + lo'_x hi_w) 2^-11 ; the dropped lo lo term is 2^-22 relative,
+// each kept product is exact in the fp32 accumulator, i.e. a product carries >= 22 mantissa bits and the result differs
+// from an fp32 FMA chain by less than the chain's own summation-order noise (tests: error against the fp64 oracle equals
+// the direct fp32 kernel's, below the Winograd kernel's).  The lo' parts are kept SCALED by 2^11 so that they live in
+// binary16's normal range whatever the magnitude of x (no dependence on subnormal handling); the two cross terms therefore
+// accumulate in a second accumulator that is folded in with 2^-11 once per tile.  Domain: |activation|, |weight| < 65504.
+// 3 MFMAs of 32 cycles per 16x(32x32) products against 8 MFMAs of 64 cycles: 5.3x less matrix-pipe time than the direct
+// f32 kernel, 2.4x less than the Winograd kernel - the convolution becomes bound by LDS / HBM traffic instead.
+//
+// Structure (the persistent, LDS-resident design of conv_bf16.hip, re-cut for twice the operand bytes):
+//   * activations stay fp32 [items][H][W][64] in HBM; the split happens when a halo tile is committed to LDS;
+//   * workgroup = 512 threads = 8 waves = (row pair rp, 32-channel tile mt) of an 8 x 32-pixel output tile;
+//   * a UNIT is (tile, half of the 64 input channels): its 10 x 34 halo of 32 channels is 128 B per pixel in LDS
+//     ([hi 64 B | lo' 64 B], 16-byte chunks XOR-swizzled like conv_bf16.hip), double-buffered (2 x 42.5 KB), next to the
+//     72 KB of packed weights of that half ([kx][ks][ky][m][hi/lo'][lane] x 16 B); accumulators run through a tile's two
+//     units.  Tiles walk the halves in boustrophedon order (0,1 | 1,0 | 0,1 ...), so the weight pack in LDS is replaced
+//     once per tile, in three 24 KB slices that follow the column taps already consumed;
+//   * per (column tap kx, 16-channel step ks): 4 halo rows x (hi, lo') + 3 row taps x (hi, lo') = 14 ds_read_b128 feed
+//     18 MFMAs (0.78 reads per MFMA; the bf16 kernel needs 1.17), fetched one row tap ahead;
+//   * a finished tile leaves through the halo buffer that is free in that phase, in two passes of 128 pixels x 256 B (one
+//     per unit of the NEXT tile): accumulators + bias -> LDS scratch (pixel-major), then whole 256-byte pixel lines
+//     to HBM with the addend / leaky-relu / residual of conv2_i applied on the way (coalesced reads of both).
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+#include "common.h"
+#include "conv_split16.h"
+
+namespace pfnl {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int CS_THREADS = 512;
+constexpr int CS_TH = 8, CS_TW = 32;
+constexpr int CS_IH = CS_TH + 2, CS_IW = CS_TW + 2;
+constexpr int CS_TILE_BYTES = CS_IH * CS_IW * 128;                  // 43 520 per buffer
+constexpr int CS_W_BYTES = 3 * 2 * 3 * 2 * 2 * 1024;                // 73 728: [kx][ks][ky][m][hi/lo][lane] x 16 B, one half
+constexpr int CS_SLOT_BYTES = CS_W_BYTES / 3;                       // the weights of one column tap
+constexpr int CS_LDS_BYTES = 2 * CS_TILE_BYTES + CS_W_BYTES + 64 * 4;   // 161 024 of 163 840
+constexpr int CS_PIECES = CS_IH * CS_IW * 8;                        // 16-byte fp32 pieces (4 channels) of a unit's halo
+constexpr int CS_ITERS = (CS_PIECES + CS_THREADS - 1) / CS_THREADS; // 6
+constexpr int CS_WITERS = CS_SLOT_BYTES / 16 / CS_THREADS;          // 3 pieces of 16 B per thread and slot
+constexpr float CS_SCALE = 2048.0f, CS_ISCALE = 1.0f / 2048.0f;
+static_assert(CS_SLOT_BYTES % (16 * CS_THREADS) == 0, "slot copy must divide evenly");
+
+__device__ __forceinline__ f32x16 mfma_f16(h8 a, h8 b, f32x16 c) {
+#ifdef CS_X_NOMFMA   /* timing experiments only (wrong results on purpose) */
+    c[0] += (float)a[0] * (float)b[0];
+    return c;
+#endif
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// x -> (hi, lo') for 4 values
+__device__ __forceinline__ void split4(f32x4 v, u32x2& hi, u32x2& lo) {
+    const h4 h = __builtin_convertvector(v, h4);                    // v_cvt_pk_f16_f32: round to nearest even
+    const f32x4 r = (v - __builtin_convertvector(h, f32x4)) * CS_SCALE;   // exact
+    hi = __builtin_bit_cast(u32x2, h);
+    lo = __builtin_bit_cast(u32x2, __builtin_convertvector(r, h4));
+}
+
+// FUSE = false: out = act(conv + bias).   FUSE = true (conv2_i per-frame half): out = act(conv + bias + addend[item / add_div]) + resid.
+template <bool FUSE>
+__global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSplitParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_smem[];
+    unsigned char* const wl = cs_smem + 2 * CS_TILE_BYTES;
+    float* const bl = reinterpret_cast<float*>(cs_smem + 2 * CS_TILE_BYTES + CS_W_BYTES);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rp = wave >> 1;                                       // rows 2rp, 2rp+1 of the tile
+    const int mt = wave & 1;                                        // output channels 32mt .. 32mt+31
+    const int H = p.H, W = p.W;
+    const int tiles_x = (W + CS_TW - 1) / CS_TW, tiles_y = (H + CS_TH - 1) / CS_TH;
+    const int per_item = tiles_x * tiles_y;
+    const int item_bytes = H * W * 256;
+    // Work order (as conv_bf16.hip): chains of the gT frames of a clip at one spatial tile (the addend tile is then an L2
+    // hit for all but the first), dealt out XCD by XCD so that neighbouring tiles share their halo rows in one L2.
+    const int gT = FUSE ? p.add_div : 1;
+    const int nchains = per_item * (p.items / gT);
+    const int xcd = blockIdx.x & 7, xj = blockIdx.x >> 3, cpx = gridDim.x >> 3;
+    const int per_xcd = (nchains + 7) >> 3;
+    const int cbeg = xcd * per_xcd;
+    const int ccnt = min(per_xcd, nchains - cbeg);
+    if (xj >= ccnt) return;
+    const int nt = ((ccnt - xj + cpx - 1) / cpx) * gT;              // tiles of this workgroup
+    const int nu = 2 * nt;                                          // units: (tile, channel half); nu >= 2
+    // tile k -> (item, y0, x0)
+#define CS_TILE(k_, item_, y0_, x0_)                                                             \
+    do {                                                                                         \
+        const int ci_ = (k_) / gT, f_ = (k_) - ci_ * gT;                                         \
+        const int ch_ = cbeg + xj + ci_ * cpx;                                                   \
+        const int cl_ = ch_ / per_item;                                                          \
+        const int sp_ = ch_ - cl_ * per_item;                                                    \
+        item_ = cl_ * gT + f_;                                                                   \
+        const int ty_ = sp_ / tiles_x;                                                           \
+        y0_ = ty_ * CS_TH;                                                                       \
+        x0_ = (sp_ - ty_ * tiles_x) * CS_TW;                                                     \
+    } while (0)
+    // unit u: tile u >> 1; the channel half walks 0,1 | 1,0 | 0,1 ... so that consecutive units of different tiles share it
+#define CS_HALF(u_) ((((u_) >> 1) ^ (u_)) & 1)
+
+    // weights of half 0 + bias -> LDS
+#pragma unroll
+    for (int k = 0; k < CS_W_BYTES / 16 / CS_THREADS; ++k)
+        reinterpret_cast<u32x4*>(wl)[k * CS_THREADS + tid] = reinterpret_cast<const u32x4*>(p.wpack)[k * CS_THREADS + tid];
+    if (tid < 64) bl[tid] = p.bias[tid];
+
+    // staging map: piece id = k*512 + tid -> halo pixel id >> 3, 4-channel piece id & 7 (8 threads read one pixel's 128 B)
+    int spk[CS_ITERS];                                              // py << 16 | px << 3 | c4
+#pragma unroll
+    for (int k = 0; k < CS_ITERS; ++k) {
+        const int id = min(k * CS_THREADS + tid, CS_PIECES - 1);    // surplus threads redo the last piece (same value)
+        const int pix = id >> 3, c = id & 7;
+        const int py = pix / CS_IW, px = pix - py * CS_IW;
+        spk[k] = (py << 16) | (px << 3) | c;
+    }
+    const int wbytes = W * 256;
+    f32x4 stg[CS_ITERS];
+#define CS_REQUEST_ALL(rs_, org_, interior_, y0_, x0_)                                           \
+    do {                                                                                         \
+        if (interior_) {                                                                         \
+            _Pragma("unroll") for (int k_ = 0; k_ < CS_ITERS; ++k_)                              \
+                stg[k_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(       \
+                    rs_, (org_) + (spk[k_] >> 16) * wbytes + ((spk[k_] >> 3) & 0x1fff) * 256 + (spk[k_] & 7) * 16, 0, 0)); \
+        } else {                                                                                 \
+            _Pragma("unroll") for (int k_ = 0; k_ < CS_ITERS; ++k_) {                            \
+                const int gy_ = (y0_) + (spk[k_] >> 16) - 1, gx_ = (x0_) + ((spk[k_] >> 3) & 0x1fff) - 1; \
+                const bool in_ = (unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W;     \
+                stg[k_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(       \
+                    rs_, in_ ? (org_) + (spk[k_] >> 16) * wbytes + ((spk[k_] >> 3) & 0x1fff) * 256 + (spk[k_] & 7) * 16 : 0x7fffffff, 0, 0)); \
+            }                                                                                    \
+        }                                                                                        \
+    } while (0)
+    // descriptor of unit u_'s halo: resource of its item, byte offset of the halo origin (+ the channel half), interior flag
+#define CS_REQ_SETUP(u_, rs_, org_, interior_, y0_, x0_)                                         \
+    int item_q_, y0_, x0_;                                                                       \
+    CS_TILE((u_) >> 1, item_q_, y0_, x0_);                                                       \
+    const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                        \
+        const_cast<float*>(p.in) + (size_t)item_q_ * H * W * 64, 0, item_bytes, 0x00020000);     \
+    const int org_ = ((y0_ - 1) * W + x0_ - 1) * 256 + CS_HALF(u_) * 128;                        \
+    const bool interior_ = y0_ > 0 && y0_ + CS_IH - 1 <= H && x0_ > 0 && x0_ + CS_IW - 1 <= W
+#ifdef CS_X_NOCOMMIT   /* timing experiments only */
+#define CS_COMMIT1(k_, buf_) do { if (stg[k_].x == 1.2345e30f) *reinterpret_cast<f32x4*>(cs_smem) = stg[k_]; } while (0)
+#else
+#define CS_COMMIT1(k_, buf_)                                                                     \
+    do {                                                                                         \
+        const int py_ = spk[k_] >> 16, px_ = (spk[k_] >> 3) & 0x1fff, c_ = spk[k_] & 7;          \
+        u32x2 hi_, lo_;                                                                          \
+        split4(stg[k_], hi_, lo_);                                                               \
+        unsigned char* const b_ = cs_smem + (buf_) * CS_TILE_BYTES + (py_ * CS_IW + px_) * 128 + 8 * (c_ & 1); \
+        const int sw_ = (px_ >> 1) & 7;                                                          \
+        *reinterpret_cast<u32x2*>(b_ + (((c_ >> 1) ^ sw_) << 4)) = hi_;                          \
+        *reinterpret_cast<u32x2*>(b_ + ((((c_ >> 1) | 4) ^ sw_) << 4)) = lo_;                    \
+    } while (0)
+#endif
+
+    // operand addresses: pixel operand of (column tap kx, k-step ks, part) = chunk 4*part + 2*ks + (lane >> 5) of halo pixel
+    // (row 2*rp + ..., column (lane & 31) + kx); weights: 16 bytes per lane
+    int paddr[3];                                                   // k-step 0; k-step 1 = the same with chunk bit 1 flipped (^ 32 bytes)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int col = (lane & 31) + kx;
+        paddr[kx] = ((2 * rp) * CS_IW + col) * 128 + ((((lane >> 5)) ^ ((col >> 1) & 7)) << 4);
+    }
+    const int lo_xor = 4 << 4;                                      // hi chunk -> lo chunk of the same pixel: chunk index ^ 4
+    const unsigned char* const wlane = wl + mt * 2048 + lane * 16;
+
+    // Accumulator rows -> channels as in conv_bf16.hip: register r of a lane is channel 32mt + 16(lane>>5) + r.
+    const int ech = 32 * mt + 16 * (lane >> 5);
+    f32x16 accm[2], accc[2], accp[2];                               // [output row]: hi.hi products / cross products (x 2^11) / finished tile
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            accm[n][r] = 0.f;
+            accc[n][r] = 0.f;
+            accp[n][r] = 0.f;
+        }
+    int ex0p = 0, ey0p = 0, eitemp = 0;                             // the tile awaiting its epilogue
+    bool pending = false;
+
+    // ---- epilogue pieces -----------------------------------------------------------------------
+    // pass n (n = 0 in the first unit of the next tile, 1 in its second): output rows 2rp + n of the 4 row pairs = 128 pixels.
+    // scratch: pixel (rp*32 + j) x 256 B, 16-byte chunk c stored at (c & 8) | ((c ^ j) & 7): conflict-free for the
+    // per-lane dump (32 lanes = 32 pixels, same chunk) and for the line read-back (16 lanes = one pixel).
+    auto dump = [&](unsigned char* scratch, int n, int h) __attribute__((always_inline)) {   // channels ech + 8h .. + 7 of row n
+        const int j = lane & 31;
+        unsigned char* const pl = scratch + (rp * 32 + j) * 256;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r0 = 8 * h + 4 * q;
+            const f32x4 v = f32x4{accp[n][r0], accp[n][r0 + 1], accp[n][r0 + 2], accp[n][r0 + 3]} +
+                            *reinterpret_cast<const f32x4*>(bl + ech + r0);
+            const int c = (ech + r0) >> 2;                          // 16-byte chunk of the pixel's line
+            *reinterpret_cast<f32x4*>(pl + (((c & 8) | ((c ^ j) & 7)) << 4)) = v;
+        }
+    };
+    const float slope = p.act ? 0.2f : 1.0f;
+    f32x4 radd[2], rres[2];                                         // FUSE: addend / residual pieces in flight (two store pieces ahead)
+    // Store piece k of a thread = 16-byte chunk c = tid & 15 of pixel (row pair k, column tid >> 4): one byte offset per
+    // thread (row pair 0), the row pair goes in the scalar offset (2 rows = wbytes2 bytes per step); rows past the image are
+    // past the end of the item's buffer resource (the range check covers voffset + soffset), columns past it and "nothing
+    // pending" are folded into the offset (0x7fffffff + k * wbytes2 stays out of range).
+    int soff0 = 0x7fffffff;
+    const int wbytes2 = 2 * W * 256;
+    auto piece_setup = [&](int n) __attribute__((always_inline)) {
+        const int sx = ex0p + (tid >> 4);
+        soff0 = (pending && sx < W) ? ((ey0p + n) * W + sx) * 256 + (tid & 15) * 16 : 0x7fffffff;
+    };
+    auto fuse_request = [&](int k) __attribute__((always_inline)) {
+        if constexpr (FUSE) {
+            const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.resid) + (size_t)eitemp * H * W * 64, 0, item_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.addend) + (size_t)(eitemp / p.add_div) * H * W * 64, 0, item_bytes, 0x00020000);
+            radd[k & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, soff0, k * wbytes2, 0));
+            rres[k & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, soff0, k * wbytes2, 0));
+        }
+    };
+    auto store_piece = [&](const unsigned char* scratch, int k) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)eitemp * H * W * 64, 0, item_bytes, 0x00020000);
+        const int id = k * CS_THREADS + tid;
+        const int pp = id >> 4, c = id & 15;
+        f32x4 v = *reinterpret_cast<const f32x4*>(scratch + pp * 256 + (((c & 8) | ((c ^ pp) & 7)) << 4));
+        if constexpr (FUSE) v += radd[k & 1];
+#ifdef CS_X_PKSLOPE
+        const f32x4 sv = v * slope;
+        v.x = fmaxf(v.x, sv.x);
+        v.y = fmaxf(v.y, sv.y);
+        v.z = fmaxf(v.z, sv.z);
+        v.w = fmaxf(v.w, sv.w);
+#else
+        v.x = fmaxf(v.x, v.x * slope);                              // leaky_relu(0.2) or identity (slope 1), branch-free
+        v.y = fmaxf(v.y, v.y * slope);
+        v.z = fmaxf(v.z, v.z * slope);
+        v.w = fmaxf(v.w, v.w * slope);
+#endif
+        if constexpr (FUSE) v += rres[k & 1];
+#ifdef CS_X_NOSTORE   /* timing experiments only */
+        if (v.x == 1.2345e30f)
+#endif
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsO, soff0, k * wbytes2, 0);
+        // Measured on gfx950 with this hipcc: a VALU write to the data registers of a 128-bit buffer store issued in the very
+        // next instruction corrupted the stored dword (the hazard recognizer inserted no wait state) - keep distance by hand.
+        asm volatile("s_nop 1");
+    };
+
+    // ---- weight replacement: a slot (24 KB, one column tap) travels L2 -> registers -> LDS, 3 x 16 B per thread.
+    // (global_load_lds_dwordx4 would need no registers, but with an LDS-DMA in flight this compiler turns EVERY vmcnt wait
+    // into vmcnt(0) - the halo commit would then wait for the stores issued a moment earlier: measured.)
+    u32x4 wnx[CS_WITERS];
+    auto w_request = [&](int half, int slot) __attribute__((always_inline)) {
+#ifndef CS_X_NOSWAP   /* timing experiments only */
+        const u32x4* src = reinterpret_cast<const u32x4*>(p.wpack) + (size_t)half * (CS_W_BYTES / 16) + slot * (CS_SLOT_BYTES / 16);
+#pragma unroll
+        for (int k = 0; k < CS_WITERS; ++k) wnx[k] = src[k * CS_THREADS + tid];
+#endif
+    };
+    auto w_write = [&](int slot) __attribute__((always_inline)) {
+#ifndef CS_X_NOSWAP
+        u32x4* dst = reinterpret_cast<u32x4*>(wl + slot * CS_SLOT_BYTES);
+#pragma unroll
+        for (int k = 0; k < CS_WITERS; ++k) dst[k * CS_THREADS + tid] = wnx[k];
+#endif
+    };
+    // Workgroup barrier of the main loop: this wave's ds_writes complete (lgkmcnt), then s_barrier - without the memory-model
+    // fences of __syncthreads() (nothing here communicates through global memory); the "memory" clobber keeps the compiler
+    // from moving accesses across.
+#define CS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+    // ---- prologue: halo of unit 0 -> buffer 0 -----------------------------------------------------------
+    {
+        CS_REQ_SETUP(0, rs, org, interior, y0q, x0q);
+        CS_REQUEST_ALL(rs, org, interior, y0q, x0q);
+#pragma unroll
+        for (int k = 0; k < CS_ITERS; ++k) CS_COMMIT1(k, 0);
+    }
+    __syncthreads();
+
+    // One loop iteration = one tile = unit A (first channel half of the tile, parity 0) + unit B (parity 1).  Everything that
+    // depends on the parity (LDS buffer, weight replacement, epilogue pass) is a compile-time constant, and the sequence of
+    // vector-memory operations of an iteration is branch-free (work that does not apply - no tile awaiting its epilogue yet -
+    // runs with out-of-range offsets: dropped stores, zero loads), so that the compiler's s_waitcnt counts are exact: a
+    // conservative vmcnt(0) in front of the halo commit would wait for the stores issued a moment earlier (measured:
+    // 120 us per conv1_i launch with runtime branches around them).
+    for (int kt = 0; kt < nt; ++kt) {
+        const int half_a = kt & 1;                                  // channel half of unit A; unit B: the other one
+        auto unit = [&](auto par) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par)::value;               // 0: unit A, 1: unit B
+            constexpr int cb = PAR;                                 // LDS buffer of this unit (u = 2 kt + PAR)
+            const unsigned char* const tile = cs_smem + cb * CS_TILE_BYTES;
+            unsigned char* const other = cs_smem + (cb ^ 1) * CS_TILE_BYTES;
+            const int u = 2 * kt + PAR;
+            if constexpr (PAR == 0) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        accm[n][r] = 0.f;
+                        accc[n][r] = 0.f;
+                    }
+            }
+            // the NEXT unit's halo: requested here, committed in groups 4-5 of this unit (4 groups = ~2 us later), i.e. request
+            // and use never straddle the loop back-edge and the compiler's vmcnt for the commit is exact
+            {
+#ifndef CS_X_NOLOAD
+                CS_REQ_SETUP(min(u + 1, nu - 1), rs, org, interior, y0q, x0q);   // past the end: harmless re-read
+                CS_REQUEST_ALL(rs, org, interior, y0q, x0q);
+#endif
+            }
+            // weights of unit B (the other channel half) follow the column taps unit A has consumed: tap 0 requested here,
+            // written after b0 (visible from b1), tap 1 requested after b0, written after b1 (visible from b2), tap 2 requested
+            // after b1, written at the start of unit B (visible from its b0, first read after its b1)
+            if constexpr (PAR == 0) w_request(half_a ^ 1, 0);
+            else w_write(2);
+            piece_setup(PAR);                                       // epilogue pass PAR of the previous tile (nothing pending: out of range)
+
+            // operands: X[row][part], Wv[substep parity][part]
+            h8 X[4][2], Wv[2][2];
+#define CS_PX(g_, r_, part_) (*reinterpret_cast<const h8*>(tile + (paddr[(g_) >> 1] ^ (((part_) ? lo_xor : 0) | (((g_) & 1) << 5))) + (r_) * (CS_IW * 128)))
+#define CS_WT(g_, ky_, part_) (*reinterpret_cast<const h8*>(wlane + (((g_) * 3 + (ky_)) << 12) + ((part_) << 10)))
+            X[0][0] = CS_PX(0, 0, 0);
+            X[0][1] = CS_PX(0, 0, 1);
+            X[1][0] = CS_PX(0, 1, 0);
+            X[1][1] = CS_PX(0, 1, 1);
+            Wv[0][0] = CS_WT(0, 0, 0);
+            Wv[0][1] = CS_WT(0, 0, 1);
+
+            auto substep = [&](auto sc) __attribute__((always_inline)) {
+                constexpr int S = decltype(sc)::value;
+                constexpr int g = S / 3, ky = S % 3;
+                // --- the slice of non-MFMA work that rides on this group (first sub-step of each group)
+                if constexpr (ky == 0) {
+                    if constexpr (g == 0) {
+                        dump(other, PAR, 0);
+                        fuse_request(0);
+                        fuse_request(1);
+                    }
+                    if constexpr (g == 1) dump(other, PAR, 1);
+                    if constexpr (g == 2) {
+                        CS_BARRIER();                              // b0: scratch complete; column tap 0 of the weights consumed
+                        if constexpr (PAR == 0) {
+                            w_write(0);
+                            w_request(half_a ^ 1, 1);
+                        }
+                        store_piece(other, 0);
+                        store_piece(other, 1);
+                        fuse_request(2);
+                        fuse_request(3);
+                    }
+                    if constexpr (g == 3) {
+                        store_piece(other, 2);
+                        store_piece(other, 3);
+                    }
+                    if constexpr (g == 4) {
+                        CS_BARRIER();                              // b1: scratch read; column tap 1 consumed
+                        if constexpr (PAR == 0) {
+                            w_write(1);
+                            w_request(half_a ^ 1, 2);
+                        }
+#pragma unroll
+                        for (int k = 0; k < CS_ITERS; ++k) asm volatile("" : "+v"(spk[k]));   // opaque: nothing derived from it is hoisted into registers
+#pragma unroll
+                        for (int k = 0; k < CS_ITERS / 2; ++k) CS_COMMIT1(k, cb ^ 1);
+                    }
+                    if constexpr (g == 5) {
+#pragma unroll
+                        for (int k = CS_ITERS / 2; k < CS_ITERS; ++k) CS_COMMIT1(k, cb ^ 1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // --- operands of the next sub-step
+                if constexpr (S < 17) {
+                    constexpr int S1 = S + 1, g1 = S1 / 3, ky1 = S1 % 3;
+                    Wv[S1 & 1][0] = CS_WT(g1, ky1, 0);
+                    Wv[S1 & 1][1] = CS_WT(g1, ky1, 1);
+                    if constexpr (ky1 == 0) {
+                        X[0][0] = CS_PX(g1, 0, 0);
+                        X[0][1] = CS_PX(g1, 0, 1);
+                        X[1][0] = CS_PX(g1, 1, 0);
+                        X[1][1] = CS_PX(g1, 1, 1);
+                    } else {
+                        X[ky1 + 1][0] = CS_PX(g1, ky1 + 1, 0);
+                        X[ky1 + 1][1] = CS_PX(g1, ky1 + 1, 1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // --- 6 MFMAs: row tap ky of both output rows
+                const h8 wh = Wv[S & 1][0], wo = Wv[S & 1][1];
+                accm[0] = mfma_f16(wh, X[ky][0], accm[0]);
+                accm[1] = mfma_f16(wh, X[ky + 1][0], accm[1]);
+                accc[0] = mfma_f16(wo, X[ky][0], accc[0]);
+                accc[1] = mfma_f16(wo, X[ky + 1][0], accc[1]);
+                accc[0] = mfma_f16(wh, X[ky][1], accc[0]);
+                accc[1] = mfma_f16(wh, X[ky + 1][1], accc[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            substep(std::integral_constant<int, 0>{});
+            substep(std::integral_constant<int, 1>{});
+            substep(std::integral_constant<int, 2>{});
+            substep(std::integral_constant<int, 3>{});
+            substep(std::integral_constant<int, 4>{});
+            substep(std::integral_constant<int, 5>{});
+            substep(std::integral_constant<int, 6>{});
+            substep(std::integral_constant<int, 7>{});
+            substep(std::integral_constant<int, 8>{});
+            substep(std::integral_constant<int, 9>{});
+            substep(std::integral_constant<int, 10>{});
+            substep(std::integral_constant<int, 11>{});
+            substep(std::integral_constant<int, 12>{});
+            substep(std::integral_constant<int, 13>{});
+            substep(std::integral_constant<int, 14>{});
+            substep(std::integral_constant<int, 15>{});
+            substep(std::integral_constant<int, 16>{});
+            substep(std::integral_constant<int, 17>{});
+#undef CS_PX
+#undef CS_WT
+            if constexpr (PAR == 1) {                               // the tile is complete: fold the cross terms in, hand it to the epilogue
+                // (the previous tile's second pass ran in this unit: accp is free)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) accp[n] = accm[n] + accc[n] * CS_ISCALE;
+                int item_e, y0e, x0e;
+                CS_TILE(kt, item_e, y0e, x0e);
+                ex0p = x0e;
+                ey0p = y0e;
+                eitemp = item_e;
+#ifndef CS_X_NOEPI   /* timing experiments only */
+                pending = true;
+#endif
+            }
+            CS_BARRIER();                                          // b2: this unit's buffer is free, the next unit's is complete
+        };
+        unit(std::integral_constant<int, 0>{});
+        unit(std::integral_constant<int, 1>{});
+    }
+
+    // ---- the last tile: both passes, any buffer is free now ------------------------------------------
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        unsigned char* const scratch = cs_smem + n * CS_TILE_BYTES;
+        piece_setup(n);
+        fuse_request(0);
+        fuse_request(1);
+        dump(scratch, n, 0);
+        dump(scratch, n, 1);
+        __syncthreads();
+        store_piece(scratch, 0);
+        store_piece(scratch, 1);
+        fuse_request(2);
+        fuse_request(3);
+        store_piece(scratch, 2);
+        store_piece(scratch, 3);
+    }
+#undef CS_COMMIT1
+#undef CS_REQ_SETUP
+#undef CS_REQUEST_ALL
+#undef CS_HALF
+#undef CS_TILE
+}
+
+hipError_t launch_conv3x3_split16(const ConvSplitParams& p, hipStream_t s) {
+    if (!p.in || !p.wpack || !p.bias || !p.out || p.items < 1 || p.H < 1 || p.W < 1) return hipErrorInvalidValue;
+    if ((p.addend == nullptr) != (p.resid == nullptr) || (p.addend && (p.add_div < 1 || p.items % p.add_div))) return hipErrorInvalidValue;
+    if ((long long)p.H * p.W * 256 >= 0x7fffffffLL) return hipErrorInvalidValue;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        ncu = prop.multiProcessorCount;
+    }
+    const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;                    // whole XCDs; surplus workgroups exit at once
+    static bool attr_dev[64][2] = {};                               // the attribute is per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    const int mode = p.addend ? 1 : 0;
+    const void* fn = mode ? reinterpret_cast<const void*>(conv3x3_split16_kernel<true>) : reinterpret_cast<const void*>(conv3x3_split16_kernel<false>);
+    if (!attr_dev[dev][mode]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_dev[dev][mode] = true;
+    }
+    if (mode) hipLaunchKernelGGL(conv3x3_split16_kernel<true>, dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, p);
+    else hipLaunchKernelGGL(conv3x3_split16_kernel<false>, dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side packing
+static int split_row_channel(int i) { return 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3); }   // MFMA row -> channel in the tile (see the kernel)
+
+static uint16_t f16_bits(float f) {
+    const _Float16 h = (_Float16)f;                                 // round to nearest even
+    uint16_t u;
+    std::memcpy(&u, &h, 2);
+    return u;
+}
+
+size_t conv3x3_split16_pack_halfs() { return 2 * (size_t)CS_W_BYTES / 2; }   // both channel halves, in 16-bit units
+
+// HWIO [3,3,cin_total,cout] rows [cin_begin, cin_begin+64) -> [half][kx][ks][ky][m][part][lane][e]:
+// W[ky][kx][cin_begin + 32 half + 16 ks + 8 (lane>>5) + e][32 m + row_channel(lane&31)], part 0 = f16(w), part 1 = f16((w - hi) 2^11)
+void conv3x3_split16_pack_weights(const float* hwio, int cin_total, int cin_begin, uint16_t* dst, int cout) {
+    for (int half = 0; half < 2; ++half)
+        for (int kx = 0; kx < 3; ++kx)
+            for (int ks = 0; ks < 2; ++ks)
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int m = 0; m < 2; ++m)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 8; ++e) {
+                                const int ci = cin_begin + 32 * half + 16 * ks + 8 * (lane >> 5) + e;
+                                const int co = 32 * m + split_row_channel(lane & 31);
+                                const float w = co < cout ? hwio[((size_t)(ky * 3 + kx) * cin_total + ci) * cout + co] : 0.f;
+                                const _Float16 hi = (_Float16)w;
+                                const float lo = (w - (float)hi) * CS_SCALE;
+                                const size_t base = (size_t)half * (CS_W_BYTES / 2) + ((((size_t)(kx * 2 + ks) * 3 + ky) * 2 + m) * 2) * 512;
+                                dst[base + lane * 8 + e] = f16_bits((float)hi);
+                                dst[base + 512 + lane * 8 + e] = f16_bits(lo);
+                            }
+}
+
+}  // namespace pfnl
