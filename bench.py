@@ -179,6 +179,14 @@ def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
                      "kernel can take past the direct algorithm's roof") if wino else "achieved = executed = algorithmic (direct convolution)"}
 
 
+def resolve_conv3x3(name, B, H, W, T=7):
+    """What conv3x3=auto runs for this shape (the rule of forward_device in pfnl_amd/csrc/capi.hip)."""
+    name = name or os.environ.get("PFNL_CONV3X3", "auto")
+    if name not in CONV3X3_KERNELS:
+        name = "split16" if B * T * ((W + 31) // 32) * ((H + 7) // 8) >= 256 else "winograd"
+    return name
+
+
 def stamped_traffic(suffix, files, key):
     """HBM bytes per launch from the rocprofv3 --pmc passes kept under profiles/ (the newest r<NN>_<suffix>), or None when
     the kernel sources have changed since they were measured (the file records the sha of the sources it was measured on)."""
@@ -202,7 +210,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads and the sustained run")
-    ap.add_argument("--conv3x3", choices=["winograd", "winograd_tile", "winograd16", "direct", "split16"], default=None, help="override the 3x3 conv algorithm")
+    ap.add_argument("--conv3x3", choices=["auto", "split16", "winograd", "winograd_tile", "winograd16", "direct"], default=None,
+                    help="override the 3x3 conv algorithm (default auto: split16 for launches of >= 256 tiles, winograd below)")
     ap.add_argument("--conv1x1", choices=["stream", "tiled"], default=None, help="override the conv10_i algorithm")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="trunk arithmetic: fp32 = the reference's (the judged line); bf16 = BASELINE.json configs[3]'s")
@@ -310,7 +319,7 @@ def main():
     value = clips_total / elapsed                                     # 1 HR frame per clip
     ms_per_step = 1e3 * elapsed / args.steps
 
-    algo = args.conv3x3 or os.environ.get("PFNL_CONV3X3", "winograd")
+    algo = resolve_conv3x3(args.conv3x3, B_PER_GPU, H, W)
     roof = conv3x3_roofline(geom, prof, B_PER_GPU, H, W, algo, bf16, args.workload)
     f_ref = geom.flops_per_clip(H, W) * B_PER_GPU
     f_exec = geom.flops_per_clip(H, W, shared_base=True) * B_PER_GPU
@@ -327,7 +336,7 @@ def main():
         "config": {"workload": ("PFNL 4xSR, 7 frames, 270x480->1080x1920 (1080p), batch=1 %s per MI355X (BASELINE.json configs[3])" if args.workload == "cfg4" else
                                 "PFNL 4xSR, 7 frames, 128x128->512x512, batch=4 %s per MI355X (BASELINE.json configs[1])") % ("bf16 trunk" if bf16 else "fp32"),
                    "clips_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU, "parallelism": "dp%d" % world, "backend": (args.backend if world > 1 else None),
-                   "weights": "synthetic Xavier (seed 0)", "input": "resident in HBM"},
+                   "weights": "synthetic Xavier (seed 0)", "input": "resident in HBM", "conv3x3": algo},
         "roofline": roof,
         "whole_forward": {"tflops_ref_graph": round(f_ref / (ms_per_step * 1e-3) / 1e12, 2),
                           "tflops_direct_shared_base": round(f_exec / (ms_per_step * 1e-3) / 1e12, 2),
@@ -399,7 +408,7 @@ def secondary_workloads(eng, geom, weights, local_dev, dev, x_cfg2, out_cfg2):
     eng.set_option("precision", "fp32")
     # configs[3] geometry in fp32 (the reference's arithmetic at 1080p)
     rec, prof = run(eng, geom, 1, 270, 480, 5, 4040, label="configs[3] geometry in fp32: 7x270x480 -> 1080x1920, batch 1")
-    rec["roofline"] = conv3x3_roofline(geom, prof, 1, 270, 480, os.environ.get("PFNL_CONV3X3", "winograd"), False, "cfg4")
+    rec["roofline"] = conv3x3_roofline(geom, prof, 1, 270, 480, resolve_conv3x3(None, 1, 270, 480), False, "cfg4")
     out.append(rec)
     # configs[0]: 7x32x32, batch 1 (the reference's CPU-runnable plumbing case; latency-bound on a GPU)
     rec, _ = run(eng, geom, 1, 32, 32, 50, 1234, label="BASELINE.json configs[0]: 4xSR 7x32x32 -> 128x128, batch 1, fp32")

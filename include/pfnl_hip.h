@@ -79,7 +79,8 @@ int pfnl_missing_weights(pfnl_handle* h, int* count);
 int pfnl_finalize_weights(pfnl_handle* h);
 
 /* Tuning knobs (all parity-tested):  key "conv3x3" =
- *   "winograd"      (default) fused Winograd F(2x2,3x3) on f32 MFMA (2.25x fewer multiplies), persistent
+ *   "auto"          (default) "split16" when a launch has at least 256 tiles of 8x32 pixels, "winograd" below that;
+ *   "winograd"      fused Winograd F(2x2,3x3) on f32 MFMA (2.25x fewer multiplies), persistent
  *                   wave-specialised kernel: matrix waves + helper waves (conv_wino_ws.hip);
  *   "winograd_tile" same maths, one 4-wave workgroup per tile (conv_wino.hip);
  *   "winograd16"    same maths, one wave per SIMD owning all 16 positions (experimental, slower);

@@ -91,7 +91,7 @@ struct pfnl_handle {
     DevBuf wdev16;                                            // bf16 packs (offsets in 16-bit elements)
     std::vector<size_t> off16_c1, off16_c10, off16_c2a, off16_c2b;
     size_t off16_m1 = 0;                                      // convmerge1: T consecutive packs (cout 48 zero-padded to 64)
-    int conv_algo = 3;                                        // conv3x3: 0 direct, 1 winograd (4 waves / tile), 2 winograd16 (1 wave / SIMD), 3 winograd_ws (persistent, wave-specialised), 4 split16 (f16 MFMA, split fp32 operands)
+    int conv_algo = 5;                                        // conv3x3: 5 auto (4 for large shapes, 3 for small), 0 direct, 1 winograd (4 waves / tile), 2 winograd16 (1 wave / SIMD), 3 winograd_ws (persistent, wave-specialised), 4 split16 (f16 MFMA, split fp32 operands)
     DevBuf wdev16s;                                           // split-f16 packs of the 3x3 kernels (offsets in 16-bit elements)
     std::vector<size_t> off16s_c1, off16s_c2a, off16s_c2b;
 
@@ -302,6 +302,10 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
     p.in_cstride = 64;
     p.chunks_per_frame = 64 / CONV_CK;
     const int wino_groups = B * ((W + 31) / 32) * ((H + 3) / 4);   // (clip, 4x32-pixel tile) groups of conv_wino_ws
+    // conv3x3 = auto (default): the split-f16 kernel (persistent, 72 KB of weights per workgroup in its prologue) when a launch
+    // has at least ~a tile per CU, the Winograd f32 kernel for small shapes (BASELINE.json configs[0], configs[4])
+    const int tiles8x32 = F * ((W + 31) / 32) * ((H + 7) / 8);
+    const int algo = h->conv_algo == 5 ? ((tiles8x32 >= 256 && (long long)H * W * 256 < 0x7fffffffLL) ? 4 : 3) : h->conv_algo;
     for (int i = 0; i < (h->bf16 ? 0 : c.num_block); ++i) {   // model/pfnl.py:65-71
         if (h->prof_mode == 2) {          // sampled profiling: blocks 0, 4, 8, ... each with a fresh event chain
             h->prof_gate = (i & 3) == 0;
@@ -321,15 +325,15 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             p.nchunks = p.chunks_per_frame;
             p.add_div = 1;
             p.act = 1;
-            if (h->conv_algo == 4) {
+            if (algo == 4) {
                 ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_c1[i], p.bias, nullptr, nullptr, p.out, H, W, F, 1, 1};
                 HIPCHK(launch_conv3x3_split16(q, s));
-            } else if (h->conv_algo == 2) {
+            } else if (algo == 2) {
                 WinoParams wp{p.in, wd + h->off_c1_u16[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 1, F, nullptr};
                 HIPCHK(launch_conv_wino16(wp, s));
-            } else if (h->conv_algo == 1 || h->conv_algo == 3) {
+            } else if (algo == 1 || algo == 3) {
                 WinoParams wp{p.in, wd + h->off_c1_u[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 1, F, nullptr};
-                HIPCHK(h->conv_algo == 3 ? launch_conv_wino_ws(wp, s) : launch_conv_wino(wp, s));
+                HIPCHK(algo == 3 ? launch_conv_wino_ws(wp, s) : launch_conv_wino(wp, s));
             } else {
                 HIPCHK(launch_conv_mfma(p, 3, F, s));
             }
@@ -349,7 +353,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
         }
         // grouped / accumulating modes chain T(+1) units inside one workgroup: only worth it when there are enough
         // (clip, tile) groups to occupy the chip (below ~220 the split launches finish sooner)
-        const bool conv2_grouped = h->conv_algo == 3 && h->conv2_grouped && wino_groups >= 224 && (long long)H * W * 256 < 0x7fffffffLL;
+        const bool conv2_grouped = algo == 3 && h->conv2_grouped && wino_groups >= 224 && (long long)H * W * 256 < 0x7fffffffLL;
         if (conv2_grouped) {
             // the whole of conv2_i in one launch: per (clip, tile) the shared half stays in LDS (conv_wino_ws MODE 2)
             ProfScope ps(h, s, PFNL_K_CONV3X3);
@@ -378,15 +382,15 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             p.frames_per_item = 1;
             p.nchunks = p.chunks_per_frame;
             p.act = 0;
-            if (h->conv_algo == 4) {
+            if (algo == 4) {
                 ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_c2a[i], p.bias, nullptr, nullptr, p.out, H, W, B, 1, 0};
                 HIPCHK(launch_conv3x3_split16(q, s));
-            } else if (h->conv_algo == 2) {
+            } else if (algo == 2) {
                 WinoParams wp{p.in, wd + h->off_c2a_u16[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 0, B, nullptr};
                 HIPCHK(launch_conv_wino16(wp, s));
-            } else if (h->conv_algo == 1 || h->conv_algo == 3) {
+            } else if (algo == 1 || algo == 3) {
                 WinoParams wp{p.in, wd + h->off_c2a_u[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 0, B, nullptr};
-                HIPCHK(h->conv_algo == 3 ? launch_conv_wino_ws(wp, s) : launch_conv_wino(wp, s));
+                HIPCHK(algo == 3 ? launch_conv_wino_ws(wp, s) : launch_conv_wino(wp, s));
             } else {
                 HIPCHK(launch_conv_mfma(p, 3, B, s));
             }
@@ -401,15 +405,15 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
             p.resid = h->inp0.p;
             p.out = h->inp0.p;
             p.act = 1;
-            if (h->conv_algo == 4) {
+            if (algo == 4) {
                 ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_c2b[i], p.bias, p.addend, p.resid, p.out, H, W, F, T, 1};
                 HIPCHK(launch_conv3x3_split16(q, s));
-            } else if (h->conv_algo == 2) {
+            } else if (algo == 2) {
                 WinoParams wp{p.in, wd + h->off_c2b_u16[i], p.bias, p.addend, p.resid, p.out, H, W, T, 1, F, nullptr};
                 HIPCHK(launch_conv_wino16(wp, s));
-            } else if (h->conv_algo == 1 || h->conv_algo == 3) {
+            } else if (algo == 1 || algo == 3) {
                 WinoParams wp{p.in, wd + h->off_c2b_u[i], p.bias, p.addend, p.resid, p.out, H, W, T, 1, F, nullptr};
-                HIPCHK(h->conv_algo == 3 ? launch_conv_wino_ws(wp, s) : launch_conv_wino(wp, s));
+                HIPCHK(algo == 3 ? launch_conv_wino_ws(wp, s) : launch_conv_wino(wp, s));
             } else {
                 HIPCHK(launch_conv_mfma(p, 3, F, s));
             }
@@ -417,7 +421,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
     }
     h->prof_gate = true;
     if (h->prof_mode == 2) h->chain_open = false;
-    const bool m1_wino = h->conv_algo == 3 && wino_groups >= 224 && (long long)H * W * 256 < 0x7fffffffLL;
+    const bool m1_wino = (algo == 3 || algo == 4) && wino_groups >= 224 && (long long)H * W * 256 < 0x7fffffffLL;
     const int mstride = m1_wino ? 64 : 48;
     h->merge_cstride = mstride;
     if (m1_wino) {
@@ -489,7 +493,7 @@ int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
     h->cfg = *cfg;
     if (const char* e = std::getenv("PFNL_CONV3X3")) {
         const std::string v(e);
-        h->conv_algo = v == "direct" ? 0 : (v == "winograd16" ? 2 : (v == "winograd_tile" ? 1 : (v == "split16" ? 4 : 3)));
+        h->conv_algo = v == "direct" ? 0 : (v == "winograd16" ? 2 : (v == "winograd_tile" ? 1 : (v == "split16" ? 4 : (v == "winograd" ? 3 : 5))));
     }
     // A BLOCKING stream: it is implicitly ordered with the legacy null stream (= torch's default stream) in both
     // directions, so host-pointer calls and graph replays on it are ordered with the caller's default-stream work.
@@ -579,7 +583,8 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         else if (v == "winograd16") h->conv_algo = 2;
         else if (v == "direct") h->conv_algo = 0;
         else if (v == "split16") h->conv_algo = 4;
-        else return fail(PFNL_ERR_INVALID, "conv3x3 must be winograd, winograd_tile, winograd16, direct or split16");
+        else if (v == "auto") h->conv_algo = 5;
+        else return fail(PFNL_ERR_INVALID, "conv3x3 must be auto, split16, winograd, winograd_tile, winograd16 or direct");
         return 0;
     }
     if (k == "conv2") {

@@ -53,6 +53,13 @@ constexpr int CS_WITERS = CS_SLOT_BYTES / 16 / CS_THREADS;          // 3 pieces 
 constexpr float CS_SCALE = 2048.0f, CS_ISCALE = 1.0f / 2048.0f;
 static_assert(CS_SLOT_BYTES % (16 * CS_THREADS) == 0, "slot copy must divide evenly");
 
+#ifdef PFNL_S16_TIMING   /* phase timeline of the kernel (tools/s16_timing.py); not part of the product build */
+__device__ long long cs_dbg[256 * 2 * 128];
+#define CS_STAMP() do { if (lane == 0 && (wave == 0 || wave == 5) && dbg_n < 128) cs_dbg[(blockIdx.x * 2 + (wave != 0)) * 128 + dbg_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CS_STAMP() do {} while (0)
+#endif
+
 __device__ __forceinline__ f32x16 mfma_f16(h8 a, h8 b, f32x16 c) {
 #ifdef CS_X_NOMFMA   /* timing experiments only (wrong results on purpose) */
     c[0] += (float)a[0] * (float)b[0];
@@ -61,12 +68,24 @@ __device__ __forceinline__ f32x16 mfma_f16(h8 a, h8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-// x -> (hi, lo') for 4 values
-__device__ __forceinline__ void split4(f32x4 v, u32x2& hi, u32x2& lo) {
-    const h4 h = __builtin_convertvector(v, h4);                    // v_cvt_pk_f16_f32: round to nearest even
-    const f32x4 r = (v - __builtin_convertvector(h, f32x4)) * CS_SCALE;   // exact
+// x -> (hi, lo') for 4 values: hi = f16(x) (round to nearest even), lo' = f16(x * 2^11 - hi * 2^11): the fused multiply-add is
+// exact here (x - hi has at most 13 significant bits), so lo' = f16((x - hi) 2^11) with one rounding.  v_fma_mix*_f16 reads the
+// f16 operand in place and writes the f16 result: 8 VALU per 4 values (the plain C++ form compiles to 12-14).
+__device__ __forceinline__ void split4(f32x4 v, u32x2& hi, u32x2& lo, float nscale) {
+    const h4 h = __builtin_convertvector(v, h4);                    // 2 x v_cvt_pk_f16_f32
     hi = __builtin_bit_cast(u32x2, h);
+#ifdef CS_X_PLAINSPLIT
+    const f32x4 r = (v - __builtin_convertvector(h, f32x4)) * CS_SCALE;
     lo = __builtin_bit_cast(u32x2, __builtin_convertvector(r, h4));
+#else
+    const f32x4 t = v * CS_SCALE;                                   // 2 x v_pk_mul_f32, exact
+    unsigned l0, l1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi.x), "s"(nscale), "v"(t.x));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l0) : "v"(hi.x), "s"(nscale), "v"(t.y));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi.y), "s"(nscale), "v"(t.z));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l1) : "v"(hi.y), "s"(nscale), "v"(t.w));
+    lo = u32x2{l0, l1};
+#endif
 }
 
 // FUSE = false: out = act(conv + bias).   FUSE = true (conv2_i per-frame half): out = act(conv + bias + addend[item / add_div]) + resid.
@@ -78,6 +97,9 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef PFNL_S16_TIMING
+    int dbg_n = 0;
+#endif
     const int rp = wave >> 1;                                       // rows 2rp, 2rp+1 of the tile
     const int mt = wave & 1;                                        // output channels 32mt .. 32mt+31
     const int H = p.H, W = p.W;
@@ -94,7 +116,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
     const int ccnt = min(per_xcd, nchains - cbeg);
     if (xj >= ccnt) return;
     const int nt = ((ccnt - xj + cpx - 1) / cpx) * gT;              // tiles of this workgroup
-    const int nu = 2 * nt;                                          // units: (tile, channel half); nu >= 2
+    [[maybe_unused]] const int nu = 2 * nt;                         // units: (tile, channel half); nu >= 2
     // tile k -> (item, y0, x0)
 #define CS_TILE(k_, item_, y0_, x0_)                                                             \
     do {                                                                                         \
@@ -117,28 +139,30 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
     if (tid < 64) bl[tid] = p.bias[tid];
 
     // staging map: piece id = k*512 + tid -> halo pixel id >> 3, 4-channel piece id & 7 (8 threads read one pixel's 128 B)
-    int spk[CS_ITERS];                                              // py << 16 | px << 3 | c4
+    // Two words per piece, constant for the life of the kernel: `grel` = byte offset of the piece relative to the halo origin
+    // in HBM, `lpk` = LDS byte address of its hi half-chunk inside a halo buffer | py << 16 | px << 24 (for the border test).
+    int grel[CS_ITERS], lpk[CS_ITERS];
+    const int wbytes = W * 256;
 #pragma unroll
     for (int k = 0; k < CS_ITERS; ++k) {
         const int id = min(k * CS_THREADS + tid, CS_PIECES - 1);    // surplus threads redo the last piece (same value)
         const int pix = id >> 3, c = id & 7;
         const int py = pix / CS_IW, px = pix - py * CS_IW;
-        spk[k] = (py << 16) | (px << 3) | c;
+        grel[k] = py * wbytes + px * 256 + c * 16;
+        lpk[k] = ((py * CS_IW + px) * 128 + 8 * (c & 1) + (((c >> 1) ^ ((px >> 1) & 7)) << 4)) | (py << 16) | (px << 24);
     }
-    const int wbytes = W * 256;
+    const float nscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -CS_SCALE)));
     f32x4 stg[CS_ITERS];
 #define CS_REQUEST_ALL(rs_, org_, interior_, y0_, x0_)                                           \
     do {                                                                                         \
         if (interior_) {                                                                         \
             _Pragma("unroll") for (int k_ = 0; k_ < CS_ITERS; ++k_)                              \
-                stg[k_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(       \
-                    rs_, (org_) + (spk[k_] >> 16) * wbytes + ((spk[k_] >> 3) & 0x1fff) * 256 + (spk[k_] & 7) * 16, 0, 0)); \
+                stg[k_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, (org_) + grel[k_], 0, 0)); \
         } else {                                                                                 \
             _Pragma("unroll") for (int k_ = 0; k_ < CS_ITERS; ++k_) {                            \
-                const int gy_ = (y0_) + (spk[k_] >> 16) - 1, gx_ = (x0_) + ((spk[k_] >> 3) & 0x1fff) - 1; \
+                const int gy_ = (y0_) + ((lpk[k_] >> 16) & 0xff) - 1, gx_ = (x0_) + ((unsigned)lpk[k_] >> 24) - 1; \
                 const bool in_ = (unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W;     \
-                stg[k_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(       \
-                    rs_, in_ ? (org_) + (spk[k_] >> 16) * wbytes + ((spk[k_] >> 3) & 0x1fff) * 256 + (spk[k_] & 7) * 16 : 0x7fffffff, 0, 0)); \
+                stg[k_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, in_ ? (org_) + grel[k_] : 0x7fffffff, 0, 0)); \
             }                                                                                    \
         }                                                                                        \
     } while (0)
@@ -155,13 +179,11 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
 #else
 #define CS_COMMIT1(k_, buf_)                                                                     \
     do {                                                                                         \
-        const int py_ = spk[k_] >> 16, px_ = (spk[k_] >> 3) & 0x1fff, c_ = spk[k_] & 7;          \
-        u32x2 hi_, lo_;                                                                          \
-        split4(stg[k_], hi_, lo_);                                                               \
-        unsigned char* const b_ = cs_smem + (buf_) * CS_TILE_BYTES + (py_ * CS_IW + px_) * 128 + 8 * (c_ & 1); \
-        const int sw_ = (px_ >> 1) & 7;                                                          \
-        *reinterpret_cast<u32x2*>(b_ + (((c_ >> 1) ^ sw_) << 4)) = hi_;                          \
-        *reinterpret_cast<u32x2*>(b_ + ((((c_ >> 1) | 4) ^ sw_) << 4)) = lo_;                    \
+        u32x2 hi_, lo2_;                                                                         \
+        split4(stg[k_], hi_, lo2_, nscale);                                                      \
+        const int lo_ = lpk[k_] & 0xffff;                                                        \
+        *reinterpret_cast<u32x2*>(cs_smem + (buf_) * CS_TILE_BYTES + lo_) = hi_;                 \
+        *reinterpret_cast<u32x2*>(cs_smem + (buf_) * CS_TILE_BYTES + (lo_ ^ 64)) = lo2_;   /* lo' chunk = hi chunk ^ 4 */ \
     } while (0)
 #endif
 
@@ -241,10 +263,13 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
         v.z = fmaxf(v.z, sv.z);
         v.w = fmaxf(v.w, sv.w);
 #else
-        v.x = fmaxf(v.x, v.x * slope);                              // leaky_relu(0.2) or identity (slope 1), branch-free
-        v.y = fmaxf(v.y, v.y * slope);
-        v.z = fmaxf(v.z, v.z * slope);
-        v.w = fmaxf(v.w, v.w * slope);
+        {                                                           // leaky_relu(0.2) or identity (slope 1), branch-free
+            const f32x4 sv = v * slope;
+            asm("v_max_f32 %0, %1, %2" : "=v"(v.x) : "v"(v.x), "v"(sv.x));   // (fmaxf adds a canonicalising v_max x,x,x per element)
+            asm("v_max_f32 %0, %1, %2" : "=v"(v.y) : "v"(v.y), "v"(sv.y));
+            asm("v_max_f32 %0, %1, %2" : "=v"(v.z) : "v"(v.z), "v"(sv.z));
+            asm("v_max_f32 %0, %1, %2" : "=v"(v.w) : "v"(v.w), "v"(sv.w));
+        }
 #endif
         if constexpr (FUSE) v += rres[k & 1];
 #ifdef CS_X_NOSTORE   /* timing experiments only */
@@ -259,7 +284,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
     // ---- weight replacement: a slot (24 KB, one column tap) travels L2 -> registers -> LDS, 3 x 16 B per thread.
     // (global_load_lds_dwordx4 would need no registers, but with an LDS-DMA in flight this compiler turns EVERY vmcnt wait
     // into vmcnt(0) - the halo commit would then wait for the stores issued a moment earlier: measured.)
-    u32x4 wnx[CS_WITERS];
+    [[maybe_unused]] u32x4 wnx[CS_WITERS];
     auto w_request = [&](int half, int slot) __attribute__((always_inline)) {
 #ifndef CS_X_NOSWAP   /* timing experiments only */
         const u32x4* src = reinterpret_cast<const u32x4*>(p.wpack) + (size_t)half * (CS_W_BYTES / 16) + slot * (CS_SLOT_BYTES / 16);
@@ -301,16 +326,8 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
             constexpr int cb = PAR;                                 // LDS buffer of this unit (u = 2 kt + PAR)
             const unsigned char* const tile = cs_smem + cb * CS_TILE_BYTES;
             unsigned char* const other = cs_smem + (cb ^ 1) * CS_TILE_BYTES;
-            const int u = 2 * kt + PAR;
-            if constexpr (PAR == 0) {
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        accm[n][r] = 0.f;
-                        accc[n][r] = 0.f;
-                    }
-            }
+            [[maybe_unused]] const int u = 2 * kt + PAR;
+            CS_STAMP();                                             // 0: unit start
             // the NEXT unit's halo: requested here, committed in groups 4-5 of this unit (4 groups = ~2 us later), i.e. request
             // and use never straddle the loop back-edge and the compiler's vmcnt for the commit is exact
             {
@@ -349,11 +366,14 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                     }
                     if constexpr (g == 1) dump(other, PAR, 1);
                     if constexpr (g == 2) {
+                        CS_STAMP();                                 // 1: groups 0-1 done
                         CS_BARRIER();                              // b0: scratch complete; column tap 0 of the weights consumed
+                        CS_STAMP();                                 // 2: past b0
                         if constexpr (PAR == 0) {
                             w_write(0);
                             w_request(half_a ^ 1, 1);
                         }
+                        CS_STAMP();                                 // 3: weights slice written
                         store_piece(other, 0);
                         store_piece(other, 1);
                         fuse_request(2);
@@ -364,15 +384,19 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                         store_piece(other, 3);
                     }
                     if constexpr (g == 4) {
+                        CS_STAMP();                                 // 4: groups 2-3 done
                         CS_BARRIER();                              // b1: scratch read; column tap 1 consumed
+                        CS_STAMP();                                 // 5: past b1
                         if constexpr (PAR == 0) {
                             w_write(1);
                             w_request(half_a ^ 1, 2);
                         }
+                        CS_STAMP();                                 // 6: weights slice written
 #pragma unroll
-                        for (int k = 0; k < CS_ITERS; ++k) asm volatile("" : "+v"(spk[k]));   // opaque: nothing derived from it is hoisted into registers
+                        for (int k = 0; k < CS_ITERS; ++k) asm volatile("" : "+v"(lpk[k]));   // opaque: addresses derived from it are not hoisted into registers
 #pragma unroll
                         for (int k = 0; k < CS_ITERS / 2; ++k) CS_COMMIT1(k, cb ^ 1);
+                        CS_STAMP();                                 // 7: first half of the halo committed
                     }
                     if constexpr (g == 5) {
 #pragma unroll
@@ -381,7 +405,11 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // --- operands of the next sub-step
+#ifdef CS_X_NOREAD   /* timing experiments only */
+                if constexpr (false) {
+#else
                 if constexpr (S < 17) {
+#endif
                     constexpr int S1 = S + 1, g1 = S1 / 3, ky1 = S1 % 3;
                     Wv[S1 & 1][0] = CS_WT(g1, ky1, 0);
                     Wv[S1 & 1][1] = CS_WT(g1, ky1, 1);
@@ -398,10 +426,18 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                 __builtin_amdgcn_sched_barrier(0);
                 // --- 6 MFMAs: row tap ky of both output rows
                 const h8 wh = Wv[S & 1][0], wo = Wv[S & 1][1];
-                accm[0] = mfma_f16(wh, X[ky][0], accm[0]);
-                accm[1] = mfma_f16(wh, X[ky + 1][0], accm[1]);
-                accc[0] = mfma_f16(wo, X[ky][0], accc[0]);
-                accc[1] = mfma_f16(wo, X[ky + 1][0], accc[1]);
+                if constexpr (PAR == 0 && S == 0) {                 // a tile's first products: C = 0 (no registers to clear)
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    accm[0] = mfma_f16(wh, X[ky][0], zero);
+                    accm[1] = mfma_f16(wh, X[ky + 1][0], zero);
+                    accc[0] = mfma_f16(wo, X[ky][0], zero);
+                    accc[1] = mfma_f16(wo, X[ky + 1][0], zero);
+                } else {
+                    accm[0] = mfma_f16(wh, X[ky][0], accm[0]);
+                    accm[1] = mfma_f16(wh, X[ky + 1][0], accm[1]);
+                    accc[0] = mfma_f16(wo, X[ky][0], accc[0]);
+                    accc[1] = mfma_f16(wo, X[ky + 1][0], accc[1]);
+                }
                 accc[0] = mfma_f16(wh, X[ky][1], accc[0]);
                 accc[1] = mfma_f16(wh, X[ky + 1][1], accc[1]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -439,6 +475,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                 pending = true;
 #endif
             }
+            CS_STAMP();                                             // 8: groups 4-5 done
             CS_BARRIER();                                          // b2: this unit's buffer is free, the next unit's is complete
         };
         unit(std::integral_constant<int, 0>{});
@@ -531,3 +568,9 @@ void conv3x3_split16_pack_weights(const float* hwio, int cin_total, int cin_begi
 }
 
 }  // namespace pfnl
+
+#ifdef PFNL_S16_TIMING
+extern "C" int pfnl_debug_read_s16_stamps(long long* host, size_t n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(pfnl::cs_dbg), n * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -69,9 +69,13 @@ def test_container_types_and_device_path():
 def test_winograd_and_direct_paths_agree():
     gd = load_golden("ragged_7x20x36_nb2")
     eng = engine_for(geometry_of(gd["meta"]))
+    eng.set_option("conv3x3", "split16")                      # f16 matrix pipe, exactly split fp32 operands
+    y_s = eng.forward(gd["x"])
+    assert np.abs(y_s - gd["y"]).max() < ABS_TOL
     eng.set_option("conv3x3", "direct")
     y_d = eng.forward(gd["x"])
-    eng.set_option("conv3x3", "winograd")                     # default: persistent wave-specialised kernel
+    assert np.abs(y_d - y_s).max() < 2e-6
+    eng.set_option("conv3x3", "winograd")                     # persistent wave-specialised Winograd kernel
     y_w = eng.forward(gd["x"])
     eng.set_option("conv3x3", "winograd_tile")                # one workgroup per tile: same arithmetic, same bits
     y_t = eng.forward(gd["x"])
@@ -80,6 +84,7 @@ def test_winograd_and_direct_paths_agree():
     assert np.abs(y_t - y_w).max() < 2e-6
     with pytest.raises(Exception):
         eng.set_option("conv3x3", "fft")
+    eng.set_option("conv3x3", "auto")
 
 
 def test_bad_inputs_raise():
@@ -252,21 +257,26 @@ def test_full_size_all_clips_against_oracle():
     eng = engine_for(geom)
     lr, gt = synth.moving_field_clips(2, 7, 128, 128, seed=4321)
     x = np.concatenate([lr, synth.uniform_clips(2, 7, 128, 128, seed=8)], 0)
-    y = eng.forward(x)
-    assert y.shape == (4, 1, 512, 512, 3) and np.isfinite(y).all()
-    assert np.array_equal(eng.forward(x[::-1].copy()), y[::-1])
+    ys = {}
+    for algo in ("auto", "winograd"):                             # auto = the split-f16 kernel at this size (the default)
+        eng.set_option("conv3x3", algo)
+        ys[algo] = eng.forward(x)
+        assert ys[algo].shape == (4, 1, 512, 512, 3) and np.isfinite(ys[algo]).all()
+        assert np.array_equal(eng.forward(x[::-1].copy()), ys[algo][::-1])
+    eng.set_option("conv3x3", "auto")
     nthr = _t.get_num_threads()
     _t.set_num_threads(min(16, os.cpu_count() or 1))
     try:
         ref = pfnl_fast.FastOracle(synth.synthetic_weights(geom, 0)).forward(x)
     finally:
         _t.set_num_threads(nthr)
-    err = np.abs(y - ref).max(axis=(1, 2, 3, 4))
-    print("configs[1] max|hip - oracle| per clip:", err)
-    assert err.max() < ABS_TOL, err
-    for b in range(2):
-        d = abs(synth.psnr(y[b, 0], gt[b]) - synth.psnr(ref[b, 0], gt[b]))
-        assert d <= PSNR_TOL_DB, d
+    for algo, y in ys.items():
+        err = np.abs(y - ref).max(axis=(1, 2, 3, 4))
+        print("configs[1] conv3x3=%s max|hip - oracle| per clip:" % algo, err)
+        assert err.max() < ABS_TOL, (algo, err)
+        for b in range(2):
+            d = abs(synth.psnr(y[b, 0], gt[b]) - synth.psnr(ref[b, 0], gt[b]))
+            assert d <= PSNR_TOL_DB, (algo, d)
 
 
 def test_configs4_geometry_full_size():
@@ -294,12 +304,15 @@ def test_1080p_fp32_against_oracle_subsample():
     geom = PFNLGeometry()
     eng = engine_for(geom)
     x = synth.uniform_clips(1, 7, 270, 480, seed=seed)
-    y = eng.forward(x)[0, 0]
-    assert y.shape == (1080, 1920, 3) and np.isfinite(y).all()
-    e1 = np.abs(y[::stride, ::stride] - gd["y_fp32"]).max()
-    e2 = np.abs(y[cy:cy + cs, cx:cx + cs] - gd["y_fp32_crop"]).max()
-    print("1080p fp32 max|hip - oracle|: subsample %.3g, crop %.3g" % (e1, e2))
-    assert e1 < ABS_TOL and e2 < ABS_TOL, (e1, e2)
+    for algo in ("auto", "winograd"):
+        eng.set_option("conv3x3", algo)
+        y = eng.forward(x)[0, 0]
+        assert y.shape == (1080, 1920, 3) and np.isfinite(y).all()
+        e1 = np.abs(y[::stride, ::stride] - gd["y_fp32"]).max()
+        e2 = np.abs(y[cy:cy + cs, cx:cx + cs] - gd["y_fp32_crop"]).max()
+        print("1080p fp32 conv3x3=%s max|hip - oracle|: subsample %.3g, crop %.3g" % (algo, e1, e2))
+        assert e1 < ABS_TOL and e2 < ABS_TOL, (algo, e1, e2)
+    eng.set_option("conv3x3", "auto")
 
 
 def test_embedded_gaussian_option_forward():
@@ -362,7 +375,7 @@ def test_random_geometry_fuzz(seed):
     eng = PFNLEngine(geom)
     eng.load_weights(w)
     ref = pfnl_fast.FastOracle(w, T, scale, nb).forward(x)
-    for algo in ("winograd", "winograd_split", "winograd_tile", "direct"):
+    for algo in ("winograd", "winograd_split", "winograd_tile", "direct", "split16", "auto"):
         eng.set_option("conv3x3", "winograd" if algo == "winograd_split" else algo)
         eng.set_option("conv2", "split" if algo == "winograd_split" else "grouped")
         y = eng.forward(x)

@@ -329,3 +329,55 @@ def test_gather_windows_and_quantise():
     sr = (rng.random((2, 1, 8, 12, 3), dtype=np.float32) * 1.4 - 0.2)
     sr.ravel()[:8] = [0.5 / 255, 1.5 / 255, 2.5 / 255, 254.5 / 255, 1.0, 0.0, -1.0, 2.0]      # ties, ends, out of range
     assert np.array_equal(ops.quantise_u8(dev(sr)).cpu().numpy(), M.quantise(sr))
+
+
+@pytest.mark.parametrize("items,H,W,fused,act", [(1, 8, 32, False, True), (7, 10, 38, True, True), (3, 5, 7, False, False), (1, 1, 1, False, True),
+                                                  (7, 33, 70, True, True), (2, 64, 96, False, True), (28, 24, 40, True, True),
+                                                  (1, 9, 130, False, True), (21, 16, 32, True, False)])
+def test_conv3x3_split16(items, H, W, fused, act):
+    """The fp32 3x3 64->64 convolution on the f16 matrix pipe with exactly split operands (conv_split16.hip; reference
+    model/pfnl.py:49-51 at :66-71): every product carries >= 22 mantissa bits, accumulation is fp32 - the error against the
+    fp64 spec must not exceed the direct f32-MFMA kernel's (an fp32 FMA chain).  Odd sizes, ragged tiles, chains of 7."""
+    rng = np.random.default_rng(items * 1000 + H * 10 + W)
+    x = rng.normal(size=(items, H, W, 64)).astype(np.float32)
+    k = (rng.normal(size=(3, 3, 64, 64)) / 24.0).astype(np.float32)
+    b = (rng.normal(size=64) * 0.1).astype(np.float32)
+    ref = pfnl_spec.conv2d_same(x.astype(np.float64), k.astype(np.float64), b.astype(np.float64))
+    kw = {}
+    if fused:
+        div = 7 if items % 7 == 0 else 1
+        add = rng.normal(size=(items // div, H, W, 64)).astype(np.float32)
+        res = rng.normal(size=(items, H, W, 64)).astype(np.float32)
+        ref = ref + np.repeat(add.astype(np.float64), div, axis=0)
+        kw = dict(addend=dev(add), add_div=div, resid=dev(res))
+    if act:
+        ref = pfnl_spec.lrelu(ref)
+    if fused:
+        ref = ref + res
+    got = ops.conv3x3_winograd(dev(x), k, b, act=act, variant="split16", **kw).cpu().numpy()
+    direct = ops.conv2d(dev(x), k, b, act=act, **kw).cpu().numpy()
+    e_s, e_d = np.abs(got - ref).max(), np.abs(direct - ref).max()
+    assert e_s < 4e-6 * max(1.0, np.abs(ref).max()), (e_s, e_d)
+    assert e_s <= 1.5 * e_d + 1e-7, (e_s, e_d)                    # as good as the fp32 FMA chain of the direct kernel
+
+
+def test_conv3x3_split16_scaling_and_data_movement():
+    """Accuracy does not depend on the magnitude of the activations inside binary16's range (lo' is kept scaled by 2^11, so
+    small values do not lean on binary16 subnormals); a delta kernel moves data bit-exactly (hi + lo' 2^-11 reconstructs x
+    when x has <= 22 significant bits)."""
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(2, 16, 32, 64)).astype(np.float32)
+    k = (rng.normal(size=(3, 3, 64, 64)) / 24.0).astype(np.float32)
+    base = ops.conv3x3_winograd(dev(x), k, None, act=False, variant="split16").cpu().numpy()
+    ref = pfnl_spec.conv2d_same(x.astype(np.float64), k.astype(np.float64), None)
+    e0 = np.abs(base - ref).max()
+    for sc in (2.0 ** -12, 2.0 ** -6, 2.0 ** 8):
+        got = ops.conv3x3_winograd(dev(x * np.float32(sc)), k, None, act=False, variant="split16").cpu().numpy()
+        assert np.abs(got / sc - ref).max() <= 1.5 * e0 + 1e-7, (sc, np.abs(got / sc - ref).max(), e0)
+    xq = (np.round(x * 1024) / 1024).astype(np.float32)            # <= 14 significant bits
+    delta = np.zeros((3, 3, 64, 64), np.float32)
+    delta[0, 2, 5, 9] = 1.0                                         # out[y, x, 9] = in[y - 1, x + 1, 5]
+    got = ops.conv3x3_winograd(dev(xq), delta, None, act=False, variant="split16").cpu().numpy()
+    xp = np.pad(xq, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    assert np.array_equal(got[..., 9], xp[:, 0:16, 2:34, 5])
+    assert not got[..., :9].any() and not got[..., 10:].any()
