@@ -100,6 +100,9 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
 #ifdef PFNL_S16_TIMING
     int dbg_n = 0;
 #endif
+#ifdef CS_PRIO_LATE   /* experiment: waves 4-7 (the younger wave of every SIMD) above waves 0-3 */
+    if (wave >= 4) __builtin_amdgcn_s_setprio(CS_PRIO_LATE);
+#endif
     const int rp = wave >> 1;                                       // rows 2rp, 2rp+1 of the tile
     const int mt = wave & 1;                                        // output channels 32mt .. 32mt+31
     const int H = p.H, W = p.W;
@@ -222,8 +225,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int r0 = 8 * h + 4 * q;
-            const f32x4 v = f32x4{accp[n][r0], accp[n][r0 + 1], accp[n][r0 + 2], accp[n][r0 + 3]} +
-                            *reinterpret_cast<const f32x4*>(bl + ech + r0);
+            const f32x4 v = f32x4{accp[n][r0], accp[n][r0 + 1], accp[n][r0 + 2], accp[n][r0 + 3]};   // (the bias is already in: initial C of the tile)
             const int c = (ech + r0) >> 2;                          // 16-byte chunk of the pixel's line
             *reinterpret_cast<f32x4*>(pl + (((c & 8) | ((c ^ j) & 7)) << 4)) = v;
         }
@@ -319,6 +321,13 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
     // runs with out-of-range offsets: dropped stores, zero loads), so that the compiler's s_waitcnt counts are exact: a
     // conservative vmcnt(0) in front of the halo commit would wait for the stores issued a moment earlier (measured:
     // 120 us per conv1_i launch with runtime branches around them).
+    // coordinates of the current tile and of the next one: ONE decode (three scalar divisions) per tile, done in unit A for the
+    // tile after this one, where its latency is nobody's critical path
+    int c_item, c_y0, c_x0, n_item, n_y0, n_x0;
+    CS_TILE(0, c_item, c_y0, c_x0);
+    n_item = c_item;
+    n_y0 = c_y0;
+    n_x0 = c_x0;
     for (int kt = 0; kt < nt; ++kt) {
         const int half_a = kt & 1;                                  // channel half of unit A; unit B: the other one
         auto unit = [&](auto par) __attribute__((always_inline)) {
@@ -332,21 +341,39 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
             // and use never straddle the loop back-edge and the compiler's vmcnt for the commit is exact
             {
 #ifndef CS_X_NOLOAD
-                CS_REQ_SETUP(min(u + 1, nu - 1), rs, org, interior, y0q, x0q);   // past the end: harmless re-read
+                // unit A asks for the other half of ITS tile, unit B for the first half of the next tile
+                const int q_item = PAR == 0 ? c_item : n_item, y0q = PAR == 0 ? c_y0 : n_y0, x0q = PAR == 0 ? c_x0 : n_x0;
+                const int q_half = half_a ^ 1;                      // (boustrophedon: unit B's half is also the next tile's first half)
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(p.in) + (size_t)q_item * H * W * 64, 0, item_bytes, 0x00020000);
+                const int org = ((y0q - 1) * W + x0q - 1) * 256 + q_half * 128;
+                const bool interior = y0q > 0 && y0q + CS_IH - 1 <= H && x0q > 0 && x0q + CS_IW - 1 <= W;
                 CS_REQUEST_ALL(rs, org, interior, y0q, x0q);
 #endif
             }
-            // weights of unit B (the other channel half) follow the column taps unit A has consumed: tap 0 requested here,
-            // written after b0 (visible from b1), tap 1 requested after b0, written after b1 (visible from b2), tap 2 requested
-            // after b1, written at the start of unit B (visible from its b0, first read after its b1)
+            // weights of unit B (the other channel half) follow the column taps unit A has consumed.  A slice must be in LDS
+            // before the barrier that precedes its first operand prefetch (issued one sub-step before its group):
+            //   tap 0: requested here, written in group 3 of unit A (free since b0; read from unit B's start, after b2)
+            //   tap 1: requested in group 3, written in group 5 (free since b1; prefetched in unit B's group 1, after b2)
+            //   tap 2: requested in group 5, written in group 1 of unit B (free since b2; prefetched in group 3, after b0)
             if constexpr (PAR == 0) w_request(half_a ^ 1, 0);
-            else w_write(2);
             piece_setup(PAR);                                       // epilogue pass PAR of the previous tile (nothing pending: out of range)
 
             // operands: X[row][part], Wv[substep parity][part]
             h8 X[4][2], Wv[2][2];
 #define CS_PX(g_, r_, part_) (*reinterpret_cast<const h8*>(tile + (paddr[(g_) >> 1] ^ (((part_) ? lo_xor : 0) | (((g_) & 1) << 5))) + (r_) * (CS_IW * 128)))
 #define CS_WT(g_, ky_, part_) (*reinterpret_cast<const h8*>(wlane + (((g_) * 3 + (ky_)) << 12) + ((part_) << 10)))
+            [[maybe_unused]] f32x16 bias16;                         // register r of a lane = channel ech + r
+            if constexpr (PAR == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + ech + 4 * q);
+                    bias16[4 * q] = b4.x;
+                    bias16[4 * q + 1] = b4.y;
+                    bias16[4 * q + 2] = b4.z;
+                    bias16[4 * q + 3] = b4.w;
+                }
+            }
             X[0][0] = CS_PX(0, 0, 0);
             X[0][1] = CS_PX(0, 0, 1);
             X[1][0] = CS_PX(0, 1, 0);
@@ -364,16 +391,15 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                         fuse_request(0);
                         fuse_request(1);
                     }
-                    if constexpr (g == 1) dump(other, PAR, 1);
+                    if constexpr (g == 1) {
+                        dump(other, PAR, 1);
+                        if constexpr (PAR == 1) w_write(2);
+                    }
                     if constexpr (g == 2) {
                         CS_STAMP();                                 // 1: groups 0-1 done
                         CS_BARRIER();                              // b0: scratch complete; column tap 0 of the weights consumed
                         CS_STAMP();                                 // 2: past b0
-                        if constexpr (PAR == 0) {
-                            w_write(0);
-                            w_request(half_a ^ 1, 1);
-                        }
-                        CS_STAMP();                                 // 3: weights slice written
+                        CS_STAMP();                                 // 3
                         store_piece(other, 0);
                         store_piece(other, 1);
                         fuse_request(2);
@@ -382,16 +408,20 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                     if constexpr (g == 3) {
                         store_piece(other, 2);
                         store_piece(other, 3);
+                        if constexpr (PAR == 0) {
+                            w_write(0);
+                            w_request(half_a ^ 1, 1);
+                        }
+                        if constexpr (PAR == 0) {                   // decode the next tile (past the end: this one again - a harmless re-read)
+                            const int kn = min(kt + 1, nt - 1);
+                            CS_TILE(kn, n_item, n_y0, n_x0);
+                        }
                     }
                     if constexpr (g == 4) {
                         CS_STAMP();                                 // 4: groups 2-3 done
                         CS_BARRIER();                              // b1: scratch read; column tap 1 consumed
                         CS_STAMP();                                 // 5: past b1
-                        if constexpr (PAR == 0) {
-                            w_write(1);
-                            w_request(half_a ^ 1, 2);
-                        }
-                        CS_STAMP();                                 // 6: weights slice written
+                        CS_STAMP();                                 // 6
 #pragma unroll
                         for (int k = 0; k < CS_ITERS; ++k) asm volatile("" : "+v"(lpk[k]));   // opaque: addresses derived from it are not hoisted into registers
 #pragma unroll
@@ -401,6 +431,10 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                     if constexpr (g == 5) {
 #pragma unroll
                         for (int k = CS_ITERS / 2; k < CS_ITERS; ++k) CS_COMMIT1(k, cb ^ 1);
+                        if constexpr (PAR == 0) {
+                            w_write(1);
+                            w_request(half_a ^ 1, 2);
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -426,10 +460,10 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                 __builtin_amdgcn_sched_barrier(0);
                 // --- 6 MFMAs: row tap ky of both output rows
                 const h8 wh = Wv[S & 1][0], wo = Wv[S & 1][1];
-                if constexpr (PAR == 0 && S == 0) {                 // a tile's first products: C = 0 (no registers to clear)
+                if constexpr (PAR == 0 && S == 0) {                 // a tile's first products: C = bias / 0 (no registers to clear)
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    accm[0] = mfma_f16(wh, X[ky][0], zero);
-                    accm[1] = mfma_f16(wh, X[ky + 1][0], zero);
+                    accm[0] = mfma_f16(wh, X[ky][0], bias16);
+                    accm[1] = mfma_f16(wh, X[ky + 1][0], bias16);
                     accc[0] = mfma_f16(wo, X[ky][0], zero);
                     accc[1] = mfma_f16(wo, X[ky + 1][0], zero);
                 } else {
@@ -466,11 +500,12 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                 // (the previous tile's second pass ran in this unit: accp is free)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) accp[n] = accm[n] + accc[n] * CS_ISCALE;
-                int item_e, y0e, x0e;
-                CS_TILE(kt, item_e, y0e, x0e);
-                ex0p = x0e;
-                ey0p = y0e;
-                eitemp = item_e;
+                ex0p = c_x0;
+                ey0p = c_y0;
+                eitemp = c_item;
+                c_item = n_item;                                    // on to the next tile
+                c_y0 = n_y0;
+                c_x0 = n_x0;
 #ifndef CS_X_NOEPI   /* timing experiments only */
                 pending = true;
 #endif
