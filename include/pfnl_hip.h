@@ -108,6 +108,13 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value);
  * the call is asynchronous on `stream`; with host pointers it returns when `out` is filled. */
 int pfnl_forward(pfnl_handle* h, const void* in, int in_is_device, void* out, int out_is_device,
                  int B, int H, int W, void* stream);
+/* Single-clip multi-GPU sharding (the reference is single-GPU, main.py:10): the rows
+ * [scale*row0, scale*(row0+nrows)) of every SR frame, written at their place in the FULL-size `out`.  `in` is the full clip
+ * (device pointers, asynchronous on `stream`).  The non-local block runs this strip's queries against ALL keys of the frame
+ * (they need the whole input, which every rank holds: 7 LR frames), the trunk runs on the strip plus a halo of
+ * 4 + 2*num_block LR rows per side that is recomputed instead of exchanged - ranks share nothing on the data path and the
+ * union of the strips equals pfnl_forward's output up to summation order (tile alignment differs). */
+int pfnl_forward_strip(pfnl_handle* h, const void* in, void* out, int B, int H, int W, int row0, int nrows, void* stream);
 int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes);
 int pfnl_sync(pfnl_handle* h);
 

@@ -44,6 +44,7 @@ SIGNATURES = {
     "pfnl_finalize_weights": (_i, [_vp]),
     "pfnl_set_option": (_i, [_vp, C.c_char_p, C.c_char_p]),
     "pfnl_forward": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "pfnl_forward_strip": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pfnl_workspace_bytes": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_size_t)]),
     "pfnl_sync": (_i, [_vp]),
     "pfnl_profile_enable": (_i, [_vp, _i]),

@@ -196,15 +196,19 @@ size_t numel(const std::vector<int64_t>& s) {
 }
 
 // forward over device buffers
-int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, int W, hipStream_t s) {
+// `strip` != null: only LR rows [strip->yoff + core0, strip->yoff + core1) of the result are produced (single-clip sharding,
+// pfnl_forward_strip): the non-local block runs its queries [q0, q1) against ALL keys, the trunk runs on the strip + halo.
+int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull, int W, hipStream_t s,
+                   const StripGeom* strip = nullptr, int q0 = 0, int q1 = -1) {
     const pfnl_config& c = h->cfg;
     const int T = c.num_frames, F = B * T;
+    const int H = strip ? strip->Hs : Hfull;                       // rows the trunk buffers hold
     const size_t P = (size_t)H * W;
-    const int N = (H / 2) * (W / 2);
+    const int N = (Hfull / 2) * (W / 2);
     const int C = 12 * T, CP = nl_padded_ch(C);
     const float* wd = h->wdev.p;
 
-    if (h->X.ensure((size_t)B * N * CP) || h->Xo.ensure((size_t)B * N * CP) ||
+    if (h->X.ensure((size_t)B * N * CP) || h->Xo.ensure((size_t)B * N * CP) ||     // (N: the FULL frame - keys are global)
         h->nlp.ensure(nl_partial_floats(B, N, C)) ||
         h->inp0.ensure((size_t)F * P * 64) || h->inp1.ensure((size_t)F * P * 64) ||
         h->base.ensure((size_t)B * P * 64) || h->pb.ensure((size_t)B * P * 64) ||
@@ -216,28 +220,28 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
 
     {   // model/pfnl.py:55-60 (+ utils.py:18-71)
         ProfScope ps(h, s, PFNL_K_NL_PACK);
-        HIPCHK(launch_nl_pack(in, h->X.p, B, T, H, W, s));
+        HIPCHK(launch_nl_pack(in, h->X.p, B, T, Hfull, W, s));
     }
     {
         ProfScope ps(h, s, PFNL_K_NL_ATTN);
         if (h->nl_theta) {   // nltype 0: queries X M + c, keys / values X (fp32 kernel in both precisions)
             if (h->Q.ensure((size_t)B * N * CP)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
             HIPCHK(launch_nl_qproj(h->X.p, wd + h->off_nl_m, wd + h->off_nl_c, h->Q.p, B, N, C, s));
-            HIPCHK(launch_nl_attn(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p, B, N, C, s, h->Q.p));
+            HIPCHK(launch_nl_attn(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p, B, N, C, s, h->Q.p, q0, q1));
         } else if (h->bf16) {
             if (h->nl16.ensure((nl_bf16_scratch_halfs(B, N) + 1) / 2)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
             HIPCHK(launch_nl_attn_bf16(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p,
-                                       reinterpret_cast<uint16_t*>(h->nl16.p), B, N, C, s));
+                                       reinterpret_cast<uint16_t*>(h->nl16.p), B, N, C, s, q0, q1));
         } else {
-            HIPCHK(launch_nl_attn(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p, B, N, C, s));
+            HIPCHK(launch_nl_attn(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p, B, N, C, s, nullptr, q0, q1));
         }
     }
     {   // model/pfnl.py:61-62
         ProfScope ps(h, s, PFNL_K_CONV0);
         if (h->bf16)
-            HIPCHK(launch_conv0_bf16(h->Xo.p, wd + h->off_conv0_w, wd + h->off_conv0_b, reinterpret_cast<uint16_t*>(h->inp0.p), B, T, H, W, s));
+            HIPCHK(launch_conv0_bf16(h->Xo.p, wd + h->off_conv0_w, wd + h->off_conv0_b, reinterpret_cast<uint16_t*>(h->inp0.p), B, T, Hfull, W, s, strip));
         else
-            HIPCHK(launch_conv0(h->Xo.p, wd + h->off_conv0_w, wd + h->off_conv0_b, h->inp0.p, B, T, H, W, s));
+            HIPCHK(launch_conv0(h->Xo.p, wd + h->off_conv0_w, wd + h->off_conv0_b, h->inp0.p, B, T, Hfull, W, s, strip));
     }
     const float* merge_in = h->inp0.p;
     if (h->bf16) {
@@ -290,7 +294,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
         h->merge_cstride = 64;
         {   // model/pfnl.py:63,76-80
             ProfScope ps(h, s, PFNL_K_TAIL);
-            HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, H, W, c.scale, 64, s));
+            HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, Hfull, W, c.scale, 64, s, strip));
         }
         h->chain_open = false;
         return 0;
@@ -460,7 +464,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int H, in
     }
     {   // model/pfnl.py:63,76-80
         ProfScope ps(h, s, PFNL_K_TAIL);
-        HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, H, W, c.scale, mstride, s));
+        HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, Hfull, W, c.scale, mstride, s, strip));
     }
     h->chain_open = false;
     return 0;
@@ -926,6 +930,28 @@ int pfnl_forward(pfnl_handle* h, const void* in, int in_is_device, void* out, in
         HIPCHK(hipStreamSynchronize(s));   // the caller may reuse its host buffer on return
     }
     return 0;
+}
+
+// Single-clip multi-GPU sharding: one rank's horizontal strip of the SR frame.
+int pfnl_forward_strip(pfnl_handle* h, const void* in, void* out, int B, int H, int W, int row0, int nrows, void* stream) {
+    if (!h || !in || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (!h->finalized) return fail(PFNL_ERR_STATE, "pfnl_finalize_weights has not been called");
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return fail(PFNL_ERR_INVALID, "B, H, W must be positive, H and W even");
+    if (row0 < 0 || nrows < 1 || row0 + nrows > H) return fail(PFNL_ERR_INVALID, "strip rows out of range");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    // receptive field of an output row in LR rows: tail conv (1) + convmerge1 (1) + 2 per progressive-fusion block + conv0 (2)
+    const int halo = 4 + 2 * h->cfg.num_block;
+    int a = row0 - halo, b = row0 + nrows + halo;
+    a = a < 0 ? 0 : (a & ~1);                                    // even: space_to_depth(2) rows, Winograd tiles
+    b = b > H ? H : ((b + 1) & ~1);
+    const StripGeom g{a, b - a, row0 - a, row0 - a + nrows};
+    // non-local block: queries = the packed rows conv0 reads (2 LR rows of margin for its 5x5), keys = the whole frame
+    const int W2 = W / 2, H2 = H / 2;
+    int qa = (a - 2) >> 1, qb = (b + 2 + 1) >> 1;
+    qa = qa < 0 ? 0 : qa;
+    qb = qb > H2 ? H2 : qb;
+    hipStream_t s = stream ? (hipStream_t)stream : (hipStream_t) nullptr;
+    return forward_device(h, (const float*)in, (float*)out, B, H, W, s, &g, qa * W2, qb * W2);
 }
 
 int pfnl_sync(pfnl_handle* h) {

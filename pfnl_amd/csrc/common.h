@@ -95,18 +95,25 @@ int nl_padded_ch(int C);                                      // 32*ceil(C/32)
 hipError_t launch_nl_pack(const float* x, float* X, int B, int T, int H, int W, hipStream_t s);
 size_t nl_partial_floats(int B, int N, int C);               // scratch for the key-split partials (0 if unsplit)
 hipError_t launch_nl_attn(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, int B,
-                          int N, int C, hipStream_t s, const float* Q = nullptr);   // Q: projected queries (nltype 0) or null = X
+                          int N, int C, hipStream_t s, const float* Q = nullptr,    // Q: projected queries (nltype 0) or null = X
+                          int q0 = 0, int q1 = -1);                                 // queries [q0, q1) only (-1: N): a strip of the frame
 hipError_t launch_nl_qproj(const float* X, const float* M, const float* c, float* Q, int B, int N, int C, hipStream_t s);
 int nl_key_splits(int B, int N);
 hipError_t launch_nl_merge(const float* X, const float* Zp, const float* ML, const float* bp, float* Xo, int B, int N, int C, int ks,
-                           hipStream_t s);
+                           hipStream_t s, int q0 = 0, int q1 = -1);
 hipError_t launch_nl_unpack(const float* Xo, float* out, int B, int T, int H, int W, hipStream_t s);
 
 // ---- head / tail (misc_kernels.hip) ----------------------------------------------------------
+// A strip of the frame (single-clip multi-GPU sharding): the trunk buffers hold LR rows [yoff, yoff + Hs)
+// of the H-row frame; only rows [core0, core1) (strip-local) of the result are written, at their place in the full output.
+struct StripGeom {
+    int yoff, Hs, core0, core1;
+};
 hipError_t launch_conv0(const float* Xo, const float* w75x64, const float* bias, float* out, int B,
-                        int T, int H, int W, hipStream_t s);
+                        int T, int H, int W, hipStream_t s, const StripGeom* strip = nullptr);
 hipError_t launch_tail(const float* merge, const float* x, const float* w2, const float* b2,
-                       float* out, int B, int T, int H, int W, int scale, int merge_cstride, hipStream_t s);
+                       float* out, int B, int T, int H, int W, int scale, int merge_cstride, hipStream_t s,
+                       const StripGeom* strip = nullptr);
 hipError_t launch_blur_decimate(const float* hr, float* lr, int F, int H, int W, int scale, hipStream_t s);
 hipError_t launch_bicubic(const float* x, float* out, int B, int H, int W, int scale, hipStream_t s);
 hipError_t run_mfma_selftest(int* mismatches);

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ Xo
                                                     const float* __restrict__ w,     // [75][64]
                                                     const float* __restrict__ bias,  // [64]
                                                     float* __restrict__ out, int T, int H, int W,
-                                                    int CP) {
+                                                    int CP, int yoff, int Hs) {   // output = LR rows [yoff, yoff + Hs) of the H-row frame
     __shared__ __attribute__((aligned(16))) float smem0[256 * 36];   // weights [75][64] | input tile, later the store slab
     float* const sw = smem0;
     float* const s_in = smem0 + 75 * 64;
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ Xo
     for (int i = tid; i < C0_IN * C0_IN * 3; i += 256) {
         const int c = i % 3, pix = i / 3;
         const int py = pix / C0_IN, px = pix % C0_IN;
-        const int gy = y0 + py - 2, gx = x0 + px - 2;
+        const int gy = yoff + y0 + py - 2, gx = x0 + px - 2;       // (frame coordinates: rows outside a strip are real data)
         float v = 0.f;
         if (gy >= 0 && gy < H && gx >= 0 && gx < W)
             v = Xb[((size_t)(gy >> 1) * W2 + (gx >> 1)) * CP + ((gy & 1) * 2 + (gx & 1)) * C3 + 3 * t + c];
@@ -88,14 +88,14 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ Xo
             const int id = it * 256 + tid;
             const int pix = id >> 3, q = id & 7;
             const int y = y0 + pix / C0_T, x = x0 + pix % C0_T;
-            if (y < H && x < W) {
+            if (y < Hs && x < W) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(slab + pix * SS + q * 4);
                 if (BF16OUT) {
                     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                    *reinterpret_cast<bf16x4*>(reinterpret_cast<uint16_t*>(out) + (((size_t)f * H + y) * W + x) * 64 + hp * 32 + q * 4) =
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<uint16_t*>(out) + (((size_t)f * Hs + y) * W + x) * 64 + hp * 32 + q * 4) =
                         __builtin_convertvector(v, bf16x4);
                 } else {
-                    *reinterpret_cast<f32x4*>(out + (((size_t)f * H + y) * W + x) * 64 + hp * 32 + q * 4) = v;
+                    *reinterpret_cast<f32x4*>(out + (((size_t)f * Hs + y) * W + x) * 64 + hp * 32 + q * 4) = v;
                 }
             }
         }
@@ -103,18 +103,20 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ Xo
 }
 
 hipError_t launch_conv0(const float* Xo, const float* w75x64, const float* bias, float* out, int B,
-                        int T, int H, int W, hipStream_t s) {
-    dim3 grid((W + C0_T - 1) / C0_T, (H + C0_T - 1) / C0_T, B * T);
+                        int T, int H, int W, hipStream_t s, const StripGeom* strip) {
+    const int yoff = strip ? strip->yoff : 0, Hs = strip ? strip->Hs : H;
+    dim3 grid((W + C0_T - 1) / C0_T, (Hs + C0_T - 1) / C0_T, B * T);
     hipLaunchKernelGGL(conv0_kernel<false>, grid, dim3(256), 0, s, Xo, w75x64, bias, out, T, H, W,
-                       nl_padded_ch(12 * T));
+                       nl_padded_ch(12 * T), yoff, Hs);
     return hipGetLastError();
 }
 
 hipError_t launch_conv0_bf16(const float* Xo, const float* w75x64, const float* bias, uint16_t* out, int B, int T, int H,
-                             int W, hipStream_t s) {
-    dim3 grid((W + C0_T - 1) / C0_T, (H + C0_T - 1) / C0_T, B * T);
+                             int W, hipStream_t s, const StripGeom* strip) {
+    const int yoff = strip ? strip->yoff : 0, Hs = strip ? strip->Hs : H;
+    dim3 grid((W + C0_T - 1) / C0_T, (Hs + C0_T - 1) / C0_T, B * T);
     hipLaunchKernelGGL(conv0_kernel<true>, grid, dim3(256), 0, s, Xo, w75x64, bias, reinterpret_cast<float*>(out), T, H, W,
-                       nl_padded_ch(12 * T));
+                       nl_padded_ch(12 * T), yoff, Hs);
     return hipGetLastError();
 }
 
@@ -189,14 +191,16 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ mer
                                                    const float* __restrict__ x,   // [B][T][H][W][3]
                                                    const float* __restrict__ w2,  // [3][3][12][CO]
                                                    const float* __restrict__ b2,  // [CO]
-                                                   float* __restrict__ out, int B, int T, int H, int W, int MS) {   // MS = floats per merge pixel (48 or 64)
+                                                   float* __restrict__ out, int B, int T, int H, int W, int MS,   // MS = floats per merge pixel (48 or 64)
+                                                   int yoff, int Hs, int core0, int core1) {   // merge holds LR rows [yoff, yoff + Hs) of the H-row frame;
+                                                                                                // only strip rows [core0, core1) are written
     constexpr int SCALE = (CO == 12) ? 4 : 2;
-    const int H2 = 2 * H, W2 = 2 * W;
+    const int H2 = 2 * Hs, W2 = 2 * W;
     const int X = blockIdx.x * 32 + (threadIdx.x & 31);
     const int Y = blockIdx.y * 8 + (threadIdx.x >> 5);
     const int b = blockIdx.z;
-    if (X >= W2 || Y >= H2) return;
-    const float* mb = merge + (size_t)b * H * W * MS;
+    if (X >= W2 || Y >= H2 || (Y >> 1) < core0 || (Y >> 1) >= core1) return;
+    const float* mb = merge + (size_t)b * Hs * W * MS;
 
     float acc[CO];
 #pragma unroll
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ mer
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int oy = 2 * Y + i, ox = 2 * X + j;
+                const int oy = 2 * (Y + 2 * yoff) + i, ox = 2 * X + j;          // frame coordinates
                 float bic[3];
                 bicubic_px(xc, H, W, (size_t)W * 3, SCALE, oy, ox, bic);
                 float* dst = ob + ((size_t)oy * OW + ox) * 3;
@@ -239,21 +243,22 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ mer
             }
     } else {
         float bic[3];
-        bicubic_px(xc, H, W, (size_t)W * 3, SCALE, Y, X, bic);
-        float* dst = ob + ((size_t)Y * OW + X) * 3;
+        bicubic_px(xc, H, W, (size_t)W * 3, SCALE, Y + 2 * yoff, X, bic);
+        float* dst = ob + ((size_t)(Y + 2 * yoff) * OW + X) * 3;
 #pragma unroll
         for (int c = 0; c < 3; ++c) dst[c] = acc[c] + bic[c];
     }
 }
 
 hipError_t launch_tail(const float* merge, const float* x, const float* w2, const float* b2, float* out,
-                       int B, int T, int H, int W, int scale, int merge_cstride, hipStream_t s) {
+                       int B, int T, int H, int W, int scale, int merge_cstride, hipStream_t s, const StripGeom* strip) {
     if (merge_cstride != 48 && merge_cstride != 64) return hipErrorInvalidValue;
-    dim3 grid((2 * W + 31) / 32, (2 * H + 7) / 8, B);
+    const StripGeom g = strip ? *strip : StripGeom{0, H, 0, H};
+    dim3 grid((2 * W + 31) / 32, (2 * g.Hs + 7) / 8, B);
     if (scale == 4)
-        hipLaunchKernelGGL(tail_kernel<12>, grid, dim3(256), 0, s, merge, x, w2, b2, out, B, T, H, W, merge_cstride);
+        hipLaunchKernelGGL(tail_kernel<12>, grid, dim3(256), 0, s, merge, x, w2, b2, out, B, T, H, W, merge_cstride, g.yoff, g.Hs, g.core0, g.core1);
     else if (scale == 2)
-        hipLaunchKernelGGL(tail_kernel<3>, grid, dim3(256), 0, s, merge, x, w2, b2, out, B, T, H, W, merge_cstride);
+        hipLaunchKernelGGL(tail_kernel<3>, grid, dim3(256), 0, s, merge, x, w2, b2, out, B, T, H, W, merge_cstride, g.yoff, g.Hs, g.core0, g.core1);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

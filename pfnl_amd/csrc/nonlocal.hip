@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
                                                          float* __restrict__ Zp,         // [B][ks][N][CP] partial W'^T O (ks > 1)
                                                          float* __restrict__ ML,         // [B][ks][N][2]  partial (max, sum)
                                                          const float* __restrict__ Q,    // [B][N][CP] queries (nltype 0: X M + c), or X
-                                                         int N) {
+                                                         int N, int q0, int q1) {   // queries [q0, q1) only (a strip of the frame)
     constexpr int CT = (C + 31) / 32;
     constexpr int CP = CT * 32;
     constexpr int LS = CP + 1;            // odd LDS row stride: key rows land on distinct banks
@@ -89,8 +89,8 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
     const int b = blockIdx.y;
     const float* Xb = X + (size_t)b * N * CP;
     float* Xob = Xo + (size_t)b * N * CP;
-    const int q = blockIdx.x * 128 + wave * 32 + xl;       // this lane's query
-    const int qc = q < N ? q : N - 1;
+    const int q = q0 + blockIdx.x * 128 + wave * 32 + xl;  // this lane's query
+    const int qc = q < q1 ? q : q1 - 1;
 
     // B operand of S^T = Xk Xq^T: lane holds Xq[q][2s + kh], pre-scaled by log2(e) so that the logits come out
     // of the MFMA in base-2 units and the softmax needs one v_exp_f32 per element (expf expands to ~8 VALU, and
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
             for (int s = 0; s < 16; ++s)
                 z = mfma32(wa[((s & 3) + 8 * (s >> 2)) * CP], o[ct][s], z);
         }
-        if (q < N) {
+        if (q < q1) {
             if (ks == 1) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
             }
         }
     }
-    if (ks > 1 && q < N && kh == 0) {
+    if (ks > 1 && q < q1 && kh == 0) {
         float* ml = ML + (((size_t)b * ks + sp) * N + q) * 2;
         ml[0] = m;
         ml[1] = l;
@@ -254,13 +254,15 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
 // out = X + sum_p e^{m_p - m} Zp_p / sum_p e^{m_p - m} l_p + b'   (merge of the key-split partials)
 __global__ void nl_merge_kernel(const float* __restrict__ X, const float* __restrict__ Zp,
                                 const float* __restrict__ ML, const float* __restrict__ bp,
-                                float* __restrict__ Xo, int B, int N, int C, int CP, int ks) {
-    const size_t total = (size_t)B * N * CP;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int co = (int)(i % CP);
+                                float* __restrict__ Xo, int B, int N, int C, int CP, int ks, int q0, int q1) {
+    const size_t nq = (size_t)(q1 - q0);
+    const size_t total = (size_t)B * nq * CP;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(j % CP);
         if (co >= C) continue;
-        const size_t qn = (i / CP) % N;
-        const size_t b = i / ((size_t)CP * N);
+        const size_t qn = q0 + (j / CP) % nq;
+        const size_t b = j / ((size_t)CP * nq);
+        const size_t i = (b * N + qn) * CP + co;
         float m = -INFINITY;
         for (int p = 0; p < ks; ++p) m = fmaxf(m, ML[((b * ks + p) * N + qn) * 2]);
         float num = 0.f, den = 0.f;
@@ -331,32 +333,35 @@ hipError_t launch_nl_qproj(const float* X, const float* M, const float* c, float
 }
 
 hipError_t launch_nl_attn(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, int B, int N,
-                          int C, hipStream_t s, const float* Q) {
+                          int C, hipStream_t s, const float* Q, int q0, int q1) {
     if (!Q) Q = X;
+    if (q1 < 0) q1 = N;
+    if (q0 < 0 || q0 >= q1 || q1 > N) return hipErrorInvalidValue;
     const int ks = nl_key_splits(B, N);
     const int CP = nl_padded_ch(C);
     if (ks > 1 && !partial) return hipErrorInvalidValue;
     float* Zp = partial;
     float* ML = partial ? partial + (size_t)B * ks * N * CP : nullptr;
-    dim3 grid((N + 127) / 128, B, ks);
+    dim3 grid((q1 - q0 + 127) / 128, B, ks);
     dim3 block(256);
     switch (C) {
-        case 84: hipLaunchKernelGGL(nl_attn_kernel<84>, grid, block, 0, s, X, Xo, Wp, bp, Zp, ML, Q, N); break;
-        case 60: hipLaunchKernelGGL(nl_attn_kernel<60>, grid, block, 0, s, X, Xo, Wp, bp, Zp, ML, Q, N); break;
-        case 36: hipLaunchKernelGGL(nl_attn_kernel<36>, grid, block, 0, s, X, Xo, Wp, bp, Zp, ML, Q, N); break;
+        case 84: hipLaunchKernelGGL(nl_attn_kernel<84>, grid, block, 0, s, X, Xo, Wp, bp, Zp, ML, Q, N, q0, q1); break;
+        case 60: hipLaunchKernelGGL(nl_attn_kernel<60>, grid, block, 0, s, X, Xo, Wp, bp, Zp, ML, Q, N, q0, q1); break;
+        case 36: hipLaunchKernelGGL(nl_attn_kernel<36>, grid, block, 0, s, X, Xo, Wp, bp, Zp, ML, Q, N, q0, q1); break;
         default: return hipErrorInvalidValue;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ks == 1) return e;
-    return launch_nl_merge(X, Zp, ML, bp, Xo, B, N, C, ks, s);
+    return launch_nl_merge(X, Zp, ML, bp, Xo, B, N, C, ks, s, q0, q1);
 }
 
 hipError_t launch_nl_merge(const float* X, const float* Zp, const float* ML, const float* bp, float* Xo, int B, int N, int C, int ks,
-                           hipStream_t s) {
+                           hipStream_t s, int q0, int q1) {
     const int CP = nl_padded_ch(C);
-    const size_t total = (size_t)B * N * CP;
+    if (q1 < 0) q1 = N;
+    const size_t total = (size_t)B * (q1 - q0) * CP;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(nl_merge_kernel, dim3(blocks), dim3(256), 0, s, X, Zp, ML, bp, Xo, B, N, C, CP, ks);
+    hipLaunchKernelGGL(nl_merge_kernel, dim3(blocks), dim3(256), 0, s, X, Zp, ML, bp, Xo, B, N, C, CP, ks, q0, q1);
     return hipGetLastError();
 }
 

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(NB_THREADS, 2) void nl_attn_bf16_kernel(const float
                                                               const uint16_t* __restrict__ Klo, const uint16_t* __restrict__ Vthi,
                                                               const uint16_t* __restrict__ Vtlo, float* __restrict__ Xo,
                                                               const float* __restrict__ Wp, const float* __restrict__ bp,
-                                                              float* __restrict__ Zp, float* __restrict__ ML, int N, int Npad) {
+                                                              float* __restrict__ Zp, float* __restrict__ ML, int N, int Npad, int q0, int q1) {
     constexpr int CT = 3;
     constexpr int CP = (C + 31) / 32 * 32;                          // row stride of X / Xo / Wp (nl_padded_ch)
     static_assert(C < NB_CP && C % 2 == 0, "needs a pad channel inside 96");
@@ -86,8 +86,8 @@ __global__ __launch_bounds__(NB_THREADS, 2) void nl_attn_bf16_kernel(const float
     const int b = blockIdx.y;
     const float* Xb = X + (size_t)b * N * CP;
     float* Xob = Xo + (size_t)b * N * CP;
-    const int q = blockIdx.x * NB_QB + wave * 32 + xl;              // this lane's query
-    const int qc = q < N ? q : N - 1;
+    const int q = q0 + blockIdx.x * NB_QB + wave * 32 + xl;         // this lane's query (queries [q0, q1): a strip of the frame)
+    const int qc = q < q1 ? q : q1 - 1;
 
     // B operand of S^T = K Q^T: this lane's query, channels 16ks + 8kh .. +7, scaled by log2(e), split hi + lo
     constexpr float LOG2E = 1.4426950408889634f;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NB_THREADS, 2) void nl_attn_bf16_kernel(const float
 #pragma unroll
             for (int s = 0; s < 16; ++s) z = mfma32(wa[((s & 3) + 8 * (s >> 2)) * CP], o[ct][s], z);
         }
-        if (q < N) {
+        if (q < q1) {
             if (ksp == 1) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(NB_THREADS, 2) void nl_attn_bf16_kernel(const float
             }
         }
     }
-    if (ksp > 1 && q < N && kh == 0) {
+    if (ksp > 1 && q < q1 && kh == 0) {
         float* ml = ML + (((size_t)b * ksp + sp) * N + q) * 2;
         ml[0] = m;
         ml[1] = l;
@@ -329,8 +329,10 @@ size_t nl_bf16_scratch_halfs(int B, int N) {                        // Khi, Klo,
 
 // X, Xo as in launch_nl_attn; scratch16: nl_bf16_scratch_halfs(B, N) 16-bit elements; partial: nl_partial_floats
 hipError_t launch_nl_attn_bf16(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, uint16_t* scratch16,
-                               int B, int N, int C, hipStream_t s) {
+                               int B, int N, int C, hipStream_t s, int q0, int q1) {
     if (C != 84 && C != 60 && C != 36) return hipErrorInvalidValue;
+    if (q1 < 0) q1 = N;
+    if (q0 < 0 || q0 >= q1 || q1 > N) return hipErrorInvalidValue;
     const int CP = nl_padded_ch(C);
     const int npad = (N + 31) / 32 * 32 + 64;
     uint16_t* Khi = scratch16;
@@ -350,7 +352,7 @@ hipError_t launch_nl_attn_bf16(const float* X, float* Xo, const float* Wp, const
     const int ks_max = nl_key_splits(B, N);
     int ks = 1;
     {
-        const long long qb = (long long)((N + NB_QB - 1) / NB_QB) * B;
+        const long long qb = (long long)((q1 - q0 + NB_QB - 1) / NB_QB) * B;
         double best = 1e30;
         for (int k = 1; k <= ks_max; ++k) {
             const double t = (double)((qb * k + 255) / 256) / k;
@@ -363,7 +365,7 @@ hipError_t launch_nl_attn_bf16(const float* X, float* Xo, const float* Wp, const
     if (ks > 1 && !partial) return hipErrorInvalidValue;
     float* Zp = partial;
     float* ML = partial ? partial + (size_t)B * ks * N * CP : nullptr;
-    dim3 grid((N + NB_QB - 1) / NB_QB, B, ks);
+    dim3 grid((q1 - q0 + NB_QB - 1) / NB_QB, B, ks);
     dim3 block(NB_THREADS);
     static bool attr_dev[64] = {};
     int dev = 0;
@@ -377,13 +379,13 @@ hipError_t launch_nl_attn_bf16(const float* X, float* Xo, const float* Wp, const
         attr_dev[dev] = true;
     }
     switch (C) {
-        case 84: hipLaunchKernelGGL(nl_attn_bf16_kernel<84>, grid, block, NB_LDS_BYTES, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad); break;
-        case 60: hipLaunchKernelGGL(nl_attn_bf16_kernel<60>, grid, block, NB_LDS_BYTES, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad); break;
-        case 36: hipLaunchKernelGGL(nl_attn_bf16_kernel<36>, grid, block, NB_LDS_BYTES, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad); break;
+        case 84: hipLaunchKernelGGL(nl_attn_bf16_kernel<84>, grid, block, NB_LDS_BYTES, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad, q0, q1); break;
+        case 60: hipLaunchKernelGGL(nl_attn_bf16_kernel<60>, grid, block, NB_LDS_BYTES, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad, q0, q1); break;
+        case 36: hipLaunchKernelGGL(nl_attn_bf16_kernel<36>, grid, block, NB_LDS_BYTES, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad, q0, q1); break;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ks == 1) return e;
-    return launch_nl_merge(X, Zp, ML, bp, Xo, B, N, C, ks, s);
+    return launch_nl_merge(X, Zp, ML, bp, Xo, B, N, C, ks, s, q0, q1);
 }
 
 }  // namespace pfnl

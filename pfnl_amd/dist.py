@@ -112,3 +112,40 @@ def sharded_forward(forward_fn: Callable[[np.ndarray], np.ndarray], clips: np.nd
         if b > a:
             outs.append(parts[r][:b - a].cpu().numpy())
     return np.concatenate(outs, axis=0)
+
+
+def sharded_frame_forward(engine, x, gather_to: Optional[int] = 0):
+    """Single-clip multi-GPU sharding: every rank holds the whole clip ``x`` [B,T,H,W,3] (a cuda
+    tensor on its GPU; 7 LR frames are small) and produces one horizontal strip of the SR frame with
+    ``PFNLEngine.forward_strip`` - the non-local block attends over the whole frame, the trunk recomputes a halo instead of
+    exchanging it, so there is NO collective on the data path; the strips are then gathered (equal, zero-padded row
+    counts) on ``gather_to`` (None: every rank returns only its rows).  Returns [B,1,sH,sW,3] on ``gather_to``."""
+    import torch
+    dist = _dist()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    B, T, H, W, _ = x.shape
+    s = engine.geom.scale
+    # strips of an even number of LR rows (space_to_depth pairs), balanced over the ranks
+    lo2, hi2 = shard_range(H // 2, rank, world)
+    lo, hi = 2 * lo2, 2 * hi2
+    out = torch.zeros(engine.out_shape(B, H, W), dtype=torch.float32, device=x.device)
+    if hi > lo:
+        engine.forward_strip(x, out, lo, hi - lo)
+    torch.cuda.current_stream(x.device).synchronize()
+    if gather_to is None:
+        return out[:, :, s * lo:s * hi]
+    per = 2 * max(shard_range(H // 2, r, world)[1] - shard_range(H // 2, r, world)[0] for r in range(world))
+    pad = torch.zeros((B, 1, s * per, s * W, 3), dtype=torch.float32, device=x.device)
+    pad[:, :, :s * (hi - lo)] = out[:, :, s * lo:s * hi]
+    backend_is_nccl = dist.get_backend() == "nccl"
+    send = pad if backend_is_nccl else pad.cpu()
+    parts = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(parts, send)
+    if rank != gather_to:
+        return None
+    rows = []
+    for r in range(world):
+        a, b = shard_range(H // 2, r, world)
+        if b > a:
+            rows.append(parts[r][:, :, :s * 2 * (b - a)].to(x.device))
+    return torch.cat(rows, dim=2)

@@ -118,6 +118,18 @@ class PFNLEngine:
         _capi.check(self._lib.pfnl_forward(self._h, C.c_void_p(in_ptr), 1, C.c_void_p(out_ptr), 1, B, H, W,
                                            C.c_void_p(stream) if stream else None))
 
+    def forward_strip(self, x, out, row0: int, nrows: int) -> None:
+        """Single-clip sharding: x [B,T,H,W,3] float32 cuda tensor (the whole clip), out [B,1,sH,sW,3] float32 cuda tensor
+        (full size); fills rows [s*row0, s*(row0+nrows)) of ``out`` (pfnl_forward_strip; asynchronous on torch's stream)."""
+        import torch
+        B, T, H, W = self._check_input(x.shape, x.dtype == torch.float32)
+        if not (x.is_cuda and out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == self.out_shape(B, H, W)
+                and x.is_contiguous() and out.is_contiguous()):
+            raise ValueError("forward_strip needs contiguous float32 cuda tensors, out of the full output shape")
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _capi.check(self._lib.pfnl_forward_strip(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), B, H, W,
+                                                 int(row0), int(nrows), C.c_void_p(stream) if stream else None))
+
     def sync(self) -> None:
         _capi.check(self._lib.pfnl_sync(self._h))
 

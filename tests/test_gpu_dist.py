@@ -162,3 +162,82 @@ def test_comm_two_ranks_rccl():
     for r in res:
         assert np.array_equal(r[1], ref[r[0]:r[0] + 1])
         assert r[2] == [3.0, 2.0] and abs(r[3][0] - 0.2) < 1e-12
+
+
+# ---- single-clip sharding: horizontal strips of one SR frame -------------------------------
+
+@pytest.mark.parametrize("nb,B,H,W,strips,prec", [(3, 1, 96, 64, 4, "fp32"), (2, 2, 40, 36, 3, "fp32"), (20, 1, 128, 128, 2, "fp32"),
+                                                    (3, 1, 96, 64, 4, "bf16"), (1, 1, 12, 20, 6, "fp32")])
+def test_forward_strips_tile_the_frame(nb, B, H, W, strips, prec):
+    """pfnl_forward_strip: the union of the strips (each computed on its own, as a rank would: non-local queries of the strip
+    against all keys, trunk on strip + recomputed halo) equals the full forward up to summation order; rows outside a strip
+    are left untouched."""
+    from pfnl_amd.engine import PFNLEngine
+    geom = PFNLGeometry(num_block=nb)
+    eng = PFNLEngine(geom, device=0)
+    eng.load_weights(synth.synthetic_weights(geom, seed=0))
+    if prec == "bf16":
+        eng.set_option("precision", "bf16")
+    x = torch.from_numpy(synth.uniform_clips(B, 7, H, W, seed=nb + H)).cuda()
+    full = eng.forward(x)
+    out = torch.full_like(full, -7.0)
+    bounds = [2 * pd.shard_range(H // 2, r, strips)[0] for r in range(strips)] + [H]
+    for r in range(strips):
+        lo, hi = bounds[r], bounds[r + 1]
+        if hi == lo:
+            continue
+        before = out.clone()
+        eng.forward_strip(x, out, lo, hi - lo)
+        torch.cuda.synchronize()
+        untouched = torch.ones(4 * H, dtype=torch.bool)
+        untouched[4 * lo:4 * hi] = False
+        assert torch.equal(out[:, :, untouched], before[:, :, untouched])          # only its own rows
+    err = (out - full).abs().max().item()
+    tol = 2e-6 if prec == "fp32" else 2e-2                                         # bf16 trunk: tile alignment moves rounding points
+    print(f"strips nb{nb} {B}x7x{H}x{W} / {strips} ({prec}): max|strips - full| = {err:.3g}")
+    assert err < tol, err
+    with pytest.raises(Exception):
+        eng.forward_strip(x, out, H - 2, 4)
+    eng.close()
+
+
+def _frame_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from pfnl_amd.engine import PFNLEngine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = PFNLGeometry(num_block=2)
+        eng = PFNLEngine(g, device=0)
+        eng.load_weights(synth.synthetic_weights(g, seed=3))
+        x = torch.from_numpy(synth.uniform_clips(1, 7, 36, 48, seed=9)).cuda()
+        y = pd.sharded_frame_forward(eng, x, gather_to=0)
+        q.put((rank, None if y is None else y.cpu().numpy()))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_frame():
+    """dist.sharded_frame_forward with two ranks (both on the one GPU, gloo transport): rank 0 ends up with the whole SR
+    frame, assembled from two independently computed strips."""
+    import torch.multiprocessing as mp
+    from pfnl_amd.engine import PFNLEngine
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_frame_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = PFNLGeometry(num_block=2)
+    eng = PFNLEngine(g, device=0)
+    eng.load_weights(synth.synthetic_weights(g, seed=3))
+    ref = eng.forward(synth.uniform_clips(1, 7, 36, 48, seed=9))
+    assert res[1][1] is None and res[0][1].shape == ref.shape
+    assert np.abs(res[0][1] - ref).max() < 2e-6
+    eng.close()
