@@ -156,17 +156,14 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
     }
     const float nscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -CS_SCALE)));
     f32x4 stg[CS_ITERS];
+// (branch-free: one arm, so that the compiler's vmcnt bookkeeping stays exact for whatever is issued around it - with an
+// interior / border pair of arms the wait for the weight slice of unit B also drained half of the halo loads just issued)
 #define CS_REQUEST_ALL(rs_, org_, interior_, y0_, x0_)                                           \
     do {                                                                                         \
-        if (interior_) {                                                                         \
-            _Pragma("unroll") for (int k_ = 0; k_ < CS_ITERS; ++k_)                              \
-                stg[k_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, (org_) + grel[k_], 0, 0)); \
-        } else {                                                                                 \
-            _Pragma("unroll") for (int k_ = 0; k_ < CS_ITERS; ++k_) {                            \
-                const int gy_ = (y0_) + ((lpk[k_] >> 16) & 0xff) - 1, gx_ = (x0_) + ((unsigned)lpk[k_] >> 24) - 1; \
-                const bool in_ = (unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W;     \
-                stg[k_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, in_ ? (org_) + grel[k_] : 0x7fffffff, 0, 0)); \
-            }                                                                                    \
+        _Pragma("unroll") for (int k_ = 0; k_ < CS_ITERS; ++k_) {                                \
+            const int gy_ = (y0_) + ((lpk[k_] >> 16) & 0xff) - 1, gx_ = (x0_) + ((unsigned)lpk[k_] >> 24) - 1; \
+            const bool in_ = (interior_) || ((unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W); \
+            stg[k_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, in_ ? (org_) + grel[k_] : 0x7fffffff, 0, 0)); \
         }                                                                                        \
     } while (0)
     // descriptor of unit u_'s halo: resource of its item, byte offset of the halo origin (+ the channel half), interior flag
@@ -337,6 +334,12 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
             unsigned char* const other = cs_smem + (cb ^ 1) * CS_TILE_BYTES;
             [[maybe_unused]] const int u = 2 * kt + PAR;
             CS_STAMP();                                             // 0: unit start
+            // weights of unit B (the other channel half) follow the column taps unit A has consumed.  A slice must be in LDS
+            // before the barrier that precedes its first operand prefetch (issued one sub-step before its group):
+            //   tap 0: requested here, written in group 3 of unit A (free since b0; read from unit B's start, after b2)
+            //   tap 1: requested in group 3, written in group 5 (free since b1; prefetched in unit B's group 1, after b2)
+            //   tap 2: requested in group 5, written in group 1 of unit B (free since b2; prefetched in group 3, after b0)
+            if constexpr (PAR == 0) w_request(half_a ^ 1, 0);
             // the NEXT unit's halo: requested here, committed in groups 4-5 of this unit (4 groups = ~2 us later), i.e. request
             // and use never straddle the loop back-edge and the compiler's vmcnt for the commit is exact
             {
@@ -351,12 +354,6 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                 CS_REQUEST_ALL(rs, org, interior, y0q, x0q);
 #endif
             }
-            // weights of unit B (the other channel half) follow the column taps unit A has consumed.  A slice must be in LDS
-            // before the barrier that precedes its first operand prefetch (issued one sub-step before its group):
-            //   tap 0: requested here, written in group 3 of unit A (free since b0; read from unit B's start, after b2)
-            //   tap 1: requested in group 3, written in group 5 (free since b1; prefetched in unit B's group 1, after b2)
-            //   tap 2: requested in group 5, written in group 1 of unit B (free since b2; prefetched in group 3, after b0)
-            if constexpr (PAR == 0) w_request(half_a ^ 1, 0);
             piece_setup(PAR);                                       // epilogue pass PAR of the previous tile (nothing pending: out of range)
 
             // operands: X[row][part], Wv[substep parity][part]

@@ -51,8 +51,19 @@ def imread_rgb(path) -> np.ndarray:
 
 
 def imsave_rgb(path, img) -> None:         # reference utils.py:362-366
+    """PNG, zlib level 1 (what cv2.imwrite - the reference's writer - uses by default in OpenCV 4; PIL's default 6 is ~4x
+    slower on a 1080p frame); the decoded pixels are identical at any level."""
     from PIL import Image
-    Image.fromarray(np.squeeze(img)).save(path)
+    Image.fromarray(np.squeeze(img)).save(path, compress_level=1)
+
+
+def imread_many(paths, threads: int = 8) -> np.ndarray:
+    """[F,H,W,3] uint8 - decoded on a thread pool (PIL releases the GIL while inflating)."""
+    if not paths:
+        return np.zeros((0, 0, 0, 3), np.uint8)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(threads, len(paths)))) as pool:
+        return np.array(list(pool.map(imread_rgb, paths)))
 
 
 def sliding_windows(frames: np.ndarray, num_frames: int) -> np.ndarray:
@@ -247,15 +258,16 @@ class PFNL(VSR):
         raise NotImplementedError("training loop (model/pfnl.py:151-199) is out of scope of the MI355X inference build")
 
     # ---- inference harness ------------------------------------------------------------------------
-    encode_threads = 4             # PNG encoders running while the GPU works on the next batch
+    encode_threads = min(16, os.cpu_count() or 1)   # PNG encoders / decoders running while the GPU works on the next batch
 
     def _run_sequence(self, lrs, save_path: str, part: int):
         """Shared tail of test_video_truth / test_video_lr (model/pfnl.py:236-262, 293-320).  ``lrs`` [F,H,W,3] float32:
         numpy (uploaded ONCE) or already a cuda tensor.  Per batch, all on the device: gather of the clamped T-frame
         windows (pfnl_op_gather_windows), pfnl_forward, uint8 quantisation (pfnl_op_quantise_u8); the uint8 frames
-        come back over PCIe (a quarter of the float bytes) and are PNG-encoded on worker threads while the next batch
-        runs.  The timed span (H2D-resident input -> quantised frames on the host) is what the reference times around
-        sess.run (:249-253), first batch excluded from the average."""
+        come back over PCIe (a quarter of the float bytes, pinned double-buffered, asynchronous) and are PNG-encoded on
+        worker threads while the NEXT batch runs on the GPU.  The time reported per batch is the device time from the
+        window gather to the frames' arrival on the host (HIP events) - what the reference times around sess.run
+        (:249-253) -, first batch excluded from the average."""
         max_frame = int(lrs.shape[0])
         if max_frame == 0:
             print('Save at {}'.format(save_path))
@@ -275,19 +287,39 @@ class PFNL(VSR):
         print('{} Inputs With Shape {}'.format(max_frame, tuple(frames.shape[1:])))
         all_time = []
         jobs = []
+        stream = torch.cuda.current_stream(frames.device)
+        host = [None, None]                                          # pinned uint8 landing buffers, double-buffered
+        inflight = None                                              # (done event, start event, host buffer, first, count)
+
+        def drain(item, pool):
+            done, started, buf, first_, count_ = item
+            done.synchronize()                                       # this batch's frames are on the host
+            all_time.append(started.elapsed_time(done) * 1e-3)       # device time of the batch: gather + forward + quantise + D2H
+            frames_u8 = buf[:count_].numpy().copy()                  # (the pinned buffer is reused two batches later)
+            for j in range(count_):
+                jobs.append(pool.submit(imsave_rgb, join(save_path, '{:0>4}.png'.format(first_ + j)), frames_u8[j][0]))
+
         with ThreadPoolExecutor(max_workers=max(1, int(self.encode_threads))) as pool:
             for i in range(part):
                 first = i * num_once
                 count = min(num_once, max_frame - first)
                 if count <= 0:
                     break
-                st_time = time.time()
+                started, done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                started.record(stream)
                 win = ops.gather_windows(frames, first, count, self.num_frames)
                 sr = eng.forward(win)
-                u8 = ops.quantise_u8(sr).cpu().numpy()               # synchronises
-                all_time.append(time.time() - st_time)
-                for j in range(count):
-                    jobs.append(pool.submit(imsave_rgb, join(save_path, '{:0>4}.png'.format(first + j)), u8[j][0]))
+                u8 = ops.quantise_u8(sr)
+                k = i & 1
+                if host[k] is None or host[k].shape[0] < count:
+                    host[k] = torch.empty((num_once,) + tuple(u8.shape[1:]), dtype=torch.uint8).pin_memory()
+                host[k][:count].copy_(u8, non_blocking=True)
+                done.record(stream)
+                if inflight is not None:                             # while the GPU runs batch i: batch i-1 goes to the PNG encoders
+                    drain(inflight, pool)
+                inflight = (done, started, host[k], first, count)
+            if inflight is not None:
+                drain(inflight, pool)
             for j in jobs:
                 j.result()
         all_time = np.array(all_time)
@@ -309,7 +341,7 @@ class PFNL(VSR):
         save_path = join(path, name)
         automkdir(save_path)
         imgs = sorted(glob.glob(join(path, 'truth', '*.png')))
-        hr = np.array([imread_rgb(i) for i in imgs]) / 255.
+        hr = imread_many(imgs, self.encode_threads) / 255.
         self._ensure_loaded(reuse)
         if hr.shape[0] == 0:
             return self._run_sequence(np.zeros((0, 0, 0, 3), np.float32), save_path, part)
@@ -326,7 +358,7 @@ class PFNL(VSR):
         save_path = join(path, name)
         automkdir(save_path)
         imgs = sorted(glob.glob(join(path, 'blur{}'.format(self.scale), '*.png')))
-        lrs = (np.array([imread_rgb(i) for i in imgs]) / 255.).astype(np.float32)
+        lrs = (imread_many(imgs, self.encode_threads) / 255.).astype(np.float32)
         self._ensure_loaded(reuse)
         if lrs.shape[0] == 0:
             lrs = np.zeros((0, 0, 0, 3), np.float32)
