@@ -155,7 +155,7 @@ def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
             rec.update({"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(f_h, 4)})
         else:
             rec.update({"achieved": round(ex, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(f_m, 4)})
-        rec.update({"traffic": stamped_traffic("traffic_split16.json", files, workload), "kernel": name,
+        rec.update({"traffic": stamped_traffic("traffic_split16.json", files, (algo, workload)), "kernel": name,
                     "avg_launch_ms": round(avg_ms, 4), "launches_timed": k["launches"], "launches_per_step": launches_per_step,
                     "mbytes_per_launch": round(bytes_per_launch / 1e6, 2), "hbm_gbs": round(gbs, 1), "hbm_frac": round(f_h, 4),
                     "mfma_f16_tflops_executed": round(ex, 1), "mfma_frac": round(f_m, 4),
@@ -167,7 +167,7 @@ def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
     name, files = CONV3X3_KERNELS[algo]
     return {"bound": "mfma", "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
-            "traffic": stamped_traffic("traffic.json", files, algo),
+            "traffic": stamped_traffic("traffic.json", files, (algo, workload)),
             "kernel": name, "avg_launch_ms": round(avg_ms, 4), "launches_timed": k["launches"],
             "launches_per_step": launches_per_step,
             "gflop_per_launch_executed": round(flops_per_launch / (2.25 if wino else 1.0) / 1e9, 3),
@@ -198,8 +198,10 @@ def stamped_traffic(suffix, files, key):
     if tj.get("kernel_src_sha") != kernel_source_sha(files):
         return None
     v = tj.get("hbm_bytes_per_launch_avg")
-    if isinstance(v, dict):
+    if isinstance(v, dict):                                # per workload (the bf16 file)
         return v.get(key)
+    if isinstance(key, tuple):                             # (algo, workload): a single figure measured on one workload
+        return v if (tj.get("algo"), tj.get("workload", "cfg2")) == key else None
     return v if tj.get("algo", key) == key else None
 
 

@@ -1,4 +1,4 @@
-"""profiles/r01_traffic.json from the FETCH_SIZE / WRITE_SIZE rocprofv3 passes (tools/run_pmc.sh):
+"""profiles/r<NN>_traffic[_split16].json from the FETCH_SIZE / WRITE_SIZE rocprofv3 passes (tools/run_pmc.sh):
 HBM bytes per launch of the 3x3 convolution kernels, with the gfx950 corrections of
 /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE x1024 x2, WRITE_SIZE x1024).
 Usage: python tools/make_traffic_json.py <fetch.db> <write.db> <algo> <out.json>"""
@@ -16,7 +16,7 @@ def per_kernel(db, ctr):
         span[(name, grid)] = (min(lo, dur), max(hi, dur))
     out = {}
     for name, grid, val, dur in raw:
-        if "conv_wino" not in name and "conv_mfma_kernel<3, 16, 2" not in name:
+        if "conv_wino" not in name and "conv_mfma_kernel<3, 16, 2" not in name and "conv3x3_split16" not in name:
             continue
         lo, hi = span[(name, grid)]
         cls = ""

@@ -18,11 +18,20 @@ geom = PFNLGeometry()
 eng = PFNLEngine(geom, device=0)
 eng.load_weights(synth.synthetic_weights(geom, seed=0))
 eng.set_option("conv3x3", algo)
+if os.environ.get("PFNL_GRAPH"):
+    eng.set_option("graph", os.environ["PFNL_GRAPH"])
 xd = torch.from_numpy(synth.uniform_clips(B, 7, H, W, seed=8)).cuda()
 out = torch.empty(eng.out_shape(B, H, W), dtype=torch.float32, device="cuda")
 for _ in range(3):
     eng.forward_device(xd.data_ptr(), out.data_ptr(), B, H, W, 0)
 torch.cuda.synchronize()
+if os.environ.get("PFNL_GRAPH"):
+    t0 = time.perf_counter()
+    for _ in range(20):
+        eng.forward_device(xd.data_ptr(), out.data_ptr(), B, H, W, 0)
+    torch.cuda.synchronize()
+    print("graph=%s %s %dx%dx%d: %.3f ms/step" % (os.environ["PFNL_GRAPH"], algo, B, H, W, (time.perf_counter() - t0) / 20 * 1e3))
+    sys.exit(0)
 eng.profile_reset()
 eng.profile(1)
 t0 = time.perf_counter()
