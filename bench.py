@@ -221,6 +221,10 @@ def main():
                     help="cfg2 = configs[1] 4x7x128x128 per GPU (default, the metric's config); cfg4 = configs[3] 1x7x270x480 (1080p)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to exercise the N>1 plumbing on a 1-GPU box)")
+    ap.add_argument("--comm", default="pfnl", choices=["pfnl", "torch"],
+                    help="--gpus > 1 with nccl: who carries the weight replica and the max-over-ranks time - the library's own RCCL "
+                         "communicator (pfnl_comm_*, include/pfnl_hip.h; falls back to torch.distributed if it cannot be created on "
+                         "every rank) or torch.distributed")
     ap.add_argument("--full-profile", action="store_true",
                     help="HIP events around every launch (default: every 4th progressive-fusion block is timed)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events (no roofline object)")
@@ -263,11 +267,26 @@ def main():
             with stdout_to_stderr():
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
                 dist.barrier()                                         # creates torch's communicator now, not inside the timed region
-                comm = Comm.from_torch_distributed(local_dev)
+                if args.comm == "pfnl":
+                    try:
+                        comm = Comm.from_torch_distributed(local_dev)
+                    except Exception as e:                             # (RCCL not loadable, id exchange failed ...)
+                        print("pfnl_comm unavailable on rank %d (%s)" % (rank, e), file=sys.stderr)
+                        comm = None
+                    # every rank must take the same road: agree through the launcher's group
+                    ok = torch.tensor([1 if comm is not None else 0], device=dev)
+                    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                    if int(ok[0]) == 0 and comm is not None:
+                        comm.close()
+                        comm = None
                 weights = synth.synthetic_weights(geom, seed=0) if rank == 0 else None
-                if rank == 0:
+                if comm is not None:
+                    if rank == 0:
+                        eng.load_weights(weights)
+                    comm.bcast_weights(eng, root=0)                    # ncclBroadcast of the packed device blobs, once
+                else:
+                    weights = pd.broadcast_weights(geom, weights, src=0, device=dev)   # the same 12 MB through torch's RCCL group
                     eng.load_weights(weights)
-                comm.bcast_weights(eng, root=0)                        # ncclBroadcast of the packed device blobs, once
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
             weights = pd.broadcast_weights(geom, synth.synthetic_weights(geom, seed=0) if rank == 0 else None, src=0)
@@ -312,7 +331,7 @@ def main():
         if comm is not None:
             elapsed = float(comm.allreduce([elapsed], "max")[0])
         else:
-            t = torch.tensor([elapsed], dtype=torch.float64)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t[0])
     assert torch.isfinite(out).all().item(), "non-finite output"
@@ -338,6 +357,7 @@ def main():
         "config": {"workload": ("PFNL 4xSR, 7 frames, 270x480->1080x1920 (1080p), batch=1 %s per MI355X (BASELINE.json configs[3])" if args.workload == "cfg4" else
                                 "PFNL 4xSR, 7 frames, 128x128->512x512, batch=4 %s per MI355X (BASELINE.json configs[1])") % ("bf16 trunk" if bf16 else "fp32"),
                    "clips_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU, "parallelism": "dp%d" % world, "backend": (args.backend if world > 1 else None),
+                   "comm": (("pfnl_comm (RCCL)" if comm is not None else "torch.distributed") if world > 1 else None),
                    "weights": "synthetic Xavier (seed 0)", "input": "resident in HBM", "conv3x3": algo},
         "roofline": roof,
         "whole_forward": {"tflops_ref_graph": round(f_ref / (ms_per_step * 1e-3) / 1e12, 2),
@@ -350,7 +370,12 @@ def main():
         n_sus = max(args.steps, int(2.2e3 / max(ms_per_step, 1e-3)) + 1)
         el = timed_steps(step, fence, n_sus)
         if use_dist:
-            el = float(comm.allreduce([el], "max")[0]) if comm is not None else el
+            if comm is not None:
+                el = float(comm.allreduce([el], "max")[0])
+            else:
+                t = torch.tensor([el], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t[0])
         res["sustained"] = {"steps": n_sus, "seconds": round(el, 3), "ms_per_step": round(1e3 * el / n_sus, 4),
                             "value": round(world * B_PER_GPU * n_sus / el, 3)}
     if rank == 0 and world == 1 and not args.no_secondary and args.workload == "cfg2" and not bf16:
