@@ -88,6 +88,8 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *   "split16"       direct 3x3 on the f16 matrix pipe with exactly split fp32 operands (3 f16 MFMAs per product block,
  *                   fp32 accumulation, >= 22 mantissa bits per product: conv_split16.hip).
  * key "conv1x1" = "stream" (default, conv1x1.hip) | "tiled" (conv_mfma.hip).
+ * key "nonlocal" (fp32 precision only) = "auto" (default: "split16" from 1024 keys, "f32" below) | "f32" (f32 MFMA, nonlocal.hip) |
+ *                 "split16" (f16 MFMA with exactly split operands: fp32-level accuracy at a third of the time, nonlocal_f16.hip).
  * key "graph"   = "off" (default) | "on" (every shape is captured into a hipGraph on its second call and replayed
  *                 between the staging buffers) | "auto" (only shapes with frames*H*W <= 65536 pixels).  Measured: no
  *                 gain - the small shapes are bound by per-kernel latency, not by launch gaps.
@@ -240,6 +242,11 @@ int pfnl_op_nonlocal(const float* x, const float* wg_host, const float* bg_host,
 /* The same block on bf16 MFMA with split (hi + lo) operands and fp32 softmax state (option precision=bf16,
  * nonlocal_bf16.hip): same arguments, fp32 in and out. */
 int pfnl_op_nonlocal_bf16(const float* x, const float* wg_host, const float* bg_host,
+                     const float* ww_host, const float* bw_host, float* out,
+                     int B, int T, int H, int W, void* stream);
+/* The same block (fp32 in and out) on the f16 matrix pipe with exactly split operands (option nonlocal=split16, nonlocal_f16.hip):
+ * Q, K, V and the probabilities are taken as f16(x) + f16(x - f16(x)), scaled by powers of two into binary16's normal range. */
+int pfnl_op_nonlocal_split16(const float* x, const float* wg_host, const float* bg_host,
                      const float* ww_host, const float* bw_host, float* out,
                      int B, int T, int H, int W, void* stream);
 /* The embedded-Gaussian form of the block (reference utils.py:18-71 with nltype 0): same contract as pfnl_op_nonlocal plus

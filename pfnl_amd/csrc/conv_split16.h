@@ -19,4 +19,10 @@ hipError_t launch_conv3x3_split16(const ConvSplitParams& p, hipStream_t s);
 size_t conv3x3_split16_pack_halfs();                                  // 16-bit elements per packed 3x3 64->64 kernel
 void conv3x3_split16_pack_weights(const float* hwio, int cin_total, int cin_begin, uint16_t* dst, int cout = 64);   // cout < 64: zero-padded
 
+// non-local block of the fp32 path on the f16 matrix pipe with exactly split operands (nonlocal_f16.hip); arguments as
+// launch_nl_attn_bf16 (conv_bf16.h)
+size_t nl_f16_scratch_halfs(int B, int N);
+hipError_t launch_nl_attn_f16(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, uint16_t* scratch16,
+                              int B, int N, int C, hipStream_t s, int q0 = 0, int q1 = -1);
+
 }  // namespace pfnl

@@ -87,6 +87,25 @@ def test_winograd_and_direct_paths_agree():
     eng.set_option("conv3x3", "auto")
 
 
+def test_nonlocal_kernels_agree_in_the_forward():
+    """nonlocal=auto (split-f16 from 1024 keys) / f32 / split16: same forward within round-off, each within ABS_TOL of the oracle."""
+    geom = PFNLGeometry(num_block=2)
+    w = synth.synthetic_weights(geom, seed=0)
+    eng = PFNLEngine(geom, device=0)
+    eng.load_weights(w)
+    x = synth.uniform_clips(1, 7, 64, 72, seed=13)                  # N = 1152 keys
+    ref = pfnl_fast.FastOracle(w, num_block=2).forward(x)
+    ys = {}
+    for nl in ("auto", "f32", "split16"):
+        eng.set_option("nonlocal", nl)
+        ys[nl] = eng.forward(x)
+        assert np.abs(ys[nl] - ref).max() < ABS_TOL, nl
+    assert np.array_equal(ys["auto"], ys["split16"]) and np.abs(ys["f32"] - ys["split16"]).max() < 5e-6
+    with pytest.raises(Exception):
+        eng.set_option("nonlocal", "fp8")
+    eng.close()
+
+
 def test_bad_inputs_raise():
     eng = engine_for(PFNLGeometry(num_block=1))
     with pytest.raises(ValueError):

@@ -185,7 +185,8 @@ def test_conv_delta_kernel_shift_is_exact():
 
 @pytest.mark.parametrize("B,T,H,W", [(1, 7, 8, 8), (2, 7, 20, 36), (1, 5, 16, 24), (1, 3, 12, 40), (1, 7, 2, 2),
                                      (1, 7, 32, 32), (1, 7, 48, 48), (2, 5, 64, 48), (1, 7, 62, 70)])   # last three: key-split path
-def test_nonlocal_residual(B, T, H, W):
+@pytest.mark.parametrize("kernel", ["fp32", "split16"])     # f32 MFMA (nonlocal.hip) / f16 MFMA with exactly split operands (nonlocal_f16.hip)
+def test_nonlocal_residual(B, T, H, W, kernel):
     rng = np.random.default_rng(B + T + H + W)
     C = 12 * T
     x = rng.random((B, T, H, W, 3), dtype=np.float32)
@@ -193,7 +194,7 @@ def test_nonlocal_residual(B, T, H, W):
     ww = (rng.normal(size=(1, 1, C, C)) / np.sqrt(C)).astype(np.float32)
     bg = rng.normal(size=C).astype(np.float32) * 0.1
     bw = rng.normal(size=C).astype(np.float32) * 0.1
-    got = ops.nonlocal_residual(dev(x), wg, bg, ww, bw).cpu().numpy()
+    got = ops.nonlocal_residual(dev(x), wg, bg, ww, bw, precision=kernel).cpu().numpy()
     x64 = x.astype(np.float64)
     stack = np.concatenate([x64[:, t] for t in range(T)], -1)
     z = pfnl_spec.nonlocal_block(pfnl_spec.space_to_depth2(stack), wg.astype(np.float64), bg.astype(np.float64),
@@ -203,7 +204,8 @@ def test_nonlocal_residual(B, T, H, W):
     assert np.abs(got - ref).max() < 2e-5, np.abs(got - ref).max()
 
 
-def test_nonlocal_constant_and_peaked_inputs():
+@pytest.mark.parametrize("kernel", ["fp32", "split16"])
+def test_nonlocal_constant_and_peaked_inputs(kernel):
     """Known answers: constant frames -> uniform affinity; a very bright pixel block -> the running-max
     rescale branch of the streaming softmax is exercised (logits ~ 84 vs ~ 2)."""
     T, H, W = 7, 16, 16
@@ -214,14 +216,14 @@ def test_nonlocal_constant_and_peaked_inputs():
     bg = rng.normal(size=C).astype(np.float32) * 0.1
     bw = rng.normal(size=C).astype(np.float32) * 0.1
     x = np.full((1, T, H, W, 3), 0.25, np.float32)
-    got = ops.nonlocal_residual(dev(x), wg, bg, ww, bw).cpu().numpy()
+    got = ops.nonlocal_residual(dev(x), wg, bg, ww, bw, precision=kernel).cpu().numpy()
     g = np.full(C, 0.25) @ wg[0, 0].astype(np.float64) + bg
     zc = g @ ww[0, 0].astype(np.float64) + bw
     ref = 0.25 + pfnl_spec.depth_to_space2(np.broadcast_to(zc, (1, H // 2, W // 2, C)).copy())
     assert np.abs(got - ref).max() < 1e-5
     x = (rng.random((1, T, H, W, 3)) * 0.15).astype(np.float32)
     x[:, :, 10:14, 4:8] = 0.97 + 0.03 * rng.random((1, T, 4, 4, 3)).astype(np.float32)   # late, dominant keys
-    got = ops.nonlocal_residual(dev(x), wg, bg, ww, bw).cpu().numpy()
+    got = ops.nonlocal_residual(dev(x), wg, bg, ww, bw, precision=kernel).cpu().numpy()
     x64 = x.astype(np.float64)
     stack = np.concatenate([x64[:, t] for t in range(T)], -1)
     z = pfnl_spec.nonlocal_block(pfnl_spec.space_to_depth2(stack), wg.astype(np.float64), bg.astype(np.float64),
