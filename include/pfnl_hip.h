@@ -87,7 +87,8 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *   "direct"        implicit-GEMM f32 MFMA (conv_mfma.hip);
  *   "split16"       direct 3x3 on the f16 matrix pipe with exactly split fp32 operands (3 f16 MFMAs per product block,
  *                   fp32 accumulation, >= 22 mantissa bits per product: conv_split16.hip).
- * key "conv1x1" = "stream" (default, conv1x1.hip) | "tiled" (conv_mfma.hip).
+ * key "conv1x1" = "split16" (default: streaming kernel on the f16 pipe, exactly split fp32 operands) | "stream" (streaming f32-MFMA
+ *                 kernel) | "tiled" (conv_mfma.hip).
  * key "nonlocal" (fp32 precision only) = "auto" (default: "split16" from 1024 keys, "f32" below) | "f32" (f32 MFMA, nonlocal.hip) |
  *                 "split16" (f16 MFMA with exactly split operands: fp32-level accuracy at a third of the time, nonlocal_f16.hip).
  * key "graph"   = "off" (default) | "on" (every shape is captured into a hipGraph on its second call and replayed
@@ -195,6 +196,9 @@ int pfnl_op_conv3x3_accum(const float* in, const float* kernel_host, const float
  * in [items*frames_per_item, HW, 64], kernel_host HWIO [1,1,64*fpi,64], out [items, HW, 64]. */
 int pfnl_op_conv1x1_stream(const float* in, const float* kernel_host, const float* bias_host, float* out,
                            int items, int frames_per_item, int HW, int act, void* stream);
+/* ... and on the f16 matrix pipe with exactly split fp32 operands (option conv1x1=split16, the default): same contract. */
+int pfnl_op_conv1x1_split16(const float* in, const float* kernel_host, const float* bias_host, float* out,
+                            int items, int frames_per_item, int HW, int act, void* stream);
 /* bf16 trunk (option precision=bf16; BASELINE.json configs[3]): the 3x3 64->64 convolution of a progressive-fusion
  * block (reference model/pfnl.py:49,51,66,69-71) on bf16 MFMA with fp32 accumulation.  Tensors are bf16 (uint16_t
  * bit patterns) [items, H, W, 64]; kernel_host fp32 HWIO [3,3,64,64] (rounded to bf16 inside), bias fp32.

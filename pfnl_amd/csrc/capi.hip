@@ -85,7 +85,7 @@ struct pfnl_handle {
     int graph_mode = 0;                                       // 0 off (default: measured slower), 1 auto (frames*H*W <= 65536 pixels), 2 on
     bool conv2_grouped = true;                                // winograd: conv2_i as one grouped launch (option conv2=grouped|split)
     int merge_cstride = 48;                                   // floats per pixel of `merge` as written by the last forward
-    int conv1x1_algo = 1;                                     // conv10: 1 streaming kernel (conv1x1.hip), 0 LDS-tiled implicit GEMM
+    int conv1x1_algo = 2;                                     // conv10: 2 streaming kernel on the f16 pipe, split operands (default), 1 streaming f32-MFMA kernel (conv1x1.hip), 0 LDS-tiled implicit GEMM
     bool bf16_fuse10 = true;                                  // bf16 trunk: conv10_i inside the conv1_i launch (option bf16_conv10=fused|separate)
     bool bf16 = false;                                        // option precision=bf16: progressive-fusion trunk in bf16 (conv_bf16.hip); NL, conv0 maths, merge, tail stay fp32
     DevBuf wdev16;                                            // bf16 packs (offsets in 16-bit elements)
@@ -94,7 +94,7 @@ struct pfnl_handle {
     int conv_algo = 5;                                        // conv3x3: 5 auto (4 for large shapes, 3 for small), 0 direct, 1 winograd (4 waves / tile), 2 winograd16 (1 wave / SIMD), 3 winograd_ws (persistent, wave-specialised), 4 split16 (f16 MFMA, split fp32 operands)
     int nl_algo = 2;                                          // non-local block of the fp32 path: 0 f32 MFMA (nonlocal.hip), 1 split-f16 (nonlocal_f16.hip), 2 auto (1 from N = 1024 keys)
     DevBuf wdev16s;                                           // split-f16 packs of the 3x3 kernels (offsets in 16-bit elements)
-    std::vector<size_t> off16s_c1, off16s_c2a, off16s_c2b;
+    std::vector<size_t> off16s_c1, off16s_c2a, off16s_c2b, off16s_c10;
 
     // device weights (offsets in floats into `wdev`)
     DevBuf wdev;
@@ -355,7 +355,9 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             p.out = h->base.p;
             p.frames_per_item = T;
             p.nchunks = T * p.chunks_per_frame;
-            if (h->conv1x1_algo == 1)
+            if (h->conv1x1_algo == 2)
+                HIPCHK(launch_conv1x1_split16(p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_c10[i], p.bias, p.out, B, T, H * W, 1, s));
+            else if (h->conv1x1_algo == 1)
                 HIPCHK(launch_conv1x1_stream(p.in, wd + h->off_c10_s[i], p.bias, p.out, B, T, H * W, 1, s));
             else
                 HIPCHK(launch_conv_mfma(p, 1, B, s));
@@ -624,7 +626,8 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
     if (k == "conv1x1") {
         if (v == "stream") h->conv1x1_algo = 1;
         else if (v == "tiled") h->conv1x1_algo = 0;
-        else return fail(PFNL_ERR_INVALID, "conv1x1 must be stream or tiled");
+        else if (v == "split16") h->conv1x1_algo = 2;
+        else return fail(PFNL_ERR_INVALID, "conv1x1 must be split16, stream or tiled");
         return 0;
     }
     return fail(PFNL_ERR_INVALID, "unknown option " + k);
@@ -799,16 +802,19 @@ int pfnl_finalize_weights(pfnl_handle* h) {
     }
     {   // split-f16 packs of the 3x3 64->64 kernels (conv3x3=split16)
         std::vector<uint16_t> b16;
-        const size_t n3 = pfnl::conv3x3_split16_pack_halfs();
+        const size_t n3 = pfnl::conv3x3_split16_pack_halfs(), n1 = pfnl::conv1x1_split16_pack_halfs(T);
         h->off16s_c1.assign(nb, 0);
         h->off16s_c2a.assign(nb, 0);
         h->off16s_c2b.assign(nb, 0);
-        b16.resize((size_t)3 * nb * n3 + 2, 0);
+        h->off16s_c10.assign(nb, 0);
+        b16.resize((size_t)nb * (3 * n3 + n1) + 2, 0);
         for (int i = 0; i < nb; ++i) {
             const std::string s = std::to_string(i);
-            h->off16s_c1[i] = (size_t)(3 * i) * n3;
-            h->off16s_c2a[i] = (size_t)(3 * i + 1) * n3;
-            h->off16s_c2b[i] = (size_t)(3 * i + 2) * n3;
+            h->off16s_c1[i] = (size_t)i * (3 * n3 + n1);
+            h->off16s_c2a[i] = h->off16s_c1[i] + n3;
+            h->off16s_c2b[i] = h->off16s_c1[i] + 2 * n3;
+            h->off16s_c10[i] = h->off16s_c1[i] + 3 * n3;
+            pfnl::conv1x1_split16_pack_weights(W("conv10_" + s).data(), T, &b16[h->off16s_c10[i]]);
             pfnl::conv3x3_split16_pack_weights(W("conv1_" + s).data(), 64, 0, &b16[h->off16s_c1[i]]);
             pfnl::conv3x3_split16_pack_weights(W("conv2_" + s).data(), 128, 0, &b16[h->off16s_c2a[i]]);
             pfnl::conv3x3_split16_pack_weights(W("conv2_" + s).data(), 128, 64, &b16[h->off16s_c2b[i]]);
@@ -1297,6 +1303,26 @@ int pfnl_op_conv1x1_bf16(const uint16_t* in, const float* kernel_host, const flo
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(dw);
     if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv1x1 bf16 op: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int pfnl_op_conv1x1_split16(const float* in, const float* kernel_host, const float* bias_host, float* out, int items,
+                            int frames_per_item, int HW, int act, void* stream) {
+    if (!in || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (items < 1 || frames_per_item < 1 || HW < 1) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
+    hipStream_t s = (hipStream_t)stream;
+    const int T = frames_per_item;
+    const size_t nh = pfnl::conv1x1_split16_pack_halfs(T);
+    std::vector<uint16_t> pack(nh + 128, 0);
+    pfnl::conv1x1_split16_pack_weights(kernel_host, T, pack.data());
+    if (bias_host) std::memcpy(&pack[nh], bias_host, 64 * sizeof(float));
+    uint16_t* dw = nullptr;
+    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(uint16_t)));
+    hipError_t e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = pfnl::launch_conv1x1_split16(in, dw, reinterpret_cast<const float*>(dw + nh), out, items, T, HW, act, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dw);
+    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv1x1 split16 op: ") + hipGetErrorString(e));
     return 0;
 }
 

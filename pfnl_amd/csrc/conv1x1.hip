@@ -161,4 +161,166 @@ void conv1x1_pack_weights(const float* hwio, int T, float* dst) {
                         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same 1x1 on the f16 matrix pipe with exactly split fp32 operands (option conv1x1=split16; see conv_split16.hip for the
+// arithmetic: x = f16(x) + f16((x - f16(x)) 2^11) 2^-11, three f16 MFMAs per product block, fp32 accumulation).  Same streaming
+// structure as conv1x1_stream_kernel - A straight from HBM two frames ahead, the frame's weights (16 KB: [k-step 4][g 2]
+// [hi/lo' 2][lane] x 16 B) through a double-buffered LDS slot one frame ahead, one barrier per frame - with 24 MFMAs of 32
+// cycles per frame instead of 64 of 64: the kernel is left with its HBM stream (117 MB read per launch at configs[1]).
+// The two float4 of 8 consecutive channels a lane holds are split in registers (8 VALU per float4) and form one MFMA operand:
+// k-step (M, h) contracts channels 32M + 16kh + 8h + e, the weights are packed in that order.
+typedef _Float16 c1h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 c1h4 __attribute__((ext_vector_type(4)));
+typedef unsigned c1u4 __attribute__((ext_vector_type(4)));
+typedef unsigned c1u2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void c1_split4(f32x4 v, c1u2& hi, c1u2& lo, float nscale) {
+    const c1h4 h = __builtin_convertvector(v, c1h4);
+    hi = __builtin_bit_cast(c1u2, h);
+    const f32x4 t = v * 2048.0f;
+    unsigned l0, l1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi.x), "s"(nscale), "v"(t.x));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l0) : "v"(hi.x), "s"(nscale), "v"(t.y));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi.y), "s"(nscale), "v"(t.z));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l1) : "v"(hi.y), "s"(nscale), "v"(t.w));
+    lo = c1u2{l0, l1};
+}
+
+__global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_split16_kernel(const float* __restrict__ in,
+                                                                        const uint16_t* __restrict__ wpack,
+                                                                        const float* __restrict__ bias,
+                                                                        float* __restrict__ out, int HW, int T, int items,
+                                                                        int act) {
+    __shared__ __attribute__((aligned(16))) c1u4 sw[2][C1_WF];      // [frame parity][k-step][g][part][lane] x 16 B
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xl = lane & 31;
+    const int kh = lane >> 5;
+    const int gpi = (HW + 31) >> 5;
+    const int ngroups = gpi * items;
+    const int g = min(blockIdx.x * 8 + wave, ngroups - 1);          // surplus waves redo the last group (same values)
+    const int item = g / gpi;
+    const int p0 = (g - item * gpi) * 32;
+    const float nscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -2048.0f)));
+
+    const c1u4* wsrc = reinterpret_cast<const c1u4*>(wpack) + tid;  // + f*C1_WF (+512)
+    c1u4 wr0 = wsrc[0], wr1 = wsrc[C1_THREADS];
+    const f32x4* ap = reinterpret_cast<const f32x4*>(in) + (((size_t)item * T * HW + min(p0 + xl, HW - 1)) * 16 + kh * 4);
+    const size_t aframe = (size_t)HW * 16;
+#define C1S_LOAD_A(dst, ap_)                                                                           \
+    do {                                                                                               \
+        _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) dst[q_] = (ap_)[(q_ >> 2) * 8 + (q_ & 3)];     \
+    } while (0)
+    f32x4 a0[8] = {}, a1[8] = {}, a2[8] = {};
+    C1S_LOAD_A(a0, ap);
+    C1S_LOAD_A(a1, ap + (size_t)min(1, T - 1) * aframe);
+    sw[0][tid] = wr0;
+    sw[0][tid + C1_THREADS] = wr1;
+    const float bias0 = bias[xl], bias1 = bias[32 + xl];
+    __syncthreads();
+
+    f32x16 accm0, accm1, accc0, accc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        accm0[r] = 0.f;
+        accm1[r] = 0.f;
+        accc0[r] = 0.f;
+        accc1[r] = 0.f;
+    }
+    c1u4 wq[2][4];                                                  // B double buffer: [step parity][g*2 + part]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wq[0][i] = sw[0][i * 64 + lane];
+
+#define C1S_FRAME(cur, far, f_)                                                                        \
+    do {                                                                                               \
+        const int fn_ = min((f_) + 1, T - 1);                   /* past the end: harmless re-read */   \
+        C1S_LOAD_A(far, ap + (size_t)min((f_) + 2, T - 1) * aframe);                                   \
+        wr0 = wsrc[(size_t)fn_ * C1_WF];                                                               \
+        wr1 = wsrc[(size_t)fn_ * C1_WF + C1_THREADS];                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        const c1u4* wl_ = &sw[(f_) & 1][lane];                                                         \
+        const c1u4* wn_ = &sw[((f_) + 1) & 1][lane];                                                   \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {      /* k-step q = (M, h): pieces 2q, 2q+1 of the frame */ \
+            if (q_ == 2) {                                      /* next frame's weights -> the other buffer */ \
+                sw[((f_) + 1) & 1][tid] = wr0;                                                         \
+                sw[((f_) + 1) & 1][tid + C1_THREADS] = wr1;                                            \
+            }                                                                                          \
+            if (q_ == 3) __syncthreads();                                                              \
+            const c1u4* wp_ = q_ < 3 ? wl_ + ((q_ + 1) * 4) * 64 : wn_;                                \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) wq[(q_ + 1) & 1][i_] = wp_[i_ * 64];      \
+            c1u2 h0_, l0_, h1_, l1_;                                                                   \
+            c1_split4(cur[2 * q_], h0_, l0_, nscale);                                                  \
+            c1_split4(cur[2 * q_ + 1], h1_, l1_, nscale);                                              \
+            const c1h8 ah_ = __builtin_bit_cast(c1h8, c1u4{h0_.x, h0_.y, h1_.x, h1_.y});               \
+            const c1h8 al_ = __builtin_bit_cast(c1h8, c1u4{l0_.x, l0_.y, l1_.x, l1_.y});               \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+            const c1h8 w0h_ = __builtin_bit_cast(c1h8, wq[q_ & 1][0]), w0l_ = __builtin_bit_cast(c1h8, wq[q_ & 1][1]); \
+            const c1h8 w1h_ = __builtin_bit_cast(c1h8, wq[q_ & 1][2]), w1l_ = __builtin_bit_cast(c1h8, wq[q_ & 1][3]); \
+            accm0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, w0h_, accm0, 0, 0, 0);                  \
+            accm1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, w1h_, accm1, 0, 0, 0);                  \
+            accc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, w0l_, accc0, 0, 0, 0);                  \
+            accc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, w1l_, accc1, 0, 0, 0);                  \
+            accc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_, w0h_, accc0, 0, 0, 0);                  \
+            accc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_, w1h_, accc1, 0, 0, 0);                  \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+        }                                                                                              \
+    } while (0)
+    for (int f = 0; f < T; f += 3) {
+        C1S_FRAME(a0, a2, f);
+        if (f + 1 < T) C1S_FRAME(a1, a0, f + 1);
+        if (f + 2 < T) C1S_FRAME(a2, a1, f + 2);
+    }
+#undef C1S_FRAME
+#undef C1S_LOAD_A
+
+    if ((int)(blockIdx.x * 8 + wave) >= ngroups) return;
+    const float slope = act ? 0.2f : 1.0f;
+    float* ob = out + ((size_t)item * HW + p0) * 64 + xl;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int px = drow(r, lane);
+        float v0 = accm0[r] + accc0[r] * (1.0f / 2048.0f) + bias0, v1 = accm1[r] + accc1[r] * (1.0f / 2048.0f) + bias1;
+        v0 = fmaxf(v0, slope * v0);
+        v1 = fmaxf(v1, slope * v1);
+        if (p0 + px < HW) {
+            ob[(size_t)px * 64] = v0;
+            ob[(size_t)px * 64 + 32] = v1;
+        }
+    }
+}
+
+hipError_t launch_conv1x1_split16(const float* in, const uint16_t* wpack, const float* bias, float* out, int items, int T,
+                                  int HW, int act, hipStream_t s) {
+    if (!in || !wpack || !bias || !out || items < 1 || T < 1 || HW < 1) return hipErrorInvalidValue;
+    const int ngroups = ((HW + 31) / 32) * items;
+    hipLaunchKernelGGL(conv1x1_split16_kernel, dim3((ngroups + 7) / 8), dim3(C1_THREADS), 0, s, in, wpack, bias, out, HW, T,
+                       items, act);
+    return hipGetLastError();
+}
+
+size_t conv1x1_split16_pack_halfs(int T) { return (size_t)T * 8192; }   // 16 KB per frame
+
+// HWIO [1,1,T*64,64] -> [f][k-step q = 2M + h][g][part][lane][e]: W[f*64 + 32M + 16(lane>>5) + 8h + e][32g + (lane&31)],
+// part 0 = f16(w), part 1 = f16((w - hi) 2^11)
+void conv1x1_split16_pack_weights(const float* hwio, int T, uint16_t* dst) {
+    for (int f = 0; f < T; ++f)
+        for (int q = 0; q < 4; ++q)
+            for (int g = 0; g < 2; ++g)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int ci = f * 64 + 32 * (q >> 1) + 16 * (lane >> 5) + 8 * (q & 1) + e;
+                        const int co = 32 * g + (lane & 31);
+                        const float w = hwio[(size_t)ci * 64 + co];
+                        const _Float16 hi = (_Float16)w;
+                        const _Float16 lo = (_Float16)((w - (float)hi) * 2048.0f);
+                        const size_t base = (((((size_t)f * 4 + q) * 2 + g) * 2) * 64 + lane) * 8 + e;
+                        uint16_t hb, lb;
+                        __builtin_memcpy(&hb, &hi, 2);
+                        __builtin_memcpy(&lb, &lo, 2);
+                        dst[base] = hb;
+                        dst[base + 512] = lb;
+                    }
+}
+
 }  // namespace pfnl

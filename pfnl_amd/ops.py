@@ -169,7 +169,7 @@ def conv1x1_bf16(x, kernel, bias=None, act=True, frames_per_item=7):
     return out
 
 
-def conv1x1_stream(x, kernel, bias=None, act=True, frames_per_item=1):
+def conv1x1_stream(x, kernel, bias=None, act=True, frames_per_item=1, variant="stream"):
     """conv10_i: 1x1 over the concat of `frames_per_item` frames, (64*fpi) -> 64, streaming kernel.
     x: [items*fpi, H, W, 64] (cuda); kernel HWIO [1,1,64*fpi,64].  Reference: model/pfnl.py:50, :67-68."""
     import torch
@@ -181,7 +181,8 @@ def conv1x1_stream(x, kernel, bias=None, act=True, frames_per_item=1):
         raise ValueError("conv1x1_stream: geometry mismatch")
     items = F // frames_per_item
     out = torch.empty((items, H, W, 64), dtype=torch.float32, device=x.device)
-    _capi.check(lib.pfnl_op_conv1x1_stream(
+    fn = lib.pfnl_op_conv1x1_split16 if variant == "split16" else lib.pfnl_op_conv1x1_stream
+    _capi.check(fn(
         _req(x, "x"), k.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p) if b is not None else None,
         _req(out, "out"), items, frames_per_item, H * W, 1 if act else 0, _stream(x)))
     return out

@@ -125,7 +125,8 @@ def test_conv3x3_accum(clips, T, H, W, cout):
     (1, 7, 1, 1, True),          # a single pixel
     (4, 7, 32, 36, True),        # several workgroups per clip
 ])
-def test_conv1x1_stream(items, fpi, H, W, act):
+@pytest.mark.parametrize("variant", ["stream", "split16"])   # f32 MFMA / f16 MFMA with exactly split fp32 operands (the default)
+def test_conv1x1_stream(items, fpi, H, W, act, variant):
     rng = np.random.default_rng(items * 100 + fpi * 10 + H + W)
     x = rng.normal(size=(items * fpi, H, W, 64)).astype(np.float32)
     k = (rng.normal(size=(1, 1, 64 * fpi, 64)) / np.sqrt(64 * fpi)).astype(np.float32)
@@ -134,7 +135,7 @@ def test_conv1x1_stream(items, fpi, H, W, act):
     ref = pfnl_spec.conv2d_same(xin.astype(np.float64), k.astype(np.float64), b.astype(np.float64))
     if act:
         ref = pfnl_spec.lrelu(ref)
-    got = ops.conv1x1_stream(dev(x), k, b, act=act, frames_per_item=fpi).cpu().numpy()
+    got = ops.conv1x1_stream(dev(x), k, b, act=act, frames_per_item=fpi, variant=variant).cpu().numpy()
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() < 5e-6 * max(1.0, np.abs(ref).max())
 
