@@ -135,11 +135,12 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
     // unit u: tile u >> 1; the channel half walks 0,1 | 1,0 | 0,1 ... so that consecutive units of different tiles share it
 #define CS_HALF(u_) ((((u_) >> 1) ^ (u_)) & 1)
 
-    // weights of half 0 + bias -> LDS
+    // weights of half 0 + bias: requested here, written to LDS in the prologue below - after the first halo has been requested
+    // too, so that the two latencies of a launch's start overlap (a launch is only 20-100 us long)
+    u32x4 w0reg[CS_W_BYTES / 16 / CS_THREADS];
 #pragma unroll
-    for (int k = 0; k < CS_W_BYTES / 16 / CS_THREADS; ++k)
-        reinterpret_cast<u32x4*>(wl)[k * CS_THREADS + tid] = reinterpret_cast<const u32x4*>(p.wpack)[k * CS_THREADS + tid];
-    if (tid < 64) bl[tid] = p.bias[tid];
+    for (int k = 0; k < CS_W_BYTES / 16 / CS_THREADS; ++k) w0reg[k] = reinterpret_cast<const u32x4*>(p.wpack)[k * CS_THREADS + tid];
+    const float bias_r = tid < 64 ? p.bias[tid] : 0.f;
 
     // staging map: piece id = k*512 + tid -> halo pixel id >> 3, 4-channel piece id & 7 (8 threads read one pixel's 128 B)
     // Two words per piece, constant for the life of the kernel: `grel` = byte offset of the piece relative to the halo origin
@@ -307,6 +308,9 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
     {
         CS_REQ_SETUP(0, rs, org, interior, y0q, x0q);
         CS_REQUEST_ALL(rs, org, interior, y0q, x0q);
+#pragma unroll
+        for (int k = 0; k < CS_W_BYTES / 16 / CS_THREADS; ++k) reinterpret_cast<u32x4*>(wl)[k * CS_THREADS + tid] = w0reg[k];
+        if (tid < 64) bl[tid] = bias_r;
 #pragma unroll
         for (int k = 0; k < CS_ITERS; ++k) CS_COMMIT1(k, 0);
     }

@@ -384,3 +384,14 @@ def test_conv3x3_split16_scaling_and_data_movement():
     xp = np.pad(xq, ((0, 0), (1, 1), (1, 1), (0, 0)))
     assert np.array_equal(got[..., 9], xp[:, 0:16, 2:34, 5])
     assert not got[..., :9].any() and not got[..., 10:].any()
+
+
+def test_split16_random_geometries():
+    """Short run of tools/stress_split16.py: the f16-pipe kernels (3x3, 1x1, non-local) against the f32-MFMA path over random
+    (T, clips, H, W, blocks, scale), the 3x3 op against the direct kernel, and bit-exact repeatability of every call."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("stress_split16", os.path.join(os.path.dirname(HERE), "tools", "stress_split16.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, worst, worst_op = mod.run(seed=7, seconds=8.0)
+    assert n >= 20 and worst < 2e-5 and worst_op < 2e-5
