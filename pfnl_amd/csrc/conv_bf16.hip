@@ -227,7 +227,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
                     v.z = lrelu(v.z);
                     v.w = lrelu(v.w);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsF, off, 16 * q, 0);
+                buffer_store_b128_guarded(__builtin_bit_cast(u32x4, v), rsF, off, 16 * q);
             }
             return;
         }
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
 #ifdef CB_X_NOSTORE   /* timing experiments only */
         if (o.x == 0x12345678u)
 #endif
-        __builtin_amdgcn_raw_buffer_store_b128(o, rsO, (sx < W && sy < H) ? (sy * W + sx) * 128 + c * 16 : 0x7fffffff, 0, 0);
+        buffer_store_b128_guarded(o, rsO, (sx < W && sy < H) ? (sy * W + sx) * 128 + c * 16 : 0x7fffffff, 0);
     };
     auto fuse_request = [&](bool with_addend, int n, int h) __attribute__((always_inline)) {   // addend / residual piece (n, h) of the tile described by eoff / eitem
         const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
                     v[q].w = lrelu(v[q].w);
                 }
                 const u32x2 lo = f32x4_to_bf16(v[0]), hi = f32x4_to_bf16(v[1]);
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, rsX, off, 16 * h, 0);
+                buffer_store_b128_guarded(u32x4{lo.x, lo.y, hi.x, hi.y}, rsX, off, 16 * h);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) bacc[n][r] = 0.f;
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(const uint16_t* __
                     }
                 }
                 const u32x2 lo = f32x4_to_bf16(v[0]), hi = f32x4_to_bf16(v[1]);
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, rsO, ooff, (32 * m + 8 * h) * 2, 0);
+                buffer_store_b128_guarded(u32x4{lo.x, lo.y, hi.x, hi.y}, rsO, ooff, (32 * m + 8 * h) * 2);
             }
     }
 }

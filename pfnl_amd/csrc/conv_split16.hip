@@ -250,11 +250,17 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
             rres[k & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, soff0, k * wbytes2, 0));
         }
     };
-    auto store_piece = [&](const unsigned char* scratch, int k) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)eitemp * H * W * 64, 0, item_bytes, 0x00020000);
+    // A store piece is taken in two steps one sub-step apart - the scratch read, then arithmetic + store - so that the LDS
+    // round trip passes under that sub-step's MFMAs instead of stalling the (in-order) wave.
+    f32x4 pv;
+    auto piece_read = [&](const unsigned char* scratch, int k) __attribute__((always_inline)) {
         const int id = k * CS_THREADS + tid;
         const int pp = id >> 4, c = id & 15;
-        f32x4 v = *reinterpret_cast<const f32x4*>(scratch + pp * 256 + (((c & 8) | ((c ^ pp) & 7)) << 4));
+        pv = *reinterpret_cast<const f32x4*>(scratch + pp * 256 + (((c & 8) | ((c ^ pp) & 7)) << 4));
+    };
+    auto piece_finish = [&](int k) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)eitemp * H * W * 64, 0, item_bytes, 0x00020000);
+        f32x4 v = pv;
         if constexpr (FUSE) v += radd[k & 1];
 #ifdef CS_X_PKSLOPE
         const f32x4 sv = v * slope;
@@ -275,10 +281,11 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
 #ifdef CS_X_NOSTORE   /* timing experiments only */
         if (v.x == 1.2345e30f)
 #endif
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsO, soff0, k * wbytes2, 0);
-        // Measured on gfx950 with this hipcc: a VALU write to the data registers of a 128-bit buffer store issued in the very
-        // next instruction corrupted the stored dword (the hazard recognizer inserted no wait state) - keep distance by hand.
-        asm volatile("s_nop 1");
+        buffer_store_b128_guarded(__builtin_bit_cast(u32x4, v), rsO, soff0, k * wbytes2);   // (common.h: store-data hazard)
+    };
+    auto store_piece = [&](const unsigned char* scratch, int k) __attribute__((always_inline)) {
+        piece_read(scratch, k);
+        piece_finish(k);
     };
 
     // ---- weight replacement: a slot (24 KB, one column tap) travels L2 -> registers -> LDS, 3 x 16 B per thread.
@@ -343,6 +350,18 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
             //   tap 0: requested here, written in group 3 of unit A (free since b0; read from unit B's start, after b2)
             //   tap 1: requested in group 3, written in group 5 (free since b1; prefetched in unit B's group 1, after b2)
             //   tap 2: requested in group 5, written in group 1 of unit B (free since b2; prefetched in group 3, after b0)
+            // operands: X[row][part], Wv[substep parity][part]; the first ones are asked for before anything else of the unit
+            // (request set-up, tile decode: ~50 scalar instructions) so that their LDS round trip passes under it
+            h8 X[4][2], Wv[2][2];
+#define CS_PX(g_, r_, part_) (*reinterpret_cast<const h8*>(tile + (paddr[(g_) >> 1] ^ (((part_) ? lo_xor : 0) | (((g_) & 1) << 5))) + (r_) * (CS_IW * 128)))
+#define CS_WT(g_, ky_, part_) (*reinterpret_cast<const h8*>(wlane + (((g_) * 3 + (ky_)) << 12) + ((part_) << 10)))
+            X[0][0] = CS_PX(0, 0, 0);
+            X[0][1] = CS_PX(0, 0, 1);
+            X[1][0] = CS_PX(0, 1, 0);
+            X[1][1] = CS_PX(0, 1, 1);
+            Wv[0][0] = CS_WT(0, 0, 0);
+            Wv[0][1] = CS_WT(0, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
             if constexpr (PAR == 0) w_request(half_a ^ 1, 0);
             // the NEXT unit's halo: requested here, committed in groups 4-5 of this unit (4 groups = ~2 us later), i.e. request
             // and use never straddle the loop back-edge and the compiler's vmcnt for the commit is exact
@@ -360,10 +379,6 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
             }
             piece_setup(PAR);                                       // epilogue pass PAR of the previous tile (nothing pending: out of range)
 
-            // operands: X[row][part], Wv[substep parity][part]
-            h8 X[4][2], Wv[2][2];
-#define CS_PX(g_, r_, part_) (*reinterpret_cast<const h8*>(tile + (paddr[(g_) >> 1] ^ (((part_) ? lo_xor : 0) | (((g_) & 1) << 5))) + (r_) * (CS_IW * 128)))
-#define CS_WT(g_, ky_, part_) (*reinterpret_cast<const h8*>(wlane + (((g_) * 3 + (ky_)) << 12) + ((part_) << 10)))
             [[maybe_unused]] f32x16 bias16;                         // register r of a lane = channel ech + r
             if constexpr (PAR == 0) {
 #pragma unroll
@@ -375,12 +390,6 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                     bias16[4 * q + 3] = b4.w;
                 }
             }
-            X[0][0] = CS_PX(0, 0, 0);
-            X[0][1] = CS_PX(0, 0, 1);
-            X[1][0] = CS_PX(0, 1, 0);
-            X[1][1] = CS_PX(0, 1, 1);
-            Wv[0][0] = CS_WT(0, 0, 0);
-            Wv[0][1] = CS_WT(0, 0, 1);
 
             auto substep = [&](auto sc) __attribute__((always_inline)) {
                 constexpr int S = decltype(sc)::value;
@@ -401,14 +410,11 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                         CS_BARRIER();                              // b0: scratch complete; column tap 0 of the weights consumed
                         CS_STAMP();                                 // 2: past b0
                         CS_STAMP();                                 // 3
-                        store_piece(other, 0);
-                        store_piece(other, 1);
-                        fuse_request(2);
-                        fuse_request(3);
+                        piece_read(other, 0);
                     }
                     if constexpr (g == 3) {
-                        store_piece(other, 2);
-                        store_piece(other, 3);
+                        piece_finish(2);
+                        piece_read(other, 3);
                         if constexpr (PAR == 0) {
                             w_write(0);
                             w_request(half_a ^ 1, 1);
@@ -438,6 +444,17 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                         }
                     }
                 }
+                if constexpr (S == 7) {
+                    piece_finish(0);
+                    fuse_request(2);
+                    piece_read(other, 1);
+                }
+                if constexpr (S == 8) {
+                    piece_finish(1);
+                    fuse_request(3);
+                    piece_read(other, 2);
+                }
+                if constexpr (S == 10) piece_finish(3);
                 __builtin_amdgcn_sched_barrier(0);
                 // --- operands of the next sub-step
 #ifdef CS_X_NOREAD   /* timing experiments only */

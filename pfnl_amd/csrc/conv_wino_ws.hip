@@ -528,7 +528,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
             o_.z = fmaxf(o_.z, so_.z);                                                           \
             o_.w = fmaxf(o_.w, so_.w);                                                           \
             if (FUSE) o_ += rv[k_][r_];                                                          \
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o_), rsOut, eoff[k_], r_ * rowb, 0); \
+            buffer_store_b128_guarded(__builtin_bit_cast(u32x4, o_), rsOut, eoff[k_], r_ * rowb);        \
         }                                                                                        \
     } while (0)
 

@@ -49,3 +49,18 @@ def test_no_cpu_fallback():
     from model.pfnl import PFNL
     with pytest.raises(_capi.PFNLHipError):
         PFNL().forward(np.zeros((1, 7, 8, 8, 3), np.float32))
+
+
+def test_no_store_data_hazard_in_emitted_isa():
+    """tools/lint_store_hazard.py over every kernel source: no VALU write to the data registers of a 16-byte buffer store
+    with an SGPR offset within two issue slots (pfnl_amd/csrc/common.h, buffer_store_b128_guarded)."""
+    import shutil
+    import subprocess
+    import sys
+
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "lint_store_hazard.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
