@@ -253,8 +253,9 @@ def main():
     dev = "cuda:%d" % local_dev
     geom = PFNLGeometry()
 
-    use_dist = world > 1
+    use_dist = world > 1 or bool(os.environ.get("PFNL_BENCH_FORCE_DIST"))   # (the env: run the N>1 code path with one rank - tests)
     comm = None
+    comm_hung = False
     eng = PFNLEngine(geom, device=local_dev)
     if use_dist:
         import torch.distributed as dist
@@ -268,11 +269,28 @@ def main():
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
                 dist.barrier()                                         # creates torch's communicator now, not inside the timed region
                 if args.comm == "pfnl":
-                    try:
-                        comm = Comm.from_torch_distributed(local_dev)
-                    except Exception as e:                             # (RCCL not loadable, id exchange failed ...)
-                        print("pfnl_comm unavailable on rank %d (%s)" % (rank, e), file=sys.stderr)
-                        comm = None
+                    # ncclCommInitRank is a collective: a rank that cannot join would hang the others.  It runs under a
+                    # watchdog so that a node where the second communicator does not come up still produces its bench line
+                    # (through torch's group) instead of running into the driver's timeout.
+                    import threading
+                    box = {}
+
+                    def _init():
+                        try:
+                            torch.cuda.set_device(local_dev)           # (the current device is per thread)
+                            box["comm"] = Comm.from_torch_distributed(local_dev)
+                        except Exception as e:                         # (RCCL not loadable, id exchange failed ...)
+                            box["err"] = e
+
+                    th = threading.Thread(target=_init, daemon=True)
+                    th.start()
+                    th.join(timeout=float(os.environ.get("PFNL_COMM_INIT_TIMEOUT", "120")))
+                    if th.is_alive():
+                        print("pfnl_comm init timed out on rank %d: falling back to torch.distributed" % rank, file=sys.stderr)
+                        comm_hung = True
+                    elif "err" in box:
+                        print("pfnl_comm unavailable on rank %d (%s)" % (rank, box["err"]), file=sys.stderr)
+                    comm = box.get("comm") if not th.is_alive() else None
                     # every rank must take the same road: agree through the launcher's group
                     ok = torch.tensor([1 if comm is not None else 0], device=dev)
                     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -356,8 +374,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
         "config": {"workload": ("PFNL 4xSR, 7 frames, 270x480->1080x1920 (1080p), batch=1 %s per MI355X (BASELINE.json configs[3])" if args.workload == "cfg4" else
                                 "PFNL 4xSR, 7 frames, 128x128->512x512, batch=4 %s per MI355X (BASELINE.json configs[1])") % ("bf16 trunk" if bf16 else "fp32"),
-                   "clips_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU, "parallelism": "dp%d" % world, "backend": (args.backend if world > 1 else None),
-                   "comm": (("pfnl_comm (RCCL)" if comm is not None else "torch.distributed") if world > 1 else None),
+                   "clips_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU, "parallelism": "dp%d" % world, "backend": (args.backend if use_dist else None),
+                   "comm": (("pfnl_comm (RCCL)" if comm is not None else "torch.distributed") if use_dist else None),
                    "weights": "synthetic Xavier (seed 0)", "input": "resident in HBM", "conv3x3": algo},
         "roofline": roof,
         "whole_forward": {"tflops_ref_graph": round(f_ref / (ms_per_step * 1e-3) / 1e12, 2),
@@ -388,6 +406,10 @@ def main():
         print(json.dumps(res), flush=True)
     if comm is not None:
         comm.close()
+    if comm_hung:                                                     # a stuck ncclCommInitRank thread would block a clean exit
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     if use_dist:
         dist.destroy_process_group()
 

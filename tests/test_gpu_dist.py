@@ -92,6 +92,23 @@ def test_bench_two_ranks_on_one_gpu():
     assert rec["value"] > 0 and rec["steps"] == 2 and "cpu_baseline" not in rec
 
 
+def test_bench_rccl_path_with_one_rank():
+    """`bench.py`'s N>1 branch on the `nccl` backend - torch.distributed as launcher, the library's own RCCL communicator for the
+    weight broadcast and the max-over-ranks time - run with ONE rank (RCCL refuses two ranks on one device; the 8-GPU run is the
+    driver's): the line must say which communicator carried it."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PFNL_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl"
+    assert d["config"]["comm"] == "pfnl_comm (RCCL)", (d["config"], r.stderr[-800:])
+    assert d["value"] > 0
+
+
 def test_comm_single_rank_rccl():
     """pfnl_comm_* on RCCL itself (one rank): unique id, init, weight broadcast into a handle that never saw
     pfnl_set_weight, scalar reductions, gather, barrier."""
