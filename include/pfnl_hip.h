@@ -140,6 +140,10 @@ int pfnl_comm_rank(pfnl_comm* c, int* rank, int* nranks);
  * handle of the same geometry; a non-root handle needs no pfnl_set_weight calls at all.  Replaces nothing in the reference
  * (tf.train.Saver.restore per process, model/base_model.py:231-243): one read of the checkpoint instead of one per GPU. */
 int pfnl_comm_bcast_weights(pfnl_comm* c, pfnl_handle* h, int root);
+/* The same replica without a communicator: the packed device blobs of `src` copied into `dst` (same geometry; same device or a
+ * peer-accessible one - hipMemcpyDefault).  `dst` needs no pfnl_set_weight calls.  For several handles per process (one per
+ * stream or per device) fed from one checkpoint read; also what the receive side of the broadcast is tested with on one GPU. */
+int pfnl_copy_weights(pfnl_handle* dst, pfnl_handle* src);
 int pfnl_comm_bcast(pfnl_comm* c, void* dev_buf, size_t bytes, int root);                 /* in place, synchronous */
 /* all-reduce of n <= 64 HOST doubles in place (squared error / frame counts: PFNL_COMM_SUM; elapsed time: PFNL_COMM_MAX) */
 int pfnl_comm_allreduce_f64(pfnl_comm* c, double* vals, int n, int op);

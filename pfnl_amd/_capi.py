@@ -81,6 +81,7 @@ SIGNATURES = {
     "pfnl_comm_destroy": (_i, [_vp]),
     "pfnl_comm_rank": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "pfnl_comm_bcast_weights": (_i, [_vp, _vp, _i]),
+    "pfnl_copy_weights": (_i, [_vp, _vp]),
     "pfnl_comm_bcast": (_i, [_vp, _vp, C.c_size_t, _i]),
     "pfnl_comm_allreduce_f64": (_i, [_vp, C.POINTER(C.c_double), _i, _i]),
     "pfnl_comm_barrier": (_i, [_vp]),

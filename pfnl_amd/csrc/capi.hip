@@ -981,23 +981,44 @@ int pfnl_sync(pfnl_handle* h) {
 }
 
 // Weight replica over RCCL (comm.hip holds the communicator): the packed device blobs root -> all.
+// A handle that is about to RECEIVE packed weights (broadcast / copy): the blob layout depends on the geometry only, so it
+// is built from zeros and the sender's bytes go over it.  Everything data-dependent lives in the three device blobs.
+static int prepare_to_receive_weights(pfnl_handle* h) {
+    if (h->finalized) return 0;
+    for (auto& kv : h->expected)
+        if (!h->host.count(kv.first)) {
+            HostTensor t;
+            t.shape = kv.second;
+            t.data.assign(numel(t.shape), 0.f);
+            h->host[kv.first] = std::move(t);
+        }
+    return pfnl_finalize_weights(h);
+}
+
+int pfnl_copy_weights(pfnl_handle* dst, pfnl_handle* src) {
+    if (!dst || !src) return fail(PFNL_ERR_INVALID, "NULL handle");
+    if (dst == src) return 0;
+    if (!src->finalized) return fail(PFNL_ERR_STATE, "the source handle has no finalized weights");
+    if (src->nl_theta) return fail(PFNL_ERR_INVALID, "theta/phi handles carry host-side state: load them through pfnl_set_weight");
+    if (int e = prepare_to_receive_weights(dst)) return e;
+    if (dst->wdev.n != src->wdev.n || dst->wdev16.n != src->wdev16.n || dst->wdev16s.n != src->wdev16s.n)
+        return fail(PFNL_ERR_STATE, "the handles differ in geometry (weight blob sizes)");
+    HIPCHK(hipSetDevice(dst->cfg.device_id));
+    HIPCHK(hipMemcpy(dst->wdev.p, src->wdev.p, src->wdev.n * sizeof(float), hipMemcpyDefault));
+    HIPCHK(hipMemcpy(dst->wdev16.p, src->wdev16.p, src->wdev16.n * sizeof(float), hipMemcpyDefault));
+    HIPCHK(hipMemcpy(dst->wdev16s.p, src->wdev16s.p, src->wdev16s.n * sizeof(float), hipMemcpyDefault));
+    ++dst->cfg_gen;
+    return 0;
+}
+
 int pfnl_comm_bcast_weights(pfnl_comm* c, pfnl_handle* h, int root) {
     if (!c || !h) return fail(PFNL_ERR_INVALID, "NULL argument");
     int rank = 0, nranks = 0;
     if (int e = pfnl_comm_rank(c, &rank, &nranks)) return e;
     if (root < 0 || root >= nranks) return fail(PFNL_ERR_INVALID, "bad root");
     if (rank == root && !h->finalized) return fail(PFNL_ERR_STATE, "root has no finalized weights");
-    if (rank != root && !h->finalized) {
-        // the blob layout depends on the geometry only: build it from zeros, then receive root's bytes over it
-        for (auto& kv : h->expected)
-            if (!h->host.count(kv.first)) {
-                HostTensor t;
-                t.shape = kv.second;
-                t.data.assign(numel(t.shape), 0.f);
-                h->host[kv.first] = std::move(t);
-            }
-        if (int e = pfnl_finalize_weights(h)) return e;
-    }
+    if (rank != root)
+        if (int e = prepare_to_receive_weights(h)) return e;
     double v[4] = {(double)h->wdev.n, -(double)h->wdev.n, (double)h->wdev16.n, -(double)h->wdev16.n};
     if (int e = pfnl_comm_allreduce_f64(c, v, 4, PFNL_COMM_MAX)) return e;
     if (v[0] != -v[1] || v[2] != -v[3]) return fail(PFNL_ERR_STATE, "ranks disagree on the weight blob size (geometry / theta-phi option)");

@@ -55,6 +55,11 @@ class PFNLEngine:
         _capi.check(self._lib.pfnl_finalize_weights(self._h))
         self._ready = True
 
+    def copy_weights_from(self, other: "PFNLEngine") -> None:
+        """Device-to-device replica of ``other``'s packed weights (pfnl_copy_weights): no host tensors, no re-packing."""
+        _capi.check(self._lib.pfnl_copy_weights(self._h, other._h))
+        self._ready = True
+
     def set_option(self, key: str, value: str) -> None:
         """e.g. ("conv3x3", "winograd" | "winograd_tile" | "winograd16" | "direct"); see include/pfnl_hip.h."""
         _capi.check(self._lib.pfnl_set_option(self._h, key.encode(), value.encode()))

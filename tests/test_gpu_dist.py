@@ -109,6 +109,31 @@ def test_bench_rccl_path_with_one_rank():
     assert d["value"] > 0
 
 
+def test_weight_replica_without_host_tensors():
+    """The RECEIVE side of pfnl_comm_bcast_weights (a handle that never saw pfnl_set_weight: layout built from zeros, the
+    sender's device blobs copied over it) cannot run under RCCL on one GPU; pfnl_copy_weights shares that code path.  The
+    replica must reproduce the source bit for bit in every arithmetic mode - i.e. nothing data-dependent lives outside the blobs."""
+    from pfnl_amd.engine import PFNLEngine
+    g = PFNLGeometry(num_block=2)
+    src = PFNLEngine(g, device=0)
+    src.load_weights(synth.synthetic_weights(g, seed=4))
+    dst = PFNLEngine(g, device=0)
+    dst.copy_weights_from(src)
+    assert dst.missing_weights() == 0
+    x = synth.uniform_clips(2, 7, 16, 32, seed=6)
+    for opts in ({}, {"conv3x3": "split16", "conv1x1": "split16", "nonlocal": "split16"}, {"conv3x3": "winograd"},
+                 {"conv3x3": "direct", "conv1x1": "tiled", "nonlocal": "f32"}, {"precision": "bf16"}):
+        for k, v in opts.items():
+            src.set_option(k, v)
+            dst.set_option(k, v)
+        assert np.array_equal(dst.forward(x), src.forward(x)), opts
+    other = PFNLEngine(PFNLGeometry(num_block=3), device=0)
+    with pytest.raises(Exception):
+        other.copy_weights_from(src)                                    # different geometry: refused
+    for e in (src, dst, other):
+        e.close()
+
+
 def test_comm_single_rank_rccl():
     """pfnl_comm_* on RCCL itself (one rank): unique id, init, weight broadcast into a handle that never saw
     pfnl_set_weight, scalar reductions, gather, barrier."""
