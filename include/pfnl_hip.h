@@ -101,6 +101,10 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *                 bf16 MFMA (conv_bf16.hip); the non-local block, its logits, conv0's arithmetic, convmerge1, the tail and
  *                 the bicubic skip stay fp32; the interface tensors stay float32.  Tolerance: DESIGN.md section 4).
  * key "bf16_conv10" = "fused" (default: conv10_i runs inside the conv1_i launch of the bf16 trunk) | "separate".
+ * key "bf16_nonlocal" = "f16" (default: the non-local block of precision=bf16 on the f16 matrix pipe with binary16 operands,
+ *                 fp32 accumulation and softmax state - nonlocal_f16.hip, hi parts only) | "split" (bf16 MFMA with hi + lo
+ *                 split logits operands, probabilities rounded to bf16 - nonlocal_bf16.hip).  Both are within 1e-3 of the
+ *                 fp64 block on [0,1]-scale outputs (measured 1e-4 ... 5e-4); "f16" needs a third of the MFMAs.
  * The default can also be set with the environment variable PFNL_CONV3X3 read by pfnl_create. */
 int pfnl_set_option(pfnl_handle* h, const char* key, const char* value);
 
@@ -255,6 +259,11 @@ int pfnl_op_nonlocal_bf16(const float* x, const float* wg_host, const float* bg_
 /* The same block (fp32 in and out) on the f16 matrix pipe with exactly split operands (option nonlocal=split16, nonlocal_f16.hip):
  * Q, K, V and the probabilities are taken as f16(x) + f16(x - f16(x)), scaled by powers of two into binary16's normal range. */
 int pfnl_op_nonlocal_split16(const float* x, const float* wg_host, const float* bg_host,
+                     const float* ww_host, const float* bw_host, float* out,
+                     int B, int T, int H, int W, void* stream);
+/* The same kernel on the hi parts only - 16-bit (binary16) operands, fp32 accumulation and softmax state: the non-local block of
+ * precision=bf16 (option bf16_nonlocal=f16, the default there; 24 instead of 72 MFMAs per 64 keys). */
+int pfnl_op_nonlocal_f16(const float* x, const float* wg_host, const float* bg_host,
                      const float* ww_host, const float* bw_host, float* out,
                      int B, int T, int H, int W, void* stream);
 /* The embedded-Gaussian form of the block (reference utils.py:18-71 with nltype 0): same contract as pfnl_op_nonlocal plus

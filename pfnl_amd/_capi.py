@@ -66,6 +66,7 @@ SIGNATURES = {
     "pfnl_op_conv3x3_winograd16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_nonlocal": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_nonlocal_split16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pfnl_op_nonlocal_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_nonlocal_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_bicubic": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_blur_decimate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

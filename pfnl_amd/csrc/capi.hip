@@ -92,6 +92,7 @@ struct pfnl_handle {
     std::vector<size_t> off16_c1, off16_c10, off16_c2a, off16_c2b;
     size_t off16_m1 = 0;                                      // convmerge1: T consecutive packs (cout 48 zero-padded to 64)
     int conv_algo = 5;                                        // conv3x3: 5 auto (4 for large shapes, 3 for small), 0 direct, 1 winograd (4 waves / tile), 2 winograd16 (1 wave / SIMD), 3 winograd_ws (persistent, wave-specialised), 4 split16 (f16 MFMA, split fp32 operands)
+    int bf16_nl = 1;                                          // non-local block of precision=bf16: 0 split-bf16 operands (nonlocal_bf16.hip), 1 f16 operands (nonlocal_f16.hip, hi parts; default)
     int nl_algo = 2;                                          // non-local block of the fp32 path: 0 f32 MFMA (nonlocal.hip), 1 split-f16 (nonlocal_f16.hip), 2 auto (1 from N = 1024 keys)
     DevBuf wdev16s;                                           // split-f16 packs of the 3x3 kernels (offsets in 16-bit elements)
     std::vector<size_t> off16s_c1, off16s_c2a, off16s_c2b, off16s_c10;
@@ -233,6 +234,10 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             if (h->nl16.ensure((nl_f16_scratch_halfs(B, N) + 1) / 2)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
             HIPCHK(launch_nl_attn_f16(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p,
                                       reinterpret_cast<uint16_t*>(h->nl16.p), B, N, C, s, q0, q1));
+        } else if (h->bf16 && h->bf16_nl == 1) {   // 16-bit operands throughout: the f16 kernel on the hi parts only
+            if (h->nl16.ensure((nl_f16_scratch_halfs(B, N) + 1) / 2)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
+            HIPCHK(launch_nl_attn_f16(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p,
+                                      reinterpret_cast<uint16_t*>(h->nl16.p), B, N, C, s, q0, q1, false));
         } else if (h->bf16) {
             if (h->nl16.ensure((nl_bf16_scratch_halfs(B, N) + 1) / 2)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
             HIPCHK(launch_nl_attn_bf16(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p,
@@ -616,6 +621,12 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         else return fail(PFNL_ERR_INVALID, "precision must be fp32 or bf16");
         return 0;
     }
+    if (k == "bf16_nonlocal") {
+        if (v == "split") h->bf16_nl = 0;
+        else if (v == "f16") h->bf16_nl = 1;
+        else return fail(PFNL_ERR_INVALID, "bf16_nonlocal must be split or f16");
+        return 0;
+    }
     if (k == "nonlocal") {
         if (v == "f32") h->nl_algo = 0;
         else if (v == "split16") h->nl_algo = 1;
@@ -842,7 +853,7 @@ int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes) {
              + 2 * B * T * P * 64                               // inp0, inp1
              + 3 * B * P * 64                                   // base, pb, merge (64 floats per pixel)
              + (size_t)B * T * P * 3 + (size_t)B * P * sc * sc * 3;   // stage_in, stage_out
-    if (h->bf16 || h->nl_algo != 0) f += (pfnl::nl_bf16_scratch_halfs(B, (int)N) + 1) / 2;   // split K / V^T operands (bf16 or f16)
+    if (h->bf16 || h->nl_algo != 0) f += (std::max(pfnl::nl_bf16_scratch_halfs(B, (int)N), pfnl::nl_f16_scratch_halfs(B, (int)N)) + 1) / 2;   // split K / V^T operands (bf16 or f16)
     if (h->nl_theta) f += (size_t)B * N * CP;                   // projected queries (nltype 0)
     *bytes = f * sizeof(float);
     return 0;
@@ -1482,7 +1493,7 @@ int pfnl_op_conv3x3_winograd16(const float* in, const float* kernel_host, const 
     return 0;
 }
 
-static int op_nonlocal(int bf16 /* 0 f32, 1 bf16 split, 2 f16 split */, const float* x, const float* wg, const float* bg, const float* ww, const float* bw,
+static int op_nonlocal(int bf16 /* 0 f32, 1 bf16 split, 2 f16 split, 3 f16 (hi parts only) */, const float* x, const float* wg, const float* bg, const float* ww, const float* bw,
                        float* out, int B, int T, int H, int W, void* stream) {
     if (!x || !wg || !bg || !ww || !bw || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
     if ((T != 3 && T != 5 && T != 7) || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1))
@@ -1513,7 +1524,7 @@ static int op_nonlocal(int bf16 /* 0 f32, 1 bf16 split, 2 f16 split */, const fl
     hipError_t e = hipMemcpy(d, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = pfnl::launch_nl_pack(x, dX, B, T, H, W, s);
     if (e == hipSuccess)
-        e = bf16 == 2 ? pfnl::launch_nl_attn_f16(dX, dXo, d, d + (size_t)CP * CP, dP, d16, B, N, C, s)
+        e = bf16 >= 2 ? pfnl::launch_nl_attn_f16(dX, dXo, d, d + (size_t)CP * CP, dP, d16, B, N, C, s, 0, -1, bf16 == 2)
           : bf16    ? pfnl::launch_nl_attn_bf16(dX, dXo, d, d + (size_t)CP * CP, dP, d16, B, N, C, s)
                     : pfnl::launch_nl_attn(dX, dXo, d, d + (size_t)CP * CP, dP, B, N, C, s);
     if (e == hipSuccess) e = pfnl::launch_nl_unpack(dXo, out, B, T, H, W, s);
@@ -1536,6 +1547,11 @@ int pfnl_op_nonlocal_bf16(const float* x, const float* wg, const float* bg, cons
 int pfnl_op_nonlocal_split16(const float* x, const float* wg, const float* bg, const float* ww, const float* bw,
                              float* out, int B, int T, int H, int W, void* stream) {
     return op_nonlocal(2, x, wg, bg, ww, bw, out, B, T, H, W, stream);
+}
+
+int pfnl_op_nonlocal_f16(const float* x, const float* wg, const float* bg, const float* ww, const float* bw,
+                         float* out, int B, int T, int H, int W, void* stream) {
+    return op_nonlocal(3, x, wg, bg, ww, bw, out, B, T, H, W, stream);
 }
 
 int pfnl_op_bicubic(const float* x, float* out, int B, int H, int W, int scale, void* stream) {

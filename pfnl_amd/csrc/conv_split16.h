@@ -23,6 +23,6 @@ void conv3x3_split16_pack_weights(const float* hwio, int cin_total, int cin_begi
 // launch_nl_attn_bf16 (conv_bf16.h)
 size_t nl_f16_scratch_halfs(int B, int N);
 hipError_t launch_nl_attn_f16(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, uint16_t* scratch16,
-                              int B, int N, int C, hipStream_t s, int q0 = 0, int q1 = -1);
+                              int B, int N, int C, hipStream_t s, int q0 = 0, int q1 = -1, bool split = true);
 
 }  // namespace pfnl

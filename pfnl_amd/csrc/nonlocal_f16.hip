@@ -81,7 +81,10 @@ __global__ void nl_pack_f16_kernel(const float* __restrict__ X, uint16_t* __rest
     }
 }
 
-template <int C>
+// SPLIT = true: the fp32 path (operands as hi + lo, 72 MFMAs per 64 keys).  SPLIT = false: the same kernel on the hi parts only
+// (24 MFMAs per 64 keys) - 16-bit operands, fp32 accumulation: the non-local block of precision=bf16, whose trunk is 16-bit
+// anyway (binary16 has 3 more mantissa bits than the bf16 of the trunk: logits good to ~2e-3, where bf16 logits are off by 16 %).
+template <int C, bool SPLIT>
 __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Khi,
                                                               const uint16_t* __restrict__ Klo, const uint16_t* __restrict__ Vthi,
                                                               const uint16_t* __restrict__ Vtlo, float* __restrict__ Xo,
@@ -105,7 +108,8 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_kernel(const float*
 
     // B operand of S^T = K Q^T: this lane's query, channels 16ks + 8kh .. +7, scaled by log2(e), split hi + lo
     constexpr float LOG2E = 1.4426950408889634f;
-    bf16x8 qh[6], ql[6];
+    bf16x8 qh[6];
+    [[maybe_unused]] bf16x8 ql[6];
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_kernel(const float*
             const float v = c < C ? Xb[(size_t)qc * CP + c] * (LOG2E * NF_XSCALE) : 0.f;
             const _Float16 h = (_Float16)v;
             qh[ks][e] = h;
-            ql[ks][e] = (_Float16)(v - (float)h);
+            if constexpr (SPLIT) ql[ks][e] = (_Float16)(v - (float)h);
         }
     constexpr int LCT = C / 32, LI = C % 32;                        // where the row-sum channel C lives in the D layout
     constexpr int LKH = (LI % 8) >= 4 ? 1 : 0, LR = (LI / 8) * 4 + (LI % 8) % 4;
@@ -141,12 +145,12 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_kernel(const float*
             const bool ok = k0 + key < N;
             const size_t ko = ((size_t)(k0 + (ok ? key : 0)) * NF_CP + c16 * 8);
             rk[i] = ok ? *reinterpret_cast<const u32x4*>(Khb + ko) : u32x4{0, 0, 0, 0};
-            rk[NI + i] = ok ? *reinterpret_cast<const u32x4*>(Klb + ko) : u32x4{0, 0, 0, 0};
+            if constexpr (SPLIT) rk[NI + i] = ok ? *reinterpret_cast<const u32x4*>(Klb + ko) : u32x4{0, 0, 0, 0};
             const int ch = id >> 3, kc = id & 7;                    // V^T: 96 rows x 8 pieces (k0 + 64 <= Npad + 32: rows are padded)
             const bool vok = k0 + kc * 8 < Npad;
             const size_t vo = (size_t)ch * Npad + k0 + (vok ? kc * 8 : 0);
             rk[2 * NI + i] = vok ? *reinterpret_cast<const u32x4*>(Vhb + vo) : u32x4{0, 0, 0, 0};
-            rk[3 * NI + i] = vok ? *reinterpret_cast<const u32x4*>(Vlb + vo) : u32x4{0, 0, 0, 0};
+            if constexpr (SPLIT) rk[3 * NI + i] = vok ? *reinterpret_cast<const u32x4*>(Vlb + vo) : u32x4{0, 0, 0, 0};
         }
     };
     auto store_tile = [&](unsigned char* buf) {
@@ -155,10 +159,10 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_kernel(const float*
             const int id = min(tid + i * NF_THREADS, 767);
             const int key = id / 12, c16 = id - key * 12;
             *reinterpret_cast<u32x4*>(buf + key * NF_KROW + c16 * 16) = rk[i];
-            *reinterpret_cast<u32x4*>(buf + NF_KT * NF_KROW + key * NF_KROW + c16 * 16) = rk[NI + i];
+            if constexpr (SPLIT) *reinterpret_cast<u32x4*>(buf + NF_KT * NF_KROW + key * NF_KROW + c16 * 16) = rk[NI + i];
             const int ch = id >> 3, kc = id & 7;
             *reinterpret_cast<u32x4*>(buf + 2 * NF_KT * NF_KROW + ch * NF_VROW + kc * 16) = rk[2 * NI + i];
-            *reinterpret_cast<u32x4*>(buf + 2 * NF_KT * NF_KROW + NF_CP * NF_VROW + ch * NF_VROW + kc * 16) = rk[3 * NI + i];
+            if constexpr (SPLIT) *reinterpret_cast<u32x4*>(buf + 2 * NF_KT * NF_KROW + NF_CP * NF_VROW + ch * NF_VROW + kc * 16) = rk[3 * NI + i];
         }
     };
 
@@ -175,21 +179,24 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_kernel(const float*
     // the two waves' softmax blocks (150 VALU, 32 of them quarter-rate v_exp_f32) simply add to the MFMA time; skewed,
     // and with the softmax at raised priority, one wave's VALU runs under the other's MFMAs.
     const bool late = wave >= 4;
-    bf16x8 pt[2][2], pl[2][2];                                      // P^T (hi, lo parts) of the tile whose P V is still to come
+    bf16x8 pt[2][2];                                                // P^T (hi, lo parts) of the tile whose P V is still to come
+    [[maybe_unused]] bf16x8 pl[2][2];
     bf16x8 ob[2][6];                                                // operands one MFMA step ahead (the compiler alone issues each
                                                                     // ds_read right in front of its MFMA: 60 LDS latencies per tile)
 #define NF_LOAD_QK(ks_, d_)                                                                                     \
     do {                                                                                                        \
         ob[d_][0] = *reinterpret_cast<const bf16x8*>(kah + (ks_) * 32);                                         \
         ob[d_][1] = *reinterpret_cast<const bf16x8*>(kah + 32 * NF_KROW + (ks_) * 32);                          \
-        ob[d_][2] = *reinterpret_cast<const bf16x8*>(kal + (ks_) * 32);                                         \
-        ob[d_][3] = *reinterpret_cast<const bf16x8*>(kal + 32 * NF_KROW + (ks_) * 32);                          \
+        if constexpr (SPLIT) {                                                                                  \
+            ob[d_][2] = *reinterpret_cast<const bf16x8*>(kal + (ks_) * 32);                                     \
+            ob[d_][3] = *reinterpret_cast<const bf16x8*>(kal + 32 * NF_KROW + (ks_) * 32);                      \
+        }                                                                                                       \
     } while (0)
 #define NF_LOAD_PV(vah_, val_, j_, d_)                                                                          \
     do {                                                                                                        \
         _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_) {                                                  \
             ob[d_][ct_] = *reinterpret_cast<const bf16x8*>((vah_) + ct_ * 32 * NF_VROW + ((j_) >> 1) * 64 + ((j_) & 1) * 32);     \
-            ob[d_][3 + ct_] = *reinterpret_cast<const bf16x8*>((val_) + ct_ * 32 * NF_VROW + ((j_) >> 1) * 64 + ((j_) & 1) * 32); \
+            if constexpr (SPLIT) ob[d_][3 + ct_] = *reinterpret_cast<const bf16x8*>((val_) + ct_ * 32 * NF_VROW + ((j_) >> 1) * 64 + ((j_) & 1) * 32); \
         }                                                                                                       \
     } while (0)
     // O^T[ch][query] += V^T[ch][keys] P^T[keys][query] for the tile in `buf`, keys in the accumulator's own order;
@@ -205,10 +212,12 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_kernel(const float*
             __builtin_amdgcn_sched_barrier(0);                                                                  \
             _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_)                                                \
                 o[ct_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[j_ & 1][ct_], pt[j_ >> 1][j_ & 1], o[ct_], 0, 0, 0);     \
-            _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_)                                                \
-                o[ct_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[j_ & 1][3 + ct_], pt[j_ >> 1][j_ & 1], o[ct_], 0, 0, 0); \
-            _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_)                                                \
-                o[ct_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[j_ & 1][ct_], pl[j_ >> 1][j_ & 1], o[ct_], 0, 0, 0);     \
+            if constexpr (SPLIT) {                                                                              \
+                _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_)                                            \
+                    o[ct_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[j_ & 1][3 + ct_], pt[j_ >> 1][j_ & 1], o[ct_], 0, 0, 0); \
+                _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_)                                            \
+                    o[ct_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[j_ & 1][ct_], pl[j_ >> 1][j_ & 1], o[ct_], 0, 0, 0);     \
+            }                                                                                                   \
         }                                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
     } while (0)
@@ -238,10 +247,12 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_kernel(const float*
             const int d = ks & 1;
             st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][0], qh[ks], st[0], 0, 0, 0);
             st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][1], qh[ks], st[1], 0, 0, 0);
-            st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][0], ql[ks], st[0], 0, 0, 0);
-            st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][1], ql[ks], st[1], 0, 0, 0);
-            st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][2], qh[ks], st[0], 0, 0, 0);
-            st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][3], qh[ks], st[1], 0, 0, 0);
+            if constexpr (SPLIT) {
+                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][0], ql[ks], st[0], 0, 0, 0);
+                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][1], ql[ks], st[1], 0, 0, 0);
+                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][2], qh[ks], st[0], 0, 0, 0);
+                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][3], qh[ks], st[1], 0, 0, 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(2);                              // the softmax VALU goes ahead of the partner wave's MFMAs
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_kernel(const float*
                 const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[sub][r], NF_SINV, NF_PSHIFT - mn));   // 2^14 exp2(s - max)
                 const _Float16 ph = (_Float16)pv;
                 pt[sub][r >> 3][r & 7] = ph;
-                pl[sub][r >> 3][r & 7] = (_Float16)(pv - (float)ph);
+                if constexpr (SPLIT) pl[sub][r >> 3][r & 7] = (_Float16)(pv - (float)ph);
             }
 #endif
         m = mn;
@@ -350,7 +361,7 @@ size_t nl_f16_scratch_halfs(int B, int N) {                        // Khi, Klo, 
 
 // X, Xo as in launch_nl_attn; scratch16: nl_f16_scratch_halfs(B, N) 16-bit elements; partial: nl_partial_floats
 hipError_t launch_nl_attn_f16(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, uint16_t* scratch16,
-                               int B, int N, int C, hipStream_t s, int q0, int q1) {
+                               int B, int N, int C, hipStream_t s, int q0, int q1, bool split) {
     if (C != 84 && C != 60 && C != 36) return hipErrorInvalidValue;
     if (q1 < 0) q1 = N;
     if (q0 < 0 || q0 >= q1 || q1 > N) return hipErrorInvalidValue;
@@ -392,18 +403,21 @@ hipError_t launch_nl_attn_f16(const float* X, float* Xo, const float* Wp, const 
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_dev[dev]) {
-        for (const void* fn : {reinterpret_cast<const void*>(nl_attn_f16_kernel<84>), reinterpret_cast<const void*>(nl_attn_f16_kernel<60>),
-                               reinterpret_cast<const void*>(nl_attn_f16_kernel<36>)}) {
+        for (const void* fn : {reinterpret_cast<const void*>(nl_attn_f16_kernel<84, true>), reinterpret_cast<const void*>(nl_attn_f16_kernel<60, true>),
+                               reinterpret_cast<const void*>(nl_attn_f16_kernel<36, true>), reinterpret_cast<const void*>(nl_attn_f16_kernel<84, false>),
+                               reinterpret_cast<const void*>(nl_attn_f16_kernel<60, false>), reinterpret_cast<const void*>(nl_attn_f16_kernel<36, false>)}) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NF_LDS_BYTES);
             if (e != hipSuccess) return e;
         }
         attr_dev[dev] = true;
     }
+#define NF_LAUNCH(C_, S_) hipLaunchKernelGGL((nl_attn_f16_kernel<C_, S_>), grid, block, NF_LDS_BYTES, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad, q0, q1)
     switch (C) {
-        case 84: hipLaunchKernelGGL(nl_attn_f16_kernel<84>, grid, block, NF_LDS_BYTES, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad, q0, q1); break;
-        case 60: hipLaunchKernelGGL(nl_attn_f16_kernel<60>, grid, block, NF_LDS_BYTES, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad, q0, q1); break;
-        case 36: hipLaunchKernelGGL(nl_attn_f16_kernel<36>, grid, block, NF_LDS_BYTES, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad, q0, q1); break;
+        case 84: if (split) NF_LAUNCH(84, true); else NF_LAUNCH(84, false); break;
+        case 60: if (split) NF_LAUNCH(60, true); else NF_LAUNCH(60, false); break;
+        case 36: if (split) NF_LAUNCH(36, true); else NF_LAUNCH(36, false); break;
     }
+#undef NF_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ks == 1) return e;
     return launch_nl_merge(X, Zp, ML, bp, Xo, B, N, C, ks, s, q0, q1);
