@@ -4,6 +4,8 @@
 //             -> [B,1,sH,sW,3]                                            (model/pfnl.py:53,63,76-80)
 //   bicubic : TF1.12 legacy ResizeBicubic (align_corners=False, no half-pixel centres, A=-0.75,
 //             clamped taps, no renormalisation)                           (model/pfnl.py:63)
+#include <cstdlib>
+
 #include "common.h"
 #include "conv_bf16.h"
 
@@ -102,9 +104,153 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ Xo
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv0 on the f16 matrix pipe (default since round 2; the VALU kernel above stays as PFNL_CONV0=valu).
+// 4800 MACs per output pixel are 84 k cycles of packed VALU per launch at configs[1]; as a GEMM (M = pixels, N = 64, K = 75)
+// with exactly split fp32 operands (conv_split16.hip: x = hi + lo' 2^-11, 3 MFMAs per product block, fp32 accumulation) the
+// arithmetic is a tenth of that and the launch is left with its 117 MB of output.
+//   * K is ordered (ky, kx, c) and padded per row tap to 16: the 15 values (kx, c) of one ky are 15 CONSECUTIVE dwords of the
+//     [row][col][3] input tile, so the A operand of k-step ky is 8 dwords per lane starting at the output pixel's own column
+//     (the 16th value is the next pixel's first channel, met by a zero weight);
+//   * the input tile is split ONCE when it is loaded, as packed (hi | lo' << 16) dwords: the gather is 8 ds_read_b32 (stride
+//     3 dwords between lanes: conflict-free) + 8 v_perm_b32 per k-step; weights are split and laid out per (ky, part, N-tile,
+//     lane) by the workgroup itself (20 KB), 16 bytes per lane and MFMA;
+//   * workgroup = 4 waves = 16 rows x 32 columns of one frame, a wave walks 4 rows: 30 MFMAs per row, the accumulators of a row
+//     leave as whole 128-byte channel lines (lane = channel, register = pixel).
+constexpr int C0M_TW = 32, C0M_TH = 16, C0M_IW = C0M_TW + 4, C0M_IH = C0M_TH + 4;
+constexpr int C0M_IN_DW = C0M_IH * C0M_IW * 3 + 4;                  // + slack for the pad element of the last pixel
+constexpr int C0M_W_BYTES = 5 * 2 * 2 * 1024;                       // [ky][part][N-tile][lane] x 16 B
+
+template <bool BF16OUT>
+__global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict__ Xo, const float* __restrict__ w,   // [75][64]
+                                                         const float* __restrict__ bias, float* __restrict__ out, int T, int H,
+                                                         int W, int CP, int yoff, int Hs) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) unsigned char sw[C0M_W_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned s_in[C0M_IN_DW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f = blockIdx.z;
+    const int b = f / T, t = f % T;
+    const int x0 = blockIdx.x * C0M_TW, y0 = blockIdx.y * C0M_TH;
+    const int W2 = W / 2, C3 = 3 * T;
+    const float* Xb = Xo + (size_t)b * (H / 2) * W2 * CP;
+
+    auto split1 = [](float v, unsigned short& hb, unsigned short& lb) {
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);    // exact difference, one rounding
+        hb = __builtin_bit_cast(unsigned short, hi);
+        lb = __builtin_bit_cast(unsigned short, lo);
+    };
+    // weights: entry (ky, g, l) = 8 values k' = 8 (l >> 5) + e of row tap ky for channel 32 g + (l & 31); k' = kx * 3 + c, k' = 15: 0
+    for (int ent = tid; ent < 5 * 2 * 64; ent += 256) {
+        const int l = ent & 63, g = (ent >> 6) & 1, ky = ent >> 7;
+        unsigned short hv[8], lv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kp = 8 * (l >> 5) + e;
+            const float wv = kp < 15 ? w[(size_t)(ky * 15 + kp) * 64 + 32 * g + (l & 31)] : 0.f;
+            split1(wv, hv[e], lv[e]);
+        }
+        u32x4 hq, lq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hq[e] = hv[2 * e] | ((unsigned)hv[2 * e + 1] << 16);
+            lq[e] = lv[2 * e] | ((unsigned)lv[2 * e + 1] << 16);
+        }
+        *reinterpret_cast<u32x4*>(sw + ((ky * 2 + 0) * 2 + g) * 1024 + l * 16) = hq;
+        *reinterpret_cast<u32x4*>(sw + ((ky * 2 + 1) * 2 + g) * 1024 + l * 16) = lq;
+    }
+    // input tile (frame coordinates: rows outside a strip are real data), split once: hi | lo' << 16
+    for (int i = tid; i < C0M_IN_DW; i += 256) {
+        const int c = i % 3, pix = i / 3;
+        const int py = pix / C0M_IW, px = pix - py * C0M_IW;
+        const int gy = yoff + y0 + py - 2, gx = x0 + px - 2;
+        float v = 0.f;
+        if (py < C0M_IH && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            v = Xb[((size_t)(gy >> 1) * W2 + (gx >> 1)) * CP + ((gy & 1) * 2 + (gx & 1)) * C3 + 3 * t + c];
+        unsigned short hb, lb;
+        split1(v, hb, lb);
+        s_in[i] = hb | ((unsigned)lb << 16);
+    }
+    __syncthreads();
+
+    const int xl = lane & 31, kh = lane >> 5;
+    const float bias0 = bias[xl], bias1 = bias[32 + xl];
+    const unsigned char* const wl = sw + lane * 16;
+#pragma unroll 1
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = wave * 4 + rr;                                  // output row of the tile
+        if (y0 + row >= Hs) break;                                      // (wave-uniform)
+        f32x16 am0, am1, ac0, ac1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            am0[r] = bias0;
+            am1[r] = bias1;
+            ac0[r] = 0.f;
+            ac1[r] = 0.f;
+        }
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky) {
+            const unsigned* ap = s_in + ((row + ky) * C0M_IW + xl) * 3 + 8 * kh;
+            unsigned d[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = ap[e];
+            u32x4 ahq, alq;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ahq[e] = __builtin_amdgcn_perm(d[2 * e + 1], d[2 * e], 0x05040100u);   // the two hi halves
+                alq[e] = __builtin_amdgcn_perm(d[2 * e + 1], d[2 * e], 0x07060302u);   // the two lo' halves
+            }
+            const h8 ah = __builtin_bit_cast(h8, ahq), al = __builtin_bit_cast(h8, alq);
+            const h8 w0h = *reinterpret_cast<const h8*>(wl + ((ky * 2 + 0) * 2 + 0) * 1024);
+            const h8 w1h = *reinterpret_cast<const h8*>(wl + ((ky * 2 + 0) * 2 + 1) * 1024);
+            const h8 w0l = *reinterpret_cast<const h8*>(wl + ((ky * 2 + 1) * 2 + 0) * 1024);
+            const h8 w1l = *reinterpret_cast<const h8*>(wl + ((ky * 2 + 1) * 2 + 1) * 1024);
+            am0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0h, am0, 0, 0, 0);
+            am1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1h, am1, 0, 0, 0);
+            ac0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0l, ac0, 0, 0, 0);
+            ac1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1l, ac1, 0, 0, 0);
+            ac0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w0h, ac0, 0, 0, 0);
+            ac1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w1h, ac1, 0, 0, 0);
+        }
+        // D register r of a lane = pixel drow(r, lane) of the row, channel xl (+32): 128-byte channel lines
+        const size_t rowbase = (((size_t)f * Hs + y0 + row) * W + x0) * 64;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int px = drow(r, lane);
+            const float v0 = lrelu(am0[r] + ac0[r] * (1.0f / 2048.0f)), v1 = lrelu(am1[r] + ac1[r] * (1.0f / 2048.0f));
+            if (x0 + px < W) {
+                if (BF16OUT) {
+                    uint16_t* o16 = reinterpret_cast<uint16_t*>(out) + rowbase + (size_t)px * 64 + xl;
+                    o16[0] = __builtin_bit_cast(unsigned short, (__bf16)v0);   // round to nearest even, as the VALU kernel's convertvector
+                    o16[32] = __builtin_bit_cast(unsigned short, (__bf16)v1);
+                } else {
+                    float* o = out + rowbase + (size_t)px * 64 + xl;
+                    o[0] = v0;
+                    o[32] = v1;
+                }
+            }
+        }
+    }
+}
+
+static bool conv0_use_valu() {
+    static const int v = [] {
+        const char* e = getenv("PFNL_CONV0");
+        return (e && e[0] == 'v') ? 1 : 0;
+    }();
+    return v != 0;
+}
+
 hipError_t launch_conv0(const float* Xo, const float* w75x64, const float* bias, float* out, int B,
                         int T, int H, int W, hipStream_t s, const StripGeom* strip) {
     const int yoff = strip ? strip->yoff : 0, Hs = strip ? strip->Hs : H;
+    if (!conv0_use_valu()) {
+        dim3 grid((W + C0M_TW - 1) / C0M_TW, (Hs + C0M_TH - 1) / C0M_TH, B * T);
+        hipLaunchKernelGGL(conv0_mfma_kernel<false>, grid, dim3(256), 0, s, Xo, w75x64, bias, out, T, H, W, nl_padded_ch(12 * T), yoff, Hs);
+        return hipGetLastError();
+    }
     dim3 grid((W + C0_T - 1) / C0_T, (Hs + C0_T - 1) / C0_T, B * T);
     hipLaunchKernelGGL(conv0_kernel<false>, grid, dim3(256), 0, s, Xo, w75x64, bias, out, T, H, W,
                        nl_padded_ch(12 * T), yoff, Hs);
@@ -114,6 +260,12 @@ hipError_t launch_conv0(const float* Xo, const float* w75x64, const float* bias,
 hipError_t launch_conv0_bf16(const float* Xo, const float* w75x64, const float* bias, uint16_t* out, int B, int T, int H,
                              int W, hipStream_t s, const StripGeom* strip) {
     const int yoff = strip ? strip->yoff : 0, Hs = strip ? strip->Hs : H;
+    if (!conv0_use_valu()) {
+        dim3 grid((W + C0M_TW - 1) / C0M_TW, (Hs + C0M_TH - 1) / C0M_TH, B * T);
+        hipLaunchKernelGGL(conv0_mfma_kernel<true>, grid, dim3(256), 0, s, Xo, w75x64, bias, reinterpret_cast<float*>(out), T, H, W,
+                           nl_padded_ch(12 * T), yoff, Hs);
+        return hipGetLastError();
+    }
     dim3 grid((W + C0_T - 1) / C0_T, (Hs + C0_T - 1) / C0_T, B * T);
     hipLaunchKernelGGL(conv0_kernel<true>, grid, dim3(256), 0, s, Xo, w75x64, bias, reinterpret_cast<float*>(out), T, H, W,
                        nl_padded_ch(12 * T), yoff, Hs);
