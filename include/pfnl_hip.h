@@ -199,6 +199,10 @@ int pfnl_op_conv2_grouped(const float* in, const float* base, const float* kerne
  * in [clips*fpc, H, W, 64], kernel_host HWIO [3,3,64*fpc,cout], out [clips, H, W, 64] (channels >= cout: act(0)). */
 int pfnl_op_conv3x3_accum(const float* in, const float* kernel_host, const float* bias_host, float* out, int clips,
                           int frames_per_clip, int H, int W, int cout, int act, void* stream);
+/* The same sum on the f16 matrix pipe with exactly split operands: the accumulating mode of conv3x3_split16_kernel (any H, W;
+ * what the forward runs for convmerge1 when conv3x3 resolves to split16; option merge1 = auto | split16 | winograd). */
+int pfnl_op_conv3x3_accum_split16(const float* in, const float* kernel_host, const float* bias_host, float* out, int clips,
+                                  int frames_per_clip, int H, int W, int cout, int act, void* stream);
 /* conv10_i (reference model/pfnl.py:50, :67-68): the 1x1, (frames_per_item*64) -> 64 convolution through
  * the streaming kernel that reads its A operand straight from HBM (no LDS; conv1x1.hip).
  * in [items*frames_per_item, HW, 64], kernel_host HWIO [1,1,64*fpi,64], out [items, HW, 64]. */

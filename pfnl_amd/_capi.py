@@ -54,6 +54,7 @@ SIGNATURES = {
     "pfnl_op_conv2d": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv2_grouped": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv3x3_accum": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "pfnl_op_conv3x3_accum_split16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv1x1_split16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv1x1_stream": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv3x3_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),

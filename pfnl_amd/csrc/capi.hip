@@ -91,6 +91,8 @@ struct pfnl_handle {
     DevBuf wdev16;                                            // bf16 packs (offsets in 16-bit elements)
     std::vector<size_t> off16_c1, off16_c10, off16_c2a, off16_c2b;
     size_t off16_m1 = 0;                                      // convmerge1: T consecutive packs (cout 48 zero-padded to 64)
+    size_t off16s_m1 = 0;                                     // convmerge1, split-f16 packs: T consecutive (frame, both halves) packs
+    int m1_algo = 0;                                          // convmerge1 with conv3x3=split16: 0 auto (= 1), 1 the split-f16 kernel's accumulating mode, 2 Winograd
     int conv_algo = 5;                                        // conv3x3: 5 auto (4 for large shapes, 3 for small), 0 direct, 1 winograd (4 waves / tile), 2 winograd16 (1 wave / SIMD), 3 winograd_ws (persistent, wave-specialised), 4 split16 (f16 MFMA, split fp32 operands)
     int bf16_nl = 1;                                          // non-local block of precision=bf16: 0 split-bf16 operands (nonlocal_bf16.hip), 1 f16 operands (nonlocal_f16.hip, hi parts; default)
     int nl_algo = 2;                                          // non-local block of the fp32 path: 0 f32 MFMA (nonlocal.hip), 1 split-f16 (nonlocal_f16.hip), 2 auto (1 from N = 1024 keys)
@@ -437,10 +439,18 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
     }
     h->prof_gate = true;
     if (h->prof_mode == 2) h->chain_open = false;
-    const bool m1_wino = (algo == 3 || algo == 4) && wino_groups >= 224 && (long long)H * W * 256 < 0x7fffffffLL;
-    const int mstride = m1_wino ? 64 : 48;
+    const bool m1_s16 = algo == 4 && h->m1_algo != 2 && (long long)H * W * 256 < 0x7fffffffLL;
+    const bool m1_wino = !m1_s16 && (algo == 3 || algo == 4) && wino_groups >= 224 && (long long)H * W * 256 < 0x7fffffffLL;
+    const int mstride = (m1_wino || m1_s16) ? 64 : 48;
     h->merge_cstride = mstride;
-    if (m1_wino) {
+    if (m1_s16) {
+        // convmerge1 (:73-74) on the f16 pipe: the accumulating mode of conv3x3_split16_kernel (the T frame tiles of a clip run
+        // through the same accumulators, every unit with its own weights; cout zero-padded to 64; one epilogue per clip tile)
+        ProfScope ps(h, s, PFNL_K_MERGE1);
+        ConvSplitParams q{merge_in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_m1, wd + h->off_m1_b, nullptr, nullptr,
+                          h->merge.p, H, W, F, T, 1, 1};
+        HIPCHK(launch_conv3x3_split16(q, s));
+    } else if (m1_wino) {
         // convmerge1 (:73-74) = sum over the T frames of a 3x3 64->48 convolution: one launch of the persistent
         // Winograd kernel in its accumulating mode (cout zero-padded to 64; the T frame tiles of a clip add into
         // the same accumulators, one epilogue per clip tile)
@@ -619,6 +629,14 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         if (v == "bf16") h->bf16 = true;
         else if (v == "fp32") h->bf16 = false;
         else return fail(PFNL_ERR_INVALID, "precision must be fp32 or bf16");
+        return 0;
+    }
+    if (k == "merge1") {
+        if (v == "auto") h->m1_algo = 0;
+        else if (v == "split16") h->m1_algo = 1;
+        else if (v == "winograd") h->m1_algo = 2;
+        else return fail(PFNL_ERR_INVALID, "merge1 must be auto, split16 or winograd");
+        ++h->cfg_gen;
         return 0;
     }
     if (k == "bf16_nonlocal") {
@@ -818,7 +836,10 @@ int pfnl_finalize_weights(pfnl_handle* h) {
         h->off16s_c2a.assign(nb, 0);
         h->off16s_c2b.assign(nb, 0);
         h->off16s_c10.assign(nb, 0);
-        b16.resize((size_t)nb * (3 * n3 + n1) + 2, 0);
+        h->off16s_m1 = (size_t)nb * (3 * n3 + n1);
+        b16.resize((size_t)nb * (3 * n3 + n1) + (size_t)T * n3 + 2, 0);
+        for (int f = 0; f < T; ++f)
+            pfnl::conv3x3_split16_pack_weights(W("convmerge1").data(), 64 * T, 64 * f, &b16[h->off16s_m1 + (size_t)f * n3], 48);
         for (int i = 0; i < nb; ++i) {
             const std::string s = std::to_string(i);
             h->off16s_c1[i] = (size_t)i * (3 * n3 + n1);
@@ -1227,6 +1248,28 @@ int pfnl_op_conv3x3_accum(const float* in, const float* kernel_host, const float
     }
     (void)hipFree(dw);
     if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("accumulating conv op: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int pfnl_op_conv3x3_accum_split16(const float* in, const float* kernel_host, const float* bias_host, float* out, int clips,
+                                  int frames_per_clip, int H, int W, int cout, int act, void* stream) {
+    if (!in || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (clips < 1 || frames_per_clip < 1 || H < 1 || W < 1 || cout < 1 || cout > 64) return fail(PFNL_ERR_INVALID, "accumulating conv needs cout <= 64");
+    if ((long long)H * W * 256 >= 0x7fffffffLL) return fail(PFNL_ERR_INVALID, "frame too large for the persistent kernel");
+    hipStream_t s = (hipStream_t)stream;
+    const int T = frames_per_clip;
+    const size_t nh = pfnl::conv3x3_split16_pack_halfs();
+    std::vector<uint16_t> pack((size_t)T * nh + 128, 0);
+    for (int f = 0; f < T; ++f) pfnl::conv3x3_split16_pack_weights(kernel_host, 64 * T, 64 * f, pack.data() + (size_t)f * nh, cout);
+    if (bias_host) std::memcpy(&pack[(size_t)T * nh], bias_host, cout * sizeof(float));
+    uint16_t* dw = nullptr;
+    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(uint16_t)));
+    hipError_t e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    pfnl::ConvSplitParams q{in, dw, reinterpret_cast<const float*>(dw + (size_t)T * nh), nullptr, nullptr, out, H, W, clips * T, T, act, 1};
+    if (e == hipSuccess) e = pfnl::launch_conv3x3_split16(q, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dw);
+    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("accumulating conv (split16) op: ") + hipGetErrorString(e));
     return 0;
 }
 

@@ -14,6 +14,7 @@ struct ConvSplitParams {
     const float* resid;      // [items][H][W][64] f32, added after the activation           / neither
     float* out;              // [items][H][W][64] f32 (may alias resid)
     int H, W, items, add_div, act;
+    int accum;               // 1: out[items/add_div] = act(sum over the add_div frames of an item group + bias); wpack = add_div packs (convmerge1)
 };
 hipError_t launch_conv3x3_split16(const ConvSplitParams& p, hipStream_t s);
 size_t conv3x3_split16_pack_halfs();                                  // 16-bit elements per packed 3x3 64->64 kernel

@@ -88,9 +88,13 @@ __device__ __forceinline__ void split4(f32x4 v, u32x2& hi, u32x2& lo, float nsca
 #endif
 }
 
-// FUSE = false: out = act(conv + bias).   FUSE = true (conv2_i per-frame half): out = act(conv + bias + addend[item / add_div]) + resid.
-template <bool FUSE>
+// MODE 0: out = act(conv + bias).   MODE 1 (FUSE; conv2_i per-frame half): out = act(conv + bias + addend[item / add_div]) + resid.
+// MODE 2 (ACCUM; convmerge1, reference model/pfnl.py:52,73-74): out[clip] = act(sum over the add_div frames f of a clip of
+// conv(in[clip * add_div + f]; weights f) + bias) - the accumulators run through the chain of a clip's frames at one spatial tile,
+// every unit brings its own weights (pack index 2 f + half), one epilogue per chain.
+template <int MODE>
 __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSplitParams p) {
+    constexpr bool FUSE = MODE == 1, ACCUM = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_smem[];
     unsigned char* const wl = cs_smem + 2 * CS_TILE_BYTES;
     float* const bl = reinterpret_cast<float*>(cs_smem + 2 * CS_TILE_BYTES + CS_W_BYTES);
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
     const int item_bytes = H * W * 256;
     // Work order (as conv_bf16.hip): chains of the gT frames of a clip at one spatial tile (the addend tile is then an L2
     // hit for all but the first), dealt out XCD by XCD so that neighbouring tiles share their halo rows in one L2.
-    const int gT = FUSE ? p.add_div : 1;
+    const int gT = (FUSE || ACCUM) ? p.add_div : 1;
     const int nchains = per_item * (p.items / gT);
     const int xcd = blockIdx.x & 7, xj = blockIdx.x >> 3, cpx = gridDim.x >> 3;
     const int per_xcd = (nchains + 7) >> 3;
@@ -229,6 +233,8 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
         }
     };
     const float slope = p.act ? 0.2f : 1.0f;
+    [[maybe_unused]] f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};            // ACCUM: the bias joins in the epilogue (chunk tid & 15 of every pixel line)
+    if constexpr (ACCUM) bias4 = *reinterpret_cast<const f32x4*>(p.bias + (tid & 15) * 4);
     f32x4 radd[2], rres[2];                                         // FUSE: addend / residual pieces in flight (two store pieces ahead)
     // Store piece k of a thread = 16-byte chunk c = tid & 15 of pixel (row pair k, column tid >> 4): one byte offset per
     // thread (row pair 0), the row pair goes in the scalar offset (2 rows = wbytes2 bytes per step); rows past the image are
@@ -262,6 +268,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
         const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)eitemp * H * W * 64, 0, item_bytes, 0x00020000);
         f32x4 v = pv;
         if constexpr (FUSE) v += radd[k & 1];
+        if constexpr (ACCUM) v += bias4;
 #ifdef CS_X_PKSLOPE
         const f32x4 sv = v * slope;
         v.x = fmaxf(v.x, sv.x);
@@ -320,6 +327,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
         if (tid < 64) bl[tid] = bias_r;
 #pragma unroll
         for (int k = 0; k < CS_ITERS; ++k) CS_COMMIT1(k, 0);
+        if constexpr (ACCUM) w_request(0, 2);                       // (every ACCUM unit writes "its" slot 2 in group 1: identical data here)
     }
     __syncthreads();
 
@@ -336,6 +344,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
     n_item = c_item;
     n_y0 = c_y0;
     n_x0 = c_x0;
+    [[maybe_unused]] int fch = 0;                                   // ACCUM: frame of the chain the current tile is
     for (int kt = 0; kt < nt; ++kt) {
         const int half_a = kt & 1;                                  // channel half of unit A; unit B: the other one
         auto unit = [&](auto par) __attribute__((always_inline)) {
@@ -362,7 +371,15 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
             Wv[0][0] = CS_WT(0, 0, 0);
             Wv[0][1] = CS_WT(0, 0, 1);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PAR == 0) w_request(half_a ^ 1, 0);
+            // ACCUM: every unit has its own weights (pack index 2 f + half): the same three-slice replacement in BOTH units,
+            // one group later - group 1: slot 2 of THIS unit written (requested in the previous unit's group 5), slot 0 of the
+            // next unit requested; group 3: slot 0 written, slot 1 requested; group 5: slot 1 written, slot 2 requested.
+            [[maybe_unused]] int w_next = 0;
+            if constexpr (ACCUM) {
+                const int fn = fch + 1 == gT ? 0 : fch + 1;
+                w_next = PAR == 0 ? 2 * fch + (half_a ^ 1) : 2 * fn + (half_a ^ 1);   // unit B's half is also the next tile's first half
+            }
+            if constexpr (PAR == 0 && !ACCUM) w_request(half_a ^ 1, 0);
             // the NEXT unit's halo: requested here, committed in groups 4-5 of this unit (4 groups = ~2 us later), i.e. request
             // and use never straddle the loop back-edge and the compiler's vmcnt for the commit is exact
             {
@@ -380,7 +397,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
             piece_setup(PAR);                                       // epilogue pass PAR of the previous tile (nothing pending: out of range)
 
             [[maybe_unused]] f32x16 bias16;                         // register r of a lane = channel ech + r
-            if constexpr (PAR == 0) {
+            if constexpr (PAR == 0 && !ACCUM) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + ech + 4 * q);
@@ -403,7 +420,12 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                     }
                     if constexpr (g == 1) {
                         dump(other, PAR, 1);
-                        if constexpr (PAR == 1) w_write(2);
+                        if constexpr (ACCUM) {
+                            w_write(2);
+                            w_request(w_next, 0);
+                        } else if constexpr (PAR == 1) {
+                            w_write(2);
+                        }
                     }
                     if constexpr (g == 2) {
                         CS_STAMP();                                 // 1: groups 0-1 done
@@ -415,7 +437,10 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                     if constexpr (g == 3) {
                         piece_finish(2);
                         piece_read(other, 3);
-                        if constexpr (PAR == 0) {
+                        if constexpr (ACCUM) {
+                            w_write(0);
+                            w_request(w_next, 1);
+                        } else if constexpr (PAR == 0) {
                             w_write(0);
                             w_request(half_a ^ 1, 1);
                         }
@@ -438,7 +463,10 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                     if constexpr (g == 5) {
 #pragma unroll
                         for (int k = CS_ITERS / 2; k < CS_ITERS; ++k) CS_COMMIT1(k, cb ^ 1);
-                        if constexpr (PAR == 0) {
+                        if constexpr (ACCUM) {
+                            w_write(1);
+                            w_request(w_next, 2);
+                        } else if constexpr (PAR == 0) {
                             w_write(1);
                             w_request(half_a ^ 1, 2);
                         }
@@ -478,7 +506,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                 __builtin_amdgcn_sched_barrier(0);
                 // --- 6 MFMAs: row tap ky of both output rows
                 const h8 wh = Wv[S & 1][0], wo = Wv[S & 1][1];
-                if constexpr (PAR == 0 && S == 0) {                 // a tile's first products: C = bias / 0 (no registers to clear)
+                if constexpr (PAR == 0 && S == 0 && !ACCUM) {       // a tile's first products: C = bias / 0 (no registers to clear)
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     accm[0] = mfma_f16(wh, X[ky][0], bias16);
                     accm[1] = mfma_f16(wh, X[ky + 1][0], bias16);
@@ -514,7 +542,29 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
             substep(std::integral_constant<int, 17>{});
 #undef CS_PX
 #undef CS_WT
-            if constexpr (PAR == 1) {                               // the tile is complete: fold the cross terms in, hand it to the epilogue
+            if constexpr (PAR == 1 && ACCUM) {                      // a tile is one frame of the chain: only the last one ends a sum
+                const bool last = fch + 1 == gT;                    // (wave-uniform; arithmetic only inside the branch)
+                if (last) {
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        accp[n] = accm[n] + accc[n] * CS_ISCALE;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            accm[n][r] = 0.f;
+                            accc[n][r] = 0.f;
+                        }
+                    }
+                    ex0p = c_x0;
+                    ey0p = c_y0;
+                    eitemp = c_item / gT;                           // output item = the clip
+                }
+                pending = last;
+                fch = last ? 0 : fch + 1;
+                c_item = n_item;
+                c_y0 = n_y0;
+                c_x0 = n_x0;
+            }
+            if constexpr (PAR == 1 && !ACCUM) {                     // the tile is complete: fold the cross terms in, hand it to the epilogue
                 // (the previous tile's second pass ran in this unit: accp is free)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) accp[n] = accm[n] + accc[n] * CS_ISCALE;
@@ -562,6 +612,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
 hipError_t launch_conv3x3_split16(const ConvSplitParams& p, hipStream_t s) {
     if (!p.in || !p.wpack || !p.bias || !p.out || p.items < 1 || p.H < 1 || p.W < 1) return hipErrorInvalidValue;
     if ((p.addend == nullptr) != (p.resid == nullptr) || (p.addend && (p.add_div < 1 || p.items % p.add_div))) return hipErrorInvalidValue;
+    if (p.accum && (p.addend || p.add_div < 1 || p.items % p.add_div)) return hipErrorInvalidValue;
     if ((long long)p.H * p.W * 256 >= 0x7fffffffLL) return hipErrorInvalidValue;
     static int ncu = 0;
     if (!ncu) {
@@ -571,18 +622,20 @@ hipError_t launch_conv3x3_split16(const ConvSplitParams& p, hipStream_t s) {
         ncu = prop.multiProcessorCount;
     }
     const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;                    // whole XCDs; surplus workgroups exit at once
-    static bool attr_dev[64][2] = {};                               // the attribute is per device
+    static bool attr_dev[64][3] = {};                               // the attribute is per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    const int mode = p.addend ? 1 : 0;
-    const void* fn = mode ? reinterpret_cast<const void*>(conv3x3_split16_kernel<true>) : reinterpret_cast<const void*>(conv3x3_split16_kernel<false>);
+    const int mode = p.accum ? 2 : p.addend ? 1 : 0;
+    const void* fn = mode == 2 ? reinterpret_cast<const void*>(conv3x3_split16_kernel<2>)
+                   : mode     ? reinterpret_cast<const void*>(conv3x3_split16_kernel<1>) : reinterpret_cast<const void*>(conv3x3_split16_kernel<0>);
     if (!attr_dev[dev][mode]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_dev[dev][mode] = true;
     }
-    if (mode) hipLaunchKernelGGL(conv3x3_split16_kernel<true>, dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, p);
-    else hipLaunchKernelGGL(conv3x3_split16_kernel<false>, dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, p);
+    if (mode == 2) hipLaunchKernelGGL(conv3x3_split16_kernel<2>, dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, p);
+    else if (mode) hipLaunchKernelGGL(conv3x3_split16_kernel<1>, dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, p);
+    else hipLaunchKernelGGL(conv3x3_split16_kernel<0>, dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, p);
     return hipGetLastError();
 }
 

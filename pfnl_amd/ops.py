@@ -78,10 +78,11 @@ def conv2_grouped(x, base, kernel, bias, resid, frames_per_clip, act=True):
     return out
 
 
-def conv3x3_accum(x, kernel, bias=None, act=True, frames_per_clip=1):
+def conv3x3_accum(x, kernel, bias=None, act=True, frames_per_clip=1, variant="winograd"):
     """convmerge1: 3x3 over the concat of `frames_per_clip` frames, (64*fpc) -> cout <= 64, one accumulating
-    launch of the persistent Winograd kernel.  x [clips*fpc, H, W, 64] (cuda); kernel HWIO [3,3,64*fpc,cout];
-    returns [clips, H, W, cout].  Reference: model/pfnl.py:52, :73-74."""
+    launch of the persistent Winograd kernel (variant "winograd": even H, W) or of the split-f16 kernel ("split16").
+    x [clips*fpc, H, W, 64] (cuda); kernel HWIO [3,3,64*fpc,cout]; returns [clips, H, W, cout].
+    Reference: model/pfnl.py:52, :73-74."""
     import torch
     lib = _capi.load_library()
     k = _host(kernel, "kernel")
@@ -91,7 +92,8 @@ def conv3x3_accum(x, kernel, bias=None, act=True, frames_per_clip=1):
     if k.shape[:3] != (3, 3, 64 * frames_per_clip) or c != 64 or F % frames_per_clip or cout > 64:
         raise ValueError("conv3x3_accum: geometry mismatch")
     out = torch.empty((F // frames_per_clip, H, W, 64), dtype=torch.float32, device=x.device)
-    _capi.check(lib.pfnl_op_conv3x3_accum(
+    fn = lib.pfnl_op_conv3x3_accum_split16 if variant == "split16" else lib.pfnl_op_conv3x3_accum
+    _capi.check(fn(
         _req(x, "x"), k.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p) if b is not None else None,
         _req(out, "out"), F // frames_per_clip, frames_per_clip, H, W, cout, 1 if act else 0, _stream(x)))
     return out[..., :cout]

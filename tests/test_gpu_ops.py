@@ -105,17 +105,27 @@ def test_conv2_grouped(clips, T, H, W):
     (3, 3, 6, 70, 64),      # T = 3, full 64 outputs
     (4, 7, 32, 64, 48),     # several groups per workgroup
     (1, 1, 2, 2, 48),       # degenerate: a single frame, a single 2x2 tile
+    (2, 7, 40, 96, 48),     # several chains per workgroup on the persistent kernels
 ])
-def test_conv3x3_accum(clips, T, H, W, cout):
+@pytest.mark.parametrize("variant", ["winograd", "split16"])   # f32 Winograd / f16 MFMA with exactly split fp32 operands
+def test_conv3x3_accum(clips, T, H, W, cout, variant):
     rng = np.random.default_rng(clips * 100 + T * 10 + H + W)
     x = rng.normal(size=(clips * T, H, W, 64)).astype(np.float32)
     k = (rng.normal(size=(3, 3, 64 * T, cout)) / np.sqrt(9 * 64 * T)).astype(np.float32)
     b = rng.normal(size=cout).astype(np.float32)
     xin = x.reshape(clips, T, H, W, 64).transpose(0, 2, 3, 1, 4).reshape(clips, H, W, 64 * T)
     ref = pfnl_spec.lrelu(pfnl_spec.conv2d_same(xin.astype(np.float64), k.astype(np.float64), b.astype(np.float64)))
-    got = ops.conv3x3_accum(dev(x), k, b, act=True, frames_per_clip=T).cpu().numpy()
+    got = ops.conv3x3_accum(dev(x), k, b, act=True, frames_per_clip=T, variant=variant).cpu().numpy()
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+    if variant == "split16" and (H * W) % 2:
+        return
+    if variant == "split16":                                          # odd sizes too: the split-f16 kernel has no parity restriction
+        xo = x[:, :H - 1, :W - 1].copy()
+        ref = pfnl_spec.lrelu(pfnl_spec.conv2d_same(xo.reshape(clips, T, H - 1, W - 1, 64).transpose(0, 2, 3, 1, 4).reshape(
+            clips, H - 1, W - 1, 64 * T).astype(np.float64), k.astype(np.float64), b.astype(np.float64)))
+        got = ops.conv3x3_accum(dev(xo), k, b, act=True, frames_per_clip=T, variant=variant).cpu().numpy()
+        assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
 
 
 @pytest.mark.parametrize("items,fpi,H,W,act", [
