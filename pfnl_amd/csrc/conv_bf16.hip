@@ -69,6 +69,16 @@ __device__ __forceinline__ f32x4 bf16x4_to_f32(u32x2 v) {
     return f32x4{__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xffff0000u),
                  __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xffff0000u)};
 }
+// leaky_relu(0.2) or identity as max(v, slope v), slope 0.2 / 1: two packed multiplies + four v_max per 4 values, no branch
+// (fmaxf adds a canonicalising v_max x,x,x per element: 3 VALU per value with the multiply)
+__device__ __forceinline__ f32x4 lrelu4(f32x4 v, float slope) {
+    const f32x4 sv = v * slope;
+    asm("v_max_f32 %0, %1, %2" : "=v"(v.x) : "v"(v.x), "v"(sv.x));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v.y) : "v"(v.y), "v"(sv.y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v.z) : "v"(v.z), "v"(sv.z));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v.w) : "v"(v.w), "v"(sv.w));
+    return v;
+}
 __device__ __forceinline__ u32x2 f32x4_to_bf16(f32x4 v) {         // round to nearest even (v_cvt_pk_bf16_f32)
     const bf16x4 b = __builtin_convertvector(v, bf16x4);
     return __builtin_bit_cast(u32x2, b);
@@ -212,6 +222,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
     // writes, the read-back and the 1x1 operand reads of MODE 2), and after a
     // barrier the workgroup stores it as whole 128-byte lines, 8 pixels per wave instruction.
     int ex0p = 0, ey0p = 0;                                         // origin of the tile awaiting its epilogue
+    const float eslope = p.act ? 0.2f : 1.0f;
     auto epilogue_unit = [&](unsigned char* scratch, int n, int h) __attribute__((always_inline)) {   // bias, addend, leaky_relu, residual, bf16
         if constexpr (ACCUM) {                                      // fp32 out, straight from the accumulators (one tile in T, 48 of 64 channels used)
             const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(p.out_f32 + (size_t)(eitemp / gT) * H * W * 64, 0, 2 * item_bytes, 0x00020000);
@@ -221,12 +232,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
             for (int q = 0; q < 2; ++q) {
                 const int r0 = 8 * h + 4 * q;
                 f32x4 v = f32x4{accp[n][r0], accp[n][r0 + 1], accp[n][r0 + 2], accp[n][r0 + 3]} + *reinterpret_cast<const f32x4*>(bl + ech + r0);
-                if (p.act) {
-                    v.x = lrelu(v.x);
-                    v.y = lrelu(v.y);
-                    v.z = lrelu(v.z);
-                    v.w = lrelu(v.w);
-                }
+                v = lrelu4(v, eslope);
                 buffer_store_b128_guarded(__builtin_bit_cast(u32x4, v), rsF, off, 16 * q);
             }
             return;
@@ -238,12 +244,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + ech + r0);
             v[q] = f32x4{accp[n][r0], accp[n][r0 + 1], accp[n][r0 + 2], accp[n][r0 + 3]} + b4;
             if (FUSE) v[q] += bf16x4_to_f32(u32x2{radd[n][h][2 * q], radd[n][h][2 * q + 1]});
-            if (p.act) {
-                v[q].x = lrelu(v[q].x);
-                v[q].y = lrelu(v[q].y);
-                v[q].z = lrelu(v[q].z);
-                v[q].w = lrelu(v[q].w);
-            }
+            v[q] = lrelu4(v[q], eslope);
             if (FUSE) v[q] += bf16x4_to_f32(u32x2{rres[n][h][2 * q], rres[n][h][2 * q + 1]});
         }
         const u32x2 lo = f32x4_to_bf16(v[0]), hi = f32x4_to_bf16(v[1]);
@@ -308,10 +309,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
                     const int r0 = 8 * h + 4 * q;
                     v[q] = f32x4{bacc[n][r0], bacc[n][r0 + 1], bacc[n][r0 + 2], bacc[n][r0 + 3]} +
                            *reinterpret_cast<const f32x4*>(p.x_bias + ech + r0);
-                    v[q].x = lrelu(v[q].x);
-                    v[q].y = lrelu(v[q].y);
-                    v[q].z = lrelu(v[q].z);
-                    v[q].w = lrelu(v[q].w);
+                    v[q] = lrelu4(v[q], 0.2f);
                 }
                 const u32x2 lo = f32x4_to_bf16(v[0]), hi = f32x4_to_bf16(v[1]);
                 buffer_store_b128_guarded(u32x4{lo.x, lo.y, hi.x, hi.y}, rsX, off, 16 * h);
