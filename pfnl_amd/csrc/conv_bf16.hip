@@ -85,8 +85,8 @@ __device__ __forceinline__ u32x2 f32x4_to_bf16(f32x4 v) {         // round to ne
 }
 
 #ifdef PFNL_BF16_TIMING   /* phase timeline of the kernel (tools/bf16_timing.py); not part of the product build */
-__device__ long long cb_dbg[256 * 8 * 64];
-#define CB_STAMP() do { if (lane == 0 && dbg_n < 64) cb_dbg[(blockIdx.x * 8 + wave) * 64 + dbg_n++] = __builtin_readcyclecounter(); } while (0)
+__device__ long long cb_dbg[256 * 8 * 256];
+#define CB_STAMP() do { if (lane == 0 && dbg_n < 256) cb_dbg[(blockIdx.x * 8 + wave) * 256 + dbg_n++] = __builtin_readcyclecounter(); } while (0)
 #else
 #define CB_STAMP() do {} while (0)
 #endif
@@ -222,6 +222,9 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
     // writes, the read-back and the 1x1 operand reads of MODE 2), and after a
     // barrier the workgroup stores it as whole 128-byte lines, 8 pixels per wave instruction.
     int ex0p = 0, ey0p = 0;                                         // origin of the tile awaiting its epilogue
+    [[maybe_unused]] uint16_t* ptrOp = p.out;                       // its item in `out`
+    [[maybe_unused]] const uint16_t* ptrR = p.resid;                // FUSE: the current tile's item in `resid`, its chain's in `addend`
+    [[maybe_unused]] const uint16_t* ptrA = p.addend;
     const float eslope = p.act ? 0.2f : 1.0f;
     auto epilogue_unit = [&](unsigned char* scratch, int n, int h) __attribute__((always_inline)) {   // bias, addend, leaky_relu, residual, bf16
         if constexpr (ACCUM) {                                      // fp32 out, straight from the accumulators (one tile in T, 48 of 64 channels used)
@@ -241,8 +244,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int r0 = 8 * h + 4 * q;
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + ech + r0);
-            v[q] = f32x4{accp[n][r0], accp[n][r0 + 1], accp[n][r0 + 2], accp[n][r0 + 3]} + b4;
+            v[q] = f32x4{accp[n][r0], accp[n][r0 + 1], accp[n][r0 + 2], accp[n][r0 + 3]};   // (the bias is in: initial C of the tile)
             if (FUSE) v[q] += bf16x4_to_f32(u32x2{radd[n][h][2 * q], radd[n][h][2 * q + 1]});
             v[q] = lrelu4(v[q], eslope);
             if (FUSE) v[q] += bf16x4_to_f32(u32x2{rres[n][h][2 * q], rres[n][h][2 * q + 1]});
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
     };
     auto store_piece = [&](const unsigned char* scratch, int k) __attribute__((always_inline)) {   // 2048 pieces, 4 per thread, whole lines per instruction
         if constexpr (ACCUM) return;                                // (stored by epilogue_unit)
-        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)eitemp * H * W * 64, 0, item_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(ptrOp, 0, item_bytes, 0x00020000);
         const int id = k * CB_THREADS + tid;
         const int pp = id >> 3, c = id & 7;
         const int sx = ex0p + (pp & 31), sy = ey0p + (pp >> 5);
@@ -265,10 +267,9 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
         buffer_store_b128_guarded(o, rsO, (sx < W && sy < H) ? (sy * W + sx) * 128 + c * 16 : 0x7fffffff, 0);
     };
     auto fuse_request = [&](bool with_addend, int n, int h) __attribute__((always_inline)) {   // addend / residual piece (n, h) of the tile described by eoff / eitem
-        const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<uint16_t*>(p.resid) + (size_t)eitem * H * W * 64, 0, item_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<uint16_t*>(p.addend) + (size_t)(eitem / p.add_div) * H * W * 64, 0, item_bytes, 0x00020000);
+        // (base pointers of the tile's items: computed once per tile, not per request - a 64-bit product and a division each)
+        const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ptrR), 0, item_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ptrA), 0, item_bytes, 0x00020000);
         if (with_addend)                                            // (same pixels for every frame of the chain)
             radd[n][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, eoff[n], (ech + 8 * h) * 2, 0));
         rres[n][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, eoff[n], (ech + 8 * h) * 2, 0));
@@ -340,7 +341,23 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
             eoff[n] = (ox < W && oy < H) ? (oy * W + ox) * 128 : 0x7fffffff;
         }
         eitem = item;
-        if (!ACCUM || item % gT == 0) {                             // (MODE 3: the accumulators run through the chain)
+        if constexpr (FUSE) {
+            ptrR = p.resid + (size_t)item * H * W * 64;
+            ptrA = p.addend + (size_t)(item / p.add_div) * H * W * 64;
+        }
+        // modes 0-2: the tile's first MFMAs take C = bias (register r of a lane = channel ech + r) - nothing to clear, no bias
+        // reads (an exposed LDS round trip in each of the four epilogue groups) and no bias adds in the epilogue
+        [[maybe_unused]] f32x16 bias16;
+        if constexpr (!ACCUM) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + ech + 4 * q);
+                bias16[4 * q] = b4.x;
+                bias16[4 * q + 1] = b4.y;
+                bias16[4 * q + 2] = b4.z;
+                bias16[4 * q + 3] = b4.w;
+            }
+        } else if (item % gT == 0) {                                // (MODE 3: the accumulators run through the chain)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -372,6 +389,9 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
         auto group = [&](auto gc) {
             constexpr int g = decltype(gc)::value;
             constexpr int cur = g & 1;
+#ifdef PFNL_BF16_TIMING
+            CB_STAMP();                                             // group start (16 stamps per tile: 12 groups + commit pair + barrier pair)
+#endif
             if constexpr (g < 4) {
                 if (pending) epilogue_unit(other, g >> 1, g & 1);
                 if (FUSE) fuse_request(chain_head, g >> 1, g & 1);
@@ -412,7 +432,15 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int n = 0; n < 2; ++n) acc[n] = mfma_bf16(wv[cur][ky], px[cur][n + ky], acc[n]);
+                for (int n = 0; n < 2; ++n) {
+                    if constexpr (g == 0 && !ACCUM) {
+                        if (ky == 0) {
+                            acc[n] = mfma_bf16(wv[cur][ky], px[cur][n + ky], bias16);
+                            continue;
+                        }
+                    }
+                    acc[n] = mfma_bf16(wv[cur][ky], px[cur][n + ky], acc[n]);
+                }
             __builtin_amdgcn_sched_barrier(0);
         };
         group(std::integral_constant<int, 0>{});
@@ -435,6 +463,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
             ex0p = x0;
             ey0p = y0;
             eitemp = eitem;
+            if constexpr (!ACCUM) ptrOp = p.out + (size_t)eitem * H * W * 64;
             pending = true;
         } else {
             pending = false;
