@@ -151,14 +151,24 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
     // piece (LDS and global offsets are recomputed per tile: ~60 VALU per thread against a tile's 2.3k MFMA cycles
     // per wave - the registers are worth more)
     int spk[CB_ITERS];                                              // py << 16 | px << 3 | chunk
+    // Modes with registers to spare keep two more words per piece, constant for the life of the kernel (as conv_split16.hip):
+    // `grel` = byte offset of the piece relative to the halo origin in HBM, `lad` = its LDS byte address inside a halo buffer -
+    // the request is then one select + one add per piece and the commit one add, instead of the packed word's decode (a
+    // 32-bit multiply among it) in every tile.  MODE 3 (252 registers) stays with the decode.
+    constexpr bool FASTREQ = MODE != 3;
+    [[maybe_unused]] int grel[CB_ITERS], lad[CB_ITERS];
+    const int wbytes = W * 128;
 #pragma unroll
     for (int k = 0; k < CB_ITERS; ++k) {
         const int id = min(k * CB_THREADS + tid, CB_CHUNKS - 1);    // surplus threads redo the last piece (same value)
         const int pix = id >> 3, c = id & 7;
         const int py = pix / CB_IW, px = pix - py * CB_IW;
         spk[k] = (py << 16) | (px << 3) | c;
+        if constexpr (FASTREQ) {
+            grel[k] = py * wbytes + px * 128 + c * 16;
+            lad[k] = (py * CB_IW + px) * 128 + ((c ^ ((px >> 1) & 7)) << 4);
+        }
     }
-    const int wbytes = W * 128;
     u32x4 stg[CB_ITERS];
 #define CB_REQUEST(u_)                                                                           \
     do {                                                                                         \
@@ -169,7 +179,14 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
         const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                    \
             const_cast<uint16_t*>(p.in) + (size_t)it_ * H * W * 64, 0, item_bytes, 0x00020000);  \
         const int org_ = ((y0_ - 1) * W + x0_ - 1) * 128;       /* halo origin */                \
-        if (y0_ > 0 && y0_ + CB_IH - 1 <= H && x0_ > 0 && x0_ + CB_IW - 1 <= W) {                \
+        if constexpr (FASTREQ) {                                /* one arm, branch-free */       \
+            const bool interior_ = y0_ > 0 && y0_ + CB_IH - 1 <= H && x0_ > 0 && x0_ + CB_IW - 1 <= W; \
+            _Pragma("unroll") for (int k_ = 0; k_ < CB_ITERS; ++k_) {                            \
+                const int gy_ = y0_ + (spk[k_] >> 16) - 1, gx_ = x0_ + ((spk[k_] >> 3) & 0x1fff) - 1; \
+                const bool in_ = interior_ || ((unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W); \
+                stg[k_] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, in_ ? org_ + grel[k_] : 0x7fffffff, 0, 0)); \
+            }                                                                                    \
+        } else if (y0_ > 0 && y0_ + CB_IH - 1 <= H && x0_ > 0 && x0_ + CB_IW - 1 <= W) {         \
             _Pragma("unroll") for (int k_ = 0; k_ < CB_ITERS; ++k_)                              \
                 stg[k_] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(       \
                     rs_, org_ + (spk[k_] >> 16) * wbytes + (spk[k_] & 0xffff) * 16, 0, 0));      \
@@ -185,8 +202,12 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
 #define CB_COMMIT(buf_)                                                                          \
     do {                                                                                         \
         _Pragma("unroll") for (int k_ = 0; k_ < CB_ITERS; ++k_) {                                \
-            const int py_ = spk[k_] >> 16, px_ = (spk[k_] >> 3) & 0x1fff, c_ = spk[k_] & 7;      \
-            *reinterpret_cast<u32x4*>(cb_smem + (buf_) * CB_TILE_BYTES + (py_ * CB_IW + px_) * 128 + ((c_ ^ ((px_ >> 1) & 7)) << 4)) = stg[k_]; \
+            if constexpr (FASTREQ) {                                                             \
+                *reinterpret_cast<u32x4*>(cb_smem + (buf_) * CB_TILE_BYTES + lad[k_]) = stg[k_]; \
+            } else {                                                                             \
+                const int py_ = spk[k_] >> 16, px_ = (spk[k_] >> 3) & 0x1fff, c_ = spk[k_] & 7;  \
+                *reinterpret_cast<u32x4*>(cb_smem + (buf_) * CB_TILE_BYTES + (py_ * CB_IW + px_) * 128 + ((c_ ^ ((px_ >> 1) & 7)) << 4)) = stg[k_]; \
+            }                                                                                    \
         }                                                                                        \
     } while (0)
 
@@ -207,7 +228,15 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
     // then channel 32mt + 16(lane>>5) + r - 16 consecutive channels, two 16-byte pieces per output row.
     const int ech = 32 * mt + 16 * (lane >> 5);
     f32x16 acc[2], accp[2];                                         // [output row]: the tile being computed / awaiting its epilogue
-    u32x4 rres[2][2], radd[2][2];                                   // FUSE: residual / addend pieces of the tile awaiting its epilogue
+    u32x4 radd[2][2];                                               // FUSE: addend pieces (accumulator layout; fetched once per chain)
+    // FUSE: the residual tile travels as WHOLE LINES - piece k of a thread = 16-byte chunk tid & 7 of pixel (row 2k + (tid >> 8),
+    // column (tid >> 3) & 31), 8 lanes per 128-byte line - into the scratch slot its output will take, and each epilogue unit
+    // reads its 16 bytes from there (a quarter of the cache-line requests of reading them in accumulator layout, a lane = a
+    // pixel: 32 lines per instruction).  Measured: the launch takes the same 89 us either way, and 67 us with the residual
+    // not read at all (-DCB_X_NOFUSELOAD) - it is the 116 MB, not the access pattern: the per-frame launch runs at the
+    // ~4.2 TB/s this chip gives a kernel that reads and writes at once.
+    u32x4 rq[4];
+    int rbase = 0x7fffffff;                                         // byte offset of this thread's piece 0 in the tile's item (out of range: nothing)
     int eoff[2] = {0x7fffffff, 0x7fffffff};                         // this lane's pixel of output row n (bytes into the item): addend / residual pieces
     int eitem = 0, eitemp = 0;
     bool pending = false;
@@ -241,18 +270,21 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
             return;
         }
         f32x4 v[2];                                                 // of row n, channels ech + 8h .. + 7 of the tile awaiting its epilogue
+        const int j = lane & 31;
+        const int c = 4 * mt + 2 * (lane >> 5) + h;                 // piece of the pixel's line
+        u32x4* const slot = reinterpret_cast<u32x4*>(scratch + ((2 * rp + n) * 32 + j) * 128 + ((c ^ ((j >> 1) & 7)) << 4));
+        [[maybe_unused]] u32x4 rr = {0, 0, 0, 0};
+        if constexpr (FUSE) rr = *slot;                             // the residual piece sits where the output piece goes
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int r0 = 8 * h + 4 * q;
             v[q] = f32x4{accp[n][r0], accp[n][r0 + 1], accp[n][r0 + 2], accp[n][r0 + 3]};   // (the bias is in: initial C of the tile)
             if (FUSE) v[q] += bf16x4_to_f32(u32x2{radd[n][h][2 * q], radd[n][h][2 * q + 1]});
             v[q] = lrelu4(v[q], eslope);
-            if (FUSE) v[q] += bf16x4_to_f32(u32x2{rres[n][h][2 * q], rres[n][h][2 * q + 1]});
+            if (FUSE) v[q] += bf16x4_to_f32(u32x2{rr[2 * q], rr[2 * q + 1]});
         }
         const u32x2 lo = f32x4_to_bf16(v[0]), hi = f32x4_to_bf16(v[1]);
-        const int j = lane & 31;
-        const int c = 4 * mt + 2 * (lane >> 5) + h;                 // piece of the pixel's line
-        *reinterpret_cast<u32x4*>(scratch + ((2 * rp + n) * 32 + j) * 128 + ((c ^ ((j >> 1) & 7)) << 4)) = u32x4{lo.x, lo.y, hi.x, hi.y};
+        *slot = u32x4{lo.x, lo.y, hi.x, hi.y};
     };
     auto store_piece = [&](const unsigned char* scratch, int k) __attribute__((always_inline)) {   // 2048 pieces, 4 per thread, whole lines per instruction
         if constexpr (ACCUM) return;                                // (stored by epilogue_unit)
@@ -268,11 +300,26 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
     };
     auto fuse_request = [&](bool with_addend, int n, int h) __attribute__((always_inline)) {   // addend / residual piece (n, h) of the tile described by eoff / eitem
         // (base pointers of the tile's items: computed once per tile, not per request - a 64-bit product and a division each)
-        const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ptrR), 0, item_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ptrA), 0, item_bytes, 0x00020000);
+#ifdef CB_X_NOFUSELOAD   /* timing experiments only (wrong results on purpose) */
+        if (eoff[n] == 0x12345)
+#endif
         if (with_addend)                                            // (same pixels for every frame of the chain)
             radd[n][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, eoff[n], (ech + 8 * h) * 2, 0));
-        rres[n][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, eoff[n], (ech + 8 * h) * 2, 0));
+    };
+    auto resid_request = [&](int k) __attribute__((always_inline)) {   // rows 2k, 2k+1 of the current tile (rows past the image: past the resource)
+        const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ptrR), 0, item_bytes, 0x00020000);
+#ifdef CB_X_NOFUSELOAD
+        if (rbase == 0x12345)
+#endif
+        rq[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, rbase, k * 2 * wbytes, 0));
+    };
+    auto resid_stage = [&](unsigned char* scratch) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pp = k * 64 + (tid >> 3), c = tid & 7;
+            *reinterpret_cast<u32x4*>(scratch + pp * 128 + ((c ^ ((pp >> 1) & 7)) << 4)) = rq[k];
+        }
     };
 
     // MODE 2: the 1x1 over the chain's frames.  Wave (rp, mt) accumulates rows 2rp, 2rp+1 x output channels 32mt..+31
@@ -342,6 +389,8 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
         }
         eitem = item;
         if constexpr (FUSE) {
+            const int rcol = x0 + ((tid >> 3) & 31), rrow = y0 + (tid >> 8);
+            rbase = rcol < W ? (rrow * W + rcol) * 128 + (tid & 7) * 16 : 0x7fffffff;
             ptrR = p.resid + (size_t)item * H * W * 64;
             ptrA = p.addend + (size_t)(item / p.add_div) * H * W * 64;
         }
@@ -392,17 +441,28 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
 #ifdef PFNL_BF16_TIMING
             CB_STAMP();                                             // group start (16 stamps per tile: 12 groups + commit pair + barrier pair)
 #endif
-            if constexpr (g < 4) {
-                if (pending) epilogue_unit(other, g >> 1, g & 1);
-                if (FUSE) fuse_request(chain_head, g >> 1, g & 1);
-                if (WITH10 && pending) x_request(g);
+            // FUSE: everything one group later - group 0 puts the residual lines of the pending tile into the scratch, group 1
+            // starts with the barrier that makes them visible
+            constexpr int SH = FUSE ? 1 : 0;
+            if constexpr (FUSE && g == 0) {
+                if (pending) resid_stage(other);
             }
-            if constexpr (g == 4) __syncthreads();
-            if constexpr (g >= 4 && g < 8) {
-                if (pending) store_piece(other, g - 4);
-                if (WITH10 && pending) x_step(other, g - 4);
+            if constexpr (FUSE && g == 1) __syncthreads();
+            if constexpr (g >= SH && g < SH + 4) {
+                constexpr int e = g - SH;
+                if (pending) epilogue_unit(other, e >> 1, e & 1);
+                if constexpr (FUSE) {
+                    fuse_request(chain_head, e >> 1, e & 1);
+                    resid_request(e);                               // (this tile's lines; staged in group 0 of the next tile)
+                }
+                if (WITH10 && pending) x_request(e);
             }
-            if constexpr (g == 8) {
+            if constexpr (g == SH + 4) __syncthreads();
+            if constexpr (g >= SH + 4 && g < SH + 8) {
+                if (pending) store_piece(other, g - SH - 4);
+                if (WITH10 && pending) x_step(other, g - SH - 4);
+            }
+            if constexpr (g == SH + 8) {
                 __syncthreads();                                       // the scratch has been read
                 if (WITH10 && pending && eitemp % gT == gT - 1) x_epilogue();   // the pending tile closed its chain
                 CB_STAMP();
@@ -480,6 +540,10 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
         }
     }
     // the last tile (its addend / residual pieces were requested in its own iteration); any buffer is free now
+    if constexpr (FUSE) {
+        resid_stage(cb_smem);
+        __syncthreads();
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (!ACCUM || pending) epilogue_unit(cb_smem, k >> 1, k & 1);
