@@ -31,8 +31,9 @@ __device__ __forceinline__ int drow(int r, int lane) { return (r & 3) + 8 * (r >
 // INPUTS: they stay live up to it, so nothing the scheduler puts in between can write them.  tools/lint_store_hazard.py checks
 // the emitted assembly of every kernel for the pattern.
 typedef unsigned pfnl_u32x4 __attribute__((ext_vector_type(4)));
+template <int AUX = 0>                                              // AUX: the cache-policy bits of the instruction (gfx940+: 1 sc0, 2 nt, 16 sc1)
 __device__ __forceinline__ void buffer_store_b128_guarded(pfnl_u32x4 v, __amdgpu_buffer_rsrc_t rs, int voffset, int soffset) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, voffset, soffset, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, voffset, soffset, AUX);
     asm volatile("s_nop 1" ::"v"(v));
 }
 

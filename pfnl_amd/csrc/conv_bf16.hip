@@ -41,6 +41,10 @@
 #include "common.h"
 #include "conv_bf16.h"
 
+#ifndef CB_STORE_AUX
+#define CB_STORE_AUX 0      // cache-policy bits of the output stores (sc0 sc1 = 17 is worth 2 % in conv_split16.hip; here it measured +0.5 %)
+#endif
+
 namespace pfnl {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
                 const int r0 = 8 * h + 4 * q;
                 f32x4 v = f32x4{accp[n][r0], accp[n][r0 + 1], accp[n][r0 + 2], accp[n][r0 + 3]} + *reinterpret_cast<const f32x4*>(bl + ech + r0);
                 v = lrelu4(v, eslope);
-                buffer_store_b128_guarded(__builtin_bit_cast(u32x4, v), rsF, off, 16 * q);
+                buffer_store_b128_guarded<CB_STORE_AUX>(__builtin_bit_cast(u32x4, v), rsF, off, 16 * q);
             }
             return;
         }
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
 #ifdef CB_X_NOSTORE   /* timing experiments only */
         if (o.x == 0x12345678u)
 #endif
-        buffer_store_b128_guarded(o, rsO, (sx < W && sy < H) ? (sy * W + sx) * 128 + c * 16 : 0x7fffffff, 0);
+        buffer_store_b128_guarded<CB_STORE_AUX>(o, rsO, (sx < W && sy < H) ? (sy * W + sx) * 128 + c * 16 : 0x7fffffff, 0);
     };
     auto fuse_request = [&](bool with_addend, int n, int h) __attribute__((always_inline)) {   // addend / residual piece (n, h) of the tile described by eoff / eitem
         // (base pointers of the tile's items: computed once per tile, not per request - a 64-bit product and a division each)
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void conv3x3_bf16_kernel(ConvBf16Par
                     v[q] = lrelu4(v[q], 0.2f);
                 }
                 const u32x2 lo = f32x4_to_bf16(v[0]), hi = f32x4_to_bf16(v[1]);
-                buffer_store_b128_guarded(u32x4{lo.x, lo.y, hi.x, hi.y}, rsX, off, 16 * h);
+                buffer_store_b128_guarded<CB_STORE_AUX>(u32x4{lo.x, lo.y, hi.x, hi.y}, rsX, off, 16 * h);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) bacc[n][r] = 0.f;
@@ -666,7 +670,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(const uint16_t* __
                     }
                 }
                 const u32x2 lo = f32x4_to_bf16(v[0]), hi = f32x4_to_bf16(v[1]);
-                buffer_store_b128_guarded(u32x4{lo.x, lo.y, hi.x, hi.y}, rsO, ooff, (32 * m + 8 * h) * 2);
+                buffer_store_b128_guarded<CB_STORE_AUX>(u32x4{lo.x, lo.y, hi.x, hi.y}, rsO, ooff, (32 * m + 8 * h) * 2);
             }
     }
 }

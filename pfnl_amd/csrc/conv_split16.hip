@@ -33,6 +33,20 @@
 #include "common.h"
 #include "conv_split16.h"
 
+#ifndef CS_STORE_AUX
+#define CS_STORE_AUX 17     // cache-policy bits of the output stores: sc0 sc1 = written through, not kept in L2.  Measured on
+                            // configs[1] (tools/s16_variants.sh, same box, ms per step): 0 (default policy) 5.43, nt 5.43, sc1 5.33,
+                            // sc0 sc1 5.30, sc1 nt 5.49 - the 117 MB an output tensor has are not read back through this L2
+                            // before they are evicted anyway; kept out, they leave it to the halo rows, weights and addend tiles.
+                            // (residual loads with sc1 or nt: no further gain; halo loads with nt: worse)
+#endif
+#ifndef CS_RESID_AUX
+#define CS_RESID_AUX 0      // ... of the residual loads
+#endif
+#ifndef CS_HALO_AUX
+#define CS_HALO_AUX 0       // ... of the halo loads
+#endif
+
 namespace pfnl {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -168,7 +182,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
         _Pragma("unroll") for (int k_ = 0; k_ < CS_ITERS; ++k_) {                                \
             const int gy_ = (y0_) + ((lpk[k_] >> 16) & 0xff) - 1, gx_ = (x0_) + ((unsigned)lpk[k_] >> 24) - 1; \
             const bool in_ = (interior_) || ((unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W); \
-            stg[k_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, in_ ? (org_) + grel[k_] : 0x7fffffff, 0, 0)); \
+            stg[k_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, in_ ? (org_) + grel[k_] : 0x7fffffff, 0, CS_HALO_AUX)); \
         }                                                                                        \
     } while (0)
     // descriptor of unit u_'s halo: resource of its item, byte offset of the halo origin (+ the channel half), interior flag
@@ -252,8 +266,16 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                 const_cast<float*>(p.resid) + (size_t)eitemp * H * W * 64, 0, item_bytes, 0x00020000);
             const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(p.addend) + (size_t)(eitemp / p.add_div) * H * W * 64, 0, item_bytes, 0x00020000);
+#ifdef CS_X_NOADDEND   /* timing experiments only (wrong results on purpose): the load is issued, always to the same cached line */
+            radd[k & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (tid & 15) * 16, 0, 0));
+#else
             radd[k & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, soff0, k * wbytes2, 0));
-            rres[k & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, soff0, k * wbytes2, 0));
+#endif
+#ifdef CS_X_NORESID
+            rres[k & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, (tid & 15) * 16, 0, 0));
+#else
+            rres[k & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, soff0, k * wbytes2, CS_RESID_AUX));
+#endif
         }
     };
     // A store piece is taken in two steps one sub-step apart - the scratch read, then arithmetic + store - so that the LDS
@@ -288,7 +310,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
 #ifdef CS_X_NOSTORE   /* timing experiments only */
         if (v.x == 1.2345e30f)
 #endif
-        buffer_store_b128_guarded(__builtin_bit_cast(u32x4, v), rsO, soff0, k * wbytes2);   // (common.h: store-data hazard)
+        buffer_store_b128_guarded<CS_STORE_AUX>(__builtin_bit_cast(u32x4, v), rsO, soff0, k * wbytes2);   // (common.h: store-data hazard)
     };
     auto store_piece = [&](const unsigned char* scratch, int k) __attribute__((always_inline)) {
         piece_read(scratch, k);
