@@ -404,18 +404,16 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
             if constexpr (PAR == 0 && !ACCUM) w_request(half_a ^ 1, 0);
             // the NEXT unit's halo: requested here, committed in groups 4-5 of this unit (4 groups = ~2 us later), i.e. request
             // and use never straddle the loop back-edge and the compiler's vmcnt for the commit is exact
-            {
-#ifndef CS_X_NOLOAD
-                // unit A asks for the other half of ITS tile, unit B for the first half of the next tile
-                const int q_item = PAR == 0 ? c_item : n_item, y0q = PAR == 0 ? c_y0 : n_y0, x0q = PAR == 0 ? c_x0 : n_x0;
-                const int q_half = half_a ^ 1;                      // (boustrophedon: unit B's half is also the next tile's first half)
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<float*>(p.in) + (size_t)q_item * H * W * 64, 0, item_bytes, 0x00020000);
-                const int org = ((y0q - 1) * W + x0q - 1) * 256 + q_half * 128;
-                const bool interior = y0q > 0 && y0q + CS_IH - 1 <= H && x0q > 0 && x0q + CS_IW - 1 <= W;
-                CS_REQUEST_ALL(rs, org, interior, y0q, x0q);
+            // unit A asks for the other half of ITS tile, unit B for the first half of the next tile
+            const int q_item = PAR == 0 ? c_item : n_item, y0q = PAR == 0 ? c_y0 : n_y0, x0q = PAR == 0 ? c_x0 : n_x0;
+            const int q_half = half_a ^ 1;                          // (boustrophedon: unit B's half is also the next tile's first half)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.in) + (size_t)q_item * H * W * 64, 0, item_bytes, 0x00020000);
+            const int org = ((y0q - 1) * W + x0q - 1) * 256 + q_half * 128;
+            const bool interior = y0q > 0 && y0q + CS_IH - 1 <= H && x0q > 0 && x0q + CS_IW - 1 <= W;
+#if !defined(CS_X_NOLOAD) && !defined(CS_SPREAD_REQ)
+            CS_REQUEST_ALL(rs, org, interior, y0q, x0q);
 #endif
-            }
             piece_setup(PAR);                                       // epilogue pass PAR of the previous tile (nothing pending: out of range)
 
             [[maybe_unused]] f32x16 bias16;                         // register r of a lane = channel ech + r
@@ -494,6 +492,13 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                         }
                     }
                 }
+#if defined(CS_SPREAD_REQ) && !defined(CS_X_NOLOAD)   /* experiment: one halo request per sub-step instead of six at the unit's start */
+                if constexpr (S < CS_ITERS) {
+                    const int gy_ = y0q + ((lpk[S] >> 16) & 0xff) - 1, gx_ = x0q + ((unsigned)lpk[S] >> 24) - 1;
+                    const bool in_ = interior || ((unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W);
+                    stg[S] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, in_ ? org + grel[S] : 0x7fffffff, 0, CS_HALO_AUX));
+                }
+#endif
                 if constexpr (S == 7) {
                     piece_finish(0);
                     fuse_request(2);
