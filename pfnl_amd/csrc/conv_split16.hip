@@ -43,6 +43,9 @@
 #ifndef CS_RESID_AUX
 #define CS_RESID_AUX 0      // ... of the residual loads
 #endif
+#ifndef CS_LATE_FINISH
+#define CS_LATE_FINISH 1    // per-frame variant: store pieces 2, 3 finished 4-5 sub-steps after their addend / residual requests
+#endif
 #ifndef CS_HALO_AUX
 #define CS_HALO_AUX 0       // ... of the halo loads
 #endif
@@ -280,15 +283,16 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
     };
     // A store piece is taken in two steps one sub-step apart - the scratch read, then arithmetic + store - so that the LDS
     // round trip passes under that sub-step's MFMAs instead of stalling the (in-order) wave.
-    f32x4 pv;
-    auto piece_read = [&](const unsigned char* scratch, int k) __attribute__((always_inline)) {
+    f32x4 pv, pvb;                                                  // (pvb: piece 3 of the per-frame variant, see CS_LATE_FINISH)
+    auto piece_read_to = [&](f32x4& dst, const unsigned char* scratch, int k) __attribute__((always_inline)) {
         const int id = k * CS_THREADS + tid;
         const int pp = id >> 4, c = id & 15;
-        pv = *reinterpret_cast<const f32x4*>(scratch + pp * 256 + (((c & 8) | ((c ^ pp) & 7)) << 4));
+        dst = *reinterpret_cast<const f32x4*>(scratch + pp * 256 + (((c & 8) | ((c ^ pp) & 7)) << 4));
     };
-    auto piece_finish = [&](int k) __attribute__((always_inline)) {
+    auto piece_read = [&](const unsigned char* scratch, int k) __attribute__((always_inline)) { piece_read_to(pv, scratch, k); };
+    auto piece_finish_from = [&](const f32x4& src, int k) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)eitemp * H * W * 64, 0, item_bytes, 0x00020000);
-        f32x4 v = pv;
+        f32x4 v = src;
         if constexpr (FUSE) v += radd[k & 1];
         if constexpr (ACCUM) v += bias4;
 #ifdef CS_X_PKSLOPE
@@ -312,6 +316,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
 #endif
         buffer_store_b128_guarded<CS_STORE_AUX>(__builtin_bit_cast(u32x4, v), rsO, soff0, k * wbytes2);   // (common.h: store-data hazard)
     };
+    auto piece_finish = [&](int k) __attribute__((always_inline)) { piece_finish_from(pv, k); };
     auto store_piece = [&](const unsigned char* scratch, int k) __attribute__((always_inline)) {
         piece_read(scratch, k);
         piece_finish(k);
@@ -455,8 +460,12 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                         piece_read(other, 0);
                     }
                     if constexpr (g == 3) {
-                        piece_finish(2);
-                        piece_read(other, 3);
+                        if constexpr (CS_LATE_FINISH && FUSE) {
+                            piece_read_to(pvb, other, 3);          // (scratch reads stay in front of b1; the arithmetic + store need not)
+                        } else {
+                            piece_finish(2);
+                            piece_read(other, 3);
+                        }
                         if constexpr (ACCUM) {
                             w_write(0);
                             w_request(w_next, 1);
@@ -509,7 +518,16 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                     fuse_request(3);
                     piece_read(other, 2);
                 }
-                if constexpr (S == 10) piece_finish(3);
+                // The addend / residual lines of pieces 2, 3 can only be requested once pieces 0, 1 have left their two register
+                // slots (sub-steps 7, 8).  Finished two sub-steps later (the plain order) a CU would have to receive 32 KB in ~1.3 k
+                // cycles - twice what the fabric gives it; the per-frame variant therefore finishes them in sub-steps 11 and 13
+                // (piece 3 after b1: it only needs its registers).
+                if constexpr (CS_LATE_FINISH && FUSE) {
+                    if constexpr (S == 11) piece_finish(2);
+                    if constexpr (S == 13) piece_finish_from(pvb, 3);
+                } else {
+                    if constexpr (S == 10) piece_finish(3);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 // --- operands of the next sub-step
 #ifdef CS_X_NOREAD   /* timing experiments only */
