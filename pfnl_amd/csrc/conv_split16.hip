@@ -290,7 +290,10 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
         dst = *reinterpret_cast<const f32x4*>(scratch + pp * 256 + (((c & 8) | ((c ^ pp) & 7)) << 4));
     };
     auto piece_read = [&](const unsigned char* scratch, int k) __attribute__((always_inline)) { piece_read_to(pv, scratch, k); };
-    auto piece_finish_from = [&](const f32x4& src, int k) __attribute__((always_inline)) {
+    // `next` >= 0: the addend / residual lines of piece `next` (same register slot as piece k) are requested between the arithmetic
+    // of piece k and its store.  vmcnt is in order and counts stores: requested AFTER the store, the wait for those lines would also
+    // be a wait for the store to reach memory.
+    auto piece_finish_from = [&](const f32x4& src, int k, int next) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)eitemp * H * W * 64, 0, item_bytes, 0x00020000);
         f32x4 v = src;
         if constexpr (FUSE) v += radd[k & 1];
@@ -311,12 +314,20 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
         }
 #endif
         if constexpr (FUSE) v += rres[k & 1];
+#ifndef CS_REQ_AFTER_STORE
+        if (next >= 0) fuse_request(next);
+#endif
 #ifdef CS_X_NOSTORE   /* timing experiments only */
         if (v.x == 1.2345e30f)
 #endif
         buffer_store_b128_guarded<CS_STORE_AUX>(__builtin_bit_cast(u32x4, v), rsO, soff0, k * wbytes2);   // (common.h: store-data hazard)
     };
-    auto piece_finish = [&](int k) __attribute__((always_inline)) { piece_finish_from(pv, k); };
+    auto piece_finish = [&](int k, int next = -1) __attribute__((always_inline)) {
+        piece_finish_from(pv, k, next);
+#ifdef CS_REQ_AFTER_STORE   /* the order before this was measured */
+        if (next >= 0) fuse_request(next);
+#endif
+    };
     auto store_piece = [&](const unsigned char* scratch, int k) __attribute__((always_inline)) {
         piece_read(scratch, k);
         piece_finish(k);
@@ -509,13 +520,11 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                 }
 #endif
                 if constexpr (S == 7) {
-                    piece_finish(0);
-                    fuse_request(2);
+                    piece_finish(0, 2);
                     piece_read(other, 1);
                 }
                 if constexpr (S == 8) {
-                    piece_finish(1);
-                    fuse_request(3);
+                    piece_finish(1, 3);
                     piece_read(other, 2);
                 }
                 // The addend / residual lines of pieces 2, 3 can only be requested once pieces 0, 1 have left their two register
@@ -524,7 +533,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                 // (piece 3 after b1: it only needs its registers).
                 if constexpr (CS_LATE_FINISH && FUSE) {
                     if constexpr (S == 11) piece_finish(2);
-                    if constexpr (S == 13) piece_finish_from(pvb, 3);
+                    if constexpr (S == 13) piece_finish_from(pvb, 3, -1);
                 } else {
                     if constexpr (S == 10) piece_finish(3);
                 }
