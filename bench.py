@@ -40,7 +40,6 @@ CONV3X3_KERNELS = {
                  ["conv_wino_ws.hip", "wino_geom.h"]),
     "winograd_tile": ("conv_wino_kernel<*> (fused Winograd F(2x2,3x3) 64->64, f32 MFMA, one workgroup per tile)",
                       ["conv_wino.hip", "wino_geom.h"]),
-    "winograd16": ("conv_wino16_kernel<*> (fused Winograd F(2x2,3x3), one wave per SIMD)", ["conv_wino16.hip", "wino_geom.h"]),
     "direct": ("conv_mfma_kernel<3,16,*> (3x3 64->64 f32 MFMA implicit GEMM)", ["conv_mfma.hip"]),
     "split16": ("conv3x3_split16_kernel<*> (direct 3x3 64->64 on f16 MFMA with exactly split fp32 operands: 3 MFMAs per product block, fp32 accumulation)",
                 ["conv_split16.hip"]),
@@ -212,7 +211,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads and the sustained run")
-    ap.add_argument("--conv3x3", choices=["auto", "split16", "winograd", "winograd_tile", "winograd16", "direct"], default=None,
+    ap.add_argument("--conv3x3", choices=["auto", "split16", "winograd", "winograd_tile", "direct"], default=None,
                     help="override the 3x3 conv algorithm (default auto: split16 for launches of >= 256 tiles, winograd below)")
     ap.add_argument("--conv1x1", choices=["split16", "stream", "tiled"], default=None, help="override the conv10_i algorithm")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
@@ -242,7 +241,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, args.gpus))
+        if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+            raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (args.gpus, world))
+        # not under a launcher: spawn one rank per GPU ourselves (the command the driver uses) and relay rank 0's line
+        import socket
+        import subprocess
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     ndev = torch.cuda.device_count()

@@ -83,7 +83,6 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *   "winograd"      fused Winograd F(2x2,3x3) on f32 MFMA (2.25x fewer multiplies), persistent
  *                   wave-specialised kernel: matrix waves + helper waves (conv_wino_ws.hip);
  *   "winograd_tile" same maths, one 4-wave workgroup per tile (conv_wino.hip);
- *   "winograd16"    same maths, one wave per SIMD owning all 16 positions (experimental, slower);
  *   "direct"        implicit-GEMM f32 MFMA (conv_mfma.hip);
  *   "split16"       direct 3x3 on the f16 matrix pipe with exactly split fp32 operands (3 f16 MFMAs per product block,
  *                   fp32 accumulation, >= 22 mantissa bits per product: conv_split16.hip).
@@ -243,13 +242,10 @@ int pfnl_op_conv1x1_bf16(const uint16_t* in, const float* kernel_host, const flo
 int pfnl_op_conv3x3_winograd(const float* in, const float* kernel_host, const float* bias_host,
                              const float* addend, int add_div, const float* resid, float* out,
                              int items, int H, int W, int act, void* stream);
-/* Same contract, one-wave-per-SIMD variant (all 16 Winograd positions in one wave's 512 registers). */
+/* Same contract, the persistent wave-specialised kernel (conv_wino_ws.hip). */
 int pfnl_op_conv3x3_winograd_ws(const float* in, const float* kernel_host, const float* bias_host,
                                 const float* addend, int add_div, const float* resid, float* out, int items, int H,
                                 int W, int act, void* stream);
-int pfnl_op_conv3x3_winograd16(const float* in, const float* kernel_host, const float* bias_host,
-                               const float* addend, int add_div, const float* resid, float* out,
-                               int items, int H, int W, int act, void* stream);
 /* utils.NonLocalBlock(nltype=1) + the residual of model/pfnl.py:55-60:
  * x [B,T,H,W,3] -> out [B,H,W,3T] = stack(x) + depth_to_space(NL(space_to_depth(stack(x)))). */
 int pfnl_op_nonlocal(const float* x, const float* wg_host, const float* bg_host,

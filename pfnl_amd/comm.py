@@ -27,6 +27,23 @@ class Comm:
         self._h = h
         self.rank, self.nranks, self.device = rank, nranks, device
 
+    @classmethod
+    def init_all(cls, devices) -> "list[Comm]":
+        """One process driving several devices (pfnl_comm_init_all = ncclCommInitAll): communicator i is rank i on devices[i]."""
+        lib = _capi.load_library()
+        devs = [int(d) for d in devices]
+        n = len(devs)
+        arr = (C.c_int * n)(*devs)
+        hs = (C.c_void_p * n)()
+        _capi.check(lib.pfnl_comm_init_all(n, arr, hs))
+        out = []
+        for i in range(n):
+            c = cls.__new__(cls)
+            c._lib, c._h = lib, C.c_void_p(hs[i])
+            c.rank, c.nranks, c.device = i, n, devs[i]
+            out.append(c)
+        return out
+
     @staticmethod
     def unique_id() -> bytes:
         buf = C.create_string_buffer(_capi.COMM_ID_BYTES)

@@ -93,7 +93,7 @@ struct pfnl_handle {
     size_t off16_m1 = 0;                                      // convmerge1: T consecutive packs (cout 48 zero-padded to 64)
     size_t off16s_m1 = 0;                                     // convmerge1, split-f16 packs: T consecutive (frame, both halves) packs
     int m1_algo = 0;                                          // convmerge1 with conv3x3=split16: 0 auto (= 1), 1 the split-f16 kernel's accumulating mode, 2 Winograd
-    int conv_algo = 5;                                        // conv3x3: 5 auto (4 for large shapes, 3 for small), 0 direct, 1 winograd (4 waves / tile), 2 winograd16 (1 wave / SIMD), 3 winograd_ws (persistent, wave-specialised), 4 split16 (f16 MFMA, split fp32 operands)
+    int conv_algo = 5;                                        // conv3x3: 5 auto (4 for large shapes, 3 for small), 0 direct, 1 winograd (4 waves / tile), 3 winograd_ws (persistent, wave-specialised), 4 split16 (f16 MFMA, split fp32 operands)
     int bf16_nl = 1;                                          // non-local block of precision=bf16: 0 split-bf16 operands (nonlocal_bf16.hip), 1 f16 operands (nonlocal_f16.hip, hi parts; default)
     int nl_algo = 2;                                          // non-local block of the fp32 path: 0 f32 MFMA (nonlocal.hip), 1 split-f16 (nonlocal_f16.hip), 2 auto (1 from N = 1024 keys)
     DevBuf wdev16s;                                           // split-f16 packs of the 3x3 kernels (offsets in 16-bit elements)
@@ -104,7 +104,6 @@ struct pfnl_handle {
     size_t off_conv0_w = 0, off_conv0_b = 0;
     std::vector<size_t> off_c1_w, off_c1_b, off_c10_w, off_c10_b, off_c10_s, off_c2a_w, off_c2b_w, off_c2_b;
     std::vector<size_t> off_c1_u, off_c2a_u, off_c2b_u;       // Winograd-packed variants
-    std::vector<size_t> off_c1_u16, off_c2a_u16, off_c2b_u16; // ... for conv_wino16_kernel
     std::vector<size_t> off_m1_u;                             // convmerge1 per frame, Winograd pack (cout 48 padded to 64)
     size_t off_m1_w = 0, off_m1_b = 0, off_m2_w = 0, off_m2_b = 0, off_nl_w = 0, off_nl_b = 0, off_zero = 0;
 
@@ -344,9 +343,6 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             if (algo == 4) {
                 ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_c1[i], p.bias, nullptr, nullptr, p.out, H, W, F, 1, 1};
                 HIPCHK(launch_conv3x3_split16(q, s));
-            } else if (algo == 2) {
-                WinoParams wp{p.in, wd + h->off_c1_u16[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 1, F, nullptr};
-                HIPCHK(launch_conv_wino16(wp, s));
             } else if (algo == 1 || algo == 3) {
                 WinoParams wp{p.in, wd + h->off_c1_u[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 1, F, nullptr};
                 HIPCHK(algo == 3 ? launch_conv_wino_ws(wp, s) : launch_conv_wino(wp, s));
@@ -403,9 +399,6 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             if (algo == 4) {
                 ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_c2a[i], p.bias, nullptr, nullptr, p.out, H, W, B, 1, 0};
                 HIPCHK(launch_conv3x3_split16(q, s));
-            } else if (algo == 2) {
-                WinoParams wp{p.in, wd + h->off_c2a_u16[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 0, B, nullptr};
-                HIPCHK(launch_conv_wino16(wp, s));
             } else if (algo == 1 || algo == 3) {
                 WinoParams wp{p.in, wd + h->off_c2a_u[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 0, B, nullptr};
                 HIPCHK(algo == 3 ? launch_conv_wino_ws(wp, s) : launch_conv_wino(wp, s));
@@ -426,9 +419,6 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             if (algo == 4) {
                 ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_c2b[i], p.bias, p.addend, p.resid, p.out, H, W, F, T, 1};
                 HIPCHK(launch_conv3x3_split16(q, s));
-            } else if (algo == 2) {
-                WinoParams wp{p.in, wd + h->off_c2b_u16[i], p.bias, p.addend, p.resid, p.out, H, W, T, 1, F, nullptr};
-                HIPCHK(launch_conv_wino16(wp, s));
             } else if (algo == 1 || algo == 3) {
                 WinoParams wp{p.in, wd + h->off_c2b_u[i], p.bias, p.addend, p.resid, p.out, H, W, T, 1, F, nullptr};
                 HIPCHK(algo == 3 ? launch_conv_wino_ws(wp, s) : launch_conv_wino(wp, s));
@@ -519,7 +509,7 @@ int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
     h->cfg = *cfg;
     if (const char* e = std::getenv("PFNL_CONV3X3")) {
         const std::string v(e);
-        h->conv_algo = v == "direct" ? 0 : (v == "winograd16" ? 2 : (v == "winograd_tile" ? 1 : (v == "split16" ? 4 : (v == "winograd" ? 3 : 5))));
+        h->conv_algo = v == "direct" ? 0 : (v == "winograd_tile" ? 1 : (v == "split16" ? 4 : (v == "winograd" ? 3 : 5)));
     }
     // A BLOCKING stream: it is implicitly ordered with the legacy null stream (= torch's default stream) in both
     // directions, so host-pointer calls and graph replays on it are ordered with the caller's default-stream work.
@@ -606,11 +596,10 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
     if (k == "conv3x3") {
         if (v == "winograd" || v == "winograd_ws") h->conv_algo = 3;
         else if (v == "winograd_tile") h->conv_algo = 1;
-        else if (v == "winograd16") h->conv_algo = 2;
         else if (v == "direct") h->conv_algo = 0;
         else if (v == "split16") h->conv_algo = 4;
         else if (v == "auto") h->conv_algo = 5;
-        else return fail(PFNL_ERR_INVALID, "conv3x3 must be auto, split16, winograd, winograd_tile, winograd16 or direct");
+        else return fail(PFNL_ERR_INVALID, "conv3x3 must be auto, split16, winograd, winograd_tile or direct");
         return 0;
     }
     if (k == "conv2") {
@@ -690,11 +679,6 @@ int pfnl_finalize_weights(pfnl_handle* h) {
         std::memcpy(&blob[off], b.data(), b.size() * sizeof(float));
         return off;
     };
-    auto put_wino16 = [&](const std::vector<float>& k, int cin_total, int cin_begin) {
-        size_t off = reserve(pfnl::wino_pack_floats());
-        pfnl::wino16_pack_weights(k.data(), cin_total, cin_begin, &blob[off]);
-        return off;
-    };
     auto put_wino = [&](const std::vector<float>& k, int cin_total, int cin_begin) {
         size_t off = reserve(pfnl::wino_pack_floats());
         pfnl::wino_pack_weights(k.data(), cin_total, cin_begin, &blob[off]);
@@ -721,9 +705,6 @@ int pfnl_finalize_weights(pfnl_handle* h) {
     h->off_c1_u.assign(nb, 0);
     h->off_c2a_u.assign(nb, 0);
     h->off_c2b_u.assign(nb, 0);
-    h->off_c1_u16.assign(nb, 0);
-    h->off_c2a_u16.assign(nb, 0);
-    h->off_c2b_u16.assign(nb, 0);
     for (int i = 0; i < nb; ++i) {
         const std::string s = std::to_string(i);
         h->off_c1_w[i] = put_pack(W("conv1_" + s), 3, 64, 0, 64, 64);
@@ -739,9 +720,6 @@ int pfnl_finalize_weights(pfnl_handle* h) {
         h->off_c1_u[i] = put_wino(W("conv1_" + s), 64, 0);
         h->off_c2a_u[i] = put_wino(W("conv2_" + s), 128, 0);
         h->off_c2b_u[i] = put_wino(W("conv2_" + s), 128, 64);
-        h->off_c1_u16[i] = put_wino16(W("conv1_" + s), 64, 0);
-        h->off_c2a_u16[i] = put_wino16(W("conv2_" + s), 128, 0);
-        h->off_c2b_u16[i] = put_wino16(W("conv2_" + s), 128, 64);
     }
     h->off_m1_w = put_pack(W("convmerge1"), 3, 64 * T, 0, 64 * T, 48);
     h->off_m1_b = put_bias(Bv("convmerge1"));
@@ -1489,52 +1467,6 @@ int pfnl_op_conv3x3_winograd_ws(const float* in, const float* kernel_host, const
     return op_conv3x3_wino(true, in, kernel_host, bias_host, addend, add_div, resid, out, items, H, W, act, stream);
 }
 
-int pfnl_op_conv3x3_winograd16(const float* in, const float* kernel_host, const float* bias_host,
-                             const float* addend, int add_div, const float* resid, float* out, int items, int H,
-                             int W, int act, void* stream) {
-    if (!in || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
-    if (items < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return fail(PFNL_ERR_INVALID, "winograd conv needs even H, W");
-    if ((addend != nullptr) != (resid != nullptr))
-        return fail(PFNL_ERR_INVALID, "addend and resid must be given together or not at all");
-    if (addend && add_div < 1) return fail(PFNL_ERR_INVALID, "add_div must be >= 1");
-    hipStream_t s = (hipStream_t)stream;
-    std::vector<float> pack(pfnl::wino_pack_floats() + 64, 0.f);
-    pfnl::wino16_pack_weights(kernel_host, 64, 0, pack.data());
-    const size_t boff = pack.size() - 64;
-    if (bias_host) std::memcpy(&pack[boff], bias_host, 64 * sizeof(float));
-    float* dw = nullptr;
-    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(float)));
-    hipError_t e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        pfnl::WinoParams wp{in, dw, dw + boff, addend, resid, out, H, W, addend ? add_div : 1, act, items, nullptr};
-#if 0
-        long long* dbg = nullptr;
-        const size_t dbg_n = 4096 * 64;
-        if (hipMalloc(&dbg, dbg_n * sizeof(long long)) == hipSuccess) {
-            (void)hipMemset(dbg, 0, dbg_n * sizeof(long long));
-            wp.dbg = dbg;
-        }
-#endif
-        e = pfnl::launch_conv_wino16(wp, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-#if 0
-        if (dbg) {
-            std::vector<long long> hst(dbg_n);
-            (void)hipMemcpy(hst.data(), dbg, dbg_n * sizeof(long long), hipMemcpyDeviceToHost);
-            for (int b : {0, 8, 16, 1024, 2048, 4096, 7000}) {
-                std::fprintf(stderr, "WINO_TIMING wg %d:", b);
-                for (int i = 1; i < 16 && hst[(size_t)b * 16 + i]; ++i)
-                    std::fprintf(stderr, " %lld", hst[(size_t)b * 16 + i] - hst[(size_t)b * 16]);
-                std::fprintf(stderr, " | t0-t0[wg0] %lld\n", hst[(size_t)b * 16] - hst[0]);
-            }
-            (void)hipFree(dbg);
-        }
-#endif
-    }
-    (void)hipFree(dw);
-    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("winograd16 conv op: ") + hipGetErrorString(e));
-    return 0;
-}
 
 static int op_nonlocal(int bf16 /* 0 f32, 1 bf16 split, 2 f16 split, 3 f16 (hi parts only) */, const float* x, const float* wg, const float* bg, const float* ww, const float* bw,
                        float* out, int B, int T, int H, int W, void* stream) {

@@ -13,6 +13,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -37,11 +38,14 @@ struct Rccl {
     std::string err;
 };
 
+static void rccl_resolve(Rccl& r);
 Rccl* rccl() {
     static Rccl r;
-    static bool tried = false;
-    if (tried) return &r;
-    tried = true;
+    static std::once_flag once;                                     // (callers may be threads of one process, one per device)
+    std::call_once(once, [] { rccl_resolve(r); });
+    return &r;
+}
+static void rccl_resolve(Rccl& r) {
     std::vector<std::string> names;
     if (const char* e = std::getenv("PFNL_RCCL_LIB")) names.push_back(e);
     for (const char* n : {"librccl.so", "librccl.so.1"}) {          // one that is already in the process (torch's)
@@ -50,8 +54,9 @@ Rccl* rccl() {
     for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) names.push_back(n);
     for (size_t i = 0; !r.lib && i < names.size(); ++i) r.lib = dlopen(names[i].c_str(), RTLD_NOW | RTLD_GLOBAL);
     if (!r.lib) {
-        r.err = std::string("RCCL not found (set PFNL_RCCL_LIB): ") + (dlerror() ? dlerror() : "?");
-        return &r;
+        const char* m = dlerror();                                  // (one call: dlerror() clears the message it returns)
+        r.err = std::string("RCCL not found (set PFNL_RCCL_LIB): ") + (m ? m : "?");
+        return;
     }
 #define PFNL_SYM(field, name)                                                       \
     r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name));               \
@@ -65,7 +70,6 @@ Rccl* rccl() {
     PFNL_SYM(AllGather, "ncclAllGather")
     PFNL_SYM(GetErrorString, "ncclGetErrorString")
 #undef PFNL_SYM
-    return &r;
 }
 
 }  // namespace

@@ -102,8 +102,6 @@ struct WinoParams {
 };
 hipError_t launch_conv_wino(const WinoParams& p, hipStream_t s);
 hipError_t launch_conv_wino_ws(const WinoParams& p, hipStream_t s);  // persistent wave-specialised variant (conv_wino_ws.hip), same packed U
-hipError_t launch_conv_wino16(const WinoParams& p, hipStream_t s);   // one-wave-per-SIMD variant (conv_wino16.hip)
-void wino16_pack_weights(const float* hwio, int cin_total, int cin_begin, float* dst);
 size_t wino_pack_floats();
 void wino_pack_weights(const float* hwio, int cin_total, int cin_begin, float* dst, int cout = 64);
 

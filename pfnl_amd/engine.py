@@ -61,7 +61,7 @@ class PFNLEngine:
         self._ready = True
 
     def set_option(self, key: str, value: str) -> None:
-        """e.g. ("conv3x3", "winograd" | "winograd_tile" | "winograd16" | "direct"); see include/pfnl_hip.h."""
+        """e.g. ("conv3x3", "auto" | "split16" | "winograd" | "winograd_tile" | "direct"); see include/pfnl_hip.h."""
         _capi.check(self._lib.pfnl_set_option(self._h, key.encode(), value.encode()))
 
     def missing_weights(self) -> int:

@@ -201,7 +201,7 @@ def conv3x3_winograd(x, kernel, bias=None, act=True, addend=None, add_div=1, res
     F, H, W, c = x.shape
     out = torch.empty((F, H, W, 64), dtype=torch.float32, device=x.device)
     fn = {"winograd": lib.pfnl_op_conv3x3_winograd, "winograd_ws": lib.pfnl_op_conv3x3_winograd_ws,
-          "winograd16": lib.pfnl_op_conv3x3_winograd16, "split16": lib.pfnl_op_conv3x3_split16}[variant]
+          "split16": lib.pfnl_op_conv3x3_split16}[variant]
     _capi.check(fn(
         _req(x, "x"), k.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p) if b is not None else None,
         _req(addend, "addend") if addend is not None else None, int(add_div),

@@ -92,6 +92,75 @@ def test_bench_two_ranks_on_one_gpu():
     assert rec["value"] > 0 and rec["steps"] == 2 and "cpu_baseline" not in rec
 
 
+def test_bench_self_spawn():
+    """`python bench.py --gpus 2` with no launcher around it spawns its own ranks (torch.distributed.run) and still prints
+    exactly one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+           "--no-secondary", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8 and rec["value"] > 0
+
+
+def _cfg2_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from pfnl_amd.engine import PFNLEngine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = PFNLGeometry()                                             # the full 20-block model
+        w = pd.broadcast_weights(g, synth.synthetic_weights(g, seed=0) if rank == 0 else None, src=0)
+        eng = PFNLEngine(g, device=0)
+        eng.load_weights(w)
+        clips = synth.uniform_clips(32, 7, 128, 128, seed=32)          # every rank holds the batch; its shard is 4 clips
+        lo, hi = pd.shard_range(32, rank, world)
+        out = pd.sharded_forward(eng.forward, clips, gather_to=0)
+        q.put((rank, (lo, hi), None if out is None else out))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_configs2_eight_ranks_batch32():
+    """BASELINE.json configs[2], functionally: B = 32 clips of 7x128x128 sharded over 8 ranks (4 clips each; all eight on the
+    one visible GPU, gloo transport - the sharding, weight replica and gather are the code an 8-GPU node runs).  The gathered
+    result is bit-equal to the unsharded forward of the same engine, and a sample of it is checked against the oracle."""
+    import torch.multiprocessing as mp
+    from oracle import pfnl_fast
+    from pfnl_amd.engine import PFNLEngine
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cfg2_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [(4 * i, 4 * i + 4) for i in range(8)]
+    got = res[0][2]
+    assert got is not None and got.shape == (32, 1, 512, 512, 3) and all(r[2] is None for r in res[1:])
+    g = PFNLGeometry()
+    w = synth.synthetic_weights(g, seed=0)
+    eng = PFNLEngine(g, device=0)
+    eng.load_weights(w)
+    clips = synth.uniform_clips(32, 7, 128, 128, seed=32)
+    for b0 in range(0, 32, 4):                                         # unsharded, in the batches the bench uses
+        assert np.array_equal(eng.forward(clips[b0:b0 + 4]), got[b0:b0 + 4])
+    eng.close()
+    for b in (0, 13, 31):                                              # checker only: three clips, one per "GPU" sampled
+        ref = pfnl_fast.FastOracle(w, num_block=20).forward(clips[b:b + 1])
+        err = float(np.abs(got[b:b + 1] - ref).max())
+        print(f"configs[2] clip {b}: max|hip - oracle| = {err:.3g}")
+        assert err < 5e-5, err
+
+
 def test_bench_rccl_path_with_one_rank():
     """`bench.py`'s N>1 branch on the `nccl` backend - torch.distributed as launcher, the library's own RCCL communicator for the
     weight broadcast and the max-over-ranks time - run with ONE rank (RCCL refuses two ranks on one device; the 8-GPU run is the
@@ -159,6 +228,14 @@ def test_comm_single_rank_rccl():
     with pytest.raises(Exception):
         c.allreduce(np.zeros(65), "sum")                                # n <= 64
     c.close()
+    # pfnl_comm_init_all: one process driving a list of devices (here: the one device there is) - ncclCommInitAll
+    cs = Comm.init_all([0])
+    assert len(cs) == 1 and (cs[0].rank, cs[0].nranks, cs[0].device) == (0, 1, 0)
+    cs[0].bcast_weights(eng, root=0)
+    assert np.array_equal(eng.forward(x), y0)
+    assert np.array_equal(cs[0].allreduce([2.0, 5.0], "max"), [2.0, 5.0])
+    cs[0].barrier()
+    cs[0].close()
     eng.close()
 
 
@@ -212,15 +289,19 @@ def test_comm_two_ranks_rccl():
                                                     (3, 1, 96, 64, 4, "bf16"), (1, 1, 12, 20, 6, "fp32")])
 def test_forward_strips_tile_the_frame(nb, B, H, W, strips, prec):
     """pfnl_forward_strip: the union of the strips (each computed on its own, as a rank would: non-local queries of the strip
-    against all keys, trunk on strip + recomputed halo) equals the full forward up to summation order; rows outside a strip
-    are left untouched."""
+    against all keys, trunk on strip + recomputed halo) equals the ORACLE's forward of the whole frame (the build's own full
+    forward is only the secondary check: equal up to summation order); rows outside a strip are left untouched."""
+    from oracle import pfnl_fast
     from pfnl_amd.engine import PFNLEngine
     geom = PFNLGeometry(num_block=nb)
     eng = PFNLEngine(geom, device=0)
-    eng.load_weights(synth.synthetic_weights(geom, seed=0))
+    w = synth.synthetic_weights(geom, seed=0)
+    eng.load_weights(w)
     if prec == "bf16":
         eng.set_option("precision", "bf16")
-    x = torch.from_numpy(synth.uniform_clips(B, 7, H, W, seed=nb + H)).cuda()
+    xh = synth.uniform_clips(B, 7, H, W, seed=nb + H)
+    x = torch.from_numpy(xh).cuda()
+    ref = pfnl_fast.FastOracle(w, num_block=nb, trunk_dtype="bf16" if prec == "bf16" else "fp32").forward(xh)   # checker only
     full = eng.forward(x)
     out = torch.full_like(full, -7.0)
     bounds = [2 * pd.shard_range(H // 2, r, strips)[0] for r in range(strips)] + [H]
@@ -234,9 +315,16 @@ def test_forward_strips_tile_the_frame(nb, B, H, W, strips, prec):
         untouched = torch.ones(4 * H, dtype=torch.bool)
         untouched[4 * lo:4 * hi] = False
         assert torch.equal(out[:, :, untouched], before[:, :, untouched])          # only its own rows
+    got = out.cpu().numpy()
+    oerr = float(np.abs(got - ref).max())
+    opsnr = synth.psnr(got, ref)
     err = (out - full).abs().max().item()
     tol = 2e-6 if prec == "fp32" else 2e-2                                         # bf16 trunk: tile alignment moves rounding points
-    print(f"strips nb{nb} {B}x7x{H}x{W} / {strips} ({prec}): max|strips - full| = {err:.3g}")
+    print(f"strips nb{nb} {B}x7x{H}x{W} / {strips} ({prec}): max|strips - oracle| = {oerr:.3g} (PSNR {opsnr:.1f} dB), max|strips - full| = {err:.3g}")
+    if prec == "fp32":
+        assert oerr < 5e-5, oerr                                                   # the bound of tests/test_gpu_forward.py (ABS_TOL)
+    else:
+        assert opsnr > 60.0, opsnr                                                 # equally-rounded oracle; bf16 rounding points move with tile alignment
     assert err < tol, err
     with pytest.raises(Exception):
         eng.forward_strip(x, out, H - 2, 4)
@@ -276,10 +364,10 @@ def test_two_ranks_share_one_frame():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    g = PFNLGeometry(num_block=2)
-    eng = PFNLEngine(g, device=0)
-    eng.load_weights(synth.synthetic_weights(g, seed=3))
-    ref = eng.forward(synth.uniform_clips(1, 7, 36, 48, seed=9))
+    from oracle import pfnl_fast
+    ref = pfnl_fast.FastOracle(synth.synthetic_weights(PFNLGeometry(num_block=2), seed=3), num_block=2).forward(
+        synth.uniform_clips(1, 7, 36, 48, seed=9))                                   # checker only
     assert res[1][1] is None and res[0][1].shape == ref.shape
-    assert np.abs(res[0][1] - ref).max() < 2e-6
-    eng.close()
+    err = float(np.abs(res[0][1] - ref).max())
+    print(f"two ranks, one frame: max|gathered strips - oracle| = {err:.3g}")
+    assert err < 5e-5, err

@@ -158,7 +158,7 @@ def test_conv1x1_stream(items, fpi, H, W, act, variant):
     (1, 2, 2, True, False),         # a single 2x2 tile: everything is halo
     (4, 64, 64, True, True),
 ])
-@pytest.mark.parametrize("variant", ["winograd", "winograd_ws", "winograd16"])
+@pytest.mark.parametrize("variant", ["winograd", "winograd_ws"])
 def test_conv3x3_winograd(items, H, W, act, fused, variant):
     rng = np.random.default_rng(items * 1000 + H * 10 + W)
     x = rng.normal(size=(items, H, W, 64)).astype(np.float32)
