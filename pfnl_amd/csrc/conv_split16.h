@@ -15,7 +15,14 @@ struct ConvSplitParams {
     float* out;              // [items][H][W][64] f32 (may alias resid)
     int H, W, items, add_div, act;
     int accum;               // 1: out[items/add_div] = act(sum over the add_div frames of an item group + bias); wpack = add_div packs (convmerge1)
+    int out_sf;              // 1 (plain mode only): `out` is written in the split format below instead of fp32
 };
+
+// THE SPLIT FORMAT ("SF") of an activation tensor that only ever feeds MFMA operands (conv1_i's output, conv10_i's output):
+// [items][H][W] pixels of 256 B = [channel half M = 0, 1][part: hi, lo'][32 channels] binary16, where for a value x
+// hi = f16(x), lo' = f16((x - hi) 2^11) - exactly the two operands conv_split16.hip builds from an fp32 tensor when it commits a
+// halo tile, built once by the producer instead.  Same bytes per value as fp32.  16-byte chunk c of a (pixel, half) = channels
+// 32 M + 8 (c & 3) .. + 7 of part c >> 2: the unit the 3x3 kernels' LDS tiles and the 1x1 kernel's operands are made of.
 hipError_t launch_conv3x3_split16(const ConvSplitParams& p, hipStream_t s);
 size_t conv3x3_split16_pack_halfs();                                  // 16-bit elements per packed 3x3 64->64 kernel
 void conv3x3_split16_pack_weights(const float* hwio, int cin_total, int cin_begin, uint16_t* dst, int cout = 64);   // cout < 64: zero-padded

@@ -109,9 +109,13 @@ __device__ __forceinline__ void split4(f32x4 v, u32x2& hi, u32x2& lo, float nsca
 // MODE 2 (ACCUM; convmerge1, reference model/pfnl.py:52,73-74): out[clip] = act(sum over the add_div frames f of a clip of
 // conv(in[clip * add_div + f]; weights f) + bias) - the accumulators run through the chain of a clip's frames at one spatial tile,
 // every unit brings its own weights (pack index 2 f + half), one epilogue per chain.
-template <int MODE>
+// OSF (MODE 0 only; conv1_i): the output is written in the SPLIT FORMAT the consumers' MFMA operands are made of (conv_split16.h:
+// per pixel 256 B = [channel half][hi 32 x f16 | lo' 32 x f16]) - the split costs 2 VALU per value once, in the producer, instead
+// of once per consumer and halo pixel, and the consumers can bring their halos in by LDS-DMA (conv_sf.hip).
+template <int MODE, bool OSF = false>
 __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSplitParams p) {
     constexpr bool FUSE = MODE == 1, ACCUM = MODE == 2;
+    static_assert(!OSF || MODE == 0, "split-format output: plain mode only");
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_smem[];
     unsigned char* const wl = cs_smem + 2 * CS_TILE_BYTES;
     float* const bl = reinterpret_cast<float*>(cs_smem + 2 * CS_TILE_BYTES + CS_W_BYTES);
@@ -259,9 +263,16 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
     // pending" are folded into the offset (0x7fffffff + k * wbytes2 stays out of range).
     int soff0 = 0x7fffffff;
     const int wbytes2 = 2 * W * 256;
+    // OSF: a thread owns 8-channel groups instead of 4-channel pieces: store pieces (2j, 2j+1) are the two halves of group
+    // cg = tid & 7 of pixel (row pair 2j + (tid >> 8), column (tid >> 3) & 31); the group leaves as one hi chunk + one lo' chunk
     auto piece_setup = [&](int n) __attribute__((always_inline)) {
-        const int sx = ex0p + (tid >> 4);
-        soff0 = (pending && sx < W) ? ((ey0p + n) * W + sx) * 256 + (tid & 15) * 16 : 0x7fffffff;
+        if constexpr (OSF) {
+            const int sx = ex0p + ((tid >> 3) & 31);
+            soff0 = (pending && sx < W) ? ((ey0p + n + 2 * (tid >> 8)) * W + sx) * 256 + ((tid >> 2) & 1) * 128 + (tid & 3) * 16 : 0x7fffffff;
+        } else {
+            const int sx = ex0p + (tid >> 4);
+            soff0 = (pending && sx < W) ? ((ey0p + n) * W + sx) * 256 + (tid & 15) * 16 : 0x7fffffff;
+        }
     };
     auto fuse_request = [&](int k) __attribute__((always_inline)) {
         if constexpr (FUSE) {
@@ -284,9 +295,17 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
     // A store piece is taken in two steps one sub-step apart - the scratch read, then arithmetic + store - so that the LDS
     // round trip passes under that sub-step's MFMAs instead of stalling the (in-order) wave.
     f32x4 pv, pvb;                                                  // (pvb: piece 3 of the per-frame variant, see CS_LATE_FINISH)
+    [[maybe_unused]] f32x4 osf_hold = {0.f, 0.f, 0.f, 0.f};
     auto piece_read_to = [&](f32x4& dst, const unsigned char* scratch, int k) __attribute__((always_inline)) {
-        const int id = k * CS_THREADS + tid;
-        const int pp = id >> 4, c = id & 15;
+        int pp, c;
+        if constexpr (OSF) {
+            pp = ((k >> 1) * CS_THREADS + tid) >> 3;
+            c = 2 * (tid & 7) + (k & 1);
+        } else {
+            const int id = k * CS_THREADS + tid;
+            pp = id >> 4;
+            c = id & 15;
+        }
         dst = *reinterpret_cast<const f32x4*>(scratch + pp * 256 + (((c & 8) | ((c ^ pp) & 7)) << 4));
     };
     auto piece_read = [&](const unsigned char* scratch, int k) __attribute__((always_inline)) { piece_read_to(pv, scratch, k); };
@@ -317,10 +336,22 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
 #ifndef CS_REQ_AFTER_STORE
         if (next >= 0) fuse_request(next);
 #endif
+        if constexpr (OSF) {
+            if ((k & 1) == 0) {
+                osf_hold = v;                                       // channels 8cg .. 8cg+3: wait for the other half of the group
+            } else {
+                u32x2 h0, l0, h1, l1;
+                split4(osf_hold, h0, l0, nscale);
+                split4(v, h1, l1, nscale);
+                buffer_store_b128_guarded<CS_STORE_AUX>(u32x4{h0.x, h0.y, h1.x, h1.y}, rsO, soff0, (k >> 1) * 2 * wbytes2);
+                buffer_store_b128_guarded<CS_STORE_AUX>(u32x4{l0.x, l0.y, l1.x, l1.y}, rsO, (int)((unsigned)soff0 + 64u), (k >> 1) * 2 * wbytes2);
+            }
+        } else {
 #ifdef CS_X_NOSTORE   /* timing experiments only */
-        if (v.x == 1.2345e30f)
+            if (v.x == 1.2345e30f)
 #endif
-        buffer_store_b128_guarded<CS_STORE_AUX>(__builtin_bit_cast(u32x4, v), rsO, soff0, k * wbytes2);   // (common.h: store-data hazard)
+            buffer_store_b128_guarded<CS_STORE_AUX>(__builtin_bit_cast(u32x4, v), rsO, soff0, k * wbytes2);   // (common.h: store-data hazard)
+        }
     };
     auto piece_finish = [&](int k, int next = -1) __attribute__((always_inline)) {
         piece_finish_from(pv, k, next);
@@ -676,18 +707,21 @@ hipError_t launch_conv3x3_split16(const ConvSplitParams& p, hipStream_t s) {
         ncu = prop.multiProcessorCount;
     }
     const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;                    // whole XCDs; surplus workgroups exit at once
-    static bool attr_dev[64][3] = {};                               // the attribute is per device
+    static bool attr_dev[64][4] = {};                               // the attribute is per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    const int mode = p.accum ? 2 : p.addend ? 1 : 0;
-    const void* fn = mode == 2 ? reinterpret_cast<const void*>(conv3x3_split16_kernel<2>)
+    if (p.out_sf && (p.accum || p.addend)) return hipErrorInvalidValue;
+    const int mode = p.out_sf ? 3 : p.accum ? 2 : p.addend ? 1 : 0;
+    const void* fn = mode == 3 ? reinterpret_cast<const void*>(conv3x3_split16_kernel<0, true>)
+                   : mode == 2 ? reinterpret_cast<const void*>(conv3x3_split16_kernel<2>)
                    : mode     ? reinterpret_cast<const void*>(conv3x3_split16_kernel<1>) : reinterpret_cast<const void*>(conv3x3_split16_kernel<0>);
     if (!attr_dev[dev][mode]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_dev[dev][mode] = true;
     }
-    if (mode == 2) hipLaunchKernelGGL(conv3x3_split16_kernel<2>, dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, p);
+    if (mode == 3) hipLaunchKernelGGL((conv3x3_split16_kernel<0, true>), dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, p);
+    else if (mode == 2) hipLaunchKernelGGL(conv3x3_split16_kernel<2>, dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, p);
     else if (mode) hipLaunchKernelGGL(conv3x3_split16_kernel<1>, dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, p);
     else hipLaunchKernelGGL(conv3x3_split16_kernel<0>, dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, p);
     return hipGetLastError();
