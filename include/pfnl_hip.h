@@ -86,6 +86,8 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *   "direct"        implicit-GEMM f32 MFMA (conv_mfma.hip);
  *   "split16"       direct 3x3 on the f16 matrix pipe with exactly split fp32 operands (3 f16 MFMAs per product block,
  *                   fp32 accumulation, >= 22 mantissa bits per product: conv_split16.hip).
+ * key "split16_sf" = "on" (default) | "off": with conv3x3 and conv1x1 on "split16", conv1_i and conv10_i write the split format
+ *   (hi, lo' binary16 pairs: the MFMA operands themselves) and both halves of conv2_i read it by LDS-DMA (conv_sf.hip).
  * key "conv1x1" = "split16" (default: streaming kernel on the f16 pipe, exactly split fp32 operands) | "stream" (streaming f32-MFMA
  *                 kernel) | "tiled" (conv_mfma.hip).
  * key "nonlocal" (fp32 precision only) = "auto" (default: "split16" from 1024 keys, "f32" below) | "f32" (f32 MFMA, nonlocal.hip) |
@@ -221,6 +223,15 @@ int pfnl_op_conv3x3_bf16(const uint16_t* in, const float* kernel_host, const flo
  * product).  Same contract as pfnl_op_conv3x3_winograd (any H, W); out may alias resid. */
 int pfnl_op_conv3x3_split16(const float* in, const float* kernel_host, const float* bias_host, const float* addend, int add_div,
                             const float* resid, float* out, int items, int H, int W, int act, void* stream);
+/* The split-format variants of the split-f16 kernels (pfnl_amd/csrc/conv_split16.h "SF": an activation tensor that only feeds MFMA
+ * operands - conv1_i's and conv10_i's outputs, model/pfnl.py:66-68 - is kept as (hi, lo') binary16 pairs, built once by its
+ * producer).  fp32 at the hook's interface: conversions bracket the kernel under test.
+ * which = 0: the 3x3 kernel of conv2_i (input SF by LDS-DMA, epilogue from registers; plain, or fused with addend + resid);
+ * which = 1: the 3x3 kernel of conv1_i writing SF. */
+int pfnl_op_conv3x3_split16_sf(int which, const float* in, const float* kernel_host, const float* bias_host, const float* addend,
+                               int add_div, const float* resid, float* out, int items, int H, int W, int act, void* stream);
+int pfnl_op_conv1x1_split16_sf(const float* in, const float* kernel_host, const float* bias_host, float* out, int items,
+                               int frames_per_item, int HW, int act, int in_sf, int out_sf, void* stream);
 /* conv1_i and conv10_i of a progressive-fusion block (reference model/pfnl.py:66-68) in ONE launch of the bf16 3x3 kernel:
  * out1 = lrelu(conv3x3(in) + b1) [clips*fpc, H, W, 64], base = lrelu(conv1x1(concat_t out1_t) + b10) [clips, H, W, 64];
  * the 1x1 contraction reads every finished tile from LDS.  fpc in {3,5,7}. */

@@ -98,6 +98,9 @@ struct pfnl_handle {
     int nl_algo = 2;                                          // non-local block of the fp32 path: 0 f32 MFMA (nonlocal.hip), 1 split-f16 (nonlocal_f16.hip), 2 auto (1 from N = 1024 keys)
     DevBuf wdev16s;                                           // split-f16 packs of the 3x3 kernels (offsets in 16-bit elements)
     std::vector<size_t> off16s_c1, off16s_c2a, off16s_c2b, off16s_c10;
+    std::vector<size_t> off16s_c2a_sf, off16s_c2b_sf;         // ... with the identity row map conv3x3_sf_kernel takes (conv_sf.hip)
+    bool sf_path = true;                                      // option split16_sf=on|off: with conv3x3 = conv1x1 = split16, conv1_i and conv10_i write the
+                                                              // split format (conv_split16.h) and both halves of conv2_i read it by LDS-DMA (conv_sf.hip)
 
     // device weights (offsets in floats into `wdev`)
     DevBuf wdev;
@@ -321,6 +324,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
     // has at least ~a tile per CU, the Winograd f32 kernel for small shapes (BASELINE.json configs[0], configs[4])
     const int tiles8x32 = F * ((W + 31) / 32) * ((H + 7) / 8);
     const int algo = h->conv_algo == 5 ? ((tiles8x32 >= 256 && (long long)H * W * 256 < 0x7fffffffLL) ? 4 : 3) : h->conv_algo;
+    const bool sf = algo == 4 && h->conv1x1_algo == 2 && h->sf_path;   // inp1 and base in the split format (conv_split16.h)
     for (int i = 0; i < (h->bf16 ? 0 : c.num_block); ++i) {   // model/pfnl.py:65-71
         if (h->prof_mode == 2) {          // sampled profiling: blocks 0, 4, 8, ... each with a fresh event chain
             h->prof_gate = (i & 3) == 0;
@@ -342,6 +346,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             p.act = 1;
             if (algo == 4) {
                 ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_c1[i], p.bias, nullptr, nullptr, p.out, H, W, F, 1, 1};
+                q.out_sf = sf ? 1 : 0;                              // inp1 in the split format: it only feeds conv10_i and conv2_i's MFMA operands
                 HIPCHK(launch_conv3x3_split16(q, s));
             } else if (algo == 1 || algo == 3) {
                 WinoParams wp{p.in, wd + h->off_c1_u[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 1, F, nullptr};
@@ -359,7 +364,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             p.frames_per_item = T;
             p.nchunks = T * p.chunks_per_frame;
             if (h->conv1x1_algo == 2)
-                HIPCHK(launch_conv1x1_split16(p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_c10[i], p.bias, p.out, B, T, H * W, 1, s));
+                HIPCHK(launch_conv1x1_split16(p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_c10[i], p.bias, p.out, B, T, H * W, 1, s, sf, sf));
             else if (h->conv1x1_algo == 1)
                 HIPCHK(launch_conv1x1_stream(p.in, wd + h->off_c10_s[i], p.bias, p.out, B, T, H * W, 1, s));
             else
@@ -397,8 +402,8 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             p.nchunks = p.chunks_per_frame;
             p.act = 0;
             if (algo == 4) {
-                ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_c2a[i], p.bias, nullptr, nullptr, p.out, H, W, B, 1, 0};
-                HIPCHK(launch_conv3x3_split16(q, s));
+                ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + (sf ? h->off16s_c2a_sf[i] : h->off16s_c2a[i]), p.bias, nullptr, nullptr, p.out, H, W, B, 1, 0};
+                HIPCHK(sf ? launch_conv3x3_sf(q, s) : launch_conv3x3_split16(q, s));
             } else if (algo == 1 || algo == 3) {
                 WinoParams wp{p.in, wd + h->off_c2a_u[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 0, B, nullptr};
                 HIPCHK(algo == 3 ? launch_conv_wino_ws(wp, s) : launch_conv_wino(wp, s));
@@ -417,8 +422,8 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             p.out = h->inp0.p;
             p.act = 1;
             if (algo == 4) {
-                ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_c2b[i], p.bias, p.addend, p.resid, p.out, H, W, F, T, 1};
-                HIPCHK(launch_conv3x3_split16(q, s));
+                ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + (sf ? h->off16s_c2b_sf[i] : h->off16s_c2b[i]), p.bias, p.addend, p.resid, p.out, H, W, F, T, 1};
+                HIPCHK(sf ? launch_conv3x3_sf(q, s) : launch_conv3x3_split16(q, s));
             } else if (algo == 1 || algo == 3) {
                 WinoParams wp{p.in, wd + h->off_c2b_u[i], p.bias, p.addend, p.resid, p.out, H, W, T, 1, F, nullptr};
                 HIPCHK(algo == 3 ? launch_conv_wino_ws(wp, s) : launch_conv_wino(wp, s));
@@ -507,6 +512,7 @@ int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
     HIPCHK(hipSetDevice(cfg->device_id));
     pfnl_handle* h = new pfnl_handle();
     h->cfg = *cfg;
+    if (const char* e = std::getenv("PFNL_SPLIT16_SF")) h->sf_path = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_CONV3X3")) {
         const std::string v(e);
         h->conv_algo = v == "direct" ? 0 : (v == "winograd_tile" ? 1 : (v == "split16" ? 4 : (v == "winograd" ? 3 : 5)));
@@ -600,6 +606,12 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         else if (v == "split16") h->conv_algo = 4;
         else if (v == "auto") h->conv_algo = 5;
         else return fail(PFNL_ERR_INVALID, "conv3x3 must be auto, split16, winograd, winograd_tile or direct");
+        return 0;
+    }
+    if (k == "split16_sf") {
+        if (v == "on") h->sf_path = true;
+        else if (v == "off") h->sf_path = false;
+        else return fail(PFNL_ERR_INVALID, "split16_sf must be on or off");
         return 0;
     }
     if (k == "conv2") {
@@ -814,16 +826,22 @@ int pfnl_finalize_weights(pfnl_handle* h) {
         h->off16s_c2a.assign(nb, 0);
         h->off16s_c2b.assign(nb, 0);
         h->off16s_c10.assign(nb, 0);
-        h->off16s_m1 = (size_t)nb * (3 * n3 + n1);
-        b16.resize((size_t)nb * (3 * n3 + n1) + (size_t)T * n3 + 2, 0);
+        h->off16s_c2a_sf.assign(nb, 0);
+        h->off16s_c2b_sf.assign(nb, 0);
+        h->off16s_m1 = (size_t)nb * (5 * n3 + n1);
+        b16.resize((size_t)nb * (5 * n3 + n1) + (size_t)T * n3 + 2, 0);
         for (int f = 0; f < T; ++f)
             pfnl::conv3x3_split16_pack_weights(W("convmerge1").data(), 64 * T, 64 * f, &b16[h->off16s_m1 + (size_t)f * n3], 48);
         for (int i = 0; i < nb; ++i) {
             const std::string s = std::to_string(i);
-            h->off16s_c1[i] = (size_t)i * (3 * n3 + n1);
+            h->off16s_c1[i] = (size_t)i * (5 * n3 + n1);
             h->off16s_c2a[i] = h->off16s_c1[i] + n3;
             h->off16s_c2b[i] = h->off16s_c1[i] + 2 * n3;
             h->off16s_c10[i] = h->off16s_c1[i] + 3 * n3;
+            h->off16s_c2a_sf[i] = h->off16s_c10[i] + n1;
+            h->off16s_c2b_sf[i] = h->off16s_c2a_sf[i] + n3;
+            pfnl::conv3x3_split16_pack_weights(W("conv2_" + s).data(), 128, 0, &b16[h->off16s_c2a_sf[i]], 64, true);
+            pfnl::conv3x3_split16_pack_weights(W("conv2_" + s).data(), 128, 64, &b16[h->off16s_c2b_sf[i]], 64, true);
             pfnl::conv1x1_split16_pack_weights(W("conv10_" + s).data(), T, &b16[h->off16s_c10[i]]);
             pfnl::conv3x3_split16_pack_weights(W("conv1_" + s).data(), 64, 0, &b16[h->off16s_c1[i]]);
             pfnl::conv3x3_split16_pack_weights(W("conv2_" + s).data(), 128, 0, &b16[h->off16s_c2a[i]]);
@@ -1376,6 +1394,73 @@ int pfnl_op_conv1x1_split16(const float* in, const float* kernel_host, const flo
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(dw);
     if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv1x1 split16 op: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// ---- the split-format ("SF", conv_split16.h) variants of the split-f16 kernels, op by op.  The hooks take and return fp32
+// tensors: fp32 -> SF and SF -> fp32 (hi + lo' 2^-11) conversions bracket the kernel under test, so that each of them is checked
+// against the fp64 spec at its own scale and not only inside the forward.
+//   which = 0: conv3x3_sf_kernel (input SF by LDS-DMA, epilogue from registers; plain or fused with addend + resid)
+//   which = 1: conv3x3_split16_kernel<0, OSF> (conv1_i: fp32 in, SF out)
+int pfnl_op_conv3x3_split16_sf(int which, const float* in, const float* kernel_host, const float* bias_host, const float* addend,
+                               int add_div, const float* resid, float* out, int items, int H, int W, int act, void* stream) {
+    if (!in || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (which < 0 || which > 1 || items < 1 || H < 1 || W < 1 || (addend == nullptr) != (resid == nullptr)) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
+    if (addend && (which != 0 || add_div < 1 || items % add_div)) return fail(PFNL_ERR_INVALID, "fused mode: which = 0, items a multiple of add_div");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nh = pfnl::conv3x3_split16_pack_halfs();
+    std::vector<uint16_t> pack(nh + 128, 0);
+    pfnl::conv3x3_split16_pack_weights(kernel_host, 64, 0, pack.data(), 64, which == 0);
+    if (bias_host) std::memcpy(&pack[nh], bias_host, 64 * sizeof(float));
+    const size_t npix = (size_t)items * H * W;
+    uint16_t *dw = nullptr, *tmp = nullptr;
+    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(uint16_t)));
+    hipError_t e = hipMalloc(&tmp, npix * 256);
+    if (e == hipSuccess) e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (which == 0) {
+        if (e == hipSuccess) e = pfnl::launch_sf_from_f32(in, tmp, npix, s);
+        pfnl::ConvSplitParams q{reinterpret_cast<const float*>(tmp), dw, reinterpret_cast<const float*>(dw + nh), addend, resid, out, H, W, items, add_div < 1 ? 1 : add_div, act};
+        if (e == hipSuccess) e = pfnl::launch_conv3x3_sf(q, s);
+    } else {
+        pfnl::ConvSplitParams q{in, dw, reinterpret_cast<const float*>(dw + nh), nullptr, nullptr, reinterpret_cast<float*>(tmp), H, W, items, 1, act};
+        q.out_sf = 1;
+        if (e == hipSuccess) e = pfnl::launch_conv3x3_split16(q, s);
+        if (e == hipSuccess) e = pfnl::launch_sf_to_f32(tmp, out, npix, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dw);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv3x3 split16 SF op: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// conv10_i with its input and / or output in the split format (fp32 at the hook's interface, see above)
+int pfnl_op_conv1x1_split16_sf(const float* in, const float* kernel_host, const float* bias_host, float* out, int items,
+                               int frames_per_item, int HW, int act, int in_sf, int out_sf, void* stream) {
+    if (!in || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (items < 1 || frames_per_item < 1 || HW < 1) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
+    hipStream_t s = (hipStream_t)stream;
+    const int T = frames_per_item;
+    const size_t nh = pfnl::conv1x1_split16_pack_halfs(T);
+    std::vector<uint16_t> pack(nh + 128, 0);
+    pfnl::conv1x1_split16_pack_weights(kernel_host, T, pack.data());
+    if (bias_host) std::memcpy(&pack[nh], bias_host, 64 * sizeof(float));
+    const size_t npin = (size_t)items * T * HW, npout = (size_t)items * HW;
+    uint16_t *dw = nullptr, *tin = nullptr, *tout = nullptr;
+    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(uint16_t)));
+    hipError_t e = hipMalloc(&tin, npin * 256);
+    if (e == hipSuccess) e = hipMalloc(&tout, npout * 256);
+    if (e == hipSuccess) e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && in_sf) e = pfnl::launch_sf_from_f32(in, tin, npin, s);
+    if (e == hipSuccess)
+        e = pfnl::launch_conv1x1_split16(in_sf ? reinterpret_cast<const float*>(tin) : in, dw, reinterpret_cast<const float*>(dw + nh),
+                                         out_sf ? reinterpret_cast<float*>(tout) : out, items, T, HW, act, s, in_sf != 0, out_sf != 0);
+    if (e == hipSuccess && out_sf) e = pfnl::launch_sf_to_f32(tout, out, npout, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dw);
+    (void)hipFree(tin);
+    (void)hipFree(tout);
+    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv1x1 split16 SF op: ") + hipGetErrorString(e));
     return 0;
 }
 

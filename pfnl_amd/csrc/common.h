@@ -76,7 +76,8 @@ void conv_pack_weights(const float* hwio, int ksize, int cin_total, int cin_begi
 hipError_t launch_conv1x1_stream(const float* in, const float* wpack, const float* bias, float* out, int items, int T,
                                  int HW, int act, hipStream_t s);
 hipError_t launch_conv1x1_split16(const float* in, const uint16_t* wpack, const float* bias, float* out, int items, int T,
-                                  int HW, int act, hipStream_t s);   // same contract on the f16 pipe, exactly split operands
+                                  int HW, int act, hipStream_t s,    // same contract on the f16 pipe, exactly split operands
+                                  bool in_sf = false, bool out_sf = false);   // in / out in the split format (conv_split16.h)
 size_t conv1x1_split16_pack_halfs(int T);
 void conv1x1_split16_pack_weights(const float* hwio, int T, uint16_t* dst);   // HWIO [1,1,T*64,64]
 size_t conv1x1_pack_floats(int T);

@@ -186,6 +186,9 @@ __device__ __forceinline__ void c1_split4(f32x4 v, c1u2& hi, c1u2& lo, float nsc
     lo = c1u2{l0, l1};
 }
 
+// ISF: `in` is in the split format (conv_split16.h): the two operands of a k-step are two 16-byte loads, no arithmetic.
+// OSF: `out` is written in the split format (base feeds the shared half of conv2_i only: conv_sf.hip).
+template <bool ISF, bool OSF>
 __global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_split16_kernel(const float* __restrict__ in,
                                                                         const uint16_t* __restrict__ wpack,
                                                                         const float* __restrict__ bias,
@@ -206,11 +209,14 @@ __global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_split16_kernel(const fl
 
     const c1u4* wsrc = reinterpret_cast<const c1u4*>(wpack) + tid;  // + f*C1_WF (+512)
     c1u4 wr0 = wsrc[0], wr1 = wsrc[C1_THREADS];
-    const f32x4* ap = reinterpret_cast<const f32x4*>(in) + (((size_t)item * T * HW + min(p0 + xl, HW - 1)) * 16 + kh * 4);
+    // fp32: piece (q >> 2) * 8 + kh * 4 + (q & 3) of the pixel's 16 (4 channels each); pieces 2q', 2q'+1 = k-step q' = (M, h).
+    // SF: 16-byte chunks of the pixel: [M][part][4]: k-step (M, h) takes chunk 2 kh + h of part hi (-> dst[2q']) and lo' (-> dst[2q'+1])
+    const f32x4* ap = reinterpret_cast<const f32x4*>(in) + (((size_t)item * T * HW + min(p0 + xl, HW - 1)) * 16 + (ISF ? kh * 2 : kh * 4));
     const size_t aframe = (size_t)HW * 16;
 #define C1S_LOAD_A(dst, ap_)                                                                           \
     do {                                                                                               \
-        _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) dst[q_] = (ap_)[(q_ >> 2) * 8 + (q_ & 3)];     \
+        _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                                \
+            dst[q_] = ISF ? (ap_)[(q_ >> 2) * 8 + ((q_ >> 1) & 1) + (q_ & 1) * 4] : (ap_)[(q_ >> 2) * 8 + (q_ & 3)]; \
     } while (0)
     f32x4 a0[8] = {}, a1[8] = {}, a2[8] = {};
     C1S_LOAD_A(a0, ap);
@@ -249,11 +255,17 @@ __global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_split16_kernel(const fl
             if (q_ == 3) __syncthreads();                                                              \
             const c1u4* wp_ = q_ < 3 ? wl_ + ((q_ + 1) * 4) * 64 : wn_;                                \
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) wq[(q_ + 1) & 1][i_] = wp_[i_ * 64];      \
-            c1u2 h0_, l0_, h1_, l1_;                                                                   \
-            c1_split4(cur[2 * q_], h0_, l0_, nscale);                                                  \
-            c1_split4(cur[2 * q_ + 1], h1_, l1_, nscale);                                              \
-            const c1h8 ah_ = __builtin_bit_cast(c1h8, c1u4{h0_.x, h0_.y, h1_.x, h1_.y});               \
-            const c1h8 al_ = __builtin_bit_cast(c1h8, c1u4{l0_.x, l0_.y, l1_.x, l1_.y});               \
+            c1h8 ah_, al_;                                                                             \
+            if constexpr (ISF) {                                                                       \
+                ah_ = __builtin_bit_cast(c1h8, cur[2 * q_]);                                           \
+                al_ = __builtin_bit_cast(c1h8, cur[2 * q_ + 1]);                                       \
+            } else {                                                                                   \
+                c1u2 h0_, l0_, h1_, l1_;                                                               \
+                c1_split4(cur[2 * q_], h0_, l0_, nscale);                                              \
+                c1_split4(cur[2 * q_ + 1], h1_, l1_, nscale);                                          \
+                ah_ = __builtin_bit_cast(c1h8, c1u4{h0_.x, h0_.y, h1_.x, h1_.y});                      \
+                al_ = __builtin_bit_cast(c1h8, c1u4{l0_.x, l0_.y, l1_.x, l1_.y});                      \
+            }                                                                                          \
             __builtin_amdgcn_sched_barrier(0);                                                         \
             const c1h8 w0h_ = __builtin_bit_cast(c1h8, wq[q_ & 1][0]), w0l_ = __builtin_bit_cast(c1h8, wq[q_ & 1][1]); \
             const c1h8 w1h_ = __builtin_bit_cast(c1h8, wq[q_ & 1][2]), w1l_ = __builtin_bit_cast(c1h8, wq[q_ & 1][3]); \
@@ -284,18 +296,30 @@ __global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_split16_kernel(const fl
         v0 = fmaxf(v0, slope * v0);
         v1 = fmaxf(v1, slope * v1);
         if (p0 + px < HW) {
-            ob[(size_t)px * 64] = v0;
-            ob[(size_t)px * 64 + 32] = v1;
+            if constexpr (OSF) {                                    // pixel = 128 halves: [M = g][hi | lo'][32]
+                _Float16* const oh = reinterpret_cast<_Float16*>(out) + ((size_t)item * HW + p0 + px) * 128 + xl;
+                const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+                oh[0] = h0;
+                oh[32] = (_Float16)((v0 - (float)h0) * 2048.0f);
+                oh[64] = h1;
+                oh[96] = (_Float16)((v1 - (float)h1) * 2048.0f);
+            } else {
+                ob[(size_t)px * 64] = v0;
+                ob[(size_t)px * 64 + 32] = v1;
+            }
         }
     }
 }
 
 hipError_t launch_conv1x1_split16(const float* in, const uint16_t* wpack, const float* bias, float* out, int items, int T,
-                                  int HW, int act, hipStream_t s) {
+                                  int HW, int act, hipStream_t s, bool in_sf, bool out_sf) {
     if (!in || !wpack || !bias || !out || items < 1 || T < 1 || HW < 1) return hipErrorInvalidValue;
     const int ngroups = ((HW + 31) / 32) * items;
-    hipLaunchKernelGGL(conv1x1_split16_kernel, dim3((ngroups + 7) / 8), dim3(C1_THREADS), 0, s, in, wpack, bias, out, HW, T,
-                       items, act);
+    const dim3 grid((ngroups + 7) / 8), block(C1_THREADS);
+    if (in_sf && out_sf) hipLaunchKernelGGL((conv1x1_split16_kernel<true, true>), grid, block, 0, s, in, wpack, bias, out, HW, T, items, act);
+    else if (in_sf) hipLaunchKernelGGL((conv1x1_split16_kernel<true, false>), grid, block, 0, s, in, wpack, bias, out, HW, T, items, act);
+    else if (out_sf) hipLaunchKernelGGL((conv1x1_split16_kernel<false, true>), grid, block, 0, s, in, wpack, bias, out, HW, T, items, act);
+    else hipLaunchKernelGGL((conv1x1_split16_kernel<false, false>), grid, block, 0, s, in, wpack, bias, out, HW, T, items, act);
     return hipGetLastError();
 }
 

@@ -1,0 +1,457 @@
+// 3x3 64->64 convolution whose INPUT is in the split format (SF, conv_split16.h): both halves of conv2_i of the progressive-fusion
+// blocks (reference model/pfnl.py:51, 69-71) - their inputs, conv1_i's and conv10_i's outputs, only ever feed MFMA operands.
+//
+// Arithmetic: that of conv_split16.hip (x = hi + lo' 2^-11 exactly split binary16 operands, three v_mfma_f32_32x32x16_f16 per
+// product block, fp32 accumulation, the two cross terms in a second accumulator folded in with 2^-11 once per tile).
+// What changes against conv3x3_split16_kernel is everything AROUND the MFMAs:
+//   * the halo tile of a unit ((tile, half of the input channels): 10 x 34 pixels x 128 B) is already in operand form in HBM, so it
+//     goes HBM -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 43 wave instructions of 1 KB per unit): no staging registers, no
+//     split arithmetic (48 VALU per thread and unit), no ds_write (12 per thread and unit).  The LDS layout keeps its XOR swizzle
+//     (16-byte chunk c of pixel (py, px) sits in slot c ^ ((px >> 1) & 7)): a DMA instruction writes 1 KB linearly (lane L ->
+//     M0 + 16 L), so the swizzle is applied to the SOURCE - lane L fetches the chunk that belongs in its slot.  Out-of-image
+//     pixels: an out-of-range buffer offset makes the DMA write zeros (tools/ubench/lds_dma.hip: measured, with everything
+//     else the kernel relies on - destinations above 64 KB, no compaction under EXEC, the immediate offset moving BOTH sides);
+//   * MFMA roles swapped (A = pixels, B = weights): D[pixel][cout], i.e. a lane owns ONE output channel and 16 pixels of a row,
+//     and 32 lanes x 4 B are a full 128-byte line of an NHWC pixel - the epilogue (bias as the initial C, leaky-relu, addend,
+//     residual) runs from registers with dword loads / stores, without the trip through an LDS scratch tile, its two barriers and
+//     the constraint that the other halo buffer be free for it in the first two thirds of a unit.  Rows past the image, columns
+//     past it and "no tile pending" cost no branches: the output / residual / addend resources are built per ROW with
+//     num_records = W * 256 bytes (or 0), and the range check covers voffset + soffset + immediate;
+//   * completion of the DMA is waited for with a FENCE LOAD: a compiler-visible 4-byte buffer load issued right after the
+//     unit's DMA instructions, consumed (an empty asm taking it as input) right before the unit's closing barrier.  vmcnt is in
+//     order, so when the compiler's own - exactly counted - wait for that load has passed, everything older has landed; the
+//     compiler knows nothing of the asm DMAs, which only ever makes its other waits stronger, never weaker.
+// Work order, weight slices (24 KB per column tap, L2 -> registers -> LDS following the taps consumed), the operand pipeline and
+// the chain order of the per-frame half are those of conv3x3_split16_kernel.
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+#include "common.h"
+#include "conv_split16.h"
+
+#ifndef SF_STORE_AUX
+#define SF_STORE_AUX 17     // output stores written through (sc0 sc1), as conv_split16.hip measured
+#endif
+
+namespace pfnl {
+
+typedef _Float16 sfh8 __attribute__((ext_vector_type(8)));
+typedef unsigned sfu4 __attribute__((ext_vector_type(4)));
+
+constexpr int SF_THREADS = 512;
+constexpr int SF_TH = 8, SF_TW = 32;
+constexpr int SF_IH = SF_TH + 2, SF_IW = SF_TW + 2;
+constexpr int SF_NPIX = SF_IH * SF_IW;                              // 340
+constexpr int SF_NDMA = (SF_NPIX + 7) / 8;                          // 43 DMA instructions of 8 pixels x 128 B
+constexpr int SF_TILE_BYTES = SF_NDMA * 1024;                       // 44 032 (the last instruction's 4 surplus pixels land in padding)
+constexpr int SF_W_BYTES = 3 * 2 * 3 * 2 * 2 * 1024;                // 73 728: [kx][ks][ky][m][hi/lo][lane] x 16 B, one channel half
+constexpr int SF_SLOT_BYTES = SF_W_BYTES / 3;
+constexpr int SF_LDS_BYTES = 2 * SF_TILE_BYTES + SF_W_BYTES + 64 * 4;   // 162 048 of 163 840
+constexpr int SF_DMA_ITERS = (SF_NDMA + 7) / 8;                     // 6 per wave (waves 3..7: 5)
+constexpr int SF_WITERS = SF_SLOT_BYTES / 16 / SF_THREADS;          // 3
+constexpr float SF_ISCALE = 1.0f / 2048.0f;
+static_assert(SF_LDS_BYTES <= 160 * 1024, "LDS budget");
+
+// one LDS-DMA instruction: lane L's 16 bytes at (resource, voff) -> LDS [lds_dst + 16 L].  m0 is compiler-reserved: saved / restored.
+__device__ __forceinline__ void sf_dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds_dst, int voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rs) : "memory");
+}
+
+// 4-byte buffer store that is safe to follow with anything (common.h, buffer_store_b128_guarded: same reasoning)
+template <int AUX>
+__device__ __forceinline__ void sf_store_b32(float v, __amdgpu_buffer_rsrc_t rs, int voffset, int soffset) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voffset, soffset, AUX);
+    asm volatile("s_nop 1" ::"v"(v));
+}
+
+__device__ __forceinline__ f32x16 sf_mfma(sfh8 a, sfh8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+// MODE 0: out = act(conv + bias).   MODE 1 (conv2_i per-frame half): out = act(conv + bias + addend[item / add_div]) + resid.
+template <int MODE>
+__global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_kernel(ConvSplitParams p) {
+    constexpr bool FUSE = MODE == 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sf_smem[];
+    unsigned char* const wl = sf_smem + 2 * SF_TILE_BYTES;
+    float* const bl = reinterpret_cast<float*>(sf_smem + 2 * SF_TILE_BYTES + SF_W_BYTES);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rp = wave >> 1;                                       // rows 2rp, 2rp+1 of the tile
+    const int nt = wave & 1;                                        // output channels 32nt .. 32nt+31
+    const int H = p.H, W = p.W;
+    const int tiles_x = (W + SF_TW - 1) / SF_TW, tiles_y = (H + SF_TH - 1) / SF_TH;
+    const int per_item = tiles_x * tiles_y;
+    const int item_bytes = H * W * 256;
+    const int wbytes = W * 256;
+    // work order: chains of the gT frames of a clip at one spatial tile, dealt out XCD by XCD (conv_split16.hip)
+    const int gT = FUSE ? p.add_div : 1;
+    const int nchains = per_item * (p.items / gT);
+    const int xcd = blockIdx.x & 7, xj = blockIdx.x >> 3, cpx = gridDim.x >> 3;
+    const int per_xcd = (nchains + 7) >> 3;
+    const int cbeg = xcd * per_xcd;
+    const int ccnt = min(per_xcd, nchains - cbeg);
+    if (xj >= ccnt) return;
+    const int nt_tiles = ((ccnt - xj + cpx - 1) / cpx) * gT;        // tiles of this workgroup
+#define SF_TILE(k_, item_, y0_, x0_)                                                             \
+    do {                                                                                         \
+        const int ci_ = (k_) / gT, f_ = (k_) - ci_ * gT;                                         \
+        const int ch_ = cbeg + xj + ci_ * cpx;                                                   \
+        const int cl_ = ch_ / per_item;                                                          \
+        const int sp_ = ch_ - cl_ * per_item;                                                    \
+        item_ = cl_ * gT + f_;                                                                   \
+        const int ty_ = sp_ / tiles_x;                                                           \
+        y0_ = ty_ * SF_TH;                                                                       \
+        x0_ = (sp_ - ty_ * tiles_x) * SF_TW;                                                     \
+    } while (0)
+#define SF_HALF(u_) ((((u_) >> 1) ^ (u_)) & 1)
+
+    // weights of half 0 + bias: requested here, written to LDS after the first halo has been requested too
+    sfu4 w0reg[SF_W_BYTES / 16 / SF_THREADS];
+#pragma unroll
+    for (int k = 0; k < SF_W_BYTES / 16 / SF_THREADS; ++k) w0reg[k] = reinterpret_cast<const sfu4*>(p.wpack)[k * SF_THREADS + tid];
+    const float bias_r = tid < 64 ? p.bias[tid] : 0.f;
+
+    // DMA map: instruction i = wave + 8 k covers halo pixels 8 i .. 8 i + 7 (linear, 34 per row); lane L -> pixel 8 i + (L >> 3),
+    // LDS slot L & 7, which holds chunk (L & 7) ^ ((px >> 1) & 7) of that pixel.  Constant for the life of the kernel:
+    // `dgrel` = byte offset of the lane's source chunk relative to the halo origin, `dpk` = py | px << 8 (border test).
+    int dgrel[SF_DMA_ITERS], dpk[SF_DMA_ITERS];
+#pragma unroll
+    for (int k = 0; k < SF_DMA_ITERS; ++k) {
+        const int pix = 8 * (wave + 8 * k) + (lane >> 3);
+        const int py = pix / SF_IW, px = pix - py * SF_IW;
+        const int c = (lane & 7) ^ ((px >> 1) & 7);
+        dgrel[k] = py * wbytes + px * 256 + c * 16;
+        dpk[k] = py | (px << 8);
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)sf_smem;             // LDS byte address of halo buffer 0
+    // (the asm DMAs are invisible to the compiler's vmcnt bookkeeping; the wave-uniform branch around the 6th only skips asm)
+#define SF_DMA_ALL(rs_, org_, interior_, y0_, x0_, buf_)                                         \
+    do {                                                                                         \
+        _Pragma("unroll") for (int k_ = 0; k_ < SF_DMA_ITERS; ++k_) {                            \
+            const int i_ = wave + 8 * k_;                                                        \
+            if (k_ < SF_DMA_ITERS - 1 || i_ < SF_NDMA) {                                         \
+                const int gy_ = (y0_) + (dpk[k_] & 0xff) - 1, gx_ = (x0_) + (dpk[k_] >> 8) - 1;  \
+                const bool in_ = (interior_) || ((unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W && (dpk[k_] & 0xff) < SF_IH); \
+                sf_dma16(rs_, lds0 + (buf_) * SF_TILE_BYTES + i_ * 1024, in_ ? (org_) + dgrel[k_] : 0x7fffffff); \
+            }                                                                                    \
+        }                                                                                        \
+    } while (0)
+
+    // operand addresses (conv_split16.hip): pixel operand of (column tap kx, k-step ks, part) = chunk 4*part + 2*ks + (lane >> 5)
+    // of halo pixel (row 2*rp + ..., column (lane & 31) + kx); weights: 16 bytes per lane
+    int paddr[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int col = (lane & 31) + kx;
+        paddr[kx] = ((2 * rp) * SF_IW + col) * 128 + ((((lane >> 5)) ^ ((col >> 1) & 7)) << 4);
+    }
+    const int lo_xor = 4 << 4;
+    const unsigned char* const wlane = wl + nt * 2048 + lane * 16;
+
+    // D[pixel][cout]: lane = output channel 32 nt + (lane & 31); register r = pixel column drow(r, lane) of the row
+    const int ech = 32 * nt + (lane & 31);
+    f32x16 accm[2], accc[2], accp[2];                               // [output row]: hi.hi / cross products (x 2^11) / finished tile
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            accm[n][r] = 0.f;
+            accc[n][r] = 0.f;
+            accp[n][r] = 0.f;
+        }
+    int ex0p = 0, ey0p = 0, eitemp = 0;                             // the tile awaiting its epilogue
+    bool pending = false;
+    const float slope = p.act ? 0.2f : 1.0f;
+
+    // ---- epilogue (from registers) --------------------------------------------------------------
+    // row n of the pending tile in unit n of the next one.  Register 4 q + j of a lane = pixel column 8 q + j + 4 (lane >> 5):
+    // byte offset in the row = evoff + j * 256 (immediate) + q * 2048 (scalar offset).
+    __amdgpu_buffer_rsrc_t rsO;
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rsR, rsA;
+    int evoff = 0;
+    [[maybe_unused]] float radd[16], rres[16];
+    auto row_setup = [&](int n) __attribute__((always_inline)) {
+        const int ey = ey0p + 2 * rp + n;
+        const int nrec = (pending && ey < H) ? wbytes : 0;
+        const size_t row = ((size_t)eitemp * H + ey) * W * 64;
+        rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + row, 0, nrec, 0x00020000);
+        if constexpr (FUSE) {
+            rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid) + row, 0, nrec, 0x00020000);
+            rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.addend) + ((size_t)(eitemp / p.add_div) * H + ey) * W * 64, 0, nrec, 0x00020000);
+        }
+        evoff = (ex0p + 4 * (lane >> 5)) * 256 + ech * 4;
+    };
+    auto quarter_request = [&](int q) __attribute__((always_inline)) {
+        if constexpr (FUSE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                radd[4 * q + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, evoff + j * 256, q * 2048, 0));
+                rres[4 * q + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, evoff + j * 256, q * 2048, 0));
+            }
+        }
+    };
+    auto quarter_finish = [&](int n, int q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = accp[n][4 * q + j];                           // (the bias is already in: initial C of the tile)
+            if constexpr (FUSE) v += radd[4 * q + j];
+            const float sv = v * slope;
+            asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(sv)); // leaky_relu(0.2) or identity (slope 1), branch-free
+            if constexpr (FUSE) v += rres[4 * q + j];
+            sf_store_b32<SF_STORE_AUX>(v, rsO, evoff + j * 256, q * 2048);
+        }
+    };
+
+    // ---- weight replacement: a slot (24 KB, one column tap) travels L2 -> registers -> LDS, 3 x 16 B per thread
+    sfu4 wnx[SF_WITERS];
+    auto w_request = [&](int half, int slot) __attribute__((always_inline)) {
+        const sfu4* src = reinterpret_cast<const sfu4*>(p.wpack) + (size_t)half * (SF_W_BYTES / 16) + slot * (SF_SLOT_BYTES / 16);
+#pragma unroll
+        for (int k = 0; k < SF_WITERS; ++k) wnx[k] = src[k * SF_THREADS + tid];
+    };
+    auto w_write = [&](int slot) __attribute__((always_inline)) {
+        sfu4* dst = reinterpret_cast<sfu4*>(wl + slot * SF_SLOT_BYTES);
+#pragma unroll
+        for (int k = 0; k < SF_WITERS; ++k) dst[k * SF_THREADS + tid] = wnx[k];
+    };
+#define SF_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+    // ---- prologue: halo of unit 0 -> buffer 0 by DMA; weights of half 0 -> LDS --------------------------------
+    int c_item, c_y0, c_x0, n_item, n_y0, n_x0;
+    SF_TILE(0, c_item, c_y0, c_x0);
+    n_item = c_item;
+    n_y0 = c_y0;
+    n_x0 = c_x0;
+    {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.in) + (size_t)c_item * H * W * 64, 0, item_bytes, 0x00020000);
+        const int org = ((c_y0 - 1) * W + c_x0 - 1) * 256 + SF_HALF(0) * 128;
+        SF_DMA_ALL(rs, org, false, c_y0, c_x0, 0);
+        const unsigned fence = __builtin_amdgcn_raw_buffer_load_b32(rs, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < SF_W_BYTES / 16 / SF_THREADS; ++k) reinterpret_cast<sfu4*>(wl)[k * SF_THREADS + tid] = w0reg[k];
+        if (tid < 64) bl[tid] = bias_r;
+        asm volatile("" ::"v"(fence));                              // the compiler's wait for the fence load: the DMAs have landed
+    }
+    __syncthreads();
+    const float bias_l = bl[ech];
+
+    for (int kt = 0; kt < nt_tiles; ++kt) {
+        const int half_a = kt & 1;                                  // channel half of unit A; unit B: the other one
+        auto unit = [&](auto par) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par)::value;               // 0: unit A, 1: unit B
+            constexpr int cb = PAR;                                 // LDS buffer of this unit
+            const unsigned char* const tile = sf_smem + cb * SF_TILE_BYTES;
+            sfh8 X[4][2], Wv[2][2];
+#define SF_PX(g_, r_, part_) (*reinterpret_cast<const sfh8*>(tile + (paddr[(g_) >> 1] ^ (((part_) ? lo_xor : 0) | (((g_) & 1) << 5))) + (r_) * (SF_IW * 128)))
+#define SF_WT(g_, ky_, part_) (*reinterpret_cast<const sfh8*>(wlane + (((g_) * 3 + (ky_)) << 12) + ((part_) << 10)))
+            X[0][0] = SF_PX(0, 0, 0);
+            X[0][1] = SF_PX(0, 0, 1);
+            X[1][0] = SF_PX(0, 1, 0);
+            X[1][1] = SF_PX(0, 1, 1);
+            Wv[0][0] = SF_WT(0, 0, 0);
+            Wv[0][1] = SF_WT(0, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // the NEXT unit's halo -> the other buffer (free since the previous unit's closing barrier): unit A asks for the other
+            // half of ITS tile, unit B for the first half of the next tile
+            const int q_item = PAR == 0 ? c_item : n_item, y0q = PAR == 0 ? c_y0 : n_y0, x0q = PAR == 0 ? c_x0 : n_x0;
+            const int q_half = half_a ^ 1;                          // (boustrophedon: unit B's half is also the next tile's first half)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.in) + (size_t)q_item * H * W * 64, 0, item_bytes, 0x00020000);
+            const int org = ((y0q - 1) * W + x0q - 1) * 256 + q_half * 128;
+            const bool interior = y0q > 0 && y0q + SF_IH - 1 <= H && x0q > 0 && x0q + SF_IW - 1 <= W;
+            SF_DMA_ALL(rs, org, interior, y0q, x0q, cb ^ 1);
+            const unsigned fence = __builtin_amdgcn_raw_buffer_load_b32(rs, 0, 0, 0);
+            if constexpr (PAR == 0) w_request(half_a ^ 1, 0);
+            row_setup(PAR);                                         // epilogue row PAR of the previous tile (nothing pending: empty resources)
+
+            auto substep = [&](auto sc) __attribute__((always_inline)) {
+                constexpr int S = decltype(sc)::value;
+                constexpr int g = S / 3, ky = S % 3;
+                // --- the slice of non-MFMA work that rides on this sub-step
+                if constexpr (FUSE) {
+                    if constexpr (S < 4) quarter_request(S);
+                    if constexpr (S == 8) quarter_finish(PAR, 0);
+                    if constexpr (S == 10) quarter_finish(PAR, 1);
+                    if constexpr (S == 12) quarter_finish(PAR, 2);
+                    if constexpr (S == 14) quarter_finish(PAR, 3);
+                } else {
+                    if constexpr (S == 2) quarter_finish(PAR, 0);
+                    if constexpr (S == 5) quarter_finish(PAR, 1);
+                    if constexpr (S == 8) quarter_finish(PAR, 2);
+                    if constexpr (S == 11) quarter_finish(PAR, 3);
+                }
+                if constexpr (ky == 0) {
+                    if constexpr (g == 1 && PAR == 1) w_write(2);   // tap 2 of this unit's half (requested in unit A's group 5; free since its closing barrier)
+                    if constexpr (g == 2) SF_BARRIER();             // b0: column tap 0 consumed (unit A) / tap 2 complete (unit B)
+                    if constexpr (g == 3 && PAR == 0) {
+                        w_write(0);
+                        w_request(half_a ^ 1, 1);
+                        const int kn = min(kt + 1, nt_tiles - 1);   // decode the next tile (past the end: this one again - a harmless re-read)
+                        SF_TILE(kn, n_item, n_y0, n_x0);
+                    }
+                    if constexpr (g == 4 && PAR == 0) SF_BARRIER(); // b1: column tap 1 consumed
+                    if constexpr (g == 5 && PAR == 0) {
+                        w_write(1);
+                        w_request(half_a ^ 1, 2);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // --- operands of the next sub-step
+                if constexpr (S < 17) {
+                    constexpr int S1 = S + 1, g1 = S1 / 3, ky1 = S1 % 3;
+                    Wv[S1 & 1][0] = SF_WT(g1, ky1, 0);
+                    Wv[S1 & 1][1] = SF_WT(g1, ky1, 1);
+                    if constexpr (ky1 == 0) {
+                        X[0][0] = SF_PX(g1, 0, 0);
+                        X[0][1] = SF_PX(g1, 0, 1);
+                        X[1][0] = SF_PX(g1, 1, 0);
+                        X[1][1] = SF_PX(g1, 1, 1);
+                    } else {
+                        X[ky1 + 1][0] = SF_PX(g1, ky1 + 1, 0);
+                        X[ky1 + 1][1] = SF_PX(g1, ky1 + 1, 1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // --- 6 MFMAs: row tap ky of both output rows (A = pixels, B = weights)
+                const sfh8 wh = Wv[S & 1][0], wo = Wv[S & 1][1];
+                if constexpr (PAR == 0 && S == 0) {                 // a tile's first products: C = bias / 0 (no registers to clear)
+                    f32x16 bias16, zero;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        bias16[r] = bias_l;
+                        zero[r] = 0.f;
+                    }
+                    accm[0] = sf_mfma(X[ky][0], wh, bias16);
+                    accm[1] = sf_mfma(X[ky + 1][0], wh, bias16);
+                    accc[0] = sf_mfma(X[ky][0], wo, zero);
+                    accc[1] = sf_mfma(X[ky + 1][0], wo, zero);
+                } else {
+                    accm[0] = sf_mfma(X[ky][0], wh, accm[0]);
+                    accm[1] = sf_mfma(X[ky + 1][0], wh, accm[1]);
+                    accc[0] = sf_mfma(X[ky][0], wo, accc[0]);
+                    accc[1] = sf_mfma(X[ky + 1][0], wo, accc[1]);
+                }
+                accc[0] = sf_mfma(X[ky][1], wh, accc[0]);
+                accc[1] = sf_mfma(X[ky + 1][1], wh, accc[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            substep(std::integral_constant<int, 0>{});
+            substep(std::integral_constant<int, 1>{});
+            substep(std::integral_constant<int, 2>{});
+            substep(std::integral_constant<int, 3>{});
+            substep(std::integral_constant<int, 4>{});
+            substep(std::integral_constant<int, 5>{});
+            substep(std::integral_constant<int, 6>{});
+            substep(std::integral_constant<int, 7>{});
+            substep(std::integral_constant<int, 8>{});
+            substep(std::integral_constant<int, 9>{});
+            substep(std::integral_constant<int, 10>{});
+            substep(std::integral_constant<int, 11>{});
+            substep(std::integral_constant<int, 12>{});
+            substep(std::integral_constant<int, 13>{});
+            substep(std::integral_constant<int, 14>{});
+            substep(std::integral_constant<int, 15>{});
+            substep(std::integral_constant<int, 16>{});
+            substep(std::integral_constant<int, 17>{});
+#undef SF_PX
+#undef SF_WT
+            if constexpr (PAR == 1) {                               // the tile is complete: fold the cross terms in, hand it to the epilogue
+#pragma unroll
+                for (int n = 0; n < 2; ++n) accp[n] = accm[n] + accc[n] * SF_ISCALE;
+                ex0p = c_x0;
+                ey0p = c_y0;
+                eitemp = c_item;
+                c_item = n_item;
+                c_y0 = n_y0;
+                c_x0 = n_x0;
+                pending = true;
+            }
+            asm volatile("" ::"v"(fence));                          // the next unit's halo has landed (fence load: see the header)
+            SF_BARRIER();                                           // b2: this unit's buffer is free, the next unit's is complete
+        };
+        unit(std::integral_constant<int, 0>{});
+        unit(std::integral_constant<int, 1>{});
+    }
+
+    // ---- the last tile: both rows ----------------------------------------------------------------------
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        row_setup(n);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) quarter_request(q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) quarter_finish(n, q);
+    }
+#undef SF_DMA_ALL
+#undef SF_HALF
+#undef SF_TILE
+#undef SF_BARRIER
+}
+
+hipError_t launch_conv3x3_sf(const ConvSplitParams& p, hipStream_t s) {
+    if (!p.in || !p.wpack || !p.bias || !p.out || p.items < 1 || p.H < 1 || p.W < 1 || p.accum || p.out_sf) return hipErrorInvalidValue;
+    if ((p.addend == nullptr) != (p.resid == nullptr) || (p.addend && (p.add_div < 1 || p.items % p.add_div))) return hipErrorInvalidValue;
+    if ((long long)p.H * p.W * 256 >= 0x7fffffffLL) return hipErrorInvalidValue;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    static int ncu[64] = {};
+    if (!ncu[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        ncu[dev] = prop.multiProcessorCount;
+    }
+    const int grid = ncu[dev] >= 8 ? ncu[dev] / 8 * 8 : 8;          // whole XCDs; surplus workgroups exit at once
+    static bool attr_dev[64][2] = {};                               // the attribute is per device
+    const int mode = p.addend ? 1 : 0;
+    const void* fn = mode ? reinterpret_cast<const void*>(conv3x3_sf_kernel<1>) : reinterpret_cast<const void*>(conv3x3_sf_kernel<0>);
+    if (!attr_dev[dev][mode]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_dev[dev][mode] = true;
+    }
+    if (mode) hipLaunchKernelGGL(conv3x3_sf_kernel<1>, dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, p);
+    else hipLaunchKernelGGL(conv3x3_sf_kernel<0>, dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
+// ---- fp32 <-> SF (op-level tests and taps only: the forward never converts) -----------------------------------------------
+__global__ void sf_from_f32_kernel(const float* in, uint16_t* out, size_t npix) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread = one (pixel, channel)
+    if (i >= npix * 64) return;
+    const size_t pix = i >> 6;
+    const int ch = (int)(i & 63);
+    const float x = in[i];
+    const _Float16 hi = (_Float16)x;
+    const _Float16 lo = (_Float16)((x - (float)hi) * 2048.0f);
+    uint16_t hb, lb;
+    __builtin_memcpy(&hb, &hi, 2);
+    __builtin_memcpy(&lb, &lo, 2);
+    uint16_t* o = out + pix * 128 + (ch >> 5) * 64 + (ch & 31);
+    o[0] = hb;
+    o[32] = lb;
+}
+__global__ void sf_to_f32_kernel(const uint16_t* in, float* out, size_t npix) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * 64) return;
+    const size_t pix = i >> 6;
+    const int ch = (int)(i & 63);
+    const uint16_t* s = in + pix * 128 + (ch >> 5) * 64 + (ch & 31);
+    _Float16 hi, lo;
+    __builtin_memcpy(&hi, s, 2);
+    __builtin_memcpy(&lo, s + 32, 2);
+    out[i] = (float)hi + (float)lo * SF_ISCALE;
+}
+hipError_t launch_sf_from_f32(const float* in, uint16_t* out, size_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(sf_from_f32_kernel, dim3((unsigned)((npix * 64 + 255) / 256)), dim3(256), 0, s, in, out, npix);
+    return hipGetLastError();
+}
+hipError_t launch_sf_to_f32(const uint16_t* in, float* out, size_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(sf_to_f32_kernel, dim3((unsigned)((npix * 64 + 255) / 256)), dim3(256), 0, s, in, out, npix);
+    return hipGetLastError();
+}
+
+}  // namespace pfnl

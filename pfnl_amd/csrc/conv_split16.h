@@ -25,7 +25,14 @@ struct ConvSplitParams {
 // 32 M + 8 (c & 3) .. + 7 of part c >> 2: the unit the 3x3 kernels' LDS tiles and the 1x1 kernel's operands are made of.
 hipError_t launch_conv3x3_split16(const ConvSplitParams& p, hipStream_t s);
 size_t conv3x3_split16_pack_halfs();                                  // 16-bit elements per packed 3x3 64->64 kernel
-void conv3x3_split16_pack_weights(const float* hwio, int cin_total, int cin_begin, uint16_t* dst, int cout = 64);   // cout < 64: zero-padded
+void conv3x3_split16_pack_weights(const float* hwio, int cin_total, int cin_begin, uint16_t* dst, int cout = 64,   // cout < 64: zero-padded
+                                  bool identity_rows = false);        // true: the pack conv3x3_sf_kernel takes
+
+// 3x3 64->64 with the INPUT in the split format (conv_sf.hip): halo tiles by LDS-DMA, epilogue from registers.  `in` points at SF
+// data ([items][H][W] x 256 B); wpack = conv3x3_split16_pack_weights(..., identity_rows = true); plain and fused (addend + resid) modes.
+hipError_t launch_conv3x3_sf(const ConvSplitParams& p, hipStream_t s);
+hipError_t launch_sf_from_f32(const float* in, uint16_t* out, size_t npix, hipStream_t s);   // [npix][64] fp32 -> SF (tests / taps)
+hipError_t launch_sf_to_f32(const uint16_t* in, float* out, size_t npix, hipStream_t s);     // SF -> hi + lo' 2^-11
 
 // non-local block of the fp32 path on the f16 matrix pipe with exactly split operands (nonlocal_f16.hip); arguments as
 // launch_nl_attn_bf16 (conv_bf16.h)

@@ -742,7 +742,9 @@ size_t conv3x3_split16_pack_halfs() { return 2 * (size_t)CS_W_BYTES / 2; }   // 
 
 // HWIO [3,3,cin_total,cout] rows [cin_begin, cin_begin+64) -> [half][kx][ks][ky][m][part][lane][e]:
 // W[ky][kx][cin_begin + 32 half + 16 ks + 8 (lane>>5) + e][32 m + row_channel(lane&31)], part 0 = f16(w), part 1 = f16((w - hi) 2^11)
-void conv3x3_split16_pack_weights(const float* hwio, int cin_total, int cin_begin, uint16_t* dst, int cout) {
+// identity_rows: MFMA row / column r of the weight operand = output channel 32 m + r (conv_sf.hip: the weights are the B operand,
+// a lane of the result owns one channel); otherwise the row -> channel map of conv3x3_split16_kernel (16 consecutive channels per lane)
+void conv3x3_split16_pack_weights(const float* hwio, int cin_total, int cin_begin, uint16_t* dst, int cout, bool identity_rows) {
     for (int half = 0; half < 2; ++half)
         for (int kx = 0; kx < 3; ++kx)
             for (int ks = 0; ks < 2; ++ks)
@@ -751,7 +753,7 @@ void conv3x3_split16_pack_weights(const float* hwio, int cin_total, int cin_begi
                         for (int lane = 0; lane < 64; ++lane)
                             for (int e = 0; e < 8; ++e) {
                                 const int ci = cin_begin + 32 * half + 16 * ks + 8 * (lane >> 5) + e;
-                                const int co = 32 * m + split_row_channel(lane & 31);
+                                const int co = 32 * m + (identity_rows ? (lane & 31) : split_row_channel(lane & 31));
                                 const float w = co < cout ? hwio[((size_t)(ky * 3 + kx) * cin_total + ci) * cout + co] : 0.f;
                                 const _Float16 hi = (_Float16)w;
                                 const float lo = (w - (float)hi) * CS_SCALE;

@@ -183,6 +183,12 @@ def conv1x1_stream(x, kernel, bias=None, act=True, frames_per_item=1, variant="s
         raise ValueError("conv1x1_stream: geometry mismatch")
     items = F // frames_per_item
     out = torch.empty((items, H, W, 64), dtype=torch.float32, device=x.device)
+    if variant.startswith("split16_sf"):                  # "split16_sf:io" - i, o in {0, 1}: input / output in the split format
+        i_sf, o_sf = int(variant[-2]), int(variant[-1])
+        _capi.check(lib.pfnl_op_conv1x1_split16_sf(
+            _req(x, "x"), k.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p) if b is not None else None,
+            _req(out, "out"), items, frames_per_item, H * W, 1 if act else 0, i_sf, o_sf, _stream(x)))
+        return out
     fn = lib.pfnl_op_conv1x1_split16 if variant == "split16" else lib.pfnl_op_conv1x1_stream
     _capi.check(fn(
         _req(x, "x"), k.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p) if b is not None else None,
@@ -200,6 +206,13 @@ def conv3x3_winograd(x, kernel, bias=None, act=True, addend=None, add_div=1, res
         raise ValueError("winograd path is 3x3, 64 -> 64 only")
     F, H, W, c = x.shape
     out = torch.empty((F, H, W, 64), dtype=torch.float32, device=x.device)
+    if variant in ("split16_sf_in", "split16_sf_out"):    # the split-format kernels (conv_sf.hip / conv1_i writing SF), fp32 at this interface
+        _capi.check(lib.pfnl_op_conv3x3_split16_sf(
+            0 if variant == "split16_sf_in" else 1,
+            _req(x, "x"), k.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p) if b is not None else None,
+            _req(addend, "addend") if addend is not None else None, int(add_div),
+            _req(resid, "resid") if resid is not None else None, _req(out, "out"), F, H, W, 1 if act else 0, _stream(x)))
+        return out
     fn = {"winograd": lib.pfnl_op_conv3x3_winograd, "winograd_ws": lib.pfnl_op_conv3x3_winograd_ws,
           "split16": lib.pfnl_op_conv3x3_split16}[variant]
     _capi.check(fn(

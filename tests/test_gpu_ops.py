@@ -376,6 +376,75 @@ def test_conv3x3_split16(items, H, W, fused, act):
     assert e_s <= 1.5 * e_d + 1e-7, (e_s, e_d)                    # as good as the fp32 FMA chain of the direct kernel
 
 
+@pytest.mark.parametrize("items,H,W,fused,act", [(1, 8, 32, False, True), (7, 10, 38, True, True), (3, 5, 7, False, False), (1, 1, 1, False, True),
+                                                  (7, 33, 70, True, True), (2, 64, 96, False, True), (28, 24, 40, True, True),
+                                                  (1, 9, 130, False, True), (21, 16, 32, True, False), (4, 128, 128, False, False)])
+def test_conv3x3_split16_sf_input(items, H, W, fused, act):
+    """conv3x3_sf_kernel (conv_sf.hip; both halves of conv2_i, reference model/pfnl.py:51,69-71): the input in the split format
+    comes in by LDS-DMA (source-side swizzle, zero-filled borders), the epilogue runs from registers.  Same arithmetic as
+    conv3x3_split16_kernel: the error against the fp64 spec is bounded by the direct f32-MFMA kernel's; and, the operands being
+    the same binary16 pairs, it agrees with that kernel to summation order."""
+    rng = np.random.default_rng(items * 1000 + H * 10 + W)
+    x = rng.normal(size=(items, H, W, 64)).astype(np.float32)
+    k = (rng.normal(size=(3, 3, 64, 64)) / 24.0).astype(np.float32)
+    b = (rng.normal(size=64) * 0.1).astype(np.float32)
+    ref = pfnl_spec.conv2d_same(x.astype(np.float64), k.astype(np.float64), b.astype(np.float64))
+    kw = {}
+    if fused:
+        div = 7 if items % 7 == 0 else 1
+        add = rng.normal(size=(items // div, H, W, 64)).astype(np.float32)
+        res = rng.normal(size=(items, H, W, 64)).astype(np.float32)
+        ref = ref + np.repeat(add.astype(np.float64), div, axis=0)
+        kw = dict(addend=dev(add), add_div=div, resid=dev(res))
+    if act:
+        ref = pfnl_spec.lrelu(ref)
+    if fused:
+        ref = ref + res
+    got = ops.conv3x3_winograd(dev(x), k, b, act=act, variant="split16_sf_in", **kw).cpu().numpy()
+    old = ops.conv3x3_winograd(dev(x), k, b, act=act, variant="split16", **kw).cpu().numpy()
+    direct = ops.conv2d(dev(x), k, b, act=act, **kw).cpu().numpy()
+    e_s, e_d, e_o = np.abs(got - ref).max(), np.abs(direct - ref).max(), np.abs(got - old).max()
+    print(f"sf_in {items}x{H}x{W} fused={fused}: err {e_s:.3g} (direct f32 {e_d:.3g}), vs split16 kernel {e_o:.3g}")
+    assert e_s < 4e-6 * max(1.0, np.abs(ref).max()), (e_s, e_d)
+    assert e_s <= 1.5 * e_d + 1e-7, (e_s, e_d)
+    assert e_o < 2e-6 * max(1.0, np.abs(ref).max()), e_o
+
+
+@pytest.mark.parametrize("items,H,W,act", [(1, 8, 32, True), (3, 5, 7, False), (1, 1, 1, True), (2, 64, 96, True), (7, 33, 70, True), (1, 9, 130, True)])
+def test_conv3x3_split16_sf_output(items, H, W, act):
+    """conv1_i writing the split format (conv3x3_split16_kernel<0, OSF>): hi + lo' 2^-11 of what it writes is the fp32 kernel's
+    output to 2^-22 relative (the split keeps 22 mantissa bits) - and hi is exactly f16(value), lo' exactly f16((value - hi) 2^11),
+    which the consumers' parity tests cover by construction (same operands as the in-kernel split)."""
+    rng = np.random.default_rng(items * 77 + H * 10 + W)
+    x = rng.normal(size=(items, H, W, 64)).astype(np.float32)
+    k = (rng.normal(size=(3, 3, 64, 64)) / 24.0).astype(np.float32)
+    b = (rng.normal(size=64) * 0.1).astype(np.float32)
+    got = ops.conv3x3_winograd(dev(x), k, b, act=act, variant="split16_sf_out").cpu().numpy()
+    old = ops.conv3x3_winograd(dev(x), k, b, act=act, variant="split16").cpu().numpy()
+    rel = np.abs(got - old) / np.maximum(np.abs(old), 2.0 ** -14)
+    print(f"sf_out {items}x{H}x{W}: max rel {rel.max():.3g}")
+    assert rel.max() <= 2.0 ** -21, rel.max()
+
+
+@pytest.mark.parametrize("T,items,H,W", [(7, 2, 16, 32), (5, 1, 6, 10), (3, 3, 9, 7), (7, 4, 64, 64)])
+@pytest.mark.parametrize("io", ["10", "01", "11"])
+def test_conv1x1_split16_sf(T, items, H, W, io):
+    """conv10_i with its input and / or output in the split format: against the fp64 spec at the tolerance of the fp32-interface
+    kernel, and against that kernel."""
+    rng = np.random.default_rng(T * 100 + H)
+    x = rng.normal(size=(items * T, H, W, 64)).astype(np.float32)
+    k = (rng.normal(size=(1, 1, 64 * T, 64)) / np.sqrt(64 * T)).astype(np.float32)
+    b = (rng.normal(size=64) * 0.1).astype(np.float32)
+    xc = x.reshape(items, T, H, W, 64).transpose(0, 2, 3, 1, 4).reshape(items, H, W, T * 64)
+    ref = pfnl_spec.lrelu(pfnl_spec.conv2d_same(xc.astype(np.float64), k.astype(np.float64), b.astype(np.float64)))
+    got = ops.conv1x1_stream(dev(x), k, b, frames_per_item=T, act=True, variant="split16_sf:" + io).cpu().numpy()
+    old = ops.conv1x1_stream(dev(x), k, b, frames_per_item=T, act=True, variant="split16").cpu().numpy()
+    e, e_o = np.abs(got - ref).max(), np.abs(got - old).max()
+    print(f"conv1x1 sf {io} T{T} {items}x{H}x{W}: err {e:.3g}, vs fp32-interface kernel {e_o:.3g}")
+    assert e < 4e-6 * max(1.0, np.abs(ref).max()), e
+    assert e_o < 2e-6 * max(1.0, np.abs(ref).max()), e_o
+
+
 def test_conv3x3_split16_scaling_and_data_movement():
     """Accuracy does not depend on the magnitude of the activations inside binary16's range (lo' is kept scaled by 2^11, so
     small values do not lean on binary16 subnormals); a delta kernel moves data bit-exactly (hi + lo' 2^-11 reconstructs x
