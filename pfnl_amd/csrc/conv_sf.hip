@@ -67,7 +67,18 @@ __device__ __forceinline__ void sf_store_b32(float v, __amdgpu_buffer_rsrc_t rs,
     asm volatile("s_nop 1" ::"v"(v));
 }
 
-__device__ __forceinline__ f32x16 sf_mfma(sfh8 a, sfh8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 sf_mfma(sfh8 a, sfh8 b, f32x16 c) {
+#ifdef SF_X_NOMFMA   /* timing experiments only (wrong results on purpose; tools/sf_variants.sh) */
+    c[0] += (float)a[0] * (float)b[0];
+    return c;
+#endif
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+#ifdef SF_X_NODMA
+#define SF_DMA16(rs_, dst_, voff_) do { if ((voff_) == 0x12345) sf_dma16(rs_, dst_, voff_); } while (0)
+#else
+#define SF_DMA16(rs_, dst_, voff_) sf_dma16(rs_, dst_, voff_)
+#endif
 
 // MODE 0: out = act(conv + bias).   MODE 1 (conv2_i per-frame half): out = act(conv + bias + addend[item / add_div]) + resid.
 template <int MODE>
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_kernel(ConvSplitPara
             if (k_ < SF_DMA_ITERS - 1 || i_ < SF_NDMA) {                                         \
                 const int gy_ = (y0_) + (dpk[k_] & 0xff) - 1, gx_ = (x0_) + (dpk[k_] >> 8) - 1;  \
                 const bool in_ = (interior_) || ((unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W && (dpk[k_] & 0xff) < SF_IH); \
-                sf_dma16(rs_, lds0 + (buf_) * SF_TILE_BYTES + i_ * 1024, in_ ? (org_) + dgrel[k_] : 0x7fffffff); \
+                SF_DMA16(rs_, lds0 + (buf_) * SF_TILE_BYTES + i_ * 1024, in_ ? (org_) + dgrel[k_] : 0x7fffffff); \
             }                                                                                    \
         }                                                                                        \
     } while (0)
@@ -188,8 +199,16 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_kernel(ConvSplitPara
         if constexpr (FUSE) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+#ifdef SF_X_NOADDEND
+                radd[4 * q + j] = 0.25f;
+#else
                 radd[4 * q + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, evoff + j * 256, q * 2048, 0));
+#endif
+#ifdef SF_X_NORESID
+                rres[4 * q + j] = 0.125f;
+#else
                 rres[4 * q + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, evoff + j * 256, q * 2048, 0));
+#endif
             }
         }
     };
@@ -201,6 +220,9 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_kernel(ConvSplitPara
             const float sv = v * slope;
             asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(sv)); // leaky_relu(0.2) or identity (slope 1), branch-free
             if constexpr (FUSE) v += rres[4 * q + j];
+#ifdef SF_X_NOSTORE
+            if (v == 1.2345e30f)
+#endif
             sf_store_b32<SF_STORE_AUX>(v, rsO, evoff + j * 256, q * 2048);
         }
     };
