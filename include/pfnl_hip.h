@@ -86,6 +86,8 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *   "direct"        implicit-GEMM f32 MFMA (conv_mfma.hip);
  *   "split16"       direct 3x3 on the f16 matrix pipe with exactly split fp32 operands (3 f16 MFMAs per product block,
  *                   fp32 accumulation, >= 22 mantissa bits per product: conv_split16.hip).
+ * key "small" = "auto" (default: the small-shape trunk kernels of conv_small.hip when a 3x3 launch has fewer than 256 tiles of 8x32
+ *   pixels - 3 launches per progressive-fusion block, conv2_i as one 128 -> 64 convolution) | "on" | "off".
  * key "split16_sf" = "on" (default) | "off": with conv3x3 and conv1x1 on "split16", conv1_i and conv10_i write the split format
  *   (hi, lo' binary16 pairs: the MFMA operands themselves) and both halves of conv2_i read it by LDS-DMA (conv_sf.hip).
  * key "conv1x1" = "split16" (default: streaming kernel on the f16 pipe, exactly split fp32 operands) | "stream" (streaming f32-MFMA
@@ -232,6 +234,13 @@ int pfnl_op_conv3x3_split16_sf(int which, const float* in, const float* kernel_h
                                int add_div, const float* resid, float* out, int items, int H, int W, int act, void* stream);
 int pfnl_op_conv1x1_split16_sf(const float* in, const float* kernel_host, const float* bias_host, float* out, int items,
                                int frames_per_item, int HW, int act, int in_sf, int out_sf, void* stream);
+/* The small-shape trunk kernel (pfnl_amd/csrc/conv_small.hip; BASELINE.json configs[0] / configs[4]): conv1_i, conv10_i, the whole of
+ * conv2_i (3x3 over concat([base, f]), model/pfnl.py:69-71) and convmerge1 as one template.  Source s of output item i is
+ * s < nA ? a[i / a_div] : b[i * b_mul + (s - nA)] ([.][H][W][64] fp32 each); kernel HWIO [ks, ks, 64 nsrc, cout <= 64];
+ * out [items][H][W][64] (channels >= cout are written as act(0)); resid may alias out. */
+int pfnl_op_conv_small(const float* a, const float* b, int nA, int a_div, int b_mul, int nsrc, const float* kernel_host,
+                       const float* bias_host, const float* resid, float* out, int items, int H, int W, int ks, int cout, int act,
+                       void* stream);
 /* conv1_i and conv10_i of a progressive-fusion block (reference model/pfnl.py:66-68) in ONE launch of the bf16 3x3 kernel:
  * out1 = lrelu(conv3x3(in) + b1) [clips*fpc, H, W, 64], base = lrelu(conv1x1(concat_t out1_t) + b10) [clips, H, W, 64];
  * the 1x1 contraction reads every finished tile from LDS.  fpc in {3,5,7}. */

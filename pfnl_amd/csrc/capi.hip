@@ -13,6 +13,7 @@
 #include "common.h"
 #include "conv_bf16.h"
 #include "conv_split16.h"
+#include "conv_small.h"
 
 namespace {
 
@@ -99,6 +100,9 @@ struct pfnl_handle {
     DevBuf wdev16s;                                           // split-f16 packs of the 3x3 kernels (offsets in 16-bit elements)
     std::vector<size_t> off16s_c1, off16s_c2a, off16s_c2b, off16s_c10;
     std::vector<size_t> off16s_c2a_sf, off16s_c2b_sf;         // ... with the identity row map conv3x3_sf_kernel takes (conv_sf.hip)
+    std::vector<size_t> off16m_c1, off16m_c10, off16m_c2;     // small-shape packs (conv_small.hip), in the same blob
+    size_t off16m_m1 = 0;
+    int small_mode = 0;                                       // option small=auto|on|off: the small-shape trunk kernels (auto: when a launch has < 256 tiles of 8x32 pixels)
     bool sf_path = true;                                      // option split16_sf=on|off: with conv3x3 = conv1x1 = split16, conv1_i and conv10_i write the
                                                               // split format (conv_split16.h) and both halves of conv2_i read it by LDS-DMA (conv_sf.hip)
 
@@ -325,10 +329,33 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
     const int tiles8x32 = F * ((W + 31) / 32) * ((H + 7) / 8);
     const int algo = h->conv_algo == 5 ? ((tiles8x32 >= 256 && (long long)H * W * 256 < 0x7fffffffLL) ? 4 : 3) : h->conv_algo;
     const bool sf = algo == 4 && h->conv1x1_algo == 2 && h->sf_path;   // inp1 and base in the split format (conv_split16.h)
+    // small shapes (BASELINE.json configs[0], configs[4]): the trunk through conv_small.hip - 3 launches per block, conv2_i as the
+    // reference writes it (3x3 over concat([base, f])); only under the default algorithm choices
+    const bool small = !h->bf16 && (long long)H * W * 256 < 0x7fffffffLL &&
+                       (h->small_mode == 1 || (h->small_mode == 0 && h->conv_algo == 5 && h->conv1x1_algo == 2 && tiles8x32 < 256));
+    const uint16_t* const w16m = reinterpret_cast<const uint16_t*>(h->wdev16s.p);
     for (int i = 0; i < (h->bf16 ? 0 : c.num_block); ++i) {   // model/pfnl.py:65-71
         if (h->prof_mode == 2) {          // sampled profiling: blocks 0, 4, 8, ... each with a fresh event chain
             h->prof_gate = (i & 3) == 0;
             h->chain_open = false;
+        }
+        if (small) {
+            {   // conv1_i (:66)
+                ProfScope ps(h, s, PFNL_K_CONV3X3);
+                ConvSmallParams q{nullptr, h->inp0.p, 0, 1, 1, 1, w16m + h->off16m_c1[i], wd + h->off_c1_b[i], nullptr, h->inp1.p, H, W, F, 1, 3};
+                HIPCHK(launch_conv_small(q, s));
+            }
+            {   // conv10_i (:67-68)
+                ProfScope ps(h, s, PFNL_K_CONV1X1);
+                ConvSmallParams q{nullptr, h->inp1.p, 0, 1, T, T, w16m + h->off16m_c10[i], wd + h->off_c10_b[i], nullptr, h->base.p, H, W, B, 1, 1};
+                HIPCHK(launch_conv_small(q, s));
+            }
+            {   // conv2_i over concat([base, inp1_t]) + lrelu + residual (:69-71)
+                ProfScope ps(h, s, PFNL_K_CONV3X3);
+                ConvSmallParams q{h->base.p, h->inp1.p, 1, T, 1, 2, w16m + h->off16m_c2[i], wd + h->off_c2_b[i], h->inp0.p, h->inp0.p, H, W, F, 1, 3};
+                HIPCHK(launch_conv_small(q, s));
+            }
+            continue;
         }
         {   // conv1_i: per frame 3x3 64->64 + lrelu                       (:66)
             ProfScope ps(h, s, PFNL_K_CONV3X3);
@@ -434,6 +461,21 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
     }
     h->prof_gate = true;
     if (h->prof_mode == 2) h->chain_open = false;
+    if (small && !h->bf16) {   // convmerge1 (:73-74): T sources, cout 48 zero-padded to 64
+        {
+            ProfScope ps(h, s, PFNL_K_MERGE1);
+            ConvSmallParams q{nullptr, merge_in, 0, 1, T, T, w16m + h->off16m_m1, wd + h->off_m1_b, nullptr, h->merge.p, H, W, B, 1, 3};
+            HIPCHK(launch_conv_small(q, s));
+        }
+        h->merge_cstride = 64;
+        {   // model/pfnl.py:63,76-80
+            ProfScope ps(h, s, PFNL_K_TAIL);
+            HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, Hfull, W, c.scale, 64, s, strip));
+        }
+        h->chain_open = false;
+        h->prof_gate = true;
+        return 0;
+    }
     const bool m1_s16 = algo == 4 && h->m1_algo != 2 && (long long)H * W * 256 < 0x7fffffffLL;
     const bool m1_wino = !m1_s16 && (algo == 3 || algo == 4) && wino_groups >= 224 && (long long)H * W * 256 < 0x7fffffffLL;
     const int mstride = (m1_wino || m1_s16) ? 64 : 48;
@@ -512,6 +554,7 @@ int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
     HIPCHK(hipSetDevice(cfg->device_id));
     pfnl_handle* h = new pfnl_handle();
     h->cfg = *cfg;
+    if (const char* e = std::getenv("PFNL_SMALL")) h->small_mode = std::string(e) == "on" ? 1 : (std::string(e) == "off" ? 2 : 0);   // (A/B runs)
     if (const char* e = std::getenv("PFNL_SPLIT16_SF")) h->sf_path = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_CONV3X3")) {
         const std::string v(e);
@@ -606,6 +649,13 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         else if (v == "split16") h->conv_algo = 4;
         else if (v == "auto") h->conv_algo = 5;
         else return fail(PFNL_ERR_INVALID, "conv3x3 must be auto, split16, winograd, winograd_tile or direct");
+        return 0;
+    }
+    if (k == "small") {
+        if (v == "auto") h->small_mode = 0;
+        else if (v == "on") h->small_mode = 1;
+        else if (v == "off") h->small_mode = 2;
+        else return fail(PFNL_ERR_INVALID, "small must be auto, on or off");
         return 0;
     }
     if (k == "split16_sf") {
@@ -829,7 +879,14 @@ int pfnl_finalize_weights(pfnl_handle* h) {
         h->off16s_c2a_sf.assign(nb, 0);
         h->off16s_c2b_sf.assign(nb, 0);
         h->off16s_m1 = (size_t)nb * (5 * n3 + n1);
-        b16.resize((size_t)nb * (5 * n3 + n1) + (size_t)T * n3 + 2, 0);
+        const size_t m3 = pfnl::conv_small_pack_halfs(3, 1), m10 = pfnl::conv_small_pack_halfs(1, T);
+        const size_t small_base = (size_t)nb * (5 * n3 + n1) + (size_t)T * n3;
+        h->off16m_c1.assign(nb, 0);
+        h->off16m_c10.assign(nb, 0);
+        h->off16m_c2.assign(nb, 0);
+        h->off16m_m1 = small_base + (size_t)nb * (3 * m3 + m10);
+        b16.resize(h->off16m_m1 + (size_t)T * m3 + 2, 0);
+        pfnl::conv_small_pack_weights(W("convmerge1").data(), 3, T, 48, &b16[h->off16m_m1]);
         for (int f = 0; f < T; ++f)
             pfnl::conv3x3_split16_pack_weights(W("convmerge1").data(), 64 * T, 64 * f, &b16[h->off16s_m1 + (size_t)f * n3], 48);
         for (int i = 0; i < nb; ++i) {
@@ -842,6 +899,12 @@ int pfnl_finalize_weights(pfnl_handle* h) {
             h->off16s_c2b_sf[i] = h->off16s_c2a_sf[i] + n3;
             pfnl::conv3x3_split16_pack_weights(W("conv2_" + s).data(), 128, 0, &b16[h->off16s_c2a_sf[i]], 64, true);
             pfnl::conv3x3_split16_pack_weights(W("conv2_" + s).data(), 128, 64, &b16[h->off16s_c2b_sf[i]], 64, true);
+            h->off16m_c1[i] = small_base + (size_t)i * (3 * m3 + m10);
+            h->off16m_c2[i] = h->off16m_c1[i] + m3;
+            h->off16m_c10[i] = h->off16m_c1[i] + 3 * m3;
+            pfnl::conv_small_pack_weights(W("conv1_" + s).data(), 3, 1, 64, &b16[h->off16m_c1[i]]);
+            pfnl::conv_small_pack_weights(W("conv2_" + s).data(), 3, 2, 64, &b16[h->off16m_c2[i]]);
+            pfnl::conv_small_pack_weights(W("conv10_" + s).data(), 1, T, 64, &b16[h->off16m_c10[i]]);
             pfnl::conv1x1_split16_pack_weights(W("conv10_" + s).data(), T, &b16[h->off16s_c10[i]]);
             pfnl::conv3x3_split16_pack_weights(W("conv1_" + s).data(), 64, 0, &b16[h->off16s_c1[i]]);
             pfnl::conv3x3_split16_pack_weights(W("conv2_" + s).data(), 128, 0, &b16[h->off16s_c2a[i]]);
@@ -1394,6 +1457,30 @@ int pfnl_op_conv1x1_split16(const float* in, const float* kernel_host, const flo
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(dw);
     if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv1x1 split16 op: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// The small-shape trunk kernel (conv_small.hip; ConvSmallParams in conv_small.h says which tensor each source comes from):
+// out[i] = act(sum_s conv_ks(src(i, s); kernel rows [64 s, 64 s + 64)) + bias) (+ resid[i]); kernel HWIO [ks, ks, 64 nsrc, cout]
+int pfnl_op_conv_small(const float* a, const float* b, int nA, int a_div, int b_mul, int nsrc, const float* kernel_host,
+                       const float* bias_host, const float* resid, float* out, int items, int H, int W, int ks, int cout, int act,
+                       void* stream) {
+    if (!b || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (items < 1 || H < 1 || W < 1 || nsrc < 1 || nsrc > 16 || (ks != 1 && ks != 3) || cout < 1 || cout > 64 || nA < 0 || nA > nsrc || (nA && !a))
+        return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nh = pfnl::conv_small_pack_halfs(ks, nsrc);
+    std::vector<uint16_t> pack(nh + 128, 0);
+    pfnl::conv_small_pack_weights(kernel_host, ks, nsrc, cout, pack.data());
+    if (bias_host) std::memcpy(&pack[nh], bias_host, cout * sizeof(float));
+    uint16_t* dw = nullptr;
+    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(uint16_t)));
+    hipError_t e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    pfnl::ConvSmallParams q{a, b, nA, a_div < 1 ? 1 : a_div, b_mul < 1 ? 1 : b_mul, nsrc, dw, reinterpret_cast<const float*>(dw + nh), resid, out, H, W, items, act, ks};
+    if (e == hipSuccess) e = pfnl::launch_conv_small(q, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dw);
+    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv_small op: ") + hipGetErrorString(e));
     return 0;
 }
 

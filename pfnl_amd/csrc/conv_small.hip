@@ -1,0 +1,279 @@
+// Small-shape convolutions of the progressive-fusion trunk (BASELINE.json configs[0]: 7 x 32 x 32, configs[4]: 5 x 64 x 64; reference
+// model/pfnl.py:24 `in_size=32`, :65-74): conv1_i, conv10_i, the WHOLE of conv2_i (3x3 over concat([base, inp1_t]), 128 -> 64, as
+// the reference writes it - below ~a tile per CU the shared-base split only adds a launch) and convmerge1, as ONE kernel template.
+//
+// Why a kernel of its own: the persistent kernels (conv_split16.hip, conv_sf.hip, conv_wino_ws.hip) are built around 8 x 32-pixel
+// tiles, 72 KB of weights per workgroup in the prologue and one workgroup per CU - at 7 x 32 x 32 a launch has 28 such tiles
+// for 256 CUs and costs 15 - 27 us whatever it computes (round 2: 85 launches, 1.6 ms).  Here a workgroup is 4 waves and owns
+// R rows x 32 pixels x 64 output channels (R = 1 or 2, picked so that a launch has >= ~200 workgroups when it can), two
+// workgroups fit a CU, and nothing is resident: K (= taps x input channels) is walked source by source (a source = the 64
+// channels of one input tensor at the tile: a frame, or `base`), split over the 4 waves as (output channel tile nt, half kh of
+// every source's channels); the two K halves meet in LDS at the end.
+//   * arithmetic: that of conv_split16.hip - every fp32 operand split exactly into two binary16 numbers, three
+//     v_mfma_f32_32x32x16_f16 per product block, fp32 accumulation, cross terms in a second accumulator (x 2^-11 at the end);
+//   * activations fp32 NHWC in HBM (L2-resident at these sizes); a source's (R + 2) x 34 halo is loaded as 16-byte pieces, split on
+//     the way into LDS ([pixel][half][hi | lo'][32 ch], 16-byte chunks XOR-swizzled with the pixel column), double-buffered, one
+//     barrier per source; out-of-image pixels: out-of-range buffer offsets (zeros);
+//   * weights never touch LDS: they are the MFMA's B operand (lane = output channel), packed per wave in the order it walks
+//     them ([kh][nt][source][step][hi / lo'][lane] x 16 B) and streamed L2 -> registers through a ring 6 k-steps deep;
+//   * MFMA roles A = pixels, B = weights: D[pixel][cout], so the K-half partials go to LDS as conflict-free 4-byte stores and
+//     come back as whole 16-byte channel pieces for a coalesced NHWC epilogue (bias, leaky-relu, residual).
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+#include "common.h"
+#include "conv_small.h"
+
+namespace pfnl {
+
+typedef _Float16 cmh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 cmh4 __attribute__((ext_vector_type(4)));
+typedef unsigned cmu4 __attribute__((ext_vector_type(4)));
+typedef unsigned cmu2 __attribute__((ext_vector_type(2)));
+
+constexpr int CM_THREADS = 256;
+
+template <int KS, int R>
+struct CmGeom {
+    static constexpr int IH = R + KS - 1, IW = 32 + KS - 1;
+    static constexpr int NPIX = IH * IW;
+    static constexpr int BUF_BYTES = NPIX * 256;                    // one source's halo in operand form
+    static constexpr int PIECES = NPIX * 16;                        // 16-byte fp32 pieces (4 channels)
+    static constexpr int ITERS = (PIECES + CM_THREADS - 1) / CM_THREADS;
+    static constexpr int STEPS = 2 * KS * KS;                       // k-steps (16 channels x one tap) of a wave per source
+    static constexpr int RING = KS == 3 ? 6 : 2;                    // weight operands in flight (divides STEPS)
+    static constexpr int RED_BYTES = 2 * R * 32 * 256;              // the two K halves of the tile, fp32 pixel lines
+    static constexpr int LDS_BYTES = (2 * BUF_BYTES > RED_BYTES ? 2 * BUF_BYTES : RED_BYTES);
+};
+
+__device__ __forceinline__ void cm_split4(f32x4 v, cmu2& hi, cmu2& lo, float nscale) {   // conv_split16.hip split4
+    const cmh4 h = __builtin_convertvector(v, cmh4);
+    hi = __builtin_bit_cast(cmu2, h);
+    const f32x4 t = v * 2048.0f;
+    unsigned l0, l1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi.x), "s"(nscale), "v"(t.x));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l0) : "v"(hi.x), "s"(nscale), "v"(t.y));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi.y), "s"(nscale), "v"(t.z));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l1) : "v"(hi.y), "s"(nscale), "v"(t.w));
+    lo = cmu2{l0, l1};
+}
+
+template <int KS, int R>
+__global__ __launch_bounds__(CM_THREADS, 2) void conv_small_kernel(ConvSmallParams p) {
+    using G = CmGeom<KS, R>;
+    constexpr int PAD = KS / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char cm_smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = wave & 1;                                        // output channels 32 nt .. 32 nt + 31
+    const int kh = wave >> 1;                                       // channels 32 kh .. 32 kh + 31 of every source
+    const int H = p.H, W = p.W;
+    const int tiles_x = (W + 31) >> 5, tiles_y = (H + R - 1) / R;
+    const int per_item = tiles_x * tiles_y;
+    const int item = blockIdx.x / per_item;
+    const int sp = blockIdx.x - item * per_item;
+    const int ty = sp / tiles_x;
+    const int y0 = ty * R, x0 = (sp - ty * tiles_x) * 32;
+    const size_t hw64 = (size_t)H * W * 64;
+    const int item_bytes = H * W * 256;
+    const int wbytes = W * 256;
+    const int nsrc = p.nsrc;
+    const int ntot = nsrc * G::STEPS;                               // k-steps of this wave
+
+    // staging map: piece id = k * 256 + tid -> halo pixel id >> 4, 4-channel piece c = id & 15.  LDS: pixel * 256 B, 16-byte chunk
+    // index = 8 M + 4 part + (channel group of 8 within the half), stored at chunk ^ (column & 15); a piece is half a chunk.
+    int grel[G::ITERS], lpk[G::ITERS];
+#pragma unroll
+    for (int k = 0; k < G::ITERS; ++k) {
+        const int id = min(k * CM_THREADS + tid, G::PIECES - 1);    // surplus threads redo the last piece (same value)
+        const int pix = id >> 4, c = id & 15;
+        const int py = pix / G::IW, px = pix - py * G::IW;
+        const int chunk = (c >> 3) * 8 + ((c & 7) >> 1);            // hi part; lo' = chunk + 4
+        grel[k] = py * wbytes + px * 256 + c * 16;
+        lpk[k] = (pix * 256 + ((chunk ^ (px & 15)) << 4) + (c & 1) * 8) | (py << 16) | (px << 24);
+    }
+    const float nscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -2048.0f)));
+    f32x4 stg[G::ITERS];
+    auto request = [&](int s) __attribute__((always_inline)) {
+        const float* src = s < p.nA ? p.a + (size_t)(item / p.a_div) * hw64 : p.b + ((size_t)item * p.b_mul + (s - p.nA)) * hw64;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, item_bytes, 0x00020000);
+        const int org = ((y0 - PAD) * W + x0 - PAD) * 256;
+#pragma unroll
+        for (int k = 0; k < G::ITERS; ++k) {
+            const int gy = y0 + ((lpk[k] >> 16) & 0xff) - PAD, gx = x0 + ((unsigned)lpk[k] >> 24) - PAD;
+            const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            stg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, in ? org + grel[k] : 0x7fffffff, 0, 0));
+        }
+    };
+    auto commit = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < G::ITERS; ++k) {
+            cmu2 hi, lo;
+            cm_split4(stg[k], hi, lo, nscale);
+            const int a = (lpk[k] & 0xffff) + buf * G::BUF_BYTES;
+            *reinterpret_cast<cmu2*>(cm_smem + a) = hi;
+            *reinterpret_cast<cmu2*>(cm_smem + (a ^ 64)) = lo;      // lo' chunk = hi chunk ^ 4
+        }
+    };
+
+    // pixel operand of (tap ky kx, row r, step parity jj, part): chunk 8 kh + 4 part + 2 jj + (lane >> 5) of halo pixel
+    // (r + ky, (lane & 31) + kx): address = paddr[kx] ^ (part * 64 + jj * 32) + (r + ky) * IW * 256
+    int paddr[KS];
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+        const int col = (lane & 31) + kx;
+        paddr[kx] = col * 256 + (((kh * 8 + (lane >> 5)) ^ (col & 15)) << 4);
+    }
+    // weights: this wave's steps are contiguous: [kh][nt][source][step][part][lane] x 16 B
+    const cmu4* const wsrc = reinterpret_cast<const cmu4*>(p.wpack) + ((size_t)(kh * 2 + nt) * ntot) * 128 + lane;
+    cmu4 wring[G::RING][2];
+#pragma unroll
+    for (int n = 0; n < G::RING; ++n) {
+        const int m = min(n, ntot - 1);
+        wring[n][0] = wsrc[(size_t)m * 128];
+        wring[n][1] = wsrc[(size_t)m * 128 + 64];
+    }
+    f32x16 accm[R], accc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            accm[r][i] = 0.f;
+            accc[r][i] = 0.f;
+        }
+
+    request(0);
+    commit(0);
+    __syncthreads();
+    for (int c = 0; c < nsrc; ++c) {
+        const unsigned char* const tile = cm_smem + (c & 1) * G::BUF_BYTES;
+        request(min(c + 1, nsrc - 1));                              // (past the end: the last source again - a harmless re-read)
+        const int nbase = c * G::STEPS;
+        auto step = [&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int tap = j >> 1, jj = j & 1, ky = tap / KS, kx = tap % KS;
+            const cmh8 wh = __builtin_bit_cast(cmh8, wring[j % G::RING][0]), wo = __builtin_bit_cast(cmh8, wring[j % G::RING][1]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const unsigned char* const q = tile + (r + ky) * (G::IW * 256);
+                const cmh8 ah = *reinterpret_cast<const cmh8*>(q + (paddr[kx] ^ (jj * 32)));
+                const cmh8 al = *reinterpret_cast<const cmh8*>(q + (paddr[kx] ^ (64 + jj * 32)));
+                accm[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, accm[r], 0, 0, 0);
+                accc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wo, accc[r], 0, 0, 0);
+                accc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, accc[r], 0, 0, 0);
+            }
+            const int m = min(nbase + j + G::RING, ntot - 1);       // the ring slot is free again: RING steps ahead
+            wring[j % G::RING][0] = wsrc[(size_t)m * 128];
+            wring[j % G::RING][1] = wsrc[(size_t)m * 128 + 64];
+        };
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        if constexpr (KS == 3) {
+            step(std::integral_constant<int, 2>{});
+            step(std::integral_constant<int, 3>{});
+            step(std::integral_constant<int, 4>{});
+            step(std::integral_constant<int, 5>{});
+            step(std::integral_constant<int, 6>{});
+            step(std::integral_constant<int, 7>{});
+            step(std::integral_constant<int, 8>{});
+            step(std::integral_constant<int, 9>{});
+            step(std::integral_constant<int, 10>{});
+            step(std::integral_constant<int, 11>{});
+            step(std::integral_constant<int, 12>{});
+            step(std::integral_constant<int, 13>{});
+            step(std::integral_constant<int, 14>{});
+            step(std::integral_constant<int, 15>{});
+            step(std::integral_constant<int, 16>{});
+            step(std::integral_constant<int, 17>{});
+        }
+        commit((c & 1) ^ 1);
+        __syncthreads();                                            // the next source is complete; this one's buffer is free
+    }
+
+    // ---- the two K halves meet in LDS (the halo buffers are free now): [kh][row][pixel] x 256 B
+    {
+        float* const red = reinterpret_cast<float*>(cm_smem) + (kh * R * 32) * 64 + 32 * nt + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[(r * 32 + drow(i, lane)) * 64] = accm[r][i] + accc[r][i] * (1.0f / 2048.0f);
+    }
+    __syncthreads();
+    const float slope = p.act ? 0.2f : 1.0f;
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + (tid & 15) * 4);
+#pragma unroll
+    for (int k = 0; k < (R * 32 * 16) / CM_THREADS; ++k) {
+        const int id = k * CM_THREADS + tid;
+        const int pp = id >> 4, cc = id & 15;                       // pixel r * 32 + x of the tile, 4-channel piece
+        const int y = y0 + (pp >> 5), x = x0 + (pp & 31);
+        f32x4 v = *reinterpret_cast<const f32x4*>(cm_smem + pp * 256 + cc * 16) +
+                  *reinterpret_cast<const f32x4*>(cm_smem + (R * 32 + pp) * 256 + cc * 16) + bias4;
+        v.x = fmaxf(v.x, v.x * slope);
+        v.y = fmaxf(v.y, v.y * slope);
+        v.z = fmaxf(v.z, v.z * slope);
+        v.w = fmaxf(v.w, v.w * slope);
+        if (y < H && x < W) {
+            const size_t o = (((size_t)item * H + y) * W + x) * 64 + cc * 4;
+            if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
+            *reinterpret_cast<f32x4*>(p.out + o) = v;
+        }
+    }
+}
+
+template <int KS, int R>
+static hipError_t cm_launch(const ConvSmallParams& p, int tiles, hipStream_t s) {
+    using G = CmGeom<KS, R>;
+    static bool attr_dev[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_dev[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_small_kernel<KS, R>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_dev[dev] = true;
+    }
+    hipLaunchKernelGGL((conv_small_kernel<KS, R>), dim3(tiles), dim3(CM_THREADS), G::LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_small(const ConvSmallParams& p, hipStream_t s) {
+    if (!p.b || !p.wpack || !p.bias || !p.out || p.items < 1 || p.H < 1 || p.W < 1 || p.nsrc < 1 || p.nA < 0 || p.nA > p.nsrc) return hipErrorInvalidValue;
+    if ((p.nA > 0 && (!p.a || p.a_div < 1)) || p.b_mul < 1 || (p.ks != 1 && p.ks != 3)) return hipErrorInvalidValue;
+    if ((long long)p.H * p.W * 256 >= 0x7fffffffLL) return hipErrorInvalidValue;
+    const int tiles_x = (p.W + 31) / 32;
+    const long long t2 = (long long)p.items * ((p.H + 1) / 2) * tiles_x, t1 = (long long)p.items * p.H * tiles_x;
+    const bool r2 = t2 >= 200;                                      // two rows per workgroup once that still fills the chip
+    if ((r2 ? t2 : t1) > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (p.ks == 3) return r2 ? cm_launch<3, 2>(p, (int)t2, s) : cm_launch<3, 1>(p, (int)t1, s);
+    return r2 ? cm_launch<1, 2>(p, (int)t2, s) : cm_launch<1, 1>(p, (int)t1, s);
+}
+
+size_t conv_small_pack_halfs(int ks, int nsrc) { return (size_t)nsrc * ks * ks * 4 * 2 * 2 * 512; }   // per source: taps x 4 channel groups x 2 nt x (hi, lo') x 1 KB
+
+// HWIO [ks, ks, 64 * nsrc, cout] -> [kh][nt][source][step j = 2 tap + jj][part][lane][e]:
+// W[tap][64 s + 16 (2 kh + jj) + 8 (lane >> 5) + e][32 nt + (lane & 31)], part 0 = f16(w), part 1 = f16((w - hi) 2^11); cout < 64: zero-padded
+void conv_small_pack_weights(const float* hwio, int ks, int nsrc, int cout, uint16_t* dst) {
+    const int steps = 2 * ks * ks, cin = 64 * nsrc;
+    for (int kh = 0; kh < 2; ++kh)
+        for (int nt = 0; nt < 2; ++nt)
+            for (int s = 0; s < nsrc; ++s)
+                for (int j = 0; j < steps; ++j)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int tap = j >> 1, jj = j & 1;
+                            const int ci = 64 * s + 16 * (2 * kh + jj) + 8 * (lane >> 5) + e;
+                            const int co = 32 * nt + (lane & 31);
+                            const float w = co < cout ? hwio[((size_t)tap * cin + ci) * cout + co] : 0.f;
+                            const _Float16 hi = (_Float16)w;
+                            const _Float16 lo = (_Float16)((w - (float)hi) * 2048.0f);
+                            uint16_t hb, lb;
+                            std::memcpy(&hb, &hi, 2);
+                            std::memcpy(&lb, &lo, 2);
+                            const size_t n = ((size_t)(kh * 2 + nt) * nsrc + s) * steps + j;
+                            dst[n * 1024 + lane * 8 + e] = hb;
+                            dst[n * 1024 + 512 + lane * 8 + e] = lb;
+                        }
+}
+
+}  // namespace pfnl

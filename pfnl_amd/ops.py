@@ -196,6 +196,27 @@ def conv1x1_stream(x, kernel, bias=None, act=True, frames_per_item=1, variant="s
     return out
 
 
+def conv_small(b, kernel, bias=None, a=None, a_div=1, b_mul=1, resid=None, items=None, act=True):
+    """The small-shape trunk kernel (conv_small.hip): out[i] = act(sum_s conv(src(i, s)) + bias) (+ resid[i]) with
+    src(i, s) = a[i // a_div] for s < nA (nA = 1 if `a` is given) else b[i * b_mul + s - nA]; kernel HWIO [ks, ks, 64 * nsrc, cout]."""
+    import torch
+    lib = _capi.load_library()
+    k = _host(kernel, "kernel")
+    bs = _host(bias, "bias")
+    ks, _, cin, cout = k.shape
+    nsrc = cin // 64
+    nA = 1 if a is not None else 0
+    Fb, H, W, c = b.shape
+    if items is None:
+        items = Fb // b_mul
+    out = torch.zeros((items, H, W, 64), dtype=torch.float32, device=b.device)
+    _capi.check(lib.pfnl_op_conv_small(
+        _req(a, "a") if a is not None else None, _req(b, "b"), nA, int(a_div), int(b_mul), nsrc, k.ctypes.data_as(C.c_void_p),
+        bs.ctypes.data_as(C.c_void_p) if bs is not None else None, _req(resid, "resid") if resid is not None else None,
+        _req(out, "out"), items, H, W, ks, cout, 1 if act else 0, _stream(b)))
+    return out
+
+
 def conv3x3_winograd(x, kernel, bias=None, act=True, addend=None, add_div=1, resid=None, variant="winograd"):
     """The 3x3 64->64 'same' convolution through the fused Winograd F(2x2,3x3) kernel (even H, W)."""
     import torch

@@ -445,6 +445,49 @@ def test_conv1x1_split16_sf(T, items, H, W, io):
     assert e_o < 2e-6 * max(1.0, np.abs(ref).max()), e_o
 
 
+@pytest.mark.parametrize("T,clips,H,W", [(7, 1, 32, 32), (5, 1, 64, 64), (7, 2, 9, 38), (3, 1, 2, 2), (7, 1, 33, 70), (5, 3, 16, 24)])
+def test_conv_small_trunk_ops(T, clips, H, W):
+    """conv_small.hip (BASELINE.json configs[0] / configs[4] path): conv1_i, conv10_i, the whole of conv2_i over
+    concat([base, f]) with residual, and convmerge1 (448 -> 48) against the fp64 spec written as model/pfnl.py:66-74; ragged
+    tiles, one and two rows per workgroup."""
+    rng = np.random.default_rng(T * 1000 + H * 10 + W)
+    F = clips * T
+    x = rng.normal(size=(F, H, W, 64)).astype(np.float32)
+    x64 = x.astype(np.float64)
+
+    def check(got, ref, what):
+        e = np.abs(got - ref).max()
+        print(f"conv_small {what} T{T} {clips}x{H}x{W}: err {e:.3g} (|ref| <= {np.abs(ref).max():.3g})")
+        assert e < 4e-6 * max(1.0, np.abs(ref).max()), (what, e)
+
+    k1 = (rng.normal(size=(3, 3, 64, 64)) / 24.0).astype(np.float32)
+    b1 = (rng.normal(size=64) * 0.1).astype(np.float32)
+    ref1 = pfnl_spec.lrelu(pfnl_spec.conv2d_same(x64, k1.astype(np.float64), b1.astype(np.float64)))
+    got1 = ops.conv_small(dev(x), k1, b1).cpu().numpy()
+    check(got1, ref1, "conv1")
+
+    k10 = (rng.normal(size=(1, 1, 64 * T, 64)) / np.sqrt(64 * T)).astype(np.float32)
+    xc = x64.reshape(clips, T, H, W, 64).transpose(0, 2, 3, 1, 4).reshape(clips, H, W, T * 64)
+    ref10 = pfnl_spec.lrelu(pfnl_spec.conv2d_same(xc, k10.astype(np.float64), b1.astype(np.float64)))
+    got10 = ops.conv_small(dev(x), k10, b1, b_mul=T).cpu().numpy()
+    check(got10, ref10, "conv10")
+
+    base = rng.normal(size=(clips, H, W, 64)).astype(np.float32)
+    res = rng.normal(size=(F, H, W, 64)).astype(np.float32)
+    k2 = (rng.normal(size=(3, 3, 128, 64)) / 34.0).astype(np.float32)
+    cat = np.concatenate([np.repeat(base.astype(np.float64), T, axis=0), x64], axis=-1)
+    ref2 = pfnl_spec.lrelu(pfnl_spec.conv2d_same(cat, k2.astype(np.float64), b1.astype(np.float64))) + res
+    got2 = ops.conv_small(dev(x), k2, b1, a=dev(base), a_div=T, resid=dev(res)).cpu().numpy()
+    check(got2, ref2, "conv2")
+
+    km = (rng.normal(size=(3, 3, 64 * T, 48)) / np.sqrt(9 * 64 * T)).astype(np.float32)
+    bm = (rng.normal(size=48) * 0.1).astype(np.float32)
+    refm = pfnl_spec.lrelu(pfnl_spec.conv2d_same(xc, km.astype(np.float64), bm.astype(np.float64)))
+    gotm = ops.conv_small(dev(x), km, bm, b_mul=T).cpu().numpy()
+    check(gotm[..., :48], refm, "convmerge1")
+    assert not gotm[..., 48:].any()
+
+
 def test_conv3x3_split16_scaling_and_data_movement():
     """Accuracy does not depend on the magnitude of the activations inside binary16's range (lo' is kept scaled by 2^11, so
     small values do not lean on binary16 subnormals); a delta kernel moves data bit-exactly (hi + lo' 2^-11 reconstructs x
