@@ -34,6 +34,13 @@ typedef unsigned cmu2 __attribute__((ext_vector_type(2)));
 
 constexpr int CM_THREADS = 256;
 
+#ifdef PFNL_CM_TIMING   /* phase timeline of a workgroup (tools/cm_timing.py); not part of the product build */
+__device__ long long cm_dbg[4096 * 16];
+#define CM_STAMP(i_) do { if (tid == 0 && blockIdx.x < 4096) cm_dbg[blockIdx.x * 16 + (i_)] = wall_clock64(); } while (0)
+#else
+#define CM_STAMP(i_) do {} while (0)
+#endif
+
 template <int KS, int R>
 struct CmGeom {
     static constexpr int IH = R + KS - 1, IW = 32 + KS - 1;
@@ -42,7 +49,7 @@ struct CmGeom {
     static constexpr int PIECES = NPIX * 16;                        // 16-byte fp32 pieces (4 channels)
     static constexpr int ITERS = (PIECES + CM_THREADS - 1) / CM_THREADS;
     static constexpr int STEPS = 2 * KS * KS;                       // k-steps (16 channels x one tap) of a wave per source
-    static constexpr int RING = KS == 3 ? 6 : 2;                    // weight operands in flight (divides STEPS)
+    static constexpr int RING = KS == 3 ? (R == 1 ? 9 : 6) : 2;     // weight operands in flight (divides STEPS; R = 1 has the registers for half a source)
     static constexpr int RED_BYTES = 2 * R * 32 * 256;              // the two K halves of the tile, fp32 pixel lines
     static constexpr int LDS_BYTES = (2 * BUF_BYTES > RED_BYTES ? 2 * BUF_BYTES : RED_BYTES);
 };
@@ -60,7 +67,7 @@ __device__ __forceinline__ void cm_split4(f32x4 v, cmu2& hi, cmu2& lo, float nsc
 }
 
 template <int KS, int R>
-__global__ __launch_bounds__(CM_THREADS, 2) void conv_small_kernel(ConvSmallParams p) {
+__global__ __launch_bounds__(CM_THREADS, R == 3 ? 1 : 2) void conv_small_kernel(ConvSmallParams p) {   // (R = 3: one workgroup per CU by construction)
     using G = CmGeom<KS, R>;
     constexpr int PAD = KS / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char cm_smem[];
@@ -144,29 +151,50 @@ __global__ __launch_bounds__(CM_THREADS, 2) void conv_small_kernel(ConvSmallPara
             accc[r][i] = 0.f;
         }
 
+    CM_STAMP(0);
     request(0);
+    CM_STAMP(1);
     commit(0);
+    CM_STAMP(2);
     __syncthreads();
+    CM_STAMP(3);
     for (int c = 0; c < nsrc; ++c) {
         const unsigned char* const tile = cm_smem + (c & 1) * G::BUF_BYTES;
-        request(min(c + 1, nsrc - 1));                              // (past the end: the last source again - a harmless re-read)
+        const bool more = c + 1 < nsrc;                             // (wave-uniform)
+        if (more) request(c + 1);
         const int nbase = c * G::STEPS;
-        auto step = [&](auto jc) __attribute__((always_inline)) {
+        // Written-out pipeline (left alone, hipcc sinks every weight load and every ds_read to the instruction in front of its MFMA
+        // and waits for it there: measured 6.8 us for 108 MFMAs): the pixel operands of step j + 1 are read before the MFMAs of
+        // step j, the ring slot a step has used is refilled right behind its MFMAs; sched_barrier fences hold the order.
+        cmh8 aop[2][R][2];
+        auto read_ops = [&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
             constexpr int tap = j >> 1, jj = j & 1, ky = tap / KS, kx = tap % KS;
-            const cmh8 wh = __builtin_bit_cast(cmh8, wring[j % G::RING][0]), wo = __builtin_bit_cast(cmh8, wring[j % G::RING][1]);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const unsigned char* const q = tile + (r + ky) * (G::IW * 256);
-                const cmh8 ah = *reinterpret_cast<const cmh8*>(q + (paddr[kx] ^ (jj * 32)));
-                const cmh8 al = *reinterpret_cast<const cmh8*>(q + (paddr[kx] ^ (64 + jj * 32)));
-                accm[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, accm[r], 0, 0, 0);
-                accc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wo, accc[r], 0, 0, 0);
-                accc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, accc[r], 0, 0, 0);
+                aop[j & 1][r][0] = *reinterpret_cast<const cmh8*>(q + (paddr[kx] ^ (jj * 32)));
+                aop[j & 1][r][1] = *reinterpret_cast<const cmh8*>(q + (paddr[kx] ^ (64 + jj * 32)));
             }
+        };
+        read_ops(std::integral_constant<int, 0>{});
+        auto step = [&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j + 1 < G::STEPS) read_ops(std::integral_constant<int, j + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            const cmh8 wh = __builtin_bit_cast(cmh8, wring[j % G::RING][0]), wo = __builtin_bit_cast(cmh8, wring[j % G::RING][1]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                accm[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop[j & 1][r][0], wh, accm[r], 0, 0, 0);
+                accc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop[j & 1][r][0], wo, accc[r], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) accc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop[j & 1][r][1], wh, accc[r], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             const int m = min(nbase + j + G::RING, ntot - 1);       // the ring slot is free again: RING steps ahead
             wring[j % G::RING][0] = wsrc[(size_t)m * 128];
             wring[j % G::RING][1] = wsrc[(size_t)m * 128 + 64];
+            __builtin_amdgcn_sched_barrier(0);
         };
         step(std::integral_constant<int, 0>{});
         step(std::integral_constant<int, 1>{});
@@ -188,11 +216,23 @@ __global__ __launch_bounds__(CM_THREADS, 2) void conv_small_kernel(ConvSmallPara
             step(std::integral_constant<int, 16>{});
             step(std::integral_constant<int, 17>{});
         }
-        commit((c & 1) ^ 1);
+        if (c == 0) CM_STAMP(4);
+        if (more) commit((c & 1) ^ 1);
         __syncthreads();                                            // the next source is complete; this one's buffer is free
     }
+    CM_STAMP(5);
 
     // ---- the two K halves meet in LDS (the halo buffers are free now): [kh][row][pixel] x 256 B
+    constexpr int EP = (R * 32 * 16) / CM_THREADS;
+    f32x4 rsd[EP];
+#pragma unroll
+    for (int k = 0; k < EP; ++k) {                                  // the residual pieces are requested now: their latency passes under the meeting
+        const int id = k * CM_THREADS + tid;
+        const int pp = id >> 4, cc = id & 15;
+        const int y = min(y0 + (pp / 32), H - 1), x = min(x0 + (pp & 31), W - 1);
+        rsd[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.resid) rsd[k] = *reinterpret_cast<const f32x4*>(p.resid + (((size_t)item * H + y) * W + x) * 64 + cc * 4);
+    }
     {
         float* const red = reinterpret_cast<float*>(cm_smem) + (kh * R * 32) * 64 + 32 * nt + (lane & 31);
 #pragma unroll
@@ -201,10 +241,11 @@ __global__ __launch_bounds__(CM_THREADS, 2) void conv_small_kernel(ConvSmallPara
             for (int i = 0; i < 16; ++i) red[(r * 32 + drow(i, lane)) * 64] = accm[r][i] + accc[r][i] * (1.0f / 2048.0f);
     }
     __syncthreads();
+    CM_STAMP(6);
     const float slope = p.act ? 0.2f : 1.0f;
     const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + (tid & 15) * 4);
 #pragma unroll
-    for (int k = 0; k < (R * 32 * 16) / CM_THREADS; ++k) {
+    for (int k = 0; k < EP; ++k) {
         const int id = k * CM_THREADS + tid;
         const int pp = id >> 4, cc = id & 15;                       // pixel r * 32 + x of the tile, 4-channel piece
         const int y = y0 + (pp >> 5), x = x0 + (pp & 31);
@@ -216,9 +257,91 @@ __global__ __launch_bounds__(CM_THREADS, 2) void conv_small_kernel(ConvSmallPara
         v.w = fmaxf(v.w, v.w * slope);
         if (y < H && x < W) {
             const size_t o = (((size_t)item * H + y) * W + x) * 64 + cc * 4;
-            if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
+            v += rsd[k];
             *reinterpret_cast<f32x4*>(p.out + o) = v;
         }
+    }
+    CM_STAMP(7);
+}
+
+// ---- conv10_i at small shapes: a 1x1 has no halo, so the A operand comes straight from HBM / L2 (as conv1x1.hip does) and the whole
+// K = T x 64 is in flight at once: every source's 32 bytes per lane are requested up front, split in registers, no LDS and no
+// barrier before the final meeting of the two K halves.  Tile = 32 consecutive pixels (linear over H x W) x 64 output channels.
+constexpr int CM1_MAXSRC = 8, CM1_THREADS = 512;
+__global__ __launch_bounds__(CM1_THREADS, 2) void conv_small_1x1_kernel(ConvSmallParams p) {
+    // 8 waves = (output channel tile nt, channel half kh, source parity sh): a wave owns <= 4 sources x 2 k-steps: everything it
+    // needs (4 x 64 B of pixels per lane, 8 x 2 weight operands) is requested at once, one round trip to L2 in all
+    __shared__ __attribute__((aligned(16))) float red1[4 * 32 * 64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = wave & 1, kh = (wave >> 1) & 1, sh = wave >> 2;
+    const int HW = p.H * p.W;
+    const int gpi = (HW + 31) >> 5;
+    const int item = blockIdx.x / gpi;
+    const int p0 = (blockIdx.x - item * gpi) * 32;
+    const int nsrc = p.nsrc;
+    const int ntot = 2 * nsrc;
+    const float nscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -2048.0f)));
+    const size_t hw64 = (size_t)HW * 64;
+    // lane (pixel p0 + (lane & 31), k half lane >> 5): channels 32 kh + 16 jj + 8 (lane >> 5) + e of a source
+    const size_t poff = (size_t)min(p0 + (lane & 31), HW - 1) * 64 + 32 * kh + 8 * (lane >> 5);
+    const cmu4* const wsrc = reinterpret_cast<const cmu4*>(p.wpack) + ((size_t)(kh * 2 + nt) * ntot) * 128 + lane;
+    f32x4 av[CM1_MAXSRC / 2][2][2];
+    cmu4 wv[CM1_MAXSRC / 2][2][2];
+#pragma unroll
+    for (int i = 0; i < CM1_MAXSRC / 2; ++i) {
+        const int sc = min(2 * i + sh, nsrc - 1);                   // (surplus slots re-read the last source: never used)
+        const float* src = (sc < p.nA ? p.a + (size_t)(item / p.a_div) * hw64 : p.b + ((size_t)item * p.b_mul + (sc - p.nA)) * hw64) + poff;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            av[i][jj][0] = *reinterpret_cast<const f32x4*>(src + 16 * jj);
+            av[i][jj][1] = *reinterpret_cast<const f32x4*>(src + 16 * jj + 4);
+            wv[i][jj][0] = wsrc[(size_t)(2 * sc + jj) * 128];
+            wv[i][jj][1] = wsrc[(size_t)(2 * sc + jj) * 128 + 64];
+        }
+    }
+    f32x16 accm, accc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        accm[r] = 0.f;
+        accc[r] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < CM1_MAXSRC / 2; ++i) {
+        if (2 * i + sh < nsrc) {                                    // wave-uniform; no memory operation inside
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                cmu2 h0, l0, h1, l1;
+                cm_split4(av[i][jj][0], h0, l0, nscale);
+                cm_split4(av[i][jj][1], h1, l1, nscale);
+                const cmh8 ah = __builtin_bit_cast(cmh8, cmu4{h0.x, h0.y, h1.x, h1.y}), al = __builtin_bit_cast(cmh8, cmu4{l0.x, l0.y, l1.x, l1.y});
+                const cmh8 wh = __builtin_bit_cast(cmh8, wv[i][jj][0]), wo = __builtin_bit_cast(cmh8, wv[i][jj][1]);
+                accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, accm, 0, 0, 0);
+                accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wo, accc, 0, 0, 0);
+                accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, accc, 0, 0, 0);
+            }
+        }
+    }
+    {
+        float* const red = red1 + ((sh * 2 + kh) * 32) * 64 + 32 * nt + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[drow(r, lane) * 64] = accm[r] + accc[r] * (1.0f / 2048.0f);
+    }
+    __syncthreads();
+    const float slope = p.act ? 0.2f : 1.0f;
+    const int pp = tid >> 4, cc = tid & 15;                         // one 16-byte piece per thread
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.bias + cc * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v += *reinterpret_cast<const f32x4*>(red1 + (q * 32 + pp) * 64 + cc * 4);
+    v.x = fmaxf(v.x, v.x * slope);
+    v.y = fmaxf(v.y, v.y * slope);
+    v.z = fmaxf(v.z, v.z * slope);
+    v.w = fmaxf(v.w, v.w * slope);
+    if (p0 + pp < HW) {
+        const size_t o = ((size_t)item * HW + p0 + pp) * 64 + cc * 4;
+        if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
+        *reinterpret_cast<f32x4*>(p.out + o) = v;
     }
 }
 
@@ -242,10 +365,36 @@ hipError_t launch_conv_small(const ConvSmallParams& p, hipStream_t s) {
     if ((p.nA > 0 && (!p.a || p.a_div < 1)) || p.b_mul < 1 || (p.ks != 1 && p.ks != 3)) return hipErrorInvalidValue;
     if ((long long)p.H * p.W * 256 >= 0x7fffffffLL) return hipErrorInvalidValue;
     const int tiles_x = (p.W + 31) / 32;
-    const long long t2 = (long long)p.items * ((p.H + 1) / 2) * tiles_x, t1 = (long long)p.items * p.H * tiles_x;
-    const bool r2 = t2 >= 200;                                      // two rows per workgroup once that still fills the chip
-    if ((r2 ? t2 : t1) > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (p.ks == 3) return r2 ? cm_launch<3, 2>(p, (int)t2, s) : cm_launch<3, 1>(p, (int)t1, s);
+    // rows per workgroup: a CU's time is ~ (workgroups it gets) x R, so minimise ceil(workgroups / CUs) x R; ties go to the larger R
+    // (fewer workgroups to dispatch, fewer weight bytes).  7 x 32 x 32 -> R = 1 (224), 5 x 64 x 64 -> R = 3 (220), 7 x 64 x 64 -> R = 2 (448)
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    long long tr[4] = {0, 0, 0, 0};
+    int bestR = 1;
+    long long best = -1;
+    for (int R = 1; R <= 3; ++R) {
+        tr[R] = (long long)p.items * ((p.H + R - 1) / R) * tiles_x;
+        const long long cost = ((tr[R] + ncu - 1) / ncu) * R;
+        if (best < 0 || cost <= best) {
+            best = cost;
+            bestR = R;
+        }
+    }
+    if (tr[bestR] > 0x7fffffffLL) return hipErrorInvalidValue;
+    const long long t2 = tr[2], t1 = tr[1];
+    const bool r2 = bestR >= 2;
+    if (p.ks == 3) return bestR == 3 ? cm_launch<3, 3>(p, (int)tr[3], s) : bestR == 2 ? cm_launch<3, 2>(p, (int)t2, s) : cm_launch<3, 1>(p, (int)t1, s);
+    if (p.nsrc <= CM1_MAXSRC) {                                     // conv10_i: no halo, no LDS staging
+        const long long g = (long long)p.items * (((long long)p.H * p.W + 31) / 32);
+        if (g > 0x7fffffffLL) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(conv_small_1x1_kernel, dim3((unsigned)g), dim3(CM1_THREADS), 0, s, p);
+        return hipGetLastError();
+    }
     return r2 ? cm_launch<1, 2>(p, (int)t2, s) : cm_launch<1, 1>(p, (int)t1, s);
 }
 
@@ -277,3 +426,9 @@ void conv_small_pack_weights(const float* hwio, int ks, int nsrc, int cout, uint
 }
 
 }  // namespace pfnl
+
+#ifdef PFNL_CM_TIMING
+extern "C" int pfnl_debug_read_cm_stamps(long long* host, size_t n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(pfnl::cm_dbg), n * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -8,6 +8,6 @@ for v in "$@"; do
   rm -rf /tmp/prof_$v
   env $L rocprofv3 --kernel-trace --stats -d /tmp/prof_$v -o p -- python tools/run_fwd.py ${SHAPE:-4 128 128} > /tmp/prof_$v.log 2>&1
   echo "== $v" >> gpurun_out/r03/variants.txt
-  python tools/rocprof_summary.py $(find /tmp/prof_$v -name "*.db" | head -1) 2>/dev/null | grep -E "conv|nl_attn" | awk -F'|' '{printf "%-70s calls %s avg %s us\n", $2, $5, $7}' >> gpurun_out/r03/variants.txt
+  python tools/rocprof_summary.py $(find /tmp/prof_$v -name "*.db" | head -1) 2>/dev/null | grep -E "conv|nl_attn" | awk -F'|' '{printf "%-70s calls %s avg %s min %s us\n", $2, $5, $7, $8}' >> gpurun_out/r03/variants.txt
 done
 cat gpurun_out/r03/variants.txt
