@@ -42,7 +42,8 @@ typedef enum pfnl_status {
     PFNL_ERR_HIP = -3,         /* a HIP runtime call failed                                    */
     PFNL_ERR_NOMEM = -4,
     PFNL_ERR_NODEVICE = -5,    /* no gfx950-capable device visible                             */
-    PFNL_ERR_COMM = -6         /* an RCCL call failed / RCCL could not be loaded               */
+    PFNL_ERR_COMM = -6,        /* an RCCL call failed / RCCL could not be loaded               */
+    PFNL_ERR_RANGE = -7        /* pfnl_sync: a device-pointer forward left the f16-pipe kernels' range (see "strict_fp32") */
 } pfnl_status;
 
 /* Mirrors the constants hard-coded in the reference (model/pfnl.py:21-23, 40-43). */
@@ -86,6 +87,13 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *   "direct"        implicit-GEMM f32 MFMA (conv_mfma.hip);
  *   "split16"       direct 3x3 on the f16 matrix pipe with exactly split fp32 operands (3 f16 MFMAs per product block,
  *                   fp32 accumulation, >= 22 mantissa bits per product: conv_split16.hip).
+ * key "strict_fp32" = "off" (default) | "on".  The default fp32 path computes on the f16 matrix pipe with exactly split operands
+ *   (fp32 tensors, fp32 accumulation, >= 22 mantissa bits per product) and therefore has a DOMAIN the reference's fp32 kernels do
+ *   not have: |activation|, |weight| < 65504, and inputs of the non-local block on a [0,1] scale (|x| < ~350).  Leaving it makes
+ *   an operand inf and the result non-finite; the tail kernel flags that.  Host-pointer calls then redo the call on the f32-MFMA
+ *   kernels before returning (pfnl_range_reruns counts them), so they cover the whole fp32 range; device-pointer calls are
+ *   asynchronous: pfnl_sync returns PFNL_ERR_RANGE.  "on" (or env PFNL_STRICT_FP32=1) uses the f32-MFMA kernels throughout; weights
+ *   beyond binary16's range select them by themselves at pfnl_finalize_weights.
  * key "small" = "auto" (default: the small-shape trunk kernels of conv_small.hip when a 3x3 launch has fewer than 256 tiles of 8x32
  *   pixels - 3 launches per progressive-fusion block, conv2_i as one 128 -> 64 convolution) | "on" | "off".
  * key "split16_sf" = "on" (default) | "off": with conv3x3 and conv1x1 on "split16", conv1_i and conv10_i write the split format
@@ -127,6 +135,8 @@ int pfnl_forward(pfnl_handle* h, const void* in, int in_is_device, void* out, in
 int pfnl_forward_strip(pfnl_handle* h, const void* in, void* out, int B, int H, int W, int row0, int nrows, void* stream);
 int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes);
 int pfnl_sync(pfnl_handle* h);
+/* number of synchronous forwards that were redone on the f32-MFMA kernels because the f16-pipe range flag was set */
+int pfnl_range_reruns(pfnl_handle* h, long long* count);
 
 /* ---- multi-GPU (RCCL over xGMI) ------------------------------------ */
 /* Clips are independent (reference model/pfnl.py:44,55: the batch is only the leading dimension), so ranks share NOTHING on

@@ -47,6 +47,7 @@ SIGNATURES = {
     "pfnl_forward_strip": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pfnl_workspace_bytes": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_size_t)]),
     "pfnl_sync": (_i, [_vp]),
+    "pfnl_range_reruns": (_i, [_vp, C.POINTER(C.c_longlong)]),
     "pfnl_profile_enable": (_i, [_vp, _i]),
     "pfnl_profile_reset": (_i, [_vp]),
     "pfnl_profile_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -102,6 +102,14 @@ struct pfnl_handle {
     std::vector<size_t> off16s_c2a_sf, off16s_c2b_sf;         // ... with the identity row map conv3x3_sf_kernel takes (conv_sf.hip)
     std::vector<size_t> off16m_c1, off16m_c10, off16m_c2;     // small-shape packs (conv_small.hip), in the same blob
     size_t off16m_m1 = 0;
+    // The f16-pipe kernels of the fp32 path have a DOMAIN (operands inside binary16's range; the non-local kernel: inputs x 2^7).
+    // Beyond it an operand becomes inf and the result non-finite - the tail kernel, which every output value passes through, ORs
+    // that into `rflag` (sticky device word).  Host-pointer calls read it before they return and, when it is set, redo the call on
+    // the f32-MFMA kernels (no such domain: the reference's own arithmetic range); device-pointer calls stay asynchronous and
+    // pfnl_sync reports PFNL_ERR_RANGE.  Option strict_fp32=on takes the f32-MFMA kernels from the start.
+    DevBuf rflag;
+    bool strict = false, strict_once = false, weights_f16_ok = true;
+    long long range_reruns = 0;
     int small_mode = 0;                                       // option small=auto|on|off: the small-shape trunk kernels (auto: when a launch has < 256 tiles of 8x32 pixels)
     bool sf_path = true;                                      // option split16_sf=on|off: with conv3x3 = conv1x1 = split16, conv1_i and conv10_i write the
                                                               // split format (conv_split16.h) and both halves of conv2_i read it by LDS-DMA (conv_sf.hip)
@@ -228,6 +236,8 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
     h->lastH = H;
     h->lastW = W;
 
+    const bool nl_strict = !h->bf16 && (h->strict || h->strict_once || !h->weights_f16_ok);
+    unsigned* const rflag = reinterpret_cast<unsigned*>(h->rflag.p);
     {   // model/pfnl.py:55-60 (+ utils.py:18-71)
         ProfScope ps(h, s, PFNL_K_NL_PACK);
         HIPCHK(launch_nl_pack(in, h->X.p, B, T, Hfull, W, s));
@@ -238,7 +248,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             if (h->Q.ensure((size_t)B * N * CP)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
             HIPCHK(launch_nl_qproj(h->X.p, wd + h->off_nl_m, wd + h->off_nl_c, h->Q.p, B, N, C, s));
             HIPCHK(launch_nl_attn(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p, B, N, C, s, h->Q.p, q0, q1));
-        } else if (!h->bf16 && (h->nl_algo == 1 || (h->nl_algo == 2 && N >= 1024))) {   // fp32 path on the f16 pipe, exactly split operands
+        } else if (!h->bf16 && !nl_strict && (h->nl_algo == 1 || (h->nl_algo == 2 && N >= 1024))) {   // fp32 path on the f16 pipe, exactly split operands
             if (h->nl16.ensure((nl_f16_scratch_halfs(B, N) + 1) / 2)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
             HIPCHK(launch_nl_attn_f16(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p,
                                       reinterpret_cast<uint16_t*>(h->nl16.p), B, N, C, s, q0, q1));
@@ -259,7 +269,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
         if (h->bf16)
             HIPCHK(launch_conv0_bf16(h->Xo.p, wd + h->off_conv0_w, wd + h->off_conv0_b, reinterpret_cast<uint16_t*>(h->inp0.p), B, T, Hfull, W, s, strip));
         else
-            HIPCHK(launch_conv0(h->Xo.p, wd + h->off_conv0_w, wd + h->off_conv0_b, h->inp0.p, B, T, Hfull, W, s, strip));
+            HIPCHK(launch_conv0(h->Xo.p, wd + h->off_conv0_w, wd + h->off_conv0_b, h->inp0.p, B, T, Hfull, W, s, strip, nl_strict));
     }
     const float* merge_in = h->inp0.p;
     if (h->bf16) {
@@ -312,7 +322,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
         h->merge_cstride = 64;
         {   // model/pfnl.py:63,76-80
             ProfScope ps(h, s, PFNL_K_TAIL);
-            HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, Hfull, W, c.scale, 64, s, strip));
+            HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, Hfull, W, c.scale, 64, s, strip, rflag));
         }
         h->chain_open = false;
         return 0;
@@ -327,11 +337,14 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
     // conv3x3 = auto (default): the split-f16 kernel (persistent, 72 KB of weights per workgroup in its prologue) when a launch
     // has at least ~a tile per CU, the Winograd f32 kernel for small shapes (BASELINE.json configs[0], configs[4])
     const int tiles8x32 = F * ((W + 31) / 32) * ((H + 7) / 8);
-    const int algo = h->conv_algo == 5 ? ((tiles8x32 >= 256 && (long long)H * W * 256 < 0x7fffffffLL) ? 4 : 3) : h->conv_algo;
-    const bool sf = algo == 4 && h->conv1x1_algo == 2 && h->sf_path;   // inp1 and base in the split format (conv_split16.h)
+    const bool strict = !h->bf16 && (h->strict || h->strict_once || !h->weights_f16_ok);   // f32-MFMA kernels only
+    const int algo0 = h->conv_algo == 5 ? ((tiles8x32 >= 256 && (long long)H * W * 256 < 0x7fffffffLL) ? 4 : 3) : h->conv_algo;
+    const int algo = (strict && algo0 == 4) ? 3 : algo0;
+    const int conv1x1_algo = (strict && h->conv1x1_algo == 2) ? 1 : h->conv1x1_algo;
+    const bool sf = algo == 4 && conv1x1_algo == 2 && h->sf_path;   // inp1 and base in the split format (conv_split16.h)
     // small shapes (BASELINE.json configs[0], configs[4]): the trunk through conv_small.hip - 3 launches per block, conv2_i as the
     // reference writes it (3x3 over concat([base, f])); only under the default algorithm choices
-    const bool small = !h->bf16 && (long long)H * W * 256 < 0x7fffffffLL &&
+    const bool small = !h->bf16 && !strict && (long long)H * W * 256 < 0x7fffffffLL &&
                        (h->small_mode == 1 || (h->small_mode == 0 && h->conv_algo == 5 && h->conv1x1_algo == 2 && tiles8x32 < 256));
     const uint16_t* const w16m = reinterpret_cast<const uint16_t*>(h->wdev16s.p);
     for (int i = 0; i < (h->bf16 ? 0 : c.num_block); ++i) {   // model/pfnl.py:65-71
@@ -390,9 +403,9 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             p.out = h->base.p;
             p.frames_per_item = T;
             p.nchunks = T * p.chunks_per_frame;
-            if (h->conv1x1_algo == 2)
+            if (conv1x1_algo == 2)
                 HIPCHK(launch_conv1x1_split16(p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_c10[i], p.bias, p.out, B, T, H * W, 1, s, sf, sf));
-            else if (h->conv1x1_algo == 1)
+            else if (conv1x1_algo == 1)
                 HIPCHK(launch_conv1x1_stream(p.in, wd + h->off_c10_s[i], p.bias, p.out, B, T, H * W, 1, s));
             else
                 HIPCHK(launch_conv_mfma(p, 1, B, s));
@@ -470,7 +483,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
         h->merge_cstride = 64;
         {   // model/pfnl.py:63,76-80
             ProfScope ps(h, s, PFNL_K_TAIL);
-            HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, Hfull, W, c.scale, 64, s, strip));
+            HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, Hfull, W, c.scale, 64, s, strip, rflag));
         }
         h->chain_open = false;
         h->prof_gate = true;
@@ -523,7 +536,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
     }
     {   // model/pfnl.py:63,76-80
         ProfScope ps(h, s, PFNL_K_TAIL);
-        HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, Hfull, W, c.scale, mstride, s, strip));
+        HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, Hfull, W, c.scale, mstride, s, strip, rflag));
     }
     h->chain_open = false;
     return 0;
@@ -566,6 +579,12 @@ int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
         delete h;
         return fail(PFNL_ERR_HIP, "hipStreamCreate failed");
     }
+    if (h->rflag.ensure(4) || hipMemset(h->rflag.p, 0, 16) != hipSuccess) {
+        hipStreamDestroy(h->stream);
+        delete h;
+        return fail(PFNL_ERR_NOMEM, "allocation failed");
+    }
+    if (const char* e = std::getenv("PFNL_STRICT_FP32")) h->strict = std::string(e) != "0" && std::string(e) != "off";
     const int T = cfg->num_frames, C = 12 * T;
     add_expected(h, "conv0", 5, 3, 64);
     for (int i = 0; i < cfg->num_block; ++i) {
@@ -600,7 +619,7 @@ int pfnl_destroy(pfnl_handle* h) {
         if (g.exec) hipGraphExecDestroy(g.exec);
         if (g.graph) hipGraphDestroy(g.graph);
     }
-    for (DevBuf* b : {&h->Q, &h->wdev16s, &h->wdev, &h->wdev16, &h->nl16, &h->X, &h->Xo, &h->nlp, &h->inp0, &h->inp1, &h->base, &h->pb, &h->merge,
+    for (DevBuf* b : {&h->rflag, &h->Q, &h->wdev16s, &h->wdev, &h->wdev16, &h->nl16, &h->X, &h->Xo, &h->nlp, &h->inp0, &h->inp1, &h->base, &h->pb, &h->merge,
                       &h->stage_in, &h->stage_out, &h->scratch})
         b->release();
     delete h;
@@ -649,6 +668,12 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         else if (v == "split16") h->conv_algo = 4;
         else if (v == "auto") h->conv_algo = 5;
         else return fail(PFNL_ERR_INVALID, "conv3x3 must be auto, split16, winograd, winograd_tile or direct");
+        return 0;
+    }
+    if (k == "strict_fp32") {
+        if (v == "on") h->strict = true;
+        else if (v == "off") h->strict = false;
+        else return fail(PFNL_ERR_INVALID, "strict_fp32 must be on or off");
         return 0;
     }
     if (k == "small") {
@@ -913,6 +938,12 @@ int pfnl_finalize_weights(pfnl_handle* h) {
         if (h->wdev16s.ensure(b16.size() / 2)) return fail(PFNL_ERR_NOMEM, "weight allocation failed");
         HIPCHK(hipMemcpy(h->wdev16s.p, b16.data(), b16.size() / 2 * 2 * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
+    {   // the f16-pipe kernels split the weights into binary16 pairs: a weight beyond that range sends the handle to the f32-MFMA kernels
+        float wmax = 0.f;
+        for (const auto& kv : h->host)
+            for (float v : kv.second.data) wmax = std::fmax(wmax, std::fabs(v));
+        h->weights_f16_ok = wmax < 65504.0f;
+    }
     if (h->wdev.ensure(blob.size())) return fail(PFNL_ERR_NOMEM, "weight allocation failed");
     HIPCHK(hipMemcpy(h->wdev.p, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
     h->finalized = true;
@@ -936,6 +967,21 @@ int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes) {
     if (h->bf16 || h->nl_algo != 0) f += (std::max(pfnl::nl_bf16_scratch_halfs(B, (int)N), pfnl::nl_f16_scratch_halfs(B, (int)N)) + 1) / 2;   // split K / V^T operands (bf16 or f16)
     if (h->nl_theta) f += (size_t)B * N * CP;                   // projected queries (nltype 0)
     *bytes = f * sizeof(float);
+    return 0;
+}
+
+// reads and clears the sticky range flag (the caller has synchronised the streams that may still be writing it)
+static int range_flag_take(pfnl_handle* h, int* flagged) {
+    unsigned f = 0;
+    HIPCHK(hipMemcpy(&f, h->rflag.p, sizeof(f), hipMemcpyDeviceToHost));
+    if (f) HIPCHK(hipMemset(h->rflag.p, 0, sizeof(f)));
+    *flagged = f != 0;
+    return 0;
+}
+
+int pfnl_range_reruns(pfnl_handle* h, long long* count) {
+    if (!h || !count) return fail(PFNL_ERR_INVALID, "NULL argument");
+    *count = h->range_reruns;
     return 0;
 }
 
@@ -1011,6 +1057,18 @@ int pfnl_forward(pfnl_handle* h, const void* in, int in_is_device, void* out, in
                                   out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
             if (!in_is_device || !out_is_device) {
                 HIPCHK(hipStreamSynchronize(s));
+                int flagged = 0;
+                if (int e = range_flag_take(h, &flagged)) return e;
+                if (flagged && !h->bf16 && !(h->strict || !h->weights_f16_ok)) {   // once more, eagerly, on the f32-MFMA kernels
+                    h->strict_once = true;
+                    const int e = forward_device(h, h->stage_in.p, h->stage_out.p, B, H, W, s);
+                    h->strict_once = false;
+                    if (e) return e;
+                    ++h->range_reruns;
+                    HIPCHK(hipMemcpyAsync(out, h->stage_out.p, n_out * sizeof(float), out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+                    HIPCHK(hipStreamSynchronize(s));
+                    if (int e2 = range_flag_take(h, &flagged)) return e2;
+                }
             } else if (!stream) {
                 HIPCHK(hipEventRecord(h->gev, s));
                 HIPCHK(hipStreamWaitEvent(nullptr, h->gev, 0));
@@ -1037,6 +1095,22 @@ int pfnl_forward(pfnl_handle* h, const void* in, int in_is_device, void* out, in
         HIPCHK(hipStreamSynchronize(s));
     } else if (!in_is_device) {
         HIPCHK(hipStreamSynchronize(s));   // the caller may reuse its host buffer on return
+    }
+    if (!in_is_device || !out_is_device) {
+        // a synchronous call: the range flag is read before it returns; set = the f16-pipe domain was left somewhere (or the
+        // input itself was non-finite): once more on the f32-MFMA kernels, whose range is the reference's
+        int flagged = 0;
+        if (int e = range_flag_take(h, &flagged)) return e;
+        if (flagged && !h->bf16 && !(h->strict || !h->weights_f16_ok)) {
+            h->strict_once = true;
+            const int e = forward_device(h, din, dout, B, H, W, s);
+            h->strict_once = false;
+            if (e) return e;
+            ++h->range_reruns;
+            if (!out_is_device) HIPCHK(hipMemcpyAsync(out, dout, n_out * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (int e2 = range_flag_take(h, &flagged)) return e2;   // (still non-finite: so is the reference's result - returned as is)
+        }
     }
     return 0;
 }
@@ -1068,6 +1142,13 @@ int pfnl_sync(pfnl_handle* h) {
     HIPCHK(hipSetDevice(h->cfg.device_id));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipStreamSynchronize(nullptr));                     // device-pointer calls with stream == NULL run on the null stream
+    // (a device-pointer call on a stream of the caller's: the caller synchronises that stream before pfnl_sync)
+    int flagged = 0;
+    if (int e = range_flag_take(h, &flagged)) return e;
+    if (flagged)
+        return fail(PFNL_ERR_RANGE, "a device-pointer forward since the last check produced non-finite values: an operand left the range of the "
+                                    "f16-pipe kernels (|x| < 65504; the non-local block: inputs on a [0,1] scale) or the input was not finite. "
+                                    "Re-run with pfnl_set_option(h, \"strict_fp32\", \"on\") (f32-MFMA kernels: the reference's range), or use host pointers");
     return 0;
 }
 

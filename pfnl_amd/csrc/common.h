@@ -126,10 +126,10 @@ struct StripGeom {
     int yoff, Hs, core0, core1;
 };
 hipError_t launch_conv0(const float* Xo, const float* w75x64, const float* bias, float* out, int B,
-                        int T, int H, int W, hipStream_t s, const StripGeom* strip = nullptr);
+                        int T, int H, int W, hipStream_t s, const StripGeom* strip = nullptr, bool force_f32 = false);   // force_f32: the VALU fp32 kernel
 hipError_t launch_tail(const float* merge, const float* x, const float* w2, const float* b2,
                        float* out, int B, int T, int H, int W, int scale, int merge_cstride, hipStream_t s,
-                       const StripGeom* strip = nullptr);
+                       const StripGeom* strip = nullptr, unsigned* nonfinite = nullptr);   // nonfinite: OR-ed with 1 if a written value is inf / NaN
 hipError_t launch_blur_decimate(const float* hr, float* lr, int F, int H, int W, int scale, hipStream_t s);
 hipError_t launch_bicubic(const float* x, float* out, int B, int H, int W, int scale, hipStream_t s);
 hipError_t run_mfma_selftest(int* mismatches);

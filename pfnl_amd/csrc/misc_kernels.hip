@@ -244,9 +244,9 @@ static bool conv0_use_valu() {
 }
 
 hipError_t launch_conv0(const float* Xo, const float* w75x64, const float* bias, float* out, int B,
-                        int T, int H, int W, hipStream_t s, const StripGeom* strip) {
+                        int T, int H, int W, hipStream_t s, const StripGeom* strip, bool force_f32) {
     const int yoff = strip ? strip->yoff : 0, Hs = strip ? strip->Hs : H;
-    if (!conv0_use_valu()) {
+    if (!conv0_use_valu() && !force_f32) {
         dim3 grid((W + C0M_TW - 1) / C0M_TW, (Hs + C0M_TH - 1) / C0M_TH, B * T);
         hipLaunchKernelGGL(conv0_mfma_kernel<false>, grid, dim3(256), 0, s, Xo, w75x64, bias, out, T, H, W, nl_padded_ch(12 * T), yoff, Hs);
         return hipGetLastError();
@@ -344,8 +344,9 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ mer
                                                    const float* __restrict__ w2,  // [3][3][12][CO]
                                                    const float* __restrict__ b2,  // [CO]
                                                    float* __restrict__ out, int B, int T, int H, int W, int MS,   // MS = floats per merge pixel (48 or 64)
-                                                   int yoff, int Hs, int core0, int core1) {   // merge holds LR rows [yoff, yoff + Hs) of the H-row frame;
+                                                   int yoff, int Hs, int core0, int core1,     // merge holds LR rows [yoff, yoff + Hs) of the H-row frame;
                                                                                                 // only strip rows [core0, core1) are written
+                                                   unsigned* __restrict__ nonfinite) {         // OR-ed with 1 when a value written is inf / NaN (or null)
     constexpr int SCALE = (CO == 12) ? 4 : 2;
     const int H2 = 2 * Hs, W2 = 2 * W;
     const int X = blockIdx.x * 32 + (threadIdx.x & 31);
@@ -381,6 +382,10 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ mer
     const float* xc = x + (((size_t)b * T + T / 2) * H) * W * 3;   // centre frame, model/pfnl.py:63
     const int OH = SCALE * H, OW = SCALE * W;
     float* ob = out + (size_t)b * OH * OW * 3;
+    // The f16-pipe kernels upstream (conv_split16.hip, conv_sf.hip, conv_small.hip, nonlocal_f16.hip, conv0_mfma) have a domain: an
+    // operand beyond binary16's range becomes inf, and everything downstream of an inf stays non-finite up to here - the one place
+    // every value of the result passes through.  One compare per value on a bandwidth-bound kernel; an atomic only when it fires.
+    bool bad = false;
     if (CO == 12) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -391,26 +396,35 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ mer
                 bicubic_px(xc, H, W, (size_t)W * 3, SCALE, oy, ox, bic);
                 float* dst = ob + ((size_t)oy * OW + ox) * 3;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) dst[c] = acc[(2 * i + j) * 3 + c] + bic[c];
+                for (int c = 0; c < 3; ++c) {
+                    const float v = acc[(2 * i + j) * 3 + c] + bic[c];
+                    bad |= !(fabsf(v) <= 3.4028234e38f);
+                    dst[c] = v;
+                }
             }
     } else {
         float bic[3];
         bicubic_px(xc, H, W, (size_t)W * 3, SCALE, Y + 2 * yoff, X, bic);
         float* dst = ob + ((size_t)(Y + 2 * yoff) * OW + X) * 3;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) dst[c] = acc[c] + bic[c];
+        for (int c = 0; c < 3; ++c) {
+            const float v = acc[c] + bic[c];
+            bad |= !(fabsf(v) <= 3.4028234e38f);
+            dst[c] = v;
+        }
     }
+    if (bad && nonfinite) atomicOr(nonfinite, 1u);
 }
 
 hipError_t launch_tail(const float* merge, const float* x, const float* w2, const float* b2, float* out,
-                       int B, int T, int H, int W, int scale, int merge_cstride, hipStream_t s, const StripGeom* strip) {
+                       int B, int T, int H, int W, int scale, int merge_cstride, hipStream_t s, const StripGeom* strip, unsigned* nonfinite) {
     if (merge_cstride != 48 && merge_cstride != 64) return hipErrorInvalidValue;
     const StripGeom g = strip ? *strip : StripGeom{0, H, 0, H};
     dim3 grid((2 * W + 31) / 32, (2 * g.Hs + 7) / 8, B);
     if (scale == 4)
-        hipLaunchKernelGGL(tail_kernel<12>, grid, dim3(256), 0, s, merge, x, w2, b2, out, B, T, H, W, merge_cstride, g.yoff, g.Hs, g.core0, g.core1);
+        hipLaunchKernelGGL(tail_kernel<12>, grid, dim3(256), 0, s, merge, x, w2, b2, out, B, T, H, W, merge_cstride, g.yoff, g.Hs, g.core0, g.core1, nonfinite);
     else if (scale == 2)
-        hipLaunchKernelGGL(tail_kernel<3>, grid, dim3(256), 0, s, merge, x, w2, b2, out, B, T, H, W, merge_cstride, g.yoff, g.Hs, g.core0, g.core1);
+        hipLaunchKernelGGL(tail_kernel<3>, grid, dim3(256), 0, s, merge, x, w2, b2, out, B, T, H, W, merge_cstride, g.yoff, g.Hs, g.core0, g.core1, nonfinite);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

@@ -136,7 +136,15 @@ class PFNLEngine:
                                                  int(row0), int(nrows), C.c_void_p(stream) if stream else None))
 
     def sync(self) -> None:
+        """Synchronise the engine's streams; raises if a device-pointer forward left the f16-pipe kernels' range
+        (PFNL_ERR_RANGE, include/pfnl_hip.h "strict_fp32")."""
         _capi.check(self._lib.pfnl_sync(self._h))
+
+    def range_reruns(self) -> int:
+        """Host-pointer forwards that were redone on the f32-MFMA kernels (range flag set)."""
+        n = C.c_longlong(0)
+        _capi.check(self._lib.pfnl_range_reruns(self._h, C.byref(n)))
+        return n.value
 
     def workspace_bytes(self, B: int, H: int, W: int) -> int:
         n = C.c_size_t(0)

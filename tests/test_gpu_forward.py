@@ -442,9 +442,103 @@ def test_graph_replay_matches_eager():
     y_dir = [eng.forward(gd["x"]) for _ in range(3)]
     assert np.array_equal(y_dir[0], y_dir[1]) and np.array_equal(y_dir[1], y_dir[2])
     assert np.abs(y_dir[0] - y_off).max() < 5e-5 and not np.array_equal(y_dir[0], y_off)
-    eng.set_option("conv3x3", "winograd")
+    eng.set_option("conv3x3", "auto")                          # back to the default choice (this shape: the small-shape kernels)
     eng.set_option("graph", "on")
     x2 = synth.uniform_clips(2, 7, 20, 36, seed=9)            # another shape: its own graph
     y2 = [eng.forward(x2) for _ in range(3)]
     assert np.array_equal(y2[0], y2[2])
     assert np.array_equal(eng.forward(gd["x"]), y_off)
+
+
+# ---- the domain of the f16-pipe kernels (the default fp32 path computes on the f16 matrix pipe with exactly split operands;
+# |activation|, |weight| < 65504, non-local inputs on a [0,1] scale) ------------------------------------------------------------------
+
+def _engine_with(geom, w):
+    e = PFNLEngine(geom, device=0)
+    e.load_weights(w)
+    return e
+
+
+def _rel_err(y, ref):
+    return float(np.abs(y - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def test_split16_domain_undamped_weights():
+    """Un-damped Xavier weights (no x0.1 on conv2_i: the trunk's activations grow block by block instead of staying O(1)) over 20
+    blocks: the default path against the fp64 spec, relative to the size of the result."""
+    geom = PFNLGeometry(num_block=20)
+    w = synth.synthetic_weights(geom, seed=4)
+    for k in w:
+        if "/conv2_" in k and k.endswith("/kernel"):
+            w[k] = (w[k] * 10.0).astype(np.float32)                  # undo synth's damping
+    x = synth.uniform_clips(1, 7, 16, 24, seed=77)
+    taps = {}
+    ref = pfnl_spec.forward(x.astype(np.float64), {k: v.astype(np.float64) for k, v in w.items()}, num_block=20, taps=taps)
+    eng = _engine_with(geom, w)
+    y = eng.forward(x)
+    trunk = eng.tap("trunk", 1, 16, 24)
+    print("undamped: |trunk| max %.3g, |y| max %.3g, rel err %.3g, reruns %d" % (np.abs(trunk).max(), np.abs(ref).max(), _rel_err(y, ref), eng.range_reruns()))
+    assert np.isfinite(y).all() and eng.range_reruns() == 0
+    assert _rel_err(y, ref) < 2e-5
+    eng.close()
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 24), (4, 128, 128)])     # the small-shape kernels / the persistent kernels
+def test_split16_domain_activation_overflow_is_caught(shape):
+    """Activations beyond binary16's range (conv0 scaled so that the trunk holds values ~1e5 .. 1e6): a host-pointer forward
+    notices (the tail kernel's flag), redoes the call on the f32-MFMA kernels and returns the reference's result; a
+    device-pointer forward stays asynchronous, its result is non-finite and pfnl_sync says so; strict_fp32=on is right from the
+    start.  Nothing returns NaN silently."""
+    import torch
+    B, H, W = shape
+    nb = 2
+    geom = PFNLGeometry(num_block=nb)
+    w = synth.synthetic_weights(geom, seed=1)
+    w["nlvsr/conv0/kernel"] = (w["nlvsr/conv0/kernel"] * 4e5).astype(np.float32)
+    x = synth.uniform_clips(B, 7, H, W, seed=3)
+    ref = pfnl_fast.FastOracle(w, num_block=nb).forward(x) if B > 1 else pfnl_spec.forward(
+        x.astype(np.float64), {k: v.astype(np.float64) for k, v in w.items()}, num_block=nb)
+    eng = _engine_with(geom, w)
+    y = eng.forward(x)                                              # host pointers: checked before it returns
+    assert eng.range_reruns() == 1 and np.isfinite(y).all()
+    print("overflow %s: |y| max %.3g, rel err after the f32 rerun %.3g" % (shape, np.abs(ref).max(), _rel_err(y, ref)))
+    assert _rel_err(y, ref) < 5e-5
+    yd = eng.forward(torch.from_numpy(x).cuda())                    # device pointers: asynchronous, flagged
+    torch.cuda.synchronize()
+    assert not torch.isfinite(yd).all()
+    with pytest.raises(Exception, match="range|non-finite"):
+        eng.sync()
+    eng.sync()                                                      # the flag was taken: clean now
+    eng.set_option("strict_fp32", "on")
+    yd = eng.forward(torch.from_numpy(x).cuda())
+    eng.sync()
+    assert np.array_equal(yd.cpu().numpy(), y) and eng.range_reruns() == 1
+    eng.close()
+
+
+def test_split16_domain_nonlocal_input_scale():
+    """Inputs far off the [0,1] scale the f16 non-local kernel assumes (x 600: 600 * 2^7 > 65504): caught the same way; the
+    f32-MFMA kernels give the (stabilised) spec's result."""
+    geom = PFNLGeometry(num_block=1)
+    w = synth.synthetic_weights(geom, seed=2)
+    x = (synth.uniform_clips(1, 7, 64, 64, seed=5) * 600.0).astype(np.float32)   # N = 1024 keys: the f16 non-local kernel
+    ref = pfnl_spec.forward(x.astype(np.float64), {k: v.astype(np.float64) for k, v in w.items()}, num_block=1, stabilise=True)
+    eng = _engine_with(geom, w)
+    y = eng.forward(x)
+    print("nl scale: reruns %d, rel err %.3g" % (eng.range_reruns(), _rel_err(y, ref)))
+    assert eng.range_reruns() == 1 and np.isfinite(y).all()
+    assert _rel_err(y, ref) < 5e-5
+    eng.close()
+
+
+def test_split16_domain_weight_range_selects_f32_kernels():
+    """A weight beyond binary16's range: pfnl_finalize_weights sends the handle to the f32-MFMA kernels by itself."""
+    geom = PFNLGeometry(num_block=1)
+    w = synth.synthetic_weights(geom, seed=2)
+    w["nlvsr/conv1_0/kernel"][1, 1, 3, 5] = 1.0e5
+    x = synth.uniform_clips(1, 7, 16, 24, seed=5)
+    ref = pfnl_spec.forward(x.astype(np.float64), {k: v.astype(np.float64) for k, v in w.items()}, num_block=1)
+    eng = _engine_with(geom, w)
+    y = eng.forward(x)
+    assert eng.range_reruns() == 0 and np.isfinite(y).all() and _rel_err(y, ref) < 5e-5
+    eng.close()
