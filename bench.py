@@ -46,8 +46,9 @@ CONV3X3_KERNELS = {
     "winograd_tile": ("conv_wino_kernel<*> (fused Winograd F(2x2,3x3) 64->64, f32 MFMA, one workgroup per tile)",
                       ["conv_wino.hip", "wino_geom.h"]),
     "direct": ("conv_mfma_kernel<3,16,*> (3x3 64->64 f32 MFMA implicit GEMM)", ["conv_mfma.hip"]),
-    "split16": ("conv3x3_split16_kernel<0,OSF> (conv1_i) + conv3x3_sf_kernel<0|1> (conv2_i: input in the split format by LDS-DMA): direct 3x3 64->64 on "
-                "f16 MFMA with exactly split fp32 operands, 3 MFMAs per product block, fp32 accumulation", ["conv_split16.hip", "conv_sf.hip"]),
+    "split16": ("conv3x3_split16_kernel<0,OSF> (conv1_i) + conv3x3_sf_chain_kernel (the whole of conv2_i: split-format input and weights by LDS-DMA, shared half "
+                "in registers): direct 3x3 64->64 on f16 MFMA with exactly split fp32 operands, 3 MFMAs per product block, fp32 accumulation",
+                ["conv_split16.hip", "conv_sf.hip"]),
     "small": ("conv_small_kernel<3,R> (small-shape trunk: conv1_i and the whole of conv2_i, 4 waves per R x 32-pixel tile, split-f16 MFMA, weights "
               "streamed as B operands)", ["conv_small.hip"]),
     "bf16": ("conv3x3_bf16_kernel<*> (direct 3x3 64->64, bf16 MFMA, fp32 accumulation, persistent)", ["conv_bf16.hip"]),
@@ -164,7 +165,9 @@ def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
                 "mfma_tflops": round(flops3 / launches_per_step / (avg_ms * 1e-3) / 1e12, 1), "mfma_peak_bf16_tflops": PEAK_F16_MFMA_TFLOPS}
     # fp32: conv1_i + conv2_i; the default kernel runs the whole of conv2_i as one grouped launch, the others launch its
     # shared half and its per-frame half separately
-    launches_per_step = (2 if algo == "winograd" else 3) * geom.num_block
+    # launches of the class per PF block: 2 with conv2_i as one launch (Winograd's grouped mode; the split-f16 chain kernel), else 3
+    chain = algo == "split16" and os.environ.get("PFNL_SF_CHAIN", "1") not in ("0", "off") and os.environ.get("PFNL_SPLIT16_SF", "1") not in ("0", "off")
+    launches_per_step = (2 if (algo == "winograd" or chain) else 3) * geom.num_block
     flops_per_launch = flops3 / launches_per_step
     direct_tflops = flops_per_launch / (avg_ms * 1e-3) / 1e12
     if algo == "split16":
@@ -172,7 +175,7 @@ def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
         # FLOPs against 2.5 PFLOP/s) and the HBM roof (conv1_i: read F + write F; shared half: read B + write B; per-frame
         # half: read F + addend B + residual F, write F - over 3 launches) - both fractions are reported, the larger binds
         name, files = CONV3X3_KERNELS[algo]
-        bytes_per_launch = P * 256.0 * (5 * F + 3 * B) / 3.0
+        bytes_per_launch = P * 256.0 * (5 * F + 3 * B) * geom.num_block / launches_per_step   # the graph's bytes (layer-granular), however many launches carry them
         gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         ex = 3.0 * direct_tflops
         # frac = ALGORITHMIC work / time / peak: the reference graph's bytes (layer-granular, shared-base split) against HBM, its

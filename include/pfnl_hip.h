@@ -98,6 +98,8 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *   pixels - 3 launches per progressive-fusion block, conv2_i as one 128 -> 64 convolution) | "on" | "off".
  * key "split16_sf" = "on" (default) | "off": with conv3x3 and conv1x1 on "split16", conv1_i and conv10_i write the split format
  *   (hi, lo' binary16 pairs: the MFMA operands themselves) and both halves of conv2_i read it by LDS-DMA (conv_sf.hip).
+ * key "split16_chain" = "on" (default) | "off": with split16_sf, conv2_i is one launch - per (clip, tile) the shared half stays in
+ *   registers as the initial C of the T per-frame tiles (no pb tensor, no addend reads, 20 launches fewer per forward).
  * key "conv1x1" = "split16" (default: streaming kernel on the f16 pipe, exactly split fp32 operands) | "stream" (streaming f32-MFMA
  *                 kernel) | "tiled" (conv_mfma.hip).
  * key "nonlocal" (fp32 precision only) = "auto" (default: "split16" from 1024 keys, "f32" below) | "f32" (f32 MFMA, nonlocal.hip) |
@@ -239,7 +241,9 @@ int pfnl_op_conv3x3_split16(const float* in, const float* kernel_host, const flo
  * operands - conv1_i's and conv10_i's outputs, model/pfnl.py:66-68 - is kept as (hi, lo') binary16 pairs, built once by its
  * producer).  fp32 at the hook's interface: conversions bracket the kernel under test.
  * which = 0: the 3x3 kernel of conv2_i (input SF by LDS-DMA, epilogue from registers; plain, or fused with addend + resid);
- * which = 1: the 3x3 kernel of conv1_i writing SF. */
+ * which = 1: the 3x3 kernel of conv1_i writing SF;
+ * which = 2: the WHOLE of conv2_i in one launch (conv3x3_sf_chain_kernel): kernel_host = HWIO [3,3,128,64], `addend` = base
+ *   [items/add_div][H][W][64] fp32, out = lrelu(conv(concat([base, in])) + bias) + resid. */
 int pfnl_op_conv3x3_split16_sf(int which, const float* in, const float* kernel_host, const float* bias_host, const float* addend,
                                int add_div, const float* resid, float* out, int items, int H, int W, int act, void* stream);
 int pfnl_op_conv1x1_split16_sf(const float* in, const float* kernel_host, const float* bias_host, float* out, int items,

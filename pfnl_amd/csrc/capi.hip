@@ -111,6 +111,7 @@ struct pfnl_handle {
     bool strict = false, strict_once = false, weights_f16_ok = true;
     long long range_reruns = 0;
     int small_mode = 0;                                       // option small=auto|on|off: the small-shape trunk kernels (auto: when a launch has < 256 tiles of 8x32 pixels)
+    bool sf_chain = true;                                     // ... and conv2_i is ONE launch (option split16_chain=on|off)
     bool sf_path = true;                                      // option split16_sf=on|off: with conv3x3 = conv1x1 = split16, conv1_i and conv10_i write the
                                                               // split format (conv_split16.h) and both halves of conv2_i read it by LDS-DMA (conv_sf.hip)
 
@@ -432,6 +433,17 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             HIPCHK(launch_conv_wino_ws(wp, s));
             continue;
         }
+        if (sf && h->sf_chain) {
+            // the whole of conv2_i in one launch (conv_sf.hip, conv3x3_sf_chain_kernel): per (clip, tile) the shared half stays in
+            // registers as the initial C of the T frame tiles; in place on inp0 (residual)
+            ProfScope ps(h, s, PFNL_K_CONV3X3);
+            const uint16_t* const w16s = reinterpret_cast<const uint16_t*>(h->wdev16s.p);
+            ConvSplitParams q{h->inp1.p, w16s + h->off16s_c2b_sf[i], wd + h->off_c2_b[i], nullptr, h->inp0.p, h->inp0.p, H, W, F, T, 1};
+            q.in2 = h->base.p;
+            q.wpack2 = w16s + h->off16s_c2a_sf[i];
+            HIPCHK(launch_conv3x3_sf_chain(q, s));
+            continue;
+        }
         {   // conv2_i, shared half: 3x3 over `base` (kernel rows 0..63), once per clip, raw
             ProfScope ps(h, s, PFNL_K_CONV3X3);
             p.in = h->base.p;
@@ -568,6 +580,7 @@ int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
     pfnl_handle* h = new pfnl_handle();
     h->cfg = *cfg;
     if (const char* e = std::getenv("PFNL_SMALL")) h->small_mode = std::string(e) == "on" ? 1 : (std::string(e) == "off" ? 2 : 0);   // (A/B runs)
+    if (const char* e = std::getenv("PFNL_SF_CHAIN")) h->sf_chain = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_SPLIT16_SF")) h->sf_path = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_CONV3X3")) {
         const std::string v(e);
@@ -681,6 +694,12 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         else if (v == "on") h->small_mode = 1;
         else if (v == "off") h->small_mode = 2;
         else return fail(PFNL_ERR_INVALID, "small must be auto, on or off");
+        return 0;
+    }
+    if (k == "split16_chain") {
+        if (v == "on") h->sf_chain = true;
+        else if (v == "off") h->sf_chain = false;
+        else return fail(PFNL_ERR_INVALID, "split16_chain must be on or off");
         return 0;
     }
     if (k == "split16_sf") {
@@ -1573,8 +1592,36 @@ int pfnl_op_conv_small(const float* a, const float* b, int nA, int a_div, int b_
 int pfnl_op_conv3x3_split16_sf(int which, const float* in, const float* kernel_host, const float* bias_host, const float* addend,
                                int add_div, const float* resid, float* out, int items, int H, int W, int act, void* stream) {
     if (!in || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
-    if (which < 0 || which > 1 || items < 1 || H < 1 || W < 1 || (addend == nullptr) != (resid == nullptr)) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
-    if (addend && (which != 0 || add_div < 1 || items % add_div)) return fail(PFNL_ERR_INVALID, "fused mode: which = 0, items a multiple of add_div");
+    if (which < 0 || which > 2 || items < 1 || H < 1 || W < 1 || (addend == nullptr) != (resid == nullptr)) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
+    if (addend && ((which != 0 && which != 2) || add_div < 1 || items % add_div)) return fail(PFNL_ERR_INVALID, "fused mode: which = 0 or 2, items a multiple of add_div");
+    if (which == 2) {   // the whole of conv2_i (conv3x3_sf_chain_kernel): kernel_host = HWIO [3,3,128,64], `addend` = base [items/add_div][H][W][64] fp32
+        if (!addend) return fail(PFNL_ERR_INVALID, "which = 2 needs base (addend argument) and resid");
+        hipStream_t s2 = (hipStream_t)stream;
+        const size_t nh2 = pfnl::conv3x3_split16_pack_halfs();
+        std::vector<uint16_t> pk(2 * nh2 + 128, 0);
+        pfnl::conv3x3_split16_pack_weights(kernel_host, 128, 0, pk.data(), 64, true);
+        pfnl::conv3x3_split16_pack_weights(kernel_host, 128, 64, pk.data() + nh2, 64, true);
+        if (bias_host) std::memcpy(&pk[2 * nh2], bias_host, 64 * sizeof(float));
+        const size_t npf = (size_t)items * H * W, npb = (size_t)(items / add_div) * H * W;
+        uint16_t *dw2 = nullptr, *tf = nullptr, *tb = nullptr;
+        HIPCHK(hipMalloc(&dw2, pk.size() * sizeof(uint16_t)));
+        hipError_t e2 = hipMalloc(&tf, npf * 256);
+        if (e2 == hipSuccess) e2 = hipMalloc(&tb, npb * 256);
+        if (e2 == hipSuccess) e2 = hipMemcpy(dw2, pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+        if (e2 == hipSuccess) e2 = pfnl::launch_sf_from_f32(in, tf, npf, s2);
+        if (e2 == hipSuccess) e2 = pfnl::launch_sf_from_f32(addend, tb, npb, s2);
+        if (e2 == hipSuccess && out != resid) e2 = hipMemcpyAsync(out, resid, npf * 256, hipMemcpyDeviceToDevice, s2);   // the kernel works in place
+        pfnl::ConvSplitParams q{reinterpret_cast<const float*>(tf), dw2 + nh2, reinterpret_cast<const float*>(dw2 + 2 * nh2), nullptr, out, out, H, W, items, add_div, act};
+        q.in2 = reinterpret_cast<const float*>(tb);
+        q.wpack2 = dw2;
+        if (e2 == hipSuccess) e2 = pfnl::launch_conv3x3_sf_chain(q, s2);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(s2);
+        (void)hipFree(dw2);
+        (void)hipFree(tf);
+        (void)hipFree(tb);
+        if (e2 != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv2 chain op: ") + hipGetErrorString(e2));
+        return 0;
+    }
     hipStream_t s = (hipStream_t)stream;
     const size_t nh = pfnl::conv3x3_split16_pack_halfs();
     std::vector<uint16_t> pack(nh + 128, 0);

@@ -414,6 +414,367 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_kernel(ConvSplitPara
 #undef SF_BARRIER
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The WHOLE of conv2_i in one launch (reference model/pfnl.py:69-71 with the exact shared-base split of DESIGN.md section 3):
+// a chain = the T + 1 tiles of one (clip, spatial tile): first the shared half (input `base`, kernel rows 0..63), whose result
+// never leaves the registers - folded with the bias it becomes the INITIAL C of the T per-frame tiles (input inp1_t, kernel rows
+// 64..127) that follow, so the addend costs neither a launch, nor its HBM round trip (write + T reads per tile), nor an add.
+// Against conv3x3_sf_kernel<0> + <1>: the weight slices travel by LDS-DMA as well (L2 -> LDS, no registers: a chain switches
+// packs twice, and every unit may now bring the next unit's weights - the same three slices following the column taps consumed -
+// skipped when the next unit uses what is already there), each slice covered by its own fence load.
+__global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSplitParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sf_smem[];
+    unsigned char* const wl = sf_smem + 2 * SF_TILE_BYTES;
+    float* const bl = reinterpret_cast<float*>(sf_smem + 2 * SF_TILE_BYTES + SF_W_BYTES);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rp = wave >> 1;
+    const int nt = wave & 1;
+    const int H = p.H, W = p.W;
+    const int tiles_x = (W + SF_TW - 1) / SF_TW, tiles_y = (H + SF_TH - 1) / SF_TH;
+    const int per_item = tiles_x * tiles_y;
+    const int item_bytes = H * W * 256;
+    const int wbytes = W * 256;
+    const int T = p.add_div, gT = T + 1;                            // tiles of a chain: the shared half, then the T frames
+    const int nchains = per_item * (p.items / T);
+    const int xcd = blockIdx.x & 7, xj = blockIdx.x >> 3, cpx = gridDim.x >> 3;
+    const int per_xcd = (nchains + 7) >> 3;
+    const int cbeg = xcd * per_xcd;
+    const int ccnt = min(per_xcd, nchains - cbeg);
+    if (xj >= ccnt) return;
+    const int nt_tiles = ((ccnt - xj + cpx - 1) / cpx) * gT;
+    // tile k -> (f = position in the chain: 0 = shared half, clip, y0, x0)
+#define SFC_TILE(k_, f_, clip_, y0_, x0_)                                                        \
+    do {                                                                                         \
+        const int ci_ = (k_) / gT;                                                               \
+        f_ = (k_) - ci_ * gT;                                                                    \
+        const int ch_ = cbeg + xj + ci_ * cpx;                                                   \
+        clip_ = ch_ / per_item;                                                                  \
+        const int sp_ = ch_ - clip_ * per_item;                                                  \
+        const int ty_ = sp_ / tiles_x;                                                           \
+        y0_ = ty_ * SF_TH;                                                                       \
+        x0_ = (sp_ - ty_ * tiles_x) * SF_TW;                                                     \
+    } while (0)
+#define SFC_HALF(u_) ((((u_) >> 1) ^ (u_)) & 1)
+
+    const float bias_r = tid < 64 ? p.bias[tid] : 0.f;
+    int dpk[SF_DMA_ITERS];                                          // py | px << 8 of the lane's halo pixel per DMA instruction (the source offset is
+#pragma unroll                                                      // recomputed from it: this kernel has no registers to spare)
+    for (int k = 0; k < SF_DMA_ITERS; ++k) {
+        const int pix = 8 * (wave + 8 * k) + (lane >> 3);
+        const int py = pix / SF_IW, px = pix - py * SF_IW;
+        dpk[k] = py | (px << 8);
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)sf_smem;
+    const unsigned ldsw = lds0 + 2 * SF_TILE_BYTES;                 // LDS byte address of the weights
+#define SFC_DMA_HALO(rs_, org_, interior_, y0_, x0_, buf_)                                       \
+    do {                                                                                         \
+        _Pragma("unroll") for (int k_ = 0; k_ < SF_DMA_ITERS; ++k_) {                            \
+            const int i_ = wave + 8 * k_;                                                        \
+            if (k_ < SF_DMA_ITERS - 1 || i_ < SF_NDMA) {                                         \
+                const int py_ = dpk[k_] & 0xff, px_ = dpk[k_] >> 8;                              \
+                const int gy_ = (y0_) + py_ - 1, gx_ = (x0_) + px_ - 1;                          \
+                const bool in_ = (interior_) || ((unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W && py_ < SF_IH); \
+                const int rel_ = py_ * wbytes + px_ * 256 + (((lane & 7) ^ ((px_ >> 1) & 7)) << 4); \
+                sf_dma16(rs_, lds0 + (buf_) * SF_TILE_BYTES + i_ * 1024, in_ ? (org_) + rel_ : 0x7fffffff); \
+            }                                                                                    \
+        }                                                                                        \
+    } while (0)
+    // one 24 KB weight slice (column tap `slot` of pack `pk_`, channel half `half_`): 24 DMA instructions, 3 per wave
+    const int wvoff = wave * 1024 + lane * 16;
+#define SFC_DMA_W(pk_, half_, slot_)                                                             \
+    do {                                                                                         \
+        const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc(                    \
+            const_cast<uint16_t*>((pk_) ? p.wpack : p.wpack2), 0, 2 * SF_W_BYTES, 0x00020000);   \
+        _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_)                                         \
+            sf_dma16(rw_, ldsw + (slot_) * SF_SLOT_BYTES + (wave + 8 * k_) * 1024, (half_) * SF_W_BYTES + (slot_) * SF_SLOT_BYTES + wvoff + k_ * 8192); \
+    } while (0)
+
+    int paddr[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int col = (lane & 31) + kx;
+        paddr[kx] = ((2 * rp) * SF_IW + col) * 128 + ((((lane >> 5)) ^ ((col >> 1) & 7)) << 4);
+    }
+    const int lo_xor = 4 << 4;
+    const unsigned char* const wlane = wl + nt * 2048 + lane * 16;
+    const int ech = 32 * nt + (lane & 31);
+    f32x16 accm[2], accc[2], accp[2], pbv[2];                       // pbv: shared half + bias of the chain = initial C of its frames
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            accm[n][r] = 0.f;
+            accc[n][r] = 0.f;
+            accp[n][r] = 0.f;
+            pbv[n][r] = 0.f;
+        }
+    int ex0p = 0, ey0p = 0, eitemp = 0;
+    bool pending = false;
+    const float slope = p.act ? 0.2f : 1.0f;
+
+    __amdgpu_buffer_rsrc_t rsO;                                     // out == resid (the launcher checks): one resource per row
+    int evoff = 0;
+    float rres[8];                                                  // the residual of two quarters at a time
+    auto row_setup = [&](int n) __attribute__((always_inline)) {
+        const int ey = ey0p + 2 * rp + n;
+        const int nrec = (pending && ey < H) ? wbytes : 0;
+        rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + ((size_t)eitemp * H + ey) * W * 64, 0, nrec, 0x00020000);
+        evoff = (ex0p + 4 * (lane >> 5)) * 256 + ech * 4;
+    };
+    auto quarter_request = [&](int q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rres[4 * (q & 1) + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsO, evoff + j * 256, q * 2048, 0));
+    };
+    auto quarter_finish = [&](int n, int q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = accp[n][4 * q + j];                           // (shared half + bias are already in: initial C of the tile)
+            const float sv = v * slope;
+            asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(sv));
+            v += rres[4 * (q & 1) + j];
+            sf_store_b32<SF_STORE_AUX>(v, rsO, evoff + j * 256, q * 2048);
+        }
+    };
+    auto quarter_finish_with = [&](int n, int q, const float (&rv)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = accp[n][4 * q + j];
+            const float sv = v * slope;
+            asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(sv));
+            v += rv[j];
+            sf_store_b32<SF_STORE_AUX>(v, rsO, evoff + j * 256, q * 2048);
+        }
+    };
+#define SFC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+    // ---- prologue: halo of unit 0 (the first chain's shared half: `base`) and its weights (pack 0 = shared half, channel half 0)
+    int c_f, c_clip, c_y0, c_x0, n_f, n_clip, n_y0, n_x0;
+    SFC_TILE(0, c_f, c_clip, c_y0, c_x0);
+    n_f = c_f;
+    n_clip = c_clip;
+    n_y0 = c_y0;
+    n_x0 = c_x0;
+    {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.in2) + (size_t)c_clip * H * W * 64, 0, item_bytes, 0x00020000);
+        const int org = ((c_y0 - 1) * W + c_x0 - 1) * 256 + SFC_HALF(0) * 128;
+        SFC_DMA_HALO(rs, org, false, c_y0, c_x0, 0);
+        SFC_DMA_W(0, SFC_HALF(0), 0);
+        SFC_DMA_W(0, SFC_HALF(0), 1);
+        SFC_DMA_W(0, SFC_HALF(0), 2);
+        const unsigned fence = __builtin_amdgcn_raw_buffer_load_b32(rs, 0, 0, 0);
+        if (tid < 64) bl[tid] = bias_r;
+        asm volatile("" ::"v"(fence));
+    }
+    __syncthreads();
+    const float bias_l = bl[ech];
+    // weights in LDS now: (pack, half) of the current unit; the slice-2 request that is still owed to the current unit
+    int w_pk = 0;                                                   // pack of the current unit: 0 = shared half, 1 = per-frame half
+    bool w_slice2_owed = false;                                     // slice 2 of the current unit's weights still has to be brought (its slot was busy)
+
+    for (int kt = 0; kt < nt_tiles; ++kt) {
+        const int half_a = kt & 1;
+        auto unit = [&](auto par) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par)::value;
+            constexpr int cb = PAR;
+            const unsigned char* const tile = sf_smem + cb * SF_TILE_BYTES;
+            const int half_u = PAR == 0 ? half_a : half_a ^ 1;      // channel half of this unit
+            // the next unit: unit B of this tile (same pack, other half), or unit A of the next tile (same half, that tile's pack)
+            const int nx_pk = PAR == 0 ? w_pk : (n_f != 0);
+            const int nx_half = half_a ^ 1;
+            const bool w_replace = PAR == 0 || nx_pk != w_pk;       // (wave-uniform; unit B -> next A only at the two ends of a chain)
+            sfh8 X[4][2], Wv[2][2];
+#define SF_PX(g_, r_, part_) (*reinterpret_cast<const sfh8*>(tile + (paddr[(g_) >> 1] ^ (((part_) ? lo_xor : 0) | (((g_) & 1) << 5))) + (r_) * (SF_IW * 128)))
+#define SF_WT(g_, ky_, part_) (*reinterpret_cast<const sfh8*>(wlane + (((g_) * 3 + (ky_)) << 12) + ((part_) << 10)))
+            X[0][0] = SF_PX(0, 0, 0);
+            X[0][1] = SF_PX(0, 0, 1);
+            X[1][0] = SF_PX(0, 1, 0);
+            X[1][1] = SF_PX(0, 1, 1);
+            Wv[0][0] = SF_WT(0, 0, 0);
+            Wv[0][1] = SF_WT(0, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // slice 2 of THIS unit's weights (its slot was free only after the previous unit's closing barrier), then the next
+            // unit's halo; one fence load covers both (slice 2 is first read after b0, the halo after this unit's closing barrier)
+            if (w_slice2_owed) SFC_DMA_W(w_pk, half_u, 2);
+            const int q_f = PAR == 0 ? c_f : n_f, q_clip = PAR == 0 ? c_clip : n_clip, y0q = PAR == 0 ? c_y0 : n_y0, x0q = PAR == 0 ? c_x0 : n_x0;
+            const float* const qsrc = q_f == 0 ? p.in2 + (size_t)q_clip * H * W * 64 : p.in + ((size_t)q_clip * T + (q_f - 1)) * H * W * 64;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qsrc), 0, item_bytes, 0x00020000);
+            const int org = ((y0q - 1) * W + x0q - 1) * 256 + nx_half * 128;
+            const bool interior = y0q > 0 && y0q + SF_IH - 1 <= H && x0q > 0 && x0q + SF_IW - 1 <= W;
+            SFC_DMA_HALO(rs, org, interior, y0q, x0q, cb ^ 1);
+            const unsigned fence = __builtin_amdgcn_raw_buffer_load_b32(rs, 0, 0, 0);
+            unsigned fence_w = 0;
+            row_setup(PAR);
+
+            auto substep = [&](auto sc) __attribute__((always_inline)) {
+                constexpr int S = decltype(sc)::value;
+                constexpr int g = S / 3, ky = S % 3;
+                // the residual lines of quarters 0, 1 are requested at the unit's start and used 6 - 7 sub-steps later; those of
+                // quarters 2, 3 take their registers over (requested BEFORE the stores of 0, 1: vmcnt is in order and counts stores)
+                if constexpr (S == 0) quarter_request(0);
+                if constexpr (S == 1) quarter_request(1);
+                if constexpr (S == 7) {
+                    float v0[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v0[j] = rres[j];
+                    quarter_request(2);
+                    quarter_finish_with(PAR, 0, v0);
+                }
+                if constexpr (S == 8) {
+                    float v1[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v1[j] = rres[4 + j];
+                    quarter_request(3);
+                    quarter_finish_with(PAR, 1, v1);
+                }
+                if constexpr (S == 14) quarter_finish(PAR, 2);
+                if constexpr (S == 15) quarter_finish(PAR, 3);
+                if constexpr (ky == 0) {
+                    if constexpr (g == 2) {
+                        asm volatile("" ::"v"(fence));              // slice 2 of this unit's weights has landed (and the halo, as it happens)
+                        SFC_BARRIER();                              // b0: column tap 0 consumed; slice 2 complete
+                        if (w_replace) SFC_DMA_W(nx_pk, nx_half, 0);
+                        if constexpr (PAR == 0) {                   // decode the next tile (past the end: this one again - a harmless re-read)
+                            const int kn = min(kt + 1, nt_tiles - 1);
+                            SFC_TILE(kn, n_f, n_clip, n_y0, n_x0);
+                        }
+                    }
+                    if constexpr (g == 4) {
+                        SFC_BARRIER();                              // b1: column tap 1 consumed
+                        if (w_replace) SFC_DMA_W(nx_pk, nx_half, 1);
+                        fence_w = __builtin_amdgcn_raw_buffer_load_b32(rs, 0, 0, 0);   // covers slices 0 and 1 of the next unit's weights
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (S < 17) {
+                    constexpr int S1 = S + 1, g1 = S1 / 3, ky1 = S1 % 3;
+                    Wv[S1 & 1][0] = SF_WT(g1, ky1, 0);
+                    Wv[S1 & 1][1] = SF_WT(g1, ky1, 1);
+                    if constexpr (ky1 == 0) {
+                        X[0][0] = SF_PX(g1, 0, 0);
+                        X[0][1] = SF_PX(g1, 0, 1);
+                        X[1][0] = SF_PX(g1, 1, 0);
+                        X[1][1] = SF_PX(g1, 1, 1);
+                    } else {
+                        X[ky1 + 1][0] = SF_PX(g1, ky1 + 1, 0);
+                        X[ky1 + 1][1] = SF_PX(g1, ky1 + 1, 1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const sfh8 wh = Wv[S & 1][0], wo = Wv[S & 1][1];
+                if constexpr (PAR == 0 && S == 0) {                 // a tile's first products: C = the chain's shared half + bias (or 0 for that half itself)
+                    f32x16 zero;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+                    accm[0] = sf_mfma(X[ky][0], wh, pbv[0]);
+                    accm[1] = sf_mfma(X[ky + 1][0], wh, pbv[1]);
+                    accc[0] = sf_mfma(X[ky][0], wo, zero);
+                    accc[1] = sf_mfma(X[ky + 1][0], wo, zero);
+                } else {
+                    accm[0] = sf_mfma(X[ky][0], wh, accm[0]);
+                    accm[1] = sf_mfma(X[ky + 1][0], wh, accm[1]);
+                    accc[0] = sf_mfma(X[ky][0], wo, accc[0]);
+                    accc[1] = sf_mfma(X[ky + 1][0], wo, accc[1]);
+                }
+                accc[0] = sf_mfma(X[ky][1], wh, accc[0]);
+                accc[1] = sf_mfma(X[ky + 1][1], wh, accc[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            substep(std::integral_constant<int, 0>{});
+            substep(std::integral_constant<int, 1>{});
+            substep(std::integral_constant<int, 2>{});
+            substep(std::integral_constant<int, 3>{});
+            substep(std::integral_constant<int, 4>{});
+            substep(std::integral_constant<int, 5>{});
+            substep(std::integral_constant<int, 6>{});
+            substep(std::integral_constant<int, 7>{});
+            substep(std::integral_constant<int, 8>{});
+            substep(std::integral_constant<int, 9>{});
+            substep(std::integral_constant<int, 10>{});
+            substep(std::integral_constant<int, 11>{});
+            substep(std::integral_constant<int, 12>{});
+            substep(std::integral_constant<int, 13>{});
+            substep(std::integral_constant<int, 14>{});
+            substep(std::integral_constant<int, 15>{});
+            substep(std::integral_constant<int, 16>{});
+            substep(std::integral_constant<int, 17>{});
+#undef SF_PX
+#undef SF_WT
+            if constexpr (PAR == 1) {
+                // The tile is complete.  A frame tile is handed to the epilogue; the shared half of a chain stays in registers
+                // (+ bias) as the initial C of the frames that follow, and is cleared behind the chain's last frame (the next
+                // tile is a shared half again: initial C = 0).  Branch-free (selects on wave-uniform conditions): arms that
+                // define 32-register vectors cost the allocator live copies of both.
+                const bool head = c_f == 0, last = c_f == T;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const f32x16 fold = accm[n] + accc[n] * SF_ISCALE;
+                    accp[n] = fold;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pbv[n][r] = head ? fold[r] + bias_l : (last ? 0.f : pbv[n][r]);
+                }
+                ex0p = c_x0;
+                ey0p = c_y0;
+                eitemp = c_clip * T + (c_f - 1);
+                pending = !head;
+                c_f = n_f;
+                c_clip = n_clip;
+                c_y0 = n_y0;
+                c_x0 = n_x0;
+            }
+            w_slice2_owed = w_replace;                              // slice 2 of the next unit's weights goes once this unit's is consumed: at its start
+            w_pk = nx_pk;
+            asm volatile("" ::"v"(fence), "v"(fence_w));            // the next unit's halo and weight slices 0, 1 have landed
+            SFC_BARRIER();                                          // b2
+        };
+        unit(std::integral_constant<int, 0>{});
+        unit(std::integral_constant<int, 1>{});
+    }
+    // ---- the last tile (a frame tile): both rows
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        row_setup(n);
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            quarter_request(2 * h2);
+            quarter_request(2 * h2 + 1);
+            quarter_finish(n, 2 * h2);
+            quarter_finish(n, 2 * h2 + 1);
+        }
+    }
+#undef SFC_DMA_HALO
+#undef SFC_DMA_W
+#undef SFC_HALF
+#undef SFC_TILE
+#undef SFC_BARRIER
+}
+
+hipError_t launch_conv3x3_sf_chain(const ConvSplitParams& p, hipStream_t s) {
+    if (!p.in || !p.in2 || !p.wpack || !p.wpack2 || !p.bias || !p.out || !p.resid || p.items < 1 || p.H < 1 || p.W < 1 || p.accum || p.out_sf)
+        return hipErrorInvalidValue;
+    if (p.add_div < 1 || p.items % p.add_div || p.out != p.resid) return hipErrorInvalidValue;   // in place: out += ...
+    if ((long long)p.H * p.W * 256 >= 0x7fffffffLL) return hipErrorInvalidValue;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    static int ncu[64] = {};
+    if (!ncu[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        ncu[dev] = prop.multiProcessorCount;
+    }
+    const int grid = ncu[dev] >= 8 ? ncu[dev] / 8 * 8 : 8;
+    static bool attr_dev[64] = {};
+    if (!attr_dev[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_sf_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_dev[dev] = true;
+    }
+    hipLaunchKernelGGL(conv3x3_sf_chain_kernel, dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv3x3_sf(const ConvSplitParams& p, hipStream_t s) {
     if (!p.in || !p.wpack || !p.bias || !p.out || p.items < 1 || p.H < 1 || p.W < 1 || p.accum || p.out_sf) return hipErrorInvalidValue;
     if ((p.addend == nullptr) != (p.resid == nullptr) || (p.addend && (p.add_div < 1 || p.items % p.add_div))) return hipErrorInvalidValue;

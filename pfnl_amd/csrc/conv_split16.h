@@ -16,6 +16,8 @@ struct ConvSplitParams {
     int H, W, items, add_div, act;
     int accum;               // 1: out[items/add_div] = act(sum over the add_div frames of an item group + bias); wpack = add_div packs (convmerge1)
     int out_sf;              // 1 (plain mode only): `out` is written in the split format below instead of fp32
+    const float* in2;        // launch_conv3x3_sf_chain only: `base` [items/add_div][H][W] in the split format (the shared half's input)
+    const uint16_t* wpack2;  // ... and the packed kernel rows that multiply it (identity rows)
 };
 
 // THE SPLIT FORMAT ("SF") of an activation tensor that only ever feeds MFMA operands (conv1_i's output, conv10_i's output):
@@ -31,6 +33,9 @@ void conv3x3_split16_pack_weights(const float* hwio, int cin_total, int cin_begi
 // 3x3 64->64 with the INPUT in the split format (conv_sf.hip): halo tiles by LDS-DMA, epilogue from registers.  `in` points at SF
 // data ([items][H][W] x 256 B); wpack = conv3x3_split16_pack_weights(..., identity_rows = true); plain and fused (addend + resid) modes.
 hipError_t launch_conv3x3_sf(const ConvSplitParams& p, hipStream_t s);
+// the whole of conv2_i in one launch: per (clip, tile) the shared half (in2, wpack2) stays in registers as the initial C of the
+// add_div frame tiles (in, wpack) that follow; bias, leaky-relu and the residual in the epilogue; out may alias resid
+hipError_t launch_conv3x3_sf_chain(const ConvSplitParams& p, hipStream_t s);
 hipError_t launch_sf_from_f32(const float* in, uint16_t* out, size_t npix, hipStream_t s);   // [npix][64] fp32 -> SF (tests / taps)
 hipError_t launch_sf_to_f32(const uint16_t* in, float* out, size_t npix, hipStream_t s);     // SF -> hi + lo' 2^-11
 

@@ -223,13 +223,15 @@ def conv3x3_winograd(x, kernel, bias=None, act=True, addend=None, add_div=1, res
     lib = _capi.load_library()
     k = _host(kernel, "kernel")
     b = _host(bias, "bias")
-    if k.shape != (3, 3, 64, 64):
+    if k.shape != (3, 3, 64, 64) and variant != "split16_sf_chain":
         raise ValueError("winograd path is 3x3, 64 -> 64 only")
     F, H, W, c = x.shape
     out = torch.empty((F, H, W, 64), dtype=torch.float32, device=x.device)
-    if variant in ("split16_sf_in", "split16_sf_out"):    # the split-format kernels (conv_sf.hip / conv1_i writing SF), fp32 at this interface
+    if variant in ("split16_sf_in", "split16_sf_out", "split16_sf_chain"):   # the split-format kernels (conv_sf.hip / conv1_i writing SF), fp32 at this interface
+        if variant != "split16_sf_chain" and k.shape != (3, 3, 64, 64):
+            raise ValueError("3x3, 64 -> 64 only")
         _capi.check(lib.pfnl_op_conv3x3_split16_sf(
-            0 if variant == "split16_sf_in" else 1,
+            {"split16_sf_in": 0, "split16_sf_out": 1, "split16_sf_chain": 2}[variant],
             _req(x, "x"), k.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p) if b is not None else None,
             _req(addend, "addend") if addend is not None else None, int(add_div),
             _req(resid, "resid") if resid is not None else None, _req(out, "out"), F, H, W, 1 if act else 0, _stream(x)))

@@ -410,6 +410,29 @@ def test_conv3x3_split16_sf_input(items, H, W, fused, act):
     assert e_o < 2e-6 * max(1.0, np.abs(ref).max()), e_o
 
 
+@pytest.mark.parametrize("T,clips,H,W", [(7, 1, 8, 32), (7, 2, 10, 38), (5, 1, 33, 70), (3, 3, 16, 24), (7, 4, 128, 128), (7, 1, 1, 1), (7, 3, 9, 130)])
+def test_conv2_chain_sf(T, clips, H, W):
+    """conv3x3_sf_chain_kernel: the WHOLE of conv2_i (reference model/pfnl.py:69-71: lrelu(conv3x3(concat([base, inp1_t]), 128 -> 64)
+    + bias) + inp0_t) in one launch, the shared half held in registers as the initial C of the T frame tiles, weights and halos
+    by LDS-DMA.  Against the fp64 spec of the concat form, and against the two-launch form (same operands: summation order only)."""
+    rng = np.random.default_rng(T * 1000 + H * 10 + W)
+    F = clips * T
+    x = rng.normal(size=(F, H, W, 64)).astype(np.float32)
+    base = rng.normal(size=(clips, H, W, 64)).astype(np.float32)
+    res = rng.normal(size=(F, H, W, 64)).astype(np.float32)
+    k2 = (rng.normal(size=(3, 3, 128, 64)) / 34.0).astype(np.float32)
+    b = (rng.normal(size=64) * 0.1).astype(np.float32)
+    cat = np.concatenate([np.repeat(base.astype(np.float64), T, axis=0), x.astype(np.float64)], axis=-1)
+    ref = pfnl_spec.lrelu(pfnl_spec.conv2d_same(cat, k2.astype(np.float64), b.astype(np.float64))) + res
+    got = ops.conv3x3_winograd(dev(x), k2, b, act=True, addend=dev(base), add_div=T, resid=dev(res), variant="split16_sf_chain").cpu().numpy()
+    pb = ops.conv3x3_winograd(dev(base), np.ascontiguousarray(k2[:, :, :64]), None, act=False, variant="split16_sf_in")
+    two = ops.conv3x3_winograd(dev(x), np.ascontiguousarray(k2[:, :, 64:]), b, act=True, addend=pb, add_div=T, resid=dev(res), variant="split16_sf_in").cpu().numpy()
+    e, e2 = np.abs(got - ref).max(), np.abs(got - two).max()
+    print(f"conv2 chain T{T} {clips}x{H}x{W}: err {e:.3g}, vs the two-launch form {e2:.3g}")
+    assert e < 4e-6 * max(1.0, np.abs(ref).max()), e
+    assert e2 < 2e-6 * max(1.0, np.abs(ref).max()), e2
+
+
 @pytest.mark.parametrize("items,H,W,act", [(1, 8, 32, True), (3, 5, 7, False), (1, 1, 1, True), (2, 64, 96, True), (7, 33, 70, True), (1, 9, 130, True)])
 def test_conv3x3_split16_sf_output(items, H, W, act):
     """conv1_i writing the split format (conv3x3_split16_kernel<0, OSF>): hi + lo' 2^-11 of what it writes is the fp32 kernel's
