@@ -16,7 +16,7 @@ def per_kernel(db, ctr):
         span[(name, grid)] = (min(lo, dur), max(hi, dur))
     out = {}
     for name, grid, val, dur in raw:
-        if "conv_wino" not in name and "conv_mfma_kernel<3, 16, 2" not in name and "conv3x3_split16" not in name:
+        if "conv_wino" not in name and "conv_mfma_kernel<3, 16, 2" not in name and "conv3x3_split16" not in name and "conv3x3_sf" not in name:
             continue
         lo, hi = span[(name, grid)]
         cls = ""
@@ -37,7 +37,7 @@ def main():
     tot_b = 0.0
     tot_n = 0
     for k in f:
-        if "ws_kernel<3>" in k:        # convmerge1 (accumulating mode): not the conv3x3 class of bench.py
+        if "ws_kernel<3>" in k or "split16_kernel<2" in k:        # convmerge1 (accumulating mode): not the conv3x3 class of bench.py
             continue
         n = f[k][0]
         fb = f[k][1] / n * 1024 * 2
