@@ -4,18 +4,18 @@
 //
 // Why a kernel of its own: the persistent kernels (conv_split16.hip, conv_sf.hip, conv_wino_ws.hip) are built around 8 x 32-pixel
 // tiles, 72 KB of weights per workgroup in the prologue and one workgroup per CU - at 7 x 32 x 32 a launch has 28 such tiles
-// for 256 CUs and costs 15 - 27 us whatever it computes (round 2: 85 launches, 1.6 ms).  Here a workgroup is 4 waves and owns
-// R rows x 32 pixels x 64 output channels (R = 1 or 2, picked so that a launch has >= ~200 workgroups when it can), two
-// workgroups fit a CU, and nothing is resident: K (= taps x input channels) is walked source by source (a source = the 64
-// channels of one input tensor at the tile: a frame, or `base`), split over the 4 waves as (output channel tile nt, half kh of
-// every source's channels); the two K halves meet in LDS at the end.
+// for 256 CUs and costs 15 - 27 us whatever it computes (round 2: 85 launches, 1.6 ms).  Here a workgroup is 8 waves (two per
+// SIMD: they cover each other's LDS and weight-load latency) and owns R rows x 32 pixels x 64 output channels (R = 1, 2 or 3,
+// picked so that a launch is a whole number of ~full rounds of workgroups), and nothing is resident: K (= taps x input
+// channels) is walked source by source (a source = the 64 channels of one input tensor at the tile: a frame, or `base`), split
+// over the 8 waves as (output channel tile nt, 16-channel group kq of every source); the four K parts meet in LDS at the end.
 //   * arithmetic: that of conv_split16.hip - every fp32 operand split exactly into two binary16 numbers, three
 //     v_mfma_f32_32x32x16_f16 per product block, fp32 accumulation, cross terms in a second accumulator (x 2^-11 at the end);
 //   * activations fp32 NHWC in HBM (L2-resident at these sizes); a source's (R + 2) x 34 halo is loaded as 16-byte pieces, split on
 //     the way into LDS ([pixel][half][hi | lo'][32 ch], 16-byte chunks XOR-swizzled with the pixel column), double-buffered, one
 //     barrier per source; out-of-image pixels: out-of-range buffer offsets (zeros);
 //   * weights never touch LDS: they are the MFMA's B operand (lane = output channel), packed per wave in the order it walks
-//     them ([kh][nt][source][step][hi / lo'][lane] x 16 B) and streamed L2 -> registers through a ring 6 k-steps deep;
+//     them ([kq][nt][source][tap][hi / lo'][lane] x 16 B) and streamed L2 -> registers through a ring up to a source deep;
 //   * MFMA roles A = pixels, B = weights: D[pixel][cout], so the K-half partials go to LDS as conflict-free 4-byte stores and
 //     come back as whole 16-byte channel pieces for a coalesced NHWC epilogue (bias, leaky-relu, residual).
 #include <cstring>
@@ -32,7 +32,10 @@ typedef _Float16 cmh4 __attribute__((ext_vector_type(4)));
 typedef unsigned cmu4 __attribute__((ext_vector_type(4)));
 typedef unsigned cmu2 __attribute__((ext_vector_type(2)));
 
-constexpr int CM_THREADS = 256;
+constexpr int CM_NW = 8;                                            // waves per workgroup: (cout tile nt) x (channel group kq of every source: 16 channels)
+constexpr int CM_THREADS = CM_NW * 64;
+constexpr int CM_NQ = CM_NW / 2;                                    // K parts that meet in LDS
+constexpr int CM_CGW = 8 / CM_NW;                                   // 16-channel groups of a source per wave (1)
 
 #ifdef PFNL_CM_TIMING   /* phase timeline of a workgroup (tools/cm_timing.py); not part of the product build */
 __device__ long long cm_dbg[4096 * 16];
@@ -48,9 +51,9 @@ struct CmGeom {
     static constexpr int BUF_BYTES = NPIX * 256;                    // one source's halo in operand form
     static constexpr int PIECES = NPIX * 16;                        // 16-byte fp32 pieces (4 channels)
     static constexpr int ITERS = (PIECES + CM_THREADS - 1) / CM_THREADS;
-    static constexpr int STEPS = 2 * KS * KS;                       // k-steps (16 channels x one tap) of a wave per source
-    static constexpr int RING = KS == 3 ? (R == 1 ? 9 : 6) : 2;     // weight operands in flight (divides STEPS; R = 1 has the registers for half a source)
-    static constexpr int RED_BYTES = 2 * R * 32 * 256;              // the two K halves of the tile, fp32 pixel lines
+    static constexpr int STEPS = CM_CGW * KS * KS;                  // k-steps (16 channels x one tap) of a wave per source
+    static constexpr int RING = KS == 3 ? (R == 3 ? 3 : 9) : 1;     // weight operands in flight (divides STEPS)
+    static constexpr int RED_BYTES = CM_NQ * R * 32 * 256;          // the K parts of the tile, fp32 pixel lines
     static constexpr int LDS_BYTES = (2 * BUF_BYTES > RED_BYTES ? 2 * BUF_BYTES : RED_BYTES);
 };
 
@@ -67,7 +70,7 @@ __device__ __forceinline__ void cm_split4(f32x4 v, cmu2& hi, cmu2& lo, float nsc
 }
 
 template <int KS, int R>
-__global__ __launch_bounds__(CM_THREADS, R == 3 ? 1 : 2) void conv_small_kernel(ConvSmallParams p) {   // (R = 3: one workgroup per CU by construction)
+__global__ __launch_bounds__(CM_THREADS, 1) void conv_small_kernel(ConvSmallParams p) {
     using G = CmGeom<KS, R>;
     constexpr int PAD = KS / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char cm_smem[];
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(CM_THREADS, R == 3 ? 1 : 2) void conv_small_kernel(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt = wave & 1;                                        // output channels 32 nt .. 32 nt + 31
-    const int kh = wave >> 1;                                       // channels 32 kh .. 32 kh + 31 of every source
+    const int kq = wave >> 1;                                       // channels 16 kq .. 16 kq + 15 of every source
     const int H = p.H, W = p.W;
     const int tiles_x = (W + 31) >> 5, tiles_y = (H + R - 1) / R;
     const int per_item = tiles_x * tiles_y;
@@ -125,16 +128,16 @@ __global__ __launch_bounds__(CM_THREADS, R == 3 ? 1 : 2) void conv_small_kernel(
         }
     };
 
-    // pixel operand of (tap ky kx, row r, step parity jj, part): chunk 8 kh + 4 part + 2 jj + (lane >> 5) of halo pixel
-    // (r + ky, (lane & 31) + kx): address = paddr[kx] ^ (part * 64 + jj * 32) + (r + ky) * IW * 256
+    // pixel operand of (tap ky kx, row r, part): chunk 8 (kq >> 1) + 4 part + 2 (kq & 1) + (lane >> 5) of halo pixel
+    // (r + ky, (lane & 31) + kx): address = paddr[kx] ^ (part * 64) + (r + ky) * IW * 256
     int paddr[KS];
 #pragma unroll
     for (int kx = 0; kx < KS; ++kx) {
         const int col = (lane & 31) + kx;
-        paddr[kx] = col * 256 + (((kh * 8 + (lane >> 5)) ^ (col & 15)) << 4);
+        paddr[kx] = col * 256 + ((((kq >> 1) * 8 + (kq & 1) * 2 + (lane >> 5)) ^ (col & 15)) << 4);
     }
-    // weights: this wave's steps are contiguous: [kh][nt][source][step][part][lane] x 16 B
-    const cmu4* const wsrc = reinterpret_cast<const cmu4*>(p.wpack) + ((size_t)(kh * 2 + nt) * ntot) * 128 + lane;
+    // weights: this wave's steps are contiguous: [kq][nt][source][tap][part][lane] x 16 B
+    const cmu4* const wsrc = reinterpret_cast<const cmu4*>(p.wpack) + ((size_t)(kq * 2 + nt) * ntot) * 128 + lane;
     cmu4 wring[G::RING][2];
 #pragma unroll
     for (int n = 0; n < G::RING; ++n) {
@@ -169,12 +172,12 @@ __global__ __launch_bounds__(CM_THREADS, R == 3 ? 1 : 2) void conv_small_kernel(
         cmh8 aop[2][R][2];
         auto read_ops = [&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
-            constexpr int tap = j >> 1, jj = j & 1, ky = tap / KS, kx = tap % KS;
+            constexpr int tap = j, ky = tap / KS, kx = tap % KS;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const unsigned char* const q = tile + (r + ky) * (G::IW * 256);
-                aop[j & 1][r][0] = *reinterpret_cast<const cmh8*>(q + (paddr[kx] ^ (jj * 32)));
-                aop[j & 1][r][1] = *reinterpret_cast<const cmh8*>(q + (paddr[kx] ^ (64 + jj * 32)));
+                aop[j & 1][r][0] = *reinterpret_cast<const cmh8*>(q + paddr[kx]);
+                aop[j & 1][r][1] = *reinterpret_cast<const cmh8*>(q + (paddr[kx] ^ 64));
             }
         };
         read_ops(std::integral_constant<int, 0>{});
@@ -197,8 +200,8 @@ __global__ __launch_bounds__(CM_THREADS, R == 3 ? 1 : 2) void conv_small_kernel(
             __builtin_amdgcn_sched_barrier(0);
         };
         step(std::integral_constant<int, 0>{});
-        step(std::integral_constant<int, 1>{});
         if constexpr (KS == 3) {
+            step(std::integral_constant<int, 1>{});
             step(std::integral_constant<int, 2>{});
             step(std::integral_constant<int, 3>{});
             step(std::integral_constant<int, 4>{});
@@ -206,15 +209,6 @@ __global__ __launch_bounds__(CM_THREADS, R == 3 ? 1 : 2) void conv_small_kernel(
             step(std::integral_constant<int, 6>{});
             step(std::integral_constant<int, 7>{});
             step(std::integral_constant<int, 8>{});
-            step(std::integral_constant<int, 9>{});
-            step(std::integral_constant<int, 10>{});
-            step(std::integral_constant<int, 11>{});
-            step(std::integral_constant<int, 12>{});
-            step(std::integral_constant<int, 13>{});
-            step(std::integral_constant<int, 14>{});
-            step(std::integral_constant<int, 15>{});
-            step(std::integral_constant<int, 16>{});
-            step(std::integral_constant<int, 17>{});
         }
         if (c == 0) CM_STAMP(4);
         if (more) commit((c & 1) ^ 1);
@@ -234,7 +228,7 @@ __global__ __launch_bounds__(CM_THREADS, R == 3 ? 1 : 2) void conv_small_kernel(
         if (p.resid) rsd[k] = *reinterpret_cast<const f32x4*>(p.resid + (((size_t)item * H + y) * W + x) * 64 + cc * 4);
     }
     {
-        float* const red = reinterpret_cast<float*>(cm_smem) + (kh * R * 32) * 64 + 32 * nt + (lane & 31);
+        float* const red = reinterpret_cast<float*>(cm_smem) + (kq * R * 32) * 64 + 32 * nt + (lane & 31);
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -249,8 +243,9 @@ __global__ __launch_bounds__(CM_THREADS, R == 3 ? 1 : 2) void conv_small_kernel(
         const int id = k * CM_THREADS + tid;
         const int pp = id >> 4, cc = id & 15;                       // pixel r * 32 + x of the tile, 4-channel piece
         const int y = y0 + (pp >> 5), x = x0 + (pp & 31);
-        f32x4 v = *reinterpret_cast<const f32x4*>(cm_smem + pp * 256 + cc * 16) +
-                  *reinterpret_cast<const f32x4*>(cm_smem + (R * 32 + pp) * 256 + cc * 16) + bias4;
+        f32x4 v = bias4;
+#pragma unroll
+        for (int q = 0; q < CM_NQ; ++q) v += *reinterpret_cast<const f32x4*>(cm_smem + (q * R * 32 + pp) * 256 + cc * 16);
         v.x = fmaxf(v.x, v.x * slope);
         v.y = fmaxf(v.y, v.y * slope);
         v.z = fmaxf(v.z, v.z * slope);
@@ -281,12 +276,12 @@ __global__ __launch_bounds__(CM1_THREADS, 2) void conv_small_1x1_kernel(ConvSmal
     const int item = blockIdx.x / gpi;
     const int p0 = (blockIdx.x - item * gpi) * 32;
     const int nsrc = p.nsrc;
-    const int ntot = 2 * nsrc;
     const float nscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -2048.0f)));
     const size_t hw64 = (size_t)HW * 64;
     // lane (pixel p0 + (lane & 31), k half lane >> 5): channels 32 kh + 16 jj + 8 (lane >> 5) + e of a source
     const size_t poff = (size_t)min(p0 + (lane & 31), HW - 1) * 64 + 32 * kh + 8 * (lane >> 5);
-    const cmu4* const wsrc = reinterpret_cast<const cmu4*>(p.wpack) + ((size_t)(kh * 2 + nt) * ntot) * 128 + lane;
+    // weights (conv_small_pack_weights, ks = 1): [channel group kq = 2 kh + jj][nt][source][part][lane] x 16 B
+    const cmu4* const wsrc = reinterpret_cast<const cmu4*>(p.wpack) + lane;
     f32x4 av[CM1_MAXSRC / 2][2][2];
     cmu4 wv[CM1_MAXSRC / 2][2][2];
 #pragma unroll
@@ -297,8 +292,9 @@ __global__ __launch_bounds__(CM1_THREADS, 2) void conv_small_1x1_kernel(ConvSmal
         for (int jj = 0; jj < 2; ++jj) {
             av[i][jj][0] = *reinterpret_cast<const f32x4*>(src + 16 * jj);
             av[i][jj][1] = *reinterpret_cast<const f32x4*>(src + 16 * jj + 4);
-            wv[i][jj][0] = wsrc[(size_t)(2 * sc + jj) * 128];
-            wv[i][jj][1] = wsrc[(size_t)(2 * sc + jj) * 128 + 64];
+            const size_t wn = ((size_t)((2 * kh + jj) * 2 + nt) * nsrc + sc) * 128;
+            wv[i][jj][0] = wsrc[wn];
+            wv[i][jj][1] = wsrc[wn + 64];
         }
     }
     f32x16 accm, accc;
@@ -365,8 +361,9 @@ hipError_t launch_conv_small(const ConvSmallParams& p, hipStream_t s) {
     if ((p.nA > 0 && (!p.a || p.a_div < 1)) || p.b_mul < 1 || (p.ks != 1 && p.ks != 3)) return hipErrorInvalidValue;
     if ((long long)p.H * p.W * 256 >= 0x7fffffffLL) return hipErrorInvalidValue;
     const int tiles_x = (p.W + 31) / 32;
-    // rows per workgroup: a CU's time is ~ (workgroups it gets) x R, so minimise ceil(workgroups / CUs) x R; ties go to the larger R
-    // (fewer workgroups to dispatch, fewer weight bytes).  7 x 32 x 32 -> R = 1 (224), 5 x 64 x 64 -> R = 3 (220), 7 x 64 x 64 -> R = 2 (448)
+    // rows per workgroup (one 8-wave workgroup per CU at a time): a CU's time is ~ (workgroups it gets) x R, so minimise
+    // ceil(workgroups / CUs) x R; ties go to the larger R (fewer workgroups to dispatch, fewer weight bytes).
+    // 7 x 32 x 32 -> R = 1 (224 workgroups), 5 x 64 x 64 -> R = 3 (220), 7 x 64 x 64 -> R = 2 (448)
     static int ncu = 0;
     if (!ncu) {
         int dev = 0;
@@ -389,29 +386,30 @@ hipError_t launch_conv_small(const ConvSmallParams& p, hipStream_t s) {
     const long long t2 = tr[2], t1 = tr[1];
     const bool r2 = bestR >= 2;
     if (p.ks == 3) return bestR == 3 ? cm_launch<3, 3>(p, (int)tr[3], s) : bestR == 2 ? cm_launch<3, 2>(p, (int)t2, s) : cm_launch<3, 1>(p, (int)t1, s);
-    if (p.nsrc <= CM1_MAXSRC) {                                     // conv10_i: no halo, no LDS staging
+    if (p.ks == 1 && p.nsrc <= CM1_MAXSRC) {                        // conv10_i: no halo, no LDS staging
         const long long g = (long long)p.items * (((long long)p.H * p.W + 31) / 32);
         if (g > 0x7fffffffLL) return hipErrorInvalidValue;
         hipLaunchKernelGGL(conv_small_1x1_kernel, dim3((unsigned)g), dim3(CM1_THREADS), 0, s, p);
         return hipGetLastError();
     }
-    return r2 ? cm_launch<1, 2>(p, (int)t2, s) : cm_launch<1, 1>(p, (int)t1, s);
+    (void)r2;
+    return cm_launch<1, 1>(p, (int)t1, s);
 }
 
 size_t conv_small_pack_halfs(int ks, int nsrc) { return (size_t)nsrc * ks * ks * 4 * 2 * 2 * 512; }   // per source: taps x 4 channel groups x 2 nt x (hi, lo') x 1 KB
 
-// HWIO [ks, ks, 64 * nsrc, cout] -> [kh][nt][source][step j = 2 tap + jj][part][lane][e]:
-// W[tap][64 s + 16 (2 kh + jj) + 8 (lane >> 5) + e][32 nt + (lane & 31)], part 0 = f16(w), part 1 = f16((w - hi) 2^11); cout < 64: zero-padded
+// HWIO [ks, ks, 64 * nsrc, cout] -> [channel group kq][nt][source][tap][part][lane][e]:
+// W[tap][64 s + 16 kq + 8 (lane >> 5) + e][32 nt + (lane & 31)], part 0 = f16(w), part 1 = f16((w - hi) 2^11); cout < 64: zero-padded
 void conv_small_pack_weights(const float* hwio, int ks, int nsrc, int cout, uint16_t* dst) {
-    const int steps = 2 * ks * ks, cin = 64 * nsrc;
-    for (int kh = 0; kh < 2; ++kh)
+    const int steps = CM_CGW * ks * ks, cin = 64 * nsrc;
+    for (int kh = 0; kh < CM_NQ; ++kh)
         for (int nt = 0; nt < 2; ++nt)
             for (int s = 0; s < nsrc; ++s)
                 for (int j = 0; j < steps; ++j)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int e = 0; e < 8; ++e) {
-                            const int tap = j >> 1, jj = j & 1;
-                            const int ci = 64 * s + 16 * (2 * kh + jj) + 8 * (lane >> 5) + e;
+                            const int tap = j / CM_CGW, jj = j % CM_CGW;
+                            const int ci = 64 * s + 16 * (CM_CGW * kh + jj) + 8 * (lane >> 5) + e;
                             const int co = 32 * nt + (lane & 31);
                             const float w = co < cout ? hwio[((size_t)tap * cin + ci) * cout + co] : 0.f;
                             const _Float16 hi = (_Float16)w;
