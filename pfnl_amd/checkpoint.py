@@ -69,6 +69,18 @@ def match_tensors(geom: PFNLGeometry, tensors: Dict[str, np.ndarray]) -> Dict[st
     if missing:
         raise KeyError("checkpoint lacks {} of {} tensors, e.g. {}".format(
             len(missing), len(geom.weight_shapes()), missing[:3]))
+    # the optional theta / phi projections of the non-local block (nltype 0 checkpoints, reference utils.py:31-42): all four
+    # travel with the model, a partial set is an error - never silently dropped (an nltype-0 model would run as nltype 1)
+    opt = geom.optional_weight_shapes()
+    got = {}
+    for name, shape in opt:
+        suffix = name.split("/", 1)[1]
+        hits = [k for k in tensors if (k == name or k == suffix or k.endswith("/" + suffix)) and tuple(np.shape(tensors[k])) == tuple(shape)]
+        if len(hits) == 1:
+            got[name] = np.asarray(tensors[hits[0]], dtype=np.float32)
+    if got and len(got) != len(opt):
+        raise KeyError("checkpoint holds {} of the {} theta / phi tensors of nlblock_0: all or none".format(len(got), len(opt)))
+    out.update(got)
     return out
 
 
@@ -82,19 +94,37 @@ def load_checkpoint(checkpoint_dir: str, geom: PFNLGeometry, step: Optional[int]
         return None
     prefix = os.path.join(checkpoint_dir, base)
     has_npz, has_tf = os.path.isfile(prefix + ".npz"), os.path.isfile(prefix + ".index")
-    # The TF bundle is the reference's format and wins; the .npz sibling is this build's cache of it and is only
-    # preferred when it is at least as new (a re-downloaded checkpoint must not be shadowed by a stale cache).
-    if has_npz and has_tf and os.path.getmtime(prefix + ".npz") < os.path.getmtime(prefix + ".index"):
-        has_npz = False
+    # The TF bundle is the reference's format and wins; the .npz sibling is this build's cache of it and is only used when it
+    # was derived from THIS bundle: it carries the size + sha1 of the .index it was written next to (mtimes say nothing: tar,
+    # unzip and rsync -t preserve old ones, so a re-downloaded checkpoint could be shadowed by a newer stale cache).
+    tensors = None
     if has_npz:
         with np.load(prefix + ".npz") as z:
-            tensors = {k: z[k] for k in z.files}
+            sig = str(z[_SIG_KEY]) if _SIG_KEY in z.files else ""
+            if not has_tf or sig == index_signature(prefix):
+                tensors = {k: z[k] for k in z.files if k != _SIG_KEY}
+    if tensors is not None:
+        pass
     elif has_tf:
         from . import tfbundle
         tensors = tfbundle.read_bundle(prefix)
     else:
         return None
     return base, match_tensors(geom, tensors)
+
+
+_SIG_KEY = "__tf_index_signature__"
+
+
+def index_signature(prefix: str) -> str:
+    """size:sha1 of <prefix>.index ("" when there is none): what ties an .npz cache to the bundle it mirrors."""
+    import hashlib
+    path = prefix + ".index"
+    if not os.path.isfile(path):
+        return ""
+    with open(path, "rb") as f:
+        data = f.read()
+    return "{}:{}".format(len(data), hashlib.sha1(data).hexdigest())
 
 
 def save_checkpoint(checkpoint_dir: str, weights: Dict[str, np.ndarray], step: int, model_name: str = "VSR",
@@ -105,12 +135,14 @@ def save_checkpoint(checkpoint_dir: str, weights: Dict[str, np.ndarray], step: i
     if fmt in ("tf", "both"):
         from . import tfbundle
         tfbundle.write_bundle(prefix, {k: np.asarray(v, np.float32) for k, v in weights.items()})
-    elif os.path.isfile(prefix + ".index"):                   # writing only the cache: drop a stale bundle of the same step
-        for suffix in (".index", ".data-00000-of-00001"):
-            if os.path.isfile(prefix + suffix):
-                os.remove(prefix + suffix)
-    if fmt in ("npz", "both"):                                 # written last: never older than its bundle
-        np.savez(prefix + ".npz", **{k: np.asarray(v, np.float32) for k, v in weights.items()})
+    elif os.path.isfile(prefix + ".index"):
+        # only the cache format was asked for, but a reference-format bundle of this step exists: it would win at load time
+        # (different signature) and this function does not delete checkpoints behind the caller's back
+        raise FileExistsError("{}.index exists: save with fmt='both' (rewrites it) or remove the bundle first".format(prefix))
+    if fmt in ("npz", "both"):                                 # written last, with the signature of the bundle it mirrors
+        arrs = {k: np.asarray(v, np.float32) for k, v in weights.items()}
+        arrs[_SIG_KEY] = np.array(index_signature(prefix))
+        np.savez(prefix + ".npz", **arrs)
     elif os.path.isfile(prefix + ".npz"):
         os.remove(prefix + ".npz")
     write_state_file(checkpoint_dir, base)

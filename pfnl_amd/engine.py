@@ -118,7 +118,8 @@ class PFNLEngine:
         return out
 
     def forward_device(self, in_ptr: int, out_ptr: int, B: int, H: int, W: int, stream: int = 0) -> None:
-        """Raw device-pointer form (asynchronous on ``stream``; 0 = the handle's own stream)."""
+        """Raw device-pointer form (asynchronous on ``stream``; 0 = the legacy null stream, i.e. torch's default stream).
+        Asynchronous calls cannot re-run on the f32 kernels when the f16-pipe range flag fires: check ``sync()``."""
         self._check_input((B, self.geom.num_frames, H, W, 3), True)
         _capi.check(self._lib.pfnl_forward(self._h, C.c_void_p(in_ptr), 1, C.c_void_p(out_ptr), 1, B, H, W,
                                            C.c_void_p(stream) if stream else None))

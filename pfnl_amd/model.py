@@ -261,6 +261,13 @@ class PFNL(VSR):
     encode_threads = min(16, os.cpu_count() or 1)   # PNG encoders / decoders running while the GPU works on the next batch
 
     def _run_sequence(self, lrs, save_path: str, part: int):
+        """Device-scoped wrapper: the harness helpers (pfnl_op_gather_windows / quantise_u8) launch on the tensor's stream without
+        a hipSetDevice of their own, so the whole body runs with this model's device current (self.device != 0)."""
+        import torch
+        with torch.cuda.device(self.device):
+            return self._run_sequence_on_device(lrs, save_path, part)
+
+    def _run_sequence_on_device(self, lrs, save_path: str, part: int):
         """Shared tail of test_video_truth / test_video_lr (model/pfnl.py:236-262, 293-320).  ``lrs`` [F,H,W,3] float32:
         numpy (uploaded ONCE) or already a cuda tensor.  Per batch, all on the device: gather of the clamped T-frame
         windows (pfnl_op_gather_windows), pfnl_forward, uint8 quantisation (pfnl_op_quantise_u8); the uint8 frames

@@ -269,15 +269,27 @@ def test_checkpoint_format_preference_and_mismatch(tmp_path):
     w_old, w_new = synth.synthetic_weights(g, seed=1), synth.synthetic_weights(g, seed=2)
     checkpoint.save_checkpoint(str(tmp_path), w_old, 10, fmt="npz")
     import time
-    time.sleep(0.05)
-    tfbundle.write_bundle(str(tmp_path / "VSR-10"), w_new)          # a (re)downloaded TF checkpoint next to a stale cache
-    os.utime(tmp_path / "VSR-10.index", (time.time() + 5, time.time() + 5))
+    tfbundle.write_bundle(str(tmp_path / "VSR-10"), w_new)          # a (re)downloaded TF checkpoint next to a stale cache ...
+    os.utime(tmp_path / "VSR-10.index", (time.time() - 500, time.time() - 500))   # ... with an OLD mtime (tar / rsync -t keep them)
     got = checkpoint.load_checkpoint(str(tmp_path), g, step=10)
-    assert np.array_equal(got[1]["nlvsr/conv0/kernel"], w_new["nlvsr/conv0/kernel"])
-    checkpoint.save_checkpoint(str(tmp_path), w_old, 10, fmt="npz")  # writing only the cache drops the stale bundle
-    assert not (tmp_path / "VSR-10.index").exists()
+    assert np.array_equal(got[1]["nlvsr/conv0/kernel"], w_new["nlvsr/conv0/kernel"])   # the cache does not carry this bundle's signature
+    with pytest.raises(FileExistsError):                             # no implicit deletion of a reference-format checkpoint
+        checkpoint.save_checkpoint(str(tmp_path), w_old, 10, fmt="npz")
+    checkpoint.save_checkpoint(str(tmp_path), w_old, 10, fmt="both")  # rewrites the bundle, stamps the cache with its signature
     got = checkpoint.load_checkpoint(str(tmp_path), g, step=10)
     assert np.array_equal(got[1]["nlvsr/conv0/kernel"], w_old["nlvsr/conv0/kernel"])
+    with np.load(tmp_path / "VSR-10.npz") as z:
+        assert str(z[checkpoint._SIG_KEY]) == checkpoint.index_signature(str(tmp_path / "VSR-10"))
+    wt = dict(w_old)                                                 # theta / phi travel with the checkpoint: all four or an error
+    for n, shp in g.optional_weight_shapes():
+        wt[n] = np.full(shp, 0.01, np.float32)
+    checkpoint.save_checkpoint(str(tmp_path), wt, 11, fmt="both")
+    got = checkpoint.load_checkpoint(str(tmp_path), g, step=11)
+    assert all(n in got[1] for n, _ in g.optional_weight_shapes())
+    del wt[g.optional_weight_shapes()[0][0]]
+    checkpoint.save_checkpoint(str(tmp_path), wt, 12, fmt="both")
+    with pytest.raises(KeyError, match="theta"):
+        checkpoint.load_checkpoint(str(tmp_path), g, step=12)
     m = M.PFNL()                                                     # default geometry (20 blocks) vs a 1-block checkpoint
     with pytest.raises(KeyError):
         m.load(None, str(tmp_path), step=10)
