@@ -71,6 +71,8 @@ struct pfnl_handle {
     std::map<std::string, std::vector<int64_t>> expected;   // tf name -> shape
     std::map<std::string, HostTensor> host;                  // tensors received so far
     bool finalized = false;
+    bool weights_external = false;                           // the device blobs came from another handle (copy / broadcast): `host` holds placeholders
+    size_t wdev_used = 0, wdev16_used = 0, wdev16s_used = 0;  // floats of each blob the current weights occupy (DevBuf.n is a grow-only capacity)
     // launch-bound shapes (e.g. BASELINE.json configs[0], 1x7x32x32: ~95 launches of a few us each): the whole
     // forward is captured once per (B, H, W) into a hipGraph between the staging buffers and replayed
     struct GraphEntry {
@@ -655,6 +657,10 @@ int pfnl_set_weight(pfnl_handle* h, const char* tf_name, const float* host, cons
     if ((int)it->second.size() != rank) return fail(PFNL_ERR_INVALID, "rank mismatch for " + name);
     for (int i = 0; i < rank; ++i)
         if (shape[i] != it->second[i]) return fail(PFNL_ERR_INVALID, "shape mismatch for " + name);
+    if (h->weights_external) {        // the placeholders of a received replica are not weights: a caller that sets one tensor sets them all
+        h->host.clear();
+        h->weights_external = false;
+    }
     HostTensor t;
     t.shape = it->second;
     t.data.assign(host, host + numel(t.shape));
@@ -910,6 +916,7 @@ int pfnl_finalize_weights(pfnl_handle* h) {
         for (int f = 0; f < T; ++f)
             pfnl::conv3x3_bf16_pack_weights(W("convmerge1").data(), 64 * T, 64 * f, &b16[h->off16_m1 + (size_t)f * pfnl::conv3x3_bf16_pack_halfs()], 48);
         b16.resize((b16.size() + 1) / 2 * 2 + 2, 0);
+        h->wdev16_used = b16.size() / 2;
         if (h->wdev16.ensure(b16.size() / 2)) return fail(PFNL_ERR_NOMEM, "weight allocation failed");
         HIPCHK(hipMemcpy(h->wdev16.p, b16.data(), b16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
@@ -954,6 +961,7 @@ int pfnl_finalize_weights(pfnl_handle* h) {
             pfnl::conv3x3_split16_pack_weights(W("conv2_" + s).data(), 128, 0, &b16[h->off16s_c2a[i]]);
             pfnl::conv3x3_split16_pack_weights(W("conv2_" + s).data(), 128, 64, &b16[h->off16s_c2b[i]]);
         }
+        h->wdev16s_used = b16.size() / 2;
         if (h->wdev16s.ensure(b16.size() / 2)) return fail(PFNL_ERR_NOMEM, "weight allocation failed");
         HIPCHK(hipMemcpy(h->wdev16s.p, b16.data(), b16.size() / 2 * 2 * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
@@ -963,6 +971,7 @@ int pfnl_finalize_weights(pfnl_handle* h) {
             for (float v : kv.second.data) wmax = std::fmax(wmax, std::fabs(v));
         h->weights_f16_ok = wmax < 65504.0f;
     }
+    h->wdev_used = blob.size();
     if (h->wdev.ensure(blob.size())) return fail(PFNL_ERR_NOMEM, "weight allocation failed");
     HIPCHK(hipMemcpy(h->wdev.p, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
     h->finalized = true;
@@ -1183,7 +1192,9 @@ static int prepare_to_receive_weights(pfnl_handle* h) {
             t.data.assign(numel(t.shape), 0.f);
             h->host[kv.first] = std::move(t);
         }
-    return pfnl_finalize_weights(h);
+    const int e = pfnl_finalize_weights(h);
+    if (!e) h->weights_external = true;                         // placeholders: a later pfnl_set_weight starts from an empty set
+    return e;
 }
 
 int pfnl_copy_weights(pfnl_handle* dst, pfnl_handle* src) {
@@ -1192,12 +1203,14 @@ int pfnl_copy_weights(pfnl_handle* dst, pfnl_handle* src) {
     if (!src->finalized) return fail(PFNL_ERR_STATE, "the source handle has no finalized weights");
     if (src->nl_theta) return fail(PFNL_ERR_INVALID, "theta/phi handles carry host-side state: load them through pfnl_set_weight");
     if (int e = prepare_to_receive_weights(dst)) return e;
-    if (dst->wdev.n != src->wdev.n || dst->wdev16.n != src->wdev16.n || dst->wdev16s.n != src->wdev16s.n)
+    if (dst->wdev_used != src->wdev_used || dst->wdev16_used != src->wdev16_used || dst->wdev16s_used != src->wdev16s_used)
         return fail(PFNL_ERR_STATE, "the handles differ in geometry (weight blob sizes)");
     HIPCHK(hipSetDevice(dst->cfg.device_id));
-    HIPCHK(hipMemcpy(dst->wdev.p, src->wdev.p, src->wdev.n * sizeof(float), hipMemcpyDefault));
-    HIPCHK(hipMemcpy(dst->wdev16.p, src->wdev16.p, src->wdev16.n * sizeof(float), hipMemcpyDefault));
-    HIPCHK(hipMemcpy(dst->wdev16s.p, src->wdev16s.p, src->wdev16s.n * sizeof(float), hipMemcpyDefault));
+    HIPCHK(hipMemcpy(dst->wdev.p, src->wdev.p, src->wdev_used * sizeof(float), hipMemcpyDefault));
+    HIPCHK(hipMemcpy(dst->wdev16.p, src->wdev16.p, src->wdev16_used * sizeof(float), hipMemcpyDefault));
+    HIPCHK(hipMemcpy(dst->wdev16s.p, src->wdev16s.p, src->wdev16s_used * sizeof(float), hipMemcpyDefault));
+    dst->weights_f16_ok = src->weights_f16_ok;                  // (the range of the weights travels with them)
+    dst->weights_external = true;
     ++dst->cfg_gen;
     return 0;
 }
@@ -1208,14 +1221,22 @@ int pfnl_comm_bcast_weights(pfnl_comm* c, pfnl_handle* h, int root) {
     if (int e = pfnl_comm_rank(c, &rank, &nranks)) return e;
     if (root < 0 || root >= nranks) return fail(PFNL_ERR_INVALID, "bad root");
     if (rank == root && !h->finalized) return fail(PFNL_ERR_STATE, "root has no finalized weights");
-    if (rank != root)
-        if (int e = prepare_to_receive_weights(h)) return e;
-    double v[4] = {(double)h->wdev.n, -(double)h->wdev.n, (double)h->wdev16.n, -(double)h->wdev16.n};
-    if (int e = pfnl_comm_allreduce_f64(c, v, 4, PFNL_COMM_MAX)) return e;
-    if (v[0] != -v[1] || v[2] != -v[3]) return fail(PFNL_ERR_STATE, "ranks disagree on the weight blob size (geometry / theta-phi option)");
-    if (int e = pfnl_comm_bcast(c, h->wdev.p, h->wdev.n * sizeof(float), root)) return e;
-    if (int e = pfnl_comm_bcast(c, h->wdev16.p, h->wdev16.n * sizeof(float), root)) return e;
-    if (int e = pfnl_comm_bcast(c, h->wdev16s.p, h->wdev16s.n * sizeof(float), root)) return e;
+    // a rank whose local preparation fails still takes part in the agreement below (status rides in v[6]: the others must not be
+    // left waiting inside the collective), then every rank returns the same verdict
+    const int prep = rank != root ? prepare_to_receive_weights(h) : 0;
+    const std::string prep_msg = prep ? std::string(pfnl_last_error()) : std::string();
+    double v[8] = {(double)h->wdev_used, -(double)h->wdev_used, (double)h->wdev16_used, -(double)h->wdev16_used,
+                   (double)h->wdev16s_used, -(double)h->wdev16s_used, prep ? 1.0 : 0.0, (rank == root && !h->weights_f16_ok) ? 1.0 : 0.0};
+    if (int e = pfnl_comm_allreduce_f64(c, v, 8, PFNL_COMM_MAX)) return e;
+    if (v[6] != 0.0) return prep ? fail(prep, prep_msg) : fail(PFNL_ERR_STATE, "another rank could not prepare to receive the weights");
+    if (v[0] != -v[1] || v[2] != -v[3] || v[4] != -v[5]) return fail(PFNL_ERR_STATE, "ranks disagree on the weight blob size (geometry / theta-phi option)");
+    if (int e = pfnl_comm_bcast(c, h->wdev.p, h->wdev_used * sizeof(float), root)) return e;
+    if (int e = pfnl_comm_bcast(c, h->wdev16.p, h->wdev16_used * sizeof(float), root)) return e;
+    if (int e = pfnl_comm_bcast(c, h->wdev16s.p, h->wdev16s_used * sizeof(float), root)) return e;
+    if (rank != root) {
+        h->weights_f16_ok = v[7] == 0.0;                            // (the root's verdict on the range of the weights travels with them)
+        h->weights_external = true;
+    }
     ++h->cfg_gen;
     return 0;
 }

@@ -199,6 +199,20 @@ def test_weight_replica_without_host_tensors():
     other = PFNLEngine(PFNLGeometry(num_block=3), device=0)
     with pytest.raises(Exception):
         other.copy_weights_from(src)                                    # different geometry: refused
+    # a received replica holds placeholders, not host tensors: setting ONE tensor afterwards must not silently rebuild the
+    # others from zeros - the handle asks for the full set again
+    import ctypes as C
+    from pfnl_amd import _capi
+    k0 = np.ascontiguousarray(synth.synthetic_weights(g, seed=9)["nlvsr/conv0/kernel"])
+    _capi.check(dst._lib.pfnl_set_weight(dst._h, b"nlvsr/conv0/kernel", k0.ctypes.data_as(C.c_void_p), (C.c_int64 * 4)(*k0.shape), 4))
+    assert dst.missing_weights() == len(g.weight_shapes()) - 1
+    with pytest.raises(Exception):
+        _capi.check(dst._lib.pfnl_finalize_weights(dst._h))
+    dst.load_weights(synth.synthetic_weights(g, seed=4))                # the full set: fine again
+    for k, v in {"precision": "fp32", "conv3x3": "auto", "conv1x1": "split16", "nonlocal": "auto"}.items():
+        src.set_option(k, v)
+        dst.set_option(k, v)
+    assert np.array_equal(dst.forward(x), src.forward(x))
     for e in (src, dst, other):
         e.close()
 
