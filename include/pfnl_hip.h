@@ -184,6 +184,8 @@ enum {
 int pfnl_profile_enable(pfnl_handle* h, int enable);
 int pfnl_profile_reset(pfnl_handle* h);
 int pfnl_profile_read(pfnl_handle* h, double* ms /*[PFNL_K_COUNT]*/, int64_t* launches /*[PFNL_K_COUNT]*/);
+/* Tracing: with env PFNL_ROCTX=1 every kernel class of a forward is wrapped in a roctx range ("pfnl:conv3x3", ...; roctx is
+ * resolved at run time, never linked): `rocprofv3 --marker-trace --kernel-trace` then shows the launches inside named ranges. */
 
 /* ---- debugging / per-stage parity --------------------------------------------------------- */
 /* Copy an internal buffer of the last forward to host (synchronises).  Names:

@@ -1,5 +1,7 @@
 // C-ABI of libpfnl_hip.so (see include/pfnl_hip.h): handle, weight repacking, the forward
 // schedule of PFNL.forward (reference model/pfnl.py:39-80) as a sequence of HIP kernel launches.
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -164,11 +166,45 @@ int prof_mark(pfnl_handle* h, hipStream_t s, int cls) {
     return hipEventRecord(h->evs[h->evs_used++], s) == hipSuccess ? 0 : -1;
 }
 
+// roctx ranges around every kernel class (the tracing hook of this path): env PFNL_ROCTX=1 resolves
+// roctxRangePushA / roctxRangePop at run time (librocprofiler-sdk-roctx, else libroctx64; never linked) - under
+// `rocprofv3 --marker-trace --kernel-trace` the launches of a forward then sit inside named ranges (nl_pack, nl_attn, conv0,
+// conv3x3, conv1x1, merge1, tail), per PF block in launch order.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+const Roctx* roctx() {
+    static const Roctx r = [] {
+        Roctx x;
+        const char* e = std::getenv("PFNL_ROCTX");
+        if (!e || !*e || *e == '0') return x;
+        for (const char* n : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4",
+                              "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "/opt/rocm/lib/libroctx64.so"}) {
+            if (void* lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) {
+                x.push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+                x.pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+                if (x.push && x.pop) break;
+                x.push = nullptr;
+                x.pop = nullptr;
+            }
+        }
+        return x;
+    }();
+    return &r;
+}
+const char* const kClassNames[PFNL_K_COUNT] = {"pfnl:nl_pack", "pfnl:nl_attn", "pfnl:conv0", "pfnl:conv3x3", "pfnl:conv1x1", "pfnl:merge1", "pfnl:tail"};
+
 struct ProfScope {
     pfnl_handle* h;
     hipStream_t s;
     int cls;
+    bool ranged = false;
     ProfScope(pfnl_handle* h_, hipStream_t s_, int cls_) : h(h_), s(s_), cls(cls_) {
+        if (roctx()->push && cls >= 0 && cls < PFNL_K_COUNT) {
+            roctx()->push(kClassNames[cls]);
+            ranged = true;
+        }
         if (h && h->prof && h->prof_gate && !h->chain_open) {
             prof_mark(h, s, -1);
             h->chain_open = true;
@@ -176,6 +212,7 @@ struct ProfScope {
     }
     ~ProfScope() {
         if (h && h->prof && h->prof_gate) prof_mark(h, s, cls);
+        if (ranged) roctx()->pop();
     }
 };
 
