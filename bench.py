@@ -133,6 +133,12 @@ class stdout_to_stderr:
         os.close(self._saved)
 
 
+def blocks_sampled(nb):
+    """PF blocks that carry events in sampled profiling (pfnl_amd/csrc/capi.hip, prof_sampled): blocks 3, 13, ... from ten blocks
+    up, every 4th below."""
+    return len([i for i in range(nb) if (i % 10 == 3 if nb >= 10 else i % 4 == 0)]) or 1
+
+
 def timed_steps(step, fence, steps):
     fence()
     t0 = time.perf_counter()
@@ -275,7 +281,7 @@ def main():
                          "communicator (pfnl_comm_*, include/pfnl_hip.h; falls back to torch.distributed if it cannot be created on "
                          "every rank) or torch.distributed")
     ap.add_argument("--full-profile", action="store_true",
-                    help="HIP events around every launch (default: every 4th progressive-fusion block is timed)")
+                    help="HIP events around every launch (default: two of the twenty progressive-fusion blocks are timed)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events (no roofline object)")
     args = ap.parse_args()
     B_PER_GPU, H, W = (1, 270, 480) if args.workload == "cfg4" else (4, 128, 128)
@@ -399,7 +405,7 @@ def main():
     fence()
     eng.profile_reset()
     # HIP events on the launch stream around the launches: all of them (--full-profile) or, by default, those
-    # of every 4th of the 20 identical PF blocks plus everything outside the blocks (an event costs ~2 us)
+    # of two of the 20 identical PF blocks plus everything outside the blocks (an event costs the stream ~2 us)
     prof_mode = 0 if args.no_profile else (1 if args.full_profile else 2)
     eng.profile(prof_mode)
     elapsed = timed_steps(step, fence, args.steps)
@@ -425,7 +431,7 @@ def main():
     f_exec = geom.flops_per_clip(H, W, shared_base=True) * B_PER_GPU
     # sampled mode: the two classes inside the PF blocks were timed in ceil(nb/4) of the nb blocks
     nb = geom.num_block
-    scale_blk = nb / float((nb + 3) // 4) if prof_mode == 2 and nb else 1.0
+    scale_blk = nb / float(blocks_sampled(nb)) if prof_mode == 2 and nb else 1.0
     breakdown = {n: round(v["ms"] / args.steps * (scale_blk if n in ("conv3x3", "conv1x1") else 1.0), 4)
                  for n, v in prof.items()}
 
@@ -504,7 +510,7 @@ def secondary_workloads(eng, geom, weights, local_dev, dev, x_cfg2, out_cfg2):
         e.profile(False)
         prof = e.profile_read()
         nb = g.num_block
-        sc = nb / float((nb + 3) // 4) if nb else 1.0
+        sc = nb / float(blocks_sampled(nb)) if nb else 1.0
         ms = 1e3 * el / steps
         rec = {"workload": label, "dtype": "bf16" if bf16 else "f32", "clips": B, "steps": steps, "ms_per_step": round(ms, 4),
                "value": round(B * steps / el, 3), "unit": "HR frames/s", "input": "resident in HBM",

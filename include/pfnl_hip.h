@@ -173,7 +173,7 @@ int pfnl_comm_allgather(pfnl_comm* c, const float* send_dev, float* recv_dev, si
 /* ---- measurement ------------------------------------------------------------------------- */
 /* Per-kernel-class HIP-event timing on the launch stream.  enable = 1: every launch of the classes
  * below is bracketed by hipEvents until disabled; enable = 2: the same for the launches outside the
- * progressive-fusion blocks and for every 4th block (blocks are identical, so average launch durations
+ * progressive-fusion blocks and for blocks 3, 13, ... (every 4th block of models with fewer than ten; blocks are identical, so average launch durations
  * are unbiased; ~30 instead of ~95 events per forward - each event costs the stream ~2 us);
  * pfnl_profile_read synchronises and returns accumulated milliseconds and the number of TIMED launches
  * since the last reset. */

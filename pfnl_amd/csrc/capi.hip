@@ -155,6 +155,10 @@ namespace {
 
 using namespace pfnl;
 
+// sampled profiling (mode 2): which PF blocks get events - two of twenty (blocks 3 and 13: an event costs the stream ~2 us and
+// the blocks are identical), every 4th below ten blocks.  bench.py scales the in-block classes by num_block / (blocks sampled).
+inline bool prof_sampled(int nb, int i) { return nb >= 10 ? (i % 10) == 3 : (i & 3) == 0; }
+
 int prof_mark(pfnl_handle* h, hipStream_t s, int cls) {
     if (h->evs_used == h->evs.size()) {
         hipEvent_t e;
@@ -322,7 +326,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
         const uint16_t* const w16 = reinterpret_cast<const uint16_t*>(h->wdev16.p);
         for (int i = 0; i < c.num_block; ++i) {   // model/pfnl.py:65-71
             if (h->prof_mode == 2) {
-                h->prof_gate = (i & 3) == 0;
+                h->prof_gate = prof_sampled(c.num_block, i);
                 h->chain_open = false;
             }
             {   // conv1_i (+ conv10_i from the LDS scratch its tiles pass through: conv_bf16.hip MODE 2)
@@ -388,8 +392,8 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
                        (h->small_mode == 1 || (h->small_mode == 0 && h->conv_algo == 5 && h->conv1x1_algo == 2 && tiles8x32 < 256));
     const uint16_t* const w16m = reinterpret_cast<const uint16_t*>(h->wdev16s.p);
     for (int i = 0; i < (h->bf16 ? 0 : c.num_block); ++i) {   // model/pfnl.py:65-71
-        if (h->prof_mode == 2) {          // sampled profiling: blocks 0, 4, 8, ... each with a fresh event chain
-            h->prof_gate = (i & 3) == 0;
+        if (h->prof_mode == 2) {          // sampled profiling: see prof_sampled; each sampled block with a fresh event chain
+            h->prof_gate = prof_sampled(c.num_block, i);
             h->chain_open = false;
         }
         if (small) {
