@@ -542,3 +542,15 @@ def test_split16_random_geometries():
     spec.loader.exec_module(mod)
     n, worst, worst_op = mod.run(seed=7, seconds=8.0)
     assert n >= 20 and worst < 2e-5 and worst_op < 2e-5
+
+
+def test_round3_random_geometries():
+    """Short run of tools/stress_r03.py: the split-format chain, the small-shape trunk and the default choice against the f32-MFMA
+    path over random (T, clips, H, W, blocks, scale); the chain and small-shape conv2_i ops against the direct kernel; bit-exact
+    repeatability of every call."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("stress_r03", os.path.join(os.path.dirname(HERE), "tools", "stress_r03.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, worst, worst_op = mod.run(seed=11, seconds=10.0)
+    assert n >= 10 and worst < 2e-5 and worst_op < 2e-5
