@@ -113,6 +113,10 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *                 the 20 progressive-fusion blocks keep their activations and weights in bf16 and accumulate in fp32 on
  *                 bf16 MFMA (conv_bf16.hip); the non-local block, its logits, conv0's arithmetic, convmerge1, the tail and
  *                 the bicubic skip stay fp32; the interface tensors stay float32.  Tolerance: DESIGN.md section 4).
+ * key "nl_type" = "auto" (default: 0 when the theta / phi variables are loaded, else 1 = PFNL's own call, model/pfnl.py:58) | "0" |
+ *                 "1" | "2": utils.NonLocalBlock's nltype (embedded Gaussian / Gaussian / dot product; 0 and 2 need theta / phi).
+ * key "nl_sub_sample" = "1" (default, PFNL's call) | n: average-pool g and phi n x n on the space_to_depth grid (utils.py:27-28,35-36).
+ *                 nl_type != 1 or nl_sub_sample > 1 run on the f32-MFMA kernel (nonlocal.hip) in both precisions.
  * key "bf16_conv10" = "fused" (default: conv10_i runs inside the conv1_i launch of the bf16 trunk) | "separate".
  * key "bf16_nonlocal" = "f16" (default: the non-local block of precision=bf16 on the f16 matrix pipe with binary16 operands,
  *                 fp32 accumulation and softmax state - nonlocal_f16.hip, hi parts only) | "split" (bf16 MFMA with hi + lo
@@ -307,6 +311,14 @@ int pfnl_op_nonlocal_f16(const float* x, const float* wg_host, const float* bg_h
 int pfnl_op_nonlocal_embedded(const float* x, const float* wg_host, const float* bg_host, const float* ww_host,
                               const float* bw_host, const float* wt_host, const float* bt_host, const float* wp_host,
                               const float* bp_host, float* out, int B, int T, int H, int W, void* stream);
+/* utils.NonLocalBlock(input_x, out_channels, sub_sample, nltype) in its general form (reference utils.py:18-71) with the same
+ * stack / space_to_depth / residual wrapper as pfnl_op_nonlocal: nltype 0 embedded Gaussian (theta, phi projections, exp / rowsum),
+ * 1 Gaussian (theta = phi = x; wt .. bp may be NULL), 2 dot product (relu / rowsum, utils.py:59-62 - a query whose affinities are
+ * all <= 0 divides by zero there and yields NaN here as well); sub_sample > 1: g and phi average-pooled (pool = stride = sub_sample,
+ * 'valid') on the space_to_depth grid (utils.py:27-28,35-36).  nltype 3 ('concat') builds no graph in the reference and is rejected. */
+int pfnl_op_nonlocal_block(const float* x, const float* wg_host, const float* bg_host, const float* ww_host,
+                           const float* bw_host, const float* wt_host, const float* bt_host, const float* wp_host,
+                           const float* bp_host, int nltype, int sub_sample, float* out, int B, int T, int H, int W, void* stream);
 /* conv0 (reference model/pfnl.py:48,61-62): lrelu(conv5x5 'same' 3 -> 64 + b) of every frame.
  * x [B,T,H,W,3] (device), kernel_host HWIO [5,5,3,64], bias_host [64] or NULL, out [B*T,H,W,64] (device). */
 int pfnl_op_conv0(const float* x, const float* kernel_host, const float* bias_host, float* out, int B, int T, int H, int W,

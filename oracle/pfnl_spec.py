@@ -2,7 +2,7 @@
 
 A naive numpy float64 restatement of the reference's PFNL forward graph, written op-for-op from
 `/root/reference/model/pfnl.py:39-80` (``PFNL.forward``) and `/root/reference/utils.py:18-71`
-(``NonLocalBlock``, nltype=1 branch), with the TensorFlow 1.12 op semantics the reference relies on
+(``NonLocalBlock``: all the branches that build a graph - nltype 0 / 1 / 2, sub_sample), with the TensorFlow 1.12 op semantics the reference relies on
 restated from their published definitions (the arithmetic lives in TF 1.12.0, named at the
 reference's `README.md:23`, not vendored and not installable here):
 
@@ -13,6 +13,7 @@ reference's `README.md:23`, not vendored and not installable here):
 * ``tf.image.resize_images(..., method=2)``: TF1 legacy bicubic, align_corners=False, no half-pixel
   centres, Keys A=-0.75, taps clamped to the border, no renormalisation           (`pfnl.py:63`)
 * affinity as written: exp, sum, divide — NO max subtraction            (`utils.py:57-58`)
+* ``tf.layers.average_pooling2d(pool, strides=pool)``: padding 'valid' (its default)  (`utils.py:27-28,35-36`)
 
 Nothing outside tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 """
@@ -100,29 +101,54 @@ def resize_bicubic_tf1(x: np.ndarray, scale: int) -> np.ndarray:
     return out
 
 
-def nonlocal_block(x: np.ndarray, wg, bg, ww, bw, stabilise: bool = False, theta=None, phi=None) -> np.ndarray:
-    """utils.py:18-71, sub_sample=1.  x [B,h,w,C] -> [B,h,w,C] (no residual, :70).
+def avg_pool_valid(x: np.ndarray, k: int) -> np.ndarray:
+    """tf.layers.average_pooling2d(pool_size=k, strides=k) with its default padding 'valid' (utils.py:27-28, 35-36):
+    x [B,h,w,C] -> [B,h//k,w//k,C]; rows / columns that do not fill a window are dropped."""
+    B, h, w, C = x.shape
+    hp, wp = h // k, w // k
+    return x[:, :hp * k, :wp * k].reshape(B, hp, k, wp, k, C).mean(axis=(2, 4))
+
+
+def nonlocal_block(x: np.ndarray, wg, bg, ww, bw, stabilise: bool = False, theta=None, phi=None,
+                   nltype: Optional[int] = None, sub_sample: int = 1) -> np.ndarray:
+    """utils.py:18-71.  x [B,h,w,C] -> [B,h,w,C] (no residual, :70).
     nltype=1 (PFNL's call, model/pfnl.py:58): theta = phi = x.  nltype=0 (embedded Gaussian; the option north_star
-    names): ``theta`` / ``phi`` = (kernel [1,1,C,C], bias [C]) of the two extra 1x1 convs (:31-32, :39-40)."""
+    names) and nltype=2 (dot product): ``theta`` / ``phi`` = (kernel [1,1,C,C], bias [C]) of the two extra 1x1 convs
+    (:31-32, :39-40).  ``nltype`` None: 0 when theta / phi are given, else 1.  sub_sample > 1: g and phi average-pooled
+    (:27-28, :35-36).  nltype 3 ('concat') builds no graph in the reference (the function falls off its ``if nltype<=2``)."""
+    if nltype is None:
+        nltype = 1 if theta is None else 0
+    if nltype not in (0, 1, 2):
+        raise ValueError("nltype 3 builds no graph in the reference (utils.py:23)")
     B, h, w, C = x.shape
     g = conv2d_same(x, wg, bg)                           # utils.py:26
+    if sub_sample > 1:
+        g = avg_pool_valid(g, sub_sample)                # :27-28
+    ph = x if nltype == 1 else conv2d_same(x, phi[0], phi[1])            # :31-34
+    if sub_sample > 1:
+        ph = avg_pool_valid(ph, sub_sample)              # :35-36
+    th = x if nltype == 1 else conv2d_same(x, theta[0], theta[1])        # :39-42
     g_x = g.reshape(B, -1, C)                            # :44
-    th = x if theta is None else conv2d_same(x, theta[0], theta[1])      # :39-42
-    ph = x if phi is None else conv2d_same(x, phi[0], phi[1])            # :31-34
     theta_x = th.reshape(B, -1, C)                       # :45
     phi_x = ph.reshape(B, -1, C).transpose(0, 2, 1)      # :49-50
     f = theta_x @ phi_x                                  # :53
-    if stabilise:
-        f = f - f.max(axis=-1, keepdims=True)
-    f = np.exp(f)                                        # :57
-    f_softmax = f / f.sum(axis=-1, keepdims=True)        # :58
+    if nltype <= 1:
+        if stabilise:
+            f = f - f.max(axis=-1, keepdims=True)
+        f = np.exp(f)                                    # :57
+        f_softmax = f / f.sum(axis=-1, keepdims=True)    # :58
+    else:
+        f = np.maximum(f, 0)                             # :60
+        with np.errstate(invalid="ignore", divide="ignore"):
+            f_softmax = f / f.sum(axis=2, keepdims=True)  # :61-63 (0 / 0 = NaN for a query without a positive affinity, as in TF)
     y = f_softmax @ g_x                                  # :64
     y = y.reshape(B, h, w, C)                            # :65
     return conv2d_same(y, ww, bw)                        # :67
 
 
 def forward(x: np.ndarray, weights: Dict[str, np.ndarray], scale: int = 4, num_block: int = 20,
-            dtype=np.float64, stabilise: bool = False, taps: Optional[dict] = None) -> np.ndarray:
+            dtype=np.float64, stabilise: bool = False, taps: Optional[dict] = None,
+            nltype: Optional[int] = None, sub_sample: int = 1) -> np.ndarray:
     """model/pfnl.py:39-80.  x [B,T,H,W,3] in [0,1] -> [B,1,scale*H,scale*W,3].
 
     ``taps``: optional dict that receives named intermediates (for per-op parity tests)."""
@@ -142,7 +168,8 @@ def forward(x: np.ndarray, weights: Dict[str, np.ndarray], scale: int = 4, num_b
             tp[j] = (Wt[f"nlvsr/nlblock_0/{n}/kernel"], Wt[f"nlvsr/nlblock_0/{n}/bias"])
     inp1 = nonlocal_block(inp1, Wt["nlvsr/nlblock_0/g/g/kernel"], Wt["nlvsr/nlblock_0/g/g/bias"],
                           Wt["nlvsr/nlblock_0/w/w/kernel"], Wt["nlvsr/nlblock_0/w/w/bias"],
-                          stabilise=stabilise, theta=tp[0], phi=tp[1])    # :58
+                          stabilise=stabilise, theta=tp[0], phi=tp[1],    # :58 (the reference pins nltype=1, sub_sample=1;
+                          nltype=nltype, sub_sample=sub_sample)           #      the two arguments are utils.NonLocalBlock's)
     inp1 = depth_to_space2(inp1)                                          # :59
     inp0 = inp0 + inp1                                                    # :60
     if taps is not None:

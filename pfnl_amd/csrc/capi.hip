@@ -132,6 +132,9 @@ struct pfnl_handle {
     bool nl_theta = false;
     size_t off_nl_m = 0, off_nl_c = 0;                        // M = Wt Wp^T [CP][CP], c = bt Wp^T [CP]
     DevBuf Q;                                                 // projected queries [B][N][CP]
+    DevBuf Xs;                                                // average-pooled keys / values [B][Nk][CP] (nl_sub_sample > 1)
+    int nl_type = -1;                                         // utils.NonLocalBlock nltype: -1 auto (0 with theta / phi variables, else 1 = PFNL's call), 0, 1, 2
+    int nl_sub = 1;                                           // ... sub_sample (utils.py:27-28,35-36); PFNL's call: 1
 
     // workspace
     DevBuf nl16;                                              // bf16 non-local: split K / V^T operands
@@ -288,10 +291,29 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
     }
     {
         ProfScope ps(h, s, PFNL_K_NL_ATTN);
-        if (h->nl_theta) {   // nltype 0: queries X M + c, keys / values X (fp32 kernel in both precisions)
-            if (h->Q.ensure((size_t)B * N * CP)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
-            HIPCHK(launch_nl_qproj(h->X.p, wd + h->off_nl_m, wd + h->off_nl_c, h->Q.p, B, N, C, s));
-            HIPCHK(launch_nl_attn(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p, B, N, C, s, h->Q.p, q0, q1));
+        const int nlt = h->nl_type < 0 ? (h->nl_theta ? 0 : 1) : h->nl_type;
+        if ((nlt == 0 || nlt == 2) && !h->nl_theta)
+            return fail(PFNL_ERR_STATE, "nl_type 0 / 2 need the nlblock_0 theta / phi variables (reference utils.py:31-42)");
+        if (nlt != 1 || h->nl_sub > 1) {
+            // the general form of utils.NonLocalBlock (nltype 0 / 2: queries X M + c; sub_sample: keys = values = avg-pooled X) on
+            // the f32-MFMA kernel in both precisions; PFNL's own call (nltype 1, sub_sample 1) takes the branches below
+            const float* Kx = h->X.p;
+            int Nk = N;
+            if (h->nl_sub > 1) {
+                const int h2 = Hfull / 2, w2 = W / 2;
+                if (h2 / h->nl_sub < 1 || w2 / h->nl_sub < 1) return fail(PFNL_ERR_INVALID, "nl_sub_sample larger than the space_to_depth grid");
+                Nk = (h2 / h->nl_sub) * (w2 / h->nl_sub);
+                if (h->Xs.ensure((size_t)B * Nk * CP)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
+                HIPCHK(launch_nl_pool(h->X.p, h->Xs.p, B, h2, w2, h->nl_sub, C, s));
+                Kx = h->Xs.p;
+            }
+            const float* Qp = nullptr;
+            if (nlt != 1) {
+                if (h->Q.ensure((size_t)B * N * CP)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
+                HIPCHK(launch_nl_qproj(h->X.p, wd + h->off_nl_m, wd + h->off_nl_c, h->Q.p, B, N, C, s, nlt == 2));
+                Qp = h->Q.p;
+            }
+            HIPCHK(launch_nl_attn_general(h->X.p, Kx, Nk, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p, B, N, C, s, Qp, q0, q1, nlt == 2));
         } else if (!h->bf16 && !nl_strict && (h->nl_algo == 1 || (h->nl_algo == 2 && N >= 1024))) {   // fp32 path on the f16 pipe, exactly split operands
             if (h->nl16.ensure((nl_f16_scratch_halfs(B, N) + 1) / 2)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
             HIPCHK(launch_nl_attn_f16(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p,
@@ -781,6 +803,20 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         ++h->cfg_gen;
         return 0;
     }
+    if (k == "nl_type") {
+        if (v == "auto") h->nl_type = -1;
+        else if (v == "0" || v == "embedded_gaussian") h->nl_type = 0;
+        else if (v == "1" || v == "gaussian") h->nl_type = 1;
+        else if (v == "2" || v == "dot_product") h->nl_type = 2;
+        else return fail(PFNL_ERR_INVALID, "nl_type: auto | 0 | 1 | 2 (nltype 3, 'concat', builds no graph in the reference either: utils.py:23)");
+        return 0;
+    }
+    if (k == "nl_sub_sample") {
+        const int n = atoi(v.c_str());
+        if (n < 1 || n > 64) return fail(PFNL_ERR_INVALID, "nl_sub_sample: an integer >= 1");
+        h->nl_sub = n;
+        return 0;
+    }
     if (k == "bf16_nonlocal") {
         if (v == "split") h->bf16_nl = 0;
         else if (v == "f16") h->bf16_nl = 1;
@@ -929,6 +965,17 @@ int pfnl_finalize_weights(pfnl_handle* h) {
                 for (int cm = 0; cm < C; ++cm) acc += (double)bt[cm] * (double)wp[(size_t)cj * C + cm];
                 blob[h->off_nl_c + cj] = (float)acc;
             }
+            // column C (a pad column: C < CP): theta_i . b_phi = X_i (Wt b_phi) + bt . b_phi - the per-query constant of the logits
+            // that cancels in the softmax of nltype 0 and does not under the relu of nltype 2 (nl_attn_kernel<., DOT>)
+            const auto& bph = Bv("nlblock_0/phi/phi");
+            double d0 = 0.0;
+            for (int cm = 0; cm < C; ++cm) d0 += (double)bt[cm] * (double)bph[cm];
+            blob[h->off_nl_c + C] = (float)d0;
+            for (int ci = 0; ci < C; ++ci) {
+                double acc = 0.0;
+                for (int cm = 0; cm < C; ++cm) acc += (double)wt[(size_t)ci * C + cm] * (double)bph[cm];
+                blob[h->off_nl_m + (size_t)ci * CP + C] = (float)acc;
+            }
         }
     }
     {   // bf16 packs of the trunk (precision=bf16)
@@ -1034,7 +1081,8 @@ int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes) {
              + 3 * B * P * 64                                   // base, pb, merge (64 floats per pixel)
              + (size_t)B * T * P * 3 + (size_t)B * P * sc * sc * 3;   // stage_in, stage_out
     if (h->bf16 || h->nl_algo != 0) f += (std::max(pfnl::nl_bf16_scratch_halfs(B, (int)N), pfnl::nl_f16_scratch_halfs(B, (int)N)) + 1) / 2;   // split K / V^T operands (bf16 or f16)
-    if (h->nl_theta) f += (size_t)B * N * CP;                   // projected queries (nltype 0)
+    if (h->nl_theta) f += (size_t)B * N * CP;                   // projected queries (nltype 0 / 2)
+    if (h->nl_sub > 1) f += (size_t)B * ((H / 2) / h->nl_sub) * ((W / 2) / h->nl_sub) * CP;   // pooled keys
     *bytes = f * sizeof(float);
     return 0;
 }

@@ -58,15 +58,23 @@ int pfnl_op_tail(const float* merge, const float* x, const float* kernel_host, c
     return 0;
 }
 
-int pfnl_op_nonlocal_embedded(const float* x, const float* wg, const float* bg, const float* ww, const float* bw,
-                              const float* wt, const float* bt, const float* wp, const float* bp, float* out, int B, int T,
-                              int H, int W, void* stream) {
-    if (!x || !wg || !bg || !ww || !bw || !wt || !bt || !wp || !bp || !out) OPS_FAIL(PFNL_ERR_INVALID, "NULL argument");
+// utils.NonLocalBlock in its general form (reference utils.py:18-71: nltype 0 embedded Gaussian, 1 Gaussian, 2 dot product; sub_sample)
+// + the stack / space_to_depth / depth_to_space / residual of model/pfnl.py:55-60.  The 1x1 convolutions are folded on the host in fp64
+// (like pfnl_finalize_weights): W' = Wg Ww, b' = bg Ww + bw (the rows of P sum to 1), M = Wt Wp^T, c = bt Wp^T, and for nltype 2 the
+// per-query constant theta_i . b_phi as column C of M / c; average pooling commutes with the 1x1 convolutions of g and phi.
+static int op_nonlocal_block(const float* x, const float* wg, const float* bg, const float* ww, const float* bw, const float* wt,
+                             const float* bt, const float* wp, const float* bp, int nltype, int sub, float* out, int B, int T, int H,
+                             int W, void* stream) {
+    if (!x || !wg || !bg || !ww || !bw || !out) OPS_FAIL(PFNL_ERR_INVALID, "NULL argument");
+    if (nltype < 0 || nltype > 2) OPS_FAIL(PFNL_ERR_INVALID, "nltype: 0 | 1 | 2 (3, 'concat', builds no graph in the reference either)");
+    if (nltype != 1 && (!wt || !bt || !wp || !bp)) OPS_FAIL(PFNL_ERR_INVALID, "nltype 0 / 2 need the theta and phi projections");
     if ((T != 3 && T != 5 && T != 7) || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1))
         OPS_FAIL(PFNL_ERR_INVALID, "unsupported non-local geometry");
+    if (sub < 1 || (H / 2) / sub < 1 || (W / 2) / sub < 1) OPS_FAIL(PFNL_ERR_INVALID, "sub_sample out of range for this geometry");
     hipStream_t s = (hipStream_t)stream;
     const int C = 12 * T, CP = pfnl::nl_padded_ch(C), N = (H / 2) * (W / 2);
-    // blob: W' = Wg Ww [CP][CP] | b' [CP] | M = Wt Wp^T [CP][CP] | c = bt Wp^T [CP]   (fp64 folds, like pfnl_finalize_weights)
+    const int Nk = sub > 1 ? ((H / 2) / sub) * ((W / 2) / sub) : N;
+    // blob: W' [CP][CP] | b' [CP] | M [CP][CP] | c [CP]
     std::vector<float> blob(2 * ((size_t)CP * CP + CP), 0.f);
     float* Wf = blob.data();
     float* bf = Wf + (size_t)CP * CP;
@@ -77,7 +85,7 @@ int pfnl_op_nonlocal_embedded(const float* x, const float* wg, const float* bg, 
             double a = 0.0, m = 0.0;
             for (int cm = 0; cm < C; ++cm) {
                 a += (double)wg[(size_t)ci * C + cm] * (double)ww[(size_t)cm * C + co];
-                m += (double)wt[(size_t)ci * C + cm] * (double)wp[(size_t)co * C + cm];
+                if (nltype != 1) m += (double)wt[(size_t)ci * C + cm] * (double)wp[(size_t)co * C + cm];
             }
             Wf[(size_t)ci * CP + co] = (float)a;
             Mf[(size_t)ci * CP + co] = (float)m;
@@ -86,27 +94,55 @@ int pfnl_op_nonlocal_embedded(const float* x, const float* wg, const float* bg, 
         double a = bw[co], m = 0.0;
         for (int cm = 0; cm < C; ++cm) {
             a += (double)bg[cm] * (double)ww[(size_t)cm * C + co];
-            m += (double)bt[cm] * (double)wp[(size_t)co * C + cm];
+            if (nltype != 1) m += (double)bt[cm] * (double)wp[(size_t)co * C + cm];
         }
         bf[co] = (float)a;
         cf[co] = (float)m;
     }
-    const size_t nX = (size_t)B * N * CP, nP = pfnl::nl_partial_floats(B, N, C);
+    if (nltype == 2) {
+        double d0 = 0.0;
+        for (int cm = 0; cm < C; ++cm) d0 += (double)bt[cm] * (double)bp[cm];
+        cf[C] = (float)d0;
+        for (int ci = 0; ci < C; ++ci) {
+            double a = 0.0;
+            for (int cm = 0; cm < C; ++cm) a += (double)wt[(size_t)ci * C + cm] * (double)bp[cm];
+            Mf[(size_t)ci * CP + C] = (float)a;
+        }
+    }
+    const size_t nX = (size_t)B * N * CP, nK = sub > 1 ? (size_t)B * Nk * CP : 0, nP = pfnl::nl_partial_floats(B, N, C);
     float* d = nullptr;
-    HIPCHK(hipMalloc(&d, (blob.size() + 3 * nX + nP) * sizeof(float)));
+    HIPCHK(hipMalloc(&d, (blob.size() + 3 * nX + nK + nP) * sizeof(float)));
     float* dX = d + blob.size();
     float* dXo = dX + nX;
     float* dQ = dXo + nX;
-    float* dP = nP ? dQ + nX : nullptr;
+    float* dK = dQ + nX;
+    float* dP = nP ? dK + nK : nullptr;
     hipError_t e = hipMemcpy(d, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = pfnl::launch_nl_pack(x, dX, B, T, H, W, s);
-    if (e == hipSuccess) e = pfnl::launch_nl_qproj(dX, d + (size_t)CP * CP + CP, d + 2 * (size_t)CP * CP + CP, dQ, B, N, C, s);
-    if (e == hipSuccess) e = pfnl::launch_nl_attn(dX, dXo, d, d + (size_t)CP * CP, dP, B, N, C, s, dQ);
+    if (e == hipSuccess && nltype != 1)
+        e = pfnl::launch_nl_qproj(dX, d + (size_t)CP * CP + CP, d + 2 * (size_t)CP * CP + CP, dQ, B, N, C, s, nltype == 2);
+    if (e == hipSuccess && sub > 1) e = pfnl::launch_nl_pool(dX, dK, B, H / 2, W / 2, sub, C, s);
+    if (e == hipSuccess)
+        e = pfnl::launch_nl_attn_general(dX, sub > 1 ? dK : dX, Nk, dXo, d, d + (size_t)CP * CP, dP, B, N, C, s, nltype != 1 ? dQ : nullptr,
+                                         0, -1, nltype == 2);
     if (e == hipSuccess) e = pfnl::launch_nl_unpack(dXo, out, B, T, H, W, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(d);
-    if (e != hipSuccess) OPS_FAIL(PFNL_ERR_HIP, std::string("embedded non-local op: ") + hipGetErrorString(e));
+    if (e != hipSuccess) OPS_FAIL(PFNL_ERR_HIP, std::string("non-local block op: ") + hipGetErrorString(e));
     return 0;
+}
+
+int pfnl_op_nonlocal_embedded(const float* x, const float* wg, const float* bg, const float* ww, const float* bw,
+                              const float* wt, const float* bt, const float* wp, const float* bp, float* out, int B, int T,
+                              int H, int W, void* stream) {
+    if (!wt || !bt || !wp || !bp) OPS_FAIL(PFNL_ERR_INVALID, "NULL argument");
+    return op_nonlocal_block(x, wg, bg, ww, bw, wt, bt, wp, bp, 0, 1, out, B, T, H, W, stream);
+}
+
+int pfnl_op_nonlocal_block(const float* x, const float* wg, const float* bg, const float* ww, const float* bw, const float* wt,
+                           const float* bt, const float* wp, const float* bp, int nltype, int sub_sample, float* out, int B, int T,
+                           int H, int W, void* stream) {
+    return op_nonlocal_block(x, wg, bg, ww, bw, wt, bt, wp, bp, nltype, sub_sample, out, B, T, H, W, stream);
 }
 
 int pfnl_op_gather_windows(const float* frames, float* win, int F, int first, int count, int T, int H, int W, void* stream) {

@@ -113,7 +113,12 @@ size_t nl_partial_floats(int B, int N, int C);               // scratch for the 
 hipError_t launch_nl_attn(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, int B,
                           int N, int C, hipStream_t s, const float* Q = nullptr,    // Q: projected queries (nltype 0) or null = X
                           int q0 = 0, int q1 = -1);                                 // queries [q0, q1) only (-1: N): a strip of the frame
-hipError_t launch_nl_qproj(const float* X, const float* M, const float* c, float* Q, int B, int N, int C, hipStream_t s);
+hipError_t launch_nl_qproj(const float* X, const float* M, const float* c, float* Q, int B, int N, int C, hipStream_t s,
+                           bool dot_column = false);                                // + column C = theta . b_phi (nltype 2)
+// the general form of the block (reference utils.py:18-71, nltype 0 / 1 / 2, sub_sample >= 1): keys = values = Kx [B][Nk][CP]
+hipError_t launch_nl_attn_general(const float* X, const float* Kx, int Nk, float* Xo, const float* Wp, const float* bp,
+                                  float* partial, int B, int N, int C, hipStream_t s, const float* Q, int q0, int q1, bool dot);
+hipError_t launch_nl_pool(const float* X, float* Xs, int B, int h2, int w2, int sub, int C, hipStream_t s);
 int nl_key_splits(int B, int N);
 hipError_t launch_nl_merge(const float* X, const float* Zp, const float* ML, const float* bp, float* Xo, int B, int N, int C, int ks,
                            hipStream_t s, int q0 = 0, int q1 = -1);

@@ -65,8 +65,12 @@ __global__ void nl_unpack_kernel(const float* __restrict__ Xo, float* __restrict
 constexpr int NL_KT = 64;   // keys per LDS tile (two 32-key MFMA sub-tiles)
 
 // One workgroup = 4 waves x 32 queries.  C = 12T real channels, CT = ceil(C/32) channel tiles.
-template <int C>
+// DOT (utils.py:59-62, nltype 2): P = relu(theta phi^T) / rowsum instead of exp(.) / rowsum - no running maximum, the logits get
+// the per-query constant theta_i . b_phi (column C of Q: it does NOT cancel under the relu) added before the clamp.
+// Kx / Nk: keys = values (sub_sample > 1: the average-pooled X, utils.py:27-28,35-36 - pooling commutes with the 1x1 convs).
+template <int C, bool DOT>
 __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict__ X,
+                                                         const float* __restrict__ Kx, int Nk,
                                                          float* __restrict__ Xo,
                                                          const float* __restrict__ Wp,   // [CP][CP], row = ci
                                                          const float* __restrict__ bp,   // [CP]
@@ -88,6 +92,7 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
     const int kh = lane >> 5;
     const int b = blockIdx.y;
     const float* Xb = X + (size_t)b * N * CP;
+    const float* Kb = Kx + (size_t)b * Nk * CP;
     float* Xob = Xo + (size_t)b * N * CP;
     const int q = q0 + blockIdx.x * 128 + wave * 32 + xl;  // this lane's query
     const int qc = q < q1 ? q : q1 - 1;
@@ -98,7 +103,8 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
     constexpr float LOG2E = 1.4426950408889634f;
     float bq[KSTEPS];
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) bq[s] = Q[((size_t)b * N + qc) * CP + 2 * s + kh] * LOG2E;
+    for (int s = 0; s < KSTEPS; ++s) bq[s] = Q[((size_t)b * N + qc) * CP + 2 * s + kh] * (DOT ? 1.0f : LOG2E);
+    [[maybe_unused]] const float dq = DOT ? Q[((size_t)b * N + qc) * CP + C] : 0.f;
     // The running sum l of the probabilities is not kept in VALU: pad channel C of the key tile in LDS is set to 1,
     // so row C of O^T = V^T P^T accumulates sum_k P (and is rescaled with O).  Where that row lives in the D layout:
     constexpr int LCT = C / 32, LI = C % 32;
@@ -122,8 +128,8 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
             rk[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (it < TILE_F4) {
                 const int row = it / (CP / 4), c4 = it % (CP / 4);
-                if (k0 + row < N)
-                    rk[i] = *reinterpret_cast<const f32x4*>(Xb + (size_t)(k0 + row) * CP + c4 * 4);
+                if (k0 + row < Nk)
+                    rk[i] = *reinterpret_cast<const f32x4*>(Kb + (size_t)(k0 + row) * CP + c4 * 4);
             }
         }
     };
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
 
     // key split: workgroup z of gridDim.z handles key tiles [kt0, kt1) (flash-decoding style); the
     // partial results are merged by nl_merge_kernel.  gridDim.z == 1: everything here, final output.
-    const int ntiles = (N + NL_KT - 1) / NL_KT;
+    const int ntiles = (Nk + NL_KT - 1) / NL_KT;
     const int ks = gridDim.z, sp = blockIdx.z;
     const int kt0 = (int)((long long)ntiles * sp / ks), kt1 = (int)((long long)ntiles * (sp + 1) / ks);
     load_tile(kt0 * NL_KT);
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
 #pragma unroll
         for (int sub = 0; sub < NL_KT / 32; ++sub) {
             const int kbase = kt * NL_KT + sub * 32;
-            if (kbase >= N) break;                         // wave-uniform
+            if (kbase >= Nk) break;                        // wave-uniform
             // S^T[key i][query j]: A = Xk[i = xl][c = 2s + kh] from LDS, B = bq.
             f32x16 st;
 #pragma unroll
@@ -166,11 +172,20 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) st = mfma32(ka[2 * s], bq[s], st);
 
+            if constexpr (DOT) {                           // relu(f), utils.py:60; keys past the end contribute nothing
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[r] = fmaxf(st[r] + dq, 0.f);
+                if (kbase + 32 > Nk) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kbase + drow(r, lane) >= Nk) st[r] = 0.f;
+                }
+            } else {
             // online softmax; register r of this lane is key kbase + drow(r, lane).
-            if (kbase + 32 > N) {                          // wave-uniform: only the last, partial key tile
+            if (kbase + 32 > Nk) {                         // wave-uniform: only the last, partial key tile
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (kbase + drow(r, lane) >= N) st[r] = -INFINITY;
+                    if (kbase + drow(r, lane) >= Nk) st[r] = -INFINITY;
             }
             float tmax = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
 #pragma unroll
@@ -186,6 +201,7 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+            }
             }
             // O^T[ch i][query j] += V^T[i][key] P^T[key][j]; contraction step s uses the key that
             // accumulator register s of this lane's half already holds: key = drow(s, lane).
@@ -245,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
     }
     if (ks > 1 && q < q1 && kh == 0) {
         float* ml = ML + (((size_t)b * ks + sp) * N + q) * 2;
-        ml[0] = m;
+        ml[0] = DOT ? 0.f : m;                            // (DOT: the partials carry no maximum - merged with weight 1)
         ml[1] = l;
     }
     // pad columns of the output are never read by conv0.
@@ -274,6 +290,15 @@ __global__ void nl_merge_kernel(const float* __restrict__ X, const float* __rest
         }
         Xo[i] = X[i] + num / den + bp[co];
     }
+}
+
+// (Nk keys for N queries: fewer keys never give more splits, so nl_partial_floats(B, N, C) bounds the pooled-key case too)
+static int nl_key_splits2(int B, int N, int Nk) {
+    const int qblocks = (N + 127) / 128, ntiles = (Nk + NL_KT - 1) / NL_KT;
+    int ks = (512 + qblocks * B - 1) / (qblocks * B);
+    if (ks > 8) ks = 8;
+    if (ks > ntiles / 4) ks = ntiles / 4;
+    return ks < 1 ? 1 : ks;
 }
 
 int nl_key_splits(int B, int N) {
@@ -308,14 +333,15 @@ hipError_t launch_nl_unpack(const float* Xo, float* out, int B, int T, int H, in
 // Embedded-Gaussian option (utils.py nltype 0: theta = X Wt + bt, phi = X Wp + bp): the logits
 //   (X_i Wt + bt) . (X_j Wp + bp) = (X_i M + c) . X_j + (terms constant in j, which cancel in the softmax over j),
 //   M = Wt Wp^T, c = bt Wp^T (folded on the host in fp64) - so only the QUERIES are projected; keys and values stay X.
+// Cq = C + 1 (nltype 2): column C of M / c holds Wt b_phi / bt . b_phi, i.e. Q[.][C] = theta_i . b_phi (see nl_attn_kernel<., DOT>).
 __global__ void nl_qproj_kernel(const float* __restrict__ X, const float* __restrict__ M, const float* __restrict__ c,
-                                float* __restrict__ Q, size_t rows, int C, int CP) {
+                                float* __restrict__ Q, size_t rows, int C, int CP, int Cq) {
     const size_t total = rows * CP;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int co = (int)(i % CP);
         const size_t n = i / CP;
         float acc = 0.f;
-        if (co < C) {
+        if (co < Cq) {
             acc = c[co];
             const float* xr = X + n * CP;
             for (int ci = 0; ci < C; ++ci) acc = fmaf(xr[ci], M[(size_t)ci * CP + co], acc);
@@ -324,35 +350,77 @@ __global__ void nl_qproj_kernel(const float* __restrict__ X, const float* __rest
     }
 }
 
-hipError_t launch_nl_qproj(const float* X, const float* M, const float* c, float* Q, int B, int N, int C, hipStream_t s) {
+hipError_t launch_nl_qproj(const float* X, const float* M, const float* c, float* Q, int B, int N, int C, hipStream_t s, bool dot_column) {
     const int CP = nl_padded_ch(C);
     const size_t total = (size_t)B * N * CP;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(nl_qproj_kernel, dim3(blocks), dim3(256), 0, s, X, M, c, Q, (size_t)B * N, C, CP);
+    hipLaunchKernelGGL(nl_qproj_kernel, dim3(blocks), dim3(256), 0, s, X, M, c, Q, (size_t)B * N, C, CP, dot_column ? C + 1 : C);
     return hipGetLastError();
 }
 
 hipError_t launch_nl_attn(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, int B, int N,
                           int C, hipStream_t s, const float* Q, int q0, int q1) {
+    return launch_nl_attn_general(X, X, N, Xo, Wp, bp, partial, B, N, C, s, Q, q0, q1, false);
+}
+
+// Kx [B][Nk][CP]: keys = values (X itself, or its average-pooled copy: launch_nl_pool); dot: the relu / rowsum form (nltype 2),
+// which needs Q with the per-query constant in column C (launch_nl_qproj with Cq = C + 1).
+hipError_t launch_nl_attn_general(const float* X, const float* Kx, int Nk, float* Xo, const float* Wp, const float* bp,
+                                  float* partial, int B, int N, int C, hipStream_t s, const float* Q, int q0, int q1, bool dot) {
+    if (dot && !Q) return hipErrorInvalidValue;
     if (!Q) Q = X;
     if (q1 < 0) q1 = N;
-    if (q0 < 0 || q0 >= q1 || q1 > N) return hipErrorInvalidValue;
-    const int ks = nl_key_splits(B, N);
+    if (q0 < 0 || q0 >= q1 || q1 > N || Nk < 1) return hipErrorInvalidValue;
+    const int ks = nl_key_splits2(B, N, Nk);
     const int CP = nl_padded_ch(C);
     if (ks > 1 && !partial) return hipErrorInvalidValue;
     float* Zp = partial;
     float* ML = partial ? partial + (size_t)B * ks * N * CP : nullptr;
     dim3 grid((q1 - q0 + 127) / 128, B, ks);
     dim3 block(256);
+#define NL_LAUNCH(C_)                                                                                                  \
+    do {                                                                                                               \
+        if (dot) hipLaunchKernelGGL((nl_attn_kernel<C_, true>), grid, block, 0, s, X, Kx, Nk, Xo, Wp, bp, Zp, ML, Q, N, q0, q1);   \
+        else hipLaunchKernelGGL((nl_attn_kernel<C_, false>), grid, block, 0, s, X, Kx, Nk, Xo, Wp, bp, Zp, ML, Q, N, q0, q1);    \
+    } while (0)
     switch (C) {
-        case 84: hipLaunchKernelGGL(nl_attn_kernel<84>, grid, block, 0, s, X, Xo, Wp, bp, Zp, ML, Q, N, q0, q1); break;
-        case 60: hipLaunchKernelGGL(nl_attn_kernel<60>, grid, block, 0, s, X, Xo, Wp, bp, Zp, ML, Q, N, q0, q1); break;
-        case 36: hipLaunchKernelGGL(nl_attn_kernel<36>, grid, block, 0, s, X, Xo, Wp, bp, Zp, ML, Q, N, q0, q1); break;
+        case 84: NL_LAUNCH(84); break;
+        case 60: NL_LAUNCH(60); break;
+        case 36: NL_LAUNCH(36); break;
         default: return hipErrorInvalidValue;
     }
+#undef NL_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ks == 1) return e;
     return launch_nl_merge(X, Zp, ML, bp, Xo, B, N, C, ks, s, q0, q1);
+}
+
+// tf.layers.average_pooling2d(pool_size = strides = sub, 'valid') of the packed X [B][h2*w2][CP] -> [B][(h2/sub)*(w2/sub)][CP]
+// (reference utils.py:27-28,35-36: applied to g and phi, which are 1x1 convolutions of X - the mean commutes with both).
+__global__ void nl_pool_kernel(const float* __restrict__ X, float* __restrict__ Xs, int B, int h2, int w2, int sub, int CP) {
+    const int hp = h2 / sub, wp = w2 / sub;
+    const size_t total = (size_t)B * hp * wp * CP;
+    const float inv = 1.0f / (float)(sub * sub);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CP);
+        const int px = (int)((i / CP) % wp);
+        const int py = (int)((i / ((size_t)CP * wp)) % hp);
+        const size_t b = i / ((size_t)CP * wp * hp);
+        float acc = 0.f;
+        for (int dy = 0; dy < sub; ++dy)
+            for (int dx = 0; dx < sub; ++dx)
+                acc += X[((b * h2 + (size_t)(py * sub + dy)) * w2 + (px * sub + dx)) * CP + c];
+        Xs[i] = acc * inv;
+    }
+}
+
+hipError_t launch_nl_pool(const float* X, float* Xs, int B, int h2, int w2, int sub, int C, hipStream_t s) {
+    if (sub < 1 || h2 / sub < 1 || w2 / sub < 1) return hipErrorInvalidValue;
+    const int CP = nl_padded_ch(C);
+    const size_t total = (size_t)B * (h2 / sub) * (w2 / sub) * CP;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(nl_pool_kernel, dim3(blocks), dim3(256), 0, s, X, Xs, B, h2, w2, sub, CP);
+    return hipGetLastError();
 }
 
 hipError_t launch_nl_merge(const float* X, const float* Zp, const float* ML, const float* bp, float* Xo, int B, int N, int C, int ks,

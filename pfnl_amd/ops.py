@@ -311,6 +311,31 @@ def nonlocal_embedded(x, wg, bg, ww, bw, wt, bt, wp, bp):
     return out
 
 
+def nonlocal_block(x, wg, bg, ww, bw, theta=None, phi=None, nltype: int = 1, sub_sample: int = 1):
+    """utils.NonLocalBlock(input_x, out_channels, sub_sample, nltype) in its general form (reference utils.py:18-71) inside the
+    wrapper of model/pfnl.py:55-60: x [B,T,H,W,3] (cuda) -> [B,H,W,3T] = stack + depth_to_space(NonLocalBlock(space_to_depth(stack))).
+    ``theta`` / ``phi`` = (kernel [C,C] or [1,1,C,C], bias [C]) of the two projections (nltype 0 and 2)."""
+    import torch
+    lib = _capi.load_library()
+    B, T, H, W, c = x.shape
+    C_ = 12 * T
+    if nltype not in (0, 1, 2):
+        raise ValueError("nltype must be 0, 1 or 2 (3, 'concat', builds no graph in the reference: utils.py:23)")
+    if nltype != 1 and (theta is None or phi is None):
+        raise ValueError("nltype 0 / 2 need the theta and phi projections")
+    arrs = [_host(a, "w") for a in (wg, bg, ww, bw)]
+    proj = [None] * 4
+    if nltype != 1:
+        proj = [_host(a, "w") for a in (theta[0], theta[1], phi[0], phi[1])]
+    for a, n in zip(arrs + [p for p in proj if p is not None], (C_ * C_, C_) * 4):
+        if a.size != n:
+            raise ValueError("nonlocal_block: weight shapes do not match 12*T channels")
+    out = torch.empty((B, H, W, 3 * T), dtype=torch.float32, device=x.device)
+    _capi.check(lib.pfnl_op_nonlocal_block(_req(x, "x"), *[_hp(a) for a in arrs], *[_hp(a) for a in proj], int(nltype),
+                                           int(sub_sample), _req(out, "out"), B, T, H, W, _stream(x)))
+    return out
+
+
 def conv0(x, kernel, bias=None):
     """conv0 (reference model/pfnl.py:48,61-62): x [B,T,H,W,3] (cuda) -> lrelu(conv5x5(frame) + b) [B*T,H,W,64]."""
     import torch

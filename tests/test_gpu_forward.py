@@ -453,6 +453,52 @@ def test_graph_replay_matches_eager():
 # ---- the domain of the f16-pipe kernels (the default fp32 path computes on the f16 matrix pipe with exactly split operands;
 # |activation|, |weight| < 65504, non-local inputs on a [0,1] scale) ------------------------------------------------------------------
 
+def test_nonlocal_options_forward():
+    """utils.NonLocalBlock's nltype / sub_sample arguments as engine options (the reference's forward pins them to 1 / 1,
+    model/pfnl.py:58): whole forward and the strip form against the fp64 spec with the same arguments; both precisions."""
+    geom = PFNLGeometry(num_block=1)
+    w = synth.synthetic_weights(geom, seed=0)
+    rng = np.random.default_rng(6)
+    C = geom.nl_ch
+    for n, sc in (("theta/theta", 0.08), ("phi/phi", 0.08)):
+        w[f"nlvsr/nlblock_0/{n}/kernel"] = (rng.normal(size=(1, 1, C, C)) * sc).astype(np.float32)
+        w[f"nlvsr/nlblock_0/{n}/bias"] = (0.3 + rng.normal(size=C) * 0.1).astype(np.float32)   # (theta . phi mostly > 0: nltype 2
+    w1 = {k: v for k, v in w.items() if "theta" not in k and "phi" not in k}                     #  divides by the sum of the positive ones)
+    x = synth.uniform_clips(2, 7, 12, 20, seed=4)
+    eng, eng1 = _engine_with(geom, w), _engine_with(geom, w1)
+    base = pfnl_spec.forward(x, w1, num_block=1)
+    for e, ww, nlt, sub in ((eng, w, 2, 1), (eng, w, 2, 2), (eng, w, 0, 3), (eng1, w1, 1, 2), (eng, w, 1, 1)):
+        e.set_option("nl_type", str(nlt))
+        e.set_option("nl_sub_sample", str(sub))
+        taps = {}
+        ref = pfnl_spec.forward(x, ww, num_block=1, taps=taps, nltype=nlt, sub_sample=sub)
+        y = e.forward(x)
+        assert np.isfinite(ref).all()
+        assert np.abs(e.tap("nl_out", 2, 12, 20) - taps["nl_out"]).max() < 5e-5, (nlt, sub)
+        assert np.abs(y - ref).max() < ABS_TOL, (nlt, sub)
+        if (nlt, sub) != (1, 1):
+            assert np.abs(ref - base).max() > 1e-5, (nlt, sub)                     # the arguments change the result
+            import torch
+            xd = torch.from_numpy(x).cuda()
+            ys = torch.zeros(e.out_shape(2, 12, 20), dtype=torch.float32, device="cuda")
+            for r0, nr in ((0, 4), (4, 8)):                                        # keys (and their pooling) are global per frame
+                e.forward_strip(xd, ys, r0, nr)
+            torch.cuda.synchronize()
+            assert np.abs(ys.cpu().numpy() - ref).max() < ABS_TOL, (nlt, sub)
+    eng1.set_option("nl_type", "2")
+    with pytest.raises(Exception):
+        eng1.forward(x)                                                             # no theta / phi variables
+    eng1.set_option("nl_type", "auto")
+    eng1.set_option("nl_sub_sample", "1")
+    with pytest.raises(Exception):
+        eng1.set_option("nl_type", "3")
+    eng.set_option("precision", "bf16")
+    eng.set_option("nl_type", "2")
+    eng.set_option("nl_sub_sample", "2")
+    ref = pfnl_spec.forward(x, w, num_block=1, nltype=2, sub_sample=2)
+    assert np.abs(eng.forward(x) - ref).max() < 2e-2                                # bf16 trunk; the block itself stays f32
+
+
 def _engine_with(geom, w):
     e = PFNLEngine(geom, device=0)
     e.load_weights(w)

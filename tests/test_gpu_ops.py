@@ -330,6 +330,54 @@ def test_nonlocal_embedded_gaussian(B, T, H, W):
     assert np.abs(plain - ref).max() > 1e-4                                      # theta/phi matter
 
 
+@pytest.mark.parametrize("B,T,H,W,nltype,sub", [
+    (1, 7, 16, 16, 2, 1), (2, 3, 6, 10, 2, 1), (1, 5, 12, 22, 2, 2),          # dot product (relu / rowsum), plain and pooled
+    (1, 7, 16, 24, 1, 2), (1, 7, 18, 14, 1, 3), (2, 5, 20, 12, 1, 2),        # PFNL's Gaussian with pooled keys (ragged: 9x7 grid / 3)
+    (1, 7, 16, 16, 0, 2), (1, 3, 22, 10, 0, 3), (1, 7, 40, 72, 1, 2),        # embedded Gaussian pooled; a key-split geometry
+    (1, 7, 40, 72, 2, 1), (1, 7, 4, 4, 1, 2), (1, 5, 12, 8, 2, 3)])          # ... for the dot product; a single pooled key; two
+def test_nonlocal_block_general(B, T, H, W, nltype, sub):
+    """utils.NonLocalBlock(input_x, C, sub_sample, nltype) as the reference writes it (utils.py:18-71: g / phi / theta convolutions,
+    average pooling of g and phi, full N x Nk affinity, exp- or relu-normalisation) + the wrapper of model/pfnl.py:55-60, in fp64,
+    against pfnl_op_nonlocal_block - which folds the convolutions, pools X instead of g and phi, and never materialises the affinity."""
+    rng = np.random.default_rng(T * 7 + H + 100 * nltype + sub)
+    C = 12 * T
+    x = rng.random((B, T, H, W, 3), dtype=np.float32)
+    mk = lambda sc: (rng.normal(size=(1, 1, C, C)) * sc).astype(np.float32)      # noqa: E731
+    mb = lambda sc=0.05: (rng.normal(size=C) * sc).astype(np.float32)            # noqa: E731
+    wg, ww, wt, wp = mk(0.1), mk(0.1), mk(0.15), mk(0.15)
+    bg, bw, bt, bp = mb(), mb(), mb(0.3), mb(0.3)                                # (b_phi matters for nltype 2 only: not small)
+    th, ph = ((wt, bt), (wp, bp)) if nltype != 1 else (None, None)
+    got = ops.nonlocal_block(dev(x), wg, bg, ww, bw, theta=th, phi=ph, nltype=nltype, sub_sample=sub).cpu().numpy()
+    stack = np.concatenate([x[:, t] for t in range(T)], -1).astype(np.float64)
+    x1 = pfnl_spec.space_to_depth2(stack)
+    f = lambda a: a.astype(np.float64)                                           # noqa: E731
+    z = pfnl_spec.nonlocal_block(x1, f(wg), f(bg), f(ww), f(bw), theta=None if th is None else (f(wt), f(bt)),
+                                 phi=None if ph is None else (f(wp), f(bp)), nltype=nltype, sub_sample=sub)
+    ref = stack + pfnl_spec.depth_to_space2(z)
+    ok = np.isfinite(ref)                                                        # (nltype 2: a query without a positive affinity is 0 / 0 in
+    assert got.shape == ref.shape and np.array_equal(np.isfinite(got), ok)       #  the reference: NaN on both sides, utils.py:61-63)
+    assert ok.mean() > 0.5 and np.abs(got[ok] - ref[ok]).max() < 2e-5, np.abs(got[ok] - ref[ok]).max()
+    if nltype == 1 and sub == 1:
+        return
+    plain = ops.nonlocal_residual(dev(x), wg, bg, ww, bw, precision="f32").cpu().numpy()
+    assert np.abs(plain[ok] - ref[ok]).max() > 1e-5                              # the options change the result
+    if nltype == 2:                                                              # ... and so does the per-query constant theta . b_phi
+        z0 = pfnl_spec.nonlocal_block(x1, f(wg), f(bg), f(ww), f(bw), theta=(f(wt), f(bt)), phi=(f(wp), 0 * f(bp)), nltype=2, sub_sample=sub)
+        assert np.nanmax(np.abs(z0 - z)) > 1e-5
+
+
+def test_nonlocal_block_rejects():
+    x = dev(np.zeros((1, 7, 8, 8, 3), np.float32))
+    C = 84
+    w, b = np.zeros((C, C), np.float32), np.zeros(C, np.float32)
+    with pytest.raises(ValueError):
+        ops.nonlocal_block(x, w, b, w, b, nltype=3)
+    with pytest.raises(ValueError):
+        ops.nonlocal_block(x, w, b, w, b, nltype=2)                              # no projections
+    with pytest.raises(Exception):
+        ops.nonlocal_block(x, w, b, w, b, nltype=1, sub_sample=5)                # 4x4 grid / 5: no key left
+
+
 def test_gather_windows_and_quantise():
     """reference model/pfnl.py:238-242 (clamped windows) and :254-257 (uint8 quantisation) on the device: bit-exact
     against the host restatements."""

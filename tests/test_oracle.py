@@ -198,3 +198,47 @@ def test_bf16_golden_outputs_reproduce():
         w = synth.synthetic_weights(geom, seed=0)
         y = pfnl_fast.FastOracle(w, geom.num_frames, geom.scale, geom.num_block, trunk_dtype="bf16").forward(gd["x"])
         assert np.abs(y - ref[name]).max() < 1e-5
+
+
+def test_nonlocal_options_known_answers():
+    """utils.NonLocalBlock's other branches (utils.py:27-28,35-36 sub_sample; :59-62 nltype 2) in the spec: known answers."""
+    rng = np.random.default_rng(5)
+    C = 12
+    mk = lambda sc: rng.normal(size=(1, 1, C, C)) * sc                           # noqa: E731
+    wg, ww, wt, wp = mk(0.3), mk(0.3), mk(0.3), mk(0.3)
+    bg, bw, bt, bp = (rng.normal(size=C) * 0.1 for _ in range(4))
+    # average pooling, 'valid': windows that do not fit are dropped
+    a = rng.random((2, 7, 5, 3))
+    p = pfnl_spec.avg_pool_valid(a, 2)
+    assert p.shape == (2, 3, 2, 3)
+    assert np.allclose(p[1, 2, 1], a[1, 4:6, 2:4].mean(axis=(0, 1)))
+    # a constant image: every affinity row is uniform whatever the normalisation -> y = g of that pixel, in all three types
+    x = np.broadcast_to(rng.random(C), (1, 4, 6, C)).copy()
+    outs = [pfnl_spec.nonlocal_block(x, wg, bg, ww, bw, theta=(wt, bt + 2.0), phi=(wp, bp + 2.0), nltype=t, sub_sample=s)
+            for t in (0, 1, 2) for s in (1, 2)]
+    want = pfnl_spec.conv2d_same(pfnl_spec.conv2d_same(x, wg, bg), ww, bw)
+    for o in outs:
+        assert np.allclose(o, want, atol=1e-12)
+    # an image that is constant on 2x2 blocks: pooling merges equal keys, which changes no softmax / relu-normalised average
+    blocks = rng.random((1, 3, 4, C))
+    xb = np.repeat(np.repeat(blocks, 2, axis=1), 2, axis=2)
+    for t in (0, 1, 2):
+        full = pfnl_spec.nonlocal_block(xb, wg, bg, ww, bw, theta=(wt, bt + 1.0), phi=(wp, bp + 1.0), nltype=t, sub_sample=1)
+        pooled = pfnl_spec.nonlocal_block(xb, wg, bg, ww, bw, theta=(wt, bt + 1.0), phi=(wp, bp + 1.0), nltype=t, sub_sample=2)
+        assert np.allclose(full, pooled, atol=1e-12), t
+    # nltype 2 on two keys by hand: P = relu(f) / rowsum
+    x2 = rng.random((1, 1, 2, C))
+    bt, bp = bt + 1.0, bp + 1.0
+    th = pfnl_spec.conv2d_same(x2, wt, bt).reshape(2, C)
+    ph = pfnl_spec.conv2d_same(x2, wp, bp).reshape(2, C)
+    g = pfnl_spec.conv2d_same(x2, wg, bg).reshape(2, C)
+    fm = np.maximum(th @ ph.T, 0)
+    y = (fm / fm.sum(1, keepdims=True)) @ g
+    want = pfnl_spec.conv2d_same(y.reshape(1, 1, 2, C), ww, bw)
+    got = pfnl_spec.nonlocal_block(x2, wg, bg, ww, bw, theta=(wt, bt), phi=(wp, bp), nltype=2)
+    assert np.isfinite(want).all() and np.allclose(got, want, atol=1e-12)
+    # a query without a positive affinity divides 0 by 0 (utils.py:61-63 has no epsilon): NaN, as TF gives
+    neg = pfnl_spec.nonlocal_block(x2, wg, bg, ww, bw, theta=(0 * wt, np.ones(C)), phi=(0 * wp, -np.ones(C)), nltype=2)
+    assert np.isnan(neg).all()
+    with pytest.raises(ValueError):
+        pfnl_spec.nonlocal_block(x2, wg, bg, ww, bw, nltype=3)
