@@ -1,0 +1,84 @@
+"""The C-ABI's host side under AddressSanitizer WITHOUT torch (torch's bundled HIP runtime aborts at initialisation under a
+preloaded sanitizer runtime; the library's own dependency, /opt/rocm's libamdhip64, does not): numpy containers only, i.e. the
+host-pointer form of pfnl_forward (what a `sess.run` replacement uses) - handle creation, weight hand-over,
+folding and packing (pfnl_finalize_weights), option changes, workspace sizing, staging copies, the range-flag rerun, weight
+replicas, taps, profiling read-out - over the kernel families of all precisions, checked against the oracle on the way.
+Run through tools/run_asan.sh --host (sets LD_PRELOAD / PFNL_HIP_LIB)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import pfnl_spec                                   # noqa: E402  (the checker)
+from pfnl_amd import _capi, synth                              # noqa: E402
+from pfnl_amd.engine import PFNLEngine                         # noqa: E402
+from pfnl_amd.spec import PFNLGeometry                         # noqa: E402
+
+
+def main():
+    assert "asan" in _capi.LIB_PATH, "run through tools/run_asan.sh --host"
+    n = 0
+    for T, scale, nb, B, H, W in ((7, 4, 2, 1, 16, 24), (5, 2, 1, 2, 10, 38), (3, 4, 1, 1, 34, 18), (7, 4, 1, 1, 2, 2)):
+        geom = PFNLGeometry(num_frames=T, scale=scale, num_block=nb)
+        w = synth.synthetic_weights(geom, seed=T)
+        x = synth.uniform_clips(B, T, H, W, seed=H)
+        ref = pfnl_spec.forward(x, w, scale=scale, num_block=nb)
+        eng = PFNLEngine(geom, device=0)
+        eng.load_weights(w)
+        for opts in ({}, {"conv3x3": "split16", "small": "off"}, {"conv3x3": "winograd"}, {"conv3x3": "direct", "conv1x1": "tiled"},
+                     {"strict_fp32": "on"}, {"split16_sf": "off"}, {"split16_chain": "off"}, {"graph": "on"}, {"precision": "bf16"},
+                     {"precision": "bf16", "bf16_nonlocal": "split", "bf16_conv10": "separate"}):
+            for k, v in opts.items():
+                eng.set_option(k, v)
+            for _ in range(2):                                 # (graph=on captures on the second call)
+                y = eng.forward(x)
+            tol = 3e-2 if opts.get("precision") == "bf16" else 5e-5
+            assert y.shape == ref.shape and np.abs(y - ref).max() < tol, (T, opts, np.abs(y - ref).max())
+            eng.workspace_bytes(B, H, W)
+            eng.tap("nl_out", B, H, W)
+            for k in opts:
+                eng.set_option(k, {"conv3x3": "auto", "small": "auto", "conv1x1": "split16", "strict_fp32": "off", "split16_sf": "on",
+                                   "split16_chain": "on", "graph": "off", "precision": "fp32", "bf16_nonlocal": "f16",
+                                   "bf16_conv10": "fused"}[k])
+            n += 1
+        eng.profile(1)
+        eng.forward(x)
+        eng.profile_read()
+        eng.profile(0)
+        twin = PFNLEngine(geom, device=0)
+        twin.copy_weights_from(eng)
+        assert np.array_equal(twin.forward(x), eng.forward(x))
+        big = x * 3e5                                          # leaves the f16 pipe's domain: the synchronous call reruns on f32 MFMA
+        yb = eng.forward(big)
+        assert np.isfinite(yb).all() and eng.range_reruns() >= 1
+        twin.close()
+        eng.close()
+    # theta / phi variables and the other arguments of utils.NonLocalBlock
+    geom = PFNLGeometry(num_block=1)
+    w = synth.synthetic_weights(geom, seed=0)
+    rng = np.random.default_rng(6)
+    for nme in ("theta/theta", "phi/phi"):
+        w[f"nlvsr/nlblock_0/{nme}/kernel"] = (rng.normal(size=(1, 1, 84, 84)) * 0.08).astype(np.float32)
+        w[f"nlvsr/nlblock_0/{nme}/bias"] = (0.3 + rng.normal(size=84) * 0.1).astype(np.float32)
+    x = synth.uniform_clips(2, 7, 12, 20, seed=4)
+    eng = PFNLEngine(geom, device=0)
+    eng.load_weights(w)
+    for nlt, sub in ((0, 1), (2, 1), (2, 2), (1, 3)):
+        eng.set_option("nl_type", str(nlt))
+        eng.set_option("nl_sub_sample", str(sub))
+        ref = pfnl_spec.forward(x, w, num_block=1, nltype=nlt, sub_sample=sub)
+        assert np.abs(eng.forward(x) - ref).max() < 5e-5, (nlt, sub)
+        n += 1
+    for bad in (("nl_type", "3"), ("conv3x3", "nope"), ("nl_sub_sample", "0")):
+        try:
+            eng.set_option(*bad)
+            raise AssertionError(bad)
+        except _capi.PFNLHipError:
+            pass
+    eng.close()
+    print(f"asan host path: {n} configurations, no report")
+
+
+if __name__ == "__main__":
+    main()
