@@ -46,7 +46,8 @@ CONV3X3_KERNELS = {
     "winograd_tile": ("conv_wino_kernel<*> (fused Winograd F(2x2,3x3) 64->64, f32 MFMA, one workgroup per tile)",
                       ["conv_wino.hip", "wino_geom.h"]),
     "direct": ("conv_mfma_kernel<3,16,*> (3x3 64->64 f32 MFMA implicit GEMM)", ["conv_mfma.hip"]),
-    "split16": ("conv3x3_split16_kernel<0,OSF> (conv1_i) + conv3x3_sf_chain_kernel (the whole of conv2_i: split-format input and weights by LDS-DMA, shared half "
+    "split16": ("conv3x3_c1c10_kernel (conv1_i + conv10_i in one launch: the frame tiles leave as split-format lines through LDS, where conv10_i takes them "
+                "as MFMA operands) + conv3x3_sf_chain_kernel (the whole of conv2_i: split-format input and weights by LDS-DMA, shared half "
                 "in registers): direct 3x3 64->64 on f16 MFMA with exactly split fp32 operands, 3 MFMAs per product block, fp32 accumulation",
                 ["conv_split16.hip", "conv_sf.hip"]),
     "small": ("conv_small_kernel<3,R> (small-shape trunk: conv1_i and the whole of conv2_i, 4 waves per R x 32-pixel tile, split-f16 MFMA, weights "
@@ -174,6 +175,10 @@ def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
     # launches of the class per PF block: 2 with conv2_i as one launch (Winograd's grouped mode; the split-f16 chain kernel), else 3
     chain = algo == "split16" and os.environ.get("PFNL_SF_CHAIN", "1") not in ("0", "off") and os.environ.get("PFNL_SPLIT16_SF", "1") not in ("0", "off")
     launches_per_step = (2 if (algo == "winograd" or chain) else 3) * geom.num_block
+    # conv10_i rides in the conv1_i launch of the default path (conv3x3_c1c10_kernel): its work belongs to this class then
+    c10 = algo == "split16" and os.environ.get("PFNL_SF_C10", "1") not in ("0", "off") and os.environ.get("PFNL_SPLIT16_SF", "1") not in ("0", "off")
+    if c10:
+        flops3 += geom.num_block * F * P * 64 * 64 * 2.0
     flops_per_launch = flops3 / launches_per_step
     direct_tflops = flops_per_launch / (avg_ms * 1e-3) / 1e12
     if algo == "split16":
@@ -181,7 +186,8 @@ def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
         # FLOPs against 2.5 PFLOP/s) and the HBM roof (conv1_i: read F + write F; shared half: read B + write B; per-frame
         # half: read F + addend B + residual F, write F - over 3 launches) - both fractions are reported, the larger binds
         name, files = CONV3X3_KERNELS[algo]
-        bytes_per_launch = P * 256.0 * (5 * F + 3 * B) * geom.num_block / launches_per_step   # the graph's bytes (layer-granular), however many launches carry them
+        # the graph's bytes (layer-granular), however many launches carry them; + conv10_i's (read F, write B) when it is part of the class
+        bytes_per_launch = P * 256.0 * (5 * F + 3 * B + ((F + B) if c10 else 0)) * geom.num_block / launches_per_step
         gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         ex = 3.0 * direct_tflops
         # frac = ALGORITHMIC work / time / peak: the reference graph's bytes (layer-granular, shared-base split) against HBM, its

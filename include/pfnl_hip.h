@@ -100,6 +100,9 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *   (hi, lo' binary16 pairs: the MFMA operands themselves) and both halves of conv2_i read it by LDS-DMA (conv_sf.hip).
  * key "split16_chain" = "on" (default) | "off": with split16_sf, conv2_i is one launch - per (clip, tile) the shared half stays in
  *   registers as the initial C of the T per-frame tiles (no pb tensor, no addend reads, 20 launches fewer per forward).
+ * key "split16_c10" = "on" (default) | "off": with split16_sf, conv1_i and conv10_i are one launch (conv3x3_c1c10_kernel): per (clip,
+ *   tile) the T frame tiles of conv1_i leave as split-format lines through LDS, where conv10_i takes them as MFMA operands - inp1 is
+ *   written once and never read back by a 1x1 launch (2 launches per progressive-fusion block with split16_chain).
  * key "conv1x1" = "split16" (default: streaming kernel on the f16 pipe, exactly split fp32 operands) | "stream" (streaming f32-MFMA
  *                 kernel) | "tiled" (conv_mfma.hip).
  * key "nonlocal" (fp32 precision only) = "auto" (default: "split16" from 1024 keys, "f32" below) | "f32" (f32 MFMA, nonlocal.hip) |
@@ -243,6 +246,13 @@ int pfnl_op_conv3x3_bf16(const uint16_t* in, const float* kernel_host, const flo
  * product).  Same contract as pfnl_op_conv3x3_winograd (any H, W); out may alias resid. */
 int pfnl_op_conv3x3_split16(const float* in, const float* kernel_host, const float* bias_host, const float* addend, int add_div,
                             const float* resid, float* out, int items, int H, int W, int act, void* stream);
+/* conv1_i + conv10_i of a progressive-fusion block as ONE launch of the fp32 path (reference model/pfnl.py:66-68;
+ * conv3x3_c1c10_kernel, option split16_c10): in [clips*T,H,W,64] fp32 (device) -> out1 = lrelu(conv3x3(in; k1) + b1) per frame,
+ * base = lrelu(conv1x1(concat_t out1; k10) + b10) [clips,H,W,64]; k1_host HWIO [3,3,64,64], k10_host HWIO [1,1,64T,64].  The kernel
+ * writes both results in the split format; the hook returns them as fp32 (hi + lo' 2^-11). */
+int pfnl_op_conv1_conv10_split16(const float* in, const float* k1_host, const float* b1_host, const float* k10_host,
+                                 const float* b10_host, float* out1, float* base, int clips, int frames_per_clip, int H, int W,
+                                 void* stream);
 /* The split-format variants of the split-f16 kernels (pfnl_amd/csrc/conv_split16.h "SF": an activation tensor that only feeds MFMA
  * operands - conv1_i's and conv10_i's outputs, model/pfnl.py:66-68 - is kept as (hi, lo') binary16 pairs, built once by its
  * producer).  fp32 at the hook's interface: conversions bracket the kernel under test.

@@ -76,6 +76,7 @@ SIGNATURES = {
     "pfnl_op_blur_decimate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_selftest_mfma": (_i, [_i]),
     "pfnl_op_nonlocal_embedded": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pfnl_op_conv1_conv10_split16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_nonlocal_block": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv0": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_tail": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -102,7 +102,7 @@ struct pfnl_handle {
     int bf16_nl = 1;                                          // non-local block of precision=bf16: 0 split-bf16 operands (nonlocal_bf16.hip), 1 f16 operands (nonlocal_f16.hip, hi parts; default)
     int nl_algo = 2;                                          // non-local block of the fp32 path: 0 f32 MFMA (nonlocal.hip), 1 split-f16 (nonlocal_f16.hip), 2 auto (1 from N = 1024 keys)
     DevBuf wdev16s;                                           // split-f16 packs of the 3x3 kernels (offsets in 16-bit elements)
-    std::vector<size_t> off16s_c1, off16s_c2a, off16s_c2b, off16s_c10;
+    std::vector<size_t> off16s_c1, off16s_c2a, off16s_c2b, off16s_c10, off16s_c10f;   // (c10f: conv10_i as conv3x3_c1c10_kernel takes it)
     std::vector<size_t> off16s_c2a_sf, off16s_c2b_sf;         // ... with the identity row map conv3x3_sf_kernel takes (conv_sf.hip)
     std::vector<size_t> off16m_c1, off16m_c10, off16m_c2;     // small-shape packs (conv_small.hip), in the same blob
     size_t off16m_m1 = 0;
@@ -116,6 +116,7 @@ struct pfnl_handle {
     long long range_reruns = 0;
     int small_mode = 0;                                       // option small=auto|on|off: the small-shape trunk kernels (auto: when a launch has < 256 tiles of 8x32 pixels)
     bool sf_chain = true;                                     // ... and conv2_i is ONE launch (option split16_chain=on|off)
+    bool sf_c10 = true;                                       // ... and conv1_i + conv10_i are ONE launch (option split16_c10=on|off)
     bool sf_path = true;                                      // option split16_sf=on|off: with conv3x3 = conv1x1 = split16, conv1_i and conv10_i write the
                                                               // split format (conv_split16.h) and both halves of conv2_i read it by LDS-DMA (conv_sf.hip)
 
@@ -436,7 +437,19 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             }
             continue;
         }
-        {   // conv1_i: per frame 3x3 64->64 + lrelu                       (:66)
+        const bool c10_fused = sf && h->sf_c10;
+        if (c10_fused) {
+            // conv1_i AND conv10_i in one launch (conv_split16.hip, conv3x3_c1c10_kernel): per (clip, tile) the T frame tiles of conv1_i
+            // leave as split-format lines through LDS, where conv10_i picks them up as MFMA operands; inp1 is written, never read back
+            ProfScope ps(h, s, PFNL_K_CONV3X3);
+            const uint16_t* const w16s = reinterpret_cast<const uint16_t*>(h->wdev16s.p);
+            ConvSplitParams q{h->inp0.p, w16s + h->off16s_c1[i], wd + h->off_c1_b[i], nullptr, nullptr, h->inp1.p, H, W, F, T, 1};
+            q.wpack2 = w16s + h->off16s_c10f[i];
+            q.bias2 = wd + h->off_c10_b[i];
+            q.out2 = h->base.p;
+            HIPCHK(launch_conv3x3_c1c10(q, s));
+        }
+        if (!c10_fused) {   // conv1_i: per frame 3x3 64->64 + lrelu                       (:66)
             ProfScope ps(h, s, PFNL_K_CONV3X3);
             p.in = h->inp0.p;
             p.wpack = wd + h->off_c1_w[i];
@@ -461,7 +474,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
                 HIPCHK(launch_conv_mfma(p, 3, F, s));
             }
         }
-        {   // conv10_i: 1x1 over the concat of T frames -> base + lrelu    (:67-68)
+        if (!c10_fused) {   // conv10_i: 1x1 over the concat of T frames -> base + lrelu    (:67-68)
             ProfScope ps(h, s, PFNL_K_CONV1X1);
             p.in = h->inp1.p;
             p.wpack = wd + h->off_c10_w[i];
@@ -646,6 +659,7 @@ int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
     h->cfg = *cfg;
     if (const char* e = std::getenv("PFNL_SMALL")) h->small_mode = std::string(e) == "on" ? 1 : (std::string(e) == "off" ? 2 : 0);   // (A/B runs)
     if (const char* e = std::getenv("PFNL_SF_CHAIN")) h->sf_chain = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
+    if (const char* e = std::getenv("PFNL_SF_C10")) h->sf_c10 = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_SPLIT16_SF")) h->sf_path = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_CONV3X3")) {
         const std::string v(e);
@@ -769,6 +783,12 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         if (v == "on") h->sf_chain = true;
         else if (v == "off") h->sf_chain = false;
         else return fail(PFNL_ERR_INVALID, "split16_chain must be on or off");
+        return 0;
+    }
+    if (k == "split16_c10") {
+        if (v == "on") h->sf_c10 = true;
+        else if (v == "off") h->sf_c10 = false;
+        else return fail(PFNL_ERR_INVALID, "split16_c10 must be on or off");
         return 0;
     }
     if (k == "split16_sf") {
@@ -1017,9 +1037,11 @@ int pfnl_finalize_weights(pfnl_handle* h) {
         h->off16s_c10.assign(nb, 0);
         h->off16s_c2a_sf.assign(nb, 0);
         h->off16s_c2b_sf.assign(nb, 0);
-        h->off16s_m1 = (size_t)nb * (5 * n3 + n1);
+        const size_t blk = 5 * n3 + n1 + pfnl::conv1x1_c10_pack_halfs(T);
+        h->off16s_c10f.assign(nb, 0);
+        h->off16s_m1 = (size_t)nb * blk;
         const size_t m3 = pfnl::conv_small_pack_halfs(3, 1), m10 = pfnl::conv_small_pack_halfs(1, T);
-        const size_t small_base = (size_t)nb * (5 * n3 + n1) + (size_t)T * n3;
+        const size_t small_base = (size_t)nb * blk + (size_t)T * n3;
         h->off16m_c1.assign(nb, 0);
         h->off16m_c10.assign(nb, 0);
         h->off16m_c2.assign(nb, 0);
@@ -1030,12 +1052,14 @@ int pfnl_finalize_weights(pfnl_handle* h) {
             pfnl::conv3x3_split16_pack_weights(W("convmerge1").data(), 64 * T, 64 * f, &b16[h->off16s_m1 + (size_t)f * n3], 48);
         for (int i = 0; i < nb; ++i) {
             const std::string s = std::to_string(i);
-            h->off16s_c1[i] = (size_t)i * (5 * n3 + n1);
+            h->off16s_c1[i] = (size_t)i * blk;
             h->off16s_c2a[i] = h->off16s_c1[i] + n3;
             h->off16s_c2b[i] = h->off16s_c1[i] + 2 * n3;
             h->off16s_c10[i] = h->off16s_c1[i] + 3 * n3;
             h->off16s_c2a_sf[i] = h->off16s_c10[i] + n1;
             h->off16s_c2b_sf[i] = h->off16s_c2a_sf[i] + n3;
+            h->off16s_c10f[i] = h->off16s_c2b_sf[i] + n3;
+            pfnl::conv1x1_c10_pack_weights(W("conv10_" + s).data(), T, &b16[h->off16s_c10f[i]]);
             pfnl::conv3x3_split16_pack_weights(W("conv2_" + s).data(), 128, 0, &b16[h->off16s_c2a_sf[i]], 64, true);
             pfnl::conv3x3_split16_pack_weights(W("conv2_" + s).data(), 128, 64, &b16[h->off16s_c2b_sf[i]], 64, true);
             h->off16m_c1[i] = small_base + (size_t)i * (3 * m3 + m10);
@@ -1756,6 +1780,42 @@ int pfnl_op_conv3x3_split16_sf(int which, const float* in, const float* kernel_h
     (void)hipFree(dw);
     (void)hipFree(tmp);
     if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv3x3 split16 SF op: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// conv1_i + conv10_i as ONE launch (conv3x3_c1c10_kernel): in fp32 [clips*T][H][W][64] -> out1 = inp1 [clips*T][H][W][64], base [clips][H][W][64];
+// the kernel writes both in the split format, the hook hands them back as fp32 (hi + lo' 2^-11: what the consumers' MFMAs see)
+int pfnl_op_conv1_conv10_split16(const float* in, const float* k1_host, const float* b1_host, const float* k10_host,
+                                 const float* b10_host, float* out1, float* base, int clips, int frames_per_clip, int H, int W,
+                                 void* stream) {
+    if (!in || !k1_host || !k10_host || !out1 || !base) return fail(PFNL_ERR_INVALID, "NULL argument");
+    const int T = frames_per_clip;
+    if (clips < 1 || T < 1 || T > 7 || H < 1 || W < 1) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n3 = pfnl::conv3x3_split16_pack_halfs(), n1 = pfnl::conv1x1_c10_pack_halfs(T);
+    std::vector<uint16_t> pack(n3 + n1 + 256, 0);
+    pfnl::conv3x3_split16_pack_weights(k1_host, 64, 0, pack.data());
+    pfnl::conv1x1_c10_pack_weights(k10_host, T, pack.data() + n3);
+    if (b1_host) std::memcpy(&pack[n3 + n1], b1_host, 64 * sizeof(float));
+    if (b10_host) std::memcpy(&pack[n3 + n1 + 128], b10_host, 64 * sizeof(float));
+    const size_t np1 = (size_t)clips * T * H * W, npb = (size_t)clips * H * W;
+    uint16_t *dw = nullptr, *t1 = nullptr, *tb = nullptr;
+    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(uint16_t)));
+    hipError_t e = hipMalloc(&t1, np1 * 256);
+    if (e == hipSuccess) e = hipMalloc(&tb, npb * 256);
+    if (e == hipSuccess) e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    pfnl::ConvSplitParams q{in, dw, reinterpret_cast<const float*>(dw + n3 + n1), nullptr, nullptr, reinterpret_cast<float*>(t1), H, W, clips * T, T, 1};
+    q.wpack2 = dw + n3;
+    q.bias2 = reinterpret_cast<const float*>(dw + n3 + n1 + 128);
+    q.out2 = reinterpret_cast<float*>(tb);
+    if (e == hipSuccess) e = pfnl::launch_conv3x3_c1c10(q, s);
+    if (e == hipSuccess) e = pfnl::launch_sf_to_f32(t1, out1, np1, s);
+    if (e == hipSuccess) e = pfnl::launch_sf_to_f32(tb, base, npb, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dw);
+    (void)hipFree(t1);
+    (void)hipFree(tb);
+    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv1+conv10 split16 op: ") + hipGetErrorString(e));
     return 0;
 }
 

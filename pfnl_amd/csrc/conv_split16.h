@@ -17,7 +17,9 @@ struct ConvSplitParams {
     int accum;               // 1: out[items/add_div] = act(sum over the add_div frames of an item group + bias); wpack = add_div packs (convmerge1)
     int out_sf;              // 1 (plain mode only): `out` is written in the split format below instead of fp32
     const float* in2;        // launch_conv3x3_sf_chain only: `base` [items/add_div][H][W] in the split format (the shared half's input)
-    const uint16_t* wpack2;  // ... and the packed kernel rows that multiply it (identity rows)
+    const uint16_t* wpack2;  // ... and the packed kernel rows that multiply it (identity rows); launch_conv3x3_c1c10: conv10_i (conv1x1_c10_pack_weights)
+    const float* bias2;      // launch_conv3x3_c1c10 only: conv10_i's bias [64]
+    float* out2;             // ... and its output `base` [items/add_div][H][W] in the split format
 };
 
 // THE SPLIT FORMAT ("SF") of an activation tensor that only ever feeds MFMA operands (conv1_i's output, conv10_i's output):
@@ -29,6 +31,12 @@ hipError_t launch_conv3x3_split16(const ConvSplitParams& p, hipStream_t s);
 size_t conv3x3_split16_pack_halfs();                                  // 16-bit elements per packed 3x3 64->64 kernel
 void conv3x3_split16_pack_weights(const float* hwio, int cin_total, int cin_begin, uint16_t* dst, int cout = 64,   // cout < 64: zero-padded
                                   bool identity_rows = false);        // true: the pack conv3x3_sf_kernel takes
+
+// conv1_i + conv10_i of a progressive-fusion block in one launch (reference model/pfnl.py:66-68): in fp32 [clips*T][H][W][64], add_div = T;
+// out = inp1 and out2 = base, both in the split format; act applies to both convolutions
+hipError_t launch_conv3x3_c1c10(const ConvSplitParams& p, hipStream_t s);
+size_t conv1x1_c10_pack_halfs(int T);
+void conv1x1_c10_pack_weights(const float* hwio, int T, uint16_t* dst);
 
 // 3x3 64->64 with the INPUT in the split format (conv_sf.hip): halo tiles by LDS-DMA, epilogue from registers.  `in` points at SF
 // data ([items][H][W] x 256 B); wpack = conv3x3_split16_pack_weights(..., identity_rows = true); plain and fused (addend + resid) modes.

@@ -694,6 +694,394 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
 #undef CS_TILE
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// conv1_i AND conv10_i of a progressive-fusion block in ONE launch (reference model/pfnl.py:66-68): a chain = the T frames of a
+// clip at one spatial tile.  Every frame tile is conv1_i as above (fp32 halo through registers, split on the way into LDS, the
+// same unit / sub-step / weight-slice pipeline); what changes is what happens to a finished tile:
+//   * it is not parked in registers for an epilogue spread over the next tile (32 registers) - it leaves at once, in a short SERIAL
+//     phase: bias (initial C) + leaky-relu + split in registers -> the unit's own halo buffer, free at that point, as 128 pixel lines
+//     of the split format (one output row of each of the 4 row pairs; two passes), from where
+//       - whole 256-byte lines go to HBM (`out`: inp1 in the split format, what conv2_i's chain kernel reads by LDS-DMA), and
+//       - the lines come back as the B operands (k = channel, n = pixel) of conv10_i's slice of this frame, W10[64 f .. 64 f + 63][:],
+//         whose A operands (32 output channels x 16 input channels, hi / lo') stream from L2 into registers: 12 MFMAs per pass and
+//         wave (K = 64) into `base_m`, the 32 registers the parked tile used to take, which run through the T frames of the chain;
+//   * behind the chain's last frame `base_m` (+ bias: its initial value) takes the same road - leaky-relu, split, lines - to `out2`.
+// conv10_i as a launch of its own read inp1 (117 MB at configs[1]) back for 11 % of conv1_i's MFMAs; here it reads nothing.
+// The serial phase costs ~2.5 k cycles per tile (two passes x [80 VALU, 4 ds_write_b128, barrier, 8 ds_read_b128 + 12 MFMAs,
+// 4 line pieces]) of ~28 k.
+constexpr int K1_LDS_BYTES = CS_LDS_BYTES + 64 * 4;                 // + conv10_i's bias
+
+__global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_smem[];
+    unsigned char* const wl = cs_smem + 2 * CS_TILE_BYTES;
+    float* const bl = reinterpret_cast<float*>(cs_smem + 2 * CS_TILE_BYTES + CS_W_BYTES);
+    float* const bl2 = bl + 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rp = wave >> 1;                                       // rows 2rp, 2rp+1 of the tile
+    const int mt = wave & 1;                                        // output channels 32mt .. 32mt+31 (of conv1_i and of conv10_i)
+    const int H = p.H, W = p.W;
+    const int tiles_x = (W + CS_TW - 1) / CS_TW, tiles_y = (H + CS_TH - 1) / CS_TH;
+    const int per_item = tiles_x * tiles_y;
+    const int item_bytes = H * W * 256;
+    const int gT = p.add_div;                                       // frames per clip = tiles per chain
+    const int nchains = per_item * (p.items / gT);
+    const int xcd = blockIdx.x & 7, xj = blockIdx.x >> 3, cpx = gridDim.x >> 3;
+    const int per_xcd = (nchains + 7) >> 3;
+    const int cbeg = xcd * per_xcd;
+    const int ccnt = min(per_xcd, nchains - cbeg);
+    if (xj >= ccnt) return;
+    const int nt = ((ccnt - xj + cpx - 1) / cpx) * gT;              // tiles of this workgroup
+#define K1_TILE(k_, item_, y0_, x0_)                                                             \
+    do {                                                                                         \
+        const int ci_ = (k_) / gT, f_ = (k_) - ci_ * gT;                                         \
+        const int ch_ = cbeg + xj + ci_ * cpx;                                                   \
+        const int cl_ = ch_ / per_item;                                                          \
+        const int sp_ = ch_ - cl_ * per_item;                                                    \
+        item_ = cl_ * gT + f_;                                                                   \
+        const int ty_ = sp_ / tiles_x;                                                           \
+        y0_ = ty_ * CS_TH;                                                                       \
+        x0_ = (sp_ - ty_ * tiles_x) * CS_TW;                                                     \
+    } while (0)
+
+    u32x4 w0reg[CS_W_BYTES / 16 / CS_THREADS];
+#pragma unroll
+    for (int k = 0; k < CS_W_BYTES / 16 / CS_THREADS; ++k) w0reg[k] = reinterpret_cast<const u32x4*>(p.wpack)[k * CS_THREADS + tid];
+    const float bias_r = tid < 64 ? p.bias[tid] : (tid < 128 ? p.bias2[tid - 64] : 0.f);
+
+    int grel[CS_ITERS], lpk[CS_ITERS];                              // staging map: as conv3x3_split16_kernel
+    const int wbytes = W * 256;
+#pragma unroll
+    for (int k = 0; k < CS_ITERS; ++k) {
+        const int id = min(k * CS_THREADS + tid, CS_PIECES - 1);
+        const int pix = id >> 3, c = id & 7;
+        const int py = pix / CS_IW, px = pix - py * CS_IW;
+        grel[k] = py * wbytes + px * 256 + c * 16;
+        lpk[k] = ((py * CS_IW + px) * 128 + 8 * (c & 1) + (((c >> 1) ^ ((px >> 1) & 7)) << 4)) | (py << 16) | (px << 24);
+    }
+    const float nscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -CS_SCALE)));
+    f32x4 stg[CS_ITERS];
+#define K1_REQUEST_ALL(rs_, org_, interior_, y0_, x0_)                                           \
+    do {                                                                                         \
+        _Pragma("unroll") for (int k_ = 0; k_ < CS_ITERS; ++k_) {                                \
+            const int gy_ = (y0_) + ((lpk[k_] >> 16) & 0xff) - 1, gx_ = (x0_) + ((unsigned)lpk[k_] >> 24) - 1; \
+            const bool in_ = (interior_) || ((unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W); \
+            stg[k_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, in_ ? (org_) + grel[k_] : 0x7fffffff, 0, CS_HALO_AUX)); \
+        }                                                                                        \
+    } while (0)
+#define K1_COMMIT1(k_, buf_)                                                                     \
+    do {                                                                                         \
+        u32x2 hi_, lo2_;                                                                         \
+        split4(stg[k_], hi_, lo2_, nscale);                                                      \
+        const int lo_ = lpk[k_] & 0xffff;                                                        \
+        *reinterpret_cast<u32x2*>(cs_smem + (buf_) * CS_TILE_BYTES + lo_) = hi_;                 \
+        *reinterpret_cast<u32x2*>(cs_smem + (buf_) * CS_TILE_BYTES + (lo_ ^ 64)) = lo2_;         \
+    } while (0)
+
+    int paddr[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int col = (lane & 31) + kx;
+        paddr[kx] = ((2 * rp) * CS_IW + col) * 128 + ((((lane >> 5)) ^ ((col >> 1) & 7)) << 4);
+    }
+    const int lo_xor = 4 << 4;
+    const unsigned char* const wlane = wl + mt * 2048 + lane * 16;
+    const int kh = lane >> 5;
+    const int ech = 32 * mt + 16 * kh;                              // register r of a lane = channel ech + r (both convolutions)
+    f32x16 accm[2], accc[2], base_m[2];                             // [output row]: hi.hi / cross products (x 2^11) of conv1_i; conv10_i of the chain
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            accm[n][r] = 0.f;
+            accc[n][r] = 0.f;
+        }
+    const float slope = p.act ? 0.2f : 1.0f;
+
+    u32x4 wnx[CS_WITERS];
+    auto w_request = [&](int half, int slot) __attribute__((always_inline)) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(p.wpack) + (size_t)half * (CS_W_BYTES / 16) + slot * (CS_SLOT_BYTES / 16);
+#pragma unroll
+        for (int k = 0; k < CS_WITERS; ++k) wnx[k] = src[k * CS_THREADS + tid];
+    };
+    auto w_write = [&](int slot) __attribute__((always_inline)) {
+        u32x4* dst = reinterpret_cast<u32x4*>(wl + slot * CS_SLOT_BYTES);
+#pragma unroll
+        for (int k = 0; k < CS_WITERS; ++k) dst[k * CS_THREADS + tid] = wnx[k];
+    };
+#define K1_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+    // ---- a finished row (n) of the workgroup's tile: leaky-relu, split, 128 pixel lines in `scratch`; optionally conv10_i's
+    // products of those lines; the lines to HBM.  Pixel slot pp = row pair * 32 + column; 16-byte chunk c of a line (conv_split16.h:
+    // c = 8 M + 4 part + channel group) sits in slot c ^ (pp & 15): conflict-free for the dump (lanes = consecutive pixels, one
+    // chunk), for the operand reads (the same) and for the line read-back (16 lanes = the 16 chunks of one pixel).
+    unsigned char* const scratch = cs_smem + CS_TILE_BYTES;         // unit B's halo buffer: free behind the tile's closing barrier
+    auto emit_row = [&](f32x16 v, int n, float* dst_item, int ey0, int ex0, auto mm, const u32x4 (&w10)[8]) __attribute__((always_inline)) {
+        constexpr bool MM = decltype(mm)::value;
+        u32x2 hi[4], lo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 t = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            const f32x4 st = t * slope;
+            asm("v_max_f32 %0, %1, %2" : "=v"(t.x) : "v"(t.x), "v"(st.x));
+            asm("v_max_f32 %0, %1, %2" : "=v"(t.y) : "v"(t.y), "v"(st.y));
+            asm("v_max_f32 %0, %1, %2" : "=v"(t.z) : "v"(t.z), "v"(st.z));
+            asm("v_max_f32 %0, %1, %2" : "=v"(t.w) : "v"(t.w), "v"(st.w));
+            split4(t, hi[q], lo[q], nscale);
+        }
+        const int pp = rp * 32 + (lane & 31);
+        const int sw = pp & 15;
+        unsigned char* const pl = scratch + pp * 256;
+        const int c0 = 8 * mt + 2 * kh;                             // hi chunk of channels ech .. ech+7; +1: ech+8 .. +15; +4: the lo' chunks
+        *reinterpret_cast<u32x4*>(pl + ((c0 ^ sw) << 4)) = u32x4{hi[0].x, hi[0].y, hi[1].x, hi[1].y};
+        *reinterpret_cast<u32x4*>(pl + (((c0 + 1) ^ sw) << 4)) = u32x4{hi[2].x, hi[2].y, hi[3].x, hi[3].y};
+        *reinterpret_cast<u32x4*>(pl + (((c0 + 4) ^ sw) << 4)) = u32x4{lo[0].x, lo[0].y, lo[1].x, lo[1].y};
+        *reinterpret_cast<u32x4*>(pl + (((c0 + 5) ^ sw) << 4)) = u32x4{lo[2].x, lo[2].y, lo[3].x, lo[3].y};
+        K1_BARRIER();                                               // the 128 lines are complete
+        u32x4 pc[4];                                                // this thread's 4 line pieces (piece id = i * 512 + tid: pixel id >> 4, chunk id & 15)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = i * CS_THREADS + tid, ppx = id >> 4, c = id & 15;
+            pc[i] = *reinterpret_cast<const u32x4*>(scratch + ppx * 256 + ((c ^ (ppx & 15)) << 4));
+        }
+        if constexpr (MM) {
+            // conv10_i, frame f: base_m[n][cout][pixel] += W10_f[cout][k] X[k][pixel], k-step q = (M, h): channels 32 M + 16 kh + 8 h + e
+            f32x16 cross;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cross[r] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cb = 8 * (q >> 1) + 2 * kh + (q & 1);
+                const h8 bh = *reinterpret_cast<const h8*>(pl + ((cb ^ sw) << 4));
+                const h8 bo = *reinterpret_cast<const h8*>(pl + (((cb + 4) ^ sw) << 4));
+                const h8 ah = __builtin_bit_cast(h8, w10[2 * q]), ao = __builtin_bit_cast(h8, w10[2 * q + 1]);
+                base_m[n] = mfma_f16(ah, bh, base_m[n]);
+                cross = mfma_f16(ao, bh, cross);
+                cross = mfma_f16(ah, bo, cross);
+            }
+            base_m[n] += cross * CS_ISCALE;
+        }
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(dst_item, 0, item_bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = i * CS_THREADS + tid, ppx = id >> 4, c = id & 15;
+            const int gy = ey0 + 2 * (ppx >> 5) + n, gx = ex0 + (ppx & 31);   // rows past the image: past the end of the resource
+            buffer_store_b128_guarded<CS_STORE_AUX>(pc[i], rsO, gx < W ? (gy * W + gx) * 256 + c * 16 : 0x7fffffff, 0);
+        }
+    };
+
+    // ---- prologue: halo of unit 0 -> buffer 0; weights of half 0, both biases -> LDS ----------------------------------------
+    int c_item, c_y0, c_x0, n_item, n_y0, n_x0;
+    K1_TILE(0, c_item, c_y0, c_x0);
+    n_item = c_item;
+    n_y0 = c_y0;
+    n_x0 = c_x0;
+    {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.in) + (size_t)c_item * H * W * 64, 0, item_bytes, 0x00020000);
+        const int org = ((c_y0 - 1) * W + c_x0 - 1) * 256;          // (unit 0: channel half 0)
+        const bool interior = c_y0 > 0 && c_y0 + CS_IH - 1 <= H && c_x0 > 0 && c_x0 + CS_IW - 1 <= W;
+        K1_REQUEST_ALL(rs, org, interior, c_y0, c_x0);
+#pragma unroll
+        for (int k = 0; k < CS_W_BYTES / 16 / CS_THREADS; ++k) reinterpret_cast<u32x4*>(wl)[k * CS_THREADS + tid] = w0reg[k];
+        if (tid < 128) bl[tid] = bias_r;                            // (bl2 = bl + 64)
+#pragma unroll
+        for (int k = 0; k < CS_ITERS; ++k) K1_COMMIT1(k, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) base_m[n][r] = bl2[ech + r];   // conv10_i's bias: the initial value of a chain's sum
+
+    int fch = 0;                                                    // frame of the chain the current tile is
+    for (int kt = 0; kt < nt; ++kt) {
+        const int half_a = kt & 1;
+        auto unit = [&](auto par) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par)::value;
+            constexpr int cb = PAR;
+            const unsigned char* const tile = cs_smem + cb * CS_TILE_BYTES;
+            h8 X[4][2], Wv[2][2];
+#define CS_PX(g_, r_, part_) (*reinterpret_cast<const h8*>(tile + (paddr[(g_) >> 1] ^ (((part_) ? lo_xor : 0) | (((g_) & 1) << 5))) + (r_) * (CS_IW * 128)))
+#define CS_WT(g_, ky_, part_) (*reinterpret_cast<const h8*>(wlane + (((g_) * 3 + (ky_)) << 12) + ((part_) << 10)))
+            X[0][0] = CS_PX(0, 0, 0);
+            X[0][1] = CS_PX(0, 0, 1);
+            X[1][0] = CS_PX(0, 1, 0);
+            X[1][1] = CS_PX(0, 1, 1);
+            Wv[0][0] = CS_WT(0, 0, 0);
+            Wv[0][1] = CS_WT(0, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PAR == 0) w_request(half_a ^ 1, 0);
+            // the NEXT unit's halo: unit A asks for the other half of ITS tile, unit B for the first half of the next tile
+            const int q_item = PAR == 0 ? c_item : n_item, y0q = PAR == 0 ? c_y0 : n_y0, x0q = PAR == 0 ? c_x0 : n_x0;
+            const int q_half = half_a ^ 1;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.in) + (size_t)q_item * H * W * 64, 0, item_bytes, 0x00020000);
+            const int org = ((y0q - 1) * W + x0q - 1) * 256 + q_half * 128;
+            const bool interior = y0q > 0 && y0q + CS_IH - 1 <= H && x0q > 0 && x0q + CS_IW - 1 <= W;
+            K1_REQUEST_ALL(rs, org, interior, y0q, x0q);
+            [[maybe_unused]] f32x16 bias16;
+            if constexpr (PAR == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + ech + 4 * q);
+                    bias16[4 * q] = b4.x;
+                    bias16[4 * q + 1] = b4.y;
+                    bias16[4 * q + 2] = b4.z;
+                    bias16[4 * q + 3] = b4.w;
+                }
+            }
+            auto substep = [&](auto sc) __attribute__((always_inline)) {
+                constexpr int S = decltype(sc)::value;
+                constexpr int g = S / 3, ky = S % 3;
+                if constexpr (ky == 0) {
+                    if constexpr (g == 1 && PAR == 1) w_write(2);
+                    if constexpr (g == 2) K1_BARRIER();             // b0: column tap 0 of the weights consumed
+                    if constexpr (g == 3 && PAR == 0) {
+                        w_write(0);
+                        w_request(half_a ^ 1, 1);
+                        const int kn = min(kt + 1, nt - 1);         // decode the next tile (past the end: this one again - a harmless re-read)
+                        K1_TILE(kn, n_item, n_y0, n_x0);
+                    }
+                    if constexpr (g == 4) {
+                        K1_BARRIER();                               // b1: column tap 1 consumed
+#pragma unroll
+                        for (int k = 0; k < CS_ITERS; ++k) asm volatile("" : "+v"(lpk[k]));
+#pragma unroll
+                        for (int k = 0; k < CS_ITERS / 2; ++k) K1_COMMIT1(k, cb ^ 1);
+                    }
+                    if constexpr (g == 5) {
+#pragma unroll
+                        for (int k = CS_ITERS / 2; k < CS_ITERS; ++k) K1_COMMIT1(k, cb ^ 1);
+                        if constexpr (PAR == 0) {
+                            w_write(1);
+                            w_request(half_a ^ 1, 2);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (S < 17) {
+                    constexpr int S1 = S + 1, g1 = S1 / 3, ky1 = S1 % 3;
+                    Wv[S1 & 1][0] = CS_WT(g1, ky1, 0);
+                    Wv[S1 & 1][1] = CS_WT(g1, ky1, 1);
+                    if constexpr (ky1 == 0) {
+                        X[0][0] = CS_PX(g1, 0, 0);
+                        X[0][1] = CS_PX(g1, 0, 1);
+                        X[1][0] = CS_PX(g1, 1, 0);
+                        X[1][1] = CS_PX(g1, 1, 1);
+                    } else {
+                        X[ky1 + 1][0] = CS_PX(g1, ky1 + 1, 0);
+                        X[ky1 + 1][1] = CS_PX(g1, ky1 + 1, 1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const h8 wh = Wv[S & 1][0], wo = Wv[S & 1][1];
+                if constexpr (PAR == 0 && S == 0) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    accm[0] = mfma_f16(wh, X[ky][0], bias16);
+                    accm[1] = mfma_f16(wh, X[ky + 1][0], bias16);
+                    accc[0] = mfma_f16(wo, X[ky][0], zero);
+                    accc[1] = mfma_f16(wo, X[ky + 1][0], zero);
+                } else {
+                    accm[0] = mfma_f16(wh, X[ky][0], accm[0]);
+                    accm[1] = mfma_f16(wh, X[ky + 1][0], accm[1]);
+                    accc[0] = mfma_f16(wo, X[ky][0], accc[0]);
+                    accc[1] = mfma_f16(wo, X[ky + 1][0], accc[1]);
+                }
+                accc[0] = mfma_f16(wh, X[ky][1], accc[0]);
+                accc[1] = mfma_f16(wh, X[ky + 1][1], accc[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            substep(std::integral_constant<int, 0>{});
+            substep(std::integral_constant<int, 1>{});
+            substep(std::integral_constant<int, 2>{});
+            substep(std::integral_constant<int, 3>{});
+            substep(std::integral_constant<int, 4>{});
+            substep(std::integral_constant<int, 5>{});
+            substep(std::integral_constant<int, 6>{});
+            substep(std::integral_constant<int, 7>{});
+            substep(std::integral_constant<int, 8>{});
+            substep(std::integral_constant<int, 9>{});
+            substep(std::integral_constant<int, 10>{});
+            substep(std::integral_constant<int, 11>{});
+            substep(std::integral_constant<int, 12>{});
+            substep(std::integral_constant<int, 13>{});
+            substep(std::integral_constant<int, 14>{});
+            substep(std::integral_constant<int, 15>{});
+            substep(std::integral_constant<int, 16>{});
+            substep(std::integral_constant<int, 17>{});
+#undef CS_PX
+#undef CS_WT
+            if constexpr (PAR == 1) {
+                // conv10_i's A operands of this frame: [f][k-step q][g = mt][hi / lo'][lane] x 16 B, requested before the closing barrier
+                u32x4 w10[8];
+                {
+                    const u32x4* src = reinterpret_cast<const u32x4*>(p.wpack2) + ((size_t)fch * 16 + 2 * mt) * 64 + lane;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        w10[2 * q] = src[(4 * q) * 64];
+                        w10[2 * q + 1] = src[(4 * q + 1) * 64];
+                    }
+                }
+                K1_BARRIER();                                       // b2: this unit's buffer (the scratch) is free, the next unit's is complete
+                float* const dst = p.out + (size_t)c_item * H * W * 64;
+                emit_row(accm[0] + accc[0] * CS_ISCALE, 0, dst, c_y0, c_x0, std::true_type{}, w10);
+                K1_BARRIER();                                       // the lines of row 0 are read
+                emit_row(accm[1] + accc[1] * CS_ISCALE, 1, dst, c_y0, c_x0, std::true_type{}, w10);
+                const bool last = fch + 1 == gT;                    // (wave-uniform)
+                if (last) {                                         // the chain's sum -> `base` (out2), and back to its initial value
+                    float* const dstb = p.out2 + (size_t)(c_item / gT) * H * W * 64;
+                    K1_BARRIER();
+                    emit_row(base_m[0], 0, dstb, c_y0, c_x0, std::false_type{}, w10);
+                    K1_BARRIER();
+                    emit_row(base_m[1], 1, dstb, c_y0, c_x0, std::false_type{}, w10);
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) base_m[n][r] = bl2[ech + r];
+                }
+                fch = last ? 0 : fch + 1;
+                c_item = n_item;
+                c_y0 = n_y0;
+                c_x0 = n_x0;
+                // (no barrier here: the scratch is next written by the halo commit of the coming unit, behind two of its barriers)
+            } else {
+                K1_BARRIER();                                       // b2
+            }
+        };
+        unit(std::integral_constant<int, 0>{});
+        unit(std::integral_constant<int, 1>{});
+    }
+#undef K1_TILE
+#undef K1_REQUEST_ALL
+#undef K1_COMMIT1
+#undef K1_BARRIER
+}
+
+hipError_t launch_conv3x3_c1c10(const ConvSplitParams& p, hipStream_t s) {
+    if (!p.in || !p.wpack || !p.bias || !p.wpack2 || !p.bias2 || !p.out || !p.out2 || p.items < 1 || p.H < 1 || p.W < 1) return hipErrorInvalidValue;
+    if (p.add_div < 1 || p.add_div > 7 || p.items % p.add_div || p.addend || p.resid || p.accum) return hipErrorInvalidValue;
+    if ((long long)p.H * p.W * 256 >= 0x7fffffffLL) return hipErrorInvalidValue;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    static int ncu[64] = {};
+    if (!ncu[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        ncu[dev] = prop.multiProcessorCount;
+    }
+    const int grid = ncu[dev] >= 8 ? ncu[dev] / 8 * 8 : 8;
+    static bool attr_dev[64] = {};
+    if (!attr_dev[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c1c10_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, K1_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_dev[dev] = true;
+    }
+    hipLaunchKernelGGL(conv3x3_c1c10_kernel, dim3(grid), dim3(CS_THREADS), K1_LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv3x3_split16(const ConvSplitParams& p, hipStream_t s) {
     if (!p.in || !p.wpack || !p.bias || !p.out || p.items < 1 || p.H < 1 || p.W < 1) return hipErrorInvalidValue;
     if ((p.addend == nullptr) != (p.resid == nullptr) || (p.addend && (p.add_div < 1 || p.items % p.add_div))) return hipErrorInvalidValue;
@@ -761,6 +1149,28 @@ void conv3x3_split16_pack_weights(const float* hwio, int cin_total, int cin_begi
                                 dst[base + lane * 8 + e] = f16_bits((float)hi);
                                 dst[base + 512 + lane * 8 + e] = f16_bits(lo);
                             }
+}
+
+size_t conv1x1_c10_pack_halfs(int T) { return (size_t)T * 8192; }      // 16 KB per frame
+
+// conv10_i for conv3x3_c1c10_kernel: HWIO [1,1,T*64,64] -> [f][k-step q = 2M + h][g][part][lane][e] =
+// W[f*64 + 32M + 16(lane>>5) + 8h + e][32g + row_channel(lane&31)] (the A operand: MFMA row -> channel as in the 3x3 packs, so that a lane
+// of the result holds 16 consecutive channels), part 0 = f16(w), part 1 = f16((w - hi) 2^11)
+void conv1x1_c10_pack_weights(const float* hwio, int T, uint16_t* dst) {
+    for (int f = 0; f < T; ++f)
+        for (int q = 0; q < 4; ++q)
+            for (int g = 0; g < 2; ++g)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int ci = f * 64 + 32 * (q >> 1) + 16 * (lane >> 5) + 8 * (q & 1) + e;
+                        const int co = 32 * g + split_row_channel(lane & 31);
+                        const float w = hwio[(size_t)ci * 64 + co];
+                        const _Float16 hi = (_Float16)w;
+                        const float lo = (w - (float)hi) * CS_SCALE;
+                        const size_t base = (((((size_t)f * 4 + q) * 2 + g) * 2) * 64 + lane) * 8 + e;
+                        dst[base] = f16_bits((float)hi);
+                        dst[base + 512] = f16_bits(lo);
+                    }
 }
 
 }  // namespace pfnl

@@ -311,6 +311,23 @@ def nonlocal_embedded(x, wg, bg, ww, bw, wt, bt, wp, bp):
     return out
 
 
+def conv1_conv10_split16(x, k1, b1, k10, b10, frames_per_clip: int):
+    """conv1_i + conv10_i of a progressive-fusion block as one launch (reference model/pfnl.py:66-68): x [clips*T,H,W,64] (cuda) ->
+    (inp1 [clips*T,H,W,64], base [clips,H,W,64]), both activated; k1 HWIO [3,3,64,64], k10 HWIO [1,1,64T,64]."""
+    import torch
+    lib = _capi.load_library()
+    F, H, W, c = x.shape
+    T = int(frames_per_clip)
+    k1h, k10h = _host(k1, "k1"), _host(k10, "k10")
+    if c != 64 or F % T or k1h.size != 9 * 64 * 64 or k10h.size != 64 * T * 64:
+        raise ValueError("conv1_conv10_split16: geometry mismatch")
+    out1 = torch.empty((F, H, W, 64), dtype=torch.float32, device=x.device)
+    base = torch.empty((F // T, H, W, 64), dtype=torch.float32, device=x.device)
+    _capi.check(lib.pfnl_op_conv1_conv10_split16(_req(x, "x"), _hp(k1h), _hp(_host(b1, "b1")), _hp(k10h), _hp(_host(b10, "b10")),
+                                                 _req(out1, "out1"), _req(base, "base"), F // T, T, H, W, _stream(x)))
+    return out1, base
+
+
 def nonlocal_block(x, wg, bg, ww, bw, theta=None, phi=None, nltype: int = 1, sub_sample: int = 1):
     """utils.NonLocalBlock(input_x, out_channels, sub_sample, nltype) in its general form (reference utils.py:18-71) inside the
     wrapper of model/pfnl.py:55-60: x [B,T,H,W,3] (cuda) -> [B,H,W,3T] = stack + depth_to_space(NonLocalBlock(space_to_depth(stack))).

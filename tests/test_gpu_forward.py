@@ -453,6 +453,34 @@ def test_graph_replay_matches_eager():
 # ---- the domain of the f16-pipe kernels (the default fp32 path computes on the f16 matrix pipe with exactly split operands;
 # |activation|, |weight| < 65504, non-local inputs on a [0,1] scale) ------------------------------------------------------------------
 
+@pytest.mark.parametrize("T,scale,nb,B,H,W", [(7, 4, 2, 2, 24, 40), (5, 2, 3, 1, 18, 70), (3, 4, 1, 3, 8, 32)])
+def test_split16_launch_structure_options(T, scale, nb, B, H, W):
+    """The launch structures of the split-f16 trunk - 4 launches per block (fp32 intermediates), split-format intermediates
+    (split16_sf), conv2_i as one launch (split16_chain), conv1_i + conv10_i as one launch (split16_c10; the default: 2 launches per
+    block) - compute the same block: each against the oracle, and against each other to summation-order noise."""
+    geom = PFNLGeometry(num_frames=T, scale=scale, num_block=nb)
+    w = synth.synthetic_weights(geom, seed=T)
+    x = synth.uniform_clips(B, T, H, W, seed=H)
+    ref = pfnl_fast.FastOracle(w, T, scale, nb).forward(x)
+    eng = _engine_with(geom, w)
+    eng.set_option("conv3x3", "split16")
+    eng.profile(1)
+    ys = {}
+    for sf, chain, c10, launches in (("off", "off", "off", (3, 1)), ("on", "off", "off", (3, 1)), ("on", "on", "off", (2, 1)),
+                                     ("on", "off", "on", (3, 0)), ("on", "on", "on", (2, 0))):
+        for k, v in (("split16_sf", sf), ("split16_chain", chain), ("split16_c10", c10)):
+            eng.set_option(k, v)
+        eng.profile_reset()
+        ys[(sf, chain, c10)] = y = eng.forward(x)
+        p = eng.profile_read()
+        assert (p["conv3x3"]["launches"], p["conv1x1"]["launches"]) == (launches[0] * nb, launches[1] * nb), (sf, chain, c10, p)
+        assert np.abs(y - ref).max() < ABS_TOL, (sf, chain, c10, np.abs(y - ref).max())
+    base = ys[("off", "off", "off")]
+    assert all(np.abs(y - base).max() < 2e-5 for y in ys.values())
+    eng.profile(0)
+    eng.close()
+
+
 def test_nonlocal_options_forward():
     """utils.NonLocalBlock's nltype / sub_sample arguments as engine options (the reference's forward pins them to 1 / 1,
     model/pfnl.py:58): whole forward and the strip form against the fp64 spec with the same arguments; both precisions."""

@@ -516,6 +516,36 @@ def test_conv1x1_split16_sf(T, items, H, W, io):
     assert e_o < 2e-6 * max(1.0, np.abs(ref).max()), e_o
 
 
+@pytest.mark.parametrize("T,clips,H,W", [(7, 1, 8, 32), (7, 2, 16, 64), (5, 1, 9, 38), (3, 3, 5, 7), (7, 1, 1, 1), (7, 1, 33, 70),
+                                          (7, 4, 128, 128), (5, 2, 64, 96), (1, 2, 24, 40), (7, 40, 8, 32)])
+def test_conv1_conv10_fused_split16(T, clips, H, W):
+    """conv1_i + conv10_i as ONE launch (conv3x3_c1c10_kernel; reference model/pfnl.py:66-68): inp1 and base against the fp64 spec
+    (two convolutions, written as the reference) and against the two-launch form it replaces; ragged tiles, one tile per chain, more
+    chains than workgroups (40 clips x 1 tile), the configs[1] geometry."""
+    rng = np.random.default_rng(T * 1000 + H * 10 + W + clips)
+    F = clips * T
+    x = rng.normal(size=(F, H, W, 64)).astype(np.float32)
+    k1 = (rng.normal(size=(3, 3, 64, 64)) / 24.0).astype(np.float32)
+    b1 = (rng.normal(size=64) * 0.1).astype(np.float32)
+    k10 = (rng.normal(size=(1, 1, 64 * T, 64)) / np.sqrt(64 * T)).astype(np.float32)
+    b10 = (rng.normal(size=64) * 0.1).astype(np.float32)
+    got1, gotb = (t.cpu().numpy() for t in ops.conv1_conv10_split16(dev(x), k1, b1, k10, b10, T))
+    two1 = ops.conv3x3_winograd(dev(x), k1, b1, act=True, variant="split16_sf_out")
+    twob = ops.conv1x1_stream(two1, k10, b10, frames_per_item=T, act=True, variant="split16_sf:01").cpu().numpy()
+    big = F * H * W > 200000                                                        # fp64 spec on a subset of the clips only
+    nc = 1 if big else clips
+    ref1 = pfnl_spec.lrelu(pfnl_spec.conv2d_same(x[:nc * T].astype(np.float64), k1.astype(np.float64), b1.astype(np.float64)))
+    cat = ref1.reshape(nc, T, H, W, 64).transpose(0, 2, 3, 1, 4).reshape(nc, H, W, T * 64)
+    refb = pfnl_spec.lrelu(pfnl_spec.conv2d_same(cat, k10.astype(np.float64), b10.astype(np.float64)))
+    e1, eb = np.abs(got1[:nc * T] - ref1).max(), np.abs(gotb[:nc] - refb).max()
+    d1, db = np.abs(got1 - two1.cpu().numpy()).max(), np.abs(gotb - twob).max()
+    print(f"conv1+conv10 fused T{T} {clips}x{H}x{W}: inp1 err {e1:.3g} (two-launch {d1:.3g}), base err {eb:.3g} (two-launch {db:.3g})")
+    assert e1 < 4e-6 * max(1.0, np.abs(ref1).max()) and eb < 4e-6 * max(1.0, np.abs(refb).max()), (e1, eb)
+    assert d1 <= 2.0 ** -20 * max(1.0, np.abs(ref1).max()), d1                      # the same MFMAs in the same order (the fold of the cross terms
+                                                                                     # may contract differently): one step of the 22-bit split
+    assert db < 2e-6 * max(1.0, np.abs(refb).max()), db
+
+
 @pytest.mark.parametrize("T,clips,H,W", [(7, 1, 32, 32), (5, 1, 64, 64), (7, 2, 9, 38), (3, 1, 2, 2), (7, 1, 33, 70), (5, 3, 16, 24)])
 def test_conv_small_trunk_ops(T, clips, H, W):
     """conv_small.hip (BASELINE.json configs[0] / configs[4] path): conv1_i, conv10_i, the whole of conv2_i over

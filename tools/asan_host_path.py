@@ -27,7 +27,7 @@ def main():
         eng = PFNLEngine(geom, device=0)
         eng.load_weights(w)
         for opts in ({}, {"conv3x3": "split16", "small": "off"}, {"conv3x3": "winograd"}, {"conv3x3": "direct", "conv1x1": "tiled"},
-                     {"strict_fp32": "on"}, {"split16_sf": "off"}, {"split16_chain": "off"}, {"graph": "on"}, {"precision": "bf16"},
+                     {"strict_fp32": "on"}, {"split16_sf": "off"}, {"split16_chain": "off"}, {"split16_c10": "off"}, {"graph": "on"}, {"precision": "bf16"},
                      {"precision": "bf16", "bf16_nonlocal": "split", "bf16_conv10": "separate"}):
             for k, v in opts.items():
                 eng.set_option(k, v)
@@ -39,7 +39,7 @@ def main():
             eng.tap("nl_out", B, H, W)
             for k in opts:
                 eng.set_option(k, {"conv3x3": "auto", "small": "auto", "conv1x1": "split16", "strict_fp32": "off", "split16_sf": "on",
-                                   "split16_chain": "on", "graph": "off", "precision": "fp32", "bf16_nonlocal": "f16",
+                                   "split16_chain": "on", "split16_c10": "on", "graph": "off", "precision": "fp32", "bf16_nonlocal": "f16",
                                    "bf16_conv10": "fused"}[k])
             n += 1
         eng.profile(1)
