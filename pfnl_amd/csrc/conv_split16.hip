@@ -817,9 +817,9 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
     // c = 8 M + 4 part + channel group) sits in slot c ^ (pp & 15): conflict-free for the dump (lanes = consecutive pixels, one
     // chunk), for the operand reads (the same) and for the line read-back (16 lanes = the 16 chunks of one pixel).
     unsigned char* const scratch = cs_smem + CS_TILE_BYTES;         // unit B's halo buffer: free behind the tile's closing barrier
-    auto emit_row = [&](f32x16 v, int n, float* dst_item, int ey0, int ex0, auto mm, const u32x4 (&w10)[8]) __attribute__((always_inline)) {
-        constexpr bool MM = decltype(mm)::value;
-        u32x2 hi[4], lo[4];
+    struct RowHalves { u32x2 hi[4], lo[4]; };                       // one output row of a wave (16 channels of a pixel per lane) as binary16 pairs
+    auto row_prep = [&](f32x16 v) __attribute__((always_inline)) {  // leaky-relu + split: 4 VALU per value
+        RowHalves h;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 t = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
@@ -828,46 +828,55 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
             asm("v_max_f32 %0, %1, %2" : "=v"(t.y) : "v"(t.y), "v"(st.y));
             asm("v_max_f32 %0, %1, %2" : "=v"(t.z) : "v"(t.z), "v"(st.z));
             asm("v_max_f32 %0, %1, %2" : "=v"(t.w) : "v"(t.w), "v"(st.w));
-            split4(t, hi[q], lo[q], nscale);
+            split4(t, h.hi[q], h.lo[q], nscale);
         }
-        const int pp = rp * 32 + (lane & 31);
-        const int sw = pp & 15;
-        unsigned char* const pl = scratch + pp * 256;
+        return h;
+    };
+    const int pp = rp * 32 + (lane & 31);
+    const int sw = pp & 15;
+    unsigned char* const pl = scratch + pp * 256;
+    auto row_dump = [&](const RowHalves& h) __attribute__((always_inline)) {
         const int c0 = 8 * mt + 2 * kh;                             // hi chunk of channels ech .. ech+7; +1: ech+8 .. +15; +4: the lo' chunks
-        *reinterpret_cast<u32x4*>(pl + ((c0 ^ sw) << 4)) = u32x4{hi[0].x, hi[0].y, hi[1].x, hi[1].y};
-        *reinterpret_cast<u32x4*>(pl + (((c0 + 1) ^ sw) << 4)) = u32x4{hi[2].x, hi[2].y, hi[3].x, hi[3].y};
-        *reinterpret_cast<u32x4*>(pl + (((c0 + 4) ^ sw) << 4)) = u32x4{lo[0].x, lo[0].y, lo[1].x, lo[1].y};
-        *reinterpret_cast<u32x4*>(pl + (((c0 + 5) ^ sw) << 4)) = u32x4{lo[2].x, lo[2].y, lo[3].x, lo[3].y};
-        K1_BARRIER();                                               // the 128 lines are complete
-        u32x4 pc[4];                                                // this thread's 4 line pieces (piece id = i * 512 + tid: pixel id >> 4, chunk id & 15)
+        *reinterpret_cast<u32x4*>(pl + ((c0 ^ sw) << 4)) = u32x4{h.hi[0].x, h.hi[0].y, h.hi[1].x, h.hi[1].y};
+        *reinterpret_cast<u32x4*>(pl + (((c0 + 1) ^ sw) << 4)) = u32x4{h.hi[2].x, h.hi[2].y, h.hi[3].x, h.hi[3].y};
+        *reinterpret_cast<u32x4*>(pl + (((c0 + 4) ^ sw) << 4)) = u32x4{h.lo[0].x, h.lo[0].y, h.lo[1].x, h.lo[1].y};
+        *reinterpret_cast<u32x4*>(pl + (((c0 + 5) ^ sw) << 4)) = u32x4{h.lo[2].x, h.lo[2].y, h.lo[3].x, h.lo[3].y};
+    };
+    // conv10_i, frame f: base_m[n][cout][pixel] += W10_f[cout][k] X[k][pixel], k-step q = (M, h): channels 32 M + 16 kh + 8 h + e
+    auto row_mm = [&](int n, const u32x4 (&w10)[8]) __attribute__((always_inline)) {
+        f32x16 cross;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cross[r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cb = 8 * (q >> 1) + 2 * kh + (q & 1);
+            const h8 bh = *reinterpret_cast<const h8*>(pl + ((cb ^ sw) << 4));
+            const h8 bo = *reinterpret_cast<const h8*>(pl + (((cb + 4) ^ sw) << 4));
+            const h8 ah = __builtin_bit_cast(h8, w10[2 * q]), ao = __builtin_bit_cast(h8, w10[2 * q + 1]);
+            base_m[n] = mfma_f16(ah, bh, base_m[n]);
+            cross = mfma_f16(ao, bh, cross);
+            cross = mfma_f16(ah, bo, cross);
+        }
+        base_m[n] += cross * CS_ISCALE;
+    };
+    // the 128 lines of the scratch -> HBM: 4 pieces per thread (piece id = i * 512 + tid: pixel id >> 4, chunk id & 15)
+    struct RowPieces { u32x4 pc[4]; };
+    auto row_read = [&]() __attribute__((always_inline)) {
+        RowPieces r;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int id = i * CS_THREADS + tid, ppx = id >> 4, c = id & 15;
-            pc[i] = *reinterpret_cast<const u32x4*>(scratch + ppx * 256 + ((c ^ (ppx & 15)) << 4));
+            r.pc[i] = *reinterpret_cast<const u32x4*>(scratch + ppx * 256 + ((c ^ (ppx & 15)) << 4));
         }
-        if constexpr (MM) {
-            // conv10_i, frame f: base_m[n][cout][pixel] += W10_f[cout][k] X[k][pixel], k-step q = (M, h): channels 32 M + 16 kh + 8 h + e
-            f32x16 cross;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cross[r] = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int cb = 8 * (q >> 1) + 2 * kh + (q & 1);
-                const h8 bh = *reinterpret_cast<const h8*>(pl + ((cb ^ sw) << 4));
-                const h8 bo = *reinterpret_cast<const h8*>(pl + (((cb + 4) ^ sw) << 4));
-                const h8 ah = __builtin_bit_cast(h8, w10[2 * q]), ao = __builtin_bit_cast(h8, w10[2 * q + 1]);
-                base_m[n] = mfma_f16(ah, bh, base_m[n]);
-                cross = mfma_f16(ao, bh, cross);
-                cross = mfma_f16(ah, bo, cross);
-            }
-            base_m[n] += cross * CS_ISCALE;
-        }
+        return r;
+    };
+    auto row_store = [&](const RowPieces& r, int n, float* dst_item, int ey0, int ex0) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(dst_item, 0, item_bytes, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int id = i * CS_THREADS + tid, ppx = id >> 4, c = id & 15;
             const int gy = ey0 + 2 * (ppx >> 5) + n, gx = ex0 + (ppx & 31);   // rows past the image: past the end of the resource
-            buffer_store_b128_guarded<CS_STORE_AUX>(pc[i], rsO, gx < W ? (gy * W + gx) * 256 + c * 16 : 0x7fffffff, 0);
+            buffer_store_b128_guarded<CS_STORE_AUX>(r.pc[i], rsO, gx < W ? (gy * W + gx) * 256 + c * 16 : 0x7fffffff, 0);
         }
     };
 
@@ -1026,16 +1035,35 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
                 }
                 K1_BARRIER();                                       // b2: this unit's buffer (the scratch) is free, the next unit's is complete
                 float* const dst = p.out + (size_t)c_item * H * W * 64;
-                emit_row(accm[0] + accc[0] * CS_ISCALE, 0, dst, c_y0, c_x0, std::true_type{}, w10);
-                K1_BARRIER();                                       // the lines of row 0 are read
-                emit_row(accm[1] + accc[1] * CS_ISCALE, 1, dst, c_y0, c_x0, std::true_type{}, w10);
+                // row 0: its leaky-relu / split is the one piece of arithmetic nothing covers; row 1's is issued next to row 0's MFMAs
+                const RowHalves h0 = row_prep(accm[0] + accc[0] * CS_ISCALE);
+                row_dump(h0);
+                K1_BARRIER();                                       // the 128 lines of row 0 are complete
+                const RowPieces r0 = row_read();
+                row_mm(0, w10);
+                const RowHalves h1 = row_prep(accm[1] + accc[1] * CS_ISCALE);
+                row_store(r0, 0, dst, c_y0, c_x0);
+                K1_BARRIER();                                       // ... and read
+                row_dump(h1);
+                K1_BARRIER();
+                const RowPieces r1 = row_read();
+                row_mm(1, w10);
+                row_store(r1, 1, dst, c_y0, c_x0);
                 const bool last = fch + 1 == gT;                    // (wave-uniform)
                 if (last) {                                         // the chain's sum -> `base` (out2), and back to its initial value
                     float* const dstb = p.out2 + (size_t)(c_item / gT) * H * W * 64;
+                    const RowHalves hb0 = row_prep(base_m[0]);
+                    const RowHalves hb1 = row_prep(base_m[1]);
                     K1_BARRIER();
-                    emit_row(base_m[0], 0, dstb, c_y0, c_x0, std::false_type{}, w10);
+                    row_dump(hb0);
                     K1_BARRIER();
-                    emit_row(base_m[1], 1, dstb, c_y0, c_x0, std::false_type{}, w10);
+                    const RowPieces rb0 = row_read();
+                    row_store(rb0, 0, dstb, c_y0, c_x0);
+                    K1_BARRIER();
+                    row_dump(hb1);
+                    K1_BARRIER();
+                    const RowPieces rb1 = row_read();
+                    row_store(rb1, 1, dstb, c_y0, c_x0);
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
 #pragma unroll
