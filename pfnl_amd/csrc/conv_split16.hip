@@ -709,6 +709,20 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
 // conv10_i as a launch of its own read inp1 (117 MB at configs[1]) back for 11 % of conv1_i's MFMAs; here it reads nothing.
 // The serial phase costs ~2.5 k cycles per tile (two passes x [80 VALU, 4 ds_write_b128, barrier, 8 ds_read_b128 + 12 MFMAs,
 // 4 line pieces]) of ~28 k.
+// one LDS-DMA instruction: lane L's 16 bytes at (resource, voff) -> LDS [lds_dst + 16 L] (conv_sf.hip, sf_dma16: m0 saved / restored)
+// + a scalar byte offset on the memory side only (the instruction's immediate offset would move the LDS side as well)
+__device__ __forceinline__ void k1_dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds_dst, int voff, int soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rs), "s"(soff) : "memory");
+}
+
+#ifndef K1_W10_AT
+#define K1_W10_AT 16          // sub-step of a tile's second unit at which conv10_i's operands are requested
+#endif
+#ifndef K1_STORE_AUX
+#define K1_STORE_AUX CS_STORE_AUX
+#endif
 constexpr int K1_LDS_BYTES = CS_LDS_BYTES + 64 * 4;                 // + conv10_i's bias
 
 __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitParams p) {
@@ -719,6 +733,9 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef PFNL_S16_TIMING
+    int dbg_n = 0;
+#endif
     const int rp = wave >> 1;                                       // rows 2rp, 2rp+1 of the tile
     const int mt = wave & 1;                                        // output channels 32mt .. 32mt+31 (of conv1_i and of conv10_i)
     const int H = p.H, W = p.W;
@@ -750,24 +767,26 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
     for (int k = 0; k < CS_W_BYTES / 16 / CS_THREADS; ++k) w0reg[k] = reinterpret_cast<const u32x4*>(p.wpack)[k * CS_THREADS + tid];
     const float bias_r = tid < 64 ? p.bias[tid] : (tid < 128 ? p.bias2[tid - 64] : 0.f);
 
-    int grel[CS_ITERS], lpk[CS_ITERS];                              // staging map: as conv3x3_split16_kernel
-    const int wbytes = W * 256;
+    int lpk[CS_ITERS];                                              // staging map: as conv3x3_split16_kernel; the source offset of a piece
+    const int wbytes = W * 256;                                     // (py * wbytes + px * 256 + 16 (tid & 7)) is recomputed from it: no registers to spare
 #pragma unroll
     for (int k = 0; k < CS_ITERS; ++k) {
         const int id = min(k * CS_THREADS + tid, CS_PIECES - 1);
         const int pix = id >> 3, c = id & 7;
         const int py = pix / CS_IW, px = pix - py * CS_IW;
-        grel[k] = py * wbytes + px * 256 + c * 16;
         lpk[k] = ((py * CS_IW + px) * 128 + 8 * (c & 1) + (((c >> 1) ^ ((px >> 1) & 7)) << 4)) | (py << 16) | (px << 24);
     }
+    const int c16 = (tid & 7) * 16;                                 // (piece id = k * 512 + tid: its 4-channel piece of the pixel is tid & 7 for every k)
     const float nscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -CS_SCALE)));
     f32x4 stg[CS_ITERS];
 #define K1_REQUEST_ALL(rs_, org_, interior_, y0_, x0_)                                           \
     do {                                                                                         \
         _Pragma("unroll") for (int k_ = 0; k_ < CS_ITERS; ++k_) {                                \
-            const int gy_ = (y0_) + ((lpk[k_] >> 16) & 0xff) - 1, gx_ = (x0_) + ((unsigned)lpk[k_] >> 24) - 1; \
-            const bool in_ = (interior_) || ((unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W); \
-            stg[k_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, in_ ? (org_) + grel[k_] : 0x7fffffff, 0, CS_HALO_AUX)); \
+            const int py_ = (lpk[k_] >> 16) & 0xff, px_ = (unsigned)lpk[k_] >> 24;               \
+            const int gy_ = (y0_) + py_ - 1, gx_ = (x0_) + px_ - 1;                              \
+            const bool in_ = (interior_) | (((unsigned)gy_ < (unsigned)H) & ((unsigned)gx_ < (unsigned)W));   /* (no short circuit: no branches) */ \
+            const int off_ = (org_) + py_ * wbytes + px_ * 256 + c16;                            \
+            stg[k_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, in_ ? off_ : 0x7fffffff, 0, CS_HALO_AUX)); \
         }                                                                                        \
     } while (0)
 #define K1_COMMIT1(k_, buf_)                                                                     \
@@ -790,6 +809,12 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
     const int kh = lane >> 5;
     const int ech = 32 * mt + 16 * kh;                              // register r of a lane = channel ech + r (both convolutions)
     f32x16 accm[2], accc[2], base_m[2];                             // [output row]: hi.hi / cross products (x 2^11) of conv1_i; conv10_i of the chain
+    // the finished tile's 256 pixel lines as this thread's 8 pieces of 16 bytes (row n: piece id = i * 512 + tid -> pixel id >> 4 of
+    // the row's 128, chunk id & 15): picked up from the scratch in the serial phase, stored one by one under the NEXT tile's MFMAs -
+    // a CU moves store data at ~16 B per clock (measured: 2 k cycles for the 32 KB of a row), far too slow to wait for
+    u32x4 held[8];
+    int hx0 = 0, hy0 = 0, hitem = 0;                                // ... and where they go
+    bool hpend = false;
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -799,17 +824,16 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
         }
     const float slope = p.act ? 0.2f : 1.0f;
 
-    u32x4 wnx[CS_WITERS];
-    auto w_request = [&](int half, int slot) __attribute__((always_inline)) {
-        const u32x4* src = reinterpret_cast<const u32x4*>(p.wpack) + (size_t)half * (CS_W_BYTES / 16) + slot * (CS_SLOT_BYTES / 16);
-#pragma unroll
-        for (int k = 0; k < CS_WITERS; ++k) wnx[k] = src[k * CS_THREADS + tid];
-    };
-    auto w_write = [&](int slot) __attribute__((always_inline)) {
-        u32x4* dst = reinterpret_cast<u32x4*>(wl + slot * CS_SLOT_BYTES);
-#pragma unroll
-        for (int k = 0; k < CS_WITERS; ++k) dst[k * CS_THREADS + tid] = wnx[k];
-    };
+    // weight replacement: a slot (24 KB, one column tap of the other channel half) travels L2 -> LDS by LDS-DMA, 3 instructions of
+    // 1 KB per wave, behind the barrier that frees it; complete (fence load, see conv_sf.hip) before the barrier in front of its first read
+    const unsigned ldsw = (unsigned)(uintptr_t)wl;
+    const int wvoff = wave * 1024 + lane * 16;
+#define K1_DMA_W(half_, slot_)                                                                   \
+    do {                                                                                         \
+        const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.wpack), 0, 2 * CS_W_BYTES, 0x00020000); \
+        _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_)                                         \
+            k1_dma16(rw_, ldsw + (slot_) * CS_SLOT_BYTES + (wave + 8 * k_) * 1024, wvoff, (half_) * CS_W_BYTES + (slot_) * CS_SLOT_BYTES + k_ * 8192); \
+    } while (0)
 #define K1_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
     // ---- a finished row (n) of the workgroup's tile: leaky-relu, split, 128 pixel lines in `scratch`; optionally conv10_i's
@@ -818,19 +842,16 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
     // chunk), for the operand reads (the same) and for the line read-back (16 lanes = the 16 chunks of one pixel).
     unsigned char* const scratch = cs_smem + CS_TILE_BYTES;         // unit B's halo buffer: free behind the tile's closing barrier
     struct RowHalves { u32x2 hi[4], lo[4]; };                       // one output row of a wave (16 channels of a pixel per lane) as binary16 pairs
-    auto row_prep = [&](f32x16 v) __attribute__((always_inline)) {  // leaky-relu + split: 4 VALU per value
-        RowHalves h;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 t = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-            const f32x4 st = t * slope;
-            asm("v_max_f32 %0, %1, %2" : "=v"(t.x) : "v"(t.x), "v"(st.x));
-            asm("v_max_f32 %0, %1, %2" : "=v"(t.y) : "v"(t.y), "v"(st.y));
-            asm("v_max_f32 %0, %1, %2" : "=v"(t.z) : "v"(t.z), "v"(st.z));
-            asm("v_max_f32 %0, %1, %2" : "=v"(t.w) : "v"(t.w), "v"(st.w));
-            split4(t, h.hi[q], h.lo[q], nscale);
-        }
-        return h;
+    auto quarter_prep = [&](RowHalves& h, const f32x16& m, const f32x16& c, int q, bool fold) __attribute__((always_inline)) {
+        // channels ech + 4q .. + 3: (cross terms folded in,) leaky-relu, split - 4 VALU per value
+        f32x4 t = {m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]};
+        if (fold) t += f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]} * CS_ISCALE;
+        const f32x4 st = t * slope;
+        asm("v_max_f32 %0, %1, %2" : "=v"(t.x) : "v"(t.x), "v"(st.x));
+        asm("v_max_f32 %0, %1, %2" : "=v"(t.y) : "v"(t.y), "v"(st.y));
+        asm("v_max_f32 %0, %1, %2" : "=v"(t.z) : "v"(t.z), "v"(st.z));
+        asm("v_max_f32 %0, %1, %2" : "=v"(t.w) : "v"(t.w), "v"(st.w));
+        split4(t, h.hi[q], h.lo[q], nscale);
     };
     const int pp = rp * 32 + (lane & 31);
     const int sw = pp & 15;
@@ -842,42 +863,55 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
         *reinterpret_cast<u32x4*>(pl + (((c0 + 4) ^ sw) << 4)) = u32x4{h.lo[0].x, h.lo[0].y, h.lo[1].x, h.lo[1].y};
         *reinterpret_cast<u32x4*>(pl + (((c0 + 5) ^ sw) << 4)) = u32x4{h.lo[2].x, h.lo[2].y, h.lo[3].x, h.lo[3].y};
     };
-    // conv10_i, frame f: base_m[n][cout][pixel] += W10_f[cout][k] X[k][pixel], k-step q = (M, h): channels 32 M + 16 kh + 8 h + e
-    auto row_mm = [&](int n, const u32x4 (&w10)[8]) __attribute__((always_inline)) {
-        f32x16 cross;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cross[r] = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int cb = 8 * (q >> 1) + 2 * kh + (q & 1);
-            const h8 bh = *reinterpret_cast<const h8*>(pl + ((cb ^ sw) << 4));
-            const h8 bo = *reinterpret_cast<const h8*>(pl + (((cb + 4) ^ sw) << 4));
-            const h8 ah = __builtin_bit_cast(h8, w10[2 * q]), ao = __builtin_bit_cast(h8, w10[2 * q + 1]);
-            base_m[n] = mfma_f16(ah, bh, base_m[n]);
-            cross = mfma_f16(ao, bh, cross);
-            cross = mfma_f16(ah, bo, cross);
-        }
-        base_m[n] += cross * CS_ISCALE;
-    };
-    // the 128 lines of the scratch -> HBM: 4 pieces per thread (piece id = i * 512 + tid: pixel id >> 4, chunk id & 15)
-    struct RowPieces { u32x4 pc[4]; };
-    auto row_read = [&]() __attribute__((always_inline)) {
-        RowPieces r;
+    // One pass over the 128 lines in the scratch: (a) this thread's 4 pieces of them -> `pc` (stored later); (b) conv10_i, frame f:
+    // base_m[n][cout][pixel] += W10_f[cout][k] X[k][pixel], k-step q = (M, h): channels 32 M + 16 kh + 8 h + e - 3 MFMAs per k-step,
+    // ordered so that none waits for the one before it; (c) `fill(q)`: arithmetic of the caller that rides in the shadow of the MFMAs
+    // (a wave issues in order: it has to sit BETWEEN them in the stream).
+    auto row_pass = [&](int n, auto mm, const u32x4 (&w10)[8], u32x4* pc, auto&& fill) __attribute__((always_inline)) {
+        constexpr bool MM = decltype(mm)::value;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int id = i * CS_THREADS + tid, ppx = id >> 4, c = id & 15;
-            r.pc[i] = *reinterpret_cast<const u32x4*>(scratch + ppx * 256 + ((c ^ (ppx & 15)) << 4));
+            pc[i] = *reinterpret_cast<const u32x4*>(scratch + ppx * 256 + ((c ^ (ppx & 15)) << 4));
         }
-        return r;
-    };
-    auto row_store = [&](const RowPieces& r, int n, float* dst_item, int ey0, int ex0) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(dst_item, 0, item_bytes, 0x00020000);
+        if constexpr (MM) {
+            h8 bh[4], bo[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int id = i * CS_THREADS + tid, ppx = id >> 4, c = id & 15;
-            const int gy = ey0 + 2 * (ppx >> 5) + n, gx = ex0 + (ppx & 31);   // rows past the image: past the end of the resource
-            buffer_store_b128_guarded<CS_STORE_AUX>(r.pc[i], rsO, gx < W ? (gy * W + gx) * 256 + c * 16 : 0x7fffffff, 0);
+            for (int q = 0; q < 4; ++q) {
+                const int cb = 8 * (q >> 1) + 2 * kh + (q & 1);
+                bh[q] = *reinterpret_cast<const h8*>(pl + ((cb ^ sw) << 4));
+                bo[q] = *reinterpret_cast<const h8*>(pl + (((cb + 4) ^ sw) << 4));
+            }
+            f32x16 cross;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cross[r] = 0.f;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const h8 ah = __builtin_bit_cast(h8, w10[2 * q]), ao = __builtin_bit_cast(h8, w10[2 * q + 1]);
+                cross = mfma_f16(ao, bh[q], cross);
+                base_m[n] = mfma_f16(ah, bh[q], base_m[n]);
+                cross = mfma_f16(ah, bo[q], cross);
+                __builtin_amdgcn_sched_barrier(0);
+                fill(q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            base_m[n] += cross * CS_ISCALE;
         }
+    };
+    // piece j (0..7: row j >> 2, piece j & 3) of the held tile -> HBM; nothing held: out of range (dropped)
+    auto held_store = [&](int j, float* base_ptr) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(base_ptr + (size_t)hitem * H * W * 64, 0, item_bytes, 0x00020000);
+        const int id = (j & 3) * CS_THREADS + tid, ppx = id >> 4, c = id & 15;
+        const int gy = hy0 + 2 * (ppx >> 5) + (j >> 2), gx = hx0 + (ppx & 31);   // rows past the image: past the end of the resource
+        const int off = (gy * W + gx) * 256 + c * 16;
+        buffer_store_b128_guarded<K1_STORE_AUX>(held[j], rsO, (hpend & (gx < W)) ? off : 0x7fffffff, 0);
+    };
+    auto base_init = [&]() __attribute__((always_inline)) {         // conv10_i's bias: the initial value of a chain's sum
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) base_m[n][r] = bl2[ech + r];
     };
 
     // ---- prologue: halo of unit 0 -> buffer 0; weights of half 0, both biases -> LDS ----------------------------------------
@@ -899,10 +933,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
         for (int k = 0; k < CS_ITERS; ++k) K1_COMMIT1(k, 0);
     }
     __syncthreads();
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) base_m[n][r] = bl2[ech + r];   // conv10_i's bias: the initial value of a chain's sum
+    base_init();
 
     int fch = 0;                                                    // frame of the chain the current tile is
     for (int kt = 0; kt < nt; ++kt) {
@@ -912,6 +943,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
             constexpr int cb = PAR;
             const unsigned char* const tile = cs_smem + cb * CS_TILE_BYTES;
             h8 X[4][2], Wv[2][2];
+            CS_STAMP();                                             // 0 / 1: unit A / B start
 #define CS_PX(g_, r_, part_) (*reinterpret_cast<const h8*>(tile + (paddr[(g_) >> 1] ^ (((part_) ? lo_xor : 0) | (((g_) & 1) << 5))) + (r_) * (CS_IW * 128)))
 #define CS_WT(g_, ky_, part_) (*reinterpret_cast<const h8*>(wlane + (((g_) * 3 + (ky_)) << 12) + ((part_) << 10)))
             X[0][0] = CS_PX(0, 0, 0);
@@ -921,7 +953,13 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
             Wv[0][0] = CS_WT(0, 0, 0);
             Wv[0][1] = CS_WT(0, 0, 1);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PAR == 0) w_request(half_a ^ 1, 0);
+            // unit B: column tap 2 of ITS half (the slot was in use until unit A's closing barrier); read from group 4 on, behind b0
+            [[maybe_unused]] unsigned fence_w = 0;
+            const __amdgpu_buffer_rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, 256, 0x00020000);
+            if constexpr (PAR == 1) {
+                K1_DMA_W(half_a ^ 1, 2);
+                fence_w = __builtin_amdgcn_raw_buffer_load_b32(rsf, 0, 0, 0);
+            }
             // the NEXT unit's halo: unit A asks for the other half of ITS tile, unit B for the first half of the next tile
             const int q_item = PAR == 0 ? c_item : n_item, y0q = PAR == 0 ? c_y0 : n_y0, x0q = PAR == 0 ? c_x0 : n_x0;
             const int q_half = half_a ^ 1;
@@ -941,20 +979,37 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
                     bias16[4 * q + 3] = b4.w;
                 }
             }
+            // conv10_i's A operands of this frame: [f][k-step q][g = mt][hi / lo'][lane] x 16 B from L2, requested two sub-steps before the
+            // tile is complete (the halo staging registers are free from there on) so that their latency passes under MFMAs
+            [[maybe_unused]] u32x4 w10[8];
             auto substep = [&](auto sc) __attribute__((always_inline)) {
                 constexpr int S = decltype(sc)::value;
                 constexpr int g = S / 3, ky = S % 3;
+                if constexpr (PAR == 1 && S == K1_W10_AT) {
+                    const u32x4* src = reinterpret_cast<const u32x4*>(p.wpack2) + ((size_t)fch * 16 + 2 * mt) * 64 + lane;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        w10[2 * q] = src[(4 * q) * 64];
+                        w10[2 * q + 1] = src[(4 * q + 1) * 64];
+                    }
+                }
+                if constexpr (PAR == 0 && S >= 1 && S <= 8) held_store(S - 1, p.out);   // the previous tile's lines, one piece per sub-step
                 if constexpr (ky == 0) {
-                    if constexpr (g == 1 && PAR == 1) w_write(2);
-                    if constexpr (g == 2) K1_BARRIER();             // b0: column tap 0 of the weights consumed
+                    if constexpr (g == 2) {
+                        if constexpr (PAR == 1) asm volatile("" ::"v"(fence_w));   // tap 2 of this unit's weights has landed
+                        K1_BARRIER();                               // b0: column tap 0 of the weights consumed (unit B: tap 2 complete)
+                        if constexpr (PAR == 0) K1_DMA_W(half_a ^ 1, 0);
+                    }
                     if constexpr (g == 3 && PAR == 0) {
-                        w_write(0);
-                        w_request(half_a ^ 1, 1);
                         const int kn = min(kt + 1, nt - 1);         // decode the next tile (past the end: this one again - a harmless re-read)
                         K1_TILE(kn, n_item, n_y0, n_x0);
                     }
                     if constexpr (g == 4) {
                         K1_BARRIER();                               // b1: column tap 1 consumed
+                        if constexpr (PAR == 0) {
+                            K1_DMA_W(half_a ^ 1, 1);
+                            fence_w = __builtin_amdgcn_raw_buffer_load_b32(rsf, 0, 0, 0);   // covers taps 0 and 1 of the next unit's weights
+                        }
 #pragma unroll
                         for (int k = 0; k < CS_ITERS; ++k) asm volatile("" : "+v"(lpk[k]));
 #pragma unroll
@@ -963,10 +1018,6 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
                     if constexpr (g == 5) {
 #pragma unroll
                         for (int k = CS_ITERS / 2; k < CS_ITERS; ++k) K1_COMMIT1(k, cb ^ 1);
-                        if constexpr (PAR == 0) {
-                            w_write(1);
-                            w_request(half_a ^ 1, 2);
-                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1023,51 +1074,56 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
 #undef CS_PX
 #undef CS_WT
             if constexpr (PAR == 1) {
-                // conv10_i's A operands of this frame: [f][k-step q][g = mt][hi / lo'][lane] x 16 B, requested before the closing barrier
-                u32x4 w10[8];
-                {
-                    const u32x4* src = reinterpret_cast<const u32x4*>(p.wpack2) + ((size_t)fch * 16 + 2 * mt) * 64 + lane;
+                // The tile leaves (see the header).  Row 0's leaky-relu / split needs nothing but this wave's registers: in FRONT of the
+                // closing barrier, where the wave of a SIMD that finishes first would only wait for the other one; row 1's rides between
+                // row 0's conv10 MFMAs.
+                RowHalves h0, h1;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        w10[2 * q] = src[(4 * q) * 64];
-                        w10[2 * q + 1] = src[(4 * q + 1) * 64];
-                    }
-                }
+                for (int q = 0; q < 4; ++q) quarter_prep(h0, accm[0], accc[0], q, true);
+                CS_STAMP();                                         // 2: sub-steps done, row 0 prepared
                 K1_BARRIER();                                       // b2: this unit's buffer (the scratch) is free, the next unit's is complete
-                float* const dst = p.out + (size_t)c_item * H * W * 64;
-                // row 0: its leaky-relu / split is the one piece of arithmetic nothing covers; row 1's is issued next to row 0's MFMAs
-                const RowHalves h0 = row_prep(accm[0] + accc[0] * CS_ISCALE);
+                CS_STAMP();                                         // 3: past b2
                 row_dump(h0);
+                CS_STAMP();                                         // 4: row 0 dumped
                 K1_BARRIER();                                       // the 128 lines of row 0 are complete
-                const RowPieces r0 = row_read();
-                row_mm(0, w10);
-                const RowHalves h1 = row_prep(accm[1] + accc[1] * CS_ISCALE);
-                row_store(r0, 0, dst, c_y0, c_x0);
+                CS_STAMP();                                         // 5
+                row_pass(0, std::true_type{}, w10, &held[0], [&](int q) __attribute__((always_inline)) { quarter_prep(h1, accm[1], accc[1], q, true); });
+                CS_STAMP();                                         // 6: row 0's lines picked up, its products issued, row 1 prepared
                 K1_BARRIER();                                       // ... and read
+                CS_STAMP();                                         // 7
                 row_dump(h1);
                 K1_BARRIER();
-                const RowPieces r1 = row_read();
-                row_mm(1, w10);
-                row_store(r1, 1, dst, c_y0, c_x0);
+                CS_STAMP();                                         // 8
+                row_pass(1, std::true_type{}, w10, &held[4], [&](int) __attribute__((always_inline)) {});
+                CS_STAMP();                                         // 9
+                hx0 = c_x0;
+                hy0 = c_y0;
+                hitem = c_item;
+                hpend = true;
                 const bool last = fch + 1 == gT;                    // (wave-uniform)
                 if (last) {                                         // the chain's sum -> `base` (out2), and back to its initial value
-                    float* const dstb = p.out2 + (size_t)(c_item / gT) * H * W * 64;
-                    const RowHalves hb0 = row_prep(base_m[0]);
-                    const RowHalves hb1 = row_prep(base_m[1]);
+                    // (once per chain: stored at once; the frame tile's own lines leave first - `held` is reused)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) held_store(j, p.out);
+                    hitem = c_item / gT;
+                    RowHalves hb0, hb1;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        quarter_prep(hb0, base_m[0], base_m[0], q, false);
+                        quarter_prep(hb1, base_m[1], base_m[1], q, false);
+                    }
                     K1_BARRIER();
                     row_dump(hb0);
                     K1_BARRIER();
-                    const RowPieces rb0 = row_read();
-                    row_store(rb0, 0, dstb, c_y0, c_x0);
+                    row_pass(0, std::false_type{}, w10, &held[0], [&](int) __attribute__((always_inline)) {});
                     K1_BARRIER();
                     row_dump(hb1);
                     K1_BARRIER();
-                    const RowPieces rb1 = row_read();
-                    row_store(rb1, 1, dstb, c_y0, c_x0);
+                    row_pass(1, std::false_type{}, w10, &held[4], [&](int) __attribute__((always_inline)) {});
 #pragma unroll
-                    for (int n = 0; n < 2; ++n)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) base_m[n][r] = bl2[ech + r];
+                    for (int j = 0; j < 8; ++j) held_store(j, p.out2);
+                    hpend = false;
+                    base_init();
                 }
                 fch = last ? 0 : fch + 1;
                 c_item = n_item;
@@ -1075,16 +1131,20 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
                 c_x0 = n_x0;
                 // (no barrier here: the scratch is next written by the halo commit of the coming unit, behind two of its barriers)
             } else {
+                asm volatile("" ::"v"(fence_w));                    // taps 0, 1 of unit B's weights have landed
                 K1_BARRIER();                                       // b2
             }
         };
         unit(std::integral_constant<int, 0>{});
         unit(std::integral_constant<int, 1>{});
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) held_store(j, p.out);               // the last tile's lines (nothing held: dropped)
 #undef K1_TILE
 #undef K1_REQUEST_ALL
 #undef K1_COMMIT1
 #undef K1_BARRIER
+#undef K1_DMA_W
 }
 
 hipError_t launch_conv3x3_c1c10(const ConvSplitParams& p, hipStream_t s) {

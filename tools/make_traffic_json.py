@@ -16,7 +16,7 @@ def per_kernel(db, ctr):
         span[(name, grid)] = (min(lo, dur), max(hi, dur))
     out = {}
     for name, grid, val, dur in raw:
-        if "conv_wino" not in name and "conv_mfma_kernel<3, 16, 2" not in name and "conv3x3_split16" not in name and "conv3x3_sf" not in name:
+        if "conv_wino" not in name and "conv_mfma_kernel<3, 16, 2" not in name and "conv3x3_split16" not in name and "conv3x3_sf" not in name and "conv3x3_c1c10" not in name:
             continue
         lo, hi = span[(name, grid)]
         cls = ""
