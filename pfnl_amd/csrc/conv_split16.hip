@@ -701,14 +701,19 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
 //   * it is not parked in registers for an epilogue spread over the next tile (32 registers) - it leaves at once, in a short SERIAL
 //     phase: bias (initial C) + leaky-relu + split in registers -> the unit's own halo buffer, free at that point, as 128 pixel lines
 //     of the split format (one output row of each of the 4 row pairs; two passes), from where
-//       - whole 256-byte lines go to HBM (`out`: inp1 in the split format, what conv2_i's chain kernel reads by LDS-DMA), and
+//       - whole 256-byte lines go to HBM (`out`: inp1 in the split format, what conv2_i's chain kernel reads by LDS-DMA) - picked
+//         up into 8 registers per thread here, stored one piece per sub-step under the NEXT tile's MFMAs (a CU moves store data at
+//         ~16 B per clock: the 32 KB of a row take 2 k cycles when waited for) - and
 //       - the lines come back as the B operands (k = channel, n = pixel) of conv10_i's slice of this frame, W10[64 f .. 64 f + 63][:],
 //         whose A operands (32 output channels x 16 input channels, hi / lo') stream from L2 into registers: 12 MFMAs per pass and
 //         wave (K = 64) into `base_m`, the 32 registers the parked tile used to take, which run through the T frames of the chain;
 //   * behind the chain's last frame `base_m` (+ bias: its initial value) takes the same road - leaky-relu, split, lines - to `out2`.
 // conv10_i as a launch of its own read inp1 (117 MB at configs[1]) back for 11 % of conv1_i's MFMAs; here it reads nothing.
-// The serial phase costs ~2.5 k cycles per tile (two passes x [80 VALU, 4 ds_write_b128, barrier, 8 ds_read_b128 + 12 MFMAs,
-// 4 line pieces]) of ~28 k.
+// The weight slices travel by LDS-DMA (no staging registers) and the halo pieces' source offsets are recomputed: 254 VGPRs.
+// The serial phase is ~4.5 - 5.5 k shader cycles per tile of ~26 k (tools/k1_timing.py: barrier waits 1.5 k, two dumps 1.1 k, the
+// two passes of operand / line reads + 12 MFMAs 2 - 2.7 k); rearranging it moves the launch time by nothing - the launch runs at the
+// pace the power cap gives its MFMAs; what the fusion saves is the 117 MB and a launch.
+
 // one LDS-DMA instruction: lane L's 16 bytes at (resource, voff) -> LDS [lds_dst + 16 L] (conv_sf.hip, sf_dma16: m0 saved / restored)
 // + a scalar byte offset on the memory side only (the instruction's immediate offset would move the LDS side as well)
 __device__ __forceinline__ void k1_dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds_dst, int voff, int soff) {

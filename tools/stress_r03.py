@@ -27,6 +27,17 @@ def run(seed=0, seconds=60.0):
         chain = ops.conv3x3_winograd(x, k2, b, act=True, addend=base, add_div=T, resid=res, variant="split16_sf_chain")
         assert torch.equal(chain, ops.conv3x3_winograd(x, k2, b, act=True, addend=base, add_div=T, resid=res, variant="split16_sf_chain")), ("chain not repeatable", T, clips, H, W)
         small = ops.conv_small(x, k2, b, a=base, a_div=T, resid=res)
+        # ... and the fused conv1_i + conv10_i launch against the direct f32 kernels, repeatable bit for bit
+        k1 = (rng.normal(size=(3, 3, 64, 64)) / 24.0).astype(np.float32)
+        k10 = (rng.normal(size=(1, 1, 64 * T, 64)) / np.sqrt(64 * T)).astype(np.float32)
+        f1, fb = ops.conv1_conv10_split16(x, k1, b, k10, b, T)
+        g1, gb = ops.conv1_conv10_split16(x, k1, b, k10, b, T)
+        assert torch.equal(f1, g1) and torch.equal(fb, gb), ("c1c10 not repeatable", T, clips, H, W)
+        r1 = ops.conv2d(x, k1, b, act=True)
+        rb = ops.conv2d(r1, k10, b, act=True, frames_per_item=T)
+        d10 = max(float((f1 - r1).abs().max()), float((fb - rb).abs().max()))
+        worst_op = max(worst_op, d10)
+        assert d10 < 2e-5, ("c1c10 mismatch", T, clips, H, W, d10)
         pb = ops.conv2d(base, np.ascontiguousarray(k2[:, :, :64]), None, act=False)
         ref = ops.conv2d(x, np.ascontiguousarray(k2[:, :, 64:]), b, act=True, addend=pb, add_div=T, resid=res)
         d = max(float((chain - ref).abs().max()), float((small - ref).abs().max()))
