@@ -66,6 +66,50 @@ def kernel_source_sha(files):
     return h.hexdigest()[:16]
 
 
+class PowerSampler:
+    """`rocm-smi --showpower --showclocks --showmaxpower` polled on a thread while the sustained steps run: the split-f16 kernels are
+    bound by the package power cap, so the line carries what the chip drew and the clock it settled at.  Best effort:
+    no rocm-smi, nothing reported."""
+
+    def __init__(self, device):
+        import threading
+        self.samples, self.cap, self._stop = [], None, threading.Event()
+        self.device = int(device)
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
+
+    def _run(self):
+        import re
+        import shutil
+        import subprocess
+        exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+        while not self._stop.is_set():
+            try:
+                out = subprocess.run([exe, "-d", str(self.device), "--showpower", "--showclocks", "--showmaxpower"], capture_output=True,
+                                     text=True, timeout=10).stdout
+            except Exception:
+                return
+            pw = re.search(r"(?:Current Socket|Average) Graphics Package Power \(W\): ([0-9.]+)", out)
+            ck = re.search(r"sclk clock level: \S+ \(([0-9]+)Mhz\)", out)
+            cap = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)", out)
+            if cap:
+                self.cap = float(cap.group(1))
+            if pw and ck and not self._stop.is_set():
+                self.samples.append((float(pw.group(1)), int(ck.group(1))))
+
+    def stop(self):
+        self._stop.set()
+        self._t.join(timeout=15)
+        s = [x for x in self.samples if x[0] > 0]
+        if not s:
+            return None
+        top = max(x[0] for x in s)
+        s = [x for x in s if x[0] >= 0.7 * top]                         # (a sample taken before the first step landed reads idle power)
+        return {"package_w": round(sum(x[0] for x in s) / len(s), 1), "package_w_max": max(x[0] for x in s), "cap_w": self.cap,
+                "sclk_mhz": round(sum(x[1] for x in s) / len(s)), "samples": len(s),
+                "source": "rocm-smi polled during the sustained run (the first samples may precede it)"}
+
+
 def cpu_baseline(weights, sample_clips, H, W, budget_s=24.0):
     """Times oracle/pfnl_fast.py (the CPU port of the reference graph) on this host."""
     import numpy as np
@@ -459,7 +503,12 @@ def main():
     if not args.no_secondary:
         # ---- sustained: >= 2 s of back-to-back steps, no events (clock droop shows up as ms/step above the headline's)
         n_sus = max(args.steps, int(2.2e3 / max(ms_per_step, 1e-3)) + 1)
+        sampler = PowerSampler(local_dev) if rank == 0 else None       # package power / shader clock while the sustained run is under way
         el = timed_steps(step, fence, n_sus)
+        if sampler is not None:
+            power = sampler.stop()
+            if power:
+                res["power"] = power
         if use_dist:
             if comm is not None:
                 el = float(comm.allreduce([el], "max")[0])
