@@ -145,7 +145,7 @@ struct pfnl_handle {
     // profiling: boundary events.  One event after every kernel launch (plus one at the start of a
     // forward); a launch's time = its event - the previous event, i.e. kernel + the gap before it.
     bool prof = false;
-    int prof_mode = 0;                // 1: every launch; 2: every launch outside the PF blocks + every 4th PF block
+    int prof_mode = 0;                // 1: every launch; 2: every launch outside the PF blocks + every 4th PF block; 3: the launches of one PF block only
     bool prof_gate = true;            // events are recorded for the launches issued now
     bool chain_open = false;          // an event has been recorded in the current forward
     std::vector<hipEvent_t> evs;
@@ -351,6 +351,9 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             if (h->prof_mode == 2) {
                 h->prof_gate = prof_sampled(c.num_block, i);
                 h->chain_open = false;
+            } else if (h->prof_mode == 3) {
+                h->prof_gate = i == c.num_block / 2;
+                h->chain_open = false;
             }
             {   // conv1_i (+ conv10_i from the LDS scratch its tiles pass through: conv_bf16.hip MODE 2)
                 ProfScope ps(h, s, PFNL_K_CONV3X3);
@@ -378,8 +381,8 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
                 HIPCHK(launch_conv3x3_bf16(q, s));
             }
         }
-        h->prof_gate = true;
-        if (h->prof_mode == 2) h->chain_open = false;
+        h->prof_gate = h->prof_mode != 3;
+        if (h->prof_mode >= 2) h->chain_open = false;
         {   // convmerge1 (:73-74): the accumulating mode of the bf16 3x3 kernel, fp32 out for the tail
             ProfScope ps(h, s, PFNL_K_MERGE1);
             ConvBf16Params q{a0, w16 + h->off16_m1, wd + h->off_m1_b, nullptr, nullptr, nullptr, H, W, F, T, 1};
@@ -417,6 +420,9 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
     for (int i = 0; i < (h->bf16 ? 0 : c.num_block); ++i) {   // model/pfnl.py:65-71
         if (h->prof_mode == 2) {          // sampled profiling: see prof_sampled; each sampled block with a fresh event chain
             h->prof_gate = prof_sampled(c.num_block, i);
+            h->chain_open = false;
+        } else if (h->prof_mode == 3) {   // the dominant class only: the launches of ONE block (3 events per forward)
+            h->prof_gate = i == c.num_block / 2;
             h->chain_open = false;
         }
         if (small) {
@@ -562,8 +568,8 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             }
         }
     }
-    h->prof_gate = true;
-    if (h->prof_mode == 2) h->chain_open = false;
+    h->prof_gate = h->prof_mode != 3;
+    if (h->prof_mode >= 2) h->chain_open = false;
     if (small && !h->bf16) {   // convmerge1 (:73-74): T sources, cout 48 zero-padded to 64
         {
             ProfScope ps(h, s, PFNL_K_MERGE1);
@@ -576,7 +582,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, Hfull, W, c.scale, 64, s, strip, rflag));
         }
         h->chain_open = false;
-        h->prof_gate = true;
+        h->prof_gate = h->prof_mode != 3;
         return 0;
     }
     const bool m1_s16 = algo == 4 && h->m1_algo != 2 && (long long)H * W * 256 < 0x7fffffffLL;
@@ -1360,8 +1366,8 @@ int pfnl_profile_enable(pfnl_handle* h, int enable) {
         if (prof_collect(h)) return fail(PFNL_ERR_HIP, "event collection failed");
     }
     h->prof = enable != 0;
-    h->prof_mode = enable == 2 ? 2 : (enable ? 1 : 0);
-    h->prof_gate = true;
+    h->prof_mode = enable == 2 ? 2 : enable == 3 ? 3 : (enable ? 1 : 0);
+    h->prof_gate = h->prof_mode != 3;
     return 0;
 }
 

@@ -154,7 +154,8 @@ class PFNLEngine:
 
     # ---- measurement / debugging ---------------------------------------------------------------
     def profile(self, enable) -> None:
-        """False/0: off; True/1: HIP events around every launch; 2: sampled (PF blocks 3, 13, ... from ten blocks up, every 4th below)."""
+        """False/0: off; True/1: HIP events around every launch; 2: sampled (PF blocks 3, 13, ... from ten blocks up, every 4th below);
+        3: the launches of one PF block only (the dominant classes, 3 events per forward)."""
         _capi.check(self._lib.pfnl_profile_enable(self._h, int(enable)))
 
     def profile_reset(self) -> None:
