@@ -309,3 +309,33 @@ def test_optional_theta_phi_layout():
     w[names[0]] = np.zeros((1, 1, 84, 84), np.float32)
     with pytest.raises(KeyError):
         check_weights(g, w)
+
+
+def test_bench_power_sampler_parses_rocm_smi(tmp_path, monkeypatch):
+    """bench.py's best-effort power sampler: the socket power and the shader clock out of rocm-smi's report (not its cap line), the
+    idle sample in front of the run dropped; no rocm-smi -> nothing reported."""
+    import importlib.util
+    import stat
+    import time
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fake = tmp_path / "rocm-smi"
+    cnt = tmp_path / "n"
+    fake.write_text("""#!/bin/sh
+n=$(cat %s 2>/dev/null || echo 0); n=$((n+1)); echo $n > %s
+if [ $n -le 1 ]; then p=250.0; c=157; else p=1370.0; c=1830; fi
+echo "GPU[0]		: sclk clock level: 1: (${c}Mhz)"
+echo "GPU[0]		: Current Socket Graphics Package Power (W): $p"
+echo "GPU[0]		: Max Graphics Package Power (W): 1400.0"
+""" % (cnt, cnt))
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ.get("PATH", ""))
+    s = bench.PowerSampler(0)
+    time.sleep(0.6)
+    got = s.stop()
+    assert got is not None and got["cap_w"] == 1400.0 and got["package_w"] == 1370.0 and got["sclk_mhz"] == 1830 and got["samples"] >= 1
+    monkeypatch.setenv("PATH", str(tmp_path / "nothing"))
+    import shutil
+    if shutil.which("rocm-smi") is None and not os.path.exists("/opt/rocm/bin/rocm-smi"):
+        assert bench.PowerSampler(0).stop() is None
