@@ -776,7 +776,9 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
     const int wbytes = W * 256;                                     // (py * wbytes + px * 256 + 16 (tid & 7)) is recomputed from it: no registers to spare
 #pragma unroll
     for (int k = 0; k < CS_ITERS; ++k) {
-        const int id = min(k * CS_THREADS + tid, CS_PIECES - 1);
+        // surplus threads redo a piece of the last pixel - the one with THEIR channel piece (tid & 7), so that the recomputed source
+        // offset below and the LDS address agree and the duplicate writes carry the same bytes
+        const int id = k * CS_THREADS + tid < CS_PIECES ? k * CS_THREADS + tid : CS_PIECES - 8 + (tid & 7);
         const int pix = id >> 3, c = id & 7;
         const int py = pix / CS_IW, px = pix - py * CS_IW;
         lpk[k] = ((py * CS_IW + px) * 128 + 8 * (c & 1) + (((c >> 1) ^ ((px >> 1) & 7)) << 4)) | (py << 16) | (px << 24);
