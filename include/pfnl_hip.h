@@ -43,7 +43,8 @@ typedef enum pfnl_status {
     PFNL_ERR_NOMEM = -4,
     PFNL_ERR_NODEVICE = -5,    /* no gfx950-capable device visible                             */
     PFNL_ERR_COMM = -6,        /* an RCCL call failed / RCCL could not be loaded               */
-    PFNL_ERR_RANGE = -7        /* pfnl_sync: a device-pointer forward left the f16-pipe kernels' range (see "strict_fp32") */
+    PFNL_ERR_RANGE = -7        /* a forward left the range of its binary16-operand kernels (see "strict_fp32"): pfnl_sync after a
+                                  device-pointer forward; pfnl_forward itself with host pointers under precision=bf16 (no f32 re-run there) */
 } pfnl_status;
 
 /* Mirrors the constants hard-coded in the reference (model/pfnl.py:21-23, 40-43). */
@@ -121,10 +122,10 @@ int pfnl_finalize_weights(pfnl_handle* h);
  * key "nl_sub_sample" = "1" (default, PFNL's call) | n: average-pool g and phi n x n on the space_to_depth grid (utils.py:27-28,35-36).
  *                 nl_type != 1 or nl_sub_sample > 1 run on the f32-MFMA kernel (nonlocal.hip) in both precisions.
  * key "bf16_conv10" = "fused" (default: conv10_i runs inside the conv1_i launch of the bf16 trunk) | "separate".
- * key "bf16_nonlocal" = "f16" (default: the non-local block of precision=bf16 on the f16 matrix pipe with binary16 operands,
- *                 fp32 accumulation and softmax state - nonlocal_f16.hip, hi parts only) | "split" (bf16 MFMA with hi + lo
- *                 split logits operands, probabilities rounded to bf16 - nonlocal_bf16.hip).  Both are within 1e-3 of the
- *                 fp64 block on [0,1]-scale outputs (measured 1e-4 ... 5e-4); "f16" needs a third of the MFMAs.
+ * key "bf16_nonlocal" = "f16" (the only value since round 4: the non-local block of precision=bf16 on the f16 matrix pipe with
+ *                 binary16 operands, fp32 accumulation and softmax state - nonlocal_f16.hip, hi parts only; within 1e-3 of the
+ *                 fp64 block on [0,1]-scale outputs, measured 1e-4 ... 5e-4.  Round 1's split-operand bf16 kernel - 2.5x the
+ *                 MFMAs at the same error - is kept out of the library under tools/experiments/nonlocal_bf16.hip).
  * The default can also be set with the environment variable PFNL_CONV3X3 read by pfnl_create. */
 int pfnl_set_option(pfnl_handle* h, const char* key, const char* value);
 
@@ -146,6 +147,14 @@ int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes);
 int pfnl_sync(pfnl_handle* h);
 /* number of synchronous forwards that were redone on the f32-MFMA kernels because the f16-pipe range flag was set */
 int pfnl_range_reruns(pfnl_handle* h, long long* count);
+/* The range flag of ASYNCHRONOUS (device-pointer) forwards, read and cleared WITHOUT synchronising: *flagged = 1 when a
+ * device-pointer forward that has completed since the last pfnl_sync / pfnl_range_flag wrote a non-finite value.  The caller
+ * orders the read behind the forwards it asks about (an event / stream synchronise of its own) - what a pipelined harness uses
+ * once per batch instead of pfnl_sync (pfnl_amd/model.py, the replacement of the loop around sess.run, reference
+ * model/pfnl.py:249-258).  Synchronous (host-pointer) forwards keep a flag of their own and never consume this one.  The fence
+ * is armed where a kernel with a binary16 domain runs and a non-finite value cannot be the reference's own result: not under
+ * strict_fp32 (f32-MFMA kernels throughout) and not with nl_type 2 (0 / 0 for a query without a positive affinity). */
+int pfnl_range_flag(pfnl_handle* h, int* flagged);
 
 /* ---- multi-GPU (RCCL over xGMI) ------------------------------------ */
 /* Clips are independent (reference model/pfnl.py:44,55: the batch is only the leading dimension), so ranks share NOTHING on
@@ -303,18 +312,13 @@ int pfnl_op_conv3x3_winograd_ws(const float* in, const float* kernel_host, const
 int pfnl_op_nonlocal(const float* x, const float* wg_host, const float* bg_host,
                      const float* ww_host, const float* bw_host, float* out,
                      int B, int T, int H, int W, void* stream);
-/* The same block on bf16 MFMA with split (hi + lo) operands and fp32 softmax state (option precision=bf16,
- * nonlocal_bf16.hip): same arguments, fp32 in and out. */
-int pfnl_op_nonlocal_bf16(const float* x, const float* wg_host, const float* bg_host,
-                     const float* ww_host, const float* bw_host, float* out,
-                     int B, int T, int H, int W, void* stream);
 /* The same block (fp32 in and out) on the f16 matrix pipe with exactly split operands (option nonlocal=split16, nonlocal_f16.hip):
  * Q, K, V and the probabilities are taken as f16(x) + f16(x - f16(x)), scaled by powers of two into binary16's normal range. */
 int pfnl_op_nonlocal_split16(const float* x, const float* wg_host, const float* bg_host,
                      const float* ww_host, const float* bw_host, float* out,
                      int B, int T, int H, int W, void* stream);
 /* The same kernel on the hi parts only - 16-bit (binary16) operands, fp32 accumulation and softmax state: the non-local block of
- * precision=bf16 (option bf16_nonlocal=f16, the default there; 24 instead of 72 MFMAs per 64 keys). */
+ * precision=bf16 (24 instead of 72 MFMAs per 64 keys). */
 int pfnl_op_nonlocal_f16(const float* x, const float* wg_host, const float* bg_host,
                      const float* ww_host, const float* bw_host, float* out,
                      int B, int T, int H, int W, void* stream);

@@ -48,6 +48,7 @@ SIGNATURES = {
     "pfnl_workspace_bytes": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_size_t)]),
     "pfnl_sync": (_i, [_vp]),
     "pfnl_range_reruns": (_i, [_vp, C.POINTER(C.c_longlong)]),
+    "pfnl_range_flag": (_i, [_vp, C.POINTER(_i)]),
     "pfnl_profile_enable": (_i, [_vp, _i]),
     "pfnl_profile_reset": (_i, [_vp]),
     "pfnl_profile_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -71,7 +72,6 @@ SIGNATURES = {
     "pfnl_op_nonlocal": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_nonlocal_split16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_nonlocal_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "pfnl_op_nonlocal_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_bicubic": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_blur_decimate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_selftest_mfma": (_i, [_i]),

@@ -129,18 +129,32 @@ def index_signature(prefix: str) -> str:
 
 def save_checkpoint(checkpoint_dir: str, weights: Dict[str, np.ndarray], step: int, model_name: str = "VSR",
                     fmt: str = "both") -> str:
-    os.makedirs(checkpoint_dir, exist_ok=True)
+    """Writes ``<model_name>-<step>`` and points the ``checkpoint`` state file at it (reference model/base_model.py:223-229).
+    fmt: "tf" = the reference's tensor bundle, "npz" = this build's cache format, "both" (default) = the bundle plus a cache that
+    carries the bundle's signature.  Contract of fmt="npz" next to an EXISTING bundle of the same step (the bundle wins at load
+    time unless the cache carries its signature): when the bundle holds exactly these weights the cache is (re)written as its
+    mirror - a loop that saves "both" once and "npz" afterwards keeps working; when it holds other weights the call raises
+    FileExistsError BEFORE touching the directory (no file written, the state file not moved) - save with fmt="both" to
+    rewrite the bundle, or remove it first."""
+    if fmt not in ("tf", "npz", "both"):
+        raise ValueError("fmt must be 'tf', 'npz' or 'both'")
     base = "{}-{}".format(model_name, int(step))
     prefix = os.path.join(checkpoint_dir, base)
+    arrs = {k: np.asarray(v, np.float32) for k, v in weights.items()}
+    if fmt == "npz" and os.path.isfile(prefix + ".index"):
+        from . import tfbundle
+        held = tfbundle.read_bundle(prefix)
+        same = set(held) >= set(arrs) and all(
+            held[k].shape == arrs[k].shape and np.array_equal(np.asarray(held[k], np.float32), arrs[k]) for k in arrs)
+        if not same:
+            raise FileExistsError("{}.index holds other weights: save with fmt='both' (rewrites it) or remove the bundle first"
+                                  .format(prefix))
+    os.makedirs(checkpoint_dir, exist_ok=True)
     if fmt in ("tf", "both"):
         from . import tfbundle
-        tfbundle.write_bundle(prefix, {k: np.asarray(v, np.float32) for k, v in weights.items()})
-    elif os.path.isfile(prefix + ".index"):
-        # only the cache format was asked for, but a reference-format bundle of this step exists: it would win at load time
-        # (different signature) and this function does not delete checkpoints behind the caller's back
-        raise FileExistsError("{}.index exists: save with fmt='both' (rewrites it) or remove the bundle first".format(prefix))
+        tfbundle.write_bundle(prefix, arrs)
     if fmt in ("npz", "both"):                                 # written last, with the signature of the bundle it mirrors
-        arrs = {k: np.asarray(v, np.float32) for k, v in weights.items()}
+        arrs = dict(arrs)
         arrs[_SIG_KEY] = np.array(index_signature(prefix))
         np.savez(prefix + ".npz", **arrs)
     elif os.path.isfile(prefix + ".npz"):

@@ -2,12 +2,18 @@
 // schedule of PFNL.forward (reference model/pfnl.py:39-80) as a sequence of HIP kernel launches.
 #include <dlfcn.h>
 
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pfnl_hip.h"
@@ -65,6 +71,93 @@ struct HostTensor {
     std::vector<float> data;
 };
 
+// Pinned (page-locked) host memory of the handle: the landing / take-off strip of host-pointer forwards.
+struct PinBuf {
+    unsigned char* p = nullptr;
+    size_t n = 0;   // bytes
+    int ensure(size_t bytes) {
+        if (bytes <= n) return 0;
+        release();
+        if (hipHostMalloc(reinterpret_cast<void**>(&p), bytes, hipHostMallocDefault) != hipSuccess) {
+            p = nullptr;
+            return -1;
+        }
+        n = bytes;
+        return 0;
+    }
+    void release() {
+        if (p) hipHostFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+// A few worker threads that move bytes between a caller's PAGEABLE buffers and the pinned strip while the copy engines move the
+// pinned side over PCIe (a host-pointer pfnl_forward is what the reference's sess.run timing covers, model/pfnl.py:249-253).
+// One job at a time: run(n, f) hands out chunk indices 0..n-1 in order; done(i) / wait() observe completion.
+struct HostPool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    std::function<void(int)> fn;
+    std::unique_ptr<std::atomic<int>[]> flag;
+    int cap = 0, n = 0, next = 0, finished = 0, device = 0;   // (a job is only started after the previous one has been waited for)
+    bool stop = false;
+    void start(int k, int dev) {
+        if (!th.empty()) return;
+        device = dev;
+        for (int i = 0; i < k; ++i) th.emplace_back([this] { loop(); });
+    }
+    void loop() {
+        hipSetDevice(device);
+        for (;;) {
+            int i;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_work.wait(lk, [&] { return stop || next < n; });
+                if (stop) return;
+                i = next++;
+            }
+            fn(i);
+            flag[i].store(1, std::memory_order_release);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                ++finished;
+            }
+            cv_done.notify_all();
+        }
+    }
+    void run(int count, std::function<void(int)> f) {
+        std::lock_guard<std::mutex> lk(m);
+        if (count > cap) {
+            flag.reset(new std::atomic<int>[count]);
+            cap = count;
+        }
+        for (int i = 0; i < count; ++i) flag[i].store(0, std::memory_order_relaxed);
+        fn = std::move(f);
+        n = count;
+        next = 0;
+        finished = 0;
+        cv_work.notify_all();
+    }
+    void wait_chunk(int i) {
+        while (!flag[i].load(std::memory_order_acquire)) std::this_thread::yield();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return finished >= n; });
+    }
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (auto& t : th) t.join();
+        th.clear();
+    }
+};
+
 }  // namespace
 
 struct pfnl_handle {
@@ -83,6 +176,7 @@ struct pfnl_handle {
         hipGraphExec_t exec;
         unsigned long long alloc_gen, cfg_gen;
         unsigned long long seen_cfg_gen;                          // cfg_gen at the eager run that `seen` counts
+        int slot;                                                 // range-flag word the captured tail kernel writes (0 synchronous / 1 asynchronous calls)
     };
     std::vector<GraphEntry> graphs;
     unsigned long long cfg_gen = 0;                           // bumped by finalize_weights / set_option
@@ -99,7 +193,6 @@ struct pfnl_handle {
     size_t off16s_m1 = 0;                                     // convmerge1, split-f16 packs: T consecutive (frame, both halves) packs
     int m1_algo = 0;                                          // convmerge1 with conv3x3=split16: 0 auto (= 1), 1 the split-f16 kernel's accumulating mode, 2 Winograd
     int conv_algo = 5;                                        // conv3x3: 5 auto (4 for large shapes, 3 for small), 0 direct, 1 winograd (4 waves / tile), 3 winograd_ws (persistent, wave-specialised), 4 split16 (f16 MFMA, split fp32 operands)
-    int bf16_nl = 1;                                          // non-local block of precision=bf16: 0 split-bf16 operands (nonlocal_bf16.hip), 1 f16 operands (nonlocal_f16.hip, hi parts; default)
     int nl_algo = 2;                                          // non-local block of the fp32 path: 0 f32 MFMA (nonlocal.hip), 1 split-f16 (nonlocal_f16.hip), 2 auto (1 from N = 1024 keys)
     DevBuf wdev16s;                                           // split-f16 packs of the 3x3 kernels (offsets in 16-bit elements)
     std::vector<size_t> off16s_c1, off16s_c2a, off16s_c2b, off16s_c10, off16s_c10f;   // (c10f: conv10_i as conv3x3_c1c10_kernel takes it)
@@ -111,7 +204,15 @@ struct pfnl_handle {
     // that into `rflag` (sticky device word).  Host-pointer calls read it before they return and, when it is set, redo the call on
     // the f32-MFMA kernels (no such domain: the reference's own arithmetic range); device-pointer calls stay asynchronous and
     // pfnl_sync reports PFNL_ERR_RANGE.  Option strict_fp32=on takes the f32-MFMA kernels from the start.
-    DevBuf rflag;
+    // Two sticky words in pinned, device-mapped host memory (written by the tail kernel with a system-scope store, read by the host
+    // without a copy once the stream is idle): [0] belongs to SYNCHRONOUS (host-pointer) calls, [1] to asynchronous (device-pointer)
+    // calls and is what pfnl_sync / pfnl_range_flag report - a host-pointer call never consumes a flag an earlier asynchronous call left.
+    unsigned* rflag_host = nullptr;
+    unsigned* rflag_dev = nullptr;
+    // host-pointer forwards: pinned strips + the threads that copy between them and the caller's pageable buffers
+    PinBuf pin_in, pin_out;
+    HostPool pool;
+    std::vector<hipEvent_t> d2h_ev;
     bool strict = false, strict_once = false, weights_f16_ok = true;
     long long range_reruns = 0;
     int small_mode = 0;                                       // option small=auto|on|off: the small-shape trunk kernels (auto: when a launch has < 256 tiles of 8x32 pixels)
@@ -265,7 +366,7 @@ size_t numel(const std::vector<int64_t>& s) {
 // `strip` != null: only LR rows [strip->yoff + core0, strip->yoff + core1) of the result are produced (single-clip sharding,
 // pfnl_forward_strip): the non-local block runs its queries [q0, q1) against ALL keys, the trunk runs on the strip + halo.
 int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull, int W, hipStream_t s,
-                   const StripGeom* strip = nullptr, int q0 = 0, int q1 = -1) {
+                   const StripGeom* strip = nullptr, int q0 = 0, int q1 = -1, int flag_slot = 1 /* 0: synchronous call, 1: asynchronous */) {
     const pfnl_config& c = h->cfg;
     const int T = c.num_frames, F = B * T;
     const int H = strip ? strip->Hs : Hfull;                       // rows the trunk buffers hold
@@ -285,7 +386,11 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
     h->lastW = W;
 
     const bool nl_strict = !h->bf16 && (h->strict || h->strict_once || !h->weights_f16_ok);
-    unsigned* const rflag = reinterpret_cast<unsigned*>(h->rflag.p);
+    // The range fence is armed only when a kernel with a binary16 DOMAIN runs (fp32 precision off the strict path: split-f16 trunk,
+    // non-local block and conv0; bf16 precision: its non-local block and conv0) and a non-finite value cannot be the reference's
+    // own result (nltype 2 divides 0 by 0 for a query without a positive affinity, utils.py:59-62).
+    const int nlt_fence = h->nl_type < 0 ? (h->nl_theta ? 0 : 1) : h->nl_type;
+    unsigned* const rflag = (nl_strict || nlt_fence == 2) ? nullptr : h->rflag_dev + flag_slot;
     {   // model/pfnl.py:55-60 (+ utils.py:18-71)
         ProfScope ps(h, s, PFNL_K_NL_PACK);
         HIPCHK(launch_nl_pack(in, h->X.p, B, T, Hfull, W, s));
@@ -319,14 +424,10 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             if (h->nl16.ensure((nl_f16_scratch_halfs(B, N) + 1) / 2)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
             HIPCHK(launch_nl_attn_f16(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p,
                                       reinterpret_cast<uint16_t*>(h->nl16.p), B, N, C, s, q0, q1));
-        } else if (h->bf16 && h->bf16_nl == 1) {   // 16-bit operands throughout: the f16 kernel on the hi parts only
+        } else if (h->bf16) {   // 16-bit operands throughout: the f16 kernel on the hi parts only
             if (h->nl16.ensure((nl_f16_scratch_halfs(B, N) + 1) / 2)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
             HIPCHK(launch_nl_attn_f16(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p,
                                       reinterpret_cast<uint16_t*>(h->nl16.p), B, N, C, s, q0, q1, false));
-        } else if (h->bf16) {
-            if (h->nl16.ensure((nl_bf16_scratch_halfs(B, N) + 1) / 2)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
-            HIPCHK(launch_nl_attn_bf16(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p,
-                                       reinterpret_cast<uint16_t*>(h->nl16.p), B, N, C, s, q0, q1));
         } else {
             HIPCHK(launch_nl_attn(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p, B, N, C, s, nullptr, q0, q1));
         }
@@ -677,11 +778,14 @@ int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
         delete h;
         return fail(PFNL_ERR_HIP, "hipStreamCreate failed");
     }
-    if (h->rflag.ensure(4) || hipMemset(h->rflag.p, 0, 16) != hipSuccess) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->rflag_host), 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&h->rflag_dev), h->rflag_host, 0) != hipSuccess) {
+        if (h->rflag_host) hipHostFree(h->rflag_host);
         hipStreamDestroy(h->stream);
         delete h;
         return fail(PFNL_ERR_NOMEM, "allocation failed");
     }
+    std::memset(h->rflag_host, 0, 64);
     if (const char* e = std::getenv("PFNL_STRICT_FP32")) h->strict = std::string(e) != "0" && std::string(e) != "off";
     const int T = cfg->num_frames, C = 12 * T;
     add_expected(h, "conv0", 5, 3, 64);
@@ -717,7 +821,12 @@ int pfnl_destroy(pfnl_handle* h) {
         if (g.exec) hipGraphExecDestroy(g.exec);
         if (g.graph) hipGraphDestroy(g.graph);
     }
-    for (DevBuf* b : {&h->rflag, &h->Q, &h->wdev16s, &h->wdev, &h->wdev16, &h->nl16, &h->X, &h->Xo, &h->nlp, &h->inp0, &h->inp1, &h->base, &h->pb, &h->merge,
+    h->pool.shutdown();
+    for (auto& e : h->d2h_ev) hipEventDestroy(e);
+    h->pin_in.release();
+    h->pin_out.release();
+    if (h->rflag_host) hipHostFree(h->rflag_host);
+    for (DevBuf* b : {&h->Xs, &h->Q, &h->wdev16s, &h->wdev, &h->wdev16, &h->nl16, &h->X, &h->Xo, &h->nlp, &h->inp0, &h->inp1, &h->base, &h->pb, &h->merge,
                       &h->stage_in, &h->stage_out, &h->scratch})
         b->release();
     delete h;
@@ -843,10 +952,8 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         h->nl_sub = n;
         return 0;
     }
-    if (k == "bf16_nonlocal") {
-        if (v == "split") h->bf16_nl = 0;
-        else if (v == "f16") h->bf16_nl = 1;
-        else return fail(PFNL_ERR_INVALID, "bf16_nonlocal must be split or f16");
+    if (k == "bf16_nonlocal") {   // (the split-bf16 kernel of round 1 left the library in round 4: tools/experiments/nonlocal_bf16.hip)
+        if (v != "f16") return fail(PFNL_ERR_INVALID, "bf16_nonlocal must be f16");
         return 0;
     }
     if (k == "nonlocal") {
@@ -1110,19 +1217,18 @@ int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes) {
              + 2 * B * T * P * 64                               // inp0, inp1
              + 3 * B * P * 64                                   // base, pb, merge (64 floats per pixel)
              + (size_t)B * T * P * 3 + (size_t)B * P * sc * sc * 3;   // stage_in, stage_out
-    if (h->bf16 || h->nl_algo != 0) f += (std::max(pfnl::nl_bf16_scratch_halfs(B, (int)N), pfnl::nl_f16_scratch_halfs(B, (int)N)) + 1) / 2;   // split K / V^T operands (bf16 or f16)
+    if (h->bf16 || h->nl_algo != 0) f += (pfnl::nl_f16_scratch_halfs(B, (int)N) + 1) / 2;   // split K / V^T operands (bf16 or f16)
     if (h->nl_theta) f += (size_t)B * N * CP;                   // projected queries (nltype 0 / 2)
     if (h->nl_sub > 1) f += (size_t)B * ((H / 2) / h->nl_sub) * ((W / 2) / h->nl_sub) * CP;   // pooled keys
     *bytes = f * sizeof(float);
     return 0;
 }
 
-// reads and clears the sticky range flag (the caller has synchronised the streams that may still be writing it)
-static int range_flag_take(pfnl_handle* h, int* flagged) {
-    unsigned f = 0;
-    HIPCHK(hipMemcpy(&f, h->rflag.p, sizeof(f), hipMemcpyDeviceToHost));
-    if (f) HIPCHK(hipMemset(h->rflag.p, 0, sizeof(f)));
-    *flagged = f != 0;
+// reads and clears a sticky range flag (pinned host memory; the caller has synchronised the work that may still be writing it)
+static int range_flag_take(pfnl_handle* h, int slot, int* flagged) {
+    volatile unsigned* const f = h->rflag_host + slot;
+    *flagged = *f != 0;
+    if (*flagged) *f = 0;
     return 0;
 }
 
@@ -1131,6 +1237,124 @@ int pfnl_range_reruns(pfnl_handle* h, long long* count) {
     *count = h->range_reruns;
     return 0;
 }
+
+// ---- host-pointer forwards: what moves between the caller's buffers and HBM (the reference times exactly this inside sess.run,
+// model/pfnl.py:249-253: feed_dict copy in, fetch copy out).  Pageable buffers go through the handle's pinned strips chunk by
+// chunk: worker threads copy host <-> pinned while the copy engine moves the pinned side over PCIe, so neither the runtime's own
+// single-threaded pageable staging (measured 6 GB/s: 2.95 ms of a 7.55 ms call at configs[1]) nor a whole-buffer memcpy is on
+// the critical path; buffers that are already page-locked (hipHostMalloc / hipHostRegister / torch pin_memory) are DMA targets as
+// they are.
+namespace {
+constexpr size_t STAGE_POOL_MIN = 512u << 10;     // below: one memcpy on the calling thread
+constexpr int STAGE_MAX_CHUNKS = 32;
+
+bool host_is_pinned(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();                   // (an ordinary malloc'ed pointer is "invalid value" to the runtime: not an error here)
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+void ensure_pool(pfnl_handle* h) {
+    if (!h->pool.th.empty()) return;
+    int k = 4;
+    if (const char* e = std::getenv("PFNL_HOST_THREADS")) k = std::atoi(e);
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 1 && k > hw - 1) k = hw - 1;
+    k = k < 1 ? 1 : (k > 16 ? 16 : k);
+    h->pool.start(k, h->cfg.device_id);
+}
+
+size_t stage_chunk_bytes(size_t bytes) {
+    size_t c = (bytes + STAGE_MAX_CHUNKS - 1) / STAGE_MAX_CHUNKS;
+    if (c < (1u << 20)) c = 1u << 20;
+    return (c + 4095) & ~(size_t)4095;
+}
+
+// caller's host buffer -> device, asynchronous on `s` (the pinned strip is free again once `s` has passed the copies)
+int stage_h2d(pfnl_handle* h, float* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (host_is_pinned(src)) {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+        return 0;
+    }
+    if (h->pin_in.ensure(bytes)) return fail(PFNL_ERR_NOMEM, "pinned staging allocation failed");
+    unsigned char* const pin = h->pin_in.p;
+    if (bytes < STAGE_POOL_MIN) {
+        std::memcpy(pin, src, bytes);
+        HIPCHK(hipMemcpyAsync(dst, pin, bytes, hipMemcpyHostToDevice, s));
+        return 0;
+    }
+    ensure_pool(h);
+    const size_t csz = stage_chunk_bytes(bytes);
+    const int n = (int)((bytes + csz - 1) / csz);
+    const unsigned char* const sp = static_cast<const unsigned char*>(src);
+    h->pool.run(n, [=](int i) {
+        const size_t off = (size_t)i * csz;
+        std::memcpy(pin + off, sp + off, std::min(csz, bytes - off));
+    });
+    hipError_t err = hipSuccess;
+    for (int i = 0; i < n; ++i) {
+        h->pool.wait_chunk(i);
+        const size_t off = (size_t)i * csz;
+        if (err == hipSuccess)
+            err = hipMemcpyAsync(reinterpret_cast<unsigned char*>(dst) + off, pin + off, std::min(csz, bytes - off), hipMemcpyHostToDevice, s);
+    }
+    h->pool.wait();
+    if (err != hipSuccess) return fail(PFNL_ERR_HIP, std::string("H2D staging: ") + hipGetErrorString(err));
+    return 0;
+}
+
+// device -> caller's host buffer; returns when `dst` is filled (`s` is idle then)
+int stage_d2h(pfnl_handle* h, void* dst, const float* src, size_t bytes, hipStream_t s) {
+    if (host_is_pinned(dst)) {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return 0;
+    }
+    if (h->pin_out.ensure(bytes)) return fail(PFNL_ERR_NOMEM, "pinned staging allocation failed");
+    unsigned char* const pin = h->pin_out.p;
+    if (bytes < STAGE_POOL_MIN) {
+        HIPCHK(hipMemcpyAsync(pin, src, bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        std::memcpy(dst, pin, bytes);
+        return 0;
+    }
+    ensure_pool(h);
+    const size_t csz = stage_chunk_bytes(bytes);
+    const int n = (int)((bytes + csz - 1) / csz);
+    while ((int)h->d2h_ev.size() < n) {
+        hipEvent_t e = nullptr;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->d2h_ev.push_back(e);
+    }
+    for (int i = 0; i < n; ++i) {
+        const size_t off = (size_t)i * csz;
+        HIPCHK(hipMemcpyAsync(pin + off, reinterpret_cast<const unsigned char*>(src) + off, std::min(csz, bytes - off), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(h->d2h_ev[i], s));
+    }
+    HIPCHK(hipEventSynchronize(h->d2h_ev[0]));     // (the forward itself: waited for here, not by every worker)
+    unsigned char* const dp = static_cast<unsigned char*>(dst);
+    hipEvent_t* const ev = h->d2h_ev.data();
+    h->pool.run(n, [=](int i) {
+        const size_t off = (size_t)i * csz;
+        (void)hipEventSynchronize(ev[i]);
+        std::memcpy(dp + off, pin + off, std::min(csz, bytes - off));
+    });
+    h->pool.wait();
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+const char* const RANGE_MSG_FP32 =
+    "a device-pointer forward since the last check produced non-finite values: an operand left the range of the f16-pipe kernels "
+    "(|x| < 65504; the non-local block: inputs on a [0,1] scale) or the input was not finite. Re-run with "
+    "pfnl_set_option(h, \"strict_fp32\", \"on\") (f32-MFMA kernels: the reference's range), or use host pointers";
+const char* const RANGE_MSG_BF16 =
+    "a precision=bf16 forward produced non-finite values: the input was not finite, or it left the range of the binary16 operands of "
+    "this precision's non-local block and conv0 (inputs on a [0,1] scale, |x| < ~350). precision=fp32 covers the whole fp32 range";
+}  // namespace
 
 int pfnl_forward(pfnl_handle* h, const void* in, int in_is_device, void* out, int out_is_device, int B,
                  int H, int W, void* stream) {
@@ -1144,6 +1368,9 @@ int pfnl_forward(pfnl_handle* h, const void* in, int in_is_device, void* out, in
     const size_t n_in = (size_t)B * T * H * W * 3, n_out = (size_t)B * H * W * sc * sc * 3;
     const float* din = (const float*)in;
     float* dout = (float*)out;
+    const bool sync_call = !in_is_device || !out_is_device;     // a host pointer: the call returns with `out` filled
+    const int slot = sync_call ? 0 : 1;                         // whose range flag the tail kernel of this call writes
+    const bool can_rerun = !h->bf16 && !(h->strict || !h->weights_f16_ok);
     const bool want_graph = !h->prof && (h->graph_mode == 2 || (h->graph_mode == 1 && (size_t)B * T * H * W <= 65536));
     // stream == NULL: device-pointer calls are launched on the LEGACY NULL STREAM itself (what a caller that passes
     // torch.cuda.current_stream().cuda_stream == 0 means: same-stream ordering with everything it has enqueued and will
@@ -1153,9 +1380,9 @@ int pfnl_forward(pfnl_handle* h, const void* in, int in_is_device, void* out, in
         if (h->stage_in.ensure(n_in) || h->stage_out.ensure(n_out)) return fail(PFNL_ERR_NOMEM, "staging allocation failed");
         pfnl_handle::GraphEntry* ge = nullptr;
         for (auto& g : h->graphs)
-            if (g.B == B && g.H == H && g.W == W) ge = &g;
+            if (g.B == B && g.H == H && g.W == W && g.slot == slot) ge = &g;
         if (!ge) {
-            h->graphs.push_back({B, H, W, 0, nullptr, nullptr, 0, 0, h->cfg_gen});
+            h->graphs.push_back({B, H, W, 0, nullptr, nullptr, 0, 0, h->cfg_gen, slot});
             ge = &h->graphs.back();
         }
         if (ge->exec && (ge->alloc_gen != g_alloc_gen || ge->cfg_gen != h->cfg_gen)) {   // buffers moved / weights or options changed
@@ -1172,7 +1399,7 @@ int pfnl_forward(pfnl_handle* h, const void* in, int in_is_device, void* out, in
         if (!ge->exec && ge->seen >= 1) {
             // second call with this shape (the first one ran eagerly: workspaces allocated, kernel attributes set)
             HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            const int fe = forward_device(h, h->stage_in.p, h->stage_out.p, B, H, W, s);
+            const int fe = forward_device(h, h->stage_in.p, h->stage_out.p, B, H, W, s, nullptr, 0, -1, slot);
             hipGraph_t g = nullptr;
             const hipError_t ce = hipStreamEndCapture(s, &g);
             if (fe) return fe;
@@ -1197,24 +1424,35 @@ int pfnl_forward(pfnl_handle* h, const void* in, int in_is_device, void* out, in
                 HIPCHK(hipEventRecord(h->gev, nullptr));
                 HIPCHK(hipStreamWaitEvent(s, h->gev, 0));
             }
-            HIPCHK(hipMemcpyAsync(h->stage_in.p, in, n_in * sizeof(float),
-                                  in_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+            if (in_is_device)
+                HIPCHK(hipMemcpyAsync(h->stage_in.p, in, n_in * sizeof(float), hipMemcpyDeviceToDevice, s));
+            else if (int e = stage_h2d(h, h->stage_in.p, in, n_in * sizeof(float), s))
+                return e;
             HIPCHK(hipGraphLaunch(ge->exec, s));
-            HIPCHK(hipMemcpyAsync(out, h->stage_out.p, n_out * sizeof(float),
-                                  out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
-            if (!in_is_device || !out_is_device) {
-                HIPCHK(hipStreamSynchronize(s));
+            if (out_is_device)
+                HIPCHK(hipMemcpyAsync(out, h->stage_out.p, n_out * sizeof(float), hipMemcpyDeviceToDevice, s));
+            if (sync_call) {
+                if (!out_is_device) {
+                    if (int e = stage_d2h(h, out, h->stage_out.p, n_out * sizeof(float), s)) return e;
+                } else {
+                    HIPCHK(hipStreamSynchronize(s));
+                }
                 int flagged = 0;
-                if (int e = range_flag_take(h, &flagged)) return e;
-                if (flagged && !h->bf16 && !(h->strict || !h->weights_f16_ok)) {   // once more, eagerly, on the f32-MFMA kernels
+                if (int e = range_flag_take(h, 0, &flagged)) return e;
+                if (flagged && can_rerun) {   // once more, eagerly, on the f32-MFMA kernels
                     h->strict_once = true;
-                    const int e = forward_device(h, h->stage_in.p, h->stage_out.p, B, H, W, s);
+                    const int e = forward_device(h, h->stage_in.p, h->stage_out.p, B, H, W, s, nullptr, 0, -1, 0);
                     h->strict_once = false;
                     if (e) return e;
                     ++h->range_reruns;
-                    HIPCHK(hipMemcpyAsync(out, h->stage_out.p, n_out * sizeof(float), out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
-                    HIPCHK(hipStreamSynchronize(s));
-                    if (int e2 = range_flag_take(h, &flagged)) return e2;
+                    if (out_is_device) {
+                        HIPCHK(hipMemcpyAsync(out, h->stage_out.p, n_out * sizeof(float), hipMemcpyDeviceToDevice, s));
+                        HIPCHK(hipStreamSynchronize(s));
+                    } else if (int e2 = stage_d2h(h, out, h->stage_out.p, n_out * sizeof(float), s)) {
+                        return e2;
+                    }
+                } else if (flagged && h->bf16) {
+                    return fail(PFNL_ERR_RANGE, RANGE_MSG_BF16);
                 }
             } else if (!stream) {
                 HIPCHK(hipEventRecord(h->gev, s));
@@ -1229,34 +1467,37 @@ int pfnl_forward(pfnl_handle* h, const void* in, int in_is_device, void* out, in
     }
     if (!in_is_device) {
         if (h->stage_in.ensure(n_in)) return fail(PFNL_ERR_NOMEM, "staging allocation failed");
-        HIPCHK(hipMemcpyAsync(h->stage_in.p, in, n_in * sizeof(float), hipMemcpyHostToDevice, s));
+        if (int e = stage_h2d(h, h->stage_in.p, in, n_in * sizeof(float), s)) return e;
         din = h->stage_in.p;
     }
     if (!out_is_device) {
         if (h->stage_out.ensure(n_out)) return fail(PFNL_ERR_NOMEM, "staging allocation failed");
         dout = h->stage_out.p;
     }
-    if (int e = forward_device(h, din, dout, B, H, W, s)) return e;
+    if (int e = forward_device(h, din, dout, B, H, W, s, nullptr, 0, -1, slot)) return e;
     if (!out_is_device) {
-        HIPCHK(hipMemcpyAsync(out, dout, n_out * sizeof(float), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        if (int e = stage_d2h(h, out, dout, n_out * sizeof(float), s)) return e;
     } else if (!in_is_device) {
         HIPCHK(hipStreamSynchronize(s));   // the caller may reuse its host buffer on return
     }
-    if (!in_is_device || !out_is_device) {
-        // a synchronous call: the range flag is read before it returns; set = the f16-pipe domain was left somewhere (or the
-        // input itself was non-finite): once more on the f32-MFMA kernels, whose range is the reference's
+    if (sync_call) {
+        // a synchronous call: its range flag (slot 0, pinned) is read before it returns; set = the f16-pipe domain was left somewhere
+        // (or the input itself was non-finite): once more on the f32-MFMA kernels, whose range is the reference's
         int flagged = 0;
-        if (int e = range_flag_take(h, &flagged)) return e;
-        if (flagged && !h->bf16 && !(h->strict || !h->weights_f16_ok)) {
+        if (int e = range_flag_take(h, 0, &flagged)) return e;
+        if (flagged && can_rerun) {
             h->strict_once = true;
-            const int e = forward_device(h, din, dout, B, H, W, s);
-            h->strict_once = false;
+            const int e = forward_device(h, din, dout, B, H, W, s, nullptr, 0, -1, 0);   // (strict: the fence is not armed; still
+            h->strict_once = false;                                                    //  non-finite = so is the reference's result)
             if (e) return e;
             ++h->range_reruns;
-            if (!out_is_device) HIPCHK(hipMemcpyAsync(out, dout, n_out * sizeof(float), hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-            if (int e2 = range_flag_take(h, &flagged)) return e2;   // (still non-finite: so is the reference's result - returned as is)
+            if (!out_is_device) {
+                if (int e2 = stage_d2h(h, out, dout, n_out * sizeof(float), s)) return e2;
+            } else {
+                HIPCHK(hipStreamSynchronize(s));
+            }
+        } else if (flagged && h->bf16) {
+            return fail(PFNL_ERR_RANGE, RANGE_MSG_BF16);
         }
     }
     return 0;
@@ -1291,12 +1532,14 @@ int pfnl_sync(pfnl_handle* h) {
     HIPCHK(hipStreamSynchronize(nullptr));                     // device-pointer calls with stream == NULL run on the null stream
     // (a device-pointer call on a stream of the caller's: the caller synchronises that stream before pfnl_sync)
     int flagged = 0;
-    if (int e = range_flag_take(h, &flagged)) return e;
-    if (flagged)
-        return fail(PFNL_ERR_RANGE, "a device-pointer forward since the last check produced non-finite values: an operand left the range of the "
-                                    "f16-pipe kernels (|x| < 65504; the non-local block: inputs on a [0,1] scale) or the input was not finite. "
-                                    "Re-run with pfnl_set_option(h, \"strict_fp32\", \"on\") (f32-MFMA kernels: the reference's range), or use host pointers");
+    if (int e = range_flag_take(h, 1, &flagged)) return e;
+    if (flagged) return fail(PFNL_ERR_RANGE, h->bf16 ? RANGE_MSG_BF16 : RANGE_MSG_FP32);
     return 0;
+}
+
+int pfnl_range_flag(pfnl_handle* h, int* flagged) {
+    if (!h || !flagged) return fail(PFNL_ERR_INVALID, "NULL argument");
+    return range_flag_take(h, 1, flagged);
 }
 
 // Weight replica over RCCL (comm.hip holds the communicator): the packed device blobs root -> all.
@@ -1944,7 +2187,7 @@ int pfnl_op_conv3x3_winograd_ws(const float* in, const float* kernel_host, const
 }
 
 
-static int op_nonlocal(int bf16 /* 0 f32, 1 bf16 split, 2 f16 split, 3 f16 (hi parts only) */, const float* x, const float* wg, const float* bg, const float* ww, const float* bw,
+static int op_nonlocal(int bf16 /* 0 f32, 2 f16 split, 3 f16 (hi parts only) */, const float* x, const float* wg, const float* bg, const float* ww, const float* bw,
                        float* out, int B, int T, int H, int W, void* stream) {
     if (!x || !wg || !bg || !ww || !bw || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
     if ((T != 3 && T != 5 && T != 7) || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1))
@@ -1966,7 +2209,7 @@ static int op_nonlocal(int bf16 /* 0 f32, 1 bf16 split, 2 f16 split, 3 f16 (hi p
     float* d = nullptr;
     const size_t nX = (size_t)B * N * CP;
     const size_t nP = pfnl::nl_partial_floats(B, N, C);
-    const size_t n16 = bf16 ? (pfnl::nl_bf16_scratch_halfs(B, N) + 1) / 2 : 0;   // in floats (same size for the f16 variant)
+    const size_t n16 = bf16 ? (pfnl::nl_f16_scratch_halfs(B, N) + 1) / 2 : 0;   // in floats
     HIPCHK(hipMalloc(&d, (blob.size() + 2 * nX + nP + n16 + 64) * sizeof(float)));
     float* dX = d + blob.size();
     float* dXo = dX + nX;
@@ -1976,7 +2219,6 @@ static int op_nonlocal(int bf16 /* 0 f32, 1 bf16 split, 2 f16 split, 3 f16 (hi p
     if (e == hipSuccess) e = pfnl::launch_nl_pack(x, dX, B, T, H, W, s);
     if (e == hipSuccess)
         e = bf16 >= 2 ? pfnl::launch_nl_attn_f16(dX, dXo, d, d + (size_t)CP * CP, dP, d16, B, N, C, s, 0, -1, bf16 == 2)
-          : bf16    ? pfnl::launch_nl_attn_bf16(dX, dXo, d, d + (size_t)CP * CP, dP, d16, B, N, C, s)
                     : pfnl::launch_nl_attn(dX, dXo, d, d + (size_t)CP * CP, dP, B, N, C, s);
     if (e == hipSuccess) e = pfnl::launch_nl_unpack(dXo, out, B, T, H, W, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -1988,11 +2230,6 @@ static int op_nonlocal(int bf16 /* 0 f32, 1 bf16 split, 2 f16 split, 3 f16 (hi p
 int pfnl_op_nonlocal(const float* x, const float* wg, const float* bg, const float* ww, const float* bw,
                      float* out, int B, int T, int H, int W, void* stream) {
     return op_nonlocal(0, x, wg, bg, ww, bw, out, B, T, H, W, stream);
-}
-
-int pfnl_op_nonlocal_bf16(const float* x, const float* wg, const float* bg, const float* ww, const float* bw,
-                          float* out, int B, int T, int H, int W, void* stream) {
-    return op_nonlocal(1, x, wg, bg, ww, bw, out, B, T, H, W, stream);
 }
 
 int pfnl_op_nonlocal_split16(const float* x, const float* wg, const float* bg, const float* ww, const float* bw,

@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #ifndef PFNL_WINO_WPS
 #define PFNL_WINO_WPS 3      // waves per SIMD the Winograd kernel is compiled for (= workgroups per CU)
 #endif
@@ -35,6 +37,23 @@ template <int AUX = 0>                                              // AUX: the 
 __device__ __forceinline__ void buffer_store_b128_guarded(pfnl_u32x4 v, __amdgpu_buffer_rsrc_t rs, int voffset, int soffset) {
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, voffset, soffset, AUX);
     asm volatile("s_nop 1" ::"v"(v));
+}
+
+// Launch-time facts that are per DEVICE.  One process may drive several devices from several host threads (pfnl_comm_init_all, one
+// handle per device): the launchers' lazy caches are indexed by the device and their slots are std::atomic, so a first launch
+// racing with another thread's is a repeated, identical initialisation - not a data race, and never another device's CU count.
+inline int device_cu_count() {                                      // CUs of the CURRENT device (0: it cannot be queried)
+    static std::atomic<int> ncu[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int n = ncu[dev].load(std::memory_order_relaxed);
+    if (!n) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 0;
+        ncu[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
 }
 
 __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, 0.2f * v); }  // tf.nn.leaky_relu
@@ -134,7 +153,7 @@ hipError_t launch_conv0(const float* Xo, const float* w75x64, const float* bias,
                         int T, int H, int W, hipStream_t s, const StripGeom* strip = nullptr, bool force_f32 = false);   // force_f32: the VALU fp32 kernel
 hipError_t launch_tail(const float* merge, const float* x, const float* w2, const float* b2,
                        float* out, int B, int T, int H, int W, int scale, int merge_cstride, hipStream_t s,
-                       const StripGeom* strip = nullptr, unsigned* nonfinite = nullptr);   // nonfinite: OR-ed with 1 if a written value is inf / NaN
+                       const StripGeom* strip = nullptr, unsigned* nonfinite = nullptr);   // nonfinite: set to 1 if a written value is inf / NaN (device or device-mapped host memory)
 hipError_t launch_blur_decimate(const float* hr, float* lr, int F, int H, int W, int scale, hipStream_t s);
 hipError_t launch_bicubic(const float* x, float* out, int B, int H, int W, int scale, hipStream_t s);
 hipError_t run_mfma_selftest(int* mismatches);

@@ -33,10 +33,6 @@ size_t conv3x3_bf16_pack_halfs();
 void conv3x3_bf16_pack_weights(const float* hwio, int cin_total, int cin_begin, uint16_t* dst, int cout = 64);   // cout < 64: zero-padded
 size_t conv1x1_bf16_pack_halfs(int T);
 void conv1x1_bf16_pack_weights(const float* hwio, int T, uint16_t* dst);
-// non-local block on bf16 MFMA with split (hi + lo) operands (nonlocal_bf16.hip)
-size_t nl_bf16_scratch_halfs(int B, int N);
-hipError_t launch_nl_attn_bf16(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, uint16_t* scratch16,
-                               int B, int N, int C, hipStream_t s, int q0 = 0, int q1 = -1);   // queries [q0, q1) only (-1: N)
 // conv0 writing the bf16 trunk input (misc_kernels.hip)
 struct StripGeom;
 hipError_t launch_conv0_bf16(const float* Xo, const float* w75x64, const float* bias, uint16_t* out, int B, int T, int H,

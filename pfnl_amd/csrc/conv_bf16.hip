@@ -569,30 +569,25 @@ hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s) {
     if (!p.in || !p.wpack || !p.bias || (!p.out && !p.out_f32) || p.items < 1 || p.H < 1 || p.W < 1) return hipErrorInvalidValue;
     if ((p.addend == nullptr) != (p.resid == nullptr) || (p.addend && (p.add_div < 1 || p.items % p.add_div))) return hipErrorInvalidValue;
     if ((long long)p.H * p.W * 128 >= 0x7fffffffLL) return hipErrorInvalidValue;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-        ncu = prop.multiProcessorCount;
-    }
+    const int ncu = device_cu_count();
+    if (!ncu) return hipErrorUnknown;
     const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;                    // whole XCDs; surplus workgroups exit at once
     const bool accum = p.out_f32 != nullptr;
     if (accum && (p.addend || p.x_out || p.add_div < 1 || p.items % p.add_div)) return hipErrorInvalidValue;
     const bool with10 = p.x_out != nullptr;
     if (with10 && (p.addend || !p.x_w || !p.x_bias || p.add_div < 1 || p.add_div > 7 || p.items % p.add_div)) return hipErrorInvalidValue;
     const int mode = accum ? 3 : (p.addend ? 1 : (with10 ? 2 : 0));
-    static bool attr_dev[64][4] = {};                               // the attribute is per device
+    static std::atomic<int> attr_dev[64][4];                               // the attribute is per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    bool* const attr = attr_dev[dev];
+    std::atomic<int>* const attr = attr_dev[dev];
     const void* fn = mode == 1 ? reinterpret_cast<const void*>(conv3x3_bf16_kernel<1>)
                    : mode == 2 ? reinterpret_cast<const void*>(conv3x3_bf16_kernel<2>)
                    : mode == 3 ? reinterpret_cast<const void*>(conv3x3_bf16_kernel<3>) : reinterpret_cast<const void*>(conv3x3_bf16_kernel<0>);
     if (!attr[mode]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr[mode] = true;
+        attr[mode] = 1;
     }
     if (mode == 1) hipLaunchKernelGGL(conv3x3_bf16_kernel<1>, dim3(grid), dim3(CB_THREADS), CB_LDS_BYTES, s, p);
     else if (mode == 2) hipLaunchKernelGGL(conv3x3_bf16_kernel<2>, dim3(grid), dim3(CB_THREADS), CB_LDS_BYTES, s, p);

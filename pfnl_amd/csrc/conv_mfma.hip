@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
 template <int KS, int CK_, int MT, bool FUSE>
 static hipError_t launch_variant(const ConvParams& p, int items, hipStream_t s) {
     const dim3 grid((p.W + CONV_TW - 1) / CONV_TW, (p.H + 4 * MT - 1) / (4 * MT), items);
-    static bool attr_set[64] = {false};
+    static std::atomic<int> attr_set[64];
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -221,7 +221,7 @@ static hipError_t launch_variant(const ConvParams& p, int items, hipStream_t s) 
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<KS, CK_, MT, FUSE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ConvGeom<KS, CK_, MT>::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set[dev] = true;
+        attr_set[dev] = 1;
     }
     constexpr size_t lds_bytes = ConvGeom<KS, CK_, MT>::LDS_BYTES;
     hipLaunchKernelGGL((conv_mfma_kernel<KS, CK_, MT, FUSE>), grid, dim3(256), lds_bytes, s, p);

@@ -758,18 +758,14 @@ hipError_t launch_conv3x3_sf_chain(const ConvSplitParams& p, hipStream_t s) {
     if ((long long)p.H * p.W * 256 >= 0x7fffffffLL) return hipErrorInvalidValue;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    static int ncu[64] = {};
-    if (!ncu[dev]) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-        ncu[dev] = prop.multiProcessorCount;
-    }
-    const int grid = ncu[dev] >= 8 ? ncu[dev] / 8 * 8 : 8;
-    static bool attr_dev[64] = {};
+    const int ncu = device_cu_count();
+    if (!ncu) return hipErrorUnknown;
+    const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;
+    static std::atomic<int> attr_dev[64];
     if (!attr_dev[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_sf_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_dev[dev] = true;
+        attr_dev[dev] = 1;
     }
     hipLaunchKernelGGL(conv3x3_sf_chain_kernel, dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, p);
     return hipGetLastError();
@@ -781,20 +777,16 @@ hipError_t launch_conv3x3_sf(const ConvSplitParams& p, hipStream_t s) {
     if ((long long)p.H * p.W * 256 >= 0x7fffffffLL) return hipErrorInvalidValue;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    static int ncu[64] = {};
-    if (!ncu[dev]) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-        ncu[dev] = prop.multiProcessorCount;
-    }
-    const int grid = ncu[dev] >= 8 ? ncu[dev] / 8 * 8 : 8;          // whole XCDs; surplus workgroups exit at once
-    static bool attr_dev[64][2] = {};                               // the attribute is per device
+    const int ncu = device_cu_count();
+    if (!ncu) return hipErrorUnknown;
+    const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;          // whole XCDs; surplus workgroups exit at once
+    static std::atomic<int> attr_dev[64][2];                               // the attribute is per device
     const int mode = p.addend ? 1 : 0;
     const void* fn = mode ? reinterpret_cast<const void*>(conv3x3_sf_kernel<1>) : reinterpret_cast<const void*>(conv3x3_sf_kernel<0>);
     if (!attr_dev[dev][mode]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_dev[dev][mode] = true;
+        attr_dev[dev][mode] = 1;
     }
     if (mode) hipLaunchKernelGGL(conv3x3_sf_kernel<1>, dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, p);
     else hipLaunchKernelGGL(conv3x3_sf_kernel<0>, dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, p);

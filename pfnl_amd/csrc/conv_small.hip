@@ -344,13 +344,13 @@ __global__ __launch_bounds__(CM1_THREADS, 2) void conv_small_1x1_kernel(ConvSmal
 template <int KS, int R>
 static hipError_t cm_launch(const ConvSmallParams& p, int tiles, hipStream_t s) {
     using G = CmGeom<KS, R>;
-    static bool attr_dev[64] = {};
+    static std::atomic<int> attr_dev[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_dev[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_small_kernel<KS, R>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_dev[dev] = true;
+        attr_dev[dev] = 1;
     }
     hipLaunchKernelGGL((conv_small_kernel<KS, R>), dim3(tiles), dim3(CM_THREADS), G::LDS_BYTES, s, p);
     return hipGetLastError();
@@ -364,13 +364,8 @@ hipError_t launch_conv_small(const ConvSmallParams& p, hipStream_t s) {
     // rows per workgroup (one 8-wave workgroup per CU at a time): a CU's time is ~ (workgroups it gets) x R, so minimise
     // ceil(workgroups / CUs) x R; ties go to the larger R (fewer workgroups to dispatch, fewer weight bytes).
     // 7 x 32 x 32 -> R = 1 (224 workgroups), 5 x 64 x 64 -> R = 3 (220), 7 x 64 x 64 -> R = 2 (448)
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int ncu = device_cu_count();                              // (of the device this launch goes to)
+    if (!ncu) return hipErrorUnknown;
     long long tr[4] = {0, 0, 0, 0};
     int bestR = 1;
     long long best = -1;

@@ -47,8 +47,8 @@ hipError_t launch_conv3x3_sf_chain(const ConvSplitParams& p, hipStream_t s);
 hipError_t launch_sf_from_f32(const float* in, uint16_t* out, size_t npix, hipStream_t s);   // [npix][64] fp32 -> SF (tests / taps)
 hipError_t launch_sf_to_f32(const uint16_t* in, float* out, size_t npix, hipStream_t s);     // SF -> hi + lo' 2^-11
 
-// non-local block of the fp32 path on the f16 matrix pipe with exactly split operands (nonlocal_f16.hip); arguments as
-// launch_nl_attn_bf16 (conv_bf16.h)
+// non-local block of the fp32 path on the f16 matrix pipe with exactly split operands (nonlocal_f16.hip); arguments as launch_nl_attn
+// (common.h) plus the operand scratch; split = false: the hi parts only (the non-local block of precision=bf16)
 size_t nl_f16_scratch_halfs(int B, int N);
 hipError_t launch_nl_attn_f16(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, uint16_t* scratch16,
                               int B, int N, int C, hipStream_t s, int q0 = 0, int q1 = -1, bool split = true);

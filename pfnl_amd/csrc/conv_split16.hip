@@ -1160,18 +1160,14 @@ hipError_t launch_conv3x3_c1c10(const ConvSplitParams& p, hipStream_t s) {
     if ((long long)p.H * p.W * 256 >= 0x7fffffffLL) return hipErrorInvalidValue;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    static int ncu[64] = {};
-    if (!ncu[dev]) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-        ncu[dev] = prop.multiProcessorCount;
-    }
-    const int grid = ncu[dev] >= 8 ? ncu[dev] / 8 * 8 : 8;
-    static bool attr_dev[64] = {};
+    const int ncu = device_cu_count();
+    if (!ncu) return hipErrorUnknown;
+    const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;
+    static std::atomic<int> attr_dev[64];
     if (!attr_dev[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c1c10_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, K1_LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_dev[dev] = true;
+        attr_dev[dev] = 1;
     }
     hipLaunchKernelGGL(conv3x3_c1c10_kernel, dim3(grid), dim3(CS_THREADS), K1_LDS_BYTES, s, p);
     return hipGetLastError();
@@ -1182,15 +1178,10 @@ hipError_t launch_conv3x3_split16(const ConvSplitParams& p, hipStream_t s) {
     if ((p.addend == nullptr) != (p.resid == nullptr) || (p.addend && (p.add_div < 1 || p.items % p.add_div))) return hipErrorInvalidValue;
     if (p.accum && (p.addend || p.add_div < 1 || p.items % p.add_div)) return hipErrorInvalidValue;
     if ((long long)p.H * p.W * 256 >= 0x7fffffffLL) return hipErrorInvalidValue;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-        ncu = prop.multiProcessorCount;
-    }
+    const int ncu = device_cu_count();
+    if (!ncu) return hipErrorUnknown;
     const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;                    // whole XCDs; surplus workgroups exit at once
-    static bool attr_dev[64][4] = {};                               // the attribute is per device
+    static std::atomic<int> attr_dev[64][4];                               // the attribute is per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (p.out_sf && (p.accum || p.addend)) return hipErrorInvalidValue;
@@ -1201,7 +1192,7 @@ hipError_t launch_conv3x3_split16(const ConvSplitParams& p, hipStream_t s) {
     if (!attr_dev[dev][mode]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_dev[dev][mode] = true;
+        attr_dev[dev][mode] = 1;
     }
     if (mode == 3) hipLaunchKernelGGL((conv3x3_split16_kernel<0, true>), dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, p);
     else if (mode == 2) hipLaunchKernelGGL(conv3x3_split16_kernel<2>, dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, p);

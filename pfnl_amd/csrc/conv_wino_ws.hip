@@ -612,7 +612,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_wino_ws_kernel(WinoParams 
 template <int MODE>
 static hipError_t launch_ws_variant(const WinoParams& p, int nblocks, hipStream_t s) {
     constexpr size_t WS_LDS = WS_LDS_BYTES + (MODE == 2 ? 4 * 32 * 64 * sizeof(float) : 0);
-    static bool attr_set[64] = {false};
+    static std::atomic<int> attr_set[64];
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -620,7 +620,7 @@ static hipError_t launch_ws_variant(const WinoParams& p, int nblocks, hipStream_
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_ws_kernel<MODE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS);
         if (e != hipSuccess) return e;
-        attr_set[dev] = true;
+        attr_set[dev] = 1;
     }
     hipLaunchKernelGGL((conv_wino_ws_kernel<MODE>), dim3(nblocks), dim3(WS_THREADS), WS_LDS, s, p);
     return hipGetLastError();

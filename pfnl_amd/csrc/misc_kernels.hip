@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ mer
                                                    float* __restrict__ out, int B, int T, int H, int W, int MS,   // MS = floats per merge pixel (48 or 64)
                                                    int yoff, int Hs, int core0, int core1,     // merge holds LR rows [yoff, yoff + Hs) of the H-row frame;
                                                                                                 // only strip rows [core0, core1) are written
-                                                   unsigned* __restrict__ nonfinite) {         // OR-ed with 1 when a value written is inf / NaN (or null)
+                                                   unsigned* __restrict__ nonfinite) {         // set to 1 when a value written is inf / NaN (or null)
     constexpr int SCALE = (CO == 12) ? 4 : 2;
     const int H2 = 2 * Hs, W2 = 2 * W;
     const int X = blockIdx.x * 32 + (threadIdx.x & 31);
@@ -413,7 +413,8 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ mer
             dst[c] = v;
         }
     }
-    if (bad && nonfinite) atomicOr(nonfinite, 1u);
+    // sticky word, only ever set to 1 by the device: a system-scope store (the word may live in pinned, device-mapped host memory)
+    if (bad && nonfinite) __hip_atomic_store(nonfinite, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 hipError_t launch_tail(const float* merge, const float* x, const float* w2, const float* b2, float* out,
@@ -466,7 +467,7 @@ __global__ void blur_decimate_kernel(const float* __restrict__ hr, float* __rest
 }
 
 hipError_t launch_blur_decimate(const float* hr, float* lr, int F, int H, int W, int scale, hipStream_t s) {
-    static bool init[64] = {false};
+    static std::atomic<int> init[64];                               // (per device; a racing first call repeats the same upload)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -484,7 +485,7 @@ hipError_t launch_blur_decimate(const float* hr, float* lr, int F, int H, int W,
             for (int b = 0; b < 13; ++b) w[a * 13 + b] = (float)((k[a] / sum) * (k[b] / sum));
         e = hipMemcpyToSymbol(HIP_SYMBOL(c_blur), w, sizeof(w));
         if (e != hipSuccess) return e;
-        init[dev] = true;
+        init[dev] = 1;
     }
     const int oh = (H + scale - 1) / scale, ow = (W + scale - 1) / scale;
     const size_t total = (size_t)F * oh * ow;

@@ -399,7 +399,7 @@ hipError_t launch_nl_attn_f16(const float* X, float* Xo, const float* Wp, const 
     float* ML = partial ? partial + (size_t)B * ks * N * CP : nullptr;
     dim3 grid((q1 - q0 + NF_QB - 1) / NF_QB, B, ks);
     dim3 block(NF_THREADS);
-    static bool attr_dev[64] = {};
+    static std::atomic<int> attr_dev[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_dev[dev]) {
@@ -409,7 +409,7 @@ hipError_t launch_nl_attn_f16(const float* X, float* Xo, const float* Wp, const 
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NF_LDS_BYTES);
             if (e != hipSuccess) return e;
         }
-        attr_dev[dev] = true;
+        attr_dev[dev] = 1;
     }
 #define NF_LAUNCH(C_, S_) hipLaunchKernelGGL((nl_attn_f16_kernel<C_, S_>), grid, block, NF_LDS_BYTES, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad, q0, q1)
     switch (C) {

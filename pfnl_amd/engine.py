@@ -112,10 +112,23 @@ class PFNLEngine:
         x = np.asarray(x)
         B, T, H, W = self._check_input(x.shape, x.dtype == np.float32)
         x = np.ascontiguousarray(x)
-        out = np.empty(self.out_shape(B, H, W), np.float32)
+        out = self._host_output(self.out_shape(B, H, W))
         _capi.check(self._lib.pfnl_forward(self._h, x.ctypes.data_as(C.c_void_p), 0,
                                            out.ctypes.data_as(C.c_void_p), 0, B, H, W, None))
         return out
+
+    @staticmethod
+    def _host_output(shape) -> np.ndarray:
+        """The numpy array a host-pointer forward fills.  Page-locked when torch can provide it (its caching host allocator:
+        no allocation per call after the first): pfnl_forward then lets the copy engine write the result straight into it
+        instead of staging it through the handle's pinned strip.  The array owns its memory (numpy keeps the tensor alive)."""
+        if int(np.prod(shape)) * 4 >= (512 << 10):
+            try:
+                import torch
+                return torch.empty(shape, dtype=torch.float32, pin_memory=True).numpy()
+            except Exception:          # no torch / no pinned memory available: pageable, staged inside the library
+                pass
+        return np.empty(shape, np.float32)
 
     def forward_device(self, in_ptr: int, out_ptr: int, B: int, H: int, W: int, stream: int = 0) -> None:
         """Raw device-pointer form (asynchronous on ``stream``; 0 = the legacy null stream, i.e. torch's default stream).
@@ -140,6 +153,13 @@ class PFNLEngine:
         """Synchronise the engine's streams; raises if a device-pointer forward left the f16-pipe kernels' range
         (PFNL_ERR_RANGE, include/pfnl_hip.h "strict_fp32")."""
         _capi.check(self._lib.pfnl_sync(self._h))
+
+    def range_flagged(self) -> bool:
+        """Reads and clears the range flag of the device-pointer forwards WITHOUT synchronising (pfnl_range_flag): the caller has
+        waited (an event of its own) for the forwards it asks about.  What a pipelined harness checks once per batch."""
+        f = C.c_int(0)
+        _capi.check(self._lib.pfnl_range_flag(self._h, C.byref(f)))
+        return bool(f.value)
 
     def range_reruns(self) -> int:
         """Host-pointer forwards that were redone on the f32-MFMA kernels (range flag set)."""

@@ -296,12 +296,34 @@ class PFNL(VSR):
         jobs = []
         stream = torch.cuda.current_stream(frames.device)
         host = [None, None]                                          # pinned uint8 landing buffers, double-buffered
-        inflight = None                                              # (done event, start event, host buffer, first, count)
+        inflight = None                                              # (done event, start event, host buffer, first, count, ran strict)
+
+        # The device-pointer forwards below are asynchronous: the f16-pipe kernels' range fence (include/pfnl_hip.h, "strict_fp32")
+        # cannot re-run them by itself.  Once per batch, when its frames have arrived, the flag is read (pfnl_range_flag: no
+        # synchronisation of its own); a flagged batch - and the one enqueued behind it before the flag was seen - is computed
+        # again on the f32-MFMA kernels, and the rest of the sequence starts there (values beyond binary16's range rarely go away
+        # from one batch of a video to the next).  The PNGs never hold quantised non-finite values silently.
+        state = {"strict": False, "redo_next": False}
+
+        def recompute_strict(buf, first_, count_):
+            win_ = ops.gather_windows(frames, first_, count_, self.num_frames)
+            u8_ = ops.quantise_u8(eng.forward(win_))
+            buf[:count_].copy_(u8_, non_blocking=True)
+            stream.synchronize()
+            eng.range_flagged()                                      # (strict path: the fence is not armed; clears a stale flag)
 
         def drain(item, pool):
-            done, started, buf, first_, count_ = item
+            done, started, buf, first_, count_, was_strict = item
             done.synchronize()                                       # this batch's frames are on the host
             all_time.append(started.elapsed_time(done) * 1e-3)       # device time of the batch: gather + forward + quantise + D2H
+            if not was_strict and (eng.range_flagged() or state["redo_next"]):
+                state["redo_next"] = not state["strict"]             # the batch already in flight ran on the f16 pipe as well
+                if not state["strict"]:
+                    eng.set_option("strict_fp32", "on")
+                    state["strict"] = True
+                recompute_strict(buf, first_, count_)
+            elif was_strict:
+                state["redo_next"] = False
             frames_u8 = buf[:count_].numpy().copy()                  # (the pinned buffer is reused two batches later)
             for j in range(count_):
                 jobs.append(pool.submit(imsave_rgb, join(save_path, '{:0>4}.png'.format(first_ + j)), frames_u8[j][0]))
@@ -314,6 +336,7 @@ class PFNL(VSR):
                     break
                 started, done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 started.record(stream)
+                was_strict = state["strict"]
                 win = ops.gather_windows(frames, first, count, self.num_frames)
                 sr = eng.forward(win)
                 u8 = ops.quantise_u8(sr)
@@ -324,11 +347,13 @@ class PFNL(VSR):
                 done.record(stream)
                 if inflight is not None:                             # while the GPU runs batch i: batch i-1 goes to the PNG encoders
                     drain(inflight, pool)
-                inflight = (done, started, host[k], first, count)
+                inflight = (done, started, host[k], first, count, was_strict)
             if inflight is not None:
                 drain(inflight, pool)
             for j in jobs:
                 j.result()
+        if state["strict"]:                                          # (an engine that was strict from the start never raises the flag)
+            eng.set_option("strict_fp32", "off")
         all_time = np.array(all_time)
         avg = np.mean(all_time[1:]) if len(all_time) > 1 else float('nan')
         print('spent {} s in total and {} s in average'.format(np.sum(all_time), avg))

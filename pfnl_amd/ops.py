@@ -256,8 +256,7 @@ def nonlocal_residual(x, wg, bg, ww, bw, precision="fp32"):
     if arrs[0].size != C_ * C_ or arrs[2].size != C_ * C_ or arrs[1].size != C_ or arrs[3].size != C_:
         raise ValueError("nonlocal: weight shapes do not match 12*T channels")
     out = torch.empty((B, H, W, 3 * T), dtype=torch.float32, device=x.device)
-    fn = {"bf16": lib.pfnl_op_nonlocal_bf16, "split16": lib.pfnl_op_nonlocal_split16,
-          "f16": lib.pfnl_op_nonlocal_f16}.get(precision, lib.pfnl_op_nonlocal)
+    fn = {"split16": lib.pfnl_op_nonlocal_split16, "f16": lib.pfnl_op_nonlocal_f16}.get(precision, lib.pfnl_op_nonlocal)
     _capi.check(fn(_req(x, "x"), *[a.ctypes.data_as(C.c_void_p) for a in arrs],
                                      _req(out, "out"), B, T, H, W, _stream(x)))
     return out

@@ -157,15 +157,13 @@ def test_forward_bf16_full_size_against_fp32_build(B, H, W):
     eng.close()
 
 
-@pytest.mark.parametrize("precision", ["f16", "bf16"])
+@pytest.mark.parametrize("precision", ["f16"])
 @pytest.mark.parametrize("B,T,H,W", [(1, 7, 16, 16), (2, 7, 20, 36), (1, 5, 18, 22), (1, 3, 34, 30), (1, 7, 64, 64)])
-def test_nonlocal_bf16_split_operands(B, T, H, W, precision):
-    """The two non-local kernels of precision=bf16 against the fp64 spec.  "bf16" (nonlocal_bf16.hip): bf16 MFMA with hi + lo
-    split operands - the logits keep ~16 mantissa bits (dropped lo*lo term < 84 * 2^-18), the probabilities are rounded to
-    bf16 only as MFMA operands and normalised by the sum of the same rounded values, V is exact to 2^-17.  "f16" (default
-    since round 2; nonlocal_f16.hip on the hi parts only): binary16 operands throughout - 11 mantissa bits in the logits'
-    inputs AND in the probabilities, a third of the MFMAs.  Bound for both: 1e-3 on [0,1]-scale outputs (fp32 kernel:
-    2e-5); observed 1e-4 ... 5e-4."""
+def test_nonlocal_bf16_precision_kernel(B, T, H, W, precision):
+    """The non-local kernel of precision=bf16 against the fp64 spec: nonlocal_f16.hip on the hi parts only - binary16 operands
+    throughout, 11 mantissa bits in the logits' inputs AND in the probabilities, fp32 accumulation and softmax state.  Bound:
+    1e-3 on [0,1]-scale outputs (fp32 kernel: 2e-5); observed 1e-4 ... 5e-4.  (Round 1's split-operand bf16 kernel left the
+    library in round 4: tools/experiments/nonlocal_bf16.hip.)"""
     from oracle import pfnl_spec
     rng = np.random.default_rng(B + T + H + W)
     C = 12 * T
@@ -185,7 +183,7 @@ def test_nonlocal_bf16_split_operands(B, T, H, W, precision):
     assert got.shape == ref.shape and err < 1e-3, err
 
 
-@pytest.mark.parametrize("precision", ["f16", "bf16"])
+@pytest.mark.parametrize("precision", ["f16"])
 def test_nonlocal_bf16_constant_and_peaked_inputs(precision):
     """Known answers (as for the fp32 kernel): constant frames -> uniform affinity -> Z = (mean G) Ww + bw exactly
     representable path; a bright block -> dominant late keys exercise the running-max rescale with logits ~84."""

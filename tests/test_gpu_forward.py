@@ -590,6 +590,92 @@ def test_split16_domain_activation_overflow_is_caught(shape):
     eng.close()
 
 
+def test_range_flags_of_sync_and_async_calls_are_kept_apart():
+    """the sticky flag of an asynchronous (device-pointer) forward is not consumed by a later host-pointer forward on the
+    same handle (which would re-run an unrelated call on the f32 kernels and hide PFNL_ERR_RANGE from pfnl_sync), and
+    pfnl_range_flag reads it without synchronising."""
+    import torch
+    geom = PFNLGeometry(num_block=1)
+    w = synth.synthetic_weights(geom, seed=1)
+    w["nlvsr/conv0/kernel"] = (w["nlvsr/conv0/kernel"] * 4e5).astype(np.float32)
+    x = synth.uniform_clips(1, 7, 16, 24, seed=3)
+    eng = _engine_with(geom, w)
+    yd = eng.forward(torch.from_numpy(x).cuda())                    # leaves binary16's range: flags the ASYNC word
+    torch.cuda.synchronize()
+    assert not torch.isfinite(yd).all()
+    y_small = eng.forward((x * 1e-7).astype(np.float32))            # an unrelated host-pointer call inside the range
+    assert np.isfinite(y_small).all() and eng.range_reruns() == 0   # ... did not consume the other call's flag
+    assert eng.range_flagged() is True                              # still there for the asynchronous side
+    assert eng.range_flagged() is False                             # read-and-clear
+    eng.sync()
+    eng.forward(torch.from_numpy(x).cuda())
+    with pytest.raises(Exception, match="range|non-finite"):
+        eng.sync()
+    y = eng.forward(x)                                              # host pointers: its own flag, its own re-run
+    assert eng.range_reruns() == 1 and np.isfinite(y).all()
+    eng.sync()                                                      # ... which left nothing behind for the asynchronous side
+    eng.close()
+
+
+def test_harness_reruns_out_of_range_batches(tmp_path):
+    """the device-side harness feeds device pointers and never called pfnl_sync - activations beyond binary16's
+    range became quantised non-finite PNGs without a word.  Now every batch's flag is read when its frames arrive; flagged
+    batches (and the one in flight) are computed again on the f32-MFMA kernels: the PNGs equal those of a strict engine."""
+    from PIL import Image
+    from model.pfnl import PFNL
+    from pfnl_amd import model as M
+    rng = np.random.default_rng(21)
+    lr_u8 = rng.integers(0, 256, size=(7, 12, 20, 3), dtype=np.uint8)
+    seq = tmp_path / "seqR"
+    (seq / "blur4").mkdir(parents=True)
+    for i, im in enumerate(lr_u8):
+        Image.fromarray(im).save(seq / "blur4" / f"{i:04d}.png")
+    geom = PFNLGeometry(num_block=1)
+    w = synth.synthetic_weights(geom, seed=1)
+    w["nlvsr/conv0/kernel"] = (w["nlvsr/conv0/kernel"] * 4e5).astype(np.float32)
+    w["nlvsr/convmerge2/kernel"] = (w["nlvsr/convmerge2/kernel"] * 1e-6).astype(np.float32)   # back onto the PNG scale
+    m = PFNL()
+    m.num_block = 1
+    m.save_dir = str(tmp_path / "none")
+    m.set_weights(w)
+    m.test_video_lr(str(seq), name="out", part=3)                  # 7 frames, part 3 -> batches of 3, 3, 1
+    got = np.stack([np.asarray(Image.open(p)) for p in sorted((seq / "out").glob("*.png"))])
+    eng = _engine_with(geom, w)
+    eng.set_option("strict_fp32", "on")
+    lrs = (lr_u8 / 255.).astype(np.float32)
+    sr = eng.forward(np.ascontiguousarray(M.sliding_windows(lrs, 7)))
+    assert np.isfinite(sr).all()
+    assert np.array_equal(got, M.quantise(sr[:, 0]))
+    assert m._get_engine().range_flagged() is False
+    y = m.forward(lrs[None, :7])                                    # the engine is back on its default kernels afterwards
+    assert np.isfinite(y).all() and m._get_engine().range_reruns() == 1
+    eng.close()
+
+
+def test_host_pointer_staging_paths():
+    """pfnl_forward with host pointers (what replaces sess.run, reference model/pfnl.py:249-253): pageable buffers go through the
+    handle's pinned strips on worker threads, page-locked buffers are DMA targets as they are, small transfers take the
+    single-copy path - all three return the bytes of the device-pointer call."""
+    import ctypes as C
+    import torch
+    from pfnl_amd import _capi
+    geom = PFNLGeometry(num_block=1)
+    eng = engine_for(geom)
+    for (B, H, W) in ((1, 16, 24), (3, 64, 96), (2, 128, 128)):     # 27 KB / 1.5 MB / 2.75 MB in; 0.07 / 3.5 / 6.3 MB out
+        x = synth.uniform_clips(B, 7, H, W, seed=B + H)
+        want = eng.forward(torch.from_numpy(x).cuda()).cpu().numpy()
+        y_default = eng.forward(x)                                   # pageable in, engine-allocated (pinned when large) out
+        out_page = np.empty(eng.out_shape(B, H, W), np.float32)      # pageable out
+        _capi.check(eng._lib.pfnl_forward(eng._h, x.ctypes.data_as(C.c_void_p), 0, out_page.ctypes.data_as(C.c_void_p), 0, B, H, W, None))
+        xp = torch.from_numpy(x).pin_memory()                        # page-locked in
+        out_pin = torch.empty(eng.out_shape(B, H, W), dtype=torch.float32, pin_memory=True)
+        _capi.check(eng._lib.pfnl_forward(eng._h, C.c_void_p(xp.data_ptr()), 0, C.c_void_p(out_pin.data_ptr()), 0, B, H, W, None))
+        for got in (y_default, out_page, out_pin.numpy()):
+            assert np.array_equal(got, want)
+        for _ in range(3):                                           # the strips and the pool are reused call after call
+            assert np.array_equal(eng.forward(x), want)
+
+
 def test_split16_domain_nonlocal_input_scale():
     """Inputs far off the [0,1] scale the f16 non-local kernel assumes (x 600: 600 * 2^7 > 65504): caught the same way; the
     f32-MFMA kernels give the (stabilised) spec's result."""

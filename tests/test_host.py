@@ -273,11 +273,19 @@ def test_checkpoint_format_preference_and_mismatch(tmp_path):
     os.utime(tmp_path / "VSR-10.index", (time.time() - 500, time.time() - 500))   # ... with an OLD mtime (tar / rsync -t keep them)
     got = checkpoint.load_checkpoint(str(tmp_path), g, step=10)
     assert np.array_equal(got[1]["nlvsr/conv0/kernel"], w_new["nlvsr/conv0/kernel"])   # the cache does not carry this bundle's signature
-    with pytest.raises(FileExistsError):                             # no implicit deletion of a reference-format checkpoint
+    checkpoint.save_checkpoint(str(tmp_path), w_old, 9, fmt="npz")   # (the state file now names step 9)
+    before = {f.name: f.stat().st_mtime_ns for f in tmp_path.iterdir()}
+    with pytest.raises(FileExistsError):                             # no implicit deletion of a reference-format checkpoint ...
         checkpoint.save_checkpoint(str(tmp_path), w_old, 10, fmt="npz")
+    assert {f.name: f.stat().st_mtime_ns for f in tmp_path.iterdir()} == before   # ... and no side effect before the raise
+    assert checkpoint.read_state_file(str(tmp_path)) == "VSR-9"
     checkpoint.save_checkpoint(str(tmp_path), w_old, 10, fmt="both")  # rewrites the bundle, stamps the cache with its signature
     got = checkpoint.load_checkpoint(str(tmp_path), g, step=10)
     assert np.array_equal(got[1]["nlvsr/conv0/kernel"], w_old["nlvsr/conv0/kernel"])
+    with np.load(tmp_path / "VSR-10.npz") as z:
+        assert str(z[checkpoint._SIG_KEY]) == checkpoint.index_signature(str(tmp_path / "VSR-10"))
+    os.remove(tmp_path / "VSR-10.npz")                               # "both" once, "npz" afterwards (a training loop): the bundle holds
+    checkpoint.save_checkpoint(str(tmp_path), w_old, 10, fmt="npz")  # these very weights, so the cache is rewritten as its mirror
     with np.load(tmp_path / "VSR-10.npz") as z:
         assert str(z[checkpoint._SIG_KEY]) == checkpoint.index_signature(str(tmp_path / "VSR-10"))
     wt = dict(w_old)                                                 # theta / phi travel with the checkpoint: all four or an error

@@ -28,7 +28,7 @@ def main():
         eng.load_weights(w)
         for opts in ({}, {"conv3x3": "split16", "small": "off"}, {"conv3x3": "winograd"}, {"conv3x3": "direct", "conv1x1": "tiled"},
                      {"strict_fp32": "on"}, {"split16_sf": "off"}, {"split16_chain": "off"}, {"split16_c10": "off"}, {"graph": "on"}, {"precision": "bf16"},
-                     {"precision": "bf16", "bf16_nonlocal": "split", "bf16_conv10": "separate"}):
+                     {"precision": "bf16", "bf16_conv10": "separate"}):
             for k, v in opts.items():
                 eng.set_option(k, v)
             for _ in range(2):                                 # (graph=on captures on the second call)
