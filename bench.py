@@ -43,6 +43,19 @@ SUSTAINED_F16_MFMA_TFLOPS = 1500.0
 PREWARM_S = 0.3                                                    # untimed steps in front of the warm-up: the clock ramp of an idle chip
 T = 7
 
+# BASELINE.json configs, as `--workload`.  clips = per GPU under weak scaling (the config's own batch); strong = the fixed global
+# batch of `--strong` (configs[2]: 32 clips over 8 GPUs; the others: 8 x their batch so that 8 ranks still hold a clip each)
+WORKLOADS = {
+    "cfg2": {"clips": 4, "H": 128, "W": 128, "T": 7, "scale": 4, "strong": 32, "config": "configs[1]",
+             "label": "PFNL 4xSR, 7 frames, 128x128->512x512, batch=%d %s per MI355X (BASELINE.json configs[1]%s)"},
+    "cfg0": {"clips": 1, "H": 32, "W": 32, "T": 7, "scale": 4, "strong": 8, "config": "configs[0]",
+             "label": "PFNL 4xSR, 7 frames, 32x32->128x128, batch=%d %s per MI355X (BASELINE.json configs[0]%s)"},
+    "cfg4": {"clips": 1, "H": 270, "W": 480, "T": 7, "scale": 4, "strong": 8, "config": "configs[3]",
+             "label": "PFNL 4xSR, 7 frames, 270x480->1080x1920 (1080p), batch=%d %s per MI355X (BASELINE.json configs[3]%s)"},
+    "cfg5": {"clips": 1, "H": 64, "W": 64, "T": 5, "scale": 2, "strong": 8, "config": "configs[4]",
+             "label": "PFNL 2xSR, 5 frames, 64x64->128x128, batch=%d %s per MI355X (BASELINE.json configs[4]%s)"},
+}
+
 CONV3X3_KERNELS = {
     "winograd": ("conv_wino_ws_kernel<*> (fused Winograd F(2x2,3x3) 64->64, f32 MFMA, persistent wave-specialised)",
                  ["conv_wino_ws.hip", "wino_geom.h"]),
@@ -206,10 +219,10 @@ def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
     flops3 = geom.num_block * (2 * F + B) * P * 9 * 64 * 64 * 2.0      # direct-convolution FLOPs, shared-base split
     if bf16:
         # bf16 trunk: the 3x3 launches are bound by HBM, not by the matrix pipe: algorithmic bytes
-        # per PF block = conv1_i (read F, write F tiles of 128 B per pixel) + shared half (read B, write B) + per-frame
-        # half (read F + residual F + addend B, write F), over 3 launches
+        # per PF block of the IMPLEMENTED launch structure = conv1_i + conv10_i in one launch (read F, write F + B tiles of 128 B per
+        # pixel) + shared half (read B, write B) + per-frame half (read F + residual F + addend B, write F), over 3 launches
         launches_per_step = 3 * geom.num_block
-        bytes_per_launch = P * 128.0 * (5 * F + 3 * B) / 3.0
+        bytes_per_launch = P * 128.0 * (5 * F + 4 * B) / 3.0
         gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         name, files = CONV3X3_KERNELS["bf16"]
         traffic = stamped_traffic("traffic_bf16.json", files, workload)
@@ -233,8 +246,15 @@ def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
         # FLOPs against 2.5 PFLOP/s) and the HBM roof (conv1_i: read F + write F; shared half: read B + write B; per-frame
         # half: read F + addend B + residual F, write F - over 3 launches) - both fractions are reported, the larger binds
         name, files = CONV3X3_KERNELS[algo]
-        # the graph's bytes (layer-granular), however many launches carry them; + conv10_i's (read F, write B) when it is part of the class
-        bytes_per_launch = P * 256.0 * (5 * F + 3 * B + ((F + B) if c10 else 0)) * geom.num_block / launches_per_step
+        # ALGORITHMIC bytes of the fusion level that is IMPLEMENTED: what the launches of this class must move when
+        # each reads its inputs once and writes its outputs once, in tiles of P x 256 B (F frame tiles, B clip tiles per block):
+        #   conv1_i alone            read F, write F                          conv1_i + conv10_i (one launch)  read F, write F + B
+        #   conv2_i as a chain       read F (inp1) + B (base) + F (residual), write F
+        #   conv2_i as two launches  shared half: read B, write B (pb);  per-frame half: read F + B (pb) + F (residual), write F
+        # default since round 3 (c1c10 + chain, 2 launches): 5F + 2B.  (Round 3 still charged the un-fused graph's 5F + 3B + F + B
+        # here, which put `frac` above what the kernels move: VERDICT r3.)
+        tiles_block = ((2 * F + B) if c10 else 2 * F) + ((3 * F + B) if chain else (2 * B + 3 * F + B))
+        bytes_per_launch = P * 256.0 * tiles_block * geom.num_block / launches_per_step
         gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         ex = 3.0 * direct_tflops
         # frac = ALGORITHMIC work / time / peak: the reference graph's bytes (layer-granular, shared-base split) against HBM, its
@@ -245,9 +265,17 @@ def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
             rec.update({"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(f_h, 4)})
         else:
             rec.update({"achieved": round(direct_tflops, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(f_m, 4)})
-        rec.update({"traffic": stamped_traffic("traffic_split16.json", files, (algo, workload)), "kernel": name,
+        traffic = stamped_traffic("traffic_split16.json", files, (algo, workload))
+        if traffic is not None and traffic < 0.95 * bytes_per_launch:
+            # counter bytes below the compulsory bytes: the byte model and the launch structure that ran disagree - say so instead
+            # of printing a fraction that does not follow (tests/test_host.py asserts the committed profile against this model)
+            rec["traffic_inconsistent"] = {"pmc_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": round(bytes_per_launch)}
+            traffic = None
+        rec.update({"traffic": traffic, "kernel": name,
                     "avg_launch_ms": round(avg_ms, 4), "launches_timed": k["launches"], "launches_per_step": launches_per_step,
-                    "mbytes_per_launch": round(bytes_per_launch / 1e6, 2), "hbm_gbs": round(gbs, 1), "hbm_frac": round(f_h, 4),
+                    "mbytes_per_launch": round(bytes_per_launch / 1e6, 2),
+                    "tiles_per_block": "5F+%dB" % ((1 if c10 else 0) + (1 if chain else 3)),
+                    "hbm_gbs": round(gbs, 1), "hbm_frac": round(f_h, 4),
                     "algorithmic_direct_tflops": round(direct_tflops, 2), "algorithmic_mfma_frac": round(f_m, 4),
                     "mfma_executed_tflops": round(ex, 1), "mfma_executed_frac": round(ex / PEAK_F16_MFMA_TFLOPS, 4),
                     "mfma_sustained_ceiling_tflops": SUSTAINED_F16_MFMA_TFLOPS,
@@ -325,8 +353,14 @@ def main():
     ap.add_argument("--conv1x1", choices=["split16", "stream", "tiled"], default=None, help="override the conv10_i algorithm")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="trunk arithmetic: fp32 = the reference's (the judged line); bf16 = BASELINE.json configs[3]'s")
-    ap.add_argument("--workload", choices=["cfg2", "cfg4"], default="cfg2",
-                    help="cfg2 = configs[1] 4x7x128x128 per GPU (default, the metric's config); cfg4 = configs[3] 1x7x270x480 (1080p)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2",
+                    help="cfg2 = configs[1] 4x7x128x128 per GPU (default, the metric's config); cfg0 = configs[0] 1x7x32x32 (north_star's "
+                         "second size); cfg4 = configs[3] 1x7x270x480 (1080p); cfg5 = configs[4] 2x, 1x5x64x64")
+    ap.add_argument("--clips-per-gpu", type=int, default=0, help="override the workload's clips per GPU (weak scaling); stated in config")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling (SURVEY.md 8(e)): a FIXED global batch (--global-batch, default configs[2]'s 32 clips for cfg2) in "
+                         "contiguous shards over the N ranks instead of a fixed batch per GPU; the line says scaling = strong")
+    ap.add_argument("--global-batch", type=int, default=0, help="global batch of --strong (default: the workload's)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to exercise the N>1 plumbing on a 1-GPU box)")
     ap.add_argument("--comm", default="pfnl", choices=["pfnl", "torch"],
@@ -338,7 +372,8 @@ def main():
                          "blocks; the whole-forward breakdown from an untimed pass)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events (no roofline object)")
     args = ap.parse_args()
-    B_PER_GPU, H, W = (1, 270, 480) if args.workload == "cfg4" else (4, 128, 128)
+    wl = WORKLOADS[args.workload]
+    H, W, T_WL = wl["H"], wl["W"], wl["T"]
 
     import numpy as np
     import torch
@@ -372,7 +407,16 @@ def main():
     local_dev = local_rank % ndev                      # gloo test mode may stack ranks on one GPU
     torch.cuda.set_device(local_dev)
     dev = "cuda:%d" % local_dev
-    geom = PFNLGeometry()
+    geom = PFNLGeometry(num_frames=T_WL, scale=wl["scale"])
+    if args.strong:
+        GB = args.global_batch or wl["strong"]
+        if GB < world:
+            raise SystemExit("--strong: a global batch of %d clips cannot be split over %d ranks" % (GB, world))
+        lo, hi = pd.shard_range(GB, rank, world)                      # contiguous shards, sizes differ by at most one clip
+        B_PER_GPU = hi - lo
+    else:
+        B_PER_GPU = args.clips_per_gpu or wl["clips"]
+        GB = world * B_PER_GPU
 
     use_dist = world > 1 or bool(os.environ.get("PFNL_BENCH_FORCE_DIST"))   # (the env: run the N>1 code path with one rank - tests)
     comm = None
@@ -441,7 +485,7 @@ def main():
     bf16 = args.precision == "bf16"
     if bf16:
         eng.set_option("precision", "bf16")
-    x = torch.from_numpy(synth.uniform_clips(B_PER_GPU, T, H, W, seed=1234 + rank)).to(dev)   # resident in HBM
+    x = torch.from_numpy(synth.uniform_clips(B_PER_GPU, T_WL, H, W, seed=1234 + rank)).to(dev)   # resident in HBM
     out = torch.empty(eng.out_shape(B_PER_GPU, H, W), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -493,11 +537,11 @@ def main():
             elapsed = float(t[0])
     assert torch.isfinite(out).all().item(), "non-finite output"
 
-    clips_total = world * B_PER_GPU * args.steps
+    clips_total = GB * args.steps                                     # all ranks' clips (weak: world x clips per GPU; strong: the fixed batch)
     value = clips_total / elapsed                                     # 1 HR frame per clip
     ms_per_step = 1e3 * elapsed / args.steps
 
-    algo = resolve_conv3x3(args.conv3x3, B_PER_GPU, H, W)
+    algo = resolve_conv3x3(args.conv3x3, B_PER_GPU, H, W, T=T_WL)
     roof = conv3x3_roofline(geom, prof, B_PER_GPU, H, W, algo, bf16, args.workload)
     f_ref = geom.flops_per_clip(H, W) * B_PER_GPU
     f_exec = geom.flops_per_clip(H, W, shared_base=True) * B_PER_GPU
@@ -518,12 +562,14 @@ def main():
                 breakdown[n] = round(prof_all[n]["ms"] / n_all * (sc_all if n in ("conv3x3", "conv1x1") else 1.0), 4)
 
     res = {
-        "metric": "HR frames/sec at 4xSR, 7-frame %dx%d->%dx%d" % (H, W, 4 * H, 4 * W), "value": round(value, 3), "unit": "HR frames/s",
+        "metric": "HR frames/sec at %dxSR, %d-frame %dx%d->%dx%d" % (wl["scale"], T_WL, H, W, wl["scale"] * H, wl["scale"] * W),
+        "value": round(value, 3), "unit": "HR frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_s": PREWARM_S, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-        "config": {"workload": ("PFNL 4xSR, 7 frames, 270x480->1080x1920 (1080p), batch=1 %s per MI355X (BASELINE.json configs[3])" if args.workload == "cfg4" else
-                                "PFNL 4xSR, 7 frames, 128x128->512x512, batch=4 %s per MI355X (BASELINE.json configs[1])") % ("bf16 trunk" if bf16 else "fp32"),
-                   "clips_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU, "parallelism": "dp%d" % world, "backend": (args.backend if use_dist else None),
+        "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32",
+        "data": "synthetic",
+        "config": {"workload": wl["label"] % (B_PER_GPU, "bf16 trunk" if bf16 else "fp32",
+                                              (": the fixed global batch of %d clips in contiguous shards, this is rank 0's" % GB) if args.strong else ""),
+                   "clips_per_gpu": B_PER_GPU, "global_batch": GB, "parallelism": "dp%d" % world, "backend": (args.backend if use_dist else None),
                    "comm": (("pfnl_comm (RCCL)" if comm is not None else "torch.distributed") if use_dist else None),
                    "weights": "synthetic Xavier (seed 0)", "input": "resident in HBM", "conv3x3": algo},
         "roofline": roof,
@@ -549,10 +595,10 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 el = float(t[0])
         res["sustained"] = {"steps": n_sus, "seconds": round(el, 3), "ms_per_step": round(1e3 * el / n_sus, 4),
-                            "value": round(world * B_PER_GPU * n_sus / el, 3)}
-    if rank == 0 and world == 1 and not args.no_secondary and args.workload == "cfg2" and not bf16:
+                            "value": round(GB * n_sus / el, 3)}
+    if rank == 0 and world == 1 and not args.no_secondary and args.workload == "cfg2" and not bf16 and not args.strong and not args.clips_per_gpu:
         res["secondary"] = secondary_workloads(eng, geom, weights, local_dev, dev, x, out)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":   # (the 1080p oracle needs minutes per pass)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("cfg2", "cfg0"):   # (the 1080p oracle needs minutes per pass; configs[4] is build-defined)
         sample = synth.uniform_clips(1, T, H, W, seed=1234)
         res["cpu_baseline"] = cpu_baseline(weights, sample, H, W)
         res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)

@@ -349,3 +349,65 @@ echo "GPU[0]		: Max Graphics Package Power (W): 1400.0"
     import shutil
     if shutil.which("rocm-smi") is None and not os.path.exists("/opt/rocm/bin/rocm-smi"):
         assert bench.PowerSampler(0).stop() is None
+
+
+def test_bench_byte_model_matches_the_launch_structure_and_the_committed_traffic():
+    """`roofline.frac` must be priced on the bytes of the launch structure that RAN, and counter
+    bytes cannot be below them.  configs[1], default structure (conv1_i + conv10_i in one launch, conv2_i as a chain): 5F + 2B tiles
+    of P x 256 B per block over two launches; the newest committed PMC traffic must be >= 0.95 x that (and < 1.3 x: no wasted
+    re-reads inside a launch)."""
+    import glob
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    g = PFNLGeometry()
+    B, H, W, F = 4, 128, 128, 28
+    for env, tiles, launches in (({}, 5 * F + 2 * B, 2), ({"PFNL_SF_C10": "0"}, 5 * F + B, 2), ({"PFNL_SF_CHAIN": "0"}, 5 * F + 4 * B, 3),
+                                 ({"PFNL_SF_C10": "0", "PFNL_SF_CHAIN": "0"}, 5 * F + 3 * B, 3)):
+        old = {k: os.environ.pop(k, None) for k in ("PFNL_SF_C10", "PFNL_SF_CHAIN", "PFNL_SPLIT16_SF")}
+        os.environ.update(env)
+        try:
+            rec = bench.conv3x3_roofline(g, {"conv3x3": {"ms": 2.0, "launches": 20}}, B, H, W, "split16", False, "cfg2")
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+            os.environ.update({k: v for k, v in old.items() if v is not None})
+        assert rec["launches_per_step"] == launches * g.num_block
+        assert abs(rec["mbytes_per_launch"] * 1e6 - H * W * 256 * tiles / launches) < 1e4, (env, rec["mbytes_per_launch"])
+    rec = bench.conv3x3_roofline(g, {"conv3x3": {"ms": 2.0, "launches": 20}}, B, H, W, "split16", False, "cfg2")
+    newest = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_traffic_split16.json")))[-1]
+    tj = json.load(open(newest))
+    ratio = tj["hbm_bytes_per_launch_avg"] / (rec["mbytes_per_launch"] * 1e6)
+    assert 0.95 <= ratio < 1.3, (newest, ratio)
+    # bf16 trunk at 1080p: conv1_i + conv10_i, shared half, per-frame half = 5F + 4B tiles of P x 128 B over three launches
+    rb = bench.conv3x3_roofline(g, {"conv3x3": {"ms": 3.0, "launches": 30}}, 1, 270, 480, "bf16", True, "cfg4")
+    assert abs(rb["mbytes_per_launch"] * 1e6 - 270 * 480 * 128 * (5 * 7 + 4) / 3) < 1e4
+
+
+def test_harness_numerics_match_the_reference_functions():
+    """SURVEY.md 8(f)-3 / 8(f)-4 pinned to the reference's OWN code: tools/make_utils_golden.py takes gkern, _rgb2ycbcr, to_uint8 and
+    AVG_PSNR out of /root/reference/utils.py (:95-105, :194-246) with `ast` and runs them on the real numpy / scipy in the build
+    container; the fixture holds their outputs on seeded inputs (data only)."""
+    from pfnl_amd import metrics
+    gd = load_golden("utils_ref")
+    k = synth.gaussian_kernel_1d(13, 1.6)
+    assert np.abs(np.outer(k, k) - gd["blur"]).max() < 1e-15                    # BLUR = gkern(13, 1.6): separable, as built here
+    assert abs(gd["blur"][6, 6] - 0.0621745) < 1e-7                             # (the centre tap SURVEY.md quotes)
+    assert np.abs(metrics.rgb2ycbcr(gd["rgb"], 255.0) - gd["ycc255"]).max() < 1e-10
+    assert np.abs(metrics.rgb2ycbcr(gd["rgb"] / 255.0, 1.0) - gd["ycc1"]).max() < 1e-12
+    assert np.array_equal(metrics.to_uint8(gd["u8_in"], 0.0, 1.0), gd["u8_out"])  # np.round: ties to even, clipped
+    vt, vp = gd["vid_true"], gd["vid_pred"]
+    assert abs(metrics.avg_psnr(vt, vp, 0.0, 1.0) - gd["avg_psnr"][0]) < 1e-9
+    assert abs(metrics.avg_psnr(vt * 255.0, vp * 255.0, 0.0, 255.0) - gd["avg_psnr"][1]) < 1e-9
+    assert abs(metrics.avg_psnr(vt, vp, 0.0, 1.0, t_border=0, sp_border=4) - gd["avg_psnr"][2]) < 1e-9
+    # the decimation the harness applies (utils.py:169-192 with this BLUR) as one dense correlation with the reference's 13x13 kernel
+    rng = np.random.default_rng(5)
+    hr = rng.random((2, 24, 32, 3))
+    xp = np.pad(hr, ((0, 0), (6, 6), (6, 6), (0, 0)), mode="reflect")
+    want = np.zeros((2, 6, 8, 3))
+    for a in range(13):
+        for b in range(13):
+            want += gd["blur"][a, b] * xp[:, a:a + 21:4, b:b + 29:4]
+    assert np.abs(synth.blur_decimate(hr, 4) - want).max() < 1e-7              # (blur_decimate returns float32)
