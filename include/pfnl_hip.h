@@ -96,7 +96,11 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *   asynchronous: pfnl_sync returns PFNL_ERR_RANGE.  "on" (or env PFNL_STRICT_FP32=1) uses the f32-MFMA kernels throughout; weights
  *   beyond binary16's range select them by themselves at pfnl_finalize_weights.
  * key "small" = "auto" (default: the small-shape trunk kernels of conv_small.hip when a 3x3 launch has fewer than 256 tiles of 8x32
- *   pixels - 3 launches per progressive-fusion block, conv2_i as one 128 -> 64 convolution) | "on" | "off".
+ *   pixels - conv2_i as one 128 -> 64 convolution) | "on" | "off".
+ * key "small_c10" = "on" (default since round 4: TWO launches per progressive-fusion block at small shapes - the conv1_i launch also
+ *   runs its finished tile through this frame's 64 x 64 slice of conv10_i and writes the partial sum; the conv2_i launch adds the T
+ *   partials (+ bias, leaky-relu) on the way into LDS: its `base` source.  No 1x1 launch, no inter-workgroup exchange inside a
+ *   launch, fixed summation order) | "off" (three launches, conv10_i on conv_small_1x1_kernel).
  * key "split16_sf" = "on" (default) | "off": with conv3x3 and conv1x1 on "split16", conv1_i and conv10_i write the split format
  *   (hi, lo' binary16 pairs: the MFMA operands themselves) and both halves of conv2_i read it by LDS-DMA (conv_sf.hip).
  * key "split16_chain" = "on" (default) | "off": with split16_sf, conv2_i is one launch - per (clip, tile) the shared half stays in
@@ -282,6 +286,13 @@ int pfnl_op_conv1x1_split16_sf(const float* in, const float* kernel_host, const 
 int pfnl_op_conv_small(const float* a, const float* b, int nA, int a_div, int b_mul, int nsrc, const float* kernel_host,
                        const float* bias_host, const float* resid, float* out, int items, int H, int W, int ks, int cout, int act,
                        void* stream);
+/* One progressive-fusion block (reference model/pfnl.py:66-71) on the small-shape kernels as the forward launches it (option
+ * small_c10 = on: two launches): inp1 = lrelu(conv3x3(x; k1) + b1) [clips*T, H, W, 64] - the same launch writes each frame's
+ * 64 x 64 slice of conv10_i as a partial sum - and out = x + lrelu(conv3x3(concat([base, inp1_t]); k2) + b2), base = lrelu(sum of
+ * the T partials + b10) formed in the second launch's prologue.  k1 HWIO [3,3,64,64], k10 [1,1,64T,64], k2 [3,3,128,64]. */
+int pfnl_op_conv_small_pf_block(const float* x, const float* k1_host, const float* b1_host, const float* k10_host, const float* b10_host,
+                                const float* k2_host, const float* b2_host, float* inp1, float* out, int clips, int T, int H, int W,
+                                void* stream);
 /* conv1_i and conv10_i of a progressive-fusion block (reference model/pfnl.py:66-68) in ONE launch of the bf16 3x3 kernel:
  * out1 = lrelu(conv3x3(in) + b1) [clips*fpc, H, W, 64], base = lrelu(conv1x1(concat_t out1_t) + b10) [clips, H, W, 64];
  * the 1x1 contraction reads every finished tile from LDS.  fpc in {3,5,7}. */

@@ -67,6 +67,7 @@ SIGNATURES = {
     "pfnl_op_conv3x3_split16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv3x3_split16_sf": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv_small": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "pfnl_op_conv_small_pf_block": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv1x1_split16_sf": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv3x3_winograd_ws": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_nonlocal": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -216,6 +216,8 @@ struct pfnl_handle {
     bool strict = false, strict_once = false, weights_f16_ok = true;
     long long range_reruns = 0;
     int small_mode = 0;                                       // option small=auto|on|off: the small-shape trunk kernels (auto: when a launch has < 256 tiles of 8x32 pixels)
+    bool small_c10 = true;                                    // ... with conv10_i inside the conv1_i launch (per-frame partials, summed in conv2_i's prologue): option small_c10=on|off
+    DevBuf p10;                                               // ... those partials [B*T][H][W][64] fp32
     bool sf_chain = true;                                     // ... and conv2_i is ONE launch (option split16_chain=on|off)
     bool sf_c10 = true;                                       // ... and conv1_i + conv10_i are ONE launch (option split16_c10=on|off)
     bool sf_path = true;                                      // option split16_sf=on|off: with conv3x3 = conv1x1 = split16, conv1_i and conv10_i write the
@@ -526,6 +528,27 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             h->prof_gate = i == c.num_block / 2;
             h->chain_open = false;
         }
+        if (small && h->small_c10) {
+            // two launches per block: conv10_i rides in the conv1_i launch as per-frame partials (W10_t^T . inp1_t), which conv2_i's
+            // prologue adds up (+ bias, leaky-relu) into its `base` source - no 1x1 launch, no inter-workgroup traffic inside a launch
+            if (h->p10.ensure((size_t)F * P * 64)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
+            {   // conv1_i (:66) + this frame's part of conv10_i (:67-68)
+                ProfScope ps(h, s, PFNL_K_CONV3X3);
+                ConvSmallParams q{nullptr, h->inp0.p, 0, 1, 1, 1, w16m + h->off16m_c1[i], wd + h->off_c1_b[i], nullptr, h->inp1.p, H, W, F, 1, 3};
+                q.x_wpack = w16m + h->off16m_c10[i];
+                q.x_out = h->p10.p;
+                q.x_T = T;
+                HIPCHK(launch_conv_small(q, s));
+            }
+            {   // conv2_i over concat([base, inp1_t]) + lrelu + residual (:69-71), base = lrelu(sum of the T partials + bias)
+                ProfScope ps(h, s, PFNL_K_CONV3X3);
+                ConvSmallParams q{h->p10.p, h->inp1.p, 1, T, 1, 2, w16m + h->off16m_c2[i], wd + h->off_c2_b[i], h->inp0.p, h->inp0.p, H, W, F, 1, 3};
+                q.a_nsum = T;
+                q.a_bias = wd + h->off_c10_b[i];
+                HIPCHK(launch_conv_small(q, s));
+            }
+            continue;
+        }
         if (small) {
             {   // conv1_i (:66)
                 ProfScope ps(h, s, PFNL_K_CONV3X3);
@@ -765,6 +788,7 @@ int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
     pfnl_handle* h = new pfnl_handle();
     h->cfg = *cfg;
     if (const char* e = std::getenv("PFNL_SMALL")) h->small_mode = std::string(e) == "on" ? 1 : (std::string(e) == "off" ? 2 : 0);   // (A/B runs)
+    if (const char* e = std::getenv("PFNL_SMALL_C10")) h->small_c10 = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_SF_CHAIN")) h->sf_chain = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_SF_C10")) h->sf_c10 = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_SPLIT16_SF")) h->sf_path = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
@@ -826,7 +850,7 @@ int pfnl_destroy(pfnl_handle* h) {
     h->pin_in.release();
     h->pin_out.release();
     if (h->rflag_host) hipHostFree(h->rflag_host);
-    for (DevBuf* b : {&h->Xs, &h->Q, &h->wdev16s, &h->wdev, &h->wdev16, &h->nl16, &h->X, &h->Xo, &h->nlp, &h->inp0, &h->inp1, &h->base, &h->pb, &h->merge,
+    for (DevBuf* b : {&h->p10, &h->Xs, &h->Q, &h->wdev16s, &h->wdev, &h->wdev16, &h->nl16, &h->X, &h->Xo, &h->nlp, &h->inp0, &h->inp1, &h->base, &h->pb, &h->merge,
                       &h->stage_in, &h->stage_out, &h->scratch})
         b->release();
     delete h;
@@ -950,6 +974,12 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         const int n = atoi(v.c_str());
         if (n < 1 || n > 64) return fail(PFNL_ERR_INVALID, "nl_sub_sample: an integer >= 1");
         h->nl_sub = n;
+        return 0;
+    }
+    if (k == "small_c10") {
+        if (v == "on") h->small_c10 = true;
+        else if (v == "off") h->small_c10 = false;
+        else return fail(PFNL_ERR_INVALID, "small_c10 must be on or off");
         return 0;
     }
     if (k == "bf16_nonlocal") {   // (the split-bf16 kernel of round 1 left the library in round 4: tools/experiments/nonlocal_bf16.hip)
@@ -1220,6 +1250,13 @@ int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes) {
     if (h->bf16 || h->nl_algo != 0) f += (pfnl::nl_f16_scratch_halfs(B, (int)N) + 1) / 2;   // split K / V^T operands (bf16 or f16)
     if (h->nl_theta) f += (size_t)B * N * CP;                   // projected queries (nltype 0 / 2)
     if (h->nl_sub > 1) f += (size_t)B * ((H / 2) / h->nl_sub) * ((W / 2) / h->nl_sub) * CP;   // pooled keys
+    {   // the small-shape trunk's conv10_i partials (the rule of forward_device)
+        const long long tiles8x32 = (long long)B * T * ((W + 31) / 32) * ((H + 7) / 8);
+        const bool strict = !h->bf16 && (h->strict || !h->weights_f16_ok);
+        const bool small = !h->bf16 && !strict && (long long)H * W * 256 < 0x7fffffffLL &&
+                           (h->small_mode == 1 || (h->small_mode == 0 && h->conv_algo == 5 && h->conv1x1_algo == 2 && tiles8x32 < 256));
+        if (small && h->small_c10) f += B * T * P * 64;
+    }
     *bytes = f * sizeof(float);
     return 0;
 }
@@ -1964,6 +2001,54 @@ int pfnl_op_conv_small(const float* a, const float* b, int nA, int a_div, int b_
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(dw);
     if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv_small op: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// One progressive-fusion block on the small-shape kernels as the forward launches it since round 4 (two launches, conv_small.h):
+// inp1 = lrelu(conv3x3(x; k1) + b1) together with the per-frame partials of conv10_i; out = x + lrelu(conv3x3(concat([base, inp1_t]); k2)
+// + b2) with base = lrelu(sum_t partial_t + b10) built in the second launch's prologue (reference model/pfnl.py:66-71).
+int pfnl_op_conv_small_pf_block(const float* x, const float* k1_host, const float* b1_host, const float* k10_host, const float* b10_host,
+                                const float* k2_host, const float* b2_host, float* inp1, float* out, int clips, int T, int H, int W,
+                                void* stream) {
+    if (!x || !k1_host || !k10_host || !k2_host || !inp1 || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (clips < 1 || T < 1 || T > 8 || H < 1 || W < 1) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n1 = pfnl::conv_small_pack_halfs(3, 1), n10 = pfnl::conv_small_pack_halfs(1, T), n2 = pfnl::conv_small_pack_halfs(3, 2);
+    std::vector<uint16_t> pack(n1 + n10 + n2 + 3 * 128, 0);
+    pfnl::conv_small_pack_weights(k1_host, 3, 1, 64, pack.data());
+    pfnl::conv_small_pack_weights(k10_host, 1, T, 64, pack.data() + n1);
+    pfnl::conv_small_pack_weights(k2_host, 3, 2, 64, pack.data() + n1 + n10);
+    uint16_t* const bh = pack.data() + n1 + n10 + n2;
+    if (b1_host) std::memcpy(bh, b1_host, 64 * sizeof(float));
+    if (b10_host) std::memcpy(bh + 128, b10_host, 64 * sizeof(float));
+    if (b2_host) std::memcpy(bh + 256, b2_host, 64 * sizeof(float));
+    const size_t F = (size_t)clips * T, tensor = F * H * W * 64;
+    uint16_t* dw = nullptr;
+    float* part = nullptr;
+    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(uint16_t)));
+    if (hipMalloc(&part, tensor * sizeof(float)) != hipSuccess) {
+        (void)hipFree(dw);
+        return fail(PFNL_ERR_NOMEM, "allocation failed");
+    }
+    hipError_t e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    const float* const db = reinterpret_cast<const float*>(dw + n1 + n10 + n2);
+    if (e == hipSuccess) {
+        pfnl::ConvSmallParams q{nullptr, x, 0, 1, 1, 1, dw, db, nullptr, inp1, H, W, (int)F, 1, 3};
+        q.x_wpack = dw + n1;
+        q.x_out = part;
+        q.x_T = T;
+        e = pfnl::launch_conv_small(q, s);
+    }
+    if (e == hipSuccess) {
+        pfnl::ConvSmallParams q{part, inp1, 1, T, 1, 2, dw + n1 + n10, db + 128, x, out, H, W, (int)F, 1, 3};
+        q.a_nsum = T;
+        q.a_bias = db + 64;
+        e = pfnl::launch_conv_small(q, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dw);
+    (void)hipFree(part);
+    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv_small block op: ") + hipGetErrorString(e));
     return 0;
 }
 

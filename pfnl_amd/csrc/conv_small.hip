@@ -55,6 +55,8 @@ struct CmGeom {
     static constexpr int RING = KS == 3 ? (R == 3 ? 3 : 9) : 1;     // weight operands in flight (divides STEPS)
     static constexpr int RED_BYTES = CM_NQ * R * 32 * 256;          // the K parts of the tile, fp32 pixel lines
     static constexpr int LDS_BYTES = (2 * BUF_BYTES > RED_BYTES ? 2 * BUF_BYTES : RED_BYTES);
+    static constexpr int XT_BYTES = R * 32 * 256;                   // fused 1x1 (X stage): the activated tile in operand form, behind the rest
+    static constexpr int LDS_BYTES_X = LDS_BYTES + XT_BYTES;
 };
 
 __device__ __forceinline__ void cm_split4(f32x4 v, cmu2& hi, cmu2& lo, float nscale) {   // conv_split16.hip split4
@@ -69,7 +71,9 @@ __device__ __forceinline__ void cm_split4(f32x4 v, cmu2& hi, cmu2& lo, float nsc
     lo = cmu2{l0, l1};
 }
 
-template <int KS, int R>
+// XS: the X stage (conv10_i's partial of this frame behind conv1_i's tile, ConvSmallParams::x_*);  ASUM: source `a` is the
+// activated sum of a_nsum tensors (conv2_i taking `base` from conv10_i's per-frame partials)
+template <int KS, int R, bool XS = false, bool ASUM = false>
 __global__ __launch_bounds__(CM_THREADS, 1) void conv_small_kernel(ConvSmallParams p) {
     using G = CmGeom<KS, R>;
     constexpr int PAD = KS / 2;
@@ -107,9 +111,40 @@ __global__ __launch_bounds__(CM_THREADS, 1) void conv_small_kernel(ConvSmallPara
     const float nscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -2048.0f)));
     f32x4 stg[G::ITERS];
     auto request = [&](int s) __attribute__((always_inline)) {
+        const int org = ((y0 - PAD) * W + x0 - PAD) * 256;
+        if constexpr (ASUM) {
+            if (s < p.nA) {                                         // (wave-uniform) `a` = lrelu(sum of the a_nsum partial tensors + a_bias)
+                const int ns = p.a_nsum;
+                const float* const src0 = p.a + (size_t)(item / p.a_div) * ns * hw64;
+                f32x4 acc[G::ITERS];
+                int off[G::ITERS];
+#pragma unroll
+                for (int k = 0; k < G::ITERS; ++k) {
+                    const int gy = y0 + ((lpk[k] >> 16) & 0xff) - PAD, gx = x0 + ((unsigned)lpk[k] >> 24) - PAD;
+                    const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                    off[k] = in ? org + grel[k] : 0x7fffffff;
+                    acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                for (int j = 0; j < ns; ++j) {                      // fixed order: deterministic
+                    const __amdgpu_buffer_rsrc_t rj = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src0 + (size_t)j * hw64), 0, item_bytes, 0x00020000);
+#pragma unroll
+                    for (int k = 0; k < G::ITERS; ++k) acc[k] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rj, off[k], 0, 0));
+                }
+#pragma unroll
+                for (int k = 0; k < G::ITERS; ++k) {
+                    const int id = min(k * CM_THREADS + tid, G::PIECES - 1);
+                    f32x4 v = acc[k] + *reinterpret_cast<const f32x4*>(p.a_bias + (id & 15) * 4);
+                    v.x = fmaxf(v.x, 0.2f * v.x);
+                    v.y = fmaxf(v.y, 0.2f * v.y);
+                    v.z = fmaxf(v.z, 0.2f * v.z);
+                    v.w = fmaxf(v.w, 0.2f * v.w);
+                    stg[k] = off[k] == 0x7fffffff ? f32x4{0.f, 0.f, 0.f, 0.f} : v;   // SAME padding of `base`: zeros, not lrelu(bias)
+                }
+                return;
+            }
+        }
         const float* src = s < p.nA ? p.a + (size_t)(item / p.a_div) * hw64 : p.b + ((size_t)item * p.b_mul + (s - p.nA)) * hw64;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, item_bytes, 0x00020000);
-        const int org = ((y0 - PAD) * W + x0 - PAD) * 256;
 #pragma unroll
         for (int k = 0; k < G::ITERS; ++k) {
             const int gy = y0 + ((lpk[k] >> 16) & 0xff) - PAD, gx = x0 + ((unsigned)lpk[k] >> 24) - PAD;
@@ -144,6 +179,12 @@ __global__ __launch_bounds__(CM_THREADS, 1) void conv_small_kernel(ConvSmallPara
         const int m = min(n, ntot - 1);
         wring[n][0] = wsrc[(size_t)m * 128];
         wring[n][1] = wsrc[(size_t)m * 128 + 64];
+    }
+    [[maybe_unused]] cmu4 xw[2];                                    // X stage: this wave's slice of conv10_i (source t = this frame), requested now
+    if constexpr (XS) {
+        const cmu4* const xs = reinterpret_cast<const cmu4*>(p.x_wpack) + ((size_t)(kq * 2 + nt) * p.x_T + (item % p.x_T)) * 128 + lane;
+        xw[0] = xs[0];
+        xw[1] = xs[64];
     }
     f32x16 accm[R], accc[R];
 #pragma unroll
@@ -250,6 +291,14 @@ __global__ __launch_bounds__(CM_THREADS, 1) void conv_small_kernel(ConvSmallPara
         v.y = fmaxf(v.y, v.y * slope);
         v.z = fmaxf(v.z, v.z * slope);
         v.w = fmaxf(v.w, v.w * slope);
+        if constexpr (XS) {                                         // the activated tile in operand form (commit()'s layout, no halo)
+            cmu2 hi, lo;
+            cm_split4(v, hi, lo, nscale);
+            const int chunk = (cc >> 3) * 8 + ((cc & 7) >> 1);
+            const int a = G::LDS_BYTES + pp * 256 + ((chunk ^ (pp & 15)) << 4) + (cc & 1) * 8;
+            *reinterpret_cast<cmu2*>(cm_smem + a) = hi;
+            *reinterpret_cast<cmu2*>(cm_smem + (a ^ 64)) = lo;
+        }
         if (y < H && x < W) {
             const size_t o = (((size_t)item * H + y) * W + x) * 64 + cc * 4;
             v += rsd[k];
@@ -257,6 +306,43 @@ __global__ __launch_bounds__(CM_THREADS, 1) void conv_small_kernel(ConvSmallPara
         }
     }
     CM_STAMP(7);
+    if constexpr (XS) {
+        // ---- X stage: conv10_i's partial of this frame, W10_t^T . tile (K = 64: one k-step per wave, three MFMAs per row); the four
+        // K parts meet in the same LDS area the 3x3 used; the sum leaves as fp32 NHWC - the NEXT launch (conv2_i) adds the T partials
+        __syncthreads();                                            // the tile is complete; the meeting area has been read
+        const cmh8 wh = __builtin_bit_cast(cmh8, xw[0]), wo = __builtin_bit_cast(cmh8, xw[1]);
+        const int col = lane & 31;
+        const int xoff = col * 256 + ((((kq >> 1) * 8 + (kq & 1) * 2 + (lane >> 5)) ^ (col & 15)) << 4);   // hi part; lo' = ^ 64
+        const unsigned char* const xt = cm_smem + G::LDS_BYTES;
+        float* const red = reinterpret_cast<float*>(cm_smem) + (kq * R * 32) * 64 + 32 * nt + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const cmh8 ah = *reinterpret_cast<const cmh8*>(xt + r * (32 * 256) + xoff);
+            const cmh8 al = *reinterpret_cast<const cmh8*>(xt + r * (32 * 256) + (xoff ^ 64));
+            f32x16 zm, zc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                zm[i] = 0.f;
+                zc[i] = 0.f;
+            }
+            zm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, zm, 0, 0, 0);
+            zc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wo, zc, 0, 0, 0);
+            zc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, zc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[(r * 32 + drow(i, lane)) * 64] = zm[i] + zc[i] * (1.0f / 2048.0f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < EP; ++k) {
+            const int id = k * CM_THREADS + tid;
+            const int pp = id >> 4, cc = id & 15;
+            const int y = y0 + (pp >> 5), x = x0 + (pp & 31);
+            f32x4 v = *reinterpret_cast<const f32x4*>(cm_smem + pp * 256 + cc * 16);
+#pragma unroll
+            for (int q = 1; q < CM_NQ; ++q) v += *reinterpret_cast<const f32x4*>(cm_smem + (q * R * 32 + pp) * 256 + cc * 16);
+            if (y < H && x < W) *reinterpret_cast<f32x4*>(p.x_out + (((size_t)item * H + y) * W + x) * 64 + cc * 4) = v;
+        }
+    }
 }
 
 // ---- conv10_i at small shapes: a 1x1 has no halo, so the A operand comes straight from HBM / L2 (as conv1x1.hip does) and the whole
@@ -341,18 +427,19 @@ __global__ __launch_bounds__(CM1_THREADS, 2) void conv_small_1x1_kernel(ConvSmal
     }
 }
 
-template <int KS, int R>
+template <int KS, int R, bool XS = false, bool ASUM = false>
 static hipError_t cm_launch(const ConvSmallParams& p, int tiles, hipStream_t s) {
     using G = CmGeom<KS, R>;
+    constexpr int LDS = XS ? G::LDS_BYTES_X : G::LDS_BYTES;
     static std::atomic<int> attr_dev[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_dev[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_small_kernel<KS, R>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_small_kernel<KS, R, XS, ASUM>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_dev[dev] = 1;
     }
-    hipLaunchKernelGGL((conv_small_kernel<KS, R>), dim3(tiles), dim3(CM_THREADS), G::LDS_BYTES, s, p);
+    hipLaunchKernelGGL((conv_small_kernel<KS, R, XS, ASUM>), dim3(tiles), dim3(CM_THREADS), LDS, s, p);
     return hipGetLastError();
 }
 
@@ -380,6 +467,11 @@ hipError_t launch_conv_small(const ConvSmallParams& p, hipStream_t s) {
     if (tr[bestR] > 0x7fffffffLL) return hipErrorInvalidValue;
     const long long t2 = tr[2], t1 = tr[1];
     const bool r2 = bestR >= 2;
+    const bool xs = p.x_wpack != nullptr, asum = p.a_nsum > 1;
+    if (xs && (p.ks != 3 || p.nsrc != 1 || p.nA != 0 || !p.x_out || p.x_T < 1 || p.items % p.x_T || p.resid)) return hipErrorInvalidValue;
+    if (asum && (p.ks != 3 || p.nA != 1 || !p.a_bias || xs)) return hipErrorInvalidValue;
+    if (xs) return bestR == 3 ? cm_launch<3, 3, true, false>(p, (int)tr[3], s) : bestR == 2 ? cm_launch<3, 2, true, false>(p, (int)t2, s) : cm_launch<3, 1, true, false>(p, (int)t1, s);
+    if (asum) return bestR == 3 ? cm_launch<3, 3, false, true>(p, (int)tr[3], s) : bestR == 2 ? cm_launch<3, 2, false, true>(p, (int)t2, s) : cm_launch<3, 1, false, true>(p, (int)t1, s);
     if (p.ks == 3) return bestR == 3 ? cm_launch<3, 3>(p, (int)tr[3], s) : bestR == 2 ? cm_launch<3, 2>(p, (int)t2, s) : cm_launch<3, 1>(p, (int)t1, s);
     if (p.ks == 1 && p.nsrc <= CM1_MAXSRC) {                        // conv10_i: no halo, no LDS staging
         const long long g = (long long)p.items * (((long long)p.H * p.W + 31) / 32);

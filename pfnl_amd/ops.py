@@ -217,6 +217,20 @@ def conv_small(b, kernel, bias=None, a=None, a_div=1, b_mul=1, resid=None, items
     return out
 
 
+def conv_small_pf_block(x, k1, b1, k10, b10, k2, b2, T):
+    """One progressive-fusion block on the small-shape kernels, two launches (pfnl_op_conv_small_pf_block; reference
+    model/pfnl.py:66-71): x [clips*T,H,W,64] (cuda) -> (inp1, x + inp2)."""
+    import torch
+    lib = _capi.load_library()
+    F, H, W, c = x.shape
+    hs = [_host(a, n) for a, n in ((k1, "k1"), (b1, "b1"), (k10, "k10"), (b10, "b10"), (k2, "k2"), (b2, "b2"))]
+    inp1 = torch.empty_like(x)
+    out = torch.empty_like(x)
+    _capi.check(lib.pfnl_op_conv_small_pf_block(_req(x, "x"), *[a.ctypes.data_as(C.c_void_p) for a in hs], _req(inp1, "inp1"), _req(out, "out"),
+                                                F // T, int(T), H, W, _stream(x)))
+    return inp1, out
+
+
 def conv3x3_winograd(x, kernel, bias=None, act=True, addend=None, add_div=1, resid=None, variant="winograd"):
     """The 3x3 64->64 'same' convolution through the fused Winograd F(2x2,3x3) kernel (even H, W)."""
     import torch

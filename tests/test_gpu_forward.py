@@ -481,6 +481,34 @@ def test_split16_launch_structure_options(T, scale, nb, B, H, W):
     eng.close()
 
 
+@pytest.mark.parametrize("T,scale,nb,B,H,W", [(7, 4, 3, 1, 32, 32), (5, 2, 2, 1, 64, 64), (7, 4, 2, 2, 18, 40)])
+def test_small_shape_launch_structures(T, scale, nb, B, H, W):
+    """The small-shape trunk with conv10_i inside the conv1_i launch (small_c10 = on, default since round 4: 2 launches per block, the
+    per-frame partials summed in conv2_i's prologue) and as a launch of its own (off: 3 per block): launch counts, each against the
+    oracle, both against each other to summation-order noise; workspace accounting covers the partials."""
+    geom = PFNLGeometry(num_frames=T, scale=scale, num_block=nb)
+    w = synth.synthetic_weights(geom, seed=T + 1)
+    x = synth.uniform_clips(B, T, H, W, seed=H + 1)
+    ref = pfnl_fast.FastOracle(w, T, scale, nb).forward(x)
+    eng = _engine_with(geom, w)
+    eng.profile(1)
+    ys = {}
+    for c10, launches in (("on", (2, 0)), ("off", (2, 1))):
+        eng.set_option("small_c10", c10)
+        eng.profile_reset()
+        ys[c10] = y = eng.forward(x)
+        p = eng.profile_read()
+        assert (p["conv3x3"]["launches"], p["conv1x1"]["launches"]) == (launches[0] * nb, launches[1] * nb), (c10, p)
+        assert np.abs(y - ref).max() < ABS_TOL, (c10, np.abs(y - ref).max())
+    assert np.abs(ys["on"] - ys["off"]).max() < 2e-5
+    eng.profile(0)
+    eng.set_option("small_c10", "on")
+    assert eng.workspace_bytes(B, H, W) - (eng.set_option("small_c10", "off") or eng.workspace_bytes(B, H, W)) == B * T * H * W * 256
+    with pytest.raises(Exception):
+        eng.set_option("small_c10", "maybe")
+    eng.close()
+
+
 def test_nonlocal_options_forward():
     """utils.NonLocalBlock's nltype / sub_sample arguments as engine options (the reference's forward pins them to 1 / 1,
     model/pfnl.py:58): whole forward and the strip form against the fp64 spec with the same arguments; both precisions."""

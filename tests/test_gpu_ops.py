@@ -589,6 +589,33 @@ def test_conv_small_trunk_ops(T, clips, H, W):
     assert not gotm[..., 48:].any()
 
 
+@pytest.mark.parametrize("T,clips,H,W", [(7, 1, 32, 32), (5, 1, 64, 64), (7, 2, 10, 36), (3, 1, 7, 70), (5, 2, 33, 31), (7, 1, 1, 1)])
+def test_conv_small_pf_block_two_launches(T, clips, H, W):
+    """The small-shape block as the forward launches it since round 4: conv10_i has no launch - the conv1_i launch
+    writes each frame's partial W10_t^T . inp1_t, the conv2_i launch sums the T partials (+ bias, leaky-relu) into its `base` source.
+    Against the fp64 spec written as model/pfnl.py:66-71 (conv1 -> concat -> conv10 -> concat([base, f]) -> conv2 -> residual);
+    ragged tiles, one / two / three rows per workgroup, a single pixel; repeated launches are bit-identical (fixed summation order)."""
+    rng = np.random.default_rng(T * 100 + H + W)
+    F = clips * T
+    x = rng.normal(size=(F, H, W, 64)).astype(np.float32)
+    k1 = (rng.normal(size=(3, 3, 64, 64)) / 24.0).astype(np.float32)
+    k10 = (rng.normal(size=(1, 1, 64 * T, 64)) / np.sqrt(64 * T)).astype(np.float32)
+    k2 = (rng.normal(size=(3, 3, 128, 64)) / 34.0).astype(np.float32)
+    b1, b10, b2 = ((rng.normal(size=64) * 0.1).astype(np.float32) for _ in range(3))
+    x64 = x.astype(np.float64)
+    r1 = pfnl_spec.lrelu(pfnl_spec.conv2d_same(x64, k1.astype(np.float64), b1.astype(np.float64)))
+    rc = r1.reshape(clips, T, H, W, 64).transpose(0, 2, 3, 1, 4).reshape(clips, H, W, T * 64)
+    rb = pfnl_spec.lrelu(pfnl_spec.conv2d_same(rc, k10.astype(np.float64), b10.astype(np.float64)))
+    cat = np.concatenate([np.repeat(rb, T, axis=0), r1], axis=-1)
+    r2 = x64 + pfnl_spec.lrelu(pfnl_spec.conv2d_same(cat, k2.astype(np.float64), b2.astype(np.float64)))
+    g1, g2 = ops.conv_small_pf_block(dev(x), k1, b1, k10, b10, k2, b2, T)
+    e1, e2 = np.abs(g1.cpu().numpy() - r1).max(), np.abs(g2.cpu().numpy() - r2).max()
+    print(f"conv_small block T{T} {clips}x{H}x{W}: inp1 err {e1:.3g}, out err {e2:.3g} (|ref| <= {np.abs(r2).max():.3g})")
+    assert e1 < 4e-6 * max(1.0, np.abs(r1).max()) and e2 < 6e-6 * max(1.0, np.abs(r2).max())
+    h1, h2 = ops.conv_small_pf_block(dev(x), k1, b1, k10, b10, k2, b2, T)
+    assert torch.equal(g1, h1) and torch.equal(g2, h2)
+
+
 def test_conv3x3_split16_scaling_and_data_movement():
     """Accuracy does not depend on the magnitude of the activations inside binary16's range (lo' is kept scaled by 2^11, so
     small values do not lean on binary16 subnormals); a delta kernel moves data bit-exactly (hi + lo' 2^-11 reconstructs x
