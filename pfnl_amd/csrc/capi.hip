@@ -2011,7 +2011,7 @@ int pfnl_op_conv_small_pf_block(const float* x, const float* k1_host, const floa
                                 const float* k2_host, const float* b2_host, float* inp1, float* out, int clips, int T, int H, int W,
                                 void* stream) {
     if (!x || !k1_host || !k10_host || !k2_host || !inp1 || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
-    if (clips < 1 || T < 1 || T > 8 || H < 1 || W < 1) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
+    if (clips < 1 || T < 1 || T > 7 || H < 1 || W < 1) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
     hipStream_t s = (hipStream_t)stream;
     const size_t n1 = pfnl::conv_small_pack_halfs(3, 1), n10 = pfnl::conv_small_pack_halfs(1, T), n2 = pfnl::conv_small_pack_halfs(3, 2);
     std::vector<uint16_t> pack(n1 + n10 + n2 + 3 * 128, 0);

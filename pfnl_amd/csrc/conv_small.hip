@@ -36,6 +36,7 @@ constexpr int CM_NW = 8;                                            // waves per
 constexpr int CM_THREADS = CM_NW * 64;
 constexpr int CM_NQ = CM_NW / 2;                                    // K parts that meet in LDS
 constexpr int CM_CGW = 8 / CM_NW;                                   // 16-channel groups of a source per wave (1)
+constexpr int CM_ASUM_MAX = 7;                                      // partial tensors a summed source can have (T <= 7)
 
 #ifdef PFNL_CM_TIMING   /* phase timeline of a workgroup (tools/cm_timing.py); not part of the product build */
 __device__ long long cm_dbg[4096 * 16];
@@ -110,30 +111,45 @@ __global__ __launch_bounds__(CM_THREADS, 1) void conv_small_kernel(ConvSmallPara
     }
     const float nscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -2048.0f)));
     f32x4 stg[G::ITERS];
-    auto request = [&](int s) __attribute__((always_inline)) {
+    auto request = [&](int s, auto first) __attribute__((always_inline)) {
         const int org = ((y0 - PAD) * W + x0 - PAD) * 256;
-        if constexpr (ASUM) {
-            if (s < p.nA) {                                         // (wave-uniform) `a` = lrelu(sum of the a_nsum partial tensors + a_bias)
+        if constexpr (ASUM && decltype(first)::value) {             // (only the prologue's call: source 0 = `a`; nA == 1 with ASUM)
+            {                                                       // `a` = lrelu(sum of the a_nsum partial tensors + a_bias)
+                // every partial's piece is requested before the first is used (ONE round trip to L2, not a_nsum of them): the loop
+                // is written out over CM_ASUM_MAX tensors, the ones past a_nsum with an empty resource (zero, no memory access);
+                // the sum runs in the fixed order j = 0, 1, ... (deterministic)
                 const int ns = p.a_nsum;
                 const float* const src0 = p.a + (size_t)(item / p.a_div) * ns * hw64;
-                f32x4 acc[G::ITERS];
                 int off[G::ITERS];
 #pragma unroll
                 for (int k = 0; k < G::ITERS; ++k) {
                     const int gy = y0 + ((lpk[k] >> 16) & 0xff) - PAD, gx = x0 + ((unsigned)lpk[k] >> 24) - PAD;
                     const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
                     off[k] = in ? org + grel[k] : 0x7fffffff;
-                    acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                for (int j = 0; j < ns; ++j) {                      // fixed order: deterministic
-                    const __amdgpu_buffer_rsrc_t rj = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src0 + (size_t)j * hw64), 0, item_bytes, 0x00020000);
+                constexpr int NB = CM_ASUM_MAX;                     // tensors per batch (registers: NB x ITERS x 4; the prologue holds little else)
+                f32x4 sum[G::ITERS];
 #pragma unroll
-                    for (int k = 0; k < G::ITERS; ++k) acc[k] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rj, off[k], 0, 0));
+                for (int j0 = 0; j0 < CM_ASUM_MAX; j0 += NB) {
+                    f32x4 part[NB][G::ITERS];
+#pragma unroll
+                    for (int jj = 0; jj < NB; ++jj) {
+                        const int j = j0 + jj;
+                        const __amdgpu_buffer_rsrc_t rj = __builtin_amdgcn_make_buffer_rsrc(
+                            const_cast<float*>(src0 + (size_t)min(j, ns - 1) * hw64), 0, (j < ns && j < CM_ASUM_MAX) ? item_bytes : 0, 0x00020000);
+#pragma unroll
+                        for (int k = 0; k < G::ITERS; ++k) part[jj][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rj, off[k], 0, 0));
+                    }
+#pragma unroll
+                    for (int k = 0; k < G::ITERS; ++k)
+#pragma unroll
+                        for (int jj = 0; jj < NB; ++jj) sum[k] = (j0 + jj == 0) ? part[0][k] : sum[k] + part[jj][k];
                 }
 #pragma unroll
                 for (int k = 0; k < G::ITERS; ++k) {
                     const int id = min(k * CM_THREADS + tid, G::PIECES - 1);
-                    f32x4 v = acc[k] + *reinterpret_cast<const f32x4*>(p.a_bias + (id & 15) * 4);
+                    f32x4 v = sum[k];
+                    v += *reinterpret_cast<const f32x4*>(p.a_bias + (id & 15) * 4);
                     v.x = fmaxf(v.x, 0.2f * v.x);
                     v.y = fmaxf(v.y, 0.2f * v.y);
                     v.z = fmaxf(v.z, 0.2f * v.z);
@@ -171,6 +187,9 @@ __global__ __launch_bounds__(CM_THREADS, 1) void conv_small_kernel(ConvSmallPara
         const int col = (lane & 31) + kx;
         paddr[kx] = col * 256 + ((((kq >> 1) * 8 + (kq & 1) * 2 + (lane >> 5)) ^ (col & 15)) << 4);
     }
+    CM_STAMP(0);
+    request(0, std::true_type{});                                   // (ahead of the weight ring: the summed source is register-hungry)
+    CM_STAMP(1);
     // weights: this wave's steps are contiguous: [kq][nt][source][tap][part][lane] x 16 B
     const cmu4* const wsrc = reinterpret_cast<const cmu4*>(p.wpack) + ((size_t)(kq * 2 + nt) * ntot) * 128 + lane;
     cmu4 wring[G::RING][2];
@@ -195,9 +214,7 @@ __global__ __launch_bounds__(CM_THREADS, 1) void conv_small_kernel(ConvSmallPara
             accc[r][i] = 0.f;
         }
 
-    CM_STAMP(0);
-    request(0);
-    CM_STAMP(1);
+
     commit(0);
     CM_STAMP(2);
     __syncthreads();
@@ -205,7 +222,7 @@ __global__ __launch_bounds__(CM_THREADS, 1) void conv_small_kernel(ConvSmallPara
     for (int c = 0; c < nsrc; ++c) {
         const unsigned char* const tile = cm_smem + (c & 1) * G::BUF_BYTES;
         const bool more = c + 1 < nsrc;                             // (wave-uniform)
-        if (more) request(c + 1);
+        if (more) request(c + 1, std::false_type{});
         const int nbase = c * G::STEPS;
         // Written-out pipeline (left alone, hipcc sinks every weight load and every ds_read to the instruction in front of its MFMA
         // and waits for it there: measured 6.8 us for 108 MFMAs): the pixel operands of step j + 1 are read before the MFMAs of
@@ -469,7 +486,7 @@ hipError_t launch_conv_small(const ConvSmallParams& p, hipStream_t s) {
     const bool r2 = bestR >= 2;
     const bool xs = p.x_wpack != nullptr, asum = p.a_nsum > 1;
     if (xs && (p.ks != 3 || p.nsrc != 1 || p.nA != 0 || !p.x_out || p.x_T < 1 || p.items % p.x_T || p.resid)) return hipErrorInvalidValue;
-    if (asum && (p.ks != 3 || p.nA != 1 || !p.a_bias || xs)) return hipErrorInvalidValue;
+    if (asum && (p.ks != 3 || p.nA != 1 || !p.a_bias || xs || p.a_nsum > CM_ASUM_MAX)) return hipErrorInvalidValue;
     if (xs) return bestR == 3 ? cm_launch<3, 3, true, false>(p, (int)tr[3], s) : bestR == 2 ? cm_launch<3, 2, true, false>(p, (int)t2, s) : cm_launch<3, 1, true, false>(p, (int)t1, s);
     if (asum) return bestR == 3 ? cm_launch<3, 3, false, true>(p, (int)tr[3], s) : bestR == 2 ? cm_launch<3, 2, false, true>(p, (int)t2, s) : cm_launch<3, 1, false, true>(p, (int)t1, s);
     if (p.ks == 3) return bestR == 3 ? cm_launch<3, 3>(p, (int)tr[3], s) : bestR == 2 ? cm_launch<3, 2>(p, (int)t2, s) : cm_launch<3, 1>(p, (int)t1, s);

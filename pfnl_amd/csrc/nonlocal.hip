@@ -297,7 +297,8 @@ static int nl_key_splits2(int B, int N, int Nk) {
     const int qblocks = (N + 127) / 128, ntiles = (Nk + NL_KT - 1) / NL_KT;
     int ks = (512 + qblocks * B - 1) / (qblocks * B);
     if (ks > 8) ks = 8;
-    if (ks > ntiles / 4) ks = ntiles / 4;
+    const int min_tiles = qblocks * B >= 32 ? 4 : 1;
+    if (ks > ntiles / min_tiles) ks = ntiles / min_tiles;
     return ks < 1 ? 1 : ks;
 }
 
@@ -305,7 +306,11 @@ int nl_key_splits(int B, int N) {
     const int qblocks = (N + 127) / 128, ntiles = (N + NL_KT - 1) / NL_KT;
     int ks = (512 + qblocks * B - 1) / (qblocks * B);          // aim at >= 2 workgroups per CU
     if (ks > 8) ks = 8;
-    if (ks > ntiles / 4) ks = ntiles / 4;                       // keep >= 4 key tiles per split
+    // keep >= 4 key tiles per split - except where a handful of workgroups is all there is (BASELINE.json configs[0]: 256 queries =
+    // 2 workgroups walking 4 tiles of f32 MFMAs each, 40 us of pure latency): there every tile gets a workgroup of its own
+    // (measured round 4: 40 -> 17 us for attention + merge at 7 x 32 x 32)
+    const int min_tiles = qblocks * B >= 32 ? 4 : 1;
+    if (ks > ntiles / min_tiles) ks = ntiles / min_tiles;
     return ks < 1 ? 1 : ks;
 }
 
