@@ -286,8 +286,9 @@ def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
                             "(shader clock 1.3 - 1.6 GHz; profiles/r03_ubench_conv_core.txt)"})
         return rec
     if algo == "small":
-        # small shapes: conv1_i + the WHOLE of conv2_i (3x3 over concat([base, f]): the reference graph's FLOPs, no shared-base split),
-        # 2 launches per block; latency-bound: the fraction of the f16 MFMA peak is what it is
+        # small shapes: conv1_i (+ conv10_i's per-frame partials since round 4) + the WHOLE of conv2_i (3x3 over concat([base, f]): the
+        # reference graph's FLOPs, no shared-base split), 2 launches per block; latency-bound: the fraction of the f16 MFMA
+        # peak is what it is
         launches_per_step = 2 * geom.num_block
         flops_ref3 = geom.num_block * 3 * F * P * 9 * 64 * 64 * 2.0
         t = flops_ref3 / launches_per_step / (avg_ms * 1e-3) / 1e12
@@ -515,18 +516,25 @@ def main():
     # forward comes from a separate, untimed pass with events on two blocks and on everything outside the blocks (--full-profile: the
     # timed steps carry events around every launch instead - an event costs the stream 2 us and more where it splits back-to-back launches)
     prof_mode = 0 if args.no_profile else (1 if args.full_profile else 3)
+    small_shape = resolve_conv3x3(args.conv3x3, B_PER_GPU, H, W, T=T_WL) == "small" and not bf16
+    if small_shape and prof_mode == 3:
+        # launch-bound shapes (~47 launches of 5 - 15 us): even three events move the step; the timed steps carry none and the
+        # breakdown pass below runs in "class runs" mode (one event per change of kernel class: pfnl_profile_enable(4))
+        prof_mode = 0
     eng.profile(prof_mode)
     elapsed = timed_steps(step, fence, args.steps)
     eng.profile(False)
     prof = eng.profile_read()
     prof_all, n_all = None, 0
-    if prof_mode == 3:
+    if prof_mode == 3 or (small_shape and not args.no_profile and not args.full_profile):
         n_all = max(3, args.steps // 2)
         eng.profile_reset()
-        eng.profile(2)
+        eng.profile(4 if small_shape else 2)
         timed_steps(step, fence, n_all)                                  # (not part of `value`)
         eng.profile(False)
         prof_all = eng.profile_read()
+        if small_shape:
+            prof = prof_all                                              # (the roofline's launch average comes from this pass)
 
     if use_dist:
         if comm is not None:
@@ -556,7 +564,9 @@ def main():
         sc_all = nb / float(blocks_sampled(nb)) if nb else 1.0
         breakdown = {}
         for n, v in prof.items():
-            if v["launches"]:
+            if small_shape:                                              # class runs: whole-forward intervals, nothing to scale
+                breakdown[n] = round(prof_all[n]["ms"] / n_all, 4)
+            elif v["launches"]:
                 breakdown[n] = round(v["ms"] / args.steps * nb, 4)
             else:
                 breakdown[n] = round(prof_all[n]["ms"] / n_all * (sc_all if n in ("conv3x3", "conv1x1") else 1.0), 4)
@@ -628,7 +638,7 @@ def secondary_workloads(eng, geom, weights, local_dev, dev, x_cfg2, out_cfg2):
     def sync():
         torch.cuda.synchronize()
 
-    def run(e, g, B, H, W, steps, seed, bf16=False, label=""):
+    def run(e, g, B, H, W, steps, seed, bf16=False, label="", small=False):
         xs = torch.from_numpy(synth.uniform_clips(B, g.num_frames, H, W, seed=seed)).to(dev)
         o = torch.empty(e.out_shape(B, H, W), dtype=torch.float32, device=dev)
         st = torch.cuda.current_stream().cuda_stream
@@ -638,12 +648,12 @@ def secondary_workloads(eng, geom, weights, local_dev, dev, x_cfg2, out_cfg2):
         sync()
         el = timed_steps(fwd, sync, steps)                           # the line's ms_per_step / value: no events
         e.profile_reset()
-        e.profile(2)
-        timed_steps(fwd, sync, steps)                                # the breakdown: sampled events
+        e.profile(4 if small else 2)                                 # the breakdown: sampled events (small shapes: one per class run)
+        timed_steps(fwd, sync, steps)
         e.profile(False)
         prof = e.profile_read()
         nb = g.num_block
-        sc = nb / float(blocks_sampled(nb)) if nb else 1.0
+        sc = 1.0 if small else (nb / float(blocks_sampled(nb)) if nb else 1.0)
         ms = 1e3 * el / steps
         rec = {"workload": label, "dtype": "bf16" if bf16 else "f32", "clips": B, "steps": steps, "ms_per_step": round(ms, 4),
                "value": round(B * steps / el, 3), "unit": "HR frames/s", "input": "resident in HBM",
@@ -663,14 +673,14 @@ def secondary_workloads(eng, geom, weights, local_dev, dev, x_cfg2, out_cfg2):
     rec["roofline"] = conv3x3_roofline(geom, prof, 1, 270, 480, resolve_conv3x3(None, 1, 270, 480), False, "cfg4")
     out.append(rec)
     # configs[0]: 7x32x32, batch 1 (the reference's CPU-runnable plumbing case; latency-bound on a GPU)
-    rec, prof = run(eng, geom, 1, 32, 32, 100, 1234, label="BASELINE.json configs[0]: 4xSR 7x32x32 -> 128x128, batch 1, fp32")
+    rec, prof = run(eng, geom, 1, 32, 32, 100, 1234, label="BASELINE.json configs[0]: 4xSR 7x32x32 -> 128x128, batch 1, fp32", small=True)
     rec["roofline"] = conv3x3_roofline(geom, prof, 1, 32, 32, resolve_conv3x3(None, 1, 32, 32), False, "cfg1")
     out.append(rec)
     # configs[4]: 2x, 5 frames, 64x64 (build-defined tail; 20 blocks)
     g5 = PFNLGeometry(num_frames=5, scale=2, num_block=20)
     e5 = PFNLEngine(g5, device=local_dev)
     e5.load_weights(synth.synthetic_weights(g5, seed=0))
-    rec, prof = run(e5, g5, 1, 64, 64, 100, 55, label="BASELINE.json configs[4]: 2xSR 5x64x64 -> 128x128, batch 1, fp32")
+    rec, prof = run(e5, g5, 1, 64, 64, 100, 55, label="BASELINE.json configs[4]: 2xSR 5x64x64 -> 128x128, batch 1, fp32", small=True)
     rec["roofline"] = conv3x3_roofline(g5, prof, 1, 64, 64, resolve_conv3x3(None, 1, 64, 64, T=5), False, "cfg5")
     out.append(rec)
     e5.close()

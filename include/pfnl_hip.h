@@ -196,7 +196,9 @@ int pfnl_comm_allgather(pfnl_comm* c, const float* send_dev, float* recv_dev, si
  * progressive-fusion blocks and for blocks 3, 13, ... (every 4th block of models with fewer than ten; blocks are identical, so average launch durations
  * are unbiased; ~30 instead of ~95 events per forward - each event costs the stream ~2 us, and more where it breaks up back-to-back
  * launches); enable = 3: the launches of ONE progressive-fusion block (block num_block / 2) and nothing else - 3 events per forward: the
- * dominant kernel classes timed live at next to no cost to the forward that is being timed;
+ * dominant kernel classes timed live at next to no cost to the forward that is being timed; enable = 4 ("class runs", for the
+ * launch-bound small shapes where an event per launch costs a fifth of the forward): ONE event wherever the class of consecutive
+ * launches changes and at the end of the forward (~8 per forward), each interval credited with the launches it holds;
  * pfnl_profile_read synchronises and returns accumulated milliseconds and the number of TIMED launches
  * since the last reset. */
 enum {

@@ -253,6 +253,10 @@ struct pfnl_handle {
     bool chain_open = false;          // an event has been recorded in the current forward
     std::vector<hipEvent_t> evs;
     std::vector<int> ev_cls;          // class of the interval ENDING at event i (-1: chain start)
+    std::vector<int> ev_cnt;          // launches inside that interval (1, except in mode 4)
+    // mode 4 ("class runs", for launch-bound shapes where an event per launch costs a fifth of the forward): ONE event where the class
+    // of consecutive launches changes (and at the end of the forward): ~8 events per forward; the run's launches are counted
+    int run_cls = -1, run_n = 0;
     size_t evs_used = 0;
     double prof_ms[PFNL_K_COUNT] = {0};
     int64_t prof_n[PFNL_K_COUNT] = {0};
@@ -266,15 +270,24 @@ using namespace pfnl;
 // the blocks are identical), every 4th below ten blocks.  bench.py scales the in-block classes by num_block / (blocks sampled).
 inline bool prof_sampled(int nb, int i) { return nb >= 10 ? (i % 10) == 3 : (i & 3) == 0; }
 
-int prof_mark(pfnl_handle* h, hipStream_t s, int cls) {
+int prof_mark(pfnl_handle* h, hipStream_t s, int cls, int count = 1) {
     if (h->evs_used == h->evs.size()) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return -1;
         h->evs.push_back(e);
         h->ev_cls.push_back(-1);
+        h->ev_cnt.push_back(1);
     }
     h->ev_cls[h->evs_used] = cls;
+    h->ev_cnt[h->evs_used] = count;
     return hipEventRecord(h->evs[h->evs_used++], s) == hipSuccess ? 0 : -1;
+}
+
+// mode 4: closes the run of same-class launches that is open (at a class change, and where a forward ends)
+void prof_flush_run(pfnl_handle* h, hipStream_t s) {
+    if (h->prof && h->prof_mode == 4 && h->run_n > 0) prof_mark(h, s, h->run_cls, h->run_n);
+    h->run_n = 0;
+    h->run_cls = -1;
 }
 
 // roctx ranges around every kernel class (the tracing hook of this path): env PFNL_ROCTX=1 resolves
@@ -316,13 +329,19 @@ struct ProfScope {
             roctx()->push(kClassNames[cls]);
             ranged = true;
         }
+        if (h && h->prof && h->prof_mode == 4 && h->run_n > 0 && h->run_cls != cls) prof_flush_run(h, s);
         if (h && h->prof && h->prof_gate && !h->chain_open) {
             prof_mark(h, s, -1);
             h->chain_open = true;
         }
     }
     ~ProfScope() {
-        if (h && h->prof && h->prof_gate) prof_mark(h, s, cls);
+        if (h && h->prof && h->prof_mode == 4) {
+            h->run_cls = cls;
+            ++h->run_n;
+        } else if (h && h->prof && h->prof_gate) {
+            prof_mark(h, s, cls);
+        }
         if (ranged) roctx()->pop();
     }
 };
@@ -335,7 +354,7 @@ int prof_collect(pfnl_handle* h) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, h->evs[i - 1], h->evs[i]) != hipSuccess) return -1;
         h->prof_ms[cls] += ms;
-        h->prof_n[cls] += 1;
+        h->prof_n[cls] += h->ev_cnt[i];
     }
     h->evs_used = 0;
     h->chain_open = false;
@@ -485,7 +504,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             }
         }
         h->prof_gate = h->prof_mode != 3;
-        if (h->prof_mode >= 2) h->chain_open = false;
+        if (h->prof_mode == 2 || h->prof_mode == 3) h->chain_open = false;
         {   // convmerge1 (:73-74): the accumulating mode of the bf16 3x3 kernel, fp32 out for the tail
             ProfScope ps(h, s, PFNL_K_MERGE1);
             ConvBf16Params q{a0, w16 + h->off16_m1, wd + h->off_m1_b, nullptr, nullptr, nullptr, H, W, F, T, 1};
@@ -497,6 +516,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             ProfScope ps(h, s, PFNL_K_TAIL);
             HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, Hfull, W, c.scale, 64, s, strip, rflag));
         }
+        prof_flush_run(h, s);
         h->chain_open = false;
         return 0;
     }
@@ -693,7 +713,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
         }
     }
     h->prof_gate = h->prof_mode != 3;
-    if (h->prof_mode >= 2) h->chain_open = false;
+    if (h->prof_mode == 2 || h->prof_mode == 3) h->chain_open = false;
     if (small && !h->bf16) {   // convmerge1 (:73-74): T sources, cout 48 zero-padded to 64
         {
             ProfScope ps(h, s, PFNL_K_MERGE1);
@@ -705,6 +725,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             ProfScope ps(h, s, PFNL_K_TAIL);
             HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, Hfull, W, c.scale, 64, s, strip, rflag));
         }
+        prof_flush_run(h, s);
         h->chain_open = false;
         h->prof_gate = h->prof_mode != 3;
         return 0;
@@ -758,6 +779,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
         ProfScope ps(h, s, PFNL_K_TAIL);
         HIPCHK(launch_tail(h->merge.p, in, wd + h->off_m2_w, wd + h->off_m2_b, out, B, T, Hfull, W, c.scale, mstride, s, strip, rflag));
     }
+    prof_flush_run(h, s);
     h->chain_open = false;
     return 0;
 }
@@ -1646,8 +1668,10 @@ int pfnl_profile_enable(pfnl_handle* h, int enable) {
         if (prof_collect(h)) return fail(PFNL_ERR_HIP, "event collection failed");
     }
     h->prof = enable != 0;
-    h->prof_mode = enable == 2 ? 2 : enable == 3 ? 3 : (enable ? 1 : 0);
+    h->prof_mode = enable == 2 ? 2 : enable == 3 ? 3 : enable == 4 ? 4 : (enable ? 1 : 0);
     h->prof_gate = h->prof_mode != 3;
+    h->run_n = 0;
+    h->run_cls = -1;
     return 0;
 }
 
