@@ -411,7 +411,7 @@ def test_profile_counts_full_and_sampled():
     eng = engine_for(geom)
     x = synth.uniform_clips(1, 7, 16, 32, seed=5)
     y0 = eng.forward(x)
-    for mode, blocks in ((1, 6), (2, 2)):            # blocks 0 and 4 are timed in sampled mode
+    for mode, blocks in ((1, 6), (2, 2), (4, 6)):    # blocks 0 and 4 are timed in sampled mode; 4 = one event per class run, every launch counted
         eng.profile_reset()
         eng.profile(mode)
         y = eng.forward(x)
