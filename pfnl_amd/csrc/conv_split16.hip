@@ -793,9 +793,17 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
             const int gy_ = (y0_) + py_ - 1, gx_ = (x0_) + px_ - 1;                              \
             const bool in_ = (interior_) | (((unsigned)gy_ < (unsigned)H) & ((unsigned)gx_ < (unsigned)W));   /* (no short circuit: no branches) */ \
             const int off_ = (org_) + py_ * wbytes + px_ * 256 + c16;                            \
-            stg[k_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, in_ ? off_ : 0x7fffffff, 0, CS_HALO_AUX)); \
+            K1_HALO_LOAD(stg[k_], rs_, in_ ? off_ : 0x7fffffff);                                  \
         }                                                                                        \
     } while (0)
+#ifdef K1_X_NOLOAD    /* timing experiments only (wrong results on purpose; tools/variant_run_r4.sh) */
+#define K1_HALO_LOAD(dst_, rs_, off_) do { dst_ = f32x4{(float)(off_), 0.25f, -0.5f, 1.5f}; } while (0)
+#else
+#define K1_HALO_LOAD(dst_, rs_, off_) do { dst_ = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, off_, 0, CS_HALO_AUX)); } while (0)
+#endif
+#ifdef K1_X_NOCOMMIT  /* timing experiments only: no split arithmetic, no ds_write of the halo (the MFMAs run on stale LDS) */
+#define K1_COMMIT1(k_, buf_) do { if (stg[k_].x == 1.2345e30f) *reinterpret_cast<f32x4*>(cs_smem) = stg[k_]; } while (0)
+#else
 #define K1_COMMIT1(k_, buf_)                                                                     \
     do {                                                                                         \
         u32x2 hi_, lo2_;                                                                         \
@@ -804,6 +812,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
         *reinterpret_cast<u32x2*>(cs_smem + (buf_) * CS_TILE_BYTES + lo_) = hi_;                 \
         *reinterpret_cast<u32x2*>(cs_smem + (buf_) * CS_TILE_BYTES + (lo_ ^ 64)) = lo2_;         \
     } while (0)
+#endif
 
     int paddr[3];
 #pragma unroll

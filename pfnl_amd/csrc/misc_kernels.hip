@@ -142,16 +142,43 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
         hb = __builtin_bit_cast(unsigned short, hi);
         lb = __builtin_bit_cast(unsigned short, lo);
     };
-    // weights: entry (ky, g, l) = 8 values k' = 8 (l >> 5) + e of row tap ky for channel 32 g + (l & 31); k' = kx * 3 + c, k' = 15: 0
-    for (int ent = tid; ent < 5 * 2 * 64; ent += 256) {
+    // Everything the prologue needs - this thread's weight values and its dwords of the input tile - is requested before any of it is
+    // used: written as a loop with the load under a bounds test, every dword of the tile waited for its own round trip (9 in a row:
+    // most of the 13 us this launch took at 7 x 32 x 32, where nothing else hides them).  Out-of-tile / out-of-image dwords read a
+    // clamped address and are zeroed.
+    constexpr int C0M_WIT = (5 * 2 * 64 + 255) / 256, C0M_XIT = (C0M_IN_DW + 255) / 256;
+    float wreg[C0M_WIT][8], xreg[C0M_XIT];
+#pragma unroll
+    for (int k = 0; k < C0M_WIT; ++k) {
+        const int ent = min(tid + k * 256, 5 * 2 * 64 - 1);
         const int l = ent & 63, g = (ent >> 6) & 1, ky = ent >> 7;
-        unsigned short hv[8], lv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int kp = 8 * (l >> 5) + e;
-            const float wv = kp < 15 ? w[(size_t)(ky * 15 + kp) * 64 + 32 * g + (l & 31)] : 0.f;
-            split1(wv, hv[e], lv[e]);
+            const float wv = w[(size_t)(ky * 15 + min(kp, 14)) * 64 + 32 * g + (l & 31)];
+            wreg[k][e] = kp < 15 ? wv : 0.f;
         }
+    }
+#pragma unroll
+    for (int k = 0; k < C0M_XIT; ++k) {
+        const int i = min(tid + k * 256, C0M_IN_DW - 1);
+        const int c = i % 3, pix = i / 3;
+        const int py = pix / C0M_IW, px = pix - py * C0M_IW;
+        const int gy = yoff + y0 + py - 2, gx = x0 + px - 2;
+        const bool in = py < C0M_IH && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const int cy = in ? gy : 0, cx = in ? gx : 0;
+        const float v = Xb[((size_t)(cy >> 1) * W2 + (cx >> 1)) * CP + ((cy & 1) * 2 + (cx & 1)) * C3 + 3 * t + c];
+        xreg[k] = in ? v : 0.f;
+    }
+    // weights: entry (ky, g, l) = 8 values k' = 8 (l >> 5) + e of row tap ky for channel 32 g + (l & 31); k' = kx * 3 + c, k' = 15: 0
+#pragma unroll
+    for (int k = 0; k < C0M_WIT; ++k) {
+        const int ent = tid + k * 256;
+        if (ent >= 5 * 2 * 64) break;
+        const int l = ent & 63, g = (ent >> 6) & 1, ky = ent >> 7;
+        unsigned short hv[8], lv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split1(wreg[k][e], hv[e], lv[e]);
         u32x4 hq, lq;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -162,15 +189,12 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
         *reinterpret_cast<u32x4*>(sw + ((ky * 2 + 1) * 2 + g) * 1024 + l * 16) = lq;
     }
     // input tile (frame coordinates: rows outside a strip are real data), split once: hi | lo' << 16
-    for (int i = tid; i < C0M_IN_DW; i += 256) {
-        const int c = i % 3, pix = i / 3;
-        const int py = pix / C0M_IW, px = pix - py * C0M_IW;
-        const int gy = yoff + y0 + py - 2, gx = x0 + px - 2;
-        float v = 0.f;
-        if (py < C0M_IH && gy >= 0 && gy < H && gx >= 0 && gx < W)
-            v = Xb[((size_t)(gy >> 1) * W2 + (gx >> 1)) * CP + ((gy & 1) * 2 + (gx & 1)) * C3 + 3 * t + c];
+#pragma unroll
+    for (int k = 0; k < C0M_XIT; ++k) {
+        const int i = tid + k * 256;
+        if (i >= C0M_IN_DW) break;
         unsigned short hb, lb;
-        split1(v, hb, lb);
+        split1(xreg[k], hb, lb);
         s_in[i] = hb | ((unsigned)lb << 16);
     }
     __syncthreads();
@@ -358,25 +382,34 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ mer
     float acc[CO];
 #pragma unroll
     for (int o = 0; o < CO; ++o) acc[o] = b2[o];
+    // all nine taps are requested before the first is used (branches around the loads made every tap wait for its own round trip:
+    // 13 us of latency at 7 x 32 x 32); a tap outside the image reads a clamped address and is zeroed
+    float4 tv[9][3];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-        const int yy = Y + dy - 1;
-        if (yy < 0 || yy >= H2) continue;
+    for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-            const int xx = X + dx - 1;
-            if (xx < 0 || xx >= W2) continue;
+            const int yy = Y + dy - 1, xx = X + dx - 1;
+            const bool in = yy >= 0 && yy < H2 && xx >= 0 && xx < W2;
+            const int yc = in ? yy : Y, xq = in ? xx : X;
             // large1[yy][xx][k] = merge[yy/2][xx/2][((yy&1)*2+(xx&1))*12 + k]   (model/pfnl.py:76)
             const float4* src = reinterpret_cast<const float4*>(
-                mb + ((size_t)(yy >> 1) * W + (xx >> 1)) * MS + ((yy & 1) * 2 + (xx & 1)) * 12);
-            const float4 v0 = src[0], v1 = src[1], v2 = src[2];
-            const float v[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-            const float* wp = w2 + (dy * 3 + dx) * 12 * CO;
+                mb + ((size_t)(yc >> 1) * W + (xq >> 1)) * MS + ((yc & 1) * 2 + (xq & 1)) * 12);
 #pragma unroll
-            for (int k = 0; k < 12; ++k)
-#pragma unroll
-                for (int o = 0; o < CO; ++o) acc[o] = fmaf(v[k], wp[k * CO + o], acc[o]);
+            for (int j = 0; j < 3; ++j) {
+                const float4 v = src[j];
+                tv[dy * 3 + dx][j] = in ? v : float4{0.f, 0.f, 0.f, 0.f};
+            }
         }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float4 v0 = tv[t][0], v1 = tv[t][1], v2 = tv[t][2];
+        const float v[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+        const float* wp = w2 + t * 12 * CO;
+#pragma unroll
+        for (int k = 0; k < 12; ++k)
+#pragma unroll
+            for (int o = 0; o < CO; ++o) acc[o] = fmaf(v[k], wp[k * CO + o], acc[o]);
     }
 
     const float* xc = x + (((size_t)b * T + T / 2) * H) * W * 3;   // centre frame, model/pfnl.py:63
