@@ -382,34 +382,25 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ mer
     float acc[CO];
 #pragma unroll
     for (int o = 0; o < CO; ++o) acc[o] = b2[o];
-    // all nine taps are requested before the first is used (branches around the loads made every tap wait for its own round trip:
-    // 13 us of latency at 7 x 32 x 32); a tap outside the image reads a clamped address and is zeroed
-    float4 tv[9][3];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = Y + dy - 1;
+        if (yy < 0 || yy >= H2) continue;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-            const int yy = Y + dy - 1, xx = X + dx - 1;
-            const bool in = yy >= 0 && yy < H2 && xx >= 0 && xx < W2;
-            const int yc = in ? yy : Y, xq = in ? xx : X;
+            const int xx = X + dx - 1;
+            if (xx < 0 || xx >= W2) continue;
             // large1[yy][xx][k] = merge[yy/2][xx/2][((yy&1)*2+(xx&1))*12 + k]   (model/pfnl.py:76)
             const float4* src = reinterpret_cast<const float4*>(
-                mb + ((size_t)(yc >> 1) * W + (xq >> 1)) * MS + ((yc & 1) * 2 + (xq & 1)) * 12);
+                mb + ((size_t)(yy >> 1) * W + (xx >> 1)) * MS + ((yy & 1) * 2 + (xx & 1)) * 12);
+            const float4 v0 = src[0], v1 = src[1], v2 = src[2];
+            const float v[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+            const float* wp = w2 + (dy * 3 + dx) * 12 * CO;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const float4 v = src[j];
-                tv[dy * 3 + dx][j] = in ? v : float4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int k = 0; k < 12; ++k)
+#pragma unroll
+                for (int o = 0; o < CO; ++o) acc[o] = fmaf(v[k], wp[k * CO + o], acc[o]);
         }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const float4 v0 = tv[t][0], v1 = tv[t][1], v2 = tv[t][2];
-        const float v[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-        const float* wp = w2 + t * 12 * CO;
-#pragma unroll
-        for (int k = 0; k < 12; ++k)
-#pragma unroll
-            for (int o = 0; o < CO; ++o) acc[o] = fmaf(v[k], wp[k * CO + o], acc[o]);
     }
 
     const float* xc = x + (((size_t)b * T + T / 2) * H) * W * 3;   // centre frame, model/pfnl.py:63
