@@ -7,6 +7,7 @@ happens in the HIP kernels behind ``pfnl_forward``; nothing here computes.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -122,7 +123,7 @@ class PFNLEngine:
         """The numpy array a host-pointer forward fills.  Page-locked when torch can provide it (its caching host allocator:
         no allocation per call after the first): pfnl_forward then lets the copy engine write the result straight into it
         instead of staging it through the handle's pinned strip.  The array owns its memory (numpy keeps the tensor alive)."""
-        if int(np.prod(shape)) * 4 >= (512 << 10):
+        if int(np.prod(shape)) * 4 >= (512 << 10) and os.environ.get("PFNL_HOST_OUTPUT", "pinned") != "pageable":
             try:
                 import torch
                 return torch.empty(shape, dtype=torch.float32, pin_memory=True).numpy()
