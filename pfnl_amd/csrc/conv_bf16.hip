@@ -34,6 +34,7 @@
 // Measured (1x7x270x480, rocprofv3): conv1_i 72 us, conv2_i per-frame half 87 us, shared half 16 us, conv10_i 29 us
 // per block; 3.2-4.3 TB/s of HBM traffic; matrix pipe 38 % busy.  -DCB_X_NOMFMA / NOSTORE / NOLOAD are timing
 // experiments (wrong results on purpose) used to find what bounds the kernel; -DPFNL_BF16_TIMING adds phase stamps.
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include <vector>
@@ -577,6 +578,20 @@ hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s) {
     const bool with10 = p.x_out != nullptr;
     if (with10 && (p.addend || !p.x_w || !p.x_bias || p.add_div < 1 || p.add_div > 7 || p.items % p.add_div)) return hipErrorInvalidValue;
     const int mode = accum ? 3 : (p.addend ? 1 : (with10 ? 2 : 0));
+    {
+        static const bool v2 = [] {
+            const char* e = std::getenv("PFNL_BF16_V2");
+            return !(e && (e[0] == '0' || (e[0] == 'o' && e[1] == 'f')));
+        }();
+        // measured (1080p, rocprofv3): conv1_i + conv10_i 79.5 -> 74.3 us on the second-generation kernel, the plain mode equal, the per-frame
+        // half of conv2_i 80.2 -> 82.6 (it is bound by its bytes in either form): PFNL_BF16_V2 = 1 (default) takes it for mode 2 only,
+        // = all for modes 0 - 2, = 0 never
+        static const bool v2_all = [] {
+            const char* e = std::getenv("PFNL_BF16_V2");
+            return e && e[0] == 'a';
+        }();
+        if (v2 && mode != 3 && (mode == 2 || v2_all)) return launch_conv3x3_bf16_v2(p, mode, s);
+    }
     static std::atomic<int> attr_dev[64][4];                               // the attribute is per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;

@@ -300,3 +300,20 @@ def test_forward_bf16_against_committed_golden(name):
     assert y.shape == ref.shape
     assert synth.psnr(y, ref) > 60.0 and np.abs(y - ref).max() < 2e-3
     eng.close()
+
+
+@pytest.mark.parametrize("sel", ["0", "all"])
+def test_bf16_3x3_kernel_generations(sel):
+    """conv_bf16_v2.hip (round 4: halo by LDS-DMA, MFMA groups that carry one memory instruction each, a serial epilogue phase) is the
+    default for conv1_i + conv10_i only (PFNL_BF16_V2=1); the env selects it for all three modes ("all") or never ("0").  The choice is
+    read once per process, so each setting runs the 3x3 op tests, the random-geometry stress and the forward tests in a process of its own."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PFNL_BF16_V2=sel)
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_bf16.py"), "-x", "-q", "-m", "gpu", "-k",
+                        "conv3x3_bf16_plain or conv3x3_bf16_fused or conv1_conv10_bf16 or random_geometries or matches_rounded_oracle"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=os.path.dirname(here))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
