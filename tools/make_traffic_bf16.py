@@ -8,7 +8,9 @@ def per_kernel(db, ctr):
     c = sqlite3.connect(db)
     out = {}
     for name, val in c.execute("select kernel_name, value from counters_collection where counter_name=?", (ctr,)).fetchall():
-        if "conv3x3_bf16_kernel" not in name:
+        if "conv3x3_bf16_kernel" not in name and "conv3x3_bf16_v2_kernel" not in name:
+            continue
+        if "conv3x3_bf16_kernel<3>" in name:                       # convmerge1 (accumulating mode): not the conv3x3 class of bench.py
             continue
         k = name.split("(")[0].replace("void ", "")
         a = out.setdefault(k, [0, 0.0])
@@ -30,7 +32,7 @@ for i in range(0, len(args) - 1, 3):
     for k in f:
         fb, wb = f[k][1] * 1024 * 2, w[k][1] * 1024
         per[k] = {"dispatches": f[k][0], "fetch_bytes_per_launch": fb / f[k][0], "write_bytes_per_launch": wb / w[k][0]}
-        tot_b += fb + wb
+        tot_b += (fb / f[k][0] + wb / w[k][0]) * f[k][0]           # (the two passes need not have run the same number of launches)
         tot_n += f[k][0]
     res["hbm_bytes_per_launch_avg"][wl] = round(tot_b / tot_n)
     res["per_kernel"][wl] = per
