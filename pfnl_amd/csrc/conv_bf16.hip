@@ -583,14 +583,14 @@ hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s) {
             const char* e = std::getenv("PFNL_BF16_V2");
             return !(e && (e[0] == '0' || (e[0] == 'o' && e[1] == 'f')));
         }();
-        // measured (1080p, rocprofv3): conv1_i + conv10_i 79.5 -> 74.3 us on the second-generation kernel, the plain mode equal, the per-frame
-        // half of conv2_i 80.2 -> 82.6 (it is bound by its bytes in either form): PFNL_BF16_V2 = 1 (default) takes it for mode 2 only,
-        // = all for modes 0 - 2, = 0 never
-        static const bool v2_all = [] {
+        // measured (1080p, rocprofv3 / same-box bench): conv1_i + conv10_i 79.5 -> 74.3 us on the second-generation kernel, the plain mode
+        // equal, the per-frame half of conv2_i 80.2 -> 79 us once its residual is fetched in accumulator layout: default for modes 0 - 2
+        // (4.40 -> 4.33 -> 4.13 ms per forward); PFNL_BF16_V2 = 0: the first kernel; = 2: the second one for conv1_i + conv10_i only
+        static const bool v2_only2 = [] {
             const char* e = std::getenv("PFNL_BF16_V2");
-            return e && e[0] == 'a';
+            return e && e[0] == '2';
         }();
-        if (v2 && mode != 3 && (mode == 2 || v2_all)) return launch_conv3x3_bf16_v2(p, mode, s);
+        if (v2 && mode != 3 && (mode == 2 || !v2_only2)) return launch_conv3x3_bf16_v2(p, mode, s);
     }
     static std::atomic<int> attr_dev[64][4];                               // the attribute is per device
     int dev = 0;

@@ -12,10 +12,10 @@
 //     zeros), issued at the START of a tile for the NEXT tile into the other buffer, waited for with a fence load at the tile's end: no
 //     staging registers (24), no commit (6 ds_write_b128 per thread), no packed-word decode;
 //   * the 12 groups of a tile are MFMAs and their operand reads and nothing else;
-//   * then a short SERIAL phase in the tile's own halo buffer (free now): [residual lines -> scratch] accumulators -> bias is the initial
-//     C, addend, leaky-relu, residual, bf16 -> pixel-major lines in LDS -> barrier -> whole 128-byte lines to HBM, and (mode 2) the 1x1 of
+//   * then a short SERIAL phase in the tile's own halo buffer (free now): accumulators -> bias is the initial C, addend, leaky-relu,
+//     residual (both fetched in accumulator layout during the first groups), bf16 -> pixel-major lines in LDS -> barrier -> whole 128-byte lines to HBM, and (mode 2) the 1x1 of
 //     conv10_i reading the same lines as its B operands.  No copy of the accumulators (32 registers), no `pending` state, no tail.
-// Barriers per tile: 3 (4 with the residual).
+// Barriers per tile: 3.
 #include <type_traits>
 
 #include "common.h"
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(B2_THREADS, 1) void conv3x3_bf16_v2_kernel(ConvBf16
     const int ech = 32 * mt + 16 * (lane >> 5);
     f32x16 acc[2];
     [[maybe_unused]] b2u4 radd[2][2];                               // FUSE: addend pieces (accumulator layout; fetched once per chain)
-    [[maybe_unused]] b2u4 rq[4];                                    // FUSE: this thread's residual pieces (whole lines)
+    [[maybe_unused]] b2u4 rq[4];                                    // FUSE: this lane's residual pieces (row n, channel half h: index 2n + h)
     [[maybe_unused]] b2u4 xw[4];                                    // WITH10: W10 operands of the tile's frame
     [[maybe_unused]] f32x16 bacc[2];
     if constexpr (WITH10) {
@@ -262,7 +262,14 @@ __global__ __launch_bounds__(B2_THREADS, 1) void conv3x3_bf16_v2_kernel(ConvBf16
                 const int sx = h_x0 + (pp & 31), sy = h_y0 + (pp >> 5);
                 buffer_store_b128_guarded<B2_STORE_AUX>(held[g], rsH, (sx < W && sy < H) ? (sy * W + sx) * 128 + c * 16 : 0x7fffffff, 0);
                 if constexpr (FUSE) {
+                    // the residual pieces in ACCUMULATOR layout (a lane = a pixel, 16 bytes of its line): 64 lines per instruction instead of
+                    // 8, but no staging through the scratch and no fourth barrier - measured 4.17 -> 4.13 ms per 1080p forward against
+                    // whole-line loads + a stage + a barrier (-DB2_RESID_LINES)
+#ifdef B2_RESID_LINES
                     rq[g] = __builtin_bit_cast(b2u4, __builtin_amdgcn_raw_buffer_load_b128(rsR, rbase, g * 2 * wbytes, 0));
+#else
+                    rq[g] = __builtin_bit_cast(b2u4, __builtin_amdgcn_raw_buffer_load_b128(rsR, eoff[g >> 1], (ech + 8 * (g & 1)) * 2, 0));
+#endif
                     if (chain_head)
                         radd[g >> 1][g & 1] = __builtin_bit_cast(b2u4, __builtin_amdgcn_raw_buffer_load_b128(rsA, eoff[g >> 1], (ech + 8 * (g & 1)) * 2, 0));
                 }
@@ -316,6 +323,7 @@ __global__ __launch_bounds__(B2_THREADS, 1) void conv3x3_bf16_v2_kernel(ConvBf16
 
         // ---- serial phase.  Scratch = pixel-major lines, 16-byte pieces XOR-swizzled by (pixel >> 1) & 7 (conflict-free for the piece
         // writes, the line read-back and the 1x1 operand reads)
+#ifdef B2_RESID_LINES
         if constexpr (FUSE) {                                       // the residual lines go where the output lines will be
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -324,6 +332,7 @@ __global__ __launch_bounds__(B2_THREADS, 1) void conv3x3_bf16_v2_kernel(ConvBf16
             }
             B2_BARRIER();
         }
+#endif
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -332,7 +341,11 @@ __global__ __launch_bounds__(B2_THREADS, 1) void conv3x3_bf16_v2_kernel(ConvBf16
                 const int c = 4 * mt + 2 * (lane >> 5) + h;         // piece of the pixel's line
                 b2u4* const slot = reinterpret_cast<b2u4*>(tile + ((2 * rp + n) * 32 + j) * 128 + ((c ^ ((j >> 1) & 7)) << 4));
                 [[maybe_unused]] b2u4 rr = {0, 0, 0, 0};
+#ifdef B2_RESID_LINES
                 if constexpr (FUSE) rr = *slot;
+#else
+                if constexpr (FUSE) rr = rq[2 * n + h];
+#endif
                 f32x4 v[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {

@@ -302,10 +302,10 @@ def test_forward_bf16_against_committed_golden(name):
     eng.close()
 
 
-@pytest.mark.parametrize("sel", ["0", "all"])
+@pytest.mark.parametrize("sel", ["0", "2"])
 def test_bf16_3x3_kernel_generations(sel):
     """conv_bf16_v2.hip (round 4: halo by LDS-DMA, MFMA groups that carry one memory instruction each, a serial epilogue phase) is the
-    default for conv1_i + conv10_i only (PFNL_BF16_V2=1); the env selects it for all three modes ("all") or never ("0").  The choice is
+    default for modes 0 - 2; the env selects the first kernel ("0") or the second one for conv1_i + conv10_i only ("2").  The choice is
     read once per process, so each setting runs the 3x3 op tests, the random-geometry stress and the forward tests in a process of its own."""
     import os
     import subprocess
