@@ -689,7 +689,7 @@ def test_host_pointer_staging_paths():
     from pfnl_amd import _capi
     geom = PFNLGeometry(num_block=1)
     eng = engine_for(geom)
-    for (B, H, W) in ((1, 16, 24), (3, 64, 96), (2, 128, 128)):     # 27 KB / 1.5 MB / 2.75 MB in; 0.07 / 3.5 / 6.3 MB out
+    for (B, H, W) in ((1, 16, 24), (3, 64, 96), (2, 128, 128), (12, 128, 128)):   # 27 KB / 1.5 / 2.75 / 16.5 MB in; 0.07 / 3.5 / 6.3 / 37.7 MB out (32 chunks)
         x = synth.uniform_clips(B, 7, H, W, seed=B + H)
         want = eng.forward(torch.from_numpy(x).cuda()).cpu().numpy()
         y_default = eng.forward(x)                                   # pageable in, engine-allocated (pinned when large) out
@@ -702,6 +702,14 @@ def test_host_pointer_staging_paths():
             assert np.array_equal(got, want)
         for _ in range(3):                                           # the strips and the pool are reused call after call
             assert np.array_equal(eng.forward(x), want)
+    # two handles, each with strips and a pool of its own, used in turn (and one destroyed while the other lives on)
+    twin = PFNLEngine(geom, device=0)
+    twin.copy_weights_from(eng)
+    x = synth.uniform_clips(3, 7, 64, 96, seed=77)
+    a, b = eng.forward(x), twin.forward(x)
+    assert np.array_equal(a, b)
+    twin.close()
+    assert np.array_equal(eng.forward(x), a)
 
 
 def test_split16_domain_nonlocal_input_scale():
