@@ -659,3 +659,16 @@ def test_round3_random_geometries():
     spec.loader.exec_module(mod)
     n, worst, worst_op = mod.run(seed=11, seconds=10.0)
     assert n >= 10 and worst < 2e-5 and worst_op < 2e-5
+
+
+def test_round4_kernels_random_geometries_short():
+    """tools/stress_r04.py for a few seconds inside the suite (the long form ran 2 038 geometries): the second-generation bf16 3x3 kernel in
+    its three modes against torch references with the same rounding points, the two-launch small-shape block against the f32-MFMA
+    kernels, every call repeatable bit for bit."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("stress_r04", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_r04.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, worst = mod.run(seed=11, seconds=6.0)
+    assert n >= 20 and worst < 3e-5, (n, worst)
