@@ -40,6 +40,10 @@ PEAK_HBM_GBS = 8000.0
 # what 256 CUs sustain on the split-f16 kernels' own MFMA + LDS-operand core with random operands, nothing else running:
 # 1.27 - 1.52 PFLOP/s at a 1.33 - 1.57 GHz shader clock (power cap; tools/ubench/conv_core.hip, profiles/r03_ubench_conv_core.txt)
 SUSTAINED_F16_MFMA_TFLOPS = 1500.0
+# what 256 CUs move when one 512-thread workgroup per CU (the launches' residency) does NOTHING but a tile's byte streams - halo by LDS-DMA,
+# residual lines, output lines: 5.5 - 5.8 TB/s of compulsory bytes, ~11 B per clock and CU (tools/ubench/cu_stream_mix.hip,
+# profiles/r04_ubench_cu_stream_mix.txt).  Context next to `frac` (which is priced on the 8 TB/s spec), not a substitute for it.
+STREAM_MIX_CEILING_GBS = 5600.0
 PREWARM_S = 0.3                                                    # untimed steps in front of the warm-up: the clock ramp of an idle chip
 T = 7
 
@@ -229,7 +233,8 @@ def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
         traffic = stamped_traffic("traffic_bf16.json", files, workload)
         return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                 "traffic": traffic, "kernel": name, "avg_launch_ms": round(avg_ms, 4), "launches_timed": k["launches"],
-                "launches_per_step": launches_per_step, "mbytes_per_launch": round(bytes_per_launch / 1e6, 2),
+                "launches_per_step": launches_per_step, "mbytes_per_launch": round(bytes_per_launch / 1e6, 2), "tiles_per_block": "5F+4B",
+                "stream_mix_ceiling_gbs": STREAM_MIX_CEILING_GBS, "hbm_vs_stream_mix_ceiling": round(gbs / STREAM_MIX_CEILING_GBS, 4),
                 "mfma_tflops": round(flops3 / launches_per_step / (avg_ms * 1e-3) / 1e12, 1), "mfma_peak_bf16_tflops": PEAK_F16_MFMA_TFLOPS}
     # fp32: conv1_i + conv2_i; the default kernel runs the whole of conv2_i as one grouped launch, the others launch its
     # shared half and its per-frame half separately
@@ -276,6 +281,7 @@ def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
                     "avg_launch_ms": round(avg_ms, 4), "launches_timed": k["launches"], "launches_per_step": launches_per_step,
                     "mbytes_per_launch": round(bytes_per_launch / 1e6, 2),
                     "tiles_per_block": "5F+%dB" % ((1 if c10 else 0) + (1 if chain else 3)),
+                    "stream_mix_ceiling_gbs": STREAM_MIX_CEILING_GBS, "hbm_vs_stream_mix_ceiling": round(gbs / STREAM_MIX_CEILING_GBS, 4),
                     "hbm_gbs": round(gbs, 1), "hbm_frac": round(f_h, 4),
                     "algorithmic_direct_tflops": round(direct_tflops, 2), "algorithmic_mfma_frac": round(f_m, 4),
                     "mfma_executed_tflops": round(ex, 1), "mfma_executed_frac": round(ex / PEAK_F16_MFMA_TFLOPS, 4),
