@@ -72,8 +72,9 @@ CONV3X3_KERNELS = {
                 ["conv_split16.hip", "conv_sf.hip"]),
     "small": ("conv_small_kernel<3,R> (small-shape trunk: conv1_i and the whole of conv2_i, 4 waves per R x 32-pixel tile, split-f16 MFMA, weights "
               "streamed as B operands)", ["conv_small.hip"]),
-    "bf16": ("conv3x3_bf16_v2_kernel<2> (conv1_i + conv10_i: halo by LDS-DMA, serial epilogue phase) + conv3x3_bf16_kernel<0 / 1> (the two halves of "
-             "conv2_i): direct 3x3 64->64, bf16 MFMA, fp32 accumulation, persistent", ["conv_bf16.hip", "conv_bf16_v2.hip"]),
+    "bf16": ("conv3x3_bf16_v3_kernel<2 / 1> (conv1_i + conv10_i, the per-frame half of conv2_i: halo by LDS-DMA, the two halves of the workgroup "
+             "half a tile period apart) + conv3x3_bf16_v2_kernel<0> (the shared half of conv2_i): direct 3x3 64->64, bf16 MFMA, fp32 "
+             "accumulation, persistent", ["conv_bf16.hip", "conv_bf16_v2.hip", "conv_bf16_v3.hip"]),
 }
 
 

@@ -590,6 +590,15 @@ hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s) {
             const char* e = std::getenv("PFNL_BF16_V2");
             return e && e[0] == '2';
         }();
+        // the third-generation kernel (conv_bf16_v3.hip: the two halves of the workgroup half a tile period apart) takes conv1_i + conv10_i and
+        // the per-frame half of conv2_i (measured at 1080p, same box, rocprofv3: 76.3 -> 73.2 and 82.5 -> 79.0 us per launch, 4.24 -> 4.09 ms
+        // per forward); the plain mode - the shared half of conv2_i, two tiles per workgroup at 1080p - stays on the second generation,
+        // whose prologue is shorter (15.8 against 16.1 us).  PFNL_BF16_V3 = 0: none, = 1: all three modes, = 2: conv1_i + conv10_i only
+        static const int v3 = [] {
+            const char* e = std::getenv("PFNL_BF16_V3");
+            return e ? std::atoi(e) : 12;
+        }();
+        if (v2 && mode != 3 && (v3 == 1 || (v3 == 12 && mode != 0) || (v3 == 2 && mode == 2))) return launch_conv3x3_bf16_v3(p, mode, s);
         if (v2 && mode != 3 && (mode == 2 || !v2_only2)) return launch_conv3x3_bf16_v2(p, mode, s);
     }
     static std::atomic<int> attr_dev[64][4];                               // the attribute is per device

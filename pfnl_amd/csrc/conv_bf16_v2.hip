@@ -117,6 +117,7 @@ __global__ __launch_bounds__(B2_THREADS, 1) void conv3x3_bf16_v2_kernel(ConvBf16
         x0_ = (sp_ - ty_ * tiles_x) * B2_TW;                                                     \
     } while (0)
 
+    B2_STAMP();                                                 // (timing build) kernel entry, past the work-order arithmetic
     // weights + bias -> LDS (once per workgroup)
 #pragma unroll
     for (int k = 0; k < B2_W_BYTES / 16 / B2_THREADS; ++k)

@@ -1,0 +1,478 @@
+// bf16 trunk, third generation of the 3x3 64->64 kernel (round 4): conv1_i + conv10_i, both halves of conv2_i (reference
+// model/pfnl.py:49-51, 66-71).  Same arithmetic, LDS layouts, packed weights, work order and epilogue pieces as conv_bf16_v2.hip (whose
+// header explains the tile: 8 x 32 pixels, halo 10 x 34 x 128 B by LDS-DMA into one of two buffers, 12 MFMA groups, a serial epilogue
+// phase in the tile's own halo buffer); what changes is that the two HALVES of the workgroup run half a tile period apart.
+//
+// Why.  In the second generation both waves of a SIMD reach the serial phase together, so the matrix pipe idles for its whole length
+// (tools/b2_timing.py: 2.3 - 3 k of a tile's 8.9 - 9.9 k cycles).  Here waves 0-3 (group A = tile rows 0-3) and waves 4-7 (group B =
+// rows 4-7) process the SAME tile sequence, group B two workgroup barriers behind group A.  A tile is four intervals -
+//     I0  MFMA groups 0-5        I1  MFMA groups 6-11        I2  epilogue dump (+ halo requests)        I3  lines out (+ conv10_i)
+// - so one half's I2 | I3 always faces the other half's I0 | I1: on every SIMD one wave feeds the matrix pipe while its partner does
+// the VALU / LDS / memory work.  Two rules follow from the phase stamps of the first attempts (tools/experiments/README.md, round 4):
+//   * a wave that is ALONE on its matrix pipe pays for everything it issues between two MFMAs beyond ~5 slots (MI355X_MICROARCH.md,
+//     "one wave per SIMD"): the 7 operand reads of the next group go one or two per MFMA gap, pinned in source order (a clump of 7
+//     before the 6 MFMAs: 350 cycles per group instead of 230), and
+//   * it issues NO vector-memory instruction (each one cost 90 - 185 cycles among the MFMAs): every store, halo piece and epilogue input
+//     is issued by the half that is in its serial phase, which has the slack.
+// What makes it fit without more LDS:
+//   * group A's scratch = bytes [0, 16 K) of the tile's buffer = halo rows 0 - 3.8, which only group A reads; group B's scratch = bytes
+//     [B3_SCR_B, + 16 K) = halo rows 6 - 9.8, which only group B reads;
+//   * the halo of tile u + 2 goes into tile u's buffer in two parts: group B issues the pieces below its scratch (i < 25) in ITS dump
+//     interval of tile u (group A's scratch there was read one interval earlier, and nobody reads halo u any more), group A issues the
+//     rest (i >= 25) in its dump interval of tile u + 1 (group B's lines of tile u left one interval earlier).  Each wave waits for its
+//     own pieces (an explicit vmcnt wait) before the barrier that precedes group A's first read of that halo.
+// All synchronisation is the workgroup barrier - 4 per tile, the same count for every wave (group B's two leading barriers pair with
+// group A's two trailing ones): no flags, no spinning.
+#include <type_traits>
+
+#include "common.h"
+#include "conv_bf16.h"
+
+#ifndef B3_STORE_AUX
+#define B3_STORE_AUX 0
+#endif
+
+namespace pfnl {
+
+typedef __bf16 b3h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b3h4 __attribute__((ext_vector_type(4)));
+typedef unsigned b3u4 __attribute__((ext_vector_type(4)));
+typedef unsigned b3u2 __attribute__((ext_vector_type(2)));
+
+constexpr int B3_THREADS = 512, B3_GTHREADS = 256;
+constexpr int B3_TH = 8, B3_TW = 32, B3_IH = 10, B3_IW = 34;
+constexpr int B3_NDMA = (B3_IH * B3_IW + 7) / 8;                    // 43 DMA instructions of 8 pixels x 128 B
+constexpr int B3_TILE_BYTES = B3_NDMA * 1024;                       // 44 032 (the last instruction's 4 surplus pixels land in padding)
+constexpr int B3_W_BYTES = 9 * 4 * 2 * 1024;                        // 73 728: conv3x3_bf16_pack_weights
+constexpr int B3_LDS_BYTES = 2 * B3_TILE_BYTES + B3_W_BYTES + 2 * 64 * 4;   // 162 304 of 163 840 (bias, conv10_i's bias)
+constexpr int B3_SCR_B = 6 * B3_IW * 128;                           // 26 112: group B's scratch starts at halo row 6
+constexpr int B3_LOW = 25;                                          // pieces i < 25 (bytes < 25 600) lie below group B's scratch
+constexpr int B3_PIECES = 7;                                        // per wave: group B i = wl + 4k < 25, group A i = 25 + wl + 4k < 43
+static_assert(B3_LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(B3_LOW * 1024 <= B3_SCR_B && B3_SCR_B + 128 * 128 <= B3_TILE_BYTES, "group B's scratch: above the low pieces, inside the buffer");
+static_assert(128 * 128 <= 4 * B3_IW * 128, "group A's scratch inside halo rows 0-3 (group B reads rows 4-9)");
+
+__device__ __forceinline__ void b3_dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds_dst, int voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rs) : "memory");
+}
+__device__ __forceinline__ f32x16 b3_mfma(b3h8 a, b3h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 b3_to_f32(b3u2 v) {
+    return f32x4{__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xffff0000u),
+                 __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xffff0000u)};
+}
+__device__ __forceinline__ f32x4 b3_lrelu4(f32x4 v, float slope) {
+    const f32x4 sv = v * slope;
+    asm("v_max_f32 %0, %1, %2" : "=v"(v.x) : "v"(v.x), "v"(sv.x));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v.y) : "v"(v.y), "v"(sv.y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v.z) : "v"(v.z), "v"(sv.z));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v.w) : "v"(v.w), "v"(sv.w));
+    return v;
+}
+__device__ __forceinline__ b3u2 b3_to_bf16(f32x4 v) {             // round to nearest even (v_cvt_pk_bf16_f32)
+    const b3h4 b = __builtin_convertvector(v, b3h4);
+    return __builtin_bit_cast(b3u2, b);
+}
+#define B3_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifdef PFNL_B3_TIMING   /* phase timeline (tools/b3_timing.py); not part of the product build */
+__device__ long long b3_dbg[256 * 2 * 128];
+#ifndef PFNL_B3_TIMING_MODE
+#define PFNL_B3_TIMING_MODE 2
+#endif
+#define B3_STAMP() do { if (MODE == PFNL_B3_TIMING_MODE && lane == 0 && (wave == 0 || wave == 5) && dbg_n < 128) b3_dbg[(blockIdx.x * 2 + (wave != 0)) * 128 + dbg_n++] = __builtin_readcyclecounter(); } while (0)
+#ifdef PFNL_B3_PSTAMPS
+#define B3_PSTAMP() B3_STAMP()
+#else
+#define B3_PSTAMP() do {} while (0)
+#endif
+#else
+#define B3_STAMP() do {} while (0)
+#define B3_PSTAMP() do {} while (0)
+#endif
+
+// MODE 0: out = act(conv + bias).  MODE 1 (conv2_i per-frame half): out = act(conv + bias + addend[item / add_div]) + resid.
+// MODE 2 (conv1_i + conv10_i): MODE 0, and per chain of add_div frames x_out = lrelu(sum_t W10_t out_t + x_bias).
+template <int MODE>
+__global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16Params p) {
+    constexpr bool FUSE = MODE == 1;
+    constexpr bool WITH10 = MODE == 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char b3_smem[];
+    unsigned char* const wl = b3_smem + 2 * B3_TILE_BYTES;
+    float* const bl = reinterpret_cast<float*>(b3_smem + 2 * B3_TILE_BYTES + B3_W_BYTES);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef PFNL_B3_TIMING
+    int dbg_n = 0;
+#endif
+    const int rp = wave >> 1;                                       // rows 2rp, 2rp+1 of the tile
+    const int mt = wave & 1;                                        // output channels 32mt .. 32mt+31
+    const int grp = wave >> 2;                                      // half of the workgroup: 0 = A (early), 1 = B (two intervals behind)
+    const int wq = wave & 3;                                        // wave within the half
+    const int rl = rp & 1;                                          // row pair within the half's scratch
+    const int tidl = tid & 255;                                     // thread within the half
+    const int H = p.H, W = p.W;
+    const int tiles_x = (W + B3_TW - 1) / B3_TW, tiles_y = (H + B3_TH - 1) / B3_TH;
+    const int per_item = tiles_x * tiles_y;
+    const int item_bytes = H * W * 128;
+    const int wbytes = W * 128;
+    // work order: chains of the gT frames of a clip at one spatial tile, dealt out XCD by XCD (conv_bf16.hip)
+    const int gT = (FUSE || WITH10) ? p.add_div : 1;
+    const int nchains = per_item * (p.items / gT);
+    const int xcd = blockIdx.x & 7, xj = blockIdx.x >> 3, cpx = gridDim.x >> 3;
+    const int per_xcd = (nchains + 7) >> 3;
+    const int cbeg = xcd * per_xcd;
+    const int ccnt = min(per_xcd, nchains - cbeg);
+    if (xj >= ccnt) return;
+    const int nu = ((ccnt - xj + cpx - 1) / cpx) * gT;              // tiles of this workgroup
+    // a unit = (item, y0, x0) + its position (chain ci of this workgroup, frame f of the chain); all wave-uniform.  Stepping inside a
+    // chain is an increment; the three integer divisions (~450 cycles) happen once per chain, in an interval that has the slack.
+    struct Unit { int item, y0, x0, f, ci; };
+    auto unit_head = [&](int ci) __attribute__((always_inline)) {
+        const int ch = cbeg + xj + ci * cpx;
+        const int cl = ch / per_item;
+        const int sp = ch - cl * per_item;
+        const int ty = sp / tiles_x;
+        return Unit{cl * gT, ty * B3_TH, (sp - ty * tiles_x) * B3_TW, 0, ci};
+    };
+    auto unit_next = [&](const Unit& c) __attribute__((always_inline)) {
+        if (c.f + 1 < gT) return Unit{c.item + 1, c.y0, c.x0, c.f + 1, c.ci};
+        return unit_head(c.ci + 1);
+    };
+
+    B3_STAMP();                                                 // (timing build) kernel entry, past the work-order arithmetic
+    // DMA map: piece i covers halo pixels 8 i .. 8 i + 7 (linear, 34 per row); lane L -> pixel 8 i + (L >> 3), LDS slot L & 7, which
+    // holds chunk (L & 7) ^ ((px >> 1) & 7) of that pixel: `drel` = byte offset of the lane's SOURCE chunk relative to the halo origin,
+    // `dpk` = py | px << 8 (border test).  This wave's pieces: group B i = wq + 4k (< 25), group A i = 25 + wq + 4k (< 43).
+    const int i0 = grp ? wq : B3_LOW + wq;
+    const int iend = grp ? B3_LOW : B3_NDMA;
+    int drel[B3_PIECES], dpk[B3_PIECES];
+#pragma unroll
+    for (int k = 0; k < B3_PIECES; ++k) {
+        const int pix = 8 * (i0 + 4 * k) + (lane >> 3);
+        const int py = pix / B3_IW, px = pix - py * B3_IW;
+        drel[k] = py * wbytes + px * 128 + (((lane & 7) ^ ((px >> 1) & 7)) << 4);
+        dpk[k] = py | (px << 8);
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)b3_smem;
+    B3_PSTAMP();                                                // (timing build) P1: DMA tables
+    // this wave's share of the halo of unit `un` -> buffer `buf`; `live` false: nothing (an empty resource)
+    auto dma_share = [&](const Unit& un, bool live, int buf) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.in) + (size_t)un.item * H * W * 64, 0, live ? item_bytes : 0, 0x00020000);
+        const int org = ((un.y0 - 1) * W + un.x0 - 1) * 128;
+        const bool interior = un.y0 > 0 && un.y0 + B3_IH - 1 <= H && un.x0 > 0 && un.x0 + B3_IW - 1 <= W;
+#pragma unroll
+        for (int k = 0; k < B3_PIECES; ++k) {
+            const int i = i0 + 4 * k;
+            if (i < iend) {                                         // (wave-uniform)
+                const int py = dpk[k] & 0xff, px = dpk[k] >> 8;
+                const int gy = un.y0 + py - 1, gx = un.x0 + px - 1;
+                const bool in = interior | (((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W) & (py < B3_IH));
+                b3_dma16(rs, lds0 + buf * B3_TILE_BYTES + i * 1024, in ? org + drel[k] : 0x7fffffff);
+            }
+        }
+    };
+    // Completion of the pieces: the vector-memory counter retires in issue order, so "at most K operations outstanding", K = the operations
+    // this wave is SURE to have issued after its last piece, means the pieces have landed.  After the pieces of a tile a wave always issues
+    // its 4 line stores and (modes 1, 2) the 4 input loads of the next tile before it waits (the addend pieces and conv10_i's stores come
+    // on top at chain boundaries: then the wait covers a few of them as well).  An explicit wait rather than a fence load whose result
+    // is "consumed": the compiler's own counter model does not see the inline-asm pieces, and with a pending fence register it fell back
+    // to vmcnt(0) in front of every piece (measured: 71 -> 90 us per launch).
+    constexpr int KWAIT = MODE == 0 ? 4 : 8;
+#define B3_PIECES_LANDED() asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KWAIT) : "memory")
+
+    // operand addresses (conv_bf16.hip): pixel operand of (column tap kx, k-step ks) = chunk 2*ks + (lane >> 5) of halo pixel
+    // (row 2*rp + ..., column (lane & 31) + kx); weights: 16 bytes per lane
+    int paddr[3][4];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int col = (lane & 31) + kx;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            paddr[kx][ks] = ((2 * rp) * B3_IW + col) * 128 + (((2 * ks + (lane >> 5)) ^ ((col >> 1) & 7)) << 4);
+    }
+    const unsigned char* const wlane = wl + mt * 1024 + lane * 16;
+    // register r of a lane = channel 32mt + 16(lane>>5) + r (the row -> channel map of the packed weights), pixel lane & 31 of the row
+    const int ech = 32 * mt + 16 * (lane >> 5);
+    f32x16 acc[2];
+    [[maybe_unused]] b3u4 radd[2][2];                               // FUSE: addend pieces (accumulator layout; fetched once per chain)
+    [[maybe_unused]] b3u4 rq[4];                                    // FUSE: this lane's residual pieces (row n, channel half h: index 2n + h)
+    [[maybe_unused]] b3u4 xw[4];                                    // WITH10: W10 operands of the tile's frame
+    [[maybe_unused]] f32x16 bacc[2];
+    if constexpr (WITH10) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bacc[n][r] = 0.f;
+    }
+    const float eslope = p.act ? 0.2f : 1.0f;
+    const __amdgpu_buffer_rsrc_t rsXW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x_w), 0, WITH10 ? gT * 8192 : 0, 0x00020000);
+    // the epilogue inputs of unit `un` (requested a serial phase ahead; `live` false: empty resources, zeros)
+    auto request_inputs = [&](const Unit& un, bool live) __attribute__((always_inline)) {
+        if constexpr (FUSE) {
+            const int ox = un.x0 + (lane & 31);
+            // (rows / columns past the image: past the resource's range)
+            const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.resid) + (size_t)un.item * H * W * 64, 0, live ? item_bytes : 0, 0x00020000);
+            // the shared-half pieces are the same pixels for every frame of a chain: fetched with its first frame
+            const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.addend) + (size_t)(un.item / p.add_div) * H * W * 64, 0, live ? item_bytes : 0, 0x00020000);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int oy = un.y0 + 2 * rp + n;
+                const int eoff = (ox < W && oy < H) ? (oy * W + ox) * 128 : 0x7fffffff;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    rq[2 * n + h] = __builtin_bit_cast(b3u4, __builtin_amdgcn_raw_buffer_load_b128(rsR, eoff, (ech + 8 * h) * 2, 0));
+                    if (un.f == 0) radd[n][h] = __builtin_bit_cast(b3u4, __builtin_amdgcn_raw_buffer_load_b128(rsA, eoff, (ech + 8 * h) * 2, 0));
+                }
+            }
+        }
+        if constexpr (WITH10) {                                     // W10[frame][k-step][channel tile mt]: 16 bytes per lane and k-step
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                xw[g] = __builtin_bit_cast(b3u4, __builtin_amdgcn_raw_buffer_load_b128(rsXW, lane * 16 + mt * 1024, (un.f * 4 + g) * 2048, 0));
+        }
+    };
+
+    // ---- prologue: halo of tile 0 -> buffer 0 (both halves' shares = all of it); group B's share of tile 1 -> buffer 1 while it waits
+    Unit cu = unit_head(0);
+    Unit nx = nu > 1 ? unit_next(cu) : cu;
+    B3_PSTAMP();                                                // P2: operand addresses, first units
+    dma_share(cu, true, 0);
+    request_inputs(cu, true);
+    B3_PSTAMP();                                                // P3: halo + input requests issued
+    // weights + bias -> LDS (once per workgroup; behind the halo requests, so that the two streams overlap)
+#pragma unroll
+    for (int k = 0; k < B3_W_BYTES / 16 / B3_THREADS; ++k)
+        reinterpret_cast<b3u4*>(wl)[k * B3_THREADS + tid] = reinterpret_cast<const b3u4*>(p.wpack)[k * B3_THREADS + tid];
+    if (tid < 64) bl[tid] = p.bias[tid];
+    if constexpr (WITH10) {
+        if (tid >= 64 && tid < 128) bl[tid] = p.x_bias[tid - 64];  // (a global load at the chain's end would sit on the critical path)
+    }
+    B3_PSTAMP();                                                // P4: weights written
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    B3_PSTAMP();                                                // P5: halo landed
+    __syncthreads();
+    f32x16 bias16;                                                  // the tile's first MFMAs take C = bias (register r of a lane = channel ech + r)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + ech + 4 * q);
+        bias16[4 * q] = b4.x;
+        bias16[4 * q + 1] = b4.y;
+        bias16[4 * q + 2] = b4.z;
+        bias16[4 * q + 3] = b4.w;
+    }
+    if (grp) {                                                      // group B: two intervals behind group A
+        dma_share(nx, nu > 1, 1);                                   // its share of tile 1's halo (nothing follows it that B3_PIECES_LANDED
+        B3_BARRIER();                                               // could count on: an unconditional wait, between the two barriers)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        B3_BARRIER();
+    }
+#ifdef B3_PRIO_B
+    if (grp) __builtin_amdgcn_s_setprio(1);
+#endif
+
+    for (int u = 0; u < nu; ++u) {
+        const int cb = u & 1;
+        B3_STAMP();                                                 // 0: tile start
+        unsigned char* const tile = b3_smem + cb * B3_TILE_BYTES;   // this tile's halo
+        unsigned char* const scr = tile + (grp ? B3_SCR_B : 0);     // then this half's 128 lines
+        const int item = cu.item, y0 = cu.y0, x0 = cu.x0;
+
+        // ---- I0 | I1: 12 groups (column tap kx, k-step ks): the 4 halo rows 2rp..2rp+3 serve the 3 row taps of both output rows - 4 pixel
+        // reads + 3 weight reads feed 6 MFMAs; the operands of group g + 1 are requested in the MFMA gaps of group g
+        b3h8 px[2][4], wv[2][3];
+#define B3_PX(g_, r_) (*reinterpret_cast<const b3h8*>(tile + paddr[(g_) >> 2][(g_) & 3] + (r_) * (B3_IW * 128)))
+#define B3_WT(g_, ky_) (*reinterpret_cast<const b3h8*>(wlane + ((((ky_) * 3 + ((g_) >> 2)) * 4 + ((g_) & 3)) << 11)))
+#pragma unroll
+        for (int r = 0; r < 4; ++r) px[0][r] = B3_PX(0, r);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) wv[0][ky] = B3_WT(0, ky);
+        auto group = [&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int cur = g & 1;
+#define B3_M(ky_, n_)                                                                                          \
+    do {                                                                                                       \
+        if constexpr (g == 0 && (ky_) == 0) acc[n_] = b3_mfma(wv[cur][ky_], px[cur][(n_) + (ky_)], bias16);     \
+        else acc[n_] = b3_mfma(wv[cur][ky_], px[cur][(n_) + (ky_)], acc[n_]);                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    } while (0)
+#define B3_RP(r_) do { if constexpr (g < 11) px[cur ^ 1][r_] = B3_PX(g + 1, r_); } while (0)
+#define B3_RW(k_) do { if constexpr (g < 11) wv[cur ^ 1][k_] = B3_WT(g + 1, k_); } while (0)
+            __builtin_amdgcn_sched_barrier(0);
+            B3_M(0, 0);
+            B3_RP(0);
+            B3_RW(0);
+            __builtin_amdgcn_sched_barrier(0);
+            B3_M(0, 1);
+            B3_RP(1);
+            __builtin_amdgcn_sched_barrier(0);
+            B3_M(1, 0);
+            B3_RP(2);
+            B3_RW(1);
+            __builtin_amdgcn_sched_barrier(0);
+            B3_M(1, 1);
+            B3_RP(3);
+            __builtin_amdgcn_sched_barrier(0);
+            B3_M(2, 0);
+            B3_RW(2);
+            __builtin_amdgcn_sched_barrier(0);
+            B3_M(2, 1);
+#undef B3_M
+#undef B3_RP
+#undef B3_RW
+        };
+        group(std::integral_constant<int, 0>{});
+        group(std::integral_constant<int, 1>{});
+        group(std::integral_constant<int, 2>{});
+        group(std::integral_constant<int, 3>{});
+        group(std::integral_constant<int, 4>{});
+        group(std::integral_constant<int, 5>{});
+        B3_STAMP();                                                 // 1: groups 0-5 issued
+        B3_BARRIER();                                               // interval boundary (the other half's dump | lines)
+        B3_STAMP();                                                 // 2
+        group(std::integral_constant<int, 6>{});
+        group(std::integral_constant<int, 7>{});
+        group(std::integral_constant<int, 8>{});
+        group(std::integral_constant<int, 9>{});
+        group(std::integral_constant<int, 10>{});
+        group(std::integral_constant<int, 11>{});
+#undef B3_PX
+#undef B3_WT
+        B3_STAMP();                                                 // 3: groups 6-11 issued
+        if (grp) B3_PIECES_LANDED();                                // group B's share of the next halo has landed (group A reads it after this barrier)
+        B3_BARRIER();                                               // this half is past its last operand read of its rows: they are its scratch now
+        B3_STAMP();                                                 // 4
+
+        // ---- I2: the halo requests this half owes, then the epilogue dump
+        const bool more = u + 1 < nu, more2 = u + 2 < nu;           // (wave-uniform)
+        const Unit n2 = more2 ? unit_next(nx) : nx;
+        auto halo_requests = [&]() __attribute__((always_inline)) {
+            if (!grp) dma_share(nx, more, cb ^ 1);                  // group A: pieces i >= 25 of tile u + 1 (group B's lines of tile u - 1 have left)
+            else dma_share(n2, more2, cb);                          // group B: pieces i < 25 of tile u + 2, below its own scratch
+        };
+        // (mode 1: the dump reads registers that compiler-issued loads filled, and the compiler's wait for them, which does not know the
+        // pieces, covers the pieces as well; issuing them behind the dump instead measured worse - 76.9 -> 81.9 us per launch: that
+        // mode runs at what the CU's memory port sustains, and the pieces cannot afford to start late)
+        halo_requests();
+        // scratch = pixel-major lines, 16-byte pieces XOR-swizzled by (pixel >> 1) & 7 (conflict-free for the piece writes, the line
+        // read-back and the 1x1 operand reads)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                           // row n, channels ech + 8h .. + 7: bias is in (initial C); addend, leaky_relu, residual, bf16
+                const int j = lane & 31;
+                const int c = 4 * mt + 2 * (lane >> 5) + h;         // piece of the pixel's line
+                b3u4* const slot = reinterpret_cast<b3u4*>(scr + ((2 * rl + n) * 32 + j) * 128 + ((c ^ ((j >> 1) & 7)) << 4));
+                f32x4 v[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int r0 = 8 * h + 4 * q;
+                    v[q] = f32x4{acc[n][r0], acc[n][r0 + 1], acc[n][r0 + 2], acc[n][r0 + 3]};
+                    if constexpr (FUSE) v[q] += b3_to_f32(b3u2{radd[n][h][2 * q], radd[n][h][2 * q + 1]});
+                    v[q] = b3_lrelu4(v[q], eslope);
+                    if constexpr (FUSE) v[q] += b3_to_f32(b3u2{rq[2 * n + h][2 * q], rq[2 * n + h][2 * q + 1]});
+                }
+                const b3u2 lo = b3_to_bf16(v[0]), hi = b3_to_bf16(v[1]);
+                *slot = b3u4{lo.x, lo.y, hi.x, hi.y};
+            }
+        B3_STAMP();                                                 // 5: epilogue pieces written
+        B3_BARRIER();                                               // this half's 128 lines are complete
+        B3_STAMP();                                                 // 6
+
+        // ---- I3: whole 128-byte lines to HBM (8 pixels per wave instruction), conv10_i on the same lines, the next tile's epilogue inputs
+        {
+            const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)item * H * W * 64, 0, item_bytes, 0x00020000);
+            b3u4 line[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                           // 1024 pieces per half, 4 per thread
+                const int id = k * B3_GTHREADS + tidl;
+                const int pp = id >> 3, c = id & 7;
+                line[k] = *reinterpret_cast<const b3u4*>(scr + pp * 128 + ((c ^ ((pp >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int id = k * B3_GTHREADS + tidl;
+                const int pp = id >> 3, c = id & 7;
+                const int sx = x0 + (pp & 31), sy = y0 + 4 * grp + (pp >> 5);
+                buffer_store_b128_guarded<B3_STORE_AUX>(line[k], rsO, (sx < W && sy < H) ? (sy * W + sx) * 128 + c * 16 : 0x7fffffff, 0);
+            }
+        }
+        if constexpr (WITH10) {                                     // conv10_i: 4 k-steps x 2 rows, B = the lines of this frame's tile, A = W10 of the frame
+            const int j = lane & 31;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const unsigned char* bp = scr + ((2 * rl) * 32 + j) * 128 + (((2 * ks + (lane >> 5)) ^ ((j >> 1) & 7)) << 4);
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    bacc[n] = b3_mfma(__builtin_bit_cast(b3h8, xw[ks]), *reinterpret_cast<const b3h8*>(bp + n * 32 * 128), bacc[n]);
+            }
+            if (cu.f == gT - 1) {                                   // (wave-uniform) the chain is complete: bias, leaky_relu, bf16, store; clear
+                const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(p.x_out + (size_t)(item / gT) * H * W * 64, 0, item_bytes, 0x00020000);
+                const int sx = x0 + (lane & 31);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int sy = y0 + 2 * rp + n;
+                    const int off = (sx < W && sy < H) ? ((sy * W + sx) * 64 + ech) * 2 : 0x7fffffff;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        f32x4 v[2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int r0 = 8 * h + 4 * q;
+                            v[q] = f32x4{bacc[n][r0], bacc[n][r0 + 1], bacc[n][r0 + 2], bacc[n][r0 + 3]} + *reinterpret_cast<const f32x4*>(bl + 64 + ech + r0);
+                            v[q] = b3_lrelu4(v[q], 0.2f);
+                        }
+                        const b3u2 lo = b3_to_bf16(v[0]), hi = b3_to_bf16(v[1]);
+                        buffer_store_b128_guarded<B3_STORE_AUX>(b3u4{lo.x, lo.y, hi.x, hi.y}, rsX, off, 16 * h);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) bacc[n][r] = 0.f;
+                }
+            }
+        }
+        request_inputs(nx, more);                                   // (after the 1x1's MFMAs have read xw)
+        cu = nx;
+        nx = n2;
+        B3_STAMP();                                                 // 7: lines out
+        if (!grp) B3_PIECES_LANDED();                               // group A's share of the next halo has landed
+        B3_BARRIER();                                               // this half's scratch has been read: its bytes are free for the halo after next
+    }
+    if (!grp) {                                                     // group A sits out group B's last two intervals
+        B3_BARRIER();
+        B3_BARRIER();
+    }
+}
+
+template <int MODE>
+static hipError_t b3_launch(const ConvBf16Params& p, int grid, int dev, hipStream_t s) {
+    static std::atomic<int> attr_dev[64];
+    if (!attr_dev[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16_v3_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_dev[dev] = 1;
+    }
+    hipLaunchKernelGGL(conv3x3_bf16_v3_kernel<MODE>, dim3(grid), dim3(B3_THREADS), B3_LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
+// modes 0 - 2 of launch_conv3x3_bf16 (conv_bf16.hip) on the third-generation kernel
+hipError_t launch_conv3x3_bf16_v3(const ConvBf16Params& p, int mode, hipStream_t s) {
+    if (mode < 0 || mode > 2) return hipErrorInvalidValue;
+    const int ncu = device_cu_count();
+    if (!ncu) return hipErrorUnknown;
+    const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;                    // whole XCDs; surplus workgroups exit at once
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (mode == 1) return b3_launch<1>(p, grid, dev, s);
+    if (mode == 2) return b3_launch<2>(p, grid, dev, s);
+    return b3_launch<0>(p, grid, dev, s);
+}
+
+}  // namespace pfnl
+
+#ifdef PFNL_B3_TIMING
+extern "C" int pfnl_debug_read_b3_stamps(long long* host, size_t n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(pfnl::b3_dbg), n * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif

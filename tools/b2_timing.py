@@ -18,19 +18,27 @@ for _ in range(3):
 torch.cuda.synchronize()
 lib = _capi.load_library()
 buf = np.zeros(256 * 2 * 128, np.int64)
-lib.pfnl_debug_read_b2_stamps.argtypes = [C.c_void_p, C.c_size_t]
-assert lib.pfnl_debug_read_b2_stamps(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
+GEN3 = os.environ.get("PFNL_BF16_V3", "0") != "0"                   # conv_bf16_v3.hip (-DPFNL_B3_TIMING): 8 stamps per tile, other phases
+reader = lib.pfnl_debug_read_b3_stamps if GEN3 else lib.pfnl_debug_read_b2_stamps
+reader.argtypes = [C.c_void_p, C.c_size_t]
+assert reader(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
 st = buf.reshape(256, 2, 128)
-names = ["requests", "MFMA groups", "fence wait", "barrier", "epilogue", "barrier", "lines+stores", "closing barrier"]
+names = (["groups 0-5", "barrier", "groups 6-11", "barrier", "requests+dump", "barrier", "lines+conv10+inputs", "closing barrier"] if GEN3 else
+         ["requests", "MFMA groups", "fence wait", "barrier", "epilogue", "barrier", "lines+stores", "closing barrier"])
 # (the stamps of the LAST launch that wrote them: the per-frame half of conv2_i - mode 1 - in a one-block forward)
 for wg in (0, 9, 100, 255):
     for wi, wname in ((0, "wave0"), (1, "wave5")):
         s = st[wg, wi]
+        entry, last = int(s[0]), int(s[s != 0][-1])
+        npro = int(os.environ.get("PFNL_B3_PSTAMPS", "0"))              # (-DPFNL_B3_PSTAMPS: 5 more stamps inside the prologue)
+        if npro:
+            print(f"wg {wg} {wname} prologue: " + " ".join(str(int(s[i + 1] - s[i])) for i in range(npro)))
+        s = s[1 + npro:]
         n = int((s != 0).sum()) // 8
         if not n:
             continue
         s = s[:n * 8].reshape(n, 8)
-        print(f"wg {wg} {wname}: {n} tiles; tile period {(s[1:, 0] - s[:-1, 0]).tolist()}")
+        print(f"wg {wg} {wname}: {n} tiles; entry -> first tile {int(s[0, 0]) - entry}, entry -> last stamp {last - entry}; first stamp {int(s[0, 0] - st[wg, 0, 1])}; tile period {(s[1:, 0] - s[:-1, 0]).tolist()}")
         for i in range(min(n, 6)):
             row = s[i]
             nxt = s[i + 1, 0] if i + 1 < n else row[7]

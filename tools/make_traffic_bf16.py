@@ -8,7 +8,7 @@ def per_kernel(db, ctr):
     c = sqlite3.connect(db)
     out = {}
     for name, val in c.execute("select kernel_name, value from counters_collection where counter_name=?", (ctr,)).fetchall():
-        if "conv3x3_bf16_kernel" not in name and "conv3x3_bf16_v2_kernel" not in name:
+        if not any(k in name for k in ("conv3x3_bf16_kernel", "conv3x3_bf16_v2_kernel", "conv3x3_bf16_v3_kernel")):
             continue
         if "conv3x3_bf16_kernel<3>" in name:                       # convmerge1 (accumulating mode): not the conv3x3 class of bench.py
             continue

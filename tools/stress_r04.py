@@ -1,5 +1,5 @@
 """Random-geometry stress of the round-4 kernels (odd sizes, tiles cut by the image edge, 1..3 clips, T in {3,5,7}):
-  * conv_bf16_v2.hip through its three modes - plain, fused (addend + residual), conv1_i + conv10_i - against fp32 torch references on
+  * the bf16 3x3 kernels the library selects (conv_bf16_v3.hip for the fused and the conv1_i + conv10_i mode, conv_bf16_v2.hip for the plain one; PFNL_BF16_V3 / PFNL_BF16_V2 select others) through the three modes - plain, fused (addend + residual), conv1_i + conv10_i - against fp32 torch references on
     the GPU with the same bf16-rounded operands (one bf16 ulp), repeatable bit for bit;
   * the two-launch small-shape block of conv_small.hip (conv1_i + conv10_i partials, conv2_i summing them) against the direct f32-MFMA
     kernels (ops.conv2d) on the same data, repeatable bit for bit.
@@ -72,4 +72,4 @@ def run(seed=0, seconds=60.0):
 
 if __name__ == "__main__":
     n, w = run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, float(sys.argv[2]) if len(sys.argv) > 2 else 60.0)
-    print("stress_r04: %d random geometries OK (bf16 v2 x 3 modes within one bf16 ulp, small two-launch block max |d| %.2e vs the f32-MFMA kernels)" % (n, w))
+    print("stress_r04: %d random geometries OK (bf16 3x3 x 3 modes within one bf16 ulp, small two-launch block max |d| %.2e vs the f32-MFMA kernels)" % (n, w))
