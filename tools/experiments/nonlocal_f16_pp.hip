@@ -1,0 +1,876 @@
+// Non-local block of the fp32 path on the f16 matrix pipe with exactly split operands (option nonlocal=split16; the same idea as
+// conv_split16.hip: x = hi + lo with hi = f16(x), lo = f16(x - hi), products hi hi + hi lo + lo hi in fp32 accumulators: >= 22 mantissa
+// bits per product).  Derived from nonlocal_bf16.hip (same streaming-softmax structure, same operand layouts); what differs:
+//   * binary16 has a 5-bit exponent, so everything is kept in its normal range by powers of two that cancel exactly:
+//     K, V and Q are scaled by 2^7 (the image is in [0,1]: hi <= 185, lo normal for x >= 0.001), the logits therefore come out of
+//     the MFMA scaled by 2^14 (undone inside the exp2 argument's fma), the probabilities are computed as 2^14 exp2(s - max) (<= 16384:
+//     representable down to 2^-28 of the row maximum) - the row sum accumulates the same scaled values, so O / l needs only 2^-7;
+//   * P is split as well (hi + lo): 3 MFMAs per V^T P^T product block instead of 2 - 72 f16 MFMAs of 32 cycles per 64 keys and 32
+//     queries against 180 f32 MFMAs of 64 in nonlocal.hip.
+// ---- (the description of the structure, from nonlocal_bf16.hip:)
+// Non-local block on bf16 MFMA (option precision=bf16; BASELINE.json configs[3]: at 1080p the affinity is
+// N = 32400 squared, 354 GFLOP - 3.3 ms on the f32 matrix pipe, more than the whole bf16 trunk).
+//
+// Same streaming-softmax structure as nonlocal.hip (reference utils.py:18-71, nltype=1), with the two contractions on
+// v_mfma_f32_32x32x16_bf16 and fp32 everywhere a bf16 value would be visible in the result:
+//   * logits S = X X^T (|S| <= 84, exp(S) needs ~1e-4 absolute): bf16 inputs alone would be wrong by ~16 %
+//     (SURVEY.md section 7), so X is split into hi + lo bf16 parts and S = hi hi + hi lo + lo hi accumulated in fp32
+//     (the dropped lo lo term is < 84 * 2^-18): 18 MFMAs of 32 cycles per 32x32 tile against 42 f32 MFMAs of 64;
+//   * P = exp2(S' - running max) in fp32, rounded to bf16 only as the MFMA operand; the row sum accumulates the SAME
+//     rounded values through the "ones" channel, so the normalisation is exact for what was summed;
+//   * V = X also as hi + lo (12 MFMAs per tile): a query dominated by one key returns that key's fp32 value;
+//   * running max / rescale, normalisation, the folded 1x1 projection (f32 MFMA) and the residual as in nonlocal.hip.
+// Operand layouts (lane = (l & 31, kh = l >> 5), 8 bf16 per lane and MFMA):
+//   K tile in LDS  [key][96 ch] (+ pad to 208 B: conflict-free b128 reads), hi and lo: A of S^T = K Q^T;
+//   Q in registers [6 k-steps] hi and lo, pre-scaled by log2(e): B of S^T;
+//   P^T straight from the S^T accumulator: register r of lane (query, kh) is key (r&3) + 8(r>>2) + 4kh, registers
+//   8t..8t+7 form the B operand of k-step t - the contraction order over keys is free, so V^T is stored by nl_pack_bf16
+//   with the keys of every 32-block permuted to exactly that order ([ch][block][t][kh][e]).
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "conv_bf16.h"
+#include "conv_split16.h"
+
+namespace pfnl {
+
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));   // (name kept from the bf16 kernel: 8 x binary16 here)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NF_KT = 64;                  // keys per LDS tile
+constexpr int NF_KROW = 208;               // bytes per key row of the K tiles (96 ch * 2 B + 16)
+constexpr int NF_VROW = 144;               // bytes per channel row of the V^T tiles (64 keys * 2 B + 16)
+constexpr int NF_CP = 96;
+constexpr int NF_THREADS = 512;           // 8 waves x 32 queries share every key tile: the K / V^T stream (48 KB per 64 keys) is what
+                                          // bounds this kernel - with 128 queries per workgroup it ran at 6.6 TB/s of L2 -> CU traffic
+                                          // (11 B/clk/CU) and 43 % matrix-pipe use, whatever was done to its instruction schedule
+constexpr int NF_QB = NF_THREADS / 2;     // queries per workgroup
+constexpr int NF_TILE_BYTES = 2 * NF_KT * NF_KROW + 2 * NF_CP * NF_VROW;   // 54 272: K hi, K lo, V^T hi, V^T lo
+constexpr int NF_LDS_BYTES = 3 * NF_TILE_BYTES;                             // 162 816 of 163 840: tiles t-1 (late waves' P V), t, t+1 (being filled)
+
+constexpr float NF_XSCALE = 128.0f;                       // 2^7 on K, V and Q
+constexpr float NF_SINV = 1.0f / (128.0f * 128.0f);       // logits leave the MFMA scaled by 2^14
+constexpr float NF_PSHIFT = 14.0f;                        // probabilities are kept as 2^14 exp2(s - max)
+__device__ __forceinline__ unsigned short bf16_bits(float f) {   // binary16, round to nearest even
+    const _Float16 b = (_Float16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf16_float(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
+
+// X [B][N][CP] fp32 (nl_pack_kernel) -> Khi, Klo [B][N][96] bf16;  Vthi, Vtlo [B][96][Npad] bf16, keys permuted per
+// 32-block, channel C = 1 (the row-sum channel), channels > C = 0
+__global__ void nl_pack_f16_kernel(const float* __restrict__ X, uint16_t* __restrict__ Khi, uint16_t* __restrict__ Klo,
+                                    uint16_t* __restrict__ Vthi, uint16_t* __restrict__ Vtlo, int B, int N, int Npad, int C,
+                                    int CPin) {
+    const size_t total = (size_t)B * Npad * NF_CP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % NF_CP);
+        const int n = (int)((i / NF_CP) % Npad);
+        const int b = (int)(i / ((size_t)NF_CP * Npad));
+        const float v = (n < N && c < C) ? X[((size_t)b * N + n) * CPin + c] * NF_XSCALE : 0.f;
+        const unsigned short hi = bf16_bits(v);
+        const unsigned short lo = bf16_bits(v - bf16_float(hi));
+        if (n < N) {
+            Khi[((size_t)b * N + n) * NF_CP + c] = hi;
+            Klo[((size_t)b * N + n) * NF_CP + c] = lo;
+        }
+        // position of key n inside its 32-block: key = (e&3) + 8(2t + (e>>2)) + 4kh  ->  pos = 16t + 8kh + e
+        const int kb = n & 31;
+        const int e = (kb & 3) | (((kb >> 3) & 1) << 2), kh = (kb >> 2) & 1, t = kb >> 4;
+        const size_t vp = ((size_t)b * NF_CP + c) * Npad + (n & ~31) + 16 * t + 8 * kh + e;
+        Vthi[vp] = c == C ? (unsigned short)0x3c00 : hi;             // 1.0 (binary16)
+        Vtlo[vp] = c == C ? (unsigned short)0 : lo;
+    }
+}
+
+// SPLIT = true: the fp32 path (operands as hi + lo, 72 MFMAs per 64 keys).  SPLIT = false: the same kernel on the hi parts only
+// (24 MFMAs per 64 keys) - 16-bit operands, fp32 accumulation: the non-local block of precision=bf16, whose trunk is 16-bit
+// anyway (binary16 has 3 more mantissa bits than the bf16 of the trunk: logits good to ~2e-3, where bf16 logits are off by 16 %).
+template <int C, bool SPLIT>
+__global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Khi,
+                                                              const uint16_t* __restrict__ Klo, const uint16_t* __restrict__ Vthi,
+                                                              const uint16_t* __restrict__ Vtlo, float* __restrict__ Xo,
+                                                              const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                              float* __restrict__ Zp, float* __restrict__ ML, int N, int Npad, int q0, int q1) {
+    constexpr int CT = 3;
+    constexpr int CP = (C + 31) / 32 * 32;                          // row stride of X / Xo / Wp (nl_padded_ch)
+    static_assert(C < NF_CP && C % 2 == 0, "needs a pad channel inside 96");
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];   // three tiles: K hi | K lo | V^T hi | V^T lo
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int xl = lane & 31;
+    const int kh = lane >> 5;
+    const int b = blockIdx.y;
+    const float* Xb = X + (size_t)b * N * CP;
+    float* Xob = Xo + (size_t)b * N * CP;
+    const int q = q0 + blockIdx.x * NF_QB + wave * 32 + xl;         // this lane's query (queries [q0, q1): a strip of the frame)
+    const int qc = q < q1 ? q : q1 - 1;
+
+    // B operand of S^T = K Q^T: this lane's query, channels 16ks + 8kh .. +7, scaled by log2(e), split hi + lo
+    constexpr float LOG2E = 1.4426950408889634f;
+    bf16x8 qh[6];
+    [[maybe_unused]] bf16x8 ql[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 16 * ks + 8 * kh + e;
+            const float v = c < C ? Xb[(size_t)qc * CP + c] * (LOG2E * NF_XSCALE) : 0.f;
+            const _Float16 h = (_Float16)v;
+            qh[ks][e] = h;
+            if constexpr (SPLIT) ql[ks][e] = (_Float16)(v - (float)h);
+        }
+    constexpr int LCT = C / 32, LI = C % 32;                        // where the row-sum channel C lives in the D layout
+    constexpr int LKH = (LI % 8) >= 4 ? 1 : 0, LR = (LI / 8) * 4 + (LI % 8) % 4;
+
+    f32x16 o[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
+    float m = -INFINITY;
+
+    // staging: 4 x 768 16-byte pieces per 64-key tile, 6 per thread (8 slots: the second pass covers pieces 512..767)
+    const uint16_t* const Khb = Khi + (size_t)b * N * NF_CP;
+    const uint16_t* const Klb = Klo + (size_t)b * N * NF_CP;
+    const uint16_t* const Vhb = Vthi + (size_t)b * NF_CP * Npad;
+    const uint16_t* const Vlb = Vtlo + (size_t)b * NF_CP * Npad;
+    constexpr int NI = 2;
+    u32x4 rk[4 * NI];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int id = min(tid + i * NF_THREADS, 767);          // 0..767 (surplus threads redo the last piece)
+            const int key = id / 12, c16 = id - key * 12;
+            const bool ok = k0 + key < N;
+            const size_t ko = ((size_t)(k0 + (ok ? key : 0)) * NF_CP + c16 * 8);
+            rk[i] = ok ? *reinterpret_cast<const u32x4*>(Khb + ko) : u32x4{0, 0, 0, 0};
+            if constexpr (SPLIT) rk[NI + i] = ok ? *reinterpret_cast<const u32x4*>(Klb + ko) : u32x4{0, 0, 0, 0};
+            const int ch = id >> 3, kc = id & 7;                    // V^T: 96 rows x 8 pieces (k0 + 64 <= Npad + 32: rows are padded)
+            const bool vok = k0 + kc * 8 < Npad;
+            const size_t vo = (size_t)ch * Npad + k0 + (vok ? kc * 8 : 0);
+            rk[2 * NI + i] = vok ? *reinterpret_cast<const u32x4*>(Vhb + vo) : u32x4{0, 0, 0, 0};
+            if constexpr (SPLIT) rk[3 * NI + i] = vok ? *reinterpret_cast<const u32x4*>(Vlb + vo) : u32x4{0, 0, 0, 0};
+        }
+    };
+    auto store_tile = [&](unsigned char* buf) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int id = min(tid + i * NF_THREADS, 767);
+            const int key = id / 12, c16 = id - key * 12;
+            *reinterpret_cast<u32x4*>(buf + key * NF_KROW + c16 * 16) = rk[i];
+            if constexpr (SPLIT) *reinterpret_cast<u32x4*>(buf + NF_KT * NF_KROW + key * NF_KROW + c16 * 16) = rk[NI + i];
+            const int ch = id >> 3, kc = id & 7;
+            *reinterpret_cast<u32x4*>(buf + 2 * NF_KT * NF_KROW + ch * NF_VROW + kc * 16) = rk[2 * NI + i];
+            if constexpr (SPLIT) *reinterpret_cast<u32x4*>(buf + 2 * NF_KT * NF_KROW + NF_CP * NF_VROW + ch * NF_VROW + kc * 16) = rk[3 * NI + i];
+        }
+    };
+
+    const int ntiles = (N + NF_KT - 1) / NF_KT;
+    const int ksp = gridDim.z, sp = blockIdx.z;
+    const int kt0 = (int)((long long)ntiles * sp / ksp), kt1 = (int)((long long)ntiles * (sp + 1) / ksp);
+    load_tile(kt0 * NF_KT);
+    store_tile(sm);
+    if (kt0 + 1 < kt1) load_tile((kt0 + 1) * NF_KT);
+    __syncthreads();
+    // The two waves of a SIMD are half a tile apart: waves 0-3 run S^T, softmax, P V of tile t; waves 4-7 run P V of
+    // tile t-1 (its P^T kept in registers, its V^T in the third LDS buffer), then S^T and softmax of tile t.  Next to
+    // a wave that keeps the matrix pipe busy a partner's VALU gets one issue slot per MFMA (tools/ubench) - phase-aligned,
+    // the two waves' softmax blocks (150 VALU, 32 of them quarter-rate v_exp_f32) simply add to the MFMA time; skewed,
+    // and with the softmax at raised priority, one wave's VALU runs under the other's MFMAs.
+    const bool late = wave >= 4;
+    bf16x8 pt[2][2];                                                // P^T (hi, lo parts) of the tile whose P V is still to come
+    [[maybe_unused]] bf16x8 pl[2][2];
+    bf16x8 ob[2][6];                                                // operands one MFMA step ahead (the compiler alone issues each
+                                                                    // ds_read right in front of its MFMA: 60 LDS latencies per tile)
+#define NF_LOAD_QK(ks_, d_)                                                                                     \
+    do {                                                                                                        \
+        ob[d_][0] = *reinterpret_cast<const bf16x8*>(kah + (ks_) * 32);                                         \
+        ob[d_][1] = *reinterpret_cast<const bf16x8*>(kah + 32 * NF_KROW + (ks_) * 32);                          \
+        if constexpr (SPLIT) {                                                                                  \
+            ob[d_][2] = *reinterpret_cast<const bf16x8*>(kal + (ks_) * 32);                                     \
+            ob[d_][3] = *reinterpret_cast<const bf16x8*>(kal + 32 * NF_KROW + (ks_) * 32);                      \
+        }                                                                                                       \
+    } while (0)
+#define NF_LOAD_PV(vah_, val_, j_, d_)                                                                          \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_) {                                                  \
+            ob[d_][ct_] = *reinterpret_cast<const bf16x8*>((vah_) + ct_ * 32 * NF_VROW + ((j_) >> 1) * 64 + ((j_) & 1) * 32);     \
+            if constexpr (SPLIT) ob[d_][3 + ct_] = *reinterpret_cast<const bf16x8*>((val_) + ct_ * 32 * NF_VROW + ((j_) >> 1) * 64 + ((j_) & 1) * 32); \
+        }                                                                                                       \
+    } while (0)
+    // O^T[ch][query] += V^T[ch][keys] P^T[keys][query] for the tile in `buf`, keys in the accumulator's own order;
+    // channel tile innermost (consecutive MFMAs go to different accumulators)
+#define NF_PV(buf_)                                                                                             \
+    do {                                                                                                        \
+        const unsigned char* const vah_ = (buf_) + 2 * NF_KT * NF_KROW + xl * NF_VROW + kh * 16;                \
+        const unsigned char* const val_ = vah_ + NF_CP * NF_VROW;                                               \
+        NF_LOAD_PV(vah_, val_, 0, 0);                                                                           \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+            if (j_ < 3) NF_LOAD_PV(vah_, val_, j_ + 1, (j_ + 1) & 1);                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+            _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_)                                                \
+                o[ct_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[j_ & 1][ct_], pt[j_ >> 1][j_ & 1], o[ct_], 0, 0, 0);     \
+            if constexpr (SPLIT) {                                                                              \
+                _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_)                                            \
+                    o[ct_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[j_ & 1][3 + ct_], pt[j_ >> 1][j_ & 1], o[ct_], 0, 0, 0); \
+                _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_)                                            \
+                    o[ct_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[j_ & 1][ct_], pl[j_ >> 1][j_ & 1], o[ct_], 0, 0, 0);     \
+            }                                                                                                   \
+        }                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+    } while (0)
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int bi = (kt - kt0) % 3;
+        unsigned char* const cur = sm + bi * NF_TILE_BYTES;
+        unsigned char* const nxt = sm + (bi == 2 ? 0 : bi + 1) * NF_TILE_BYTES;   // held tile kt-2: read by nobody any more
+        const unsigned char* const prv = sm + (bi == 0 ? 2 : bi - 1) * NF_TILE_BYTES;
+        if (late && kt > kt0) NF_PV(prv);
+        // S^T for both 32-key halves of the tile (two independent accumulators, alternating: no MFMA waits for its
+        // predecessor), then ONE running-max / rescale update for the 64 keys
+        const int kbase = kt * NF_KT;
+        f32x16 st[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
+        const unsigned char* const kah = cur + xl * NF_KROW + kh * 16;
+        const unsigned char* const kal = kah + NF_KT * NF_KROW;
+        NF_LOAD_QK(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks < 5) NF_LOAD_QK(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int d = ks & 1;
+            st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][0], qh[ks], st[0], 0, 0, 0);
+            st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][1], qh[ks], st[1], 0, 0, 0);
+            if constexpr (SPLIT) {
+                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][0], ql[ks], st[0], 0, 0, 0);
+                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][1], ql[ks], st[1], 0, 0, 0);
+                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][2], qh[ks], st[0], 0, 0, 0);
+                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][3], qh[ks], st[1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(2);                              // the softmax VALU goes ahead of the partner wave's MFMAs
+        if (kbase + NF_KT > N) {                                    // wave-uniform: only the last, partial key tile
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + sub * 32 + drow(r, lane) >= N) st[sub][r] = -INFINITY;
+        }
+        float tmax = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[1][0], st[1][1]));
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) tmax = fmaxf(tmax, fmaxf(fmaxf(st[0][r], st[0][r + 1]), fmaxf(st[1][r], st[1][r + 1])));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * NF_SINV;            // true base-2 logit (the scale is positive: max commutes)
+        const float mn = fmaxf(m, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);         // m = -inf on the first tile -> 0
+#ifdef NF_X_NOSOFTMAX   /* timing experiment only: wrong results */
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; r += 8) pl[sub][r >> 3] = pt[sub][r >> 3] = __builtin_bit_cast(bf16x8, u32x4{__builtin_bit_cast(unsigned, st[sub][r]), __builtin_bit_cast(unsigned, st[sub][r + 1]), __builtin_bit_cast(unsigned, st[sub][r + 2]), __builtin_bit_cast(unsigned, st[sub][r + 3])});
+#else
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[sub][r], NF_SINV, NF_PSHIFT - mn));   // 2^14 exp2(s - max)
+                const _Float16 ph = (_Float16)pv;
+                pt[sub][r >> 3][r & 7] = ph;
+                if constexpr (SPLIT) pl[sub][r >> 3][r & 7] = (_Float16)(pv - (float)ph);
+            }
+#endif
+        m = mn;
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!late) NF_PV(cur);
+        if (kt + 1 < kt1) {                                         // next tile (requested a tile ago) -> the third buffer; the tile
+            store_tile(nxt);                                        // after it requested
+            if (kt + 2 < kt1) load_tile((kt + 2) * NF_KT);
+        }
+        __syncthreads();                                            // this tile's S^T operands are free, the next tile is complete
+    }
+    if (late) NF_PV(sm + ((kt1 - 1 - kt0) % 3) * NF_TILE_BYTES);    // the late waves' last P V
+#undef NF_PV
+#undef NF_LOAD_PV
+#undef NF_LOAD_QK
+
+    float l = o[LCT][LR];
+    {
+        const float lo = __shfl_xor(l, 32);
+        if (kh != LKH) l = lo;
+    }
+    const float inv = (ksp == 1) ? (1.0f / NF_XSCALE) / l : (1.0f / NF_XSCALE);   // V carries 2^7; l and O share the 2^14 of P
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] *= inv;
+
+    // Z^T = W'^T O^T on the f32 matrix pipe, as in nonlocal.hip (pad rows of W' are zero: the row-sum channel drops out)
+    constexpr int CTW = CP / 32;
+#pragma unroll
+    for (int cot = 0; cot < CTW; ++cot) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) {
+            const float* wa = Wp + (size_t)(ct * 32 + 4 * kh) * CP + cot * 32 + xl;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) z = mfma32(wa[((s & 3) + 8 * (s >> 2)) * CP], o[ct][s], z);
+        }
+        if (q < q1) {
+            if (ksp == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cot * 32 + drow(r, lane);
+                    if (co < C) {
+                        const size_t idx = (size_t)q * CP + co;
+                        Xob[idx] = Xb[idx] + z[r] + bp[co];            // residual, model/pfnl.py:60
+                    }
+                }
+            } else {
+                float* zp = Zp + (((size_t)b * ksp + sp) * N + q) * CP;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zp[cot * 32 + drow(r, lane)] = z[r];
+            }
+        }
+    }
+    if (ksp > 1 && q < q1 && kh == 0) {
+        float* ml = ML + (((size_t)b * ksp + sp) * N + q) * 2;
+        ml[0] = m;
+        ml[1] = l;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same arithmetic with the two halves of the workgroup in ANTI-PHASE (nl_attn_f16_pp_kernel, the default;
+// PFNL_NL_PP=0 selects the kernel above).  Counted on the kernel above at 1080p (bf16 precision: 3.8 k cycles per 64-key tile and SIMD
+// for 1.5 k of MFMA and 2 x 1.0 k of softmax VALU): its half-tile skew makes three phases per tile - [S^T | P V], [softmax | S^T],
+// [P V | softmax] - plus the staging of the next tile through registers, i.e. both softmax blocks AND an MFMA-beside-MFMA phase are on
+// the critical path.  Here a tile is two phases per wave,
+//     Y(t): S^T of tile t and P V of tile t-1 (matrix pipe)          X(t): the softmax of tile t (VALU, raised priority)
+// and waves 4-7 run one phase behind waves 0-3 (one wave of each half per SIMD), so that a SIMD always has one wave in Y and one in X:
+// 2 x max(X, Y) per tile instead of X + X + Y/2 + staging.  Two workgroup barriers per tile, the same count for every wave.
+// The K / V^T tiles travel by LDS-DMA (`buffer_load_dwordx4 ... lds`; the four packed arrays are one allocation = one buffer resource,
+// the padded LDS rows are produced by per-lane source offsets, keys past N and the pad chunks by an out-of-range offset = zeros): no
+// staging registers, no ds_write, and the requests ride on the S^T steps of the MFMA phase.  Ring of NSLOT tiles (3 with split
+// operands - LDS is full - and 5 of 32 KB on the hi parts only): at the start of Y(t) the slot of tile t-2 is free (the late half read
+// it in ITS Y(t-1), one phase ago) and takes tile t + NSLOT - 2; a wave waits for its own pieces of tile t + 1 at the end of the phase
+// that precedes the early half's Y(t+1) - `s_waitcnt vmcnt((NSLOT - 3) x pieces per wave)`: the counter retires in issue order and
+// every wave issues the same number of pieces per tile (past the last tile: against an empty resource), so that count is exact.
+template <bool SPLIT>
+struct NfPP {
+    static constexpr int KLO_OFF = NF_KT * NF_KROW;                                    // 13 312 (split only)
+    static constexpr int VHI_OFF = SPLIT ? 2 * NF_KT * NF_KROW : NF_KT * NF_KROW;      // 26 624 | 13 312
+    static constexpr int VLO_OFF = VHI_OFF + NF_CP * NF_VROW;                          // + 13 824 (split only)
+    static constexpr int TILE_BYTES = SPLIT ? VLO_OFF + NF_CP * NF_VROW : VLO_OFF;     // 54 272 | 27 136
+    static constexpr int NSLOT = SPLIT ? 3 : 5;
+    static constexpr int PIECES = SPLIT ? 53 : 32;                                     // 1 KB DMA instructions per tile (hi only: 27 carry data)
+    static constexpr int SLOT_BYTES = PIECES * 1024;                                   // 54 272 | 32 768
+    static constexpr int PW = (PIECES + 7) / 8;                                        // per wave: 7 (waves 5-7: 6) | 4
+    static constexpr int LDS_BYTES = NSLOT * SLOT_BYTES;                               // 162 816 | 163 840
+    static_assert(TILE_BYTES <= SLOT_BYTES && LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(SPLIT || PIECES % 8 == 0, "the vmcnt wait of the hi-only ring counts on equal shares");
+};
+
+__device__ __forceinline__ void nf_dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds_dst, int voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rs) : "memory");
+}
+#ifndef NP_PRIO_X
+#define NP_PRIO_X 2
+#endif
+#ifndef NP_PRIO_Y
+#define NP_PRIO_Y 0
+#endif
+#define NF_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifdef PFNL_NP_TIMING   /* phase timeline (tools/np_timing.py); not part of the product build */
+__device__ long long np_dbg[256 * 2 * 128];
+#define NP_STAMP() do { if (SPLIT == (PFNL_NP_TIMING != 0) && lane == 0 && (wave == 0 || wave == 4) && dbg_n < 128 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 256) np_dbg[(blockIdx.x * 2 + (wave != 0)) * 128 + dbg_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define NP_STAMP() do {} while (0)
+#endif
+
+// K16 = Khi (the lowest address of the scratch); rel_* = byte offsets of Klo, Vthi, Vtlo from it; scratch_bytes = the whole allocation
+template <int C, bool SPLIT>
+__global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_pp_kernel(const float* __restrict__ X, const uint16_t* __restrict__ K16,
+                                                                 unsigned rel_klo, unsigned rel_vhi, unsigned rel_vlo, unsigned scratch_bytes,
+                                                                 float* __restrict__ Xo, const float* __restrict__ Wp,
+                                                                 const float* __restrict__ bp, float* __restrict__ Zp,
+                                                                 float* __restrict__ ML, int N, int Npad, int q0, int q1) {
+    using G = NfPP<SPLIT>;
+    constexpr int CT = 3;
+    constexpr int CP = (C + 31) / 32 * 32;                          // row stride of X / Xo / Wp (nl_padded_ch)
+    static_assert(C < NF_CP && C % 2 == 0, "needs a pad channel inside 96");
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];   // NSLOT tiles: K hi | (K lo) | V^T hi | (V^T lo)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool late = wave >= 4;                                    // the half that runs one phase behind
+#ifdef PFNL_NP_TIMING
+    int dbg_n = 0;
+#endif
+    const int xl = lane & 31;
+    const int kh = lane >> 5;
+    const int b = blockIdx.y;
+    const float* Xb = X + (size_t)b * N * CP;
+    float* Xob = Xo + (size_t)b * N * CP;
+    const int q = q0 + blockIdx.x * NF_QB + (tid >> 6) * 32 + xl;   // this lane's query (queries [q0, q1): a strip of the frame)
+    const int qc = q < q1 ? q : q1 - 1;
+
+    // B operand of S^T = K Q^T: this lane's query, channels 16ks + 8kh .. +7, scaled by log2(e), split hi + lo
+    constexpr float LOG2E = 1.4426950408889634f;
+    bf16x8 qh[6];
+    [[maybe_unused]] bf16x8 ql[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 16 * ks + 8 * kh + e;
+            const float v = c < C ? Xb[(size_t)qc * CP + c] * (LOG2E * NF_XSCALE) : 0.f;
+            const _Float16 h = (_Float16)v;
+            qh[ks][e] = h;
+            if constexpr (SPLIT) ql[ks][e] = (_Float16)(v - (float)h);
+        }
+    constexpr int LCT = C / 32, LI = C % 32;                        // where the row-sum channel C lives in the D layout
+    constexpr int LKH = (LI % 8) >= 4 ? 1 : 0, LR = (LI / 8) * 4 + (LI % 8) % 4;
+
+    f32x16 o[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
+    float m = -INFINITY;
+
+    // DMA map: piece i = wave + 8k writes slot bytes [1024 i, + 1024), lane L the 16 bytes at p = 1024 i + 16 L.  `srel` = byte offset of
+    // that chunk's source from K16 for key tile 0 (0x7fffffff: a pad chunk - stays out of range), `rowk` = its key row for the K arrays
+    // (the range test against N), very negative for V^T (always inside: the rows are padded by a tile).  Per tile: + k0 x (192 | 2).
+    int srel[G::PW], rowk[G::PW];
+#pragma unroll
+    for (int k = 0; k < G::PW; ++k) {
+        const int p = (wave + 8 * k) * 1024 + 16 * lane;
+        int sr = 0x7fffffff, rk = 1 << 20;
+        if (p < NF_KT * NF_KROW || (SPLIT && p < 2 * NF_KT * NF_KROW)) {
+            const bool lo = p >= NF_KT * NF_KROW;
+            const int r = p - (lo ? NF_KT * NF_KROW : 0);
+            const int row = r / NF_KROW, col = r - row * NF_KROW;
+            if (col < NF_CP * 2) {
+                sr = (int)((lo ? rel_klo : 0u) + (unsigned)(((size_t)b * N + row) * (NF_CP * 2)) + col);
+                rk = row;
+            }
+        } else if (p < G::TILE_BYTES) {
+            const bool lo = SPLIT && p >= G::VLO_OFF;
+            const int r = p - (lo ? G::VLO_OFF : G::VHI_OFF);
+            const int ch = r / NF_VROW, col = r - ch * NF_VROW;
+            if (col < NF_KT * 2) {
+                sr = (int)((lo ? rel_vlo : rel_vhi) + (unsigned)(((size_t)b * NF_CP + ch) * Npad * 2) + col);
+                rk = -(1 << 20);
+            }
+        }
+        srel[k] = sr;
+        rowk[k] = rk;
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)sm;
+    // piece k of this wave for key tile `kt` -> ring slot `slot`; `live` false (past the last tile): an empty resource, nothing moves
+    auto tile_piece = [&](int k, int kt, int slot, bool live) __attribute__((always_inline)) {
+        const int i = wave + 8 * k;
+        if (i < G::PIECES) {                                        // (wave-uniform; split: waves 5-7 have 6 pieces)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(K16), 0, live ? scratch_bytes : 0, 0x00020000);
+            const int k0 = kt * NF_KT;
+            const bool isk = i * 1024 < (SPLIT ? 2 : 1) * NF_KT * NF_KROW;   // (the K | V^T boundary is a multiple of 1024)
+            const int off = rowk[k] < N - k0 ? srel[k] + k0 * (isk ? NF_CP * 2 : 2) : 0x7fffffff;
+            nf_dma16(rs, lds0 + slot * G::SLOT_BYTES + i * 1024, off);
+        }
+    };
+
+    const int ntiles = (N + NF_KT - 1) / NF_KT;
+    const int ksp = gridDim.z, sp = blockIdx.z;
+    const int kt0 = (int)((long long)ntiles * sp / ksp), kt1 = (int)((long long)ntiles * (sp + 1) / ksp);
+    // A wave's pieces of a tile are requested in two parts: pieces k >= NPX ride on the first steps of a Y phase, one per step (a
+    // vector-memory instruction among the MFMAs of a wave that is alone on its pipe costs it ~100 cycles), pieces k < NPX go out at the
+    // start of an X phase (there a request blocks the wave for as long as the CU's request queue is full: all of a tile at once,
+    // 16 - 28 KB from the four waves of a half, took 0.9 - 1.9 k cycles of the softmax phase; none: Y gets too long).  Early half: tile
+    // t + NSLOT - 2 in Y(t) and X(t).  Late half: its X(t) runs beside the early half's Y(t+1), which reads tiles t and t + 1, so its X
+    // part belongs to the NEXT tile: tile t + NSLOT - 1 in X(t), the rest of it in Y(t+1).
+    constexpr int NPX = SPLIT ? 4 : 1;
+    // prologue: every wave's pieces of tiles kt0 .. kt0 + NSLOT - 3 -> slots 0 .., the late half's X part of tile kt0 + NSLOT - 2; an
+    // all-zero tile -> slot NSLOT - 1, the "tile kt0 - 1" of the first P V (whose P^T is zero: no branch around the first P V, but
+    // 0 x whatever the LDS held could be NaN)
+#pragma unroll
+    for (int j = 0; j < G::NSLOT - 2; ++j)
+#pragma unroll
+        for (int k = 0; k < G::PW; ++k) tile_piece(k, kt0 + j, j, kt0 + j < kt1);
+    if (late) {
+#pragma unroll
+        for (int k = 0; k < NPX; ++k) tile_piece(k, kt0 + G::NSLOT - 2, G::NSLOT - 2, kt0 + G::NSLOT - 2 < kt1);
+    }
+#pragma unroll
+    for (int k = 0; k < G::PW; ++k) tile_piece(k, 0, G::NSLOT - 1, false);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (late) NF_BARRIER();                                         // the late half: one phase behind
+
+    bf16x8 pt[2][2];                                                // P^T (hi, lo parts) of the tile whose P V is still to come
+    [[maybe_unused]] bf16x8 pl[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pt[i][j][e] = (_Float16)0.f;
+                if constexpr (SPLIT) pl[i][j][e] = (_Float16)0.f;
+            }
+    // Y is one sequence of 10 MFMA steps - S^T k-steps 0..5 (2 | 6 MFMAs each), P V key steps 0..3 (3 | 9) - whose operands are read
+    // D steps ahead: a wave that is alone on its matrix pipe (its partner is in the softmax) waits out every LDS latency itself, and a
+    // hi-only S^T step is 64 cycles of MFMA against ~130 of ds_read_b128 latency (measured with D = 1: 1.55 k cycles for 0.77 k of MFMA)
+    constexpr int D = SPLIT ? 1 : 3;
+    constexpr int NOPS = SPLIT ? 6 : 3;                             // operand registers (x 4) per step
+    bf16x8 ob[D + 1][NOPS];
+    int s_cur = 0, s_prv = G::NSLOT - 1;                            // ring slots of tiles t, t - 1
+    int s_fy = G::NSLOT - 2;                                        // of the tile requested in Y(t): t + NSLOT - 2
+    int s_fx = late ? G::NSLOT - 1 : G::NSLOT - 2;                  // and in X(t): t + NSLOT - 2 | t + NSLOT - 1
+    for (int kt = kt0; kt < kt1; ++kt) {
+        NP_STAMP();                                                 // 0: Y starts
+        const unsigned char* const cur = sm + s_cur * G::SLOT_BYTES;
+        const unsigned char* const prv = sm + s_prv * G::SLOT_BYTES;
+        const int kbase = kt * NF_KT;
+        f32x16 st[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
+        const unsigned char* const kah = cur + xl * NF_KROW + kh * 16;
+        [[maybe_unused]] const unsigned char* const kal = kah + G::KLO_OFF;
+        const unsigned char* const vah = prv + G::VHI_OFF + xl * NF_VROW + kh * 16;
+        [[maybe_unused]] const unsigned char* const val = prv + G::VLO_OFF + xl * NF_VROW + kh * 16;
+        // step s < 6: S^T k-step s (A = key rows of both 32-key halves); step 6 + j: P V key step j (A = V^T rows of the 3 channel tiles)
+        auto load_step = [&](auto sc) __attribute__((always_inline)) {
+            constexpr int s_ = decltype(sc)::value;
+            constexpr int d = s_ % (D + 1);
+            if constexpr (s_ < 6) {
+                ob[d][0] = *reinterpret_cast<const bf16x8*>(kah + s_ * 32);
+                ob[d][1] = *reinterpret_cast<const bf16x8*>(kah + 32 * NF_KROW + s_ * 32);
+                if constexpr (SPLIT) {
+                    ob[d][2] = *reinterpret_cast<const bf16x8*>(kal + s_ * 32);
+                    ob[d][3] = *reinterpret_cast<const bf16x8*>(kal + 32 * NF_KROW + s_ * 32);
+                }
+            } else if constexpr (s_ < 10) {
+                constexpr int j = s_ - 6;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    ob[d][ct] = *reinterpret_cast<const bf16x8*>(vah + ct * 32 * NF_VROW + (j >> 1) * 64 + (j & 1) * 32);
+                    if constexpr (SPLIT) ob[d][3 + ct] = *reinterpret_cast<const bf16x8*>(val + ct * 32 * NF_VROW + (j >> 1) * 64 + (j & 1) * 32);
+                }
+            }
+        };
+        auto mfma_step = [&](auto sc) __attribute__((always_inline)) {
+            constexpr int s_ = decltype(sc)::value;
+            constexpr int d = s_ % (D + 1);
+            if constexpr (s_ < 6) {
+                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][0], qh[s_], st[0], 0, 0, 0);
+                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][1], qh[s_], st[1], 0, 0, 0);
+                if constexpr (SPLIT) {
+                    st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][0], ql[s_], st[0], 0, 0, 0);
+                    st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][1], ql[s_], st[1], 0, 0, 0);
+                    st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][2], qh[s_], st[0], 0, 0, 0);
+                    st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][3], qh[s_], st[1], 0, 0, 0);
+                }
+            } else {
+                // O^T[ch][query] += V^T[ch][keys] P^T[keys][query], keys in the accumulator's own order; channel tile innermost
+                // (consecutive MFMAs go to different accumulators)
+                constexpr int j = s_ - 6;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][ct], pt[j >> 1][j & 1], o[ct], 0, 0, 0);
+                if constexpr (SPLIT) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][3 + ct], pt[j >> 1][j & 1], o[ct], 0, 0, 0);
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][ct], pl[j >> 1][j & 1], o[ct], 0, 0, 0);
+                }
+            }
+        };
+        auto y_step = [&](auto sc) __attribute__((always_inline)) {
+            constexpr int s_ = decltype(sc)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            load_step(std::integral_constant<int, s_ + D>{});      // (past step 9: nothing)
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(sc);
+            if constexpr (s_ + NPX < G::PW) {                       // the Y part of tile t + NSLOT - 2, a piece per step
+                __builtin_amdgcn_sched_barrier(0);
+                tile_piece(s_ + NPX, kt + G::NSLOT - 2, s_fy, kt + G::NSLOT - 2 < kt1);
+            }
+        };
+        // ---- Y(t): S^T of tile t, then the P V of tile t - 1
+#pragma unroll
+        for (int s0 = 0; s0 < D; ++s0) {
+            if (s0 == 0) load_step(std::integral_constant<int, 0>{});
+            if (s0 == 1) load_step(std::integral_constant<int, 1>{});
+            if (s0 == 2) load_step(std::integral_constant<int, 2>{});
+        }
+        y_step(std::integral_constant<int, 0>{});
+        y_step(std::integral_constant<int, 1>{});
+        y_step(std::integral_constant<int, 2>{});
+        y_step(std::integral_constant<int, 3>{});
+        y_step(std::integral_constant<int, 4>{});
+        y_step(std::integral_constant<int, 5>{});
+        y_step(std::integral_constant<int, 6>{});
+        y_step(std::integral_constant<int, 7>{});
+        y_step(std::integral_constant<int, 8>{});
+        y_step(std::integral_constant<int, 9>{});
+        __builtin_amdgcn_sched_barrier(0);
+        NP_STAMP();                                                 // 1: MFMAs issued
+        if (late) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G::NSLOT - 3) * G::PW) : "memory");   // its pieces of tile t + 1 have landed
+        NF_BARRIER();
+        NP_STAMP();                                                 // 2: X starts
+
+        // ---- X(t): the X part of this half's requests, then ONE running-max / rescale update for the 64 keys, P^T straight from the
+        // S^T accumulators
+        {
+            const int kfill = kt + (late ? G::NSLOT - 1 : G::NSLOT - 2);
+#pragma unroll
+            for (int k = 0; k < NPX; ++k) tile_piece(k, kfill, s_fx, kfill < kt1);
+        }
+        __builtin_amdgcn_s_setprio(NP_PRIO_X);
+        if (kbase + NF_KT > N) {                                    // wave-uniform: only the last, partial key tile
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + sub * 32 + drow(r, lane) >= N) st[sub][r] = -INFINITY;
+        }
+        float tmax = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[1][0], st[1][1]));
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) tmax = fmaxf(tmax, fmaxf(fmaxf(st[0][r], st[0][r + 1]), fmaxf(st[1][r], st[1][r + 1])));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * NF_SINV;            // true base-2 logit (the scale is positive: max commutes)
+        const float mn = fmaxf(m, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);         // m = -inf on the first tile -> 0
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[sub][r], NF_SINV, NF_PSHIFT - mn));   // 2^14 exp2(s - max)
+                const _Float16 ph = (_Float16)pv;
+                pt[sub][r >> 3][r & 7] = ph;
+                if constexpr (SPLIT) pl[sub][r >> 3][r & 7] = (_Float16)(pv - (float)ph);
+            }
+        m = mn;
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+        }
+        __builtin_amdgcn_s_setprio(NP_PRIO_Y);
+        __builtin_amdgcn_sched_barrier(0);
+        NP_STAMP();                                                 // 3: softmax done
+        if (!late) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G::NSLOT - 3) * G::PW) : "memory");   // its pieces of tile t + 1 have landed
+        NF_BARRIER();
+        s_prv = s_cur;
+        s_cur = s_cur + 1 == G::NSLOT ? 0 : s_cur + 1;
+        s_fy = s_fy + 1 == G::NSLOT ? 0 : s_fy + 1;
+        s_fx = s_fx + 1 == G::NSLOT ? 0 : s_fx + 1;
+    }
+    if (!late) NF_BARRIER();                                        // pairs with the late half's last barrier
+    {   // the last tile's P V (nothing is written into its slot any more: requests past kt1 go against an empty resource - but they do
+        // write zeros, and the slot of tile kt1 - 1 is never a target: the last requests are for tiles kt1 - 1 + NSLOT - 2 | - 1)
+        const unsigned char* const prv = sm + s_prv * G::SLOT_BYTES;
+        const unsigned char* const vah = prv + G::VHI_OFF + xl * NF_VROW + kh * 16;
+        [[maybe_unused]] const unsigned char* const val = prv + G::VLO_OFF + xl * NF_VROW + kh * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x8 vh[CT];
+            [[maybe_unused]] bf16x8 vl[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                vh[ct] = *reinterpret_cast<const bf16x8*>(vah + ct * 32 * NF_VROW + (j >> 1) * 64 + (j & 1) * 32);
+                if constexpr (SPLIT) vl[ct] = *reinterpret_cast<const bf16x8*>(val + ct * 32 * NF_VROW + (j >> 1) * 64 + (j & 1) * 32);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[ct], pt[j >> 1][j & 1], o[ct], 0, 0, 0);
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[ct], pt[j >> 1][j & 1], o[ct], 0, 0, 0);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[ct], pl[j >> 1][j & 1], o[ct], 0, 0, 0);
+            }
+        }
+    }
+
+    float l = o[LCT][LR];
+    {
+        const float lo = __shfl_xor(l, 32);
+        if (kh != LKH) l = lo;
+    }
+    const float inv = (ksp == 1) ? (1.0f / NF_XSCALE) / l : (1.0f / NF_XSCALE);   // V carries 2^7; l and O share the 2^14 of P
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] *= inv;
+
+    // Z^T = W'^T O^T on the f32 matrix pipe, as in nonlocal.hip (pad rows of W' are zero: the row-sum channel drops out)
+    constexpr int CTW = CP / 32;
+#pragma unroll
+    for (int cot = 0; cot < CTW; ++cot) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) {
+            const float* wa = Wp + (size_t)(ct * 32 + 4 * kh) * CP + cot * 32 + xl;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) z = mfma32(wa[((s & 3) + 8 * (s >> 2)) * CP], o[ct][s], z);
+        }
+        if (q < q1) {
+            if (ksp == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cot * 32 + drow(r, lane);
+                    if (co < C) {
+                        const size_t idx = (size_t)q * CP + co;
+                        Xob[idx] = Xb[idx] + z[r] + bp[co];            // residual, model/pfnl.py:60
+                    }
+                }
+            } else {
+                float* zp = Zp + (((size_t)b * ksp + sp) * N + q) * CP;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zp[cot * 32 + drow(r, lane)] = z[r];
+            }
+        }
+    }
+    if (ksp > 1 && q < q1 && kh == 0) {
+        float* ml = ML + (((size_t)b * ksp + sp) * N + q) * 2;
+        ml[0] = m;
+        ml[1] = l;
+    }
+}
+
+size_t nl_f16_scratch_halfs(int B, int N) {                        // Khi, Klo, Vthi, Vtlo
+    const size_t npad = (size_t)(N + 31) / 32 * 32 + 64;            // + one tile of slack for the last tile's V^T pieces
+    return 2 * (size_t)B * N * NF_CP + 2 * (size_t)B * NF_CP * npad;
+}
+
+// X, Xo as in launch_nl_attn; scratch16: nl_f16_scratch_halfs(B, N) 16-bit elements; partial: nl_partial_floats
+hipError_t launch_nl_attn_f16(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, uint16_t* scratch16,
+                               int B, int N, int C, hipStream_t s, int q0, int q1, bool split) {
+    if (C != 84 && C != 60 && C != 36) return hipErrorInvalidValue;
+    if (q1 < 0) q1 = N;
+    if (q0 < 0 || q0 >= q1 || q1 > N) return hipErrorInvalidValue;
+    const int CP = nl_padded_ch(C);
+    const int npad = (N + 31) / 32 * 32 + 64;
+    uint16_t* Khi = scratch16;
+    uint16_t* Klo = Khi + (size_t)B * N * NF_CP;
+    uint16_t* Vthi = Klo + (size_t)B * N * NF_CP;
+    uint16_t* Vtlo = Vthi + (size_t)B * NF_CP * npad;
+    {
+        const size_t total = (size_t)B * npad * NF_CP;
+        const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        hipLaunchKernelGGL(nl_pack_f16_kernel, dim3(blocks), dim3(256), 0, s, X, Khi, Klo, Vthi, Vtlo, B, N, npad, C, CP);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    // key splits: this kernel runs 1 workgroup per CU (LDS), so the grid should fill a whole number of 256-workgroup
+    // rounds: time ~ ceil(query blocks * B * ks / 256) / ks.  (1080p: 127 blocks -> ks = 2 is one full round.)  Bounded
+    // by the fp32 kernel's choice, which sized the partial-result buffer.
+    const int ks_max = nl_key_splits(B, N);
+    int ks = 1;
+    {
+        const long long qb = (long long)((q1 - q0 + NF_QB - 1) / NF_QB) * B;
+        double best = 1e30;
+        for (int k = 1; k <= ks_max; ++k) {
+            const double t = (double)((qb * k + 255) / 256) / k;
+            if (t < best - 1e-9) {
+                best = t;
+                ks = k;
+            }
+        }
+    }
+    if (ks > 1 && !partial) return hipErrorInvalidValue;
+    float* Zp = partial;
+    float* ML = partial ? partial + (size_t)B * ks * N * CP : nullptr;
+    dim3 grid((q1 - q0 + NF_QB - 1) / NF_QB, B, ks);
+    dim3 block(NF_THREADS);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    // the anti-phase kernel (round 4) addresses the four packed arrays as ONE buffer resource with 32-bit offsets and an out-of-range
+    // sentinel of 2^31 - 1: a scratch of 2 GB or more (> 5.5 M keys in the batch) stays on the first kernel.  PFNL_NL_PP=0: always.
+    static const bool pp_on = [] {
+        const char* e = std::getenv("PFNL_NL_PP");
+        return !(e && e[0] == '0');
+    }();
+    const size_t scratch_bytes = 2 * nl_f16_scratch_halfs(B, N);
+    if (pp_on && scratch_bytes < 0x7fff0000ull) {
+        static std::atomic<int> attr_pp[64];
+        if (!attr_pp[dev]) {
+            for (const void* fn : {reinterpret_cast<const void*>(nl_attn_f16_pp_kernel<84, true>), reinterpret_cast<const void*>(nl_attn_f16_pp_kernel<60, true>),
+                                   reinterpret_cast<const void*>(nl_attn_f16_pp_kernel<36, true>)}) {
+                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NfPP<true>::LDS_BYTES);
+                if (e != hipSuccess) return e;
+            }
+            for (const void* fn : {reinterpret_cast<const void*>(nl_attn_f16_pp_kernel<84, false>), reinterpret_cast<const void*>(nl_attn_f16_pp_kernel<60, false>),
+                                   reinterpret_cast<const void*>(nl_attn_f16_pp_kernel<36, false>)}) {
+                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NfPP<false>::LDS_BYTES);
+                if (e != hipSuccess) return e;
+            }
+            attr_pp[dev] = 1;
+        }
+        const unsigned rel_klo = (unsigned)((Klo - Khi) * 2), rel_vhi = (unsigned)((Vthi - Khi) * 2), rel_vlo = (unsigned)((Vtlo - Khi) * 2);
+#define NP_LAUNCH(C_, S_) hipLaunchKernelGGL((nl_attn_f16_pp_kernel<C_, S_>), grid, block, NfPP<S_>::LDS_BYTES, s, X, Khi, rel_klo, rel_vhi, rel_vlo, \
+                                             (unsigned)scratch_bytes, Xo, Wp, bp, Zp, ML, N, npad, q0, q1)
+        switch (C) {
+            case 84: if (split) NP_LAUNCH(84, true); else NP_LAUNCH(84, false); break;
+            case 60: if (split) NP_LAUNCH(60, true); else NP_LAUNCH(60, false); break;
+            case 36: if (split) NP_LAUNCH(36, true); else NP_LAUNCH(36, false); break;
+        }
+#undef NP_LAUNCH
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess || ks == 1) return e;
+        return launch_nl_merge(X, Zp, ML, bp, Xo, B, N, C, ks, s, q0, q1);
+    }
+    static std::atomic<int> attr_dev[64];
+    if (!attr_dev[dev]) {
+        for (const void* fn : {reinterpret_cast<const void*>(nl_attn_f16_kernel<84, true>), reinterpret_cast<const void*>(nl_attn_f16_kernel<60, true>),
+                               reinterpret_cast<const void*>(nl_attn_f16_kernel<36, true>), reinterpret_cast<const void*>(nl_attn_f16_kernel<84, false>),
+                               reinterpret_cast<const void*>(nl_attn_f16_kernel<60, false>), reinterpret_cast<const void*>(nl_attn_f16_kernel<36, false>)}) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NF_LDS_BYTES);
+            if (e != hipSuccess) return e;
+        }
+        attr_dev[dev] = 1;
+    }
+#define NF_LAUNCH(C_, S_) hipLaunchKernelGGL((nl_attn_f16_kernel<C_, S_>), grid, block, NF_LDS_BYTES, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad, q0, q1)
+    switch (C) {
+        case 84: if (split) NF_LAUNCH(84, true); else NF_LAUNCH(84, false); break;
+        case 60: if (split) NF_LAUNCH(60, true); else NF_LAUNCH(60, false); break;
+        case 36: if (split) NF_LAUNCH(36, true); else NF_LAUNCH(36, false); break;
+    }
+#undef NF_LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || ks == 1) return e;
+    return launch_nl_merge(X, Zp, ML, bp, Xo, B, N, C, ks, s, q0, q1);
+}
+
+}  // namespace pfnl
+
+#ifdef PFNL_NP_TIMING
+extern "C" int pfnl_debug_read_np_stamps(long long* host, size_t n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(pfnl::np_dbg), n * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif

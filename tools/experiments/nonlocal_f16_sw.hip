@@ -1,0 +1,953 @@
+// Non-local block of the fp32 path on the f16 matrix pipe with exactly split operands (option nonlocal=split16; the same idea as
+// conv_split16.hip: x = hi + lo with hi = f16(x), lo = f16(x - hi), products hi hi + hi lo + lo hi in fp32 accumulators: >= 22 mantissa
+// bits per product).  Derived from nonlocal_bf16.hip (same streaming-softmax structure, same operand layouts); what differs:
+//   * binary16 has a 5-bit exponent, so everything is kept in its normal range by powers of two that cancel exactly:
+//     K, V and Q are scaled by 2^7 (the image is in [0,1]: hi <= 185, lo normal for x >= 0.001), the logits therefore come out of
+//     the MFMA scaled by 2^14 (undone inside the exp2 argument's fma), the probabilities are computed as 2^14 exp2(s - max) (<= 16384:
+//     representable down to 2^-28 of the row maximum) - the row sum accumulates the same scaled values, so O / l needs only 2^-7;
+//   * P is split as well (hi + lo): 3 MFMAs per V^T P^T product block instead of 2 - 72 f16 MFMAs of 32 cycles per 64 keys and 32
+//     queries against 180 f32 MFMAs of 64 in nonlocal.hip.
+// ---- (the description of the structure, from nonlocal_bf16.hip:)
+// Non-local block on bf16 MFMA (option precision=bf16; BASELINE.json configs[3]: at 1080p the affinity is
+// N = 32400 squared, 354 GFLOP - 3.3 ms on the f32 matrix pipe, more than the whole bf16 trunk).
+//
+// Same streaming-softmax structure as nonlocal.hip (reference utils.py:18-71, nltype=1), with the two contractions on
+// v_mfma_f32_32x32x16_bf16 and fp32 everywhere a bf16 value would be visible in the result:
+//   * logits S = X X^T (|S| <= 84, exp(S) needs ~1e-4 absolute): bf16 inputs alone would be wrong by ~16 %
+//     (SURVEY.md section 7), so X is split into hi + lo bf16 parts and S = hi hi + hi lo + lo hi accumulated in fp32
+//     (the dropped lo lo term is < 84 * 2^-18): 18 MFMAs of 32 cycles per 32x32 tile against 42 f32 MFMAs of 64;
+//   * P = exp2(S' - running max) in fp32, rounded to bf16 only as the MFMA operand; the row sum accumulates the SAME
+//     rounded values through the "ones" channel, so the normalisation is exact for what was summed;
+//   * V = X also as hi + lo (12 MFMAs per tile): a query dominated by one key returns that key's fp32 value;
+//   * running max / rescale, normalisation, the folded 1x1 projection (f32 MFMA) and the residual as in nonlocal.hip.
+// Operand layouts (lane = (l & 31, kh = l >> 5), 8 bf16 per lane and MFMA):
+//   K tile in LDS  [key][96 ch] (+ pad to 208 B: conflict-free b128 reads), hi and lo: A of S^T = K Q^T;
+//   Q in registers [6 k-steps] hi and lo, pre-scaled by log2(e): B of S^T;
+//   P^T straight from the S^T accumulator: register r of lane (query, kh) is key (r&3) + 8(r>>2) + 4kh, registers
+//   8t..8t+7 form the B operand of k-step t - the contraction order over keys is free, so V^T is stored by nl_pack_bf16
+//   with the keys of every 32-block permuted to exactly that order ([ch][block][t][kh][e]).
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "conv_bf16.h"
+#include "conv_split16.h"
+
+namespace pfnl {
+
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));   // (name kept from the bf16 kernel: 8 x binary16 here)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NF_KT = 64;                  // keys per LDS tile
+constexpr int NF_KROW = 208;               // bytes per key row of the K tiles (96 ch * 2 B + 16)
+constexpr int NF_VROW = 144;               // bytes per channel row of the V^T tiles (64 keys * 2 B + 16)
+constexpr int NF_CP = 96;
+constexpr int NF_THREADS = 512;           // 8 waves x 32 queries share every key tile: the K / V^T stream (48 KB per 64 keys) is what
+                                          // bounds this kernel - with 128 queries per workgroup it ran at 6.6 TB/s of L2 -> CU traffic
+                                          // (11 B/clk/CU) and 43 % matrix-pipe use, whatever was done to its instruction schedule
+constexpr int NF_QB = NF_THREADS / 2;     // queries per workgroup
+constexpr int NF_TILE_BYTES = 2 * NF_KT * NF_KROW + 2 * NF_CP * NF_VROW;   // 54 272: K hi, K lo, V^T hi, V^T lo
+constexpr int NF_LDS_BYTES = 3 * NF_TILE_BYTES;                             // 162 816 of 163 840: tiles t-1 (late waves' P V), t, t+1 (being filled)
+
+constexpr float NF_XSCALE = 128.0f;                       // 2^7 on K, V and Q
+constexpr float NF_SINV = 1.0f / (128.0f * 128.0f);       // logits leave the MFMA scaled by 2^14
+constexpr float NF_PSHIFT = 14.0f;                        // probabilities are kept as 2^14 exp2(s - max)
+__device__ __forceinline__ unsigned short bf16_bits(float f) {   // binary16, round to nearest even
+    const _Float16 b = (_Float16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf16_float(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
+
+// X [B][N][CP] fp32 (nl_pack_kernel) -> Khi, Klo [B][N][96] bf16;  Vthi, Vtlo [B][96][Npad] bf16, keys permuted per
+// 32-block, channel C = 1 (the row-sum channel), channels > C = 0
+__global__ void nl_pack_f16_kernel(const float* __restrict__ X, uint16_t* __restrict__ Khi, uint16_t* __restrict__ Klo,
+                                    uint16_t* __restrict__ Vthi, uint16_t* __restrict__ Vtlo, int B, int N, int Npad, int C,
+                                    int CPin) {
+    const size_t total = (size_t)B * Npad * NF_CP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % NF_CP);
+        const int n = (int)((i / NF_CP) % Npad);
+        const int b = (int)(i / ((size_t)NF_CP * Npad));
+        const float v = (n < N && c < C) ? X[((size_t)b * N + n) * CPin + c] * NF_XSCALE : 0.f;
+        const unsigned short hi = bf16_bits(v);
+        const unsigned short lo = bf16_bits(v - bf16_float(hi));
+        if (n < N) {
+            Khi[((size_t)b * N + n) * NF_CP + c] = hi;
+            Klo[((size_t)b * N + n) * NF_CP + c] = lo;
+        }
+        // position of key n inside its 32-block: key = (e&3) + 8(2t + (e>>2)) + 4kh  ->  pos = 16t + 8kh + e
+        const int kb = n & 31;
+        const int e = (kb & 3) | (((kb >> 3) & 1) << 2), kh = (kb >> 2) & 1, t = kb >> 4;
+        const size_t vp = ((size_t)b * NF_CP + c) * Npad + (n & ~31) + 16 * t + 8 * kh + e;
+        Vthi[vp] = c == C ? (unsigned short)0x3c00 : hi;             // 1.0 (binary16)
+        Vtlo[vp] = c == C ? (unsigned short)0 : lo;
+    }
+}
+
+// SPLIT = true: the fp32 path (operands as hi + lo, 72 MFMAs per 64 keys).  SPLIT = false: the same kernel on the hi parts only
+// (24 MFMAs per 64 keys) - 16-bit operands, fp32 accumulation: the non-local block of precision=bf16, whose trunk is 16-bit
+// anyway (binary16 has 3 more mantissa bits than the bf16 of the trunk: logits good to ~2e-3, where bf16 logits are off by 16 %).
+template <int C, bool SPLIT>
+__global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Khi,
+                                                              const uint16_t* __restrict__ Klo, const uint16_t* __restrict__ Vthi,
+                                                              const uint16_t* __restrict__ Vtlo, float* __restrict__ Xo,
+                                                              const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                              float* __restrict__ Zp, float* __restrict__ ML, int N, int Npad, int q0, int q1) {
+    constexpr int CT = 3;
+    constexpr int CP = (C + 31) / 32 * 32;                          // row stride of X / Xo / Wp (nl_padded_ch)
+    static_assert(C < NF_CP && C % 2 == 0, "needs a pad channel inside 96");
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];   // three tiles: K hi | K lo | V^T hi | V^T lo
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int xl = lane & 31;
+    const int kh = lane >> 5;
+    const int b = blockIdx.y;
+    const float* Xb = X + (size_t)b * N * CP;
+    float* Xob = Xo + (size_t)b * N * CP;
+    const int q = q0 + blockIdx.x * NF_QB + wave * 32 + xl;         // this lane's query (queries [q0, q1): a strip of the frame)
+    const int qc = q < q1 ? q : q1 - 1;
+
+    // B operand of S^T = K Q^T: this lane's query, channels 16ks + 8kh .. +7, scaled by log2(e), split hi + lo
+    constexpr float LOG2E = 1.4426950408889634f;
+    bf16x8 qh[6];
+    [[maybe_unused]] bf16x8 ql[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 16 * ks + 8 * kh + e;
+            const float v = c < C ? Xb[(size_t)qc * CP + c] * (LOG2E * NF_XSCALE) : 0.f;
+            const _Float16 h = (_Float16)v;
+            qh[ks][e] = h;
+            if constexpr (SPLIT) ql[ks][e] = (_Float16)(v - (float)h);
+        }
+    constexpr int LCT = C / 32, LI = C % 32;                        // where the row-sum channel C lives in the D layout
+    constexpr int LKH = (LI % 8) >= 4 ? 1 : 0, LR = (LI / 8) * 4 + (LI % 8) % 4;
+
+    f32x16 o[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
+    float m = -INFINITY;
+
+    // staging: 4 x 768 16-byte pieces per 64-key tile, 6 per thread (8 slots: the second pass covers pieces 512..767)
+    const uint16_t* const Khb = Khi + (size_t)b * N * NF_CP;
+    const uint16_t* const Klb = Klo + (size_t)b * N * NF_CP;
+    const uint16_t* const Vhb = Vthi + (size_t)b * NF_CP * Npad;
+    const uint16_t* const Vlb = Vtlo + (size_t)b * NF_CP * Npad;
+    constexpr int NI = 2;
+    u32x4 rk[4 * NI];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int id = min(tid + i * NF_THREADS, 767);          // 0..767 (surplus threads redo the last piece)
+            const int key = id / 12, c16 = id - key * 12;
+            const bool ok = k0 + key < N;
+            const size_t ko = ((size_t)(k0 + (ok ? key : 0)) * NF_CP + c16 * 8);
+            rk[i] = ok ? *reinterpret_cast<const u32x4*>(Khb + ko) : u32x4{0, 0, 0, 0};
+            if constexpr (SPLIT) rk[NI + i] = ok ? *reinterpret_cast<const u32x4*>(Klb + ko) : u32x4{0, 0, 0, 0};
+            const int ch = id >> 3, kc = id & 7;                    // V^T: 96 rows x 8 pieces (k0 + 64 <= Npad + 32: rows are padded)
+            const bool vok = k0 + kc * 8 < Npad;
+            const size_t vo = (size_t)ch * Npad + k0 + (vok ? kc * 8 : 0);
+            rk[2 * NI + i] = vok ? *reinterpret_cast<const u32x4*>(Vhb + vo) : u32x4{0, 0, 0, 0};
+            if constexpr (SPLIT) rk[3 * NI + i] = vok ? *reinterpret_cast<const u32x4*>(Vlb + vo) : u32x4{0, 0, 0, 0};
+        }
+    };
+    auto store_tile = [&](unsigned char* buf) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int id = min(tid + i * NF_THREADS, 767);
+            const int key = id / 12, c16 = id - key * 12;
+            *reinterpret_cast<u32x4*>(buf + key * NF_KROW + c16 * 16) = rk[i];
+            if constexpr (SPLIT) *reinterpret_cast<u32x4*>(buf + NF_KT * NF_KROW + key * NF_KROW + c16 * 16) = rk[NI + i];
+            const int ch = id >> 3, kc = id & 7;
+            *reinterpret_cast<u32x4*>(buf + 2 * NF_KT * NF_KROW + ch * NF_VROW + kc * 16) = rk[2 * NI + i];
+            if constexpr (SPLIT) *reinterpret_cast<u32x4*>(buf + 2 * NF_KT * NF_KROW + NF_CP * NF_VROW + ch * NF_VROW + kc * 16) = rk[3 * NI + i];
+        }
+    };
+
+    const int ntiles = (N + NF_KT - 1) / NF_KT;
+    const int ksp = gridDim.z, sp = blockIdx.z;
+    const int kt0 = (int)((long long)ntiles * sp / ksp), kt1 = (int)((long long)ntiles * (sp + 1) / ksp);
+    load_tile(kt0 * NF_KT);
+    store_tile(sm);
+    if (kt0 + 1 < kt1) load_tile((kt0 + 1) * NF_KT);
+    __syncthreads();
+    // The two waves of a SIMD are half a tile apart: waves 0-3 run S^T, softmax, P V of tile t; waves 4-7 run P V of
+    // tile t-1 (its P^T kept in registers, its V^T in the third LDS buffer), then S^T and softmax of tile t.  Next to
+    // a wave that keeps the matrix pipe busy a partner's VALU gets one issue slot per MFMA (tools/ubench) - phase-aligned,
+    // the two waves' softmax blocks (150 VALU, 32 of them quarter-rate v_exp_f32) simply add to the MFMA time; skewed,
+    // and with the softmax at raised priority, one wave's VALU runs under the other's MFMAs.
+    const bool late = wave >= 4;
+    bf16x8 pt[2][2];                                                // P^T (hi, lo parts) of the tile whose P V is still to come
+    [[maybe_unused]] bf16x8 pl[2][2];
+    bf16x8 ob[2][6];                                                // operands one MFMA step ahead (the compiler alone issues each
+                                                                    // ds_read right in front of its MFMA: 60 LDS latencies per tile)
+#define NF_LOAD_QK(ks_, d_)                                                                                     \
+    do {                                                                                                        \
+        ob[d_][0] = *reinterpret_cast<const bf16x8*>(kah + (ks_) * 32);                                         \
+        ob[d_][1] = *reinterpret_cast<const bf16x8*>(kah + 32 * NF_KROW + (ks_) * 32);                          \
+        if constexpr (SPLIT) {                                                                                  \
+            ob[d_][2] = *reinterpret_cast<const bf16x8*>(kal + (ks_) * 32);                                     \
+            ob[d_][3] = *reinterpret_cast<const bf16x8*>(kal + 32 * NF_KROW + (ks_) * 32);                      \
+        }                                                                                                       \
+    } while (0)
+#define NF_LOAD_PV(vah_, val_, j_, d_)                                                                          \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_) {                                                  \
+            ob[d_][ct_] = *reinterpret_cast<const bf16x8*>((vah_) + ct_ * 32 * NF_VROW + ((j_) >> 1) * 64 + ((j_) & 1) * 32);     \
+            if constexpr (SPLIT) ob[d_][3 + ct_] = *reinterpret_cast<const bf16x8*>((val_) + ct_ * 32 * NF_VROW + ((j_) >> 1) * 64 + ((j_) & 1) * 32); \
+        }                                                                                                       \
+    } while (0)
+    // O^T[ch][query] += V^T[ch][keys] P^T[keys][query] for the tile in `buf`, keys in the accumulator's own order;
+    // channel tile innermost (consecutive MFMAs go to different accumulators)
+#define NF_PV(buf_)                                                                                             \
+    do {                                                                                                        \
+        const unsigned char* const vah_ = (buf_) + 2 * NF_KT * NF_KROW + xl * NF_VROW + kh * 16;                \
+        const unsigned char* const val_ = vah_ + NF_CP * NF_VROW;                                               \
+        NF_LOAD_PV(vah_, val_, 0, 0);                                                                           \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+            if (j_ < 3) NF_LOAD_PV(vah_, val_, j_ + 1, (j_ + 1) & 1);                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+            _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_)                                                \
+                o[ct_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[j_ & 1][ct_], pt[j_ >> 1][j_ & 1], o[ct_], 0, 0, 0);     \
+            if constexpr (SPLIT) {                                                                              \
+                _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_)                                            \
+                    o[ct_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[j_ & 1][3 + ct_], pt[j_ >> 1][j_ & 1], o[ct_], 0, 0, 0); \
+                _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_)                                            \
+                    o[ct_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[j_ & 1][ct_], pl[j_ >> 1][j_ & 1], o[ct_], 0, 0, 0);     \
+            }                                                                                                   \
+        }                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+    } while (0)
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int bi = (kt - kt0) % 3;
+        unsigned char* const cur = sm + bi * NF_TILE_BYTES;
+        unsigned char* const nxt = sm + (bi == 2 ? 0 : bi + 1) * NF_TILE_BYTES;   // held tile kt-2: read by nobody any more
+        const unsigned char* const prv = sm + (bi == 0 ? 2 : bi - 1) * NF_TILE_BYTES;
+        if (late && kt > kt0) NF_PV(prv);
+        // S^T for both 32-key halves of the tile (two independent accumulators, alternating: no MFMA waits for its
+        // predecessor), then ONE running-max / rescale update for the 64 keys
+        const int kbase = kt * NF_KT;
+        f32x16 st[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
+        const unsigned char* const kah = cur + xl * NF_KROW + kh * 16;
+        const unsigned char* const kal = kah + NF_KT * NF_KROW;
+        NF_LOAD_QK(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks < 5) NF_LOAD_QK(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int d = ks & 1;
+            st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][0], qh[ks], st[0], 0, 0, 0);
+            st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][1], qh[ks], st[1], 0, 0, 0);
+            if constexpr (SPLIT) {
+                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][0], ql[ks], st[0], 0, 0, 0);
+                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][1], ql[ks], st[1], 0, 0, 0);
+                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][2], qh[ks], st[0], 0, 0, 0);
+                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ob[d][3], qh[ks], st[1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(2);                              // the softmax VALU goes ahead of the partner wave's MFMAs
+        if (kbase + NF_KT > N) {                                    // wave-uniform: only the last, partial key tile
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + sub * 32 + drow(r, lane) >= N) st[sub][r] = -INFINITY;
+        }
+        float tmax = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[1][0], st[1][1]));
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) tmax = fmaxf(tmax, fmaxf(fmaxf(st[0][r], st[0][r + 1]), fmaxf(st[1][r], st[1][r + 1])));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * NF_SINV;            // true base-2 logit (the scale is positive: max commutes)
+        const float mn = fmaxf(m, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);         // m = -inf on the first tile -> 0
+#ifdef NF_X_NOSOFTMAX   /* timing experiment only: wrong results */
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; r += 8) pl[sub][r >> 3] = pt[sub][r >> 3] = __builtin_bit_cast(bf16x8, u32x4{__builtin_bit_cast(unsigned, st[sub][r]), __builtin_bit_cast(unsigned, st[sub][r + 1]), __builtin_bit_cast(unsigned, st[sub][r + 2]), __builtin_bit_cast(unsigned, st[sub][r + 3])});
+#else
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[sub][r], NF_SINV, NF_PSHIFT - mn));   // 2^14 exp2(s - max)
+                const _Float16 ph = (_Float16)pv;
+                pt[sub][r >> 3][r & 7] = ph;
+                if constexpr (SPLIT) pl[sub][r >> 3][r & 7] = (_Float16)(pv - (float)ph);
+            }
+#endif
+        m = mn;
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!late) NF_PV(cur);
+        if (kt + 1 < kt1) {                                         // next tile (requested a tile ago) -> the third buffer; the tile
+            store_tile(nxt);                                        // after it requested
+            if (kt + 2 < kt1) load_tile((kt + 2) * NF_KT);
+        }
+        __syncthreads();                                            // this tile's S^T operands are free, the next tile is complete
+    }
+    if (late) NF_PV(sm + ((kt1 - 1 - kt0) % 3) * NF_TILE_BYTES);    // the late waves' last P V
+#undef NF_PV
+#undef NF_LOAD_PV
+#undef NF_LOAD_QK
+
+    float l = o[LCT][LR];
+    {
+        const float lo = __shfl_xor(l, 32);
+        if (kh != LKH) l = lo;
+    }
+    const float inv = (ksp == 1) ? (1.0f / NF_XSCALE) / l : (1.0f / NF_XSCALE);   // V carries 2^7; l and O share the 2^14 of P
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] *= inv;
+
+    // Z^T = W'^T O^T on the f32 matrix pipe, as in nonlocal.hip (pad rows of W' are zero: the row-sum channel drops out)
+    constexpr int CTW = CP / 32;
+#pragma unroll
+    for (int cot = 0; cot < CTW; ++cot) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) {
+            const float* wa = Wp + (size_t)(ct * 32 + 4 * kh) * CP + cot * 32 + xl;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) z = mfma32(wa[((s & 3) + 8 * (s >> 2)) * CP], o[ct][s], z);
+        }
+        if (q < q1) {
+            if (ksp == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cot * 32 + drow(r, lane);
+                    if (co < C) {
+                        const size_t idx = (size_t)q * CP + co;
+                        Xob[idx] = Xb[idx] + z[r] + bp[co];            // residual, model/pfnl.py:60
+                    }
+                }
+            } else {
+                float* zp = Zp + (((size_t)b * ksp + sp) * N + q) * CP;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zp[cot * 32 + drow(r, lane)] = z[r];
+            }
+        }
+    }
+    if (ksp > 1 && q < q1 && kh == 0) {
+        float* ml = ML + (((size_t)b * ksp + sp) * N + q) * 2;
+        ml[0] = m;
+        ml[1] = l;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same arithmetic with the two halves of the workgroup in ANTI-PHASE (nl_attn_f16_pp_kernel, the default;
+// PFNL_NL_PP=0 selects the kernel above).  Counted on the kernel above at 1080p (bf16 precision: 3.8 k cycles per 64-key tile and SIMD
+// for 1.5 k of MFMA and 2 x 1.0 k of softmax VALU): its half-tile skew makes three phases per tile - [S^T | P V], [softmax | S^T],
+// [P V | softmax] - plus the staging of the next tile through registers, i.e. both softmax blocks AND an MFMA-beside-MFMA phase are on
+// the critical path.  Here a tile is two phases per wave,
+//     Y(t): S^T of tile t and P V of tile t-1 (matrix pipe)          X(t): the softmax of tile t (VALU, raised priority)
+// and waves 4-7 run one phase behind waves 0-3 (one wave of each half per SIMD), so that a SIMD always has one wave in Y and one in X:
+// 2 x max(X, Y) per tile instead of X + X + Y/2 + staging.  Two workgroup barriers per tile, the same count for every wave.
+// The K / V^T tiles travel by LDS-DMA (`buffer_load_dwordx4 ... lds`; the four packed arrays are one allocation = one buffer resource,
+// the padded LDS rows are produced by per-lane source offsets, keys past N and the pad chunks by an out-of-range offset = zeros): no
+// staging registers, no ds_write, and the requests ride on the S^T steps of the MFMA phase.  Ring of NSLOT tiles (3 with split
+// operands - LDS is full - and 5 of 32 KB on the hi parts only): at the start of Y(t) the slot of tile t-2 is free (the late half read
+// it in ITS Y(t-1), one phase ago) and takes tile t + NSLOT - 2; a wave waits for its own pieces of tile t + 1 at the end of the phase
+// that precedes the early half's Y(t+1) - `s_waitcnt vmcnt((NSLOT - 3) x pieces per wave)`: the counter retires in issue order and
+// every wave issues the same number of pieces per tile (past the last tile: against an empty resource), so that count is exact.
+template <bool SPLIT>
+struct NfPP {
+    static constexpr int KLO_OFF = NF_KT * NF_KROW;                                    // 13 312 (split only)
+    static constexpr int VHI_OFF = SPLIT ? 2 * NF_KT * NF_KROW : NF_KT * NF_KROW;      // 26 624 | 13 312
+    static constexpr int VLO_OFF = VHI_OFF + NF_CP * NF_VROW;                          // + 13 824 (split only)
+    static constexpr int TILE_BYTES = SPLIT ? VLO_OFF + NF_CP * NF_VROW : VLO_OFF;     // 54 272 | 27 136
+    static constexpr int NSLOT = SPLIT ? 3 : 5;
+    static constexpr int PIECES = SPLIT ? 53 : 32;                                     // 1 KB DMA instructions per tile (hi only: 27 carry data)
+    static constexpr int SLOT_BYTES = PIECES * 1024;                                   // 54 272 | 32 768
+    static constexpr int PW = (PIECES + 7) / 8;                                        // per wave: 7 (waves 5-7: 6) | 4
+    static constexpr int LDS_BYTES = NSLOT * SLOT_BYTES;                               // 162 816 | 163 840
+    static_assert(TILE_BYTES <= SLOT_BYTES && LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(SPLIT || PIECES % 8 == 0, "the vmcnt wait of the hi-only ring counts on equal shares");
+};
+
+__device__ __forceinline__ void nf_dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds_dst, int voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rs) : "memory");
+}
+// scheduling hints for the software-pipelined body: per MFMA one LDS read and NP_VPM VALU (sched_group_barrier masks: 0x8 MFMA, 0x100 DS
+// read, 0x2 VALU)
+#ifndef NP_VPM
+#define NP_VPM (SPLIT ? 4 : 9)
+#endif
+#ifndef NP_SCHED_A
+#define NP_SCHED_A()                                                                        \
+    do {                                                                                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < (SPLIT ? 36 : 12); ++i_) {                  \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                              \
+            __builtin_amdgcn_sched_group_barrier(0x002, NP_VPM, 0);                         \
+        }                                                                                   \
+    } while (0)
+#define NP_SCHED_B() NP_SCHED_A()
+#endif
+#ifndef NP_PRIO_X
+#define NP_PRIO_X 2
+#endif
+#ifndef NP_PRIO_Y
+#define NP_PRIO_Y 0
+#endif
+#define NF_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifdef PFNL_NP_TIMING   /* phase timeline (tools/np_timing.py); not part of the product build */
+__device__ long long np_dbg[256 * 2 * 128];
+#define NP_STAMP() do { if (SPLIT == (PFNL_NP_TIMING != 0) && lane == 0 && (wave == 0 || wave == 4) && dbg_n < 128 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 256) np_dbg[(blockIdx.x * 2 + (wave != 0)) * 128 + dbg_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define NP_STAMP() do {} while (0)
+#endif
+
+// K16 = Khi (the lowest address of the scratch); rel_* = byte offsets of Klo, Vthi, Vtlo from it; scratch_bytes = the whole allocation
+template <int C, bool SPLIT>
+__global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_pp_kernel(const float* __restrict__ X, const uint16_t* __restrict__ K16,
+                                                                 unsigned rel_klo, unsigned rel_vhi, unsigned rel_vlo, unsigned scratch_bytes,
+                                                                 float* __restrict__ Xo, const float* __restrict__ Wp,
+                                                                 const float* __restrict__ bp, float* __restrict__ Zp,
+                                                                 float* __restrict__ ML, int N, int Npad, int q0, int q1) {
+    using G = NfPP<SPLIT>;
+    constexpr int CT = 3;
+    constexpr int CP = (C + 31) / 32 * 32;                          // row stride of X / Xo / Wp (nl_padded_ch)
+    static_assert(C < NF_CP && C % 2 == 0, "needs a pad channel inside 96");
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];   // NSLOT tiles: K hi | (K lo) | V^T hi | (V^T lo)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef PFNL_NP_TIMING
+    int dbg_n = 0;
+#endif
+    const int xl = lane & 31;
+    const int kh = lane >> 5;
+    const int b = blockIdx.y;
+    const float* Xb = X + (size_t)b * N * CP;
+    float* Xob = Xo + (size_t)b * N * CP;
+    const int q = q0 + blockIdx.x * NF_QB + (tid >> 6) * 32 + xl;   // this lane's query (queries [q0, q1): a strip of the frame)
+    const int qc = q < q1 ? q : q1 - 1;
+
+    // B operand of S^T = K Q^T: this lane's query, channels 16ks + 8kh .. +7, scaled by log2(e), split hi + lo
+    constexpr float LOG2E = 1.4426950408889634f;
+    bf16x8 qh[6];
+    [[maybe_unused]] bf16x8 ql[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 16 * ks + 8 * kh + e;
+            const float v = c < C ? Xb[(size_t)qc * CP + c] * (LOG2E * NF_XSCALE) : 0.f;
+            const _Float16 h = (_Float16)v;
+            qh[ks][e] = h;
+            if constexpr (SPLIT) ql[ks][e] = (_Float16)(v - (float)h);
+        }
+    constexpr int LCT = C / 32, LI = C % 32;                        // where the row-sum channel C lives in the D layout
+    constexpr int LKH = (LI % 8) >= 4 ? 1 : 0, LR = (LI / 8) * 4 + (LI % 8) % 4;
+
+    f32x16 o[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
+    float m = -INFINITY;
+
+    // DMA map: piece i = wave + 8k writes slot bytes [1024 i, + 1024), lane L the 16 bytes at p = 1024 i + 16 L.  `srel` = byte offset of
+    // that chunk's source from K16 for key tile 0 (0x7fffffff: a pad chunk - stays out of range), `rowk` = its key row for the K arrays
+    // (the range test against N), very negative for V^T (always inside: the rows are padded by a tile).  Per tile: + k0 x (192 | 2).
+    int srel[G::PW], rowk[G::PW];
+#pragma unroll
+    for (int k = 0; k < G::PW; ++k) {
+        const int p = (wave + 8 * k) * 1024 + 16 * lane;
+        int sr = 0x7fffffff, rk = 1 << 20;
+        if (p < NF_KT * NF_KROW || (SPLIT && p < 2 * NF_KT * NF_KROW)) {
+            const bool lo = p >= NF_KT * NF_KROW;
+            const int r = p - (lo ? NF_KT * NF_KROW : 0);
+            const int row = r / NF_KROW, col = r - row * NF_KROW;
+            if (col < NF_CP * 2) {
+                sr = (int)((lo ? rel_klo : 0u) + (unsigned)(((size_t)b * N + row) * (NF_CP * 2)) + col);
+                rk = row;
+            }
+        } else if (p < G::TILE_BYTES) {
+            const bool lo = SPLIT && p >= G::VLO_OFF;
+            const int r = p - (lo ? G::VLO_OFF : G::VHI_OFF);
+            const int ch = r / NF_VROW, col = r - ch * NF_VROW;
+            if (col < NF_KT * 2) {
+                sr = (int)((lo ? rel_vlo : rel_vhi) + (unsigned)(((size_t)b * NF_CP + ch) * Npad * 2) + col);
+                rk = -(1 << 20);
+            }
+        }
+        srel[k] = sr;
+        rowk[k] = rk;
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)sm;
+    // piece k of this wave for key tile `kt` -> ring slot `slot`; `live` false (past the last tile): an empty resource, nothing moves
+    auto tile_piece = [&](int k, int kt, int slot, bool live) __attribute__((always_inline)) {
+        const int i = wave + 8 * k;
+        if (G::PIECES % 8 == 0 || 8 * k + 7 < G::PIECES || i < G::PIECES) {   // (wave-uniform; split: waves 5-7 have no seventh piece)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(K16), 0, live ? scratch_bytes : 0, 0x00020000);
+            const int k0 = kt * NF_KT;
+            const bool isk = i * 1024 < (SPLIT ? 2 : 1) * NF_KT * NF_KROW;   // (the K | V^T boundary is a multiple of 1024)
+            const int off = rowk[k] < N - k0 ? srel[k] + k0 * (isk ? NF_CP * 2 : 2) : 0x7fffffff;
+            nf_dma16(rs, lds0 + slot * G::SLOT_BYTES + i * 1024, off);
+        }
+    };
+
+    const int ntiles = (N + NF_KT - 1) / NF_KT;
+    const int ksp = gridDim.z, sp = blockIdx.z;
+    const int kt0 = (int)((long long)ntiles * sp / ksp), kt1 = (int)((long long)ntiles * (sp + 1) / ksp);
+    // prologue: tiles kt0 .. kt0 + NSLOT - 2 -> slots 0 ..; an all-zero tile -> slot NSLOT - 1, the "tile kt0 - 1" of the first P V
+    // (whose P^T is zero: no branch around it, but 0 x whatever the LDS held could be NaN)
+#pragma unroll
+    for (int j = 0; j < G::NSLOT - 1; ++j)
+#pragma unroll
+        for (int k = 0; k < G::PW; ++k) tile_piece(k, kt0 + j, j, kt0 + j < kt1);
+#pragma unroll
+    for (int k = 0; k < G::PW; ++k) tile_piece(k, 0, G::NSLOT - 1, false);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    bf16x8 pt[2][2];                                                // P^T of the two 32-key halves of a tile (hi, lo parts)
+    [[maybe_unused]] bf16x8 pl[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pt[i][j][e] = (_Float16)0.f;
+                if constexpr (SPLIT) pl[i][j][e] = (_Float16)0.f;
+            }
+#ifdef NP_X_NOMFMA      /* timing experiment only: wrong results */
+#define NP_MFMA(a_, b_, c_) ((c_) + (float)(a_)[0] * (float)(b_)[0])
+#else
+#define NP_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, 0, 0, 0)
+#endif
+    f32x16 st[2];                                                   // S^T of the 32-key half in flight and of the one being exponentiated
+    // The loop is software-pipelined over 32-key halves h = 2t, 2t + 1.  One HALF-BODY issues, from ONE wave and in one pinned order,
+    //     the MFMAs of S^T(h + 1) and P V(h - 1)   |   their operand reads, AHEAD reads in front   |   the VALU of softmax(h)
+    // - what a wave issues between two of its OWN MFMAs rides in their shadow (MI355X_MICROARCH.md: ~5 issue slots per 32-cycle
+    // MFMA), while VALU of the partner wave on the SIMD does not (tools/ubench/valu_under_mfma: one slot per MFMA; measured here on a
+    // two-phase variant with the halves of the workgroup in anti-phase, tools/experiments/nonlocal_f16_pp.hip: S^T + P V and the softmax
+    // simply added up, 4.1 k cycles per 64-key tile whichever wave had the priority).  The compiler's own schedule of the same three
+    // streams clumps (12 reads with a wait after each, the max reduction as a block between branches): every step is pinned with
+    // sched_barrier(0) in source order.
+    // MFMA i of a half-body: i < NQ: S^T k-step i (split: k-step i/3, products hh, hl, lh); then P V: (key step jj, channel tile ct)
+    // (split: x (Vh Ph, Vh Pl, Vl Ph) - consecutive MFMAs on one accumulator run at full rate: tools/ubench/mfma_bf16_rate).  Its A
+    // operand is read q(i) of the half-body's read sequence: i (hi only) | 2 (i / 3) + (i % 3 == 2) (split: hi row, lo row per step).
+    constexpr int NQ = SPLIT ? 18 : 6, NR = SPLIT ? 24 : 12;
+    // The exponentials are only used one half-body later, behind a barrier - and LLVM sinks a pure computation to its use: without an
+    // opaque use where they are written, the whole softmax of half h reappears in front of the first P V MFMA of half h + 1 (seen in the
+    // ISA; it is why every variant of this loop measured the SUM of its matrix and VALU time)
+#define NP_PIN(v_) asm volatile("" : "+v"(v_))
+    constexpr int AHEAD = 4;                                        // reads in flight in front of the one in use
+    constexpr int RING = AHEAD + 2;
+    bf16x8 rb[RING];
+    auto half_body = [&](auto hc, auto maskc, const unsigned char* qbuf, const unsigned char* vbuf, int kb, int kt_fill, int s_fill) __attribute__((always_inline)) {
+        constexpr int H = decltype(hc)::value;                      // 0: half a of a tile (softmax of its keys 0..31), 1: half b
+        f32x16& stc = st[H];
+        f32x16& stn = st[H ^ 1];
+        // S^T(h + 1): key rows 32 (1 - H) .. of `qbuf`;  P V(h - 1): V^T keys 32 (1 - H) .. of `vbuf`, P^T = pt[1 - H]
+        const unsigned char* const kah = qbuf + ((1 - H) * 32 + xl) * NF_KROW + kh * 16;
+        const unsigned char* const vah = vbuf + G::VHI_OFF + xl * NF_VROW + kh * 16 + (1 - H) * 64;
+        auto read = [&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;
+            if constexpr (q < NR) {
+                constexpr int d = q % RING;
+                if constexpr (!SPLIT) {
+                    if constexpr (q < 6) rb[d] = *reinterpret_cast<const bf16x8*>(kah + q * 32);
+                    else rb[d] = *reinterpret_cast<const bf16x8*>(vah + ((q - 6) % 3) * 32 * NF_VROW + ((q - 6) / 3) * 32);
+                } else {
+                    if constexpr (q < 12) rb[d] = *reinterpret_cast<const bf16x8*>(kah + (q & 1) * G::KLO_OFF + (q >> 1) * 32);
+                    else {
+                        constexpr int u = (q - 12) >> 1, lo = (q - 12) & 1;   // u = 3 jj + ct
+                        rb[d] = *reinterpret_cast<const bf16x8*>(vah + lo * (G::VLO_OFF - G::VHI_OFF) + (u % 3) * 32 * NF_VROW + (u / 3) * 32);
+                    }
+                }
+            }
+        };
+        auto mfma = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int q = SPLIT ? 2 * (i / 3) + (i % 3 == 2) : i;
+            const bf16x8 a = rb[q % RING];
+            if constexpr (i < NQ) {
+                constexpr int ks = SPLIT ? i / 3 : i;
+                bf16x8 bq = qh[ks];
+                if constexpr (SPLIT) {
+                    if constexpr (i % 3 == 1) bq = ql[ks];
+                }
+                if constexpr (i == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    stn = NP_MFMA(a, bq, z);
+                } else {
+                    stn = NP_MFMA(a, bq, stn);
+                }
+            } else {
+                constexpr int j = i - NQ;
+                constexpr int u = SPLIT ? j / 3 : j;                // 3 jj + ct
+                constexpr int jj = u / 3, ct = u % 3;
+                bf16x8 bp = pt[1 - H][jj];
+                if constexpr (SPLIT) {
+                    if constexpr (j % 3 == 1) bp = pl[1 - H][jj];
+                }
+                o[ct] = NP_MFMA(a, bp, o[ct]);
+            }
+        };
+        // ---- reads in flight, then the part of the softmax that everything else waits for: the running max of the 32 keys
+#pragma unroll
+        for (int q0_ = 0; q0_ <= AHEAD; ++q0_) {
+            if (q0_ == 0) read(std::integral_constant<int, 0>{});
+            if (q0_ == 1) read(std::integral_constant<int, 1>{});
+            if (q0_ == 2) read(std::integral_constant<int, 2>{});
+            if (q0_ == 3) read(std::integral_constant<int, 3>{});
+            if (q0_ == 4) read(std::integral_constant<int, 4>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (decltype(maskc)::value) {                     // (only the body of the last, partial tile is compiled with the mask)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kb + drow(r, lane) >= N) stc[r] = -INFINITY;
+        }
+        float tmax = fmaxf(fmaxf(stc[0], stc[1]), fmaxf(stc[2], stc[3]));
+#pragma unroll
+        for (int r = 4; r < 16; r += 4) tmax = fmaxf(tmax, fmaxf(fmaxf(stc[r], stc[r + 1]), fmaxf(stc[r + 2], stc[r + 3])));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * NF_SINV;            // true base-2 logit (the scale is positive: max commutes)
+        const float mn = fmaxf(m, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);         // m = -inf on the first half -> 0
+        float shift = NF_PSHIFT - mn;
+        m = mn;
+        asm volatile("" : "+v"(shift));                             // (computed HERE: see NP_PIN)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- the MFMAs, one gap each: the read AHEAD in front, a slice of the exponentials (a pair of keys: 2 fma, 2 exp, the packed
+        // conversion; split: the lo parts in the following gap), in b a request of the next tile now and then
+        [[maybe_unused]] float pv0 = 0.f, pv1 = 0.f;
+        auto gap = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            mfma(ic);
+            __builtin_amdgcn_sched_barrier(0);
+            {   // the first MFMA that takes read q sends read q + AHEAD on its way (reads 0 .. AHEAD went out in front of the max)
+                constexpr int qn = (SPLIT ? 2 * (i / 3) + (i % 3 == 2) : i) + AHEAD + 1;
+                constexpr int qp = i == 0 ? AHEAD + 1 : (SPLIT ? 2 * ((i - 1) / 3) + ((i - 1) % 3 == 2) : i - 1) + AHEAD + 1;
+                if constexpr (qn > qp) read(std::integral_constant<int, qn - 1 < NR ? (qn - 1 >= qp ? qn - 1 : NR) : NR>{});
+            }
+            if constexpr (!SPLIT) {
+                if constexpr (i % 3 != 2 && (i / 3) * 2 + i % 3 < 8) {
+                    constexpr int r = 2 * ((i / 3) * 2 + i % 3);
+                    const float a0 = __builtin_amdgcn_exp2f(__builtin_fmaf(stc[r], NF_SINV, shift));       // 2^14 exp2(s - max)
+                    const float a1 = __builtin_amdgcn_exp2f(__builtin_fmaf(stc[r + 1], NF_SINV, shift));
+                    pt[H][r >> 3][r & 7] = (_Float16)a0;
+                    pt[H][r >> 3][(r & 7) + 1] = (_Float16)a1;
+                    NP_PIN(pt[H][r >> 3]);
+                }
+            } else {
+                if constexpr (i % 2 == 0 && i < 32) {
+                    constexpr int r = 2 * (i / 4);
+                    if constexpr ((i / 2) % 2 == 0) {
+                        pv0 = __builtin_amdgcn_exp2f(__builtin_fmaf(stc[r], NF_SINV, shift));
+                        pv1 = __builtin_amdgcn_exp2f(__builtin_fmaf(stc[r + 1], NF_SINV, shift));
+                        asm volatile("" : "+v"(pv0), "+v"(pv1));
+                    } else {
+                        const _Float16 h0 = (_Float16)pv0, h1 = (_Float16)pv1;
+                        pt[H][r >> 3][r & 7] = h0;
+                        pt[H][r >> 3][(r & 7) + 1] = h1;
+                        pl[H][r >> 3][r & 7] = (_Float16)(pv0 - (float)h0);
+                        pl[H][r >> 3][(r & 7) + 1] = (_Float16)(pv1 - (float)h1);
+                        NP_PIN(pt[H][r >> 3]);
+                        NP_PIN(pl[H][r >> 3]);
+                    }
+                }
+            }
+            if constexpr (H == 1) {
+                constexpr int step = SPLIT ? 5 : 3;
+                if constexpr (i % step == 2 && i / step < G::PW) tile_piece(i / step, kt_fill, s_fill, kt_fill < kt1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        gap(std::integral_constant<int, 0>{});
+        gap(std::integral_constant<int, 1>{});
+        gap(std::integral_constant<int, 2>{});
+        gap(std::integral_constant<int, 3>{});
+        gap(std::integral_constant<int, 4>{});
+        gap(std::integral_constant<int, 5>{});
+        gap(std::integral_constant<int, 6>{});
+        gap(std::integral_constant<int, 7>{});
+        gap(std::integral_constant<int, 8>{});
+        gap(std::integral_constant<int, 9>{});
+        gap(std::integral_constant<int, 10>{});
+        gap(std::integral_constant<int, 11>{});
+        if constexpr (SPLIT) {
+            gap(std::integral_constant<int, 12>{});
+            gap(std::integral_constant<int, 13>{});
+            gap(std::integral_constant<int, 14>{});
+            gap(std::integral_constant<int, 15>{});
+            gap(std::integral_constant<int, 16>{});
+            gap(std::integral_constant<int, 17>{});
+            gap(std::integral_constant<int, 18>{});
+            gap(std::integral_constant<int, 19>{});
+            gap(std::integral_constant<int, 20>{});
+            gap(std::integral_constant<int, 21>{});
+            gap(std::integral_constant<int, 22>{});
+            gap(std::integral_constant<int, 23>{});
+            gap(std::integral_constant<int, 24>{});
+            gap(std::integral_constant<int, 25>{});
+            gap(std::integral_constant<int, 26>{});
+            gap(std::integral_constant<int, 27>{});
+            gap(std::integral_constant<int, 28>{});
+            gap(std::integral_constant<int, 29>{});
+            gap(std::integral_constant<int, 30>{});
+            gap(std::integral_constant<int, 31>{});
+            gap(std::integral_constant<int, 32>{});
+            gap(std::integral_constant<int, 33>{});
+            gap(std::integral_constant<int, 34>{});
+            gap(std::integral_constant<int, 35>{});
+        }
+        // ---- the output accumulators follow the new maximum before the next P V (rare once the maximum has settled)
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+        }
+    };
+
+    int s_cur = 0, s_prv = G::NSLOT - 1, s_nxt = 1;                 // ring slots of tiles t, t - 1, t + 1
+    {   // S^T of the first half (plain: nothing to overlap with yet)
+        const unsigned char* const kah = sm + xl * NF_KROW + kh * 16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[0][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(kah + ks * 32);
+            st[0] = NP_MFMA(ah, qh[ks], st[0]);
+            if constexpr (SPLIT) {
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(kah + G::KLO_OFF + ks * 32);
+                st[0] = NP_MFMA(ah, ql[ks], st[0]);
+                st[0] = NP_MFMA(al, qh[ks], st[0]);
+            }
+        }
+    }
+    for (int kt = kt0; kt < kt1; ++kt) {
+        NP_STAMP();                                                 // 0
+        const unsigned char* const cur = sm + s_cur * G::SLOT_BYTES;
+        const unsigned char* const prv = sm + s_prv * G::SLOT_BYTES;
+        const unsigned char* const nxt = sm + s_nxt * G::SLOT_BYTES;
+        const int kbase = kt * NF_KT;
+        // (the key mask of the last, partial tile lives in a second copy of the body: a branch inside would cut the pinned sequence)
+        auto body = [&](auto maskc) __attribute__((always_inline)) {
+            // ---- a: softmax(2t) | S^T(2t + 1) | P V(2t - 1)
+            half_body(std::integral_constant<int, 0>{}, maskc, cur, prv, kbase, 0, 0);
+            NP_STAMP();                                             // 1
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G::NSLOT - 3) * G::PW) : "memory");   // this wave's pieces of tile t + 1 have landed
+            NF_BARRIER();                                           // tile t + 1 is complete; nobody reads tile t - 1 any more
+            NP_STAMP();                                             // 2
+            // ---- b: softmax(2t + 1) | S^T(2t + 2) | P V(2t); the pieces of tile t + NSLOT - 1 -> the slot of tile t - 1
+            // (S^T past the last tile: an all-zero tile, the result is not used)
+            half_body(std::integral_constant<int, 1>{}, maskc, nxt, cur, kbase + 32, kt + G::NSLOT - 1, s_prv);
+        };
+        if (kbase + NF_KT > N) body(std::true_type{});              // (wave-uniform)
+        else body(std::false_type{});
+        NP_STAMP();                                                 // 3
+        s_prv = s_cur;
+        s_cur = s_nxt;
+        s_nxt = s_nxt + 1 == G::NSLOT ? 0 : s_nxt + 1;
+    }
+    {   // the last half's P V
+        const unsigned char* const vah = sm + s_prv * G::SLOT_BYTES + G::VHI_OFF + xl * NF_VROW + kh * 16 + 64;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const bf16x8 vh = *reinterpret_cast<const bf16x8*>(vah + ct * 32 * NF_VROW + jj * 32);
+                o[ct] = NP_MFMA(vh, pt[1][jj], o[ct]);
+                if constexpr (SPLIT) {
+                    const bf16x8 vl = *reinterpret_cast<const bf16x8*>(vah + (G::VLO_OFF - G::VHI_OFF) + ct * 32 * NF_VROW + jj * 32);
+                    o[ct] = NP_MFMA(vh, pl[1][jj], o[ct]);
+                    o[ct] = NP_MFMA(vl, pt[1][jj], o[ct]);
+                }
+            }
+    }
+
+    float l = o[LCT][LR];
+    {
+        const float lo = __shfl_xor(l, 32);
+        if (kh != LKH) l = lo;
+    }
+    const float inv = (ksp == 1) ? (1.0f / NF_XSCALE) / l : (1.0f / NF_XSCALE);   // V carries 2^7; l and O share the 2^14 of P
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] *= inv;
+
+    // Z^T = W'^T O^T on the f32 matrix pipe, as in nonlocal.hip (pad rows of W' are zero: the row-sum channel drops out)
+    constexpr int CTW = CP / 32;
+#pragma unroll
+    for (int cot = 0; cot < CTW; ++cot) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) {
+            const float* wa = Wp + (size_t)(ct * 32 + 4 * kh) * CP + cot * 32 + xl;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) z = mfma32(wa[((s & 3) + 8 * (s >> 2)) * CP], o[ct][s], z);
+        }
+        if (q < q1) {
+            if (ksp == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cot * 32 + drow(r, lane);
+                    if (co < C) {
+                        const size_t idx = (size_t)q * CP + co;
+                        Xob[idx] = Xb[idx] + z[r] + bp[co];            // residual, model/pfnl.py:60
+                    }
+                }
+            } else {
+                float* zp = Zp + (((size_t)b * ksp + sp) * N + q) * CP;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zp[cot * 32 + drow(r, lane)] = z[r];
+            }
+        }
+    }
+    if (ksp > 1 && q < q1 && kh == 0) {
+        float* ml = ML + (((size_t)b * ksp + sp) * N + q) * 2;
+        ml[0] = m;
+        ml[1] = l;
+    }
+}
+
+size_t nl_f16_scratch_halfs(int B, int N) {                        // Khi, Klo, Vthi, Vtlo
+    const size_t npad = (size_t)(N + 31) / 32 * 32 + 64;            // + one tile of slack for the last tile's V^T pieces
+    return 2 * (size_t)B * N * NF_CP + 2 * (size_t)B * NF_CP * npad;
+}
+
+// X, Xo as in launch_nl_attn; scratch16: nl_f16_scratch_halfs(B, N) 16-bit elements; partial: nl_partial_floats
+hipError_t launch_nl_attn_f16(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, uint16_t* scratch16,
+                               int B, int N, int C, hipStream_t s, int q0, int q1, bool split) {
+    if (C != 84 && C != 60 && C != 36) return hipErrorInvalidValue;
+    if (q1 < 0) q1 = N;
+    if (q0 < 0 || q0 >= q1 || q1 > N) return hipErrorInvalidValue;
+    const int CP = nl_padded_ch(C);
+    const int npad = (N + 31) / 32 * 32 + 64;
+    uint16_t* Khi = scratch16;
+    uint16_t* Klo = Khi + (size_t)B * N * NF_CP;
+    uint16_t* Vthi = Klo + (size_t)B * N * NF_CP;
+    uint16_t* Vtlo = Vthi + (size_t)B * NF_CP * npad;
+    {
+        const size_t total = (size_t)B * npad * NF_CP;
+        const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        hipLaunchKernelGGL(nl_pack_f16_kernel, dim3(blocks), dim3(256), 0, s, X, Khi, Klo, Vthi, Vtlo, B, N, npad, C, CP);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    // key splits: this kernel runs 1 workgroup per CU (LDS), so the grid should fill a whole number of 256-workgroup
+    // rounds: time ~ ceil(query blocks * B * ks / 256) / ks.  (1080p: 127 blocks -> ks = 2 is one full round.)  Bounded
+    // by the fp32 kernel's choice, which sized the partial-result buffer.
+    const int ks_max = nl_key_splits(B, N);
+    int ks = 1;
+    {
+        const long long qb = (long long)((q1 - q0 + NF_QB - 1) / NF_QB) * B;
+        double best = 1e30;
+        for (int k = 1; k <= ks_max; ++k) {
+            const double t = (double)((qb * k + 255) / 256) / k;
+            if (t < best - 1e-9) {
+                best = t;
+                ks = k;
+            }
+        }
+    }
+    if (ks > 1 && !partial) return hipErrorInvalidValue;
+    float* Zp = partial;
+    float* ML = partial ? partial + (size_t)B * ks * N * CP : nullptr;
+    dim3 grid((q1 - q0 + NF_QB - 1) / NF_QB, B, ks);
+    dim3 block(NF_THREADS);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    // the anti-phase kernel (round 4) addresses the four packed arrays as ONE buffer resource with 32-bit offsets and an out-of-range
+    // sentinel of 2^31 - 1: a scratch of 2 GB or more (> 5.5 M keys in the batch) stays on the first kernel.  PFNL_NL_PP=0: always.
+    static const bool pp_on = [] {
+        const char* e = std::getenv("PFNL_NL_PP");
+        return !(e && e[0] == '0');
+    }();
+    const size_t scratch_bytes = 2 * nl_f16_scratch_halfs(B, N);
+    if (pp_on && scratch_bytes < 0x7fff0000ull) {
+        static std::atomic<int> attr_pp[64];
+        if (!attr_pp[dev]) {
+            for (const void* fn : {reinterpret_cast<const void*>(nl_attn_f16_pp_kernel<84, true>), reinterpret_cast<const void*>(nl_attn_f16_pp_kernel<60, true>),
+                                   reinterpret_cast<const void*>(nl_attn_f16_pp_kernel<36, true>)}) {
+                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NfPP<true>::LDS_BYTES);
+                if (e != hipSuccess) return e;
+            }
+            for (const void* fn : {reinterpret_cast<const void*>(nl_attn_f16_pp_kernel<84, false>), reinterpret_cast<const void*>(nl_attn_f16_pp_kernel<60, false>),
+                                   reinterpret_cast<const void*>(nl_attn_f16_pp_kernel<36, false>)}) {
+                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NfPP<false>::LDS_BYTES);
+                if (e != hipSuccess) return e;
+            }
+            attr_pp[dev] = 1;
+        }
+        const unsigned rel_klo = (unsigned)((Klo - Khi) * 2), rel_vhi = (unsigned)((Vthi - Khi) * 2), rel_vlo = (unsigned)((Vtlo - Khi) * 2);
+#define NP_LAUNCH(C_, S_) hipLaunchKernelGGL((nl_attn_f16_pp_kernel<C_, S_>), grid, block, NfPP<S_>::LDS_BYTES, s, X, Khi, rel_klo, rel_vhi, rel_vlo, \
+                                             (unsigned)scratch_bytes, Xo, Wp, bp, Zp, ML, N, npad, q0, q1)
+        switch (C) {
+            case 84: if (split) NP_LAUNCH(84, true); else NP_LAUNCH(84, false); break;
+            case 60: if (split) NP_LAUNCH(60, true); else NP_LAUNCH(60, false); break;
+            case 36: if (split) NP_LAUNCH(36, true); else NP_LAUNCH(36, false); break;
+        }
+#undef NP_LAUNCH
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess || ks == 1) return e;
+        return launch_nl_merge(X, Zp, ML, bp, Xo, B, N, C, ks, s, q0, q1);
+    }
+    static std::atomic<int> attr_dev[64];
+    if (!attr_dev[dev]) {
+        for (const void* fn : {reinterpret_cast<const void*>(nl_attn_f16_kernel<84, true>), reinterpret_cast<const void*>(nl_attn_f16_kernel<60, true>),
+                               reinterpret_cast<const void*>(nl_attn_f16_kernel<36, true>), reinterpret_cast<const void*>(nl_attn_f16_kernel<84, false>),
+                               reinterpret_cast<const void*>(nl_attn_f16_kernel<60, false>), reinterpret_cast<const void*>(nl_attn_f16_kernel<36, false>)}) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NF_LDS_BYTES);
+            if (e != hipSuccess) return e;
+        }
+        attr_dev[dev] = 1;
+    }
+#define NF_LAUNCH(C_, S_) hipLaunchKernelGGL((nl_attn_f16_kernel<C_, S_>), grid, block, NF_LDS_BYTES, s, X, Khi, Klo, Vthi, Vtlo, Xo, Wp, bp, Zp, ML, N, npad, q0, q1)
+    switch (C) {
+        case 84: if (split) NF_LAUNCH(84, true); else NF_LAUNCH(84, false); break;
+        case 60: if (split) NF_LAUNCH(60, true); else NF_LAUNCH(60, false); break;
+        case 36: if (split) NF_LAUNCH(36, true); else NF_LAUNCH(36, false); break;
+    }
+#undef NF_LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || ks == 1) return e;
+    return launch_nl_merge(X, Zp, ML, bp, Xo, B, N, C, ks, s, q0, q1);
+}
+
+}  // namespace pfnl
+
+#ifdef PFNL_NP_TIMING
+extern "C" int pfnl_debug_read_np_stamps(long long* host, size_t n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(pfnl::np_dbg), n * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif
