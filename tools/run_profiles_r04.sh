@@ -36,5 +36,6 @@ rocprofv3 --kernel-trace --stats -d $o/prof_bf16 -o p -- python bench.py --workl
 python tools/rocprof_summary.py $(find $o/prof_bf16 -name "*.db" | head -1) $o/${tag}_bf16_kernel_stats_cfg4.md > /dev/null
 rm -rf $o/prof $o/prof_cfg0 $o/prof_cfg5 $o/prof_bf16 $o/pmc_1 $o/pmc_2 $o/pmc_3 $o/pmc_4 $o/pmc_5 $o/pmc_6
 tools/ubench/cu_stream_mix > $o/${tag}_ubench_cu_stream_mix.txt 2>&1
+cp $o/${tag}_traffic_split16.json $o/${tag}_traffic_bf16.json profiles/    # (on the GPU box: the bench line below reports them as roofline.traffic)
 python bench.py --steps 20 --warmup 5 > $o/${tag}_bench.json 2> $o/bench.err
 head -8 $o/${tag}_kernel_stats.md | cut -c1-160; cat $o/${tag}_traffic_split16.json | head -12; tail -c 400 $o/bench.err
