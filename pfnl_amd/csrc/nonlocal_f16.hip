@@ -26,6 +26,9 @@
 //   P^T straight from the S^T accumulator: register r of lane (query, kh) is key (r&3) + 8(r>>2) + 4kh, registers
 //   8t..8t+7 form the B operand of k-step t - the contraction order over keys is free, so V^T is stored by nl_pack_bf16
 //   with the keys of every 32-block permuted to exactly that order ([ch][block][t][kh][e]).
+#include <cstdlib>
+#include <type_traits>
+
 #include "common.h"
 #include "conv_bf16.h"
 #include "conv_split16.h"
@@ -55,7 +58,7 @@ __device__ __forceinline__ unsigned short bf16_bits(float f) {   // binary16, ro
 }
 __device__ __forceinline__ float bf16_float(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
 
-// X [B][N][CP] fp32 (nl_pack_kernel) -> Khi, Klo [B][N][96] bf16;  Vthi, Vtlo [B][96][Npad] bf16, keys permuted per
+// X [B][N][CP] fp32 (nl_pack_kernel) -> Khi, Klo [B][Npad][96] bf16;  Vthi, Vtlo [B][96][Npad] bf16, keys permuted per
 // 32-block, channel C = 1 (the row-sum channel), channels > C = 0
 __global__ void nl_pack_f16_kernel(const float* __restrict__ X, uint16_t* __restrict__ Khi, uint16_t* __restrict__ Klo,
                                     uint16_t* __restrict__ Vthi, uint16_t* __restrict__ Vtlo, int B, int N, int Npad, int C,
@@ -68,10 +71,10 @@ __global__ void nl_pack_f16_kernel(const float* __restrict__ X, uint16_t* __rest
         const float v = (n < N && c < C) ? X[((size_t)b * N + n) * CPin + c] * NF_XSCALE : 0.f;
         const unsigned short hi = bf16_bits(v);
         const unsigned short lo = bf16_bits(v - bf16_float(hi));
-        if (n < N) {
-            Khi[((size_t)b * N + n) * NF_CP + c] = hi;
-            Klo[((size_t)b * N + n) * NF_CP + c] = lo;
-        }
+        // key rows up to Npad (>= the last tile's end).  Keys past N carry -65504 in the pad channel C: a query operand with a
+        // positive entry there (nl_attn_f16_sw_kernel: 1024) gets a logit of -4 000 for them - the key mask as DATA, no code
+        Khi[((size_t)b * Npad + n) * NF_CP + c] = (n >= N && c == C) ? (unsigned short)0xfbff : hi;
+        Klo[((size_t)b * Npad + n) * NF_CP + c] = lo;
         // position of key n inside its 32-block: key = (e&3) + 8(2t + (e>>2)) + 4kh  ->  pos = 16t + 8kh + e
         const int kb = n & 31;
         const int e = (kb & 3) | (((kb >> 3) & 1) << 2), kh = (kb >> 2) & 1, t = kb >> 4;
@@ -131,8 +134,8 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_kernel(const float*
     float m = -INFINITY;
 
     // staging: 4 x 768 16-byte pieces per 64-key tile, 6 per thread (8 slots: the second pass covers pieces 512..767)
-    const uint16_t* const Khb = Khi + (size_t)b * N * NF_CP;
-    const uint16_t* const Klb = Klo + (size_t)b * N * NF_CP;
+    const uint16_t* const Khb = Khi + (size_t)b * Npad * NF_CP;
+    const uint16_t* const Klb = Klo + (size_t)b * Npad * NF_CP;
     const uint16_t* const Vhb = Vthi + (size_t)b * NF_CP * Npad;
     const uint16_t* const Vlb = Vtlo + (size_t)b * NF_CP * Npad;
     constexpr int NI = 2;
@@ -354,9 +357,462 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_kernel(const float*
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same arithmetic, software-pipelined INSIDE a wave (nl_attn_f16_sw_kernel, the default; PFNL_NL_SW=0 selects the
+// kernel above, which also serves batches whose packed operands exceed 2 GB).  Counted on the kernel above at 1080p (hi parts only:
+// 4.05 k cycles per 64-key tile and SIMD for 1.5 k of MFMA and 2 x 1.0 k of softmax VALU; split: 7.6 k for 4.6 k of MFMA): its half-tile
+// skew lets one wave's softmax face the other wave's MFMAs - and on this chip that hides nothing: the VALU of one wave gets about one
+// issue slot per MFMA of the OTHER wave of its SIMD (tools/ubench/valu_under_mfma; a two-phase ping-pong of the half-workgroups measured
+// Y + X per phase, not max(Y, X): tools/experiments/README.md).  What a wave issues between two of its OWN MFMAs does ride in their
+// shadow.  So the loop runs over 32-key halves h, and ONE half-body issues, from one wave and in one pinned order,
+//     the MFMAs of S^T(h + 1) and P V(h - 1)   |   their operand reads, AHEAD reads in front   |   the VALU of softmax(h)
+// with S^T double-buffered per half (the same 32 registers as before) and no phase difference between the waves.  Three things this
+// needed beyond writing it down:
+//   * every step pinned with sched_barrier(0): left alone the compiler clumps the three streams (twelve reads with a wait after each,
+//     the max reduction as one block);
+//   * the exponentials pinned where they are written (NP_PIN): their only use is one half-body later, and LLVM sinks a pure computation
+//     to its use - the whole softmax reappeared in front of the first P V MFMA that consumes it, which is the SUM again;
+//   * no branch in the body: with the key mask of the last, partial tile as a second copy of the body behind a (uniform) branch the
+//     allocator kept nine 16-register accumulator blocks instead of five (250 registers hi-only, spills split).  The mask is DATA now:
+//     key rows past N carry -65504 in pad channel C (nl_pack_f16_kernel), the query operand 1024 there - a logit of -4 000.
+// The K / V^T tiles travel by LDS-DMA (`buffer_load_dwordx4 ... lds`; the four packed arrays are one allocation = one buffer resource,
+// the padded LDS rows are produced by per-lane source offsets, the pad chunks by an out-of-range offset = zeros): no staging registers, no
+// ds_write.  Ring of NSLOT tiles (3 with split operands - LDS is full - and 5 of 32 KB on the hi parts only); one workgroup barrier per
+// tile, between its two half-bodies: behind it tile t + 1 is complete and the slot of tile t - 1 is free for tile t + NSLOT - 1, whose pieces
+// ride on the MFMA gaps of half-body b.  A wave waits for its own pieces of tile t + 1 in front of that barrier with `s_waitcnt
+// vmcnt((NSLOT - 3) x pieces per wave)`: the counter retires in issue order and every wave issues the same number of pieces per tile (past
+// the last tile: against an empty resource), so the count is exact.
+template <bool SPLIT>
+struct NfSW {
+    static constexpr int KLO_OFF = NF_KT * NF_KROW;                                    // 13 312 (split only)
+    static constexpr int VHI_OFF = SPLIT ? 2 * NF_KT * NF_KROW : NF_KT * NF_KROW;      // 26 624 | 13 312
+    static constexpr int VLO_OFF = VHI_OFF + NF_CP * NF_VROW;                          // + 13 824 (split only)
+    static constexpr int TILE_BYTES = SPLIT ? VLO_OFF + NF_CP * NF_VROW : VLO_OFF;     // 54 272 | 27 136
+    static constexpr int NSLOT = SPLIT ? 3 : 5;
+    static constexpr int PIECES = SPLIT ? 53 : 32;                                     // 1 KB DMA instructions per tile (hi only: 27 carry data)
+    static constexpr int SLOT_BYTES = PIECES * 1024;                                   // 54 272 | 32 768
+    static constexpr int PW = (PIECES + 7) / 8;                                        // per wave: 7 (waves 5-7: 6) | 4
+    static constexpr int LDS_BYTES = NSLOT * SLOT_BYTES;                               // 162 816 | 163 840
+    static_assert(TILE_BYTES <= SLOT_BYTES && LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(SPLIT || PIECES % 8 == 0, "the vmcnt wait of the hi-only ring counts on equal shares");
+};
+
+__device__ __forceinline__ void nf_dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds_dst, int voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rs) : "memory");
+}
+#define NF_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifdef PFNL_NP_TIMING   /* phase timeline (tools/np_timing.py); not part of the product build */
+__device__ long long np_dbg[256 * 2 * 128];
+#define NP_STAMP() do { if (SPLIT == (PFNL_NP_TIMING != 0) && lane == 0 && (wave == 0 || wave == 4) && dbg_n < 128 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 256) np_dbg[(blockIdx.x * 2 + (wave != 0)) * 128 + dbg_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define NP_STAMP() do {} while (0)
+#endif
+
+// K16 = Khi (the lowest address of the scratch); rel_* = byte offsets of Klo, Vthi, Vtlo from it; scratch_bytes = the whole allocation
+template <int C, bool SPLIT>
+__global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_sw_kernel(const float* __restrict__ X, const uint16_t* __restrict__ K16,
+                                                                 unsigned rel_klo, unsigned rel_vhi, unsigned rel_vlo, unsigned scratch_bytes,
+                                                                 float* __restrict__ Xo, const float* __restrict__ Wp,
+                                                                 const float* __restrict__ bp, float* __restrict__ Zp,
+                                                                 float* __restrict__ ML, int N, int Npad, int q0, int q1) {
+    using G = NfSW<SPLIT>;
+    constexpr int CT = 3;
+    constexpr int CP = (C + 31) / 32 * 32;                          // row stride of X / Xo / Wp (nl_padded_ch)
+    static_assert(C < NF_CP && C % 2 == 0, "needs a pad channel inside 96");
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];   // NSLOT tiles: K hi | (K lo) | V^T hi | (V^T lo)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef PFNL_NP_TIMING
+    int dbg_n = 0;
+#endif
+    const int xl = lane & 31;
+    const int kh = lane >> 5;
+    const int b = blockIdx.y;
+    const float* Xb = X + (size_t)b * N * CP;
+    float* Xob = Xo + (size_t)b * N * CP;
+    const int q = q0 + blockIdx.x * NF_QB + (tid >> 6) * 32 + xl;   // this lane's query (queries [q0, q1): a strip of the frame)
+    const int qc = q < q1 ? q : q1 - 1;
+
+    // B operand of S^T = K Q^T: this lane's query, channels 16ks + 8kh .. +7, scaled by log2(e), split hi + lo
+    constexpr float LOG2E = 1.4426950408889634f;
+    bf16x8 qh[6];
+    [[maybe_unused]] bf16x8 ql[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 16 * ks + 8 * kh + e;
+            // (channel C: the key rows past N carry -65504 there (nl_pack_f16_kernel), every other key 0 - the key mask as data)
+            const float v = c < C ? Xb[(size_t)qc * CP + c] * (LOG2E * NF_XSCALE) : (c == C ? 1024.f : 0.f);
+            const _Float16 h = (_Float16)v;
+            qh[ks][e] = h;
+            if constexpr (SPLIT) ql[ks][e] = (_Float16)(v - (float)h);
+        }
+    constexpr int LCT = C / 32, LI = C % 32;                        // where the row-sum channel C lives in the D layout
+    constexpr int LKH = (LI % 8) >= 4 ? 1 : 0, LR = (LI / 8) * 4 + (LI % 8) % 4;
+
+    f32x16 o[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
+    float m = -INFINITY;
+
+    // DMA map: piece i = wave + 8k writes slot bytes [1024 i, + 1024), lane L the 16 bytes at p = 1024 i + 16 L.  `srel` = byte offset of
+    // that chunk's source from K16 for key tile 0 (0x7fffffff: a pad chunk - stays out of range).  Per tile: + k0 x (192 | 2); every key
+    // row and V^T column of a tile exists (both arrays are padded past the last tile; keys past N are masked by their data).
+    int srel[G::PW];
+#pragma unroll
+    for (int k = 0; k < G::PW; ++k) {
+        const int p = (wave + 8 * k) * 1024 + 16 * lane;
+        int sr = 0x7fffffff;
+        if (p < NF_KT * NF_KROW || (SPLIT && p < 2 * NF_KT * NF_KROW)) {
+            const bool lo = p >= NF_KT * NF_KROW;
+            const int r = p - (lo ? NF_KT * NF_KROW : 0);
+            const int row = r / NF_KROW, col = r - row * NF_KROW;
+            if (col < NF_CP * 2) {
+                sr = (int)((lo ? rel_klo : 0u) + (unsigned)(((size_t)b * Npad + row) * (NF_CP * 2)) + col);
+            }
+        } else if (p < G::TILE_BYTES) {
+            const bool lo = SPLIT && p >= G::VLO_OFF;
+            const int r = p - (lo ? G::VLO_OFF : G::VHI_OFF);
+            const int ch = r / NF_VROW, col = r - ch * NF_VROW;
+            if (col < NF_KT * 2) {
+                sr = (int)((lo ? rel_vlo : rel_vhi) + (unsigned)(((size_t)b * NF_CP + ch) * Npad * 2) + col);
+            }
+        }
+        srel[k] = sr;
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)sm;
+    // piece k of this wave for key tile `kt` -> ring slot `slot`; `live` false (past the last tile): an empty resource, nothing moves
+    auto tile_piece = [&](int k, int kt, int slot, bool live) __attribute__((always_inline)) {
+        const int i = wave + 8 * k;
+        if (G::PIECES % 8 == 0 || 8 * k + 7 < G::PIECES || i < G::PIECES) {   // (wave-uniform; split: waves 5-7 have no seventh piece)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(K16), 0, live ? scratch_bytes : 0, 0x00020000);
+            const int k0 = kt * NF_KT;
+            const bool isk = i * 1024 < (SPLIT ? 2 : 1) * NF_KT * NF_KROW;   // (the K | V^T boundary is a multiple of 1024)
+            const int off = (int)((unsigned)srel[k] + (unsigned)(k0 * (isk ? NF_CP * 2 : 2)));   // (a pad chunk stays past the range)
+            nf_dma16(rs, lds0 + slot * G::SLOT_BYTES + i * 1024, off);
+        }
+    };
+
+    const int ntiles = (N + NF_KT - 1) / NF_KT;
+    const int ksp = gridDim.z, sp = blockIdx.z;
+    const int kt0 = (int)((long long)ntiles * sp / ksp), kt1 = (int)((long long)ntiles * (sp + 1) / ksp);
+    // prologue: tiles kt0 .. kt0 + NSLOT - 2 -> slots 0 ..; an all-zero tile -> slot NSLOT - 1, the "tile kt0 - 1" of the first P V
+    // (whose P^T is zero: no branch around it, but 0 x whatever the LDS held could be NaN)
+#pragma unroll
+    for (int j = 0; j < G::NSLOT - 1; ++j)
+#pragma unroll
+        for (int k = 0; k < G::PW; ++k) tile_piece(k, kt0 + j, j, kt0 + j < kt1);
+#pragma unroll
+    for (int k = 0; k < G::PW; ++k) tile_piece(k, 0, G::NSLOT - 1, false);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    bf16x8 pt[2][2];                                                // P^T of the two 32-key halves of a tile (hi, lo parts)
+    [[maybe_unused]] bf16x8 pl[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pt[i][j][e] = (_Float16)0.f;
+                if constexpr (SPLIT) pl[i][j][e] = (_Float16)0.f;
+            }
+#define NP_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, 0, 0, 0)
+    f32x16 st[2];                                                   // S^T of the 32-key half in flight and of the one being exponentiated
+    // MFMA i of a half-body: i < NQ: S^T k-step i (split: k-step i/3, products hh, hl, lh); then P V: (key step jj, channel tile ct)
+    // (split: x (Vh Ph, Vh Pl, Vl Ph) - consecutive MFMAs on one accumulator run at full rate: tools/ubench/mfma_bf16_rate).  Its A
+    // operand is read q(i) of the half-body's read sequence: i (hi only) | 2 (i / 3) + (i % 3 == 2) (split: hi row, lo row per step).
+    constexpr int NQ = SPLIT ? 18 : 6, NR = SPLIT ? 24 : 12;
+    // (an opaque use where a value is written: see the header - LLVM would sink the softmax to the MFMA that consumes it)
+#define NP_PIN(v_) asm volatile("" : "+v"(v_))
+    constexpr int AHEAD = 4;                                        // reads in flight in front of the one in use
+    constexpr int RING = AHEAD + 2;
+    bf16x8 rb[RING];
+    auto half_body = [&](auto hc, const unsigned char* qbuf, const unsigned char* vbuf, int kt_fill, int s_fill) __attribute__((always_inline)) {
+        constexpr int H = decltype(hc)::value;                      // 0: half a of a tile (softmax of its keys 0..31), 1: half b
+        f32x16& stc = st[H];
+        f32x16& stn = st[H ^ 1];
+        // S^T(h + 1): key rows 32 (1 - H) .. of `qbuf`;  P V(h - 1): V^T keys 32 (1 - H) .. of `vbuf`, P^T = pt[1 - H]
+        const unsigned char* const kah = qbuf + ((1 - H) * 32 + xl) * NF_KROW + kh * 16;
+        const unsigned char* const vah = vbuf + G::VHI_OFF + xl * NF_VROW + kh * 16 + (1 - H) * 64;
+        auto read = [&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;
+            if constexpr (q < NR) {
+                constexpr int d = q % RING;
+                if constexpr (!SPLIT) {
+                    if constexpr (q < 6) rb[d] = *reinterpret_cast<const bf16x8*>(kah + q * 32);
+                    else rb[d] = *reinterpret_cast<const bf16x8*>(vah + ((q - 6) % 3) * 32 * NF_VROW + ((q - 6) / 3) * 32);
+                } else {
+                    if constexpr (q < 12) rb[d] = *reinterpret_cast<const bf16x8*>(kah + (q & 1) * G::KLO_OFF + (q >> 1) * 32);
+                    else {
+                        constexpr int u = (q - 12) >> 1, lo = (q - 12) & 1;   // u = 3 jj + ct
+                        rb[d] = *reinterpret_cast<const bf16x8*>(vah + lo * (G::VLO_OFF - G::VHI_OFF) + (u % 3) * 32 * NF_VROW + (u / 3) * 32);
+                    }
+                }
+            }
+        };
+        auto mfma = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int q = SPLIT ? 2 * (i / 3) + (i % 3 == 2) : i;
+            const bf16x8 a = rb[q % RING];
+            if constexpr (i < NQ) {
+                constexpr int ks = SPLIT ? i / 3 : i;
+                bf16x8 bq = qh[ks];
+                if constexpr (SPLIT) {
+                    if constexpr (i % 3 == 1) bq = ql[ks];
+                }
+                if constexpr (i == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    stn = NP_MFMA(a, bq, z);
+                } else {
+                    stn = NP_MFMA(a, bq, stn);
+                }
+            } else {
+                constexpr int j = i - NQ;
+                constexpr int u = SPLIT ? j / 3 : j;                // 3 jj + ct
+                constexpr int jj = u / 3, ct = u % 3;
+                bf16x8 bp = pt[1 - H][jj];
+                if constexpr (SPLIT) {
+                    if constexpr (j % 3 == 1) bp = pl[1 - H][jj];
+                }
+                o[ct] = NP_MFMA(a, bp, o[ct]);
+            }
+        };
+        // ---- reads in flight
+#pragma unroll
+        for (int q0_ = 0; q0_ <= AHEAD; ++q0_) {
+            if (q0_ == 0) read(std::integral_constant<int, 0>{});
+            if (q0_ == 1) read(std::integral_constant<int, 1>{});
+            if (q0_ == 2) read(std::integral_constant<int, 2>{});
+            if (q0_ == 3) read(std::integral_constant<int, 3>{});
+            if (q0_ == 4) read(std::integral_constant<int, 4>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float tmax = 0.f, tsw = 0.f, alpha = 1.f, shift = 0.f;
+        // ---- the MFMAs, one gap each: the read AHEAD in front and a slice of the softmax - gaps 0..3 the running max of the 32 keys (a
+        // dependent chain with a cross-lane exchange in it: as a block in front of the MFMAs it was ~300 cycles of idle matrix pipe per
+        // half), then the exponentials (a pair of keys per gap: 2 fma, 2 exp, the packed conversion; split: the lo parts in the gap
+        // after) - and in b a request of the next tile now and then
+        [[maybe_unused]] float pv0 = 0.f, pv1 = 0.f;
+        auto gap = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            mfma(ic);
+            __builtin_amdgcn_sched_barrier(0);
+            {   // the first MFMA that takes read q sends read q + AHEAD on its way (reads 0 .. AHEAD went out in front of the max)
+                constexpr int qn = (SPLIT ? 2 * (i / 3) + (i % 3 == 2) : i) + AHEAD + 1;
+                constexpr int qp = i == 0 ? AHEAD + 1 : (SPLIT ? 2 * ((i - 1) / 3) + ((i - 1) % 3 == 2) : i - 1) + AHEAD + 1;
+                if constexpr (qn > qp) read(std::integral_constant<int, qn - 1 < NR ? (qn - 1 >= qp ? qn - 1 : NR) : NR>{});
+            }
+            if constexpr (i == 0) {
+                tmax = fmaxf(fmaxf(stc[0], stc[1]), fmaxf(stc[2], stc[3]));
+#pragma unroll
+                for (int r = 4; r < 16; r += 4) tmax = fmaxf(tmax, fmaxf(fmaxf(stc[r], stc[r + 1]), fmaxf(stc[r + 2], stc[r + 3])));
+                NP_PIN(tmax);
+            } else if constexpr (i == 1) {
+                tsw = __shfl_xor(tmax, 32);
+                NP_PIN(tsw);
+            } else if constexpr (i == 3) {
+                tmax = fmaxf(tmax, tsw) * NF_SINV;                    // true base-2 logit (the scale is positive: max commutes)
+                const float mn = fmaxf(m, tmax);
+                alpha = __builtin_amdgcn_exp2f(m - mn);             // m = -inf on the first half -> 0
+                shift = NF_PSHIFT - mn;
+                m = mn;
+                NP_PIN(shift);
+                NP_PIN(alpha);
+            }
+            if constexpr (!SPLIT) {
+                if constexpr (i >= 4) {
+                    constexpr int r = 2 * (i - 4);
+                    const float a0 = __builtin_amdgcn_exp2f(__builtin_fmaf(stc[r], NF_SINV, shift));       // 2^14 exp2(s - max)
+                    const float a1 = __builtin_amdgcn_exp2f(__builtin_fmaf(stc[r + 1], NF_SINV, shift));
+                    pt[H][r >> 3][r & 7] = (_Float16)a0;
+                    pt[H][r >> 3][(r & 7) + 1] = (_Float16)a1;
+                    NP_PIN(pt[H][r >> 3]);
+                }
+            } else {
+                if constexpr (i >= 4 && i % 2 == 0) {
+                    constexpr int r = 2 * ((i - 4) / 4);
+                    if constexpr (((i - 4) / 2) % 2 == 0) {
+                        pv0 = __builtin_amdgcn_exp2f(__builtin_fmaf(stc[r], NF_SINV, shift));
+                        pv1 = __builtin_amdgcn_exp2f(__builtin_fmaf(stc[r + 1], NF_SINV, shift));
+                        asm volatile("" : "+v"(pv0), "+v"(pv1));
+                    } else {
+                        const _Float16 h0 = (_Float16)pv0, h1 = (_Float16)pv1;
+                        pt[H][r >> 3][r & 7] = h0;
+                        pt[H][r >> 3][(r & 7) + 1] = h1;
+                        pl[H][r >> 3][r & 7] = (_Float16)(pv0 - (float)h0);
+                        pl[H][r >> 3][(r & 7) + 1] = (_Float16)(pv1 - (float)h1);
+                        NP_PIN(pt[H][r >> 3]);
+                        NP_PIN(pl[H][r >> 3]);
+                    }
+                }
+            }
+            if constexpr (H == 1) {
+                constexpr int step = SPLIT ? 5 : 3;
+                if constexpr (i % step == 2 && i / step < G::PW) tile_piece(i / step, kt_fill, s_fill, kt_fill < kt1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        gap(std::integral_constant<int, 0>{});
+        gap(std::integral_constant<int, 1>{});
+        gap(std::integral_constant<int, 2>{});
+        gap(std::integral_constant<int, 3>{});
+        gap(std::integral_constant<int, 4>{});
+        gap(std::integral_constant<int, 5>{});
+        gap(std::integral_constant<int, 6>{});
+        gap(std::integral_constant<int, 7>{});
+        gap(std::integral_constant<int, 8>{});
+        gap(std::integral_constant<int, 9>{});
+        gap(std::integral_constant<int, 10>{});
+        gap(std::integral_constant<int, 11>{});
+        if constexpr (SPLIT) {
+            gap(std::integral_constant<int, 12>{});
+            gap(std::integral_constant<int, 13>{});
+            gap(std::integral_constant<int, 14>{});
+            gap(std::integral_constant<int, 15>{});
+            gap(std::integral_constant<int, 16>{});
+            gap(std::integral_constant<int, 17>{});
+            gap(std::integral_constant<int, 18>{});
+            gap(std::integral_constant<int, 19>{});
+            gap(std::integral_constant<int, 20>{});
+            gap(std::integral_constant<int, 21>{});
+            gap(std::integral_constant<int, 22>{});
+            gap(std::integral_constant<int, 23>{});
+            gap(std::integral_constant<int, 24>{});
+            gap(std::integral_constant<int, 25>{});
+            gap(std::integral_constant<int, 26>{});
+            gap(std::integral_constant<int, 27>{});
+            gap(std::integral_constant<int, 28>{});
+            gap(std::integral_constant<int, 29>{});
+            gap(std::integral_constant<int, 30>{});
+            gap(std::integral_constant<int, 31>{});
+            gap(std::integral_constant<int, 32>{});
+            gap(std::integral_constant<int, 33>{});
+            gap(std::integral_constant<int, 34>{});
+            gap(std::integral_constant<int, 35>{});
+        }
+        // ---- the output accumulators follow the new maximum before the next P V (rare once the maximum has settled)
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+        }
+    };
+
+    int s_cur = 0, s_prv = G::NSLOT - 1, s_nxt = 1;                 // ring slots of tiles t, t - 1, t + 1
+    {   // S^T of the first half (plain: nothing to overlap with yet)
+        const unsigned char* const kah = sm + xl * NF_KROW + kh * 16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[0][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(kah + ks * 32);
+            st[0] = NP_MFMA(ah, qh[ks], st[0]);
+            if constexpr (SPLIT) {
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(kah + G::KLO_OFF + ks * 32);
+                st[0] = NP_MFMA(ah, ql[ks], st[0]);
+                st[0] = NP_MFMA(al, qh[ks], st[0]);
+            }
+        }
+    }
+    for (int kt = kt0; kt < kt1; ++kt) {
+        NP_STAMP();                                                 // 0
+        const unsigned char* const cur = sm + s_cur * G::SLOT_BYTES;
+        const unsigned char* const prv = sm + s_prv * G::SLOT_BYTES;
+        const unsigned char* const nxt = sm + s_nxt * G::SLOT_BYTES;
+        // ---- a: softmax(2t) | S^T(2t + 1) | P V(2t - 1)
+        half_body(std::integral_constant<int, 0>{}, cur, prv, 0, 0);
+        NP_STAMP();                                                 // 1
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G::NSLOT - 3) * G::PW) : "memory");   // this wave's pieces of tile t + 1 have landed
+        NF_BARRIER();                                               // tile t + 1 is complete; nobody reads tile t - 1 any more
+        NP_STAMP();                                                 // 2
+        // ---- b: softmax(2t + 1) | S^T(2t + 2) | P V(2t); the pieces of tile t + NSLOT - 1 -> the slot of tile t - 1
+        // (S^T past the last tile: an all-zero tile, the result is not used)
+        half_body(std::integral_constant<int, 1>{}, nxt, cur, kt + G::NSLOT - 1, s_prv);
+        NP_STAMP();                                                 // 3
+        s_prv = s_cur;
+        s_cur = s_nxt;
+        s_nxt = s_nxt + 1 == G::NSLOT ? 0 : s_nxt + 1;
+    }
+    {   // the last half's P V
+        const unsigned char* const vah = sm + s_prv * G::SLOT_BYTES + G::VHI_OFF + xl * NF_VROW + kh * 16 + 64;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const bf16x8 vh = *reinterpret_cast<const bf16x8*>(vah + ct * 32 * NF_VROW + jj * 32);
+                o[ct] = NP_MFMA(vh, pt[1][jj], o[ct]);
+                if constexpr (SPLIT) {
+                    const bf16x8 vl = *reinterpret_cast<const bf16x8*>(vah + (G::VLO_OFF - G::VHI_OFF) + ct * 32 * NF_VROW + jj * 32);
+                    o[ct] = NP_MFMA(vh, pl[1][jj], o[ct]);
+                    o[ct] = NP_MFMA(vl, pt[1][jj], o[ct]);
+                }
+            }
+    }
+
+    float l = o[LCT][LR];
+    {
+        const float lo = __shfl_xor(l, 32);
+        if (kh != LKH) l = lo;
+    }
+    const float inv = (ksp == 1) ? (1.0f / NF_XSCALE) / l : (1.0f / NF_XSCALE);   // V carries 2^7; l and O share the 2^14 of P
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] *= inv;
+
+    // Z^T = W'^T O^T on the f32 matrix pipe, as in nonlocal.hip (pad rows of W' are zero: the row-sum channel drops out)
+    constexpr int CTW = CP / 32;
+#pragma unroll
+    for (int cot = 0; cot < CTW; ++cot) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) {
+            const float* wa = Wp + (size_t)(ct * 32 + 4 * kh) * CP + cot * 32 + xl;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) z = mfma32(wa[((s & 3) + 8 * (s >> 2)) * CP], o[ct][s], z);
+        }
+        if (q < q1) {
+            if (ksp == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cot * 32 + drow(r, lane);
+                    if (co < C) {
+                        const size_t idx = (size_t)q * CP + co;
+                        Xob[idx] = Xb[idx] + z[r] + bp[co];            // residual, model/pfnl.py:60
+                    }
+                }
+            } else {
+                float* zp = Zp + (((size_t)b * ksp + sp) * N + q) * CP;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zp[cot * 32 + drow(r, lane)] = z[r];
+            }
+        }
+    }
+    if (ksp > 1 && q < q1 && kh == 0) {
+        float* ml = ML + (((size_t)b * ksp + sp) * N + q) * 2;
+        ml[0] = m;
+        ml[1] = l;
+    }
+}
+
 size_t nl_f16_scratch_halfs(int B, int N) {                        // Khi, Klo, Vthi, Vtlo
     const size_t npad = (size_t)(N + 31) / 32 * 32 + 64;            // + one tile of slack for the last tile's V^T pieces
-    return 2 * (size_t)B * N * NF_CP + 2 * (size_t)B * NF_CP * npad;
+    return 4 * (size_t)B * NF_CP * npad;
 }
 
 // X, Xo as in launch_nl_attn; scratch16: nl_f16_scratch_halfs(B, N) 16-bit elements; partial: nl_partial_floats
@@ -368,8 +824,8 @@ hipError_t launch_nl_attn_f16(const float* X, float* Xo, const float* Wp, const 
     const int CP = nl_padded_ch(C);
     const int npad = (N + 31) / 32 * 32 + 64;
     uint16_t* Khi = scratch16;
-    uint16_t* Klo = Khi + (size_t)B * N * NF_CP;
-    uint16_t* Vthi = Klo + (size_t)B * N * NF_CP;
+    uint16_t* Klo = Khi + (size_t)B * npad * NF_CP;
+    uint16_t* Vthi = Klo + (size_t)B * npad * NF_CP;
     uint16_t* Vtlo = Vthi + (size_t)B * NF_CP * npad;
     {
         const size_t total = (size_t)B * npad * NF_CP;
@@ -399,9 +855,44 @@ hipError_t launch_nl_attn_f16(const float* X, float* Xo, const float* Wp, const 
     float* ML = partial ? partial + (size_t)B * ks * N * CP : nullptr;
     dim3 grid((q1 - q0 + NF_QB - 1) / NF_QB, B, ks);
     dim3 block(NF_THREADS);
-    static std::atomic<int> attr_dev[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    // the software-pipelined kernel (round 4) addresses the four packed arrays as ONE buffer resource with 32-bit offsets and an
+    // out-of-range sentinel of 2^31 - 1: a scratch of 2 GB or more (> 2.7 M keys in the batch) stays on the first kernel.  PFNL_NL_SW=0: always.
+    static const bool sw_on = [] {
+        const char* e = std::getenv("PFNL_NL_SW");
+        return !(e && e[0] == '0');
+    }();
+    const size_t scratch_bytes = 2 * nl_f16_scratch_halfs(B, N);
+    if (sw_on && scratch_bytes < 0x7fff0000ull) {
+        static std::atomic<int> attr_sw[64];
+        if (!attr_sw[dev]) {
+            for (const void* fn : {reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<84, true>), reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<60, true>),
+                                   reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<36, true>)}) {
+                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NfSW<true>::LDS_BYTES);
+                if (e != hipSuccess) return e;
+            }
+            for (const void* fn : {reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<84, false>), reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<60, false>),
+                                   reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<36, false>)}) {
+                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NfSW<false>::LDS_BYTES);
+                if (e != hipSuccess) return e;
+            }
+            attr_sw[dev] = 1;
+        }
+        const unsigned rel_klo = (unsigned)((Klo - Khi) * 2), rel_vhi = (unsigned)((Vthi - Khi) * 2), rel_vlo = (unsigned)((Vtlo - Khi) * 2);
+#define NP_LAUNCH(C_, S_) hipLaunchKernelGGL((nl_attn_f16_sw_kernel<C_, S_>), grid, block, NfSW<S_>::LDS_BYTES, s, X, Khi, rel_klo, rel_vhi, rel_vlo, \
+                                             (unsigned)scratch_bytes, Xo, Wp, bp, Zp, ML, N, npad, q0, q1)
+        switch (C) {
+            case 84: if (split) NP_LAUNCH(84, true); else NP_LAUNCH(84, false); break;
+            case 60: if (split) NP_LAUNCH(60, true); else NP_LAUNCH(60, false); break;
+            case 36: if (split) NP_LAUNCH(36, true); else NP_LAUNCH(36, false); break;
+        }
+#undef NP_LAUNCH
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess || ks == 1) return e;
+        return launch_nl_merge(X, Zp, ML, bp, Xo, B, N, C, ks, s, q0, q1);
+    }
+    static std::atomic<int> attr_dev[64];
     if (!attr_dev[dev]) {
         for (const void* fn : {reinterpret_cast<const void*>(nl_attn_f16_kernel<84, true>), reinterpret_cast<const void*>(nl_attn_f16_kernel<60, true>),
                                reinterpret_cast<const void*>(nl_attn_f16_kernel<36, true>), reinterpret_cast<const void*>(nl_attn_f16_kernel<84, false>),
@@ -424,3 +915,9 @@ hipError_t launch_nl_attn_f16(const float* X, float* Xo, const float* Wp, const 
 }
 
 }  // namespace pfnl
+
+#ifdef PFNL_NP_TIMING
+extern "C" int pfnl_debug_read_np_stamps(long long* host, size_t n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(pfnl::np_dbg), n * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif

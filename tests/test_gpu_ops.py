@@ -215,6 +215,44 @@ def test_nonlocal_residual(B, T, H, W, kernel):
     assert np.abs(got - ref).max() < 2e-5, np.abs(got - ref).max()
 
 
+@pytest.mark.parametrize("N", [1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 193, 321])
+@pytest.mark.parametrize("kernel", ["split16", "f16"])
+def test_nonlocal_key_counts_around_tile_edges(N, kernel):
+    """nl_attn_f16_sw_kernel (round 4) masks the keys past N through DATA - key rows past N carry -65504 in the pad channel, the query
+    operand 1024 - and pipelines over 32-key halves of 64-key tiles in a ring of 3 / 5 LDS slots: every N around the half, tile and
+    ring boundaries, a half that is entirely masked (N = 1, 31, 32, 65 ...), against the fp64 spec."""
+    T, H, W = 3, 2, 2 * N
+    rng = np.random.default_rng(N)
+    C = 12 * T
+    x = rng.random((1, T, H, W, 3), dtype=np.float32)
+    wg = (rng.normal(size=(1, 1, C, C)) / np.sqrt(C)).astype(np.float32)
+    ww = (rng.normal(size=(1, 1, C, C)) / np.sqrt(C)).astype(np.float32)
+    bg = rng.normal(size=C).astype(np.float32) * 0.1
+    bw = rng.normal(size=C).astype(np.float32) * 0.1
+    got = ops.nonlocal_residual(dev(x), wg, bg, ww, bw, precision=kernel).cpu().numpy()
+    x64 = x.astype(np.float64)
+    stack = np.concatenate([x64[:, t] for t in range(T)], -1)
+    z = pfnl_spec.nonlocal_block(pfnl_spec.space_to_depth2(stack), wg.astype(np.float64), bg.astype(np.float64),
+                                 ww.astype(np.float64), bw.astype(np.float64))
+    ref = stack + pfnl_spec.depth_to_space2(z)
+    tol = 2e-5 if kernel == "split16" else 2e-3                     # (f16: binary16 operands, the non-local block of precision=bf16)
+    assert np.abs(got - ref).max() < tol, np.abs(got - ref).max()
+
+
+def test_nonlocal_f16_first_kernel_still_serves():
+    """PFNL_NL_SW=0 (and any batch whose packed operands exceed 2 GB) runs nl_attn_f16_kernel, on the same packed arrays (their key rows
+    are padded since round 4).  The choice is read once per process: the non-local tests again, in a process of their own."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_ops.py"), os.path.join(here, "test_gpu_bf16.py"), "-x", "-q",
+                        "-m", "gpu", "-k", "nonlocal and not first_kernel"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, PFNL_NL_SW="0"), cwd=os.path.dirname(here))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
 @pytest.mark.parametrize("kernel", ["fp32", "split16"])
 def test_nonlocal_constant_and_peaked_inputs(kernel):
     """Known answers: constant frames -> uniform affinity; a very bright pixel block -> the running-max

@@ -1,6 +1,6 @@
-"""Phase timeline of nl_attn_f16_pp_kernel (variant build -DPFNL_NP_TIMING=0|1 (hi only | split) -> pfnl_amd/lib/var_np_T.so): per key tile
-4 stamps (shader cycles) of waves 0 (early half) and 4 (late half): Y starts, its MFMAs issued, X starts (barrier passed), softmax done;
-the next tile's first stamp follows the second barrier.
+"""Phase timeline of nl_attn_f16_sw_kernel (variant build -DPFNL_NP_TIMING=0|1 (hi only | split) -> pfnl_amd/lib/var_np_T.so): per key tile
+4 stamps (shader cycles) of waves 0 and 4 (the two waves of SIMD 0): tile starts, half-body a issued, the barrier between the half-bodies
+passed, half-body b issued.
 usage: PFNL_HIP_LIB=pfnl_amd/lib/var_np_T.so python tools/np_timing.py [bf16|f32]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,7 +24,7 @@ assert lib.pfnl_debug_read_np_stamps(buf.ctypes.data_as(C.c_void_p), buf.size) =
 st = buf.reshape(256, 2, 128)
 names = ["a: softmax(2t) | S^T(2t+1) | P V(2t-1)", "wait + barrier", "b: softmax(2t+1) | S^T(2t+2) | P V(2t) + requests", "loop"]
 for wg in (0, 9, 100):
-    for wi, wname in ((0, "wave0 (early)"), (1, "wave4 (late)")):
+    for wi, wname in ((0, "wave0"), (1, "wave4")):
         s = st[wg, wi]
         n = int((s != 0).sum()) // 4
         if not n:

@@ -1,4 +1,4 @@
-# phase stamps of the anti-phase non-local kernel (tools/np_timing.py): variant build with -DPFNL_NP_TIMING=$1 (0: hi parts only = bf16 precision, 1: split)
+# phase stamps of the software-pipelined non-local kernel (tools/np_timing.py): variant build with -DPFNL_NP_TIMING=$1 (0: hi parts only = bf16 precision, 1: split)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 m=${1:-0}
 cd pfnl_amd/csrc
