@@ -615,15 +615,24 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_sw_kernel(const flo
                 if constexpr (qn > qp) read(std::integral_constant<int, qn - 1 < NR ? (qn - 1 >= qp ? qn - 1 : NR) : NR>{});
             }
             if constexpr (i == 0) {
-                tmax = fmaxf(fmaxf(stc[0], stc[1]), fmaxf(stc[2], stc[3]));
-#pragma unroll
-                for (int r = 4; r < 16; r += 4) tmax = fmaxf(tmax, fmaxf(fmaxf(stc[r], stc[r + 1]), fmaxf(stc[r + 2], stc[r + 3])));
+                // (v_max3_f32 by hand: fmaxf() puts a canonicalising v_max x, x in front of every MFMA output - 20 instructions for 16
+                // values; the logits are finite)
+                float ta, tb;
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(ta) : "v"(stc[0]), "v"(stc[1]), "v"(stc[2]));
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tb) : "v"(stc[8]), "v"(stc[9]), "v"(stc[10]));
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(ta) : "v"(ta), "v"(stc[3]), "v"(stc[4]));
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tb) : "v"(tb), "v"(stc[11]), "v"(stc[12]));
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(ta) : "v"(ta), "v"(stc[5]), "v"(stc[6]));
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tb) : "v"(tb), "v"(stc[13]), "v"(stc[14]));
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(ta) : "v"(ta), "v"(stc[7]), "v"(stc[15]));
+                asm("v_max_f32 %0, %1, %2" : "=v"(tmax) : "v"(ta), "v"(tb));
                 NP_PIN(tmax);
             } else if constexpr (i == 1) {
                 tsw = __shfl_xor(tmax, 32);
                 NP_PIN(tsw);
             } else if constexpr (i == 3) {
-                tmax = fmaxf(tmax, tsw) * NF_SINV;                    // true base-2 logit (the scale is positive: max commutes)
+                asm("v_max_f32 %0, %1, %2" : "=v"(tmax) : "v"(tmax), "v"(tsw));
+                tmax *= NF_SINV;                                    // true base-2 logit (the scale is positive: max commutes)
                 const float mn = fmaxf(m, tmax);
                 alpha = __builtin_amdgcn_exp2f(m - mn);             // m = -inf on the first half -> 0
                 shift = NF_PSHIFT - mn;
