@@ -44,6 +44,7 @@ SUSTAINED_F16_MFMA_TFLOPS = 1500.0
 # residual lines, output lines: 5.5 - 5.8 TB/s of compulsory bytes, ~11 B per clock and CU (tools/ubench/cu_stream_mix.hip,
 # profiles/r04_ubench_cu_stream_mix.txt).  Context next to `frac` (which is priced on the 8 TB/s spec), not a substitute for it.
 STREAM_MIX_CEILING_GBS = 5600.0
+CU_PORT_B_PER_CLK = 11.2                                           # what a CU's memory port moved per shader clock with nothing else to do (ibid.)
 PREWARM_S = 0.3                                                    # untimed steps in front of the warm-up: the clock ramp of an idle chip
 T = 7
 
@@ -272,6 +273,11 @@ def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
             rec.update({"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(f_h, 4)})
         else:
             rec.update({"achieved": round(direct_tflops, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(f_m, 4)})
+        # what passes through a CU's memory port besides the compulsory bytes: the split weight pack does not fit next to the halo buffers
+        # (147 KB), so every 8 x 32-pixel tile replaces one channel half of it from L2 (73 728 B; conv_split16.hip / conv_sf.hip) - bytes
+        # that never reach HBM but share the port's ~11 B per clock and CU (tools/ubench/cu_stream_mix) with the ones that do
+        tiles_item = ((H + 7) // 8) * ((W + 31) // 32)
+        wstream = 73728.0 * tiles_item * (2 * F + B) * geom.num_block / launches_per_step
         traffic = stamped_traffic("traffic_split16.json", files, (algo, workload))
         if traffic is not None and traffic < 0.95 * bytes_per_launch:
             # counter bytes below the compulsory bytes: the byte model and the launch structure that ran disagree - say so instead
@@ -283,6 +289,12 @@ def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
                     "mbytes_per_launch": round(bytes_per_launch / 1e6, 2),
                     "tiles_per_block": "5F+%dB" % ((1 if c10 else 0) + (1 if chain else 3)),
                     "stream_mix_ceiling_gbs": STREAM_MIX_CEILING_GBS, "hbm_vs_stream_mix_ceiling": round(gbs / STREAM_MIX_CEILING_GBS, 4),
+                    "cu_port": {"l2_weight_stream_mbytes_per_launch": round(wstream / 1e6, 2),
+                                "mbytes_per_launch": round((bytes_per_launch + wstream) / 1e6, 2),
+                                "gbs": round((bytes_per_launch + wstream) / (avg_ms * 1e-3) / 1e9, 1),
+                                "ceiling_b_per_clk_cu": CU_PORT_B_PER_CLK,
+                                "note": "compulsory bytes + the weight halves a tile re-reads from L2; b_per_clk_cu / frac are filled in "
+                                        "from the shader clock of the sustained run (power.sclk_mhz) when rocm-smi reports it"},
                     "hbm_gbs": round(gbs, 1), "hbm_frac": round(f_h, 4),
                     "algorithmic_direct_tflops": round(direct_tflops, 2), "algorithmic_mfma_frac": round(f_m, 4),
                     "mfma_executed_tflops": round(ex, 1), "mfma_executed_frac": round(ex / PEAK_F16_MFMA_TFLOPS, 4),
@@ -605,6 +617,11 @@ def main():
             power = sampler.stop()
             if power:
                 res["power"] = power
+                port = (res.get("roofline") or {}).get("cu_port")
+                if port and power.get("sclk_mhz"):                  # per shader clock and CU: the unit the port's ceiling was measured in
+                    n_cu = torch.cuda.get_device_properties(local_dev).multi_processor_count
+                    port["b_per_clk_cu"] = round(port["gbs"] * 1e9 / (n_cu * power["sclk_mhz"] * 1e6), 2)
+                    port["frac"] = round(port["b_per_clk_cu"] / CU_PORT_B_PER_CLK, 3)
         if use_dist:
             if comm is not None:
                 el = float(comm.allreduce([el], "max")[0])

@@ -381,6 +381,11 @@ def test_bench_byte_model_matches_the_launch_structure_and_the_committed_traffic
     tj = json.load(open(newest))
     ratio = tj["hbm_bytes_per_launch_avg"] / (rec["mbytes_per_launch"] * 1e6)
     assert 0.95 <= ratio < 1.3, (newest, ratio)
+    # what shares the CU's memory port with those bytes: one 73 728-byte half of the split weight pack per 8 x 32 tile, from L2
+    port = rec["cu_port"]
+    tiles = (H // 8) * (W // 32) * (2 * F + B) * g.num_block / rec["launches_per_step"]
+    assert abs(port["l2_weight_stream_mbytes_per_launch"] * 1e6 - 73728 * tiles) < 1e4
+    assert abs(port["mbytes_per_launch"] - rec["mbytes_per_launch"] - port["l2_weight_stream_mbytes_per_launch"]) < 0.02
     # bf16 trunk at 1080p: conv1_i + conv10_i, shared half, per-frame half = 5F + 4B tiles of P x 128 B over three launches
     rb = bench.conv3x3_roofline(g, {"conv3x3": {"ms": 3.0, "launches": 30}}, 1, 270, 480, "bf16", True, "cfg4")
     assert abs(rb["mbytes_per_launch"] * 1e6 - 270 * 480 * 128 * (5 * 7 + 4) / 3) < 1e4
