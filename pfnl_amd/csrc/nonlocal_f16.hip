@@ -534,7 +534,10 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_sw_kernel(const flo
     constexpr int NQ = SPLIT ? 18 : 6, NR = SPLIT ? 24 : 12;
     // (an opaque use where a value is written: see the header - LLVM would sink the softmax to the MFMA that consumes it)
 #define NP_PIN(v_) asm volatile("" : "+v"(v_))
-    constexpr int AHEAD = 4;                                        // reads in flight in front of the one in use
+#ifndef NP_AHEAD
+#define NP_AHEAD 4
+#endif
+    constexpr int AHEAD = NP_AHEAD;                                 // reads in flight in front of the one in use (<= 6)
     constexpr int RING = AHEAD + 2;
     bf16x8 rb[RING];
     auto half_body = [&](auto hc, const unsigned char* qbuf, const unsigned char* vbuf, int kt_fill, int s_fill) __attribute__((always_inline)) {
@@ -597,6 +600,8 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_sw_kernel(const flo
             if (q0_ == 2) read(std::integral_constant<int, 2>{});
             if (q0_ == 3) read(std::integral_constant<int, 3>{});
             if (q0_ == 4) read(std::integral_constant<int, 4>{});
+            if (q0_ == 5) read(std::integral_constant<int, 5>{});
+            if (q0_ == 6) read(std::integral_constant<int, 6>{});
         }
         __builtin_amdgcn_sched_barrier(0);
         float tmax = 0.f, tsw = 0.f, alpha = 1.f, shift = 0.f;
@@ -720,6 +725,9 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_sw_kernel(const flo
         }
     };
 
+#ifdef NP_PRIO_YOUNG   /* experiment: static priority for the younger half of the workgroup */
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     int s_cur = 0, s_prv = G::NSLOT - 1, s_nxt = 1;                 // ring slots of tiles t, t - 1, t + 1
     {   // S^T of the first half (plain: nothing to overlap with yet)
         const unsigned char* const kah = sm + xl * NF_KROW + kh * 16;

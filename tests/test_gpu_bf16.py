@@ -320,3 +320,16 @@ def test_bf16_3x3_kernel_generations(sel):
                        capture_output=True, text=True, timeout=900, env=env, cwd=os.path.dirname(here))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_round4_schedules_are_deterministic_and_bit_equal_across_generations():
+    """tools/soak_r04.py: the kernels whose LDS traffic is ordered by counted `s_waitcnt vmcnt` waits (the third-generation bf16 3x3
+    kernel, the software-pipelined non-local kernel) - every forward repeated and compared bit for bit with its first run, and the bf16
+    forward bit for bit with the second-generation kernels' output (same arithmetic, other schedule)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_r04.py"), "4"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and "soak_r04: ok" in r.stdout, r.stdout[-1500:] + r.stderr[-800:]
+

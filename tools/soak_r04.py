@@ -1,0 +1,54 @@
+"""Race detector for the round-4 kernels whose LDS traffic is ordered by counted `s_waitcnt vmcnt` waits and workgroup barriers only
+(conv_bf16_v3.hip: halo pieces by LDS-DMA into buffers that double as scratch; nl_attn_f16_sw_kernel: a ring of LDS-DMA tiles): a piece that
+lands late or a slot that is refilled early shows up as run-to-run NONDETERMINISM.  Every forward below is repeated and compared bit for
+bit with its first run; the bf16 forward is also compared bit for bit with the second-generation kernels' (same arithmetic, other schedule),
+whose output a child process with PFNL_BF16_V3=0 writes first.
+usage: python tools/soak_r04.py [repeats]"""
+import os, subprocess, sys, tempfile
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from pfnl_amd import synth
+from pfnl_amd.engine import PFNLEngine
+from pfnl_amd.spec import PFNLGeometry
+
+CASES = [("bf16", 1, 270, 480), ("bf16", 2, 96, 160), ("fp32", 1, 270, 480), ("fp32", 4, 128, 128), ("bf16", 1, 66, 130)]
+
+
+def run(prec, B, H, W, reps):
+    g = PFNLGeometry()
+    e = PFNLEngine(g)
+    e.load_weights(synth.synthetic_weights(g, seed=0))
+    if prec == "bf16":
+        e.set_option("precision", "bf16")
+    x = torch.from_numpy(synth.uniform_clips(B, 7, H, W, seed=B + H)).cuda()
+    first = None
+    for r in range(reps):
+        y = e.forward(x)
+        y = y.cpu().numpy() if hasattr(y, "cpu") else np.asarray(y)
+        if first is None:
+            first = y.copy()
+        elif not np.array_equal(first, y):
+            raise SystemExit("NONDETERMINISTIC: %s %dx7x%dx%d run %d differs from run 0 in %d values (max %g)"
+                             % (prec, B, H, W, r, int((first != y).sum()), float(np.abs(first - y).max())))
+    e.close()
+    return first
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--child":
+        out = {"%s_%d_%d_%d" % c: run(*c, 1) for c in CASES if c[0] == "bf16"}
+        np.savez(sys.argv[2], **out)
+        sys.exit(0)
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 25
+    with tempfile.TemporaryDirectory() as d:
+        ref = os.path.join(d, "v2.npz")
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--child", ref], check=True, env=dict(os.environ, PFNL_BF16_V3="0"))
+        v2 = np.load(ref)
+        for c in CASES:
+            y = run(*c, reps)
+            key = "%s_%d_%d_%d" % c
+            if key in v2.files and not np.array_equal(v2[key], y):
+                raise SystemExit("bf16 forward %s: third-generation 3x3 kernels differ from the second generation's in %d values"
+                                 % (key, int((v2[key] != y).sum())))
+            print("%s %dx7x%dx%d: %d runs bit-identical%s" % (*c, reps, "; equal to the second-generation kernels' output" if key in v2.files else ""))
+    print("soak_r04: ok")
