@@ -241,33 +241,17 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
     dma_share(cu, true, 0);
     request_inputs(cu, true);
     B3_PSTAMP();                                                // P3: halo + input requests issued
-    // bias (and conv10_i's) by LDS-DMA, 16 lanes x 16 B, IN FRONT of the weight pieces (the wait below counts the late ones); a load the compiler sees would make its wait for it cover the pieces too
-    if (wave == 0 && lane < 16)
-        b3_dma16(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, 256, 0x00020000), lds0 + 2 * B3_TILE_BYTES + B3_W_BYTES, lane * 16);
+    // weights + bias -> LDS (once per workgroup; behind the halo requests, so that the two streams overlap)
+#pragma unroll
+    for (int k = 0; k < B3_W_BYTES / 16 / B3_THREADS; ++k)
+        reinterpret_cast<b3u4*>(wl)[k * B3_THREADS + tid] = reinterpret_cast<const b3u4*>(p.wpack)[k * B3_THREADS + tid];
+    if (tid < 64) bl[tid] = p.bias[tid];
     if constexpr (WITH10) {
-        if (wave == 1 && lane < 16)
-            b3_dma16(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x_bias), 0, 256, 0x00020000), lds0 + 2 * B3_TILE_BYTES + B3_W_BYTES + 256, lane * 16);
+        if (tid >= 64 && tid < 128) bl[tid] = p.x_bias[tid - 64];  // (a global load at the chain's end would sit on the critical path)
     }
-    // weights -> LDS by LDS-DMA as well (the pack is the LDS image: piece w = 2 slice + mt, slice = (ky 3 + kx) 4 + ks; this wave's pieces
-    // w = wave + 8 j have k-step wave >> 1, column tap j % 3, row tap j / 3), in TWO parts: a workgroup's prologue moves 72 KB of
-    // weights + 44 KB of halo through a port that takes ~11 B per clock - 10 k cycles - and the first six MFMA groups of a tile only
-    // read the slices with 4 kx + ks < 6.  Those go first and are waited for here; the rest may still be on its way when tile 0 starts and
-    // is waited for in front of tile 0's mid barrier (every wave for its own pieces: behind that barrier all of it is there).
-    {
-        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.wpack), 0, B3_W_BYTES, 0x00020000);
-        const int ks0 = wave >> 1;
-#pragma unroll
-        for (int part = 0; part < 2; ++part)
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const bool early = 4 * (j % 3) + ks0 < 6;           // (wave-uniform)
-                if (early == (part == 0)) b3_dma16(rsW, lds0 + 2 * B3_TILE_BYTES + (wave + 8 * j) * 1024, (wave + 8 * j) * 1024 + lane * 16);
-            }
-    }
-    B3_PSTAMP();                                                // P4: weights requested
-    if (wave < 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // all but the late weight pieces (waves 0-3: three of nine, waves 4-7: six)
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    B3_PSTAMP();                                                // P5: halo and the early weights landed
+    B3_PSTAMP();                                                // P4: weights written
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    B3_PSTAMP();                                                // P5: halo landed
     __syncthreads();
     f32x16 bias16;                                                  // the tile's first MFMAs take C = bias (register r of a lane = channel ech + r)
 #pragma unroll
@@ -345,7 +329,6 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
         group(std::integral_constant<int, 4>{});
         group(std::integral_constant<int, 5>{});
         B3_STAMP();                                                 // 1: groups 0-5 issued
-        if (u == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the late weight pieces of the prologue (groups 6-11 read them)
         B3_BARRIER();                                               // interval boundary (the other half's dump | lines)
         B3_STAMP();                                                 // 2
         group(std::integral_constant<int, 6>{});
