@@ -239,6 +239,17 @@ def test_nonlocal_key_counts_around_tile_edges(N, kernel):
     assert np.abs(got - ref).max() < tol, np.abs(got - ref).max()
 
 
+def test_nonlocal_f16_random_geometries_short():
+    """tools/stress_nl.py (3 900 geometries clean when the software-pipelined kernel was committed): a short run of it - random B, T, H, W
+    against the fp64 spec in both operand forms."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import stress_nl
+    n, worst = stress_nl.run(seed=11, seconds=8.0, max_iters=60)
+    assert n >= 10 and worst["split16"] < 2e-5 and worst["f16"] < 2e-3, (n, worst)
+
+
 def test_nonlocal_f16_first_kernel_still_serves():
     """PFNL_NL_SW=0 (and any batch whose packed operands exceed 2 GB) runs nl_attn_f16_kernel, on the same packed arrays (their key rows
     are padded since round 4).  The choice is read once per process: the non-local tests again, in a process of their own."""
