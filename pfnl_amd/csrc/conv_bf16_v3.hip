@@ -57,6 +57,11 @@ __device__ __forceinline__ void b3_dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rs) : "memory");
 }
+__device__ __forceinline__ void b3_dma4(__amdgpu_buffer_rsrc_t rs, unsigned lds_dst, int voff) {   // one dword per lane: LDS [lds_dst + 4 L]
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rs) : "memory");
+}
 __device__ __forceinline__ f32x16 b3_mfma(b3h8 a, b3h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 b3_to_f32(b3u2 v) {
     return f32x4{__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xffff0000u),
@@ -241,17 +246,33 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
     dma_share(cu, true, 0);
     request_inputs(cu, true);
     B3_PSTAMP();                                                // P3: halo + input requests issued
-    // weights + bias -> LDS (once per workgroup; behind the halo requests, so that the two streams overlap)
-#pragma unroll
-    for (int k = 0; k < B3_W_BYTES / 16 / B3_THREADS; ++k)
-        reinterpret_cast<b3u4*>(wl)[k * B3_THREADS + tid] = reinterpret_cast<const b3u4*>(p.wpack)[k * B3_THREADS + tid];
-    if (tid < 64) bl[tid] = p.bias[tid];
+    // bias (and conv10_i's) by LDS-DMA, IN FRONT of the weight pieces (the wait below counts the late ones): one dword per lane
+    if (wave == 0) b3_dma4(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, 256, 0x00020000), lds0 + 2 * B3_TILE_BYTES + B3_W_BYTES, lane * 4);
     if constexpr (WITH10) {
-        if (tid >= 64 && tid < 128) bl[tid] = p.x_bias[tid - 64];  // (a global load at the chain's end would sit on the critical path)
+        if (wave == 1) b3_dma4(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x_bias), 0, 256, 0x00020000), lds0 + 2 * B3_TILE_BYTES + B3_W_BYTES + 256, lane * 4);
     }
-    B3_PSTAMP();                                                // P4: weights written
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    B3_PSTAMP();                                                // P5: halo landed
+    // weights -> LDS by LDS-DMA as well (the pack is the LDS image: piece w = 2 slice + mt, slice = (ky 3 + kx) 4 + ks; this wave's pieces
+    // w = wave + 8 j have k-step wave >> 1, column tap j % 3, row tap j / 3), in TWO parts: a workgroup's prologue moves 72 KB of
+    // weights + 44 KB of halo through a port that takes ~11 B per clock - 10 k cycles - and up to its mid barrier a tile only reads the
+    // slices with 4 kx + ks < 7: groups 0-5, AND group 6, whose operands group 5 requests one group ahead (with "< 6" here the stress
+    // found a rare wrong tile: group 5's prefetch read late slices before anything had waited for them).  Those go first and are waited
+    // for here; the rest may still be on its way when tile 0 starts and is waited for in front of tile 0's mid barrier (every wave for its
+    // own pieces, group B in front of the leading barrier that pairs with it: behind that barrier all of it is there).
+    {
+        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.wpack), 0, B3_W_BYTES, 0x00020000);
+        const int ks0 = wave >> 1;
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const bool early = 4 * (j % 3) + ks0 < 7;           // (wave-uniform)
+                if (early == (part == 0)) b3_dma16(rsW, lds0 + 2 * B3_TILE_BYTES + (wave + 8 * j) * 1024, (wave + 8 * j) * 1024 + lane * 16);
+            }
+    }
+    B3_PSTAMP();                                                // P4: weights requested
+    if (wave < 6) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // all but the late weight pieces (waves 0-5: three of nine, waves 6-7: six)
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    B3_PSTAMP();                                                // P5: halo and the early weights landed
     __syncthreads();
     f32x16 bias16;                                                  // the tile's first MFMAs take C = bias (register r of a lane = channel ech + r)
 #pragma unroll
@@ -263,6 +284,9 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
         bias16[4 * q + 3] = b4.w;
     }
     if (grp) {                                                      // group B: two intervals behind group A
+        // (group B's first leading barrier is group A's mid barrier of tile 0, behind which A reads the LATE weight slices - group B's
+        // share of them included: it has to have landed before group B arrives there)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         dma_share(nx, nu > 1, 1);                                   // its share of tile 1's halo (nothing follows it that B3_PIECES_LANDED
         B3_BARRIER();                                               // could count on: an unconditional wait, between the two barriers)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -329,6 +353,7 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
         group(std::integral_constant<int, 4>{});
         group(std::integral_constant<int, 5>{});
         B3_STAMP();                                                 // 1: groups 0-5 issued
+        if (u == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the late weight pieces of the prologue (groups 6-11 read them)
         B3_BARRIER();                                               // interval boundary (the other half's dump | lines)
         B3_STAMP();                                                 // 2
         group(std::integral_constant<int, 6>{});
