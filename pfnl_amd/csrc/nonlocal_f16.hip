@@ -58,16 +58,22 @@ __device__ __forceinline__ unsigned short bf16_bits(float f) {   // binary16, ro
 }
 __device__ __forceinline__ float bf16_float(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
 
-// X [B][N][CP] fp32 (nl_pack_kernel) -> Khi, Klo [B][Npad][96] bf16;  Vthi, Vtlo [B][96][Npad] bf16, keys permuted per
-// 32-block, channel C = 1 (the row-sum channel), channels > C = 0
-__global__ void nl_pack_f16_kernel(const float* __restrict__ X, uint16_t* __restrict__ Khi, uint16_t* __restrict__ Klo,
-                                    uint16_t* __restrict__ Vthi, uint16_t* __restrict__ Vtlo, int B, int N, int Npad, int C,
-                                    int CPin) {
-    const size_t total = (size_t)B * Npad * NF_CP;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % NF_CP);
-        const int n = (int)((i / NF_CP) % Npad);
-        const int b = (int)(i / ((size_t)NF_CP * Npad));
+// X [B][N][CP] fp32 (nl_pack_kernel) -> Khi, Klo [B][Npad][96] binary16;  Vthi, Vtlo [B][96][Npad] binary16, keys permuted per
+// 32-block, channel C = 1 (the row-sum channel), channels > C = 0.  One workgroup per 32-key block: rows of X in, rows of K out, the
+// transposed block through LDS so that V^T leaves as 64-byte row segments (round 4: the element-per-thread form wrote V^T as 2-byte
+// stores a row apart - 38 us at 1080p for 31 MB).
+__global__ __launch_bounds__(256) void nl_pack_f16_kernel(const float* __restrict__ X, uint16_t* __restrict__ Khi, uint16_t* __restrict__ Klo,
+                                                          uint16_t* __restrict__ Vthi, uint16_t* __restrict__ Vtlo, int B, int N, int Npad, int C,
+                                                          int CPin) {
+    __shared__ uint16_t vth[NF_CP][34], vtl[NF_CP][34];             // [channel][position in the block] (+2: odd word stride)
+    const int nblk = Npad / 32;
+    const int b = blockIdx.x / nblk, n0 = (blockIdx.x - b * nblk) * 32;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 32 * NF_CP / 256; ++j) {
+        const int i = tid + 256 * j;
+        const int kk = i / NF_CP, c = i - kk * NF_CP;
+        const int n = n0 + kk;
         const float v = (n < N && c < C) ? X[((size_t)b * N + n) * CPin + c] * NF_XSCALE : 0.f;
         const unsigned short hi = bf16_bits(v);
         const unsigned short lo = bf16_bits(v - bf16_float(hi));
@@ -75,12 +81,20 @@ __global__ void nl_pack_f16_kernel(const float* __restrict__ X, uint16_t* __rest
         // positive entry there (nl_attn_f16_sw_kernel: 1024) gets a logit of -4 000 for them - the key mask as DATA, no code
         Khi[((size_t)b * Npad + n) * NF_CP + c] = (n >= N && c == C) ? (unsigned short)0xfbff : hi;
         Klo[((size_t)b * Npad + n) * NF_CP + c] = lo;
-        // position of key n inside its 32-block: key = (e&3) + 8(2t + (e>>2)) + 4kh  ->  pos = 16t + 8kh + e
-        const int kb = n & 31;
-        const int e = (kb & 3) | (((kb >> 3) & 1) << 2), kh = (kb >> 2) & 1, t = kb >> 4;
-        const size_t vp = ((size_t)b * NF_CP + c) * Npad + (n & ~31) + 16 * t + 8 * kh + e;
-        Vthi[vp] = c == C ? (unsigned short)0x3c00 : hi;             // 1.0 (binary16)
-        Vtlo[vp] = c == C ? (unsigned short)0 : lo;
+        // position of key kk inside its 32-block: key = (e&3) + 8(2t + (e>>2)) + 4kh  ->  pos = 16t + 8kh + e
+        const int e = (kk & 3) | (((kk >> 3) & 1) << 2), kh = (kk >> 2) & 1, t = kk >> 4;
+        const int pos = 16 * t + 8 * kh + e;
+        vth[c][pos] = c == C ? (unsigned short)0x3c00 : hi;         // 1.0 (binary16)
+        vtl[c][pos] = c == C ? (unsigned short)0 : lo;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16 * NF_CP / 256; ++j) {                    // 96 rows x 16 pairs of positions
+        const int i = tid + 256 * j;
+        const int c = i >> 4, pp = (i & 15) * 2;
+        const size_t vp = ((size_t)b * NF_CP + c) * Npad + n0 + pp;
+        *reinterpret_cast<unsigned*>(Vthi + vp) = (unsigned)vth[c][pp] | ((unsigned)vth[c][pp + 1] << 16);
+        *reinterpret_cast<unsigned*>(Vtlo + vp) = (unsigned)vtl[c][pp] | ((unsigned)vtl[c][pp + 1] << 16);
     }
 }
 
@@ -845,9 +859,7 @@ hipError_t launch_nl_attn_f16(const float* X, float* Xo, const float* Wp, const 
     uint16_t* Vthi = Klo + (size_t)B * npad * NF_CP;
     uint16_t* Vtlo = Vthi + (size_t)B * NF_CP * npad;
     {
-        const size_t total = (size_t)B * npad * NF_CP;
-        const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-        hipLaunchKernelGGL(nl_pack_f16_kernel, dim3(blocks), dim3(256), 0, s, X, Khi, Klo, Vthi, Vtlo, B, N, npad, C, CP);
+        hipLaunchKernelGGL(nl_pack_f16_kernel, dim3(B * (npad / 32)), dim3(256), 0, s, X, Khi, Klo, Vthi, Vtlo, B, N, npad, C, CP);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
