@@ -267,28 +267,37 @@ __global__ __launch_bounds__(256, 2) void nl_attn_kernel(const float* __restrict
     // pad columns of the output are never read by conv0.
 }
 
-// out = X + sum_p e^{m_p - m} Zp_p / sum_p e^{m_p - m} l_p + b'   (merge of the key-split partials)
+// out = X + sum_p e^{m_p - m} Zp_p / sum_p e^{m_p - m} l_p + b'   (merge of the key-split partials); four channels per thread (C and CP
+// are multiples of 4): the weights of a query are computed once per 16 bytes moved, not once per 4
 __global__ void nl_merge_kernel(const float* __restrict__ X, const float* __restrict__ Zp,
                                 const float* __restrict__ ML, const float* __restrict__ bp,
                                 float* __restrict__ Xo, int B, int N, int C, int CP, int ks, int q0, int q1) {
     const size_t nq = (size_t)(q1 - q0);
-    const size_t total = (size_t)B * nq * CP;
+    const int cq = CP >> 2;
+    const size_t total = (size_t)B * nq * cq;
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (size_t)gridDim.x * blockDim.x) {
-        const int co = (int)(j % CP);
+        const int co = (int)(j % cq) * 4;
         if (co >= C) continue;
-        const size_t qn = q0 + (j / CP) % nq;
-        const size_t b = j / ((size_t)CP * nq);
+        const size_t qn = q0 + (j / cq) % nq;
+        const size_t b = j / ((size_t)cq * nq);
         const size_t i = (b * N + qn) * CP + co;
         float m = -INFINITY;
         for (int p = 0; p < ks; ++p) m = fmaxf(m, ML[((b * ks + p) * N + qn) * 2]);
-        float num = 0.f, den = 0.f;
+        f32x4 num = {0.f, 0.f, 0.f, 0.f};
+        float den = 0.f;
         for (int p = 0; p < ks; ++p) {
             const float* ml = ML + ((b * ks + p) * N + qn) * 2;
             const float w = exp2f(ml[0] - m);                 // the partial maxima are base-2 logits
-            num = fmaf(w, Zp[((b * ks + p) * N + qn) * CP + co], num);
+            const f32x4 z = *reinterpret_cast<const f32x4*>(Zp + ((b * ks + p) * N + qn) * CP + co);
+            num.x = fmaf(w, z.x, num.x);
+            num.y = fmaf(w, z.y, num.y);
+            num.z = fmaf(w, z.z, num.z);
+            num.w = fmaf(w, z.w, num.w);
             den = fmaf(w, ml[1], den);
         }
-        Xo[i] = X[i] + num / den + bp[co];
+        const f32x4 x = *reinterpret_cast<const f32x4*>(X + i);    // (X, Xo, Zp: rows of CP floats from 16-byte aligned bases; bp: only float-aligned)
+        *reinterpret_cast<f32x4*>(Xo + i) = f32x4{x.x + num.x / den + bp[co], x.y + num.y / den + bp[co + 1], x.z + num.z / den + bp[co + 2],
+                                                  x.w + num.w / den + bp[co + 3]};
     }
 }
 
@@ -432,7 +441,7 @@ hipError_t launch_nl_merge(const float* X, const float* Zp, const float* ML, con
                            hipStream_t s, int q0, int q1) {
     const int CP = nl_padded_ch(C);
     if (q1 < 0) q1 = N;
-    const size_t total = (size_t)B * (q1 - q0) * CP;
+    const size_t total = (size_t)B * (q1 - q0) * (CP / 4);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(nl_merge_kernel, dim3(blocks), dim3(256), 0, s, X, Zp, ML, bp, Xo, B, N, C, CP, ks, q0, q1);
     return hipGetLastError();
