@@ -429,6 +429,9 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if PFNL_S16_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(PFNL_S16_PRIO);
+#endif
     const int rp = wave >> 1;
     const int nt = wave & 1;
     const int H = p.H, W = p.W;
@@ -648,6 +651,47 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#if PFNL_S16_SPREAD
+                // the next sub-step's operand reads between this sub-step's MFMAs (conv_split16.hip, conv3x3_c1c10_kernel)
+                {
+                    constexpr int S1 = S + 1, g1 = S1 / 3, ky1 = S1 % 3;
+                    constexpr bool RD = S < 17;
+                    constexpr bool FIRST = PAR == 0 && S == 0;   // a tile's first products: C = the chain's shared half + bias (or 0 for that half itself)
+                    f32x16 zero;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+                    const sfh8 wh = Wv[S & 1][0], wo = Wv[S & 1][1];
+                    accm[0] = sf_mfma(X[ky][0], wh, FIRST ? pbv[0] : accm[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (RD) {
+                        Wv[S1 & 1][0] = SF_WT(g1, ky1, 0);
+                        Wv[S1 & 1][1] = SF_WT(g1, ky1, 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    accm[1] = sf_mfma(X[ky + 1][0], wh, FIRST ? pbv[1] : accm[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (RD) {
+                        if constexpr (ky1 == 0) {
+                            X[0][0] = SF_PX(g1, 0, 0);
+                            X[0][1] = SF_PX(g1, 0, 1);
+                        } else {
+                            X[ky1 + 1][0] = SF_PX(g1, ky1 + 1, 0);
+                            X[ky1 + 1][1] = SF_PX(g1, ky1 + 1, 1);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    accc[0] = sf_mfma(X[ky][0], wo, FIRST ? zero : accc[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (RD && ky1 == 0) {
+                        X[1][0] = SF_PX(g1, 1, 0);
+                        X[1][1] = SF_PX(g1, 1, 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    accc[1] = sf_mfma(X[ky + 1][0], wo, FIRST ? zero : accc[1]);
+                    accc[0] = sf_mfma(X[ky][1], wh, accc[0]);
+                    accc[1] = sf_mfma(X[ky + 1][1], wh, accc[1]);
+                }
+#else
                 if constexpr (S < 17) {
                     constexpr int S1 = S + 1, g1 = S1 / 3, ky1 = S1 % 3;
                     Wv[S1 & 1][0] = SF_WT(g1, ky1, 0);
@@ -680,6 +724,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
                 }
                 accc[0] = sf_mfma(X[ky][1], wh, accc[0]);
                 accc[1] = sf_mfma(X[ky + 1][1], wh, accc[1]);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             };
             substep(std::integral_constant<int, 0>{});

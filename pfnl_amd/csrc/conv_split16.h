@@ -4,6 +4,14 @@
 #include <stddef.h>
 #include <stdint.h>
 
+// schedule switches of the two launches of a progressive-fusion block (conv3x3_c1c10_kernel, conv3x3_sf_chain_kernel)
+#ifndef PFNL_S16_SPREAD
+#define PFNL_S16_SPREAD 1    // 1: the next sub-step's operand reads between the MFMAs of the current one instead of in front of them
+#endif
+#ifndef PFNL_S16_PRIO
+#define PFNL_S16_PRIO 1      // > 0: s_setprio of waves 4-7 (the younger wave of every SIMD)
+#endif
+
 namespace pfnl {
 
 struct ConvSplitParams {

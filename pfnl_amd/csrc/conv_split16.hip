@@ -728,6 +728,9 @@ __device__ __forceinline__ void k1_dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds
 #ifndef K1_STORE_AUX
 #define K1_STORE_AUX CS_STORE_AUX
 #endif
+#ifndef K1_COMMIT_PAIR8
+#define K1_COMMIT_PAIR8 1     // halo commit: the two pixels of a 16-lane ds_write_b64 group are 8 apart (bank-conflict-free), not neighbours
+#endif
 constexpr int K1_LDS_BYTES = CS_LDS_BYTES + 64 * 4;                 // + conv10_i's bias
 
 __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitParams p) {
@@ -740,6 +743,9 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef PFNL_S16_TIMING
     int dbg_n = 0;
+#endif
+#if PFNL_S16_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(PFNL_S16_PRIO);      // the younger wave of every SIMD above the older one (tools/ubench/conv_core V3)
 #endif
     const int rp = wave >> 1;                                       // rows 2rp, 2rp+1 of the tile
     const int mt = wave & 1;                                        // output channels 32mt .. 32mt+31 (of conv1_i and of conv10_i)
@@ -779,7 +785,15 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
         // surplus threads redo a piece of the last pixel - the one with THEIR channel piece (tid & 7), so that the recomputed source
         // offset below and the LDS address agree and the duplicate writes carry the same bytes
         const int id = k * CS_THREADS + tid < CS_PIECES ? k * CS_THREADS + tid : CS_PIECES - 8 + (tid & 7);
-        const int pix = id >> 3, c = id & 7;
+        int pix = id >> 3;
+        const int c = id & 7;
+#if K1_COMMIT_PAIR8
+        // a ds_write_b64 is served 16 lanes (two pixels of 8 pieces) at a time over 32 banks = one 128-byte pixel slot: with pixels p, p + 1
+        // both hi halves (and then both lo' halves) fall on the same 16 banks - 2-way conflicts on every commit (SQ_LDS_BANK_CONFLICT 1.3e6
+        // per launch, profiles/r04_pmc.md).  Paired as (p, p + 8) the swizzle term (px >> 1) & 7 differs in bit 2: one pixel's hi half
+        // occupies the banks of the other's lo' half.  (the last 4 pixels of the 340 keep their order)
+        if (pix < (CS_IH * CS_IW & ~15)) pix = (pix & ~15) | ((pix & 1) << 3) | ((pix & 15) >> 1);
+#endif
         const int py = pix / CS_IW, px = pix - py * CS_IW;
         lpk[k] = ((py * CS_IW + px) * 128 + 8 * (c & 1) + (((c >> 1) ^ ((px >> 1) & 7)) << 4)) | (py << 16) | (px << 24);
     }
@@ -1037,6 +1051,47 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#if PFNL_S16_SPREAD
+                // the next sub-step's operand reads ride BETWEEN this sub-step's MFMAs (M w w M x x M x x M M M, every position pinned):
+                // as a clump in front of the six MFMAs they are ~100 cycles in which this wave's share of the matrix pipe idles
+                // (tools/ubench/conv_core: 5.66 -> 5.02 us per unit for the bare core)
+                {
+                    constexpr int S1 = S + 1, g1 = S1 / 3, ky1 = S1 % 3;
+                    constexpr bool RD = S < 17;
+                    constexpr bool FIRST = PAR == 0 && S == 0;
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    const h8 wh = Wv[S & 1][0], wo = Wv[S & 1][1];
+                    accm[0] = mfma_f16(wh, X[ky][0], FIRST ? bias16 : accm[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (RD) {
+                        Wv[S1 & 1][0] = CS_WT(g1, ky1, 0);
+                        Wv[S1 & 1][1] = CS_WT(g1, ky1, 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    accm[1] = mfma_f16(wh, X[ky + 1][0], FIRST ? bias16 : accm[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (RD) {
+                        if constexpr (ky1 == 0) {
+                            X[0][0] = CS_PX(g1, 0, 0);
+                            X[0][1] = CS_PX(g1, 0, 1);
+                        } else {
+                            X[ky1 + 1][0] = CS_PX(g1, ky1 + 1, 0);
+                            X[ky1 + 1][1] = CS_PX(g1, ky1 + 1, 1);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    accc[0] = mfma_f16(wo, X[ky][0], FIRST ? zero : accc[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (RD && ky1 == 0) {
+                        X[1][0] = CS_PX(g1, 1, 0);
+                        X[1][1] = CS_PX(g1, 1, 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    accc[1] = mfma_f16(wo, X[ky + 1][0], FIRST ? zero : accc[1]);
+                    accc[0] = mfma_f16(wh, X[ky][1], accc[0]);
+                    accc[1] = mfma_f16(wh, X[ky + 1][1], accc[1]);
+                }
+#else
                 if constexpr (S < 17) {
                     constexpr int S1 = S + 1, g1 = S1 / 3, ky1 = S1 % 3;
                     Wv[S1 & 1][0] = CS_WT(g1, ky1, 0);
@@ -1067,6 +1122,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
                 }
                 accc[0] = mfma_f16(wh, X[ky][1], accc[0]);
                 accc[1] = mfma_f16(wh, X[ky + 1][1], accc[1]);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             };
             substep(std::integral_constant<int, 0>{});

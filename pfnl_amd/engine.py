@@ -31,6 +31,7 @@ class PFNLEngine:
         _capi.check(self._lib.pfnl_create(C.byref(cfg), C.byref(h)))
         self._h = h
         self._ready = False
+        self._options: Dict[str, str] = {}       # what set_option was called with (the library keeps no getter)
 
     # ---- lifetime --------------------------------------------------------------------------
     def close(self) -> None:
@@ -64,6 +65,11 @@ class PFNLEngine:
     def set_option(self, key: str, value: str) -> None:
         """e.g. ("conv3x3", "auto" | "split16" | "winograd" | "winograd_tile" | "direct"); see include/pfnl_hip.h."""
         _capi.check(self._lib.pfnl_set_option(self._h, key.encode(), value.encode()))
+        self._options[key] = value
+
+    def option(self, key: str, default: Optional[str] = None) -> Optional[str]:
+        """The value this engine's ``set_option(key, ...)`` last took (None / default: never set, the library's default applies)."""
+        return self._options.get(key, default)
 
     def missing_weights(self) -> int:
         n = C.c_int(0)

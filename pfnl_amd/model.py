@@ -303,7 +303,21 @@ class PFNL(VSR):
         # synchronisation of its own); a flagged batch - and the one enqueued behind it before the flag was seen - is computed
         # again on the f32-MFMA kernels, and the rest of the sequence starts there (values beyond binary16's range rarely go away
         # from one batch of a video to the next).  The PNGs never hold quantised non-finite values silently.
+        # precision=bf16: `strict_fp32` changes nothing there (its non-local block and conv0 keep their binary16 operands, capi.hip
+        # nl_strict), so the recomputation - and the rest of the sequence - runs at precision=fp32 on the strict kernels: the only
+        # path of the library that covers the whole fp32 range.  Both options are restored when the sequence ends, however it ends.
         state = {"strict": False, "redo_next": False}
+        was_bf16 = eng.option("precision", "fp32") == "bf16"
+        was_strict_engine = eng.option("strict_fp32", "off") == "on"
+
+        def go_strict():
+            stream.synchronize()                                     # no forward of the old configuration is in flight when it changes
+            if was_bf16:
+                eng.set_option("precision", "fp32")
+                print('precision=bf16: a batch left the binary16 range of its non-local block / conv0; recomputed (and the rest of the '
+                      'sequence computed) at precision=fp32, strict_fp32=on')
+            eng.set_option("strict_fp32", "on")
+            state["strict"] = True
 
         def recompute_strict(buf, first_, count_):
             win_ = ops.gather_windows(frames, first_, count_, self.num_frames)
@@ -319,8 +333,7 @@ class PFNL(VSR):
             if not was_strict and (eng.range_flagged() or state["redo_next"]):
                 state["redo_next"] = not state["strict"]             # the batch already in flight ran on the f16 pipe as well
                 if not state["strict"]:
-                    eng.set_option("strict_fp32", "on")
-                    state["strict"] = True
+                    go_strict()
                 recompute_strict(buf, first_, count_)
             elif was_strict:
                 state["redo_next"] = False
@@ -328,32 +341,38 @@ class PFNL(VSR):
             for j in range(count_):
                 jobs.append(pool.submit(imsave_rgb, join(save_path, '{:0>4}.png'.format(first_ + j)), frames_u8[j][0]))
 
-        with ThreadPoolExecutor(max_workers=max(1, int(self.encode_threads))) as pool:
-            for i in range(part):
-                first = i * num_once
-                count = min(num_once, max_frame - first)
-                if count <= 0:
-                    break
-                started, done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                started.record(stream)
-                was_strict = state["strict"]
-                win = ops.gather_windows(frames, first, count, self.num_frames)
-                sr = eng.forward(win)
-                u8 = ops.quantise_u8(sr)
-                k = i & 1
-                if host[k] is None or host[k].shape[0] < count:
-                    host[k] = torch.empty((num_once,) + tuple(u8.shape[1:]), dtype=torch.uint8).pin_memory()
-                host[k][:count].copy_(u8, non_blocking=True)
-                done.record(stream)
-                if inflight is not None:                             # while the GPU runs batch i: batch i-1 goes to the PNG encoders
+        try:
+            with ThreadPoolExecutor(max_workers=max(1, int(self.encode_threads))) as pool:
+                for i in range(part):
+                    first = i * num_once
+                    count = min(num_once, max_frame - first)
+                    if count <= 0:
+                        break
+                    started, done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    started.record(stream)
+                    was_strict = state["strict"]
+                    win = ops.gather_windows(frames, first, count, self.num_frames)
+                    sr = eng.forward(win)
+                    u8 = ops.quantise_u8(sr)
+                    k = i & 1
+                    if host[k] is None or host[k].shape[0] < count:
+                        host[k] = torch.empty((num_once,) + tuple(u8.shape[1:]), dtype=torch.uint8).pin_memory()
+                    host[k][:count].copy_(u8, non_blocking=True)
+                    done.record(stream)
+                    if inflight is not None:                         # while the GPU runs batch i: batch i-1 goes to the PNG encoders
+                        drain(inflight, pool)
+                    inflight = (done, started, host[k], first, count, was_strict)
+                if inflight is not None:
                     drain(inflight, pool)
-                inflight = (done, started, host[k], first, count, was_strict)
-            if inflight is not None:
-                drain(inflight, pool)
-            for j in jobs:
-                j.result()
-        if state["strict"]:                                          # (an engine that was strict from the start never raises the flag)
-            eng.set_option("strict_fp32", "off")
+                for j in jobs:
+                    j.result()
+        finally:
+            if state["strict"]:                                      # back to the caller's configuration (also when an encoder raised)
+                stream.synchronize()
+                if not was_strict_engine:
+                    eng.set_option("strict_fp32", "off")
+                if was_bf16:
+                    eng.set_option("precision", "bf16")
         all_time = np.array(all_time)
         avg = np.mean(all_time[1:]) if len(all_time) > 1 else float('nan')
         print('spent {} s in total and {} s in average'.format(np.sum(all_time), avg))

@@ -680,6 +680,45 @@ def test_harness_reruns_out_of_range_batches(tmp_path):
     eng.close()
 
 
+def test_harness_reruns_out_of_range_batches_bf16(tmp_path):
+    """under precision=bf16 `strict_fp32` changes no kernel (the non-local block and conv0 keep binary16 operands), so
+    the recomputation of a flagged batch re-ran the same kernels, cleared the flag and wrote quantised non-finite values.  Now the flagged
+    batch and the rest of the sequence run at precision=fp32 + strict_fp32 (the only path that covers the whole fp32 range) and the
+    engine returns to bf16 afterwards."""
+    from PIL import Image
+    from model.pfnl import PFNL
+    from pfnl_amd import model as M
+    rng = np.random.default_rng(22)
+    lr_u8 = rng.integers(0, 256, size=(7, 12, 20, 3), dtype=np.uint8)
+    seq = tmp_path / "seqB"
+    (seq / "blur4").mkdir(parents=True)
+    for i, im in enumerate(lr_u8):
+        Image.fromarray(im).save(seq / "blur4" / f"{i:04d}.png")
+    geom = PFNLGeometry(num_block=1)
+    w = synth.synthetic_weights(geom, seed=1)
+    w["nlvsr/conv0/kernel"] = (w["nlvsr/conv0/kernel"] * 4e5).astype(np.float32)
+    w["nlvsr/convmerge2/kernel"] = (w["nlvsr/convmerge2/kernel"] * 1e-6).astype(np.float32)
+    m = PFNL()
+    m.num_block = 1
+    m.precision = "bf16"
+    m.save_dir = str(tmp_path / "none")
+    m.set_weights(w)
+    m.test_video_lr(str(seq), name="out", part=3)
+    got = np.stack([np.asarray(Image.open(p)) for p in sorted((seq / "out").glob("*.png"))])
+    eng = _engine_with(geom, w)
+    eng.set_option("strict_fp32", "on")
+    lrs = (lr_u8 / 255.).astype(np.float32)
+    sr = eng.forward(np.ascontiguousarray(M.sliding_windows(lrs, 7)))
+    assert np.isfinite(sr).all()
+    assert np.array_equal(got, M.quantise(sr[:, 0]))               # every batch: the first one raised the flag
+    me = m._get_engine()
+    assert me.range_flagged() is False
+    assert me.option("precision") == "bf16" and me.option("strict_fp32") == "off"   # the caller's configuration is back
+    with pytest.raises(RuntimeError):                               # ... and a bf16 forward of these weights still reports the range
+        m.forward(lrs[None, :7])
+    eng.close()
+
+
 def test_host_pointer_staging_paths():
     """pfnl_forward with host pointers (what replaces sess.run, reference model/pfnl.py:249-253): pageable buffers go through the
     handle's pinned strips on worker threads, page-locked buffers are DMA targets as they are, small transfers take the
