@@ -263,6 +263,12 @@ int pfnl_op_conv3x3_bf16(const uint16_t* in, const float* kernel_host, const flo
  * product).  Same contract as pfnl_op_conv3x3_winograd (any H, W); out may alias resid. */
 int pfnl_op_conv3x3_split16(const float* in, const float* kernel_host, const float* bias_host, const float* addend, int add_div,
                             const float* resid, float* out, int items, int H, int W, int act, void* stream);
+/* The same convolution as Winograd F(2x2,3x3) on the f16 matrix pipe with split operands (option conv3x3=wsplit, conv_wsplit.hip;
+ * replaces the Conv2D nodes of reference model/pfnl.py:49,51 as run at :66,69): U = G g G^T (fp64 on the host) and V = B^T d B (fp32 in
+ * the kernel) are each taken as f16(x) + f16((x - f16(x)) 2^11) 2^-11, fp32 accumulation, 2.25x fewer MFMAs than the direct form; the
+ * transformed weights stay in the registers of a 4-wave workgroup.  Same contract as pfnl_op_conv3x3_split16; out may alias resid. */
+int pfnl_op_conv3x3_wsplit(const float* in, const float* kernel_host, const float* bias_host, const float* addend, int add_div,
+                           const float* resid, float* out, int items, int H, int W, int act, void* stream);
 /* conv1_i + conv10_i of a progressive-fusion block as ONE launch of the fp32 path (reference model/pfnl.py:66-68;
  * conv3x3_c1c10_kernel, option split16_c10): in [clips*T,H,W,64] fp32 (device) -> out1 = lrelu(conv3x3(in; k1) + b1) per frame,
  * base = lrelu(conv1x1(concat_t out1; k10) + b10) [clips,H,W,64]; k1_host HWIO [3,3,64,64], k10_host HWIO [1,1,64T,64].  The kernel

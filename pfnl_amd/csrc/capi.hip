@@ -21,6 +21,7 @@
 #include "common.h"
 #include "conv_bf16.h"
 #include "conv_split16.h"
+#include "conv_wsplit.h"
 #include "conv_small.h"
 
 namespace {
@@ -196,6 +197,7 @@ struct pfnl_handle {
     int nl_algo = 2;                                          // non-local block of the fp32 path: 0 f32 MFMA (nonlocal.hip), 1 split-f16 (nonlocal_f16.hip), 2 auto (1 from N = 1024 keys)
     DevBuf wdev16s;                                           // split-f16 packs of the 3x3 kernels (offsets in 16-bit elements)
     std::vector<size_t> off16s_c1, off16s_c2a, off16s_c2b, off16s_c10, off16s_c10f;   // (c10f: conv10_i as conv3x3_c1c10_kernel takes it)
+    std::vector<size_t> off16w_c1, off16w_c2a, off16w_c2b;    // Winograd packs of conv_wsplit.hip (conv3x3=wsplit), in the same blob
     std::vector<size_t> off16s_c2a_sf, off16s_c2b_sf;         // ... with the identity row map conv3x3_sf_kernel takes (conv_sf.hip)
     std::vector<size_t> off16m_c1, off16m_c10, off16m_c2;     // small-shape packs (conv_small.hip), in the same blob
     size_t off16m_m1 = 0;
@@ -532,7 +534,9 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
     const int tiles8x32 = F * ((W + 31) / 32) * ((H + 7) / 8);
     const bool strict = !h->bf16 && (h->strict || h->strict_once || !h->weights_f16_ok);   // f32-MFMA kernels only
     const int algo0 = h->conv_algo == 5 ? ((tiles8x32 >= 256 && (long long)H * W * 256 < 0x7fffffffLL) ? 4 : 3) : h->conv_algo;
-    const int algo = (strict && algo0 == 4) ? 3 : algo0;
+    const int algo = (strict && (algo0 == 4 || algo0 == 6)) ? 3 : algo0;                       // 6: Winograd on the f16 pipe, split operands (conv_wsplit.hip)
+    const bool wsl = algo == 6;
+    const uint16_t* const w16w = reinterpret_cast<const uint16_t*>(h->wdev16s.p);
     const int conv1x1_algo = (strict && h->conv1x1_algo == 2) ? 1 : h->conv1x1_algo;
     const bool sf = algo == 4 && conv1x1_algo == 2 && h->sf_path;   // inp1 and base in the split format (conv_split16.h)
     // small shapes (BASELINE.json configs[0], configs[4]): the trunk through conv_small.hip - 3 launches per block, conv2_i as the
@@ -617,6 +621,9 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
                 ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_c1[i], p.bias, nullptr, nullptr, p.out, H, W, F, 1, 1};
                 q.out_sf = sf ? 1 : 0;                              // inp1 in the split format: it only feeds conv10_i and conv2_i's MFMA operands
                 HIPCHK(launch_conv3x3_split16(q, s));
+            } else if (wsl) {
+                ConvWsParams q{p.in, w16w + h->off16w_c1[i], p.bias, nullptr, nullptr, p.out, H, W, F, 1, 1};
+                HIPCHK(launch_conv_wsplit(q, s));
             } else if (algo == 1 || algo == 3) {
                 WinoParams wp{p.in, wd + h->off_c1_u[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 1, F, nullptr};
                 HIPCHK(algo == 3 ? launch_conv_wino_ws(wp, s) : launch_conv_wino(wp, s));
@@ -684,6 +691,9 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             if (algo == 4) {
                 ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + (sf ? h->off16s_c2a_sf[i] : h->off16s_c2a[i]), p.bias, nullptr, nullptr, p.out, H, W, B, 1, 0};
                 HIPCHK(sf ? launch_conv3x3_sf(q, s) : launch_conv3x3_split16(q, s));
+            } else if (wsl) {
+                ConvWsParams q{p.in, w16w + h->off16w_c2a[i], p.bias, nullptr, nullptr, p.out, H, W, B, 1, 0};
+                HIPCHK(launch_conv_wsplit(q, s));
             } else if (algo == 1 || algo == 3) {
                 WinoParams wp{p.in, wd + h->off_c2a_u[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 0, B, nullptr};
                 HIPCHK(algo == 3 ? launch_conv_wino_ws(wp, s) : launch_conv_wino(wp, s));
@@ -704,6 +714,9 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             if (algo == 4) {
                 ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + (sf ? h->off16s_c2b_sf[i] : h->off16s_c2b[i]), p.bias, p.addend, p.resid, p.out, H, W, F, T, 1};
                 HIPCHK(sf ? launch_conv3x3_sf(q, s) : launch_conv3x3_split16(q, s));
+            } else if (wsl) {
+                ConvWsParams q{p.in, w16w + h->off16w_c2b[i], p.bias, p.addend, p.resid, p.out, H, W, F, T, 1};
+                HIPCHK(launch_conv_wsplit(q, s));
             } else if (algo == 1 || algo == 3) {
                 WinoParams wp{p.in, wd + h->off_c2b_u[i], p.bias, p.addend, p.resid, p.out, H, W, T, 1, F, nullptr};
                 HIPCHK(algo == 3 ? launch_conv_wino_ws(wp, s) : launch_conv_wino(wp, s));
@@ -730,7 +743,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
         h->prof_gate = h->prof_mode != 3;
         return 0;
     }
-    const bool m1_s16 = algo == 4 && h->m1_algo != 2 && (long long)H * W * 256 < 0x7fffffffLL;
+    const bool m1_s16 = (algo == 4 || algo == 6) && h->m1_algo != 2 && (long long)H * W * 256 < 0x7fffffffLL;
     const bool m1_wino = !m1_s16 && (algo == 3 || algo == 4) && wino_groups >= 224 && (long long)H * W * 256 < 0x7fffffffLL;
     const int mstride = (m1_wino || m1_s16) ? 64 : 48;
     h->merge_cstride = mstride;
@@ -816,7 +829,7 @@ int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
     if (const char* e = std::getenv("PFNL_SPLIT16_SF")) h->sf_path = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_CONV3X3")) {
         const std::string v(e);
-        h->conv_algo = v == "direct" ? 0 : (v == "winograd_tile" ? 1 : (v == "split16" ? 4 : (v == "winograd" ? 3 : 5)));
+        h->conv_algo = v == "direct" ? 0 : (v == "winograd_tile" ? 1 : (v == "split16" ? 4 : (v == "wsplit" ? 6 : (v == "winograd" ? 3 : 5))));
     }
     // A BLOCKING stream: it is implicitly ordered with the legacy null stream (= torch's default stream) in both
     // directions, so host-pointer calls and graph replays on it are ordered with the caller's default-stream work.
@@ -923,8 +936,9 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         else if (v == "winograd_tile") h->conv_algo = 1;
         else if (v == "direct") h->conv_algo = 0;
         else if (v == "split16") h->conv_algo = 4;
+        else if (v == "wsplit") h->conv_algo = 6;
         else if (v == "auto") h->conv_algo = 5;
-        else return fail(PFNL_ERR_INVALID, "conv3x3 must be auto, split16, winograd, winograd_tile or direct");
+        else return fail(PFNL_ERR_INVALID, "conv3x3 must be auto, split16, wsplit, winograd, winograd_tile or direct");
         return 0;
     }
     if (k == "strict_fp32") {
@@ -1211,7 +1225,20 @@ int pfnl_finalize_weights(pfnl_handle* h) {
         h->off16m_c10.assign(nb, 0);
         h->off16m_c2.assign(nb, 0);
         h->off16m_m1 = small_base + (size_t)nb * (3 * m3 + m10);
-        b16.resize(h->off16m_m1 + (size_t)T * m3 + 2, 0);
+        const size_t ws_base = (h->off16m_m1 + (size_t)T * m3 + 2 + 127) / 128 * 128, nw = pfnl::conv_wsplit_pack_halfs();
+        h->off16w_c1.assign(nb, 0);
+        h->off16w_c2a.assign(nb, 0);
+        h->off16w_c2b.assign(nb, 0);
+        b16.resize(ws_base + (size_t)nb * 3 * nw + 2, 0);             // ... + the Winograd packs of conv_wsplit.hip (conv3x3=wsplit)
+        for (int i = 0; i < nb; ++i) {
+            const std::string s = std::to_string(i);
+            h->off16w_c1[i] = ws_base + (size_t)i * 3 * nw;
+            h->off16w_c2a[i] = h->off16w_c1[i] + nw;
+            h->off16w_c2b[i] = h->off16w_c1[i] + 2 * nw;
+            pfnl::conv_wsplit_pack_weights(W("conv1_" + s).data(), 64, 0, &b16[h->off16w_c1[i]]);
+            pfnl::conv_wsplit_pack_weights(W("conv2_" + s).data(), 128, 0, &b16[h->off16w_c2a[i]]);
+            pfnl::conv_wsplit_pack_weights(W("conv2_" + s).data(), 128, 64, &b16[h->off16w_c2b[i]]);
+        }
         pfnl::conv_small_pack_weights(W("convmerge1").data(), 3, T, 48, &b16[h->off16m_m1]);
         for (int f = 0; f < T; ++f)
             pfnl::conv3x3_split16_pack_weights(W("convmerge1").data(), 64 * T, 64 * f, &b16[h->off16s_m1 + (size_t)f * n3], 48);
@@ -1914,6 +1941,27 @@ int pfnl_op_conv3x3_split16(const float* in, const float* kernel_host, const flo
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(dw);
     if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv3x3 split16 op: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int pfnl_op_conv3x3_wsplit(const float* in, const float* kernel_host, const float* bias_host, const float* addend, int add_div,
+                           const float* resid, float* out, int items, int H, int W, int act, void* stream) {
+    if (!in || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (items < 1 || H < 1 || W < 1 || (addend == nullptr) != (resid == nullptr)) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
+    if (addend && (add_div < 1 || items % add_div)) return fail(PFNL_ERR_INVALID, "items must be a multiple of add_div");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nh = pfnl::conv_wsplit_pack_halfs();
+    std::vector<uint16_t> pack(nh + 128, 0);
+    pfnl::conv_wsplit_pack_weights(kernel_host, 64, 0, pack.data());
+    if (bias_host) std::memcpy(&pack[nh], bias_host, 64 * sizeof(float));
+    uint16_t* dw = nullptr;
+    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(uint16_t)));
+    hipError_t e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    pfnl::ConvWsParams q{in, dw, reinterpret_cast<const float*>(dw + nh), addend, resid, out, H, W, items, add_div < 1 ? 1 : add_div, act};
+    if (e == hipSuccess) e = pfnl::launch_conv_wsplit(q, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dw);
+    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv3x3 wsplit op: ") + hipGetErrorString(e));
     return 0;
 }
 

@@ -251,7 +251,7 @@ def conv3x3_winograd(x, kernel, bias=None, act=True, addend=None, add_div=1, res
             _req(resid, "resid") if resid is not None else None, _req(out, "out"), F, H, W, 1 if act else 0, _stream(x)))
         return out
     fn = {"winograd": lib.pfnl_op_conv3x3_winograd, "winograd_ws": lib.pfnl_op_conv3x3_winograd_ws,
-          "split16": lib.pfnl_op_conv3x3_split16}[variant]
+          "split16": lib.pfnl_op_conv3x3_split16, "wsplit": lib.pfnl_op_conv3x3_wsplit}[variant]
     _capi.check(fn(
         _req(x, "x"), k.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p) if b is not None else None,
         _req(addend, "addend") if addend is not None else None, int(add_div),
