@@ -87,7 +87,11 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *   "winograd_tile" same maths, one 4-wave workgroup per tile (conv_wino.hip);
  *   "direct"        implicit-GEMM f32 MFMA (conv_mfma.hip);
  *   "split16"       direct 3x3 on the f16 matrix pipe with exactly split fp32 operands (3 f16 MFMAs per product block,
- *                   fp32 accumulation, >= 22 mantissa bits per product: conv_split16.hip).
+ *                   fp32 accumulation, >= 22 mantissa bits per product: conv_split16.hip);
+ *   "wsplit"        (round 5) Winograd F(2x2,3x3) on the f16 matrix pipe with the same split operands - 2.25x fewer MFMAs, the
+ *                   transformed weights resident in the registers of a 4-wave workgroup (conv_wsplit.hip); four launches per block
+ *                   (conv1_i, conv10_i, both halves of conv2_i).  Parity-tested, measured SLOWER than "split16" at every shape
+ *                   (a lone wave per SIMD pays its LDS reads and its input transform in full): not chosen by "auto".
  * key "strict_fp32" = "off" (default) | "on".  The default fp32 path computes on the f16 matrix pipe with exactly split operands
  *   (fp32 tensors, fp32 accumulation, >= 22 mantissa bits per product) and therefore has a DOMAIN the reference's fp32 kernels do
  *   not have: |activation|, |weight| < 65504, and inputs of the non-local block on a [0,1] scale (|x| < ~350).  Leaving it makes

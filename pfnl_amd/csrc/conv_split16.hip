@@ -88,6 +88,52 @@ __device__ __forceinline__ f32x16 mfma_f16(h8 a, h8 b, f32x16 c) {
 // x -> (hi, lo') for 4 values: hi = f16(x) (round to nearest even), lo' = f16(x * 2^11 - hi * 2^11): the fused multiply-add is
 // exact here (x - hi has at most 13 significant bits), so lo' = f16((x - hi) 2^11) with one rounding.  v_fma_mix*_f16 reads the
 // f16 operand in place and writes the f16 result: 8 VALU per 4 values (the plain C++ form compiles to 12-14).
+// f32x4 times / fma with a wave-uniform scalar as FOUR scalar instructions.  Written as v * s the compiler emits v_pk_mul_f32 / v_pk_fma_f32,
+// and packed fp32 VALU is an anti-lever next to MFMAs on gfx950: it does not run in their shadow, every one stops the matrix pipe for its
+// ~4.5 cycles plus a restart (tools/ubench/mfma_agpr_src: 2 v_pk_fma_f32 behind each MFMA = 53 cycles per MFMA, 6 v_fma_f32 = 34.5) -
+// for BOTH waves of the SIMD.  Same arithmetic (a product is a product, the fma the contraction the compiler chose): bit-identical results.
+#ifndef CS_SCALAR_F32
+#define CS_SCALAR_F32 1
+#endif
+__device__ __forceinline__ f32x4 mul4s(f32x4 v, float s) {
+#if CS_SCALAR_F32
+    f32x4 r;
+    asm("v_mul_f32 %0, %4, %5\n\tv_mul_f32 %1, %4, %6\n\tv_mul_f32 %2, %4, %7\n\tv_mul_f32 %3, %4, %8"
+        : "=&v"(r.x), "=&v"(r.y), "=&v"(r.z), "=&v"(r.w) : "s"(s), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+    return r;
+#else
+    return v * s;
+#endif
+}
+__device__ __forceinline__ f32x4 fma4s(f32x4 a, float s, f32x4 c) {   // a * s + c
+#if CS_SCALAR_F32
+    f32x4 r;
+    asm("v_fma_f32 %0, %5, %4, %9\n\tv_fma_f32 %1, %6, %4, %10\n\tv_fma_f32 %2, %7, %4, %11\n\tv_fma_f32 %3, %8, %4, %12"
+        : "=&v"(r.x), "=&v"(r.y), "=&v"(r.z), "=&v"(r.w)
+        : "s"(s), "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w));
+    return r;
+#else
+    return a * s + c;
+#endif
+}
+
+__device__ __forceinline__ f32x16 fma16s(const f32x16& a, float s, const f32x16& c) {   // a * s + c, 16 scalar fmas
+#if CS_SCALAR_F32
+    f32x16 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 t = fma4s(f32x4{a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]}, s, f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]});
+        r[4 * q] = t.x;
+        r[4 * q + 1] = t.y;
+        r[4 * q + 2] = t.z;
+        r[4 * q + 3] = t.w;
+    }
+    return r;
+#else
+    return a * s + c;
+#endif
+}
+
 __device__ __forceinline__ void split4(f32x4 v, u32x2& hi, u32x2& lo, float nscale) {
     const h4 h = __builtin_convertvector(v, h4);                    // 2 x v_cvt_pk_f16_f32
     hi = __builtin_bit_cast(u32x2, h);
@@ -95,7 +141,7 @@ __device__ __forceinline__ void split4(f32x4 v, u32x2& hi, u32x2& lo, float nsca
     const f32x4 r = (v - __builtin_convertvector(h, f32x4)) * CS_SCALE;
     lo = __builtin_bit_cast(u32x2, __builtin_convertvector(r, h4));
 #else
-    const f32x4 t = v * CS_SCALE;                                   // 2 x v_pk_mul_f32, exact
+    const f32x4 t = mul4s(v, CS_SCALE);                             // exact
     unsigned l0, l1;
     asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi.x), "s"(nscale), "v"(t.x));
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l0) : "v"(hi.x), "s"(nscale), "v"(t.y));
@@ -318,14 +364,14 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
         if constexpr (FUSE) v += radd[k & 1];
         if constexpr (ACCUM) v += bias4;
 #ifdef CS_X_PKSLOPE
-        const f32x4 sv = v * slope;
+        const f32x4 sv = mul4s(v, slope);
         v.x = fmaxf(v.x, sv.x);
         v.y = fmaxf(v.y, sv.y);
         v.z = fmaxf(v.z, sv.z);
         v.w = fmaxf(v.w, sv.w);
 #else
         {                                                           // leaky_relu(0.2) or identity (slope 1), branch-free
-            const f32x4 sv = v * slope;
+            const f32x4 sv = mul4s(v, slope);
             asm("v_max_f32 %0, %1, %2" : "=v"(v.x) : "v"(v.x), "v"(sv.x));   // (fmaxf adds a canonicalising v_max x,x,x per element)
             asm("v_max_f32 %0, %1, %2" : "=v"(v.y) : "v"(v.y), "v"(sv.y));
             asm("v_max_f32 %0, %1, %2" : "=v"(v.z) : "v"(v.z), "v"(sv.z));
@@ -632,7 +678,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                 if (last) {
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
-                        accp[n] = accm[n] + accc[n] * CS_ISCALE;
+                        accp[n] = fma16s(accc[n], CS_ISCALE, accm[n]);
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             accm[n][r] = 0.f;
@@ -652,7 +698,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
             if constexpr (PAR == 1 && !ACCUM) {                     // the tile is complete: fold the cross terms in, hand it to the epilogue
                 // (the previous tile's second pass ran in this unit: accp is free)
 #pragma unroll
-                for (int n = 0; n < 2; ++n) accp[n] = accm[n] + accc[n] * CS_ISCALE;
+                for (int n = 0; n < 2; ++n) accp[n] = fma16s(accc[n], CS_ISCALE, accm[n]);
                 ex0p = c_x0;
                 ey0p = c_y0;
                 eitemp = c_item;
@@ -875,8 +921,8 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
     auto quarter_prep = [&](RowHalves& h, const f32x16& m, const f32x16& c, int q, bool fold) __attribute__((always_inline)) {
         // channels ech + 4q .. + 3: (cross terms folded in,) leaky-relu, split - 4 VALU per value
         f32x4 t = {m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]};
-        if (fold) t += f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]} * CS_ISCALE;
-        const f32x4 st = t * slope;
+        if (fold) t = fma4s(f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]}, CS_ISCALE, t);
+        const f32x4 st = mul4s(t, slope);
         asm("v_max_f32 %0, %1, %2" : "=v"(t.x) : "v"(t.x), "v"(st.x));
         asm("v_max_f32 %0, %1, %2" : "=v"(t.y) : "v"(t.y), "v"(st.y));
         asm("v_max_f32 %0, %1, %2" : "=v"(t.z) : "v"(t.z), "v"(st.z));
@@ -926,7 +972,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
                 fill(q);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            base_m[n] += cross * CS_ISCALE;
+            base_m[n] = fma16s(cross, CS_ISCALE, base_m[n]);
         }
     };
     // piece j (0..7: row j >> 2, piece j & 3) of the held tile -> HBM; nothing held: out of range (dropped)

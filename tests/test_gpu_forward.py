@@ -680,6 +680,24 @@ def test_harness_reruns_out_of_range_batches(tmp_path):
     eng.close()
 
 
+@pytest.mark.parametrize("B,T,H,W,nb,scale", [(1, 7, 16, 24, 2, 4), (2, 7, 32, 32, 20, 4), (1, 5, 20, 36, 3, 2), (1, 7, 46, 78, 2, 4)])
+def test_forward_option_wsplit(B, T, H, W, nb, scale):
+    """The whole forward with conv3x3=wsplit (conv1_i, both halves of conv2_i through conv_wsplit.hip; conv10_i and convmerge1 on the
+    split-f16 kernels) against the oracle - same tolerance as the default path."""
+    geom = PFNLGeometry(num_frames=T, scale=scale, num_block=nb)
+    w = synth.synthetic_weights(geom, seed=0)
+    x = synth.uniform_clips(B, T, H, W, seed=5)
+    eng = _engine_with(geom, w)
+    eng.set_option("conv3x3", "wsplit")
+    y = eng.forward(x)
+    ref = pfnl_fast.FastOracle(w, num_frames=T, scale=scale, num_block=nb).forward(x)
+    assert np.abs(y - ref).max() < 5e-5
+    eng.set_option("strict_fp32", "on")                            # the strict path replaces it like the other f16-pipe kernels
+    ys = eng.forward(x)
+    assert np.abs(ys - ref).max() < 5e-5
+    eng.close()
+
+
 def test_harness_reruns_out_of_range_batches_bf16(tmp_path):
     """under precision=bf16 `strict_fp32` changes no kernel (the non-local block and conv0 keep binary16 operands), so
     the recomputation of a flagged batch re-ran the same kernels, cleared the flag and wrote quantised non-finite values.  Now the flagged

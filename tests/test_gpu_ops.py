@@ -473,6 +473,40 @@ def test_conv3x3_split16(items, H, W, fused, act):
     assert e_s <= 1.5 * e_d + 1e-7, (e_s, e_d)                    # as good as the fp32 FMA chain of the direct kernel
 
 
+@pytest.mark.parametrize("items,H,W,fused,act", [(1, 8, 16, False, False), (1, 8, 32, False, True), (7, 10, 38, True, True), (3, 5, 7, False, False),
+                                                  (1, 1, 1, False, True), (7, 33, 70, True, True), (2, 64, 96, False, True), (28, 24, 40, True, True),
+                                                  (1, 9, 130, False, True), (21, 16, 32, True, False), (4, 128, 128, False, False), (2, 2, 2, False, False),
+                                                  (1, 30, 18, True, True), (300, 8, 16, False, True)])
+def test_conv3x3_wsplit(items, H, W, fused, act):
+    """conv_wsplit_kernel (option conv3x3=wsplit; reference model/pfnl.py:49-51 at :66-71): Winograd F(2x2,3x3) on the f16 pipe with exactly
+    split operands, the transformed weights resident in the AGPRs of a 4-wave workgroup.  U is transformed in fp64 on the host, V in fp32 in
+    the kernel, both split into binary16 pairs (>= 22 mantissa bits per product): the error against the fp64 spec stays below the direct
+    split-f16 kernel's bound.  Odd sizes, ragged M-blocks (8 x 16 pixels), single pixels, more blocks than workgroups, the fused epilogue."""
+    rng = np.random.default_rng(items * 1000 + H * 10 + W)
+    x = rng.normal(size=(items, H, W, 64)).astype(np.float32)
+    k = (rng.normal(size=(3, 3, 64, 64)) / 24.0).astype(np.float32)
+    b = (rng.normal(size=64) * 0.1).astype(np.float32)
+    ref = pfnl_spec.conv2d_same(x.astype(np.float64), k.astype(np.float64), b.astype(np.float64))
+    kw = {}
+    if fused:
+        div = 7 if items % 7 == 0 else 1
+        add = rng.normal(size=(items // div, H, W, 64)).astype(np.float32)
+        res = rng.normal(size=(items, H, W, 64)).astype(np.float32)
+        ref = ref + np.repeat(add.astype(np.float64), div, axis=0)
+        kw = dict(addend=dev(add), add_div=div, resid=dev(res))
+    if act:
+        ref = pfnl_spec.lrelu(ref)
+    if fused:
+        ref = ref + res
+    got = ops.conv3x3_winograd(dev(x), k, b, act=act, variant="wsplit", **kw).cpu().numpy()
+    direct = ops.conv2d(dev(x), k, b, act=act, **kw).cpu().numpy()
+    e_w, e_d = np.abs(got - ref).max(), np.abs(direct - ref).max()
+    assert e_w < 4e-6 * max(1.0, np.abs(ref).max()), (e_w, e_d)
+    assert e_w <= 1.5 * e_d + 2e-7, (e_w, e_d)                    # as good as the fp32 FMA chain of the direct kernel
+    again = ops.conv3x3_winograd(dev(x), k, b, act=act, variant="wsplit", **kw).cpu().numpy()
+    assert np.array_equal(got, again)                              # deterministic (no atomics, fixed meeting order of the four waves)
+
+
 @pytest.mark.parametrize("items,H,W,fused,act", [(1, 8, 32, False, True), (7, 10, 38, True, True), (3, 5, 7, False, False), (1, 1, 1, False, True),
                                                   (7, 33, 70, True, True), (2, 64, 96, False, True), (28, 24, 40, True, True),
                                                   (1, 9, 130, False, True), (21, 16, 32, True, False), (4, 128, 128, False, False)])
