@@ -133,8 +133,9 @@ class PowerSampler:
                 "source": "rocm-smi polled during the sustained run (the first samples may precede it)"}
 
 
-def cpu_baseline(weights, sample_clips, H, W, budget_s=24.0):
-    """Times oracle/pfnl_fast.py (the CPU port of the reference graph) on this host."""
+def cpu_baseline(weights, sample_clips, H, W, budget_s=30.0):
+    """Times oracle/pfnl_fast.py (the CPU port of the reference graph) on this host: SURVEY.md 8(d) - the same [B,7,H,W,3] input as the
+    GPU line, 1 warm-up + min of >= 3 runs per thread count (mirrors model/pfnl.py:262), n = 8 and all physical cores both reported."""
     import numpy as np
     import torch
     from oracle import pfnl_fast
@@ -145,16 +146,16 @@ def cpu_baseline(weights, sample_clips, H, W, budget_s=24.0):
         fo.forward(sample_clips)                      # warm-up, discarded (reference model/pfnl.py:262)
         times = []
         t_end = time.time() + budget
-        while len(times) < 2 or (time.time() < t_end and len(times) < 5):
+        while len(times) < 3 or (time.time() < t_end and len(times) < 5):
             t0 = time.time()
             fo.forward(sample_clips)
             times.append(time.time() - t0)
-        return sample_clips.shape[0] / min(times), sample_clips.shape[0] / float(np.mean(times))
+        return sample_clips.shape[0] / min(times), sample_clips.shape[0] / float(np.mean(times)), len(times)
 
     ncpu = os.cpu_count() or 1
     phys = physical_cores() or ncpu
     default_thr = torch.get_num_threads()
-    cands = sorted({c for c in (8, 16, 32, default_thr, phys) if 1 <= c <= max(ncpu, 1)})   # n = 8 and all physical cores
+    cands = sorted({c for c in (8, 16, phys) if 1 <= c <= max(ncpu, 1)})   # n = 8 and all physical cores (+ 16: the best on most hosts)
     per_run_budget = max(3.0, budget_s / len(cands))
     results = {}
     for c in cands:                                   # oversubscription hurts oneDNN: report the best
@@ -162,11 +163,14 @@ def cpu_baseline(weights, sample_clips, H, W, budget_s=24.0):
     torch.set_num_threads(default_thr)
     best = max(results, key=lambda c: results[c][0])
     return {"value": round(results[best][0], 4), "unit": "HR frames/s", "cores": best, "kind": "port",
-            "sample": "%d clip(s) of 7x%dx%d->%dx%d fp32 through oracle/pfnl_fast.py (torch-CPU, oneDNN), "
-                      "1 warm-up + min of >=2 runs per thread count; best thread count reported"
+            "sample": "%d clip(s) of 7x%dx%d->%dx%d fp32 (the GPU line's batch) through oracle/pfnl_fast.py (torch-CPU, oneDNN), "
+                      "1 warm-up + min of >=3 runs per thread count; best thread count reported, n = 8 and all physical cores in by_threads"
                       % (sample_clips.shape[0], H, W, 4 * H, 4 * W),
             "threads_used": best, "host_physical_cores": phys,
             "mean_value": round(results[best][1], 4), "host_logical_cpus": ncpu,
+            "value_8_threads": round(results[8][0], 4) if 8 in results else None,
+            "value_all_physical_cores": round(results[phys][0], 4) if phys in results else None,
+            "runs_per_thread_count": {str(c): v[2] for c, v in results.items()},
             "by_threads": {str(c): round(v[0], 4) for c, v in results.items()}}
 
 
@@ -336,6 +340,73 @@ def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
                      "kernel can take past the direct algorithm's roof") if wino else "achieved = executed = algorithmic (direct convolution)"}
 
 
+def nl_sources_sha():
+    return kernel_source_sha(["nonlocal_f16.hip", "nonlocal.hip"])
+
+
+def nonlocal_roofline(geom, kernel_ms, B, H, W, bf16):
+    """`roofline_nl`: the affinity matmul + softmax class (reference utils.py:53-64) against the dense f16 MFMA peak.  Algorithmic FLOPs
+    = SURVEY.md 8(a)-C: 4 N^2 C + 4 N C^2 per clip (S = X X^T and Y = P X, then the folded 1x1 pair); executed = what the kernel's MFMAs
+    do: channels padded to CP = 32 ceil(C / 32), three f16 MFMAs per product block in the fp32 path (exactly split operands), one under
+    precision=bf16 (hi parts only).  kernel_ms = the class's HIP-event time per step (pack + attention + merge launches)."""
+    ms = kernel_ms.get("nl_attn")
+    if not ms:
+        return None
+    N = (H // 2) * (W // 2)
+    C = 4 * 3 * geom.num_frames
+    CP = 32 * ((C + 31) // 32)
+    alg = B * (4.0 * N * N * C + 4.0 * N * C * C)
+    mult = 1 if bf16 else 3
+    ex = B * (4.0 * N * N * CP * mult + 4.0 * N * CP * CP)
+    t = ms * 1e-3
+    rec = {"bound": "mfma", "achieved": round(alg / t / 1e12, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+           "frac": round(alg / t / 1e12 / PEAK_F16_MFMA_TFLOPS, 4), "class_ms_per_step": round(ms, 4),
+           "algorithmic_gflop_per_step": round(alg / 1e9, 3), "keys": N, "channels": C, "channels_padded": CP,
+           "mfma_per_product": mult, "mfma_executed_tflops": round(ex / t / 1e12, 1),
+           "mfma_executed_frac": round(ex / t / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+           "kernel": "nl_attn_f16_sw_kernel<C, %s> (+ nl_pack_f16 / nl_merge in the class time)" % ("false" if bf16 else "true"),
+           "matrix_pipe_busy": None,
+           "note": "frac = algorithmic FLOPs / class time / 2.5 PFLOP/s; the class time includes the pack and merge launches around the attention kernel"}
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_nl.json")))
+    if cands:
+        pj = json.load(open(cands[-1]))
+        key = "%dx%d_%s" % (H, W, "bf16" if bf16 else "fp32")
+        if pj.get("kernel_src_sha") == nl_sources_sha() and key in pj.get("matrix_pipe_busy", {}):
+            rec["matrix_pipe_busy"] = pj["matrix_pipe_busy"][key]         # SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x GRBM_GUI_ACTIVE / XCDs), PMC pass
+            rec["matrix_pipe_busy_source"] = os.path.basename(cands[-1])
+    return rec
+
+
+def hbm_class_rooflines(geom, kernel_ms, B, H, W, merge_stride=64):
+    """Achieved GB/s of the bandwidth-class kernels (gather / scatter / tail / bicubic) against 8 TB/s: the
+    ALGORITHMIC bytes each class must move (inputs read once, outputs written once) over its HIP-event time per step."""
+    T, sc = geom.num_frames, geom.scale
+    P, N = H * W, (H // 2) * (W // 2)
+    C = 4 * 3 * T
+    CP = 32 * ((C + 31) // 32)
+    out = {}
+    model = {
+        # x [B,T,H,W,3] fp32 -> X [B,N,CP] fp32 (space_to_depth of the stacked frames, model/pfnl.py:55-57)
+        "nl_pack": B * (T * P * 3 * 4.0 + N * CP * 4.0),
+        # Xo [B,N,CP] (+ the LR frames' residual already inside) -> conv 5x5 3->64 + lrelu -> inp0 [B*T,H,W,64] fp32 (model/pfnl.py:61-62)
+        "conv0": B * (N * CP * 4.0 + T * P * 64 * 4.0),
+        # convmerge1: reads the trunk [B*T,H,W,64], writes merge [B,H,W,merge_stride] (model/pfnl.py:73-74)
+        "merge1": B * (T * P * 64 * 4.0 + P * merge_stride * 4.0),
+        # tail: merge (48 channels used) + the centre LR frame (bicubic) -> out [B,1,sH,sW,3] (model/pfnl.py:63,76-80)
+        "tail": B * (P * 48 * 4.0 + P * 3 * 4.0 + sc * sc * P * 3 * 4.0),
+    }
+    for k, nbytes in model.items():
+        ms = kernel_ms.get(k)
+        if ms:
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            out[k] = {"ms_per_step": round(ms, 4), "algorithmic_mbytes_per_step": round(nbytes / 1e6, 3), "gbs": round(gbs, 1),
+                      "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4)}
+    out["note"] = ("launch-latency-class kernels at these sizes (10 - 100 us each): merge1 is an MFMA kernel (convmerge1 448 -> 48), listed with its "
+                   "bytes for completeness; peak = 8 TB/s")
+    return out
+
+
 def resolve_conv3x3(name, B, H, W, T=7):
     """What conv3x3=auto runs for this shape (the rule of forward_device in pfnl_amd/csrc/capi.hip)."""
     name = name or os.environ.get("PFNL_CONV3X3", "auto")
@@ -388,6 +459,8 @@ def main():
                     help="--gpus > 1 with nccl: who carries the weight replica and the max-over-ranks time - the library's own RCCL "
                          "communicator (pfnl_comm_*, include/pfnl_hip.h; falls back to torch.distributed if it cannot be created on "
                          "every rank) or torch.distributed")
+    ap.add_argument("--require-comm", action="store_true",
+                    help="with --comm pfnl: no fallback to torch.distributed - a rank whose pfnl_comm (RCCL) does not come up fails the run")
     ap.add_argument("--full-profile", action="store_true",
                     help="HIP events around every launch of the timed steps (default: the launches of one of the twenty progressive-fusion "
                          "blocks; the whole-forward breakdown from an untimed pass)")
@@ -480,6 +553,9 @@ def main():
                     # every rank must take the same road: agree through the launcher's group
                     ok = torch.tensor([1 if comm is not None else 0], device=dev)
                     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                    if int(ok[0]) == 0 and args.require_comm:
+                        raise SystemExit("--require-comm: pfnl_comm (RCCL) did not come up on every rank (rank %d: %s)"
+                                         % (rank, "ok" if comm is not None else box.get("err", "timed out")))
                     if int(ok[0]) == 0 and comm is not None:
                         comm.close()
                         comm = None
@@ -499,6 +575,11 @@ def main():
         weights = synth.synthetic_weights(geom, seed=0)
         eng.load_weights(weights)
 
+    comm_nranks = comm_rank = None
+    if comm is not None:                                                # what RCCL itself reports (pfnl_comm_rank): the line proves N ranks were seen
+        comm_rank, comm_nranks = comm.rank_and_size()
+        if comm_nranks != world or comm_rank != rank:
+            raise SystemExit("pfnl_comm reports rank %d of %d, the launcher rank %d of %d" % (comm_rank, comm_nranks, rank, world))
     if args.conv3x3:
         eng.set_option("conv3x3", args.conv3x3)
     if args.conv1x1:
@@ -601,8 +682,11 @@ def main():
                                               (": the fixed global batch of %d clips in contiguous shards, this is rank 0's" % GB) if args.strong else ""),
                    "clips_per_gpu": B_PER_GPU, "global_batch": GB, "parallelism": "dp%d" % world, "backend": (args.backend if use_dist else None),
                    "comm": (("pfnl_comm (RCCL)" if comm is not None else "torch.distributed") if use_dist else None),
+                   "comm_nranks": comm_nranks, "comm_required": bool(args.require_comm),
                    "weights": "synthetic Xavier (seed 0)", "input": "resident in HBM", "conv3x3": algo},
         "roofline": roof,
+        "roofline_nl": nonlocal_roofline(geom, breakdown, B_PER_GPU, H, W, bf16),
+        "roofline_hbm_classes": hbm_class_rooflines(geom, breakdown, B_PER_GPU, H, W),
         "whole_forward": {"tflops_ref_graph": round(f_ref / (ms_per_step * 1e-3) / 1e12, 2),
                           "tflops_direct_shared_base": round(f_exec / (ms_per_step * 1e-3) / 1e12, 2),
                           "kernel_ms_per_step": breakdown},
@@ -631,10 +715,14 @@ def main():
                 el = float(t[0])
         res["sustained"] = {"steps": n_sus, "seconds": round(el, 3), "ms_per_step": round(1e3 * el / n_sus, 4),
                             "value": round(GB * n_sus / el, 3)}
+        if res.get("power") and world == 1:
+            # energy per HR frame = package power x time per step / clips per step, both from the sustained run: the split-f16 launches sit on
+            # the package power cap, so a kernel change is a change of THIS number or it is nothing
+            res["joules_per_frame"] = round(res["power"]["package_w"] * (el / n_sus) / B_PER_GPU, 4)
     if rank == 0 and world == 1 and not args.no_secondary and args.workload == "cfg2" and not bf16 and not args.strong and not args.clips_per_gpu:
         res["secondary"] = secondary_workloads(eng, geom, weights, local_dev, dev, x, out)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("cfg2", "cfg0"):   # (the 1080p oracle needs minutes per pass; configs[4] is build-defined)
-        sample = synth.uniform_clips(1, T, H, W, seed=1234)
+        sample = synth.uniform_clips(B_PER_GPU, T, H, W, seed=1234)     # the GPU line's batch (same seed: the same clips)
         res["cpu_baseline"] = cpu_baseline(weights, sample, H, W)
         res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
     if rank == 0:
@@ -684,6 +772,7 @@ def secondary_workloads(eng, geom, weights, local_dev, dev, x_cfg2, out_cfg2):
                "value": round(B * steps / el, 3), "unit": "HR frames/s", "input": "resident in HBM",
                "kernel_ms_per_step": {n: round(v["ms"] / steps * (sc if n in ("conv3x3", "conv1x1") else 1.0), 4) for n, v in prof.items()}}
         assert torch.isfinite(o).all().item(), "non-finite output (%s)" % label
+        rec["roofline_nl"] = nonlocal_roofline(g, rec["kernel_ms_per_step"], B, H, W, bf16)
         return rec, prof
 
     out = []

@@ -178,6 +178,8 @@ int pfnl_comm_get_unique_id(void* id /*[PFNL_COMM_ID_BYTES]*/);
 int pfnl_comm_init_rank(int nranks, int rank, const void* id, int device_id, pfnl_comm** out);
 int pfnl_comm_init_all(int ndev, const int* devs, pfnl_comm** comms /*[ndev]*/);
 int pfnl_comm_destroy(pfnl_comm* c);
+/* (rank, nranks) as RCCL itself reports them for this communicator (ncclCommUserRank / ncclCommCount when the library exports them; they
+ * must equal what the communicator was created with, else PFNL_ERR_COMM): bench.py prints them as config.comm_nranks. */
 int pfnl_comm_rank(pfnl_comm* c, int* rank, int* nranks);
 /* ncclBroadcast of the packed DEVICE weight blobs of `h` (what pfnl_finalize_weights built on `root`) to every rank's
  * handle of the same geometry; a non-root handle needs no pfnl_set_weight calls at all.  Replaces nothing in the reference

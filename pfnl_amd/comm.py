@@ -88,6 +88,13 @@ class Comm:
             self._h, v.ctypes.data_as(C.POINTER(C.c_double)), v.size, _capi.COMM_SUM if op == "sum" else _capi.COMM_MAX))
         return v
 
+    def rank_and_size(self):
+        """(rank, nranks) as the RCCL communicator itself reports them (pfnl_comm_rank -> ncclCommUserRank / ncclCommCount): what a bench
+        line quotes to show that N ranks really joined, not what the launcher's environment claimed."""
+        r, n = C.c_int(-1), C.c_int(-1)
+        _capi.check(self._lib.pfnl_comm_rank(self._h, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
     def barrier(self) -> None:
         _capi.check(self._lib.pfnl_comm_barrier(self._h))
 

@@ -35,6 +35,8 @@ struct Rccl {
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;            // optional: pfnl_comm_rank asks the communicator itself when present
+    decltype(&ncclCommCount) CommCount = nullptr;
     std::string err;
 };
 
@@ -70,6 +72,8 @@ static void rccl_resolve(Rccl& r) {
     PFNL_SYM(AllGather, "ncclAllGather")
     PFNL_SYM(GetErrorString, "ncclGetErrorString")
 #undef PFNL_SYM
+    r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.lib, "ncclCommUserRank"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
 }
 
 }  // namespace
@@ -179,6 +183,17 @@ int pfnl_comm_rank(pfnl_comm* c, int* rank, int* nranks) {
     if (!c || !rank || !nranks) COMM_FAIL(PFNL_ERR_INVALID, "NULL argument");
     *rank = c->rank;
     *nranks = c->nranks;
+    // what RCCL itself says about this communicator (ncclCommUserRank / ncclCommCount): a bench line that quotes these figures shows that
+    // N ranks really joined the communicator, not what the launcher's environment claimed
+    Rccl* R = rccl();
+    if (c->comm && R->lib && R->CommUserRank && R->CommCount) {
+        int r = -1, n = -1;
+        NCHK(R->CommUserRank(c->comm, &r));
+        NCHK(R->CommCount(c->comm, &n));
+        if (r != c->rank || n != c->nranks) COMM_FAIL(PFNL_ERR_COMM, "RCCL reports another rank / size than the communicator was created with");
+        *rank = r;
+        *nranks = n;
+    }
     return 0;
 }
 

@@ -334,6 +334,53 @@ def test_1080p_fp32_against_oracle_subsample():
     eng.set_option("conv3x3", "auto")
 
 
+@pytest.mark.parametrize("name", ["vid4_144x180", "vid4_144x176", "vid4_120x180", "udm10_180x318", "eval_4x128x240"])
+def test_reference_harness_geometries_against_oracle(name):
+    """The geometries the reference's own harness exists for (reference model/pfnl.py:25, 86, 203-332): Vid4 LR 144x180 /
+    144x176 / 120x180 (N = 6480 / 6336 / 5400 keys), UDM10 LR 180x318 (W not a multiple of 32; N = 14 310, a multiple of 2 only) and
+    the eval batch [4,7,128,240,3] - the full 20-block fp32 forward against the ORACLE (tests/golden/ref_geoms_stride8.npz: every 8th HR
+    pixel + a dense 48x48 crop across a tile corner, tools/make_golden_ref_geoms.py; seeded synthetic clips of those shapes)."""
+    gd = load_golden("ref_geoms_stride8")
+    stride, cs = (int(v) for v in gd["meta"])
+    B, H, W, seed, cy, cx = (int(v) for v in gd[name + "_shape"])
+    eng = engine_for(PFNLGeometry())
+    x = synth.uniform_clips(B, 7, H, W, seed=seed)
+    y = eng.forward(x)[:, 0]
+    assert y.shape == (B, 4 * H, 4 * W, 3) and np.isfinite(y).all()
+    e1 = np.abs(y[:, ::stride, ::stride] - gd[name + "_sub"]).max()
+    e2 = np.abs(y[:, cy:cy + cs, cx:cx + cs] - gd[name + "_crop"]).max()
+    print("%s max|hip - oracle|: subsample %.3g, crop %.3g" % (name, e1, e2))
+    assert e1 < ABS_TOL and e2 < ABS_TOL, (name, e1, e2)
+    import torch
+    yd = eng.forward(torch.from_numpy(x).cuda()).cpu().numpy()[:, 0]          # device-pointer call: the same bytes
+    assert np.array_equal(yd, y)
+
+
+def test_harness_udm10_geometry_is_byte_identical(tmp_path):
+    """test_video_lr at the UDM10 LR size 180x318 (reference model/pfnl.py:264-320, README.md:30: HR 1272x720) through the device-side
+    harness, 20 blocks: the PNG bytes equal the host restatement of the harness (clamped windows, forward, clip / round-half-even /
+    uint8) around the same engine."""
+    from PIL import Image
+    from model.pfnl import PFNL
+    from pfnl_amd import model as M
+    rng = np.random.default_rng(31)
+    lr_u8 = rng.integers(0, 256, size=(5, 180, 318, 3), dtype=np.uint8)
+    seq = tmp_path / "udm"
+    (seq / "blur4").mkdir(parents=True)
+    for i, im in enumerate(lr_u8):
+        Image.fromarray(im).save(seq / "blur4" / f"{i:04d}.png")
+    geom = PFNLGeometry()
+    m = PFNL()
+    m.save_dir = str(tmp_path / "none")
+    m.set_weights(synth.synthetic_weights(geom, seed=0))
+    m.test_video_lr(str(seq), name="out", part=2)                  # 5 frames, part 2 -> batches of 3, 2
+    got = np.stack([np.asarray(Image.open(p)) for p in sorted((seq / "out").glob("*.png"))])
+    lrs = (lr_u8 / 255.).astype(np.float32)
+    want = M.quantise(engine_for(geom).forward(np.ascontiguousarray(M.sliding_windows(lrs, 7)))[:, 0])
+    assert got.shape == want.shape == (5, 720, 1272, 3)
+    assert np.array_equal(got, want)
+
+
 def test_embedded_gaussian_option_forward():
     """The theta/phi option north_star names (reference utils.py:31-42, nltype 0): optional nlblock_0/{theta,phi} variables
     switch the non-local block to theta(x) phi(x)^T logits; whole forward against the fp64 spec written as the reference."""

@@ -391,6 +391,32 @@ def test_bench_byte_model_matches_the_launch_structure_and_the_committed_traffic
     assert abs(rb["mbytes_per_launch"] * 1e6 - 270 * 480 * 128 * (5 * 7 + 4) / 3) < 1e4
 
 
+def test_bench_nonlocal_flop_model_and_hbm_classes():
+    """bench.py's `roofline_nl` prices the affinity class on SURVEY.md 8(a)-C's FLOPs (4 N^2 C + 4 N C^2 per clip:
+    5.75 GFLOP at configs[1], 353.6 at 1080p) and on what the kernel's MFMAs execute (channels padded to 96, x3 for exactly split operands,
+    x1 under precision=bf16); `roofline_hbm_classes` prices pack / conv0 / tail on the bytes their tensors have."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    g = PFNLGeometry()
+    r = bench.nonlocal_roofline(g, {"nl_attn": 0.1}, 4, 128, 128, False)
+    assert abs(r["algorithmic_gflop_per_step"] - 4 * 5.75) < 0.05 and r["keys"] == 4096 and r["channels"] == 84 and r["channels_padded"] == 96
+    assert abs(r["achieved"] - 4 * 5.7519e9 / 1e-4 / 1e12) < 0.5 and abs(r["frac"] - r["achieved"] / 2500.0) < 1e-3
+    ex = 4 * (4 * 4096 ** 2 * 96 * 3 + 4 * 4096 * 96 ** 2) / 1e-4 / 1e12
+    assert abs(r["mfma_executed_tflops"] - ex) < 0.2 and r["mfma_per_product"] == 3
+    rb = bench.nonlocal_roofline(g, {"nl_attn": 0.44}, 1, 270, 480, True)
+    assert abs(rb["algorithmic_gflop_per_step"] - 353.6) < 0.5 and rb["mfma_per_product"] == 1 and rb["keys"] == 32400
+    assert bench.nonlocal_roofline(g, {"nl_attn": 0.0}, 1, 32, 32, False) is None
+    g5 = PFNLGeometry(num_frames=5, scale=2)
+    assert bench.nonlocal_roofline(g5, {"nl_attn": 0.05}, 1, 64, 64, False)["channels"] == 60
+    h = bench.hbm_class_rooflines(g, {"nl_pack": 0.012, "conv0": 0.035, "tail": 0.027, "merge1": 0.1}, 4, 128, 128)
+    P = 128 * 128
+    assert abs(h["tail"]["algorithmic_mbytes_per_step"] - 4 * (P * 48 * 4 + P * 12 + 16 * P * 12) / 1e6) < 1e-3
+    assert abs(h["conv0"]["algorithmic_mbytes_per_step"] - 4 * (P // 4 * 96 * 4 + 7 * P * 256) / 1e6) < 1e-3
+    assert abs(h["nl_pack"]["gbs"] - h["nl_pack"]["algorithmic_mbytes_per_step"] / 0.012) < 0.1 and 0 < h["tail"]["frac_of_hbm_peak"] < 1
+
+
 def test_harness_numerics_match_the_reference_functions():
     """SURVEY.md 8(f)-3 / 8(f)-4 pinned to the reference's OWN code: tools/make_utils_golden.py takes gkern, _rgb2ycbcr, to_uint8 and
     AVG_PSNR out of /root/reference/utils.py (:95-105, :194-246) with `ast` and runs them on the real numpy / scipy in the build
