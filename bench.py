@@ -820,6 +820,7 @@ def secondary_workloads(eng, geom, weights, local_dev, dev, x_cfg2, out_cfg2):
     out.append({"roofline": rf_h, "pcie_mbytes_per_step": round((xh.nbytes + yh.nbytes) / 1e6, 2),
                 "workload": "BASELINE.json configs[1] through HOST pointers (pageable numpy in/out: 5.5 MB H2D + 12.6 MB D2H inside pfnl_forward; "
                             "what the reference's sess.run timing covers, model/pfnl.py:249-253)",
+                "host_output": PFNLEngine.host_output_mode(),
                 "dtype": "f32", "clips": int(xh.shape[0]), "steps": steps, "ms_per_step": round(1e3 * el / steps, 4),
                 "value": round(xh.shape[0] * steps / el, 3), "unit": "HR frames/s", "input": "host memory (PCIe-inclusive)"})
     return out

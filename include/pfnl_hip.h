@@ -129,6 +129,12 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *                 "1" | "2": utils.NonLocalBlock's nltype (embedded Gaussian / Gaussian / dot product; 0 and 2 need theta / phi).
  * key "nl_sub_sample" = "1" (default, PFNL's call) | n: average-pool g and phi n x n on the space_to_depth grid (utils.py:27-28,35-36).
  *                 nl_type != 1 or nl_sub_sample > 1 run on the f32-MFMA kernel (nonlocal.hip) in both precisions.
+ *                 ONE DIVERGENCE FROM THE REFERENCE AS WRITTEN, by design: utils.py:57-58 takes exp(S) and then divides by its row sum
+ *                 without subtracting the row maximum, so a row whose sum exceeds fp32's range (N exp(s) > 3.4e38: at N = 4096 every
+ *                 logit > 80.4, i.e. a 128x128 input that is >= 0.98-white throughout) comes out as P = 0 / inf = 0 and the block returns
+ *                 its bias there.  Every kernel here runs the softmax as a streaming, max-subtracted recurrence: on those inputs it
+ *                 returns the mathematically defined softmax (tested against the stabilised fp64 oracle), everywhere else the same
+ *                 values as the reference's formula.  There is no "as written" switch: reproducing an overflow is not a feature.
  * key "bf16_conv10" = "fused" (default: conv10_i runs inside the conv1_i launch of the bf16 trunk) | "separate".
  * key "bf16_nonlocal" = "f16" (the only value since round 4: the non-local block of precision=bf16 on the f16 matrix pipe with
  *                 binary16 operands, fp32 accumulation and softmax state - nonlocal_f16.hip, hi parts only; within 1e-3 of the
@@ -161,8 +167,18 @@ int pfnl_range_reruns(pfnl_handle* h, long long* count);
  * once per batch instead of pfnl_sync (pfnl_amd/model.py, the replacement of the loop around sess.run, reference
  * model/pfnl.py:249-258).  Synchronous (host-pointer) forwards keep a flag of their own and never consume this one.  The fence
  * is armed where a kernel with a binary16 domain runs and a non-finite value cannot be the reference's own result: not under
- * strict_fp32 (f32-MFMA kernels throughout) and not with nl_type 2 (0 / 0 for a query without a positive affinity). */
+ * strict_fp32 (f32-MFMA kernels throughout) and not with nl_type 2 (0 / 0 for a query without a positive affinity).
+ * The word is taken with one atomic exchange, so a flag raised by a forward that is STILL IN FLIGHT while this is called is not lost:
+ * it is either returned now or by the next call - i.e. a returned 1 may also cover forwards that have not completed yet (a caller that
+ * re-runs a batch on it should treat the batches already enqueued behind it as suspect too: pfnl_amd/model.py does). */
 int pfnl_range_flag(pfnl_handle* h, int* flagged);
+
+/* Page-locked host buffers (hipHostMalloc / hipHostFree) for the tensors a caller hands to a host-pointer pfnl_forward - the call that
+ * replaces sess.run(SR_test, feed_dict={L_test: ...}) (reference model/pfnl.py:252,309): the copy engine then moves them directly, with
+ * no staging copy through the handle's strips.  Process-wide, not tied to a handle; pfnl_amd/engine.py keeps a small, size-capped pool of
+ * them for the arrays PFNLEngine.forward returns (no torch involved: ADVICE r4). */
+int pfnl_host_alloc(size_t bytes, void** out);
+int pfnl_host_free(void* p);
 
 /* ---- multi-GPU (RCCL over xGMI) ------------------------------------ */
 /* Clips are independent (reference model/pfnl.py:44,55: the batch is only the leading dimension), so ranks share NOTHING on

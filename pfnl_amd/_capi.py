@@ -49,6 +49,8 @@ SIGNATURES = {
     "pfnl_sync": (_i, [_vp]),
     "pfnl_range_reruns": (_i, [_vp, C.POINTER(C.c_longlong)]),
     "pfnl_range_flag": (_i, [_vp, C.POINTER(_i)]),
+    "pfnl_host_alloc": (_i, [C.c_size_t, C.POINTER(_vp)]),
+    "pfnl_host_free": (_i, [_vp]),
     "pfnl_profile_enable": (_i, [_vp, _i]),
     "pfnl_profile_reset": (_i, [_vp]),
     "pfnl_profile_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -135,7 +135,9 @@ def save_checkpoint(checkpoint_dir: str, weights: Dict[str, np.ndarray], step: i
     time unless the cache carries its signature): when the bundle holds exactly these weights the cache is (re)written as its
     mirror - a loop that saves "both" once and "npz" afterwards keeps working; when it holds other weights the call raises
     FileExistsError BEFORE touching the directory (no file written, the state file not moved) - save with fmt="both" to
-    rewrite the bundle, or remove it first."""
+    rewrite the bundle, or remove it first.  "Mirror" means the MODEL weights: a training bundle's extra tensors (Adam slots,
+    global_step, beta powers) are not copied into the cache, which is all an inference load reads; NaNs compare equal (a diverged
+    run's weights are mirrored like any other instead of raising)."""
     if fmt not in ("tf", "npz", "both"):
         raise ValueError("fmt must be 'tf', 'npz' or 'both'")
     base = "{}-{}".format(model_name, int(step))
@@ -145,7 +147,7 @@ def save_checkpoint(checkpoint_dir: str, weights: Dict[str, np.ndarray], step: i
         from . import tfbundle
         held = tfbundle.read_bundle(prefix)
         same = set(held) >= set(arrs) and all(
-            held[k].shape == arrs[k].shape and np.array_equal(np.asarray(held[k], np.float32), arrs[k]) for k in arrs)
+            held[k].shape == arrs[k].shape and np.array_equal(np.asarray(held[k], np.float32), arrs[k], equal_nan=True) for k in arrs)
         if not same:
             raise FileExistsError("{}.index holds other weights: save with fmt='both' (rewrites it) or remove the bundle first"
                                   .format(prefix))

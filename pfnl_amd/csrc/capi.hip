@@ -1310,11 +1310,12 @@ int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes) {
     return 0;
 }
 
-// reads and clears a sticky range flag (pinned host memory; the caller has synchronised the work that may still be writing it)
+// reads and clears a sticky range flag (pinned, device-mapped host memory).  One atomic exchange: pfnl_range_flag is documented for use
+// while later forwards are in flight, and with a plain read followed by a plain write of 0 a device store of 1 landing between the two
+// would be lost.  A returned 1 may therefore also cover a forward that is still running.
 static int range_flag_take(pfnl_handle* h, int slot, int* flagged) {
-    volatile unsigned* const f = h->rflag_host + slot;
-    *flagged = *f != 0;
-    if (*flagged) *f = 0;
+    unsigned* const f = h->rflag_host + slot;
+    *flagged = __atomic_exchange_n(f, 0u, __ATOMIC_ACQ_REL) != 0;
     return 0;
 }
 
@@ -1472,6 +1473,9 @@ int pfnl_forward(pfnl_handle* h, const void* in, int in_is_device, void* out, in
             ge = &h->graphs.back();
         }
         if (ge->exec && (ge->alloc_gen != g_alloc_gen || ge->cfg_gen != h->cfg_gen)) {   // buffers moved / weights or options changed
+            // a replay of this graph may still be running on the stream (an asynchronous device-pointer call followed by pfnl_set_option):
+            // whether the runtime defers the destruction of an executing graph depends on its version - wait for it
+            HIPCHK(hipStreamSynchronize(s));
             hipGraphExecDestroy(ge->exec);
             hipGraphDestroy(ge->graph);
             ge->exec = nullptr;
@@ -1620,6 +1624,28 @@ int pfnl_sync(pfnl_handle* h) {
     int flagged = 0;
     if (int e = range_flag_take(h, 1, &flagged)) return e;
     if (flagged) return fail(PFNL_ERR_RANGE, h->bf16 ? RANGE_MSG_BF16 : RANGE_MSG_FP32);
+    return 0;
+}
+
+// Page-locked host memory for a caller's input / output buffers (hipHostMalloc): a host-pointer pfnl_forward lets the copy engine read /
+// write such a buffer directly instead of staging it through the handle's pinned strips.  Process-wide (no handle: a result may outlive
+// the handle that filled it); the caller frees every block it took.
+int pfnl_host_alloc(size_t bytes, void** out) {
+    if (!out || !bytes) return fail(PFNL_ERR_INVALID, "bad host allocation");
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess || !p) {
+        (void)hipGetLastError();
+        return fail(PFNL_ERR_NOMEM, "hipHostMalloc failed");
+    }
+    *out = p;
+    return 0;
+}
+
+int pfnl_host_free(void* p) {
+    if (p && hipHostFree(p) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(PFNL_ERR_HIP, "hipHostFree failed");
+    }
     return 0;
 }
 

@@ -20,6 +20,57 @@ def _is_torch(x) -> bool:
     return type(x).__module__.startswith("torch")
 
 
+class _PinnedPool:
+    """Free page-locked blocks by size.  Thread-safe; blocks in use are owned by their numpy arrays (a finalizer on the array's base
+    returns them here)."""
+
+    def __init__(self):
+        import threading
+        self._free = {}                       # nbytes -> [ptr, ...]
+        self._free_bytes = 0
+        self._lock = threading.Lock()
+
+    def _cap(self) -> int:
+        return int(float(os.environ.get("PFNL_PINNED_POOL_MB", "256")) * (1 << 20))
+
+    def array(self, shape, nbytes: int) -> Optional[np.ndarray]:
+        import weakref
+        lib = _capi.load_library()
+        ptr = None
+        with self._lock:
+            lst = self._free.get(nbytes)
+            if lst:
+                ptr = lst.pop()
+                self._free_bytes -= nbytes
+        if ptr is None:
+            p = C.c_void_p()
+            if lib.pfnl_host_alloc(nbytes, C.byref(p)) != 0 or not p.value:
+                return None                    # no pinned memory to be had: the caller falls back to pageable memory
+            ptr = p.value
+        base = (C.c_float * (nbytes // 4)).from_address(ptr)
+        weakref.finalize(base, self._give, ptr, nbytes)
+        return np.ctypeslib.as_array(base).reshape(shape)
+
+    def _give(self, ptr: int, nbytes: int) -> None:
+        keep = False
+        with self._lock:
+            if self._free_bytes + nbytes <= self._cap():
+                self._free.setdefault(nbytes, []).append(ptr)
+                self._free_bytes += nbytes
+                keep = True
+        if not keep:
+            try:
+                _capi.load_library().pfnl_host_free(C.c_void_p(ptr))
+            except Exception:                  # interpreter shutdown: the OS takes the memory back
+                pass
+
+    def free_bytes(self) -> int:
+        return self._free_bytes
+
+
+_pinned_pool = _PinnedPool()
+
+
 class PFNLEngine:
     def __init__(self, geom: PFNLGeometry = PFNLGeometry(), device: int = 0):
         self.geom = geom
@@ -126,16 +177,22 @@ class PFNLEngine:
 
     @staticmethod
     def _host_output(shape) -> np.ndarray:
-        """The numpy array a host-pointer forward fills.  Page-locked when torch can provide it (its caching host allocator:
-        no allocation per call after the first): pfnl_forward then lets the copy engine write the result straight into it
-        instead of staging it through the handle's pinned strip.  The array owns its memory (numpy keeps the tensor alive)."""
-        if int(np.prod(shape)) * 4 >= (512 << 10) and os.environ.get("PFNL_HOST_OUTPUT", "pinned") != "pageable":
-            try:
-                import torch
-                return torch.empty(shape, dtype=torch.float32, pin_memory=True).numpy()
-            except Exception:          # no torch / no pinned memory available: pageable, staged inside the library
-                pass
+        """The numpy array a host-pointer forward fills.  Large results are page-locked (pfnl_host_alloc: pfnl_forward then lets the
+        copy engine write the result straight into the array instead of staging it through the handle's pinned strip), from a small pool
+        owned by this module: a block goes back to the pool when the last view of its array dies, and the pool keeps at most
+        PFNL_PINNED_POOL_MB (default 256) of free blocks - anything beyond that is returned to the OS, so many distinct output shapes do
+        not accumulate page-locked memory.  No torch involved.  PFNL_HOST_OUTPUT=pageable: plain numpy memory (staged inside the library)."""
+        nbytes = int(np.prod(shape)) * 4
+        if nbytes >= (512 << 10) and os.environ.get("PFNL_HOST_OUTPUT", "pinned") != "pageable":
+            arr = _pinned_pool.array(shape, nbytes)
+            if arr is not None:
+                return arr
         return np.empty(shape, np.float32)
+
+    @staticmethod
+    def host_output_mode() -> str:
+        """"pinned" (pool of pfnl_host_alloc blocks) or "pageable": what bench.py records next to its host-pointer line."""
+        return "pageable" if os.environ.get("PFNL_HOST_OUTPUT", "pinned") == "pageable" else "pinned (pfnl_host_alloc pool)"
 
     def forward_device(self, in_ptr: int, out_ptr: int, B: int, H: int, W: int, stream: int = 0) -> None:
         """Raw device-pointer form (asynchronous on ``stream``; 0 = the legacy null stream, i.e. torch's default stream).

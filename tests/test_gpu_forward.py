@@ -784,6 +784,38 @@ def test_harness_reruns_out_of_range_batches_bf16(tmp_path):
     eng.close()
 
 
+def test_pinned_output_pool(monkeypatch):
+    """the arrays PFNLEngine.forward returns for large host-pointer results are page-locked blocks of the LIBRARY
+    (pfnl_host_alloc), pooled by size - a block returns to the pool when its array dies and is handed out again; the pool of free blocks
+    is capped (PFNL_PINNED_POOL_MB), beyond the cap blocks go back to the OS; a result outlives its engine; no torch allocator involved."""
+    import gc
+    from pfnl_amd import engine as E
+    geom = PFNLGeometry(num_block=1)
+    eng = PFNLEngine(geom, device=0)
+    eng.load_weights(synth.synthetic_weights(geom, seed=0))
+    x = synth.uniform_clips(2, 7, 64, 96, seed=8)                   # 2.4 MB out: above the 512 KB threshold
+    y1 = eng.forward(x)
+    want = y1.copy()
+    p1 = y1.ctypes.data
+    del y1
+    gc.collect()
+    assert E._pinned_pool.free_bytes() >= want.nbytes
+    y2 = eng.forward(x)
+    assert y2.ctypes.data == p1 and np.array_equal(y2, want)        # the same block again
+    eng.close()
+    assert np.array_equal(y2, want)                                 # the array owns its block: it outlives the engine
+    monkeypatch.setenv("PFNL_PINNED_POOL_MB", "0")
+    before = E._pinned_pool.free_bytes()
+    del y2
+    gc.collect()
+    assert E._pinned_pool.free_bytes() == before                    # over the cap: freed, not pooled
+    monkeypatch.setenv("PFNL_HOST_OUTPUT", "pageable")
+    eng2 = PFNLEngine(geom, device=0)
+    eng2.load_weights(synth.synthetic_weights(geom, seed=0))
+    assert np.array_equal(eng2.forward(x), want) and PFNLEngine.host_output_mode() == "pageable"
+    eng2.close()
+
+
 def test_host_pointer_staging_paths():
     """pfnl_forward with host pointers (what replaces sess.run, reference model/pfnl.py:249-253): pageable buffers go through the
     handle's pinned strips on worker threads, page-locked buffers are DMA targets as they are, small transfers take the
