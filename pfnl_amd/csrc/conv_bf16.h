@@ -25,7 +25,7 @@ struct ConvBf16Params {
 };
 hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s);
 // the second-generation kernel (conv_bf16_v2.hip: halo by LDS-DMA, MFMA groups with nothing else in them, a serial epilogue phase) for
-// modes 0 (plain), 1 (addend + resid), 2 (conv1_i + conv10_i); launch_conv3x3_bf16 takes it unless PFNL_BF16_V2=0 (= 2: for mode 2 only)
+// modes 0 (plain), 1 (addend + resid), 2 (conv1_i + conv10_i); launch_conv3x3_bf16 takes it for the modes the third generation does not (PFNL_BF16_V3)
 hipError_t launch_conv3x3_bf16_v2(const ConvBf16Params& p, int mode, hipStream_t s);
 // the third-generation kernel (conv_bf16_v3.hip: the two halves of the workgroup half a tile period apart), same modes
 hipError_t launch_conv3x3_bf16_v3(const ConvBf16Params& p, int mode, hipStream_t s);

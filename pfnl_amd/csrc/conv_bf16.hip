@@ -578,45 +578,30 @@ hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s) {
     const bool with10 = p.x_out != nullptr;
     if (with10 && (p.addend || !p.x_w || !p.x_bias || p.add_div < 1 || p.add_div > 7 || p.items % p.add_div)) return hipErrorInvalidValue;
     const int mode = accum ? 3 : (p.addend ? 1 : (with10 ? 2 : 0));
-    {
-        static const bool v2 = [] {
-            const char* e = std::getenv("PFNL_BF16_V2");
-            return !(e && (e[0] == '0' || (e[0] == 'o' && e[1] == 'f')));
-        }();
-        // measured (1080p, rocprofv3 / same-box bench): conv1_i + conv10_i 79.5 -> 74.3 us on the second-generation kernel, the plain mode
-        // equal, the per-frame half of conv2_i 80.2 -> 79 us once its residual is fetched in accumulator layout: default for modes 0 - 2
-        // (4.40 -> 4.33 -> 4.13 ms per forward); PFNL_BF16_V2 = 0: the first kernel; = 2: the second one for conv1_i + conv10_i only
-        static const bool v2_only2 = [] {
-            const char* e = std::getenv("PFNL_BF16_V2");
-            return e && e[0] == '2';
-        }();
-        // the third-generation kernel (conv_bf16_v3.hip: the two halves of the workgroup half a tile period apart) takes conv1_i + conv10_i and
-        // the per-frame half of conv2_i (measured at 1080p, same box, rocprofv3: 76.3 -> 73.2 and 82.5 -> 79.0 us per launch, 4.24 -> 4.09 ms
-        // per forward); the plain mode - the shared half of conv2_i, two tiles per workgroup at 1080p - stays on the second generation,
-        // whose prologue is shorter (15.8 against 16.1 us).  PFNL_BF16_V3 = 0: none, = 1: all three modes, = 2: conv1_i + conv10_i only
+    if (mode != 3) {
+        // Modes 0 - 2 run on the later generations (round 5: this file's kernel keeps the accumulating mode 3 = convmerge1 only; its modes 0 - 2
+        // were reachable through PFNL_BF16_V2=0 alone and left the library).  The third-generation kernel (conv_bf16_v3.hip: the two halves
+        // of the workgroup half a tile period apart) takes conv1_i + conv10_i and the per-frame half of conv2_i (1080p, same box, rocprofv3:
+        // 76.3 -> 73.2 and 82.5 -> 79.0 us per launch, 4.24 -> 4.09 ms per forward); the plain mode - the shared half of conv2_i, two tiles per
+        // workgroup at 1080p - stays on the second generation (conv_bf16_v2.hip), whose prologue is shorter (15.8 against 16.1 us).
+        // PFNL_BF16_V3 = 0: the second generation for all three modes, = 1: the third for all three, = 2: the third for conv1_i + conv10_i only -
+        // same arithmetic, other schedule: kept as the A/B switch and as the bit-equality reference of tools/soak_r04.py.
         static const int v3 = [] {
             const char* e = std::getenv("PFNL_BF16_V3");
             return e ? std::atoi(e) : 12;
         }();
-        if (v2 && mode != 3 && (v3 == 1 || (v3 == 12 && mode != 0) || (v3 == 2 && mode == 2))) return launch_conv3x3_bf16_v3(p, mode, s);
-        if (v2 && mode != 3 && (mode == 2 || !v2_only2)) return launch_conv3x3_bf16_v2(p, mode, s);
+        if (v3 == 1 || (v3 == 12 && mode != 0) || (v3 == 2 && mode == 2)) return launch_conv3x3_bf16_v3(p, mode, s);
+        return launch_conv3x3_bf16_v2(p, mode, s);
     }
-    static std::atomic<int> attr_dev[64][4];                               // the attribute is per device
+    static std::atomic<int> attr_dev[64];                                  // the attribute is per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    std::atomic<int>* const attr = attr_dev[dev];
-    const void* fn = mode == 1 ? reinterpret_cast<const void*>(conv3x3_bf16_kernel<1>)
-                   : mode == 2 ? reinterpret_cast<const void*>(conv3x3_bf16_kernel<2>)
-                   : mode == 3 ? reinterpret_cast<const void*>(conv3x3_bf16_kernel<3>) : reinterpret_cast<const void*>(conv3x3_bf16_kernel<0>);
-    if (!attr[mode]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS_BYTES);
+    if (!attr_dev[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr[mode] = 1;
+        attr_dev[dev] = 1;
     }
-    if (mode == 1) hipLaunchKernelGGL(conv3x3_bf16_kernel<1>, dim3(grid), dim3(CB_THREADS), CB_LDS_BYTES, s, p);
-    else if (mode == 2) hipLaunchKernelGGL(conv3x3_bf16_kernel<2>, dim3(grid), dim3(CB_THREADS), CB_LDS_BYTES, s, p);
-    else if (mode == 3) hipLaunchKernelGGL(conv3x3_bf16_kernel<3>, dim3(grid), dim3(CB_THREADS), CB_LDS_BYTES, s, p);
-    else hipLaunchKernelGGL(conv3x3_bf16_kernel<0>, dim3(grid), dim3(CB_THREADS), CB_LDS_BYTES, s, p);
+    hipLaunchKernelGGL(conv3x3_bf16_kernel<3>, dim3(grid), dim3(CB_THREADS), CB_LDS_BYTES, s, p);
     return hipGetLastError();
 }
 

@@ -250,16 +250,21 @@ def test_nonlocal_f16_random_geometries_short():
     assert n >= 10 and worst["split16"] < 2e-5 and worst["f16"] < 2e-3, (n, worst)
 
 
-def test_nonlocal_f16_first_kernel_still_serves():
-    """PFNL_NL_SW=0 (and any batch whose packed operands exceed 2 GB) runs nl_attn_f16_kernel, on the same packed arrays (their key rows
-    are padded since round 4).  The choice is read once per process: the non-local tests again, in a process of their own."""
+def test_nonlocal_f16_clip_chunks():
+    """nl_attn_f16_sw_kernel reaches its packed operands through ONE buffer resource with 32-bit offsets: a batch whose operands exceed
+    ~2 GB runs in chunks of whole clips through the same scratch (launch_nl_attn_f16; the first-generation kernel that used to serve such
+    batches left the library in round 5).  The limit is a testing hook (PFNL_NL_CHUNK_BYTES, read once per process): the non-local tests
+    again with a limit of two clips' worth at 16x24 - every multi-clip case runs chunked - in a process of their own."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_ops.py"), os.path.join(here, "test_gpu_bf16.py"), "-x", "-q",
-                        "-m", "gpu", "-k", "nonlocal and not first_kernel"], capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, PFNL_NL_SW="0"), cwd=os.path.dirname(here))
+    npad = (8 * 12 + 31) // 32 * 32 + 64                           # N = 96 keys at 16x24
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_ops.py"), os.path.join(here, "test_gpu_bf16.py"),
+                        os.path.join(here, "test_gpu_forward.py"), "-x", "-q", "-m", "gpu",
+                        "-k", "(nonlocal and not clip_chunks) or forward_matches_golden or full_size_all_clips"],
+                       capture_output=True, text=True, timeout=1200,
+                       env=dict(os.environ, PFNL_NL_CHUNK_BYTES=str(2 * 2 * 4 * 96 * npad)), cwd=os.path.dirname(here))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
     assert " passed" in r.stdout and "failed" not in r.stdout
 

@@ -1,5 +1,5 @@
 """Random-geometry stress of the non-local kernels on the f16 matrix pipe (nonlocal_f16.hip: nl_attn_f16_sw_kernel by default,
-PFNL_NL_SW=0: nl_attn_f16_kernel) against the fp64 spec: random B, T in {3, 5, 7}, H, W (even), i.e. random key counts across the ring,
+the only kernel since round 5) against the fp64 spec: random B, T in {3, 5, 7}, H, W (even), i.e. random key counts across the ring,
 tile, half and key-split boundaries, in both operand forms.  A DMA piece that lands late or a ring slot refilled early is a wrong block of
 64 keys - far above the tolerances.
 usage: python tools/stress_nl.py [seconds] [seed]"""
