@@ -143,19 +143,20 @@ def cpu_baseline(weights, sample_clips, H, W, budget_s=30.0):
     def run(threads, budget):
         torch.set_num_threads(threads)
         fo = pfnl_fast.FastOracle(weights)
-        t0 = time.time()
         fo.forward(sample_clips)                      # warm-up, discarded (reference model/pfnl.py:262)
-        warm = time.time() - t0
-        # a thread count that needs more than 4 s per pass of the batch (oversubscribed oneDNN on a many-core host) is timed on the
-        # batch's first clip, so that the whole baseline stays a bounded sample (stated per thread count in clips_timed)
-        sample = sample_clips if warm <= 4.0 else sample_clips[:1]
-        times = []
+        # a thread count that needs more than 4 s per pass of the batch (oversubscribed oneDNN on a many-core host) continues on the
+        # batch's first clip, so that the whole baseline stays a bounded sample (clips_timed says which)
+        sample = sample_clips
+        fps = []
         t_end = time.time() + budget
-        while len(times) < 3 or (time.time() < t_end and len(times) < 5):
+        while len(fps) < 3 or (time.time() < t_end and len(fps) < 5):
             t0 = time.time()
             fo.forward(sample)
-            times.append(time.time() - t0)
-        return sample.shape[0] / min(times), sample.shape[0] / float(np.mean(times)), len(times), int(sample.shape[0])
+            dt = time.time() - t0
+            fps.append(sample.shape[0] / dt)
+            if dt > 4.0 and sample.shape[0] > 1:
+                sample = sample_clips[:1]
+        return max(fps), float(np.mean(fps)), len(fps), int(sample.shape[0])
 
     ncpu = os.cpu_count() or 1
     phys = physical_cores() or ncpu

@@ -221,7 +221,11 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
 #pragma unroll
     for (int k = 0; k < CS_ITERS; ++k) {
         const int id = min(k * CS_THREADS + tid, CS_PIECES - 1);    // surplus threads redo the last piece (same value)
-        const int pix = id >> 3, c = id & 7;
+        int pix = id >> 3;
+        const int c = id & 7;
+        // the two pixels of a 16-lane ds_write_b64 group are 8 apart, not neighbours: their hi halves (and then their lo' halves) fall on
+        // different banks (see conv3x3_c1c10_kernel, K1_COMMIT_PAIR8: SQ_LDS_BANK_CONFLICT 1.3e6 -> 9e4 per launch)
+        if (pix < (CS_IH * CS_IW & ~15)) pix = (pix & ~15) | ((pix & 1) << 3) | ((pix & 15) >> 1);
         const int py = pix / CS_IW, px = pix - py * CS_IW;
         grel[k] = py * wbytes + px * 256 + c * 16;
         lpk[k] = ((py * CS_IW + px) * 128 + 8 * (c & 1) + (((c >> 1) ^ ((px >> 1) & 7)) << 4)) | (py << 16) | (px << 24);
