@@ -422,7 +422,13 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_kernel(ConvSplitPara
 // Against conv3x3_sf_kernel<0> + <1>: the weight slices travel by LDS-DMA as well (L2 -> LDS, no registers: a chain switches
 // packs twice, and every unit may now bring the next unit's weights - the same three slices following the column taps consumed -
 // skipped when the next unit uses what is already there), each slice covered by its own fence load.
+#ifdef PFNL_SFC_TIMING
+__device__ long long sfc_dbg[256 * 2 * 160];
+#endif
 __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSplitParams p) {
+#ifdef PFNL_SFC_TIMING
+    int dbg_n = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char sf_smem[];
     unsigned char* const wl = sf_smem + 2 * SF_TILE_BYTES;
     float* const bl = reinterpret_cast<float*>(sf_smem + 2 * SF_TILE_BYTES + SF_W_BYTES);
@@ -551,6 +557,11 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
         }
     };
 #define SFC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifdef PFNL_SFC_TIMING   /* phase timeline of the chain kernel (tools/sfc_timing.py); not part of the product build */
+#define SFC_STAMP() do { if (lane == 0 && (wave == 0 || wave == 5) && dbg_n < 160) sfc_dbg[(blockIdx.x * 2 + (wave != 0)) * 160 + dbg_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SFC_STAMP() do {} while (0)
+#endif
 
     // ---- prologue: halo of unit 0 (the first chain's shared half: `base`) and its weights (pack 0 = shared half, channel half 0)
     int c_f, c_clip, c_y0, c_x0, n_f, n_clip, n_y0, n_x0;
@@ -588,6 +599,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
             const int nx_pk = PAR == 0 ? w_pk : (n_f != 0);
             const int nx_half = half_a ^ 1;
             const bool w_replace = PAR == 0 || nx_pk != w_pk;       // (wave-uniform; unit B -> next A only at the two ends of a chain)
+            SFC_STAMP();                                            // 0: unit start
             sfh8 X[4][2], Wv[2][2];
 #define SF_PX(g_, r_, part_) (*reinterpret_cast<const sfh8*>(tile + (paddr[(g_) >> 1] ^ (((part_) ? lo_xor : 0) | (((g_) & 1) << 5))) + (r_) * (SF_IW * 128)))
 #define SF_WT(g_, ky_, part_) (*reinterpret_cast<const sfh8*>(wlane + (((g_) * 3 + (ky_)) << 12) + ((part_) << 10)))
@@ -636,8 +648,11 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
                 if constexpr (S == 15) quarter_finish(PAR, 3);
                 if constexpr (ky == 0) {
                     if constexpr (g == 2) {
+                        SFC_STAMP();                                // 1: groups 0-1 done
                         asm volatile("" ::"v"(fence));              // slice 2 of this unit's weights has landed (and the halo, as it happens)
+                        SFC_STAMP();                                // 2: fence passed
                         SFC_BARRIER();                              // b0: column tap 0 consumed; slice 2 complete
+                        SFC_STAMP();                                // 3: past b0
                         if (w_replace) SFC_DMA_W(nx_pk, nx_half, 0);
                         if constexpr (PAR == 0) {                   // decode the next tile (past the end: this one again - a harmless re-read)
                             const int kn = min(kt + 1, nt_tiles - 1);
@@ -645,7 +660,9 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
                         }
                     }
                     if constexpr (g == 4) {
+                        SFC_STAMP();                                // 4: groups 2-3 done
                         SFC_BARRIER();                              // b1: column tap 1 consumed
+                        SFC_STAMP();                                // 5: past b1
                         if (w_replace) SFC_DMA_W(nx_pk, nx_half, 1);
                         fence_w = __builtin_amdgcn_raw_buffer_load_b32(rs, 0, 0, 0);   // covers slices 0 and 1 of the next unit's weights
                     }
@@ -771,7 +788,9 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
             }
             w_slice2_owed = w_replace;                              // slice 2 of the next unit's weights goes once this unit's is consumed: at its start
             w_pk = nx_pk;
+            SFC_STAMP();                                            // 6: groups 4-5 done
             asm volatile("" ::"v"(fence), "v"(fence_w));            // the next unit's halo and weight slices 0, 1 have landed
+            SFC_STAMP();                                            // 7: fences passed
             SFC_BARRIER();                                          // b2
         };
         unit(std::integral_constant<int, 0>{});
@@ -875,3 +894,9 @@ hipError_t launch_sf_to_f32(const uint16_t* in, float* out, size_t npix, hipStre
 }
 
 }  // namespace pfnl
+
+#ifdef PFNL_SFC_TIMING
+extern "C" int pfnl_debug_read_sfc_stamps(long long* host, size_t n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(pfnl::sfc_dbg), n * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif

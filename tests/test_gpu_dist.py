@@ -277,6 +277,7 @@ def test_comm_single_rank_rccl():
     assert np.array_equal(v, [1.5, -2.0, 7.0])
     assert np.array_equal(c.allreduce([3.25], "max"), [3.25])
     c.barrier()
+    assert c.rank_and_size() == (0, 1)                                  # pfnl_comm_rank: what ncclCommUserRank / ncclCommCount report
     t = torch.arange(24, dtype=torch.float32, device="cuda").reshape(2, 12)
     got = c.allgather(t)
     assert got.shape == (1, 2, 12) and torch.equal(got[0], t)
@@ -285,7 +286,7 @@ def test_comm_single_rank_rccl():
     c.close()
     # pfnl_comm_init_all: one process driving a list of devices (here: the one device there is) - ncclCommInitAll
     cs = Comm.init_all([0])
-    assert len(cs) == 1 and (cs[0].rank, cs[0].nranks, cs[0].device) == (0, 1, 0)
+    assert len(cs) == 1 and (cs[0].rank, cs[0].nranks, cs[0].device) == (0, 1, 0) and cs[0].rank_and_size() == (0, 1)
     cs[0].bcast_weights(eng, root=0)
     assert np.array_equal(eng.forward(x), y0)
     assert np.array_equal(cs[0].allreduce([2.0, 5.0], "max"), [2.0, 5.0])

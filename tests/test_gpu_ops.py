@@ -512,6 +512,35 @@ def test_conv3x3_wsplit(items, H, W, fused, act):
     assert np.array_equal(got, again)                              # deterministic (no atomics, fixed meeting order of the four waves)
 
 
+def test_conv3x3_wsplit_random_geometries():
+    """Random geometries through conv_wsplit_kernel (the halo arrives by LDS-DMA behind a counted wait, the four waves meet in LDS behind two
+    barriers per block: a piece that lands late or an exchange area reused early is a wrong 8 x 16 block - far above the tolerance): ~8 s of
+    random (items, H, W, fused, act) incl. sizes around the M-block edges, more blocks than workgroups and single rows / columns."""
+    import time
+    rng = np.random.default_rng(77)
+    k = (rng.normal(size=(3, 3, 64, 64)) / 24.0).astype(np.float32)
+    b = (rng.normal(size=64) * 0.1).astype(np.float32)
+    t_end, n = time.time() + 8.0, 0
+    while time.time() < t_end or n < 12:
+        items = int(rng.choice([1, 2, 3, 7, 14, 40]))
+        H = int(rng.choice([1, 2, 7, 8, 9, 15, 16, 17, 24, 31, 33, 50]))
+        W = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 80]))
+        fused, act = bool(rng.integers(2)), bool(rng.integers(2))
+        x = rng.normal(size=(items, H, W, 64)).astype(np.float32)
+        kw, div = {}, 1
+        if fused:
+            div = 7 if items % 7 == 0 else 1
+            add = rng.normal(size=(items // div, H, W, 64)).astype(np.float32)
+            res = rng.normal(size=(items, H, W, 64)).astype(np.float32)
+            kw = dict(addend=dev(add), add_div=div, resid=dev(res))
+        got = ops.conv3x3_winograd(dev(x), k, b, act=act, variant="wsplit", **kw).cpu().numpy()
+        ref = ops.conv3x3_winograd(dev(x), k, b, act=act, variant="split16", **kw).cpu().numpy()   # (itself oracle-tested above)
+        err = np.abs(got - ref).max()
+        assert err < 8e-6 * max(1.0, np.abs(ref).max()), (items, H, W, fused, act, err)
+        n += 1
+    assert n >= 12
+
+
 @pytest.mark.parametrize("items,H,W,fused,act", [(1, 8, 32, False, True), (7, 10, 38, True, True), (3, 5, 7, False, False), (1, 1, 1, False, True),
                                                   (7, 33, 70, True, True), (2, 64, 96, False, True), (28, 24, 40, True, True),
                                                   (1, 9, 130, False, True), (21, 16, 32, True, False), (4, 128, 128, False, False)])
