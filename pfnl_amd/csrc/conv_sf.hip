@@ -490,6 +490,17 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
             }                                                                                    \
         }                                                                                        \
     } while (0)
+#define SFC_DMA_HALO_PIECE(k_, rs_, org_, interior_, y0_, x0_, buf_)                             \
+    do {                                                                                         \
+        const int i_ = wave + 8 * (k_);                                                          \
+        if ((k_) < SF_DMA_ITERS - 1 || i_ < SF_NDMA) {                                           \
+            const int py_ = dpk[k_] & 0xff, px_ = dpk[k_] >> 8;                                  \
+            const int gy_ = (y0_) + py_ - 1, gx_ = (x0_) + px_ - 1;                              \
+            const bool in_ = (interior_) || ((unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W && py_ < SF_IH); \
+            const int rel_ = py_ * wbytes + px_ * 256 + (((lane & 7) ^ ((px_ >> 1) & 7)) << 4);   \
+            sf_dma16(rs_, lds0 + (buf_) * SF_TILE_BYTES + i_ * 1024, in_ ? (org_) + rel_ : 0x7fffffff); \
+        }                                                                                        \
+    } while (0)
     // one 24 KB weight slice (column tap `slot` of pack `pk_`, channel half `half_`): 24 DMA instructions, 3 per wave
     const int wvoff = wave * 1024 + lane * 16;
 #define SFC_DMA_W(pk_, half_, slot_)                                                             \
@@ -557,6 +568,9 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
         }
     };
 #define SFC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifndef SFC_SPREAD_HALO
+#define SFC_SPREAD_HALO 0
+#endif
 #ifdef PFNL_SFC_TIMING   /* phase timeline of the chain kernel (tools/sfc_timing.py); not part of the product build */
 #define SFC_STAMP() do { if (lane == 0 && (wave == 0 || wave == 5) && dbg_n < 160) sfc_dbg[(blockIdx.x * 2 + (wave != 0)) * 160 + dbg_n++] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -618,8 +632,14 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qsrc), 0, item_bytes, 0x00020000);
             const int org = ((y0q - 1) * W + x0q - 1) * 256 + nx_half * 128;
             const bool interior = y0q > 0 && y0q + SF_IH - 1 <= H && x0q > 0 && x0q + SF_IW - 1 <= W;
+#if SFC_SPREAD_HALO
+            // the halo pieces go one per sub-step BEHIND b0 (sub-steps 6 .. 11) instead of in a burst at the unit's start, where both waves
+            // of a SIMD issue their DMAs at the same time and nobody computes; slice 2 of this unit's weights keeps a fence of its own
+            unsigned fence = __builtin_amdgcn_raw_buffer_load_b32(rs, 0, 0, 0);   // (covers slice 2; re-issued behind the last halo piece)
+#else
             SFC_DMA_HALO(rs, org, interior, y0q, x0q, cb ^ 1);
             const unsigned fence = __builtin_amdgcn_raw_buffer_load_b32(rs, 0, 0, 0);
+#endif
             unsigned fence_w = 0;
             row_setup(PAR);
 
@@ -646,6 +666,10 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
                 }
                 if constexpr (S == 14) quarter_finish(PAR, 2);
                 if constexpr (S == 15) quarter_finish(PAR, 3);
+#if SFC_SPREAD_HALO
+                if constexpr (S >= 7 && S < 6 + SF_DMA_ITERS) SFC_DMA_HALO_PIECE(S - 6, rs, org, interior, y0q, x0q, cb ^ 1);
+                if constexpr (S == 6 + SF_DMA_ITERS) fence = __builtin_amdgcn_raw_buffer_load_b32(rs, 0, 0, 0);   // behind the last piece
+#endif
                 if constexpr (ky == 0) {
                     if constexpr (g == 2) {
                         SFC_STAMP();                                // 1: groups 0-1 done
@@ -654,6 +678,9 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
                         SFC_BARRIER();                              // b0: column tap 0 consumed; slice 2 complete
                         SFC_STAMP();                                // 3: past b0
                         if (w_replace) SFC_DMA_W(nx_pk, nx_half, 0);
+#if SFC_SPREAD_HALO
+                        SFC_DMA_HALO_PIECE(0, rs, org, interior, y0q, x0q, cb ^ 1);
+#endif
                         if constexpr (PAR == 0) {                   // decode the next tile (past the end: this one again - a harmless re-read)
                             const int kn = min(kt + 1, nt_tiles - 1);
                             SFC_TILE(kn, n_f, n_clip, n_y0, n_x0);
