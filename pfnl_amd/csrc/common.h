@@ -62,6 +62,8 @@ __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, 0.2f * v); }  
 // re-packs adjacent scalar adds by itself), and packed fp32 VALU is an anti-lever next to MFMAs on gfx950: it does not run in their shadow -
 // every one stops the SIMD's matrix pipe for its ~4.5 cycles plus a restart (tools/ubench/mfma_agpr_src: 2 v_pk_fma_f32 behind each MFMA =
 // 53 cycles per MFMA instead of 32; 6 v_fma_f32 = 34.5), for BOTH waves of the SIMD.  Same arithmetic, bit-identical results.
+// NEVER on operands that are MFMA results: an inline-asm consumer gets none of the XDL -> VALU wait states the compiler pads its own
+// instructions with (conv_split16.hip, mul4s).
 __device__ __forceinline__ f32x4 pfnl_add4(f32x4 a, f32x4 b) {
     f32x4 r;
     asm("v_add_f32 %0, %4, %8\n\tv_add_f32 %1, %5, %9\n\tv_add_f32 %2, %6, %10\n\tv_add_f32 %3, %7, %11"

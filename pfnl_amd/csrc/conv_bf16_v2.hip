@@ -51,7 +51,14 @@ __device__ __forceinline__ f32x4 b2_to_f32(b2u2 v) {
     return f32x4{__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xffff0000u),
                  __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xffff0000u)};
 }
-__device__ __forceinline__ f32x4 b2_lrelu4(f32x4 v, float slope) { return pfnl_lrelu4(v, slope); }   // (scalar instructions: common.h)
+__device__ __forceinline__ f32x4 b2_lrelu4(f32x4 v, float slope) {
+    const f32x4 sv = v * slope;
+    asm("v_max_f32 %0, %1, %2" : "=v"(v.x) : "v"(v.x), "v"(sv.x));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v.y) : "v"(v.y), "v"(sv.y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v.z) : "v"(v.z), "v"(sv.z));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v.w) : "v"(v.w), "v"(sv.w));
+    return v;
+}
 __device__ __forceinline__ b2u2 b2_to_bf16(f32x4 v) {             // round to nearest even (v_cvt_pk_bf16_f32)
     const b2h4 b = __builtin_convertvector(v, b2h4);
     return __builtin_bit_cast(b2u2, b);
@@ -345,9 +352,9 @@ __global__ __launch_bounds__(B2_THREADS, 1) void conv3x3_bf16_v2_kernel(ConvBf16
                 for (int q = 0; q < 2; ++q) {
                     const int r0 = 8 * h + 4 * q;
                     v[q] = f32x4{acc[n][r0], acc[n][r0 + 1], acc[n][r0 + 2], acc[n][r0 + 3]};
-                    if constexpr (FUSE) v[q] = pfnl_add4(v[q], b2_to_f32(b2u2{radd[n][h][2 * q], radd[n][h][2 * q + 1]}));
+                    if constexpr (FUSE) v[q] += b2_to_f32(b2u2{radd[n][h][2 * q], radd[n][h][2 * q + 1]});
                     v[q] = b2_lrelu4(v[q], eslope);
-                    if constexpr (FUSE) v[q] = pfnl_add4(v[q], b2_to_f32(b2u2{rr[2 * q], rr[2 * q + 1]}));
+                    if constexpr (FUSE) v[q] += b2_to_f32(b2u2{rr[2 * q], rr[2 * q + 1]});
                 }
                 const b2u2 lo = b2_to_bf16(v[0]), hi = b2_to_bf16(v[1]);
                 *slot = b2u4{lo.x, lo.y, hi.x, hi.y};
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(B2_THREADS, 1) void conv3x3_bf16_v2_kernel(ConvBf16
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const int r0 = 8 * h + 4 * q;
-                            v[q] = pfnl_add4(f32x4{bacc[n][r0], bacc[n][r0 + 1], bacc[n][r0 + 2], bacc[n][r0 + 3]}, *reinterpret_cast<const f32x4*>(p.x_bias + ech + r0));
+                            v[q] = f32x4{bacc[n][r0], bacc[n][r0 + 1], bacc[n][r0 + 2], bacc[n][r0 + 3]} + *reinterpret_cast<const f32x4*>(p.x_bias + ech + r0);
                             v[q] = b2_lrelu4(v[q], 0.2f);
                         }
                         const b2u2 lo = b2_to_bf16(v[0]), hi = b2_to_bf16(v[1]);

@@ -67,7 +67,14 @@ __device__ __forceinline__ f32x4 b3_to_f32(b3u2 v) {
     return f32x4{__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xffff0000u),
                  __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xffff0000u)};
 }
-__device__ __forceinline__ f32x4 b3_lrelu4(f32x4 v, float slope) { return pfnl_lrelu4(v, slope); }   // (scalar instructions: common.h)
+__device__ __forceinline__ f32x4 b3_lrelu4(f32x4 v, float slope) {
+    const f32x4 sv = v * slope;
+    asm("v_max_f32 %0, %1, %2" : "=v"(v.x) : "v"(v.x), "v"(sv.x));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v.y) : "v"(v.y), "v"(sv.y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v.z) : "v"(v.z), "v"(sv.z));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v.w) : "v"(v.w), "v"(sv.w));
+    return v;
+}
 __device__ __forceinline__ b3u2 b3_to_bf16(f32x4 v) {             // round to nearest even (v_cvt_pk_bf16_f32)
     const b3h4 b = __builtin_convertvector(v, b3h4);
     return __builtin_bit_cast(b3u2, b);
@@ -387,9 +394,9 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
                 for (int q = 0; q < 2; ++q) {
                     const int r0 = 8 * h + 4 * q;
                     v[q] = f32x4{acc[n][r0], acc[n][r0 + 1], acc[n][r0 + 2], acc[n][r0 + 3]};
-                    if constexpr (FUSE) v[q] = pfnl_add4(v[q], b3_to_f32(b3u2{radd[n][h][2 * q], radd[n][h][2 * q + 1]}));
+                    if constexpr (FUSE) v[q] += b3_to_f32(b3u2{radd[n][h][2 * q], radd[n][h][2 * q + 1]});
                     v[q] = b3_lrelu4(v[q], eslope);
-                    if constexpr (FUSE) v[q] = pfnl_add4(v[q], b3_to_f32(b3u2{rq[2 * n + h][2 * q], rq[2 * n + h][2 * q + 1]}));
+                    if constexpr (FUSE) v[q] += b3_to_f32(b3u2{rq[2 * n + h][2 * q], rq[2 * n + h][2 * q + 1]});
                 }
                 const b3u2 lo = b3_to_bf16(v[0]), hi = b3_to_bf16(v[1]);
                 *slot = b3u4{lo.x, lo.y, hi.x, hi.y};
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const int r0 = 8 * h + 4 * q;
-                            v[q] = pfnl_add4(f32x4{bacc[n][r0], bacc[n][r0 + 1], bacc[n][r0 + 2], bacc[n][r0 + 3]}, *reinterpret_cast<const f32x4*>(bl + 64 + ech + r0));
+                            v[q] = f32x4{bacc[n][r0], bacc[n][r0 + 1], bacc[n][r0 + 2], bacc[n][r0 + 3]} + *reinterpret_cast<const f32x4*>(bl + 64 + ech + r0);
                             v[q] = b3_lrelu4(v[q], 0.2f);
                         }
                         const b3u2 lo = b3_to_bf16(v[0]), hi = b3_to_bf16(v[1]);

@@ -91,7 +91,10 @@ __device__ __forceinline__ f32x16 mfma_f16(h8 a, h8 b, f32x16 c) {
 // f32x4 times / fma with a wave-uniform scalar as FOUR scalar instructions.  Written as v * s the compiler emits v_pk_mul_f32 / v_pk_fma_f32,
 // and packed fp32 VALU is an anti-lever next to MFMAs on gfx950: it does not run in their shadow, every one stops the matrix pipe for its
 // ~4.5 cycles plus a restart (tools/ubench/mfma_agpr_src: 2 v_pk_fma_f32 behind each MFMA = 53 cycles per MFMA, 6 v_fma_f32 = 34.5) -
-// for BOTH waves of the SIMD.  Same arithmetic (a product is a product, the fma the contraction the compiler chose): bit-identical results.
+// for BOTH waves of the SIMD.  Same arithmetic: bit-identical results.  ONLY for operands a VALU instruction produced: an inline-asm
+// consumer of MFMA results gets none of the XDL -> VALU wait states the compiler pads its own instructions with (round 5: a fold written
+// this way read the cross-term accumulator one MFMA after it was issued - repeatable at -O3, caught as run-to-run noise of 1e-7 by the -O1
+// ASAN build); the folds of accumulators therefore stay compiler-generated.
 #ifndef CS_SCALAR_F32
 #define CS_SCALAR_F32 1
 #endif
@@ -105,35 +108,6 @@ __device__ __forceinline__ f32x4 mul4s(f32x4 v, float s) {
     return v * s;
 #endif
 }
-__device__ __forceinline__ f32x4 fma4s(f32x4 a, float s, f32x4 c) {   // a * s + c
-#if CS_SCALAR_F32
-    f32x4 r;
-    asm("v_fma_f32 %0, %5, %4, %9\n\tv_fma_f32 %1, %6, %4, %10\n\tv_fma_f32 %2, %7, %4, %11\n\tv_fma_f32 %3, %8, %4, %12"
-        : "=&v"(r.x), "=&v"(r.y), "=&v"(r.z), "=&v"(r.w)
-        : "s"(s), "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w));
-    return r;
-#else
-    return a * s + c;
-#endif
-}
-
-__device__ __forceinline__ f32x16 fma16s(const f32x16& a, float s, const f32x16& c) {   // a * s + c, 16 scalar fmas
-#if CS_SCALAR_F32
-    f32x16 r;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 t = fma4s(f32x4{a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]}, s, f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]});
-        r[4 * q] = t.x;
-        r[4 * q + 1] = t.y;
-        r[4 * q + 2] = t.z;
-        r[4 * q + 3] = t.w;
-    }
-    return r;
-#else
-    return a * s + c;
-#endif
-}
-
 __device__ __forceinline__ void split4(f32x4 v, u32x2& hi, u32x2& lo, float nscale) {
     const h4 h = __builtin_convertvector(v, h4);                    // 2 x v_cvt_pk_f16_f32
     hi = __builtin_bit_cast(u32x2, h);
@@ -682,7 +656,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                 if (last) {
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
-                        accp[n] = fma16s(accc[n], CS_ISCALE, accm[n]);
+                        accp[n] = accm[n] + accc[n] * CS_ISCALE;   // (MFMA results: compiler-generated, hazard-padded)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             accm[n][r] = 0.f;
@@ -702,7 +676,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
             if constexpr (PAR == 1 && !ACCUM) {                     // the tile is complete: fold the cross terms in, hand it to the epilogue
                 // (the previous tile's second pass ran in this unit: accp is free)
 #pragma unroll
-                for (int n = 0; n < 2; ++n) accp[n] = fma16s(accc[n], CS_ISCALE, accm[n]);
+                for (int n = 0; n < 2; ++n) accp[n] = accm[n] + accc[n] * CS_ISCALE;   // (MFMA results: compiler-generated, hazard-padded)
                 ex0p = c_x0;
                 ey0p = c_y0;
                 eitemp = c_item;
@@ -925,7 +899,9 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
     auto quarter_prep = [&](RowHalves& h, const f32x16& m, const f32x16& c, int q, bool fold) __attribute__((always_inline)) {
         // channels ech + 4q .. + 3: (cross terms folded in,) leaky-relu, split - 4 VALU per value
         f32x4 t = {m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]};
-        if (fold) t = fma4s(f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]}, CS_ISCALE, t);
+        // (the fold reads MFMA results: compiler-generated arithmetic, which gets the XDL -> VALU wait states - inline asm would not)
+        if (fold) t += f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]} * CS_ISCALE;
+        else asm volatile("" : "+v"(t));                            // (not folded: t = a copy of registers a VALU wrote - base_m after its own fold)
         const f32x4 st = mul4s(t, slope);
         asm("v_max_f32 %0, %1, %2" : "=v"(t.x) : "v"(t.x), "v"(st.x));
         asm("v_max_f32 %0, %1, %2" : "=v"(t.y) : "v"(t.y), "v"(st.y));
@@ -976,7 +952,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
                 fill(q);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            base_m[n] = fma16s(cross, CS_ISCALE, base_m[n]);
+            base_m[n] += cross * CS_ISCALE;                         // (MFMA results: compiler-generated, hazard-padded)
         }
     };
     // piece j (0..7: row j >> 2, piece j & 3) of the held tile -> HBM; nothing held: out of range (dropped)

@@ -53,7 +53,10 @@ def test_no_cpu_fallback():
 
 def test_no_store_data_hazard_in_emitted_isa():
     """tools/lint_store_hazard.py over every kernel source: no VALU write to the data registers of a 16-byte buffer store
-    with an SGPR offset within two issue slots (pfnl_amd/csrc/common.h, buffer_store_b128_guarded)."""
+    with an SGPR offset within two issue slots (pfnl_amd/csrc/common.h, buffer_store_b128_guarded); and (round 5) no inline-asm
+    instruction reading a register an MFMA wrote fewer than 11 issue slots earlier, no instruction at all reading the result of an
+    inline-asm MFMA inside that window - the compiler pads neither (a fold of accumulators written as inline asm read them one MFMA
+    after they were issued: repeatable at -O3, run-to-run noise in the -O1 ASAN build)."""
     import shutil
     import subprocess
     import sys

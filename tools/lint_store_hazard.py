@@ -6,6 +6,15 @@ once in ~10^5 stores).  The recognizer of this compiler inserts no wait state, s
 a two-wait-state s_nop that takes the stored registers as inputs - they stay live up to it.  This script compiles the .hip
 files to gfx950 assembly and checks the rule on what the compiler actually emitted.
 
+Second rule (round 5): the compiler pads ITS OWN consumers of MFMA results with the XDL -> VALU wait states (8-pass MFMA: 11), but an
+INLINE-ASM instruction that reads a register an MFMA has just written gets none: it reads the accumulator before the matrix pipe has
+written it back.  Found as run-to-run noise of 1e-7 in the -O1 (ASAN) build after a fold of accumulators had been rewritten as inline-asm
+v_fma_f32 (repeatable, within every tolerance, at -O3).  The lint flags every instruction inside an ;;#ASMSTART / ;;#ASMEND block that
+reads a VGPR written by a v_mfma fewer than MFMA_STATES issue slots earlier (another MFMA that takes it whole as C is the accumulate
+chain: exempt; an s_nop n counts n + 1 slots; every other instruction 1 - conservative: an MFMA in between occupies more).  The
+reverse case is checked too: an MFMA that is ITSELF inline asm (conv_wsplit.hip: B operands in AGPRs) is unknown to the compiler, so any
+instruction reading its result inside the window is flagged.
+
 usage: python tools/lint_store_hazard.py [file.hip ...]      (default: every pfnl_amd/csrc/*.hip)      exit status 1 on a hit
 """
 import glob
@@ -61,6 +70,70 @@ def lint(asm, need=2):
     return hits
 
 
+MFMA = re.compile(r"^\s*v_mfma_\S+\s+v\[(\d+):(\d+)\]")
+VREG = re.compile(r"v\[(\d+):(\d+)\]|\bv(\d+)\b")
+MFMA_STATES = 11                                                   # 8-pass XDL write -> VALU read (12 for safety below 16-pass: these kernels use 8-pass MFMAs)
+
+
+def raw_lines(path):
+    """(instruction, inside an inline-asm block) pairs"""
+    inside = False
+    for ln in open(path):
+        if ";;#ASMSTART" in ln:
+            inside = True
+            continue
+        if ";;#ASMEND" in ln:
+            inside = False
+            continue
+        s = ln.split(";")[0].rstrip()
+        if not s.strip() or s.lstrip().startswith((".", "//")) or s.rstrip().endswith(":"):
+            continue
+        yield s, inside
+
+
+def regs_read(ins):
+    """VGPRs an instruction names as sources (every operand behind the first: destinations that are also sources - accumulate forms - are
+    named again among them)"""
+    ops = ins.split(None, 1)
+    if len(ops) < 2:
+        return set()
+    parts = ops[1].split(",")
+    out = set()
+    for part in parts[1:]:
+        for m in VREG.finditer(part):
+            if m.group(3) is not None:
+                out.add(int(m.group(3)))
+            else:
+                out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+
+def lint_mfma_asm(asm):
+    ins = list(raw_lines(asm))
+    hits = []
+    for i, (s, mfma_in_asm) in enumerate(ins):
+        m = MFMA.match(s)
+        if not m:
+            continue
+        dst = set(range(int(m.group(1)), int(m.group(2)) + 1))
+        waited, j = 0, i + 1
+        while waited < MFMA_STATES and j < len(ins):
+            t, inside = ins[j]
+            n = NOP.match(t)
+            if n:
+                waited += int(n.group(1)) + 1
+            else:
+                if MFMA.match(t) and (written_mfma := set(range(int(MFMA.match(t).group(1)), int(MFMA.match(t).group(2)) + 1))) & dst:
+                    break                                            # the accumulate chain (or the register is rewritten): the rule ends here
+                # (an MFMA that is itself inline asm - conv_wsplit.hip - is unknown to the compiler: then EVERY reader counts)
+                if (inside or mfma_in_asm) and not t.lstrip().startswith(("s_", "v_mfma")) and regs_read(t) & dst:
+                    hits.append((s.strip(), t.strip(), waited))
+                    break
+                waited += 1
+            j += 1
+    return hits
+
+
 def main():
     files = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "pfnl_amd", "csrc", "*.hip")))
     bad = 0
@@ -75,6 +148,12 @@ def main():
             for st, wr, w in hits:
                 print("    %s\n      -> %s   (after %d wait states)" % (st, wr, w))
             bad += len(hits)
+            h2 = lint_mfma_asm(asm)
+            if h2:
+                print("    %d inline-asm reader(s) of fresh MFMA results:" % len(h2))
+            for mf, rd, w in h2[:8]:
+                print("    %s\n      -> %s   (after %d issue slots, %d needed)" % (mf, rd, w, MFMA_STATES))
+            bad += len(h2)
     return 1 if bad else 0
 
 
