@@ -58,33 +58,6 @@ inline int device_cu_count() {                                      // CUs of th
 
 __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, 0.2f * v); }  // tf.nn.leaky_relu
 
-// f32x4 arithmetic as FOUR scalar instructions.  Written with vector operators the compiler emits v_pk_add / v_pk_mul / v_pk_fma_f32 (and it
-// re-packs adjacent scalar adds by itself), and packed fp32 VALU is an anti-lever next to MFMAs on gfx950: it does not run in their shadow -
-// every one stops the SIMD's matrix pipe for its ~4.5 cycles plus a restart (tools/ubench/mfma_agpr_src: 2 v_pk_fma_f32 behind each MFMA =
-// 53 cycles per MFMA instead of 32; 6 v_fma_f32 = 34.5), for BOTH waves of the SIMD.  Same arithmetic, bit-identical results.
-// NEVER on operands that are MFMA results: an inline-asm consumer gets none of the XDL -> VALU wait states the compiler pads its own
-// instructions with (conv_split16.hip, mul4s).
-__device__ __forceinline__ f32x4 pfnl_add4(f32x4 a, f32x4 b) {
-    f32x4 r;
-    asm("v_add_f32 %0, %4, %8\n\tv_add_f32 %1, %5, %9\n\tv_add_f32 %2, %6, %10\n\tv_add_f32 %3, %7, %11"
-        : "=&v"(r.x), "=&v"(r.y), "=&v"(r.z), "=&v"(r.w)
-        : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
-    return r;
-}
-__device__ __forceinline__ f32x4 pfnl_mul4s(f32x4 v, float s) {     // v * s, s wave-uniform
-    f32x4 r;
-    asm("v_mul_f32 %0, %4, %5\n\tv_mul_f32 %1, %4, %6\n\tv_mul_f32 %2, %4, %7\n\tv_mul_f32 %3, %4, %8"
-        : "=&v"(r.x), "=&v"(r.y), "=&v"(r.z), "=&v"(r.w) : "s"(s), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-    return r;
-}
-__device__ __forceinline__ f32x4 pfnl_lrelu4(f32x4 v, float slope) {   // max(v, v * slope): leaky_relu (0.2) or identity (1), branch-free
-    f32x4 r;
-    asm("v_mul_f32 %0, %4, %5\n\tv_mul_f32 %1, %4, %6\n\tv_mul_f32 %2, %4, %7\n\tv_mul_f32 %3, %4, %8\n\t"
-        "v_max_f32 %0, %0, %5\n\tv_max_f32 %1, %1, %6\n\tv_max_f32 %2, %2, %7\n\tv_max_f32 %3, %3, %8"
-        : "=&v"(r.x), "=&v"(r.y), "=&v"(r.z), "=&v"(r.w) : "s"(slope), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-    return r;
-}
-
 // ---- MFMA implicit-GEMM convolution (conv_mfma.hip) ------------------------------------------
 // Output tile of one workgroup: 8 rows x 32 columns x 64 output channels of one item.
 constexpr int CONV_TW = 32;
