@@ -140,7 +140,14 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *                 binary16 operands, fp32 accumulation and softmax state - nonlocal_f16.hip, hi parts only; within 1e-3 of the
  *                 fp64 block on [0,1]-scale outputs, measured 1e-4 ... 5e-4.  Round 1's split-operand bf16 kernel - 2.5x the
  *                 MFMAs at the same error - is kept out of the library under tools/experiments/nonlocal_bf16.hip).
- * The default can also be set with the environment variable PFNL_CONV3X3 read by pfnl_create. */
+ * The default can also be set with the environment variable PFNL_CONV3X3 read by pfnl_create.
+ * Kernel generations that are NOT options (round 5): the library ships one kernel per job.  What remains switchable by environment, read
+ * once per process, is the assignment of the two bf16 3x3 generations to the three modes - PFNL_BF16_V3 = 0 (second generation,
+ * conv_bf16_v2.hip, for all three), 1 (third generation for all three), 2 (third for conv1_i + conv10_i only); default: third for conv1_i +
+ * conv10_i and the per-frame half of conv2_i, second for the shared half.  Same arithmetic in every assignment (bit-equal results): it
+ * exists as the same-box A/B switch and as the reference of the schedule soak test (tools/soak_r04.py), not as a fallback for a failure.
+ * Gone since round 5: PFNL_BF16_V2 (first-generation bf16 kernel for modes 0 - 2), PFNL_NL_SW (first-generation non-local kernel; batches
+ * beyond 2 GB of packed operands run through the one kernel in clip chunks). */
 int pfnl_set_option(pfnl_handle* h, const char* key, const char* value);
 
 /* ---- the hot path ------------------------------------------------------------------------ */
