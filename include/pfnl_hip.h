@@ -112,6 +112,11 @@ int pfnl_finalize_weights(pfnl_handle* h);
  * key "split16_c10" = "on" (default) | "off": with split16_sf, conv1_i and conv10_i are one launch (conv3x3_c1c10_kernel): per (clip,
  *   tile) the T frame tiles of conv1_i leave as split-format lines through LDS, where conv10_i takes them as MFMA operands - inp1 is
  *   written once and never read back by a 1x1 launch (2 launches per progressive-fusion block with split16_chain).
+ * key "split16_mid" = "auto" (default since round 5) | "off": the two-launch block deals out CHAINS - a workgroup takes the T frames of
+ *   a (clip, 8x32-pixel tile) - so a launch with fewer chains than CUs leaves most of the chip idle (one clip of 128x128: 64 chains).
+ *   Below 136 chains (and above the small-shape rule's 256 tiles) the block runs as four launches that deal out single tiles:
+ *   conv1_i, conv10_i, the shared half of conv2_i, the per-frame half in flat order (same arithmetic as split16_c10=off +
+ *   split16_chain=off; tools/precision_ladder.py has the crossover).  Only with conv3x3=auto and both of those options on.
  * key "conv1x1" = "split16" (default: streaming kernel on the f16 pipe, exactly split fp32 operands) | "stream" (streaming f32-MFMA
  *                 kernel) | "tiled" (conv_mfma.hip).
  * key "nonlocal" (fp32 precision only) = "auto" (default: "split16" from 1024 keys, "f32" below) | "f32" (f32 MFMA, nonlocal.hip) |

@@ -222,6 +222,8 @@ struct pfnl_handle {
     DevBuf p10;                                               // ... those partials [B*T][H][W][64] fp32
     bool sf_chain = true;                                     // ... and conv2_i is ONE launch (option split16_chain=on|off)
     bool sf_c10 = true;                                       // ... and conv1_i + conv10_i are ONE launch (option split16_c10=on|off)
+    bool sf_mid = true;                                       // option split16_mid=auto|off: launches with fewer (clip, tile) chains than sf_mid_chains run the block as four per-tile launches
+    int sf_mid_chains = 136;                                  // (measured crossover, tools/precision_ladder.py; env PFNL_SF_MID_CHAINS for sweeps)
     bool sf_path = true;                                      // option split16_sf=on|off: with conv3x3 = conv1x1 = split16, conv1_i and conv10_i write the
                                                               // split format (conv_split16.h) and both halves of conv2_i read it by LDS-DMA (conv_sf.hip)
 
@@ -471,6 +473,11 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
         uint16_t* const ab = reinterpret_cast<uint16_t*>(h->base.p);
         uint16_t* const ap = reinterpret_cast<uint16_t*>(h->pb.p);
         const uint16_t* const w16 = reinterpret_cast<const uint16_t*>(h->wdev16.p);
+        // MID shapes (as in the fp32 trunk below): with fewer (clip, tile) chains than sf_mid_chains the chained launches - conv1_i +
+        // conv10_i, the per-frame half of conv2_i - leave most CUs idle for T tile times; conv10_i then runs as its own launch and the
+        // per-frame half deals out single tiles (bit-identical: this kernel has one summation order)
+        const bool bmid = h->sf_mid && h->bf16_fuse10 && B * ((W + 31) / 32) * ((H + 7) / 8) < h->sf_mid_chains;
+        const bool fuse10 = h->bf16_fuse10 && !bmid;
         for (int i = 0; i < c.num_block; ++i) {   // model/pfnl.py:65-71
             if (h->prof_mode == 2) {
                 h->prof_gate = prof_sampled(c.num_block, i);
@@ -482,7 +489,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             {   // conv1_i (+ conv10_i from the LDS scratch its tiles pass through: conv_bf16.hip MODE 2)
                 ProfScope ps(h, s, PFNL_K_CONV3X3);
                 ConvBf16Params q{a0, w16 + h->off16_c1[i], wd + h->off_c1_b[i], nullptr, nullptr, a1, H, W, F, 1, 1};
-                if (h->bf16_fuse10) {
+                if (fuse10) {
                     q.add_div = T;
                     q.x_w = w16 + h->off16_c10[i];
                     q.x_bias = wd + h->off_c10_b[i];
@@ -490,7 +497,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
                 }
                 HIPCHK(launch_conv3x3_bf16(q, s));
             }
-            if (!h->bf16_fuse10) {   // conv10_i as a launch of its own
+            if (!fuse10) {   // conv10_i as a launch of its own
                 ProfScope ps(h, s, PFNL_K_CONV1X1);
                 HIPCHK(launch_conv1x1_bf16(a1, w16 + h->off16_c10[i], wd + h->off_c10_b[i], ab, B, T, H * W, 1, s));
             }
@@ -502,6 +509,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             {   // conv2_i, per-frame half + shared half + bias, lrelu, residual
                 ProfScope ps(h, s, PFNL_K_CONV3X3);
                 ConvBf16Params q{a1, w16 + h->off16_c2b[i], wd + h->off_c2_b[i], ap, a0, a0, H, W, F, T, 1};
+                q.flat = bmid ? 1 : 0;
                 HIPCHK(launch_conv3x3_bf16(q, s));
             }
         }
@@ -591,7 +599,12 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             }
             continue;
         }
-        const bool c10_fused = sf && h->sf_c10;
+        // MID shapes: the two-launch block deals out CHAINS (a workgroup takes the T frames of a (clip, tile), + the shared half), so a
+        // launch with fewer chains than CUs leaves most of the chip idle for T + 2 tile times (1 clip of 128x128: 64 chains - 3.06 ms
+        // for a quarter of configs[1]'s work).  Below sf_mid_chains the block runs as four launches that deal out single tiles: conv1_i,
+        // conv10_i (1x1), the shared half of conv2_i, the per-frame half in flat order.
+        const bool mid = sf && h->sf_mid && h->conv_algo == 5 && h->sf_c10 && h->sf_chain && tiles8x32 / T < h->sf_mid_chains;   // (only under the default choices, like `small`)
+        const bool c10_fused = sf && h->sf_c10 && !mid;
         if (c10_fused) {
             // conv1_i AND conv10_i in one launch (conv_split16.hip, conv3x3_c1c10_kernel): per (clip, tile) the T frame tiles of conv1_i
             // leave as split-format lines through LDS, where conv10_i picks them up as MFMA operands; inp1 is written, never read back
@@ -668,7 +681,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             HIPCHK(launch_conv_wino_ws(wp, s));
             continue;
         }
-        if (sf && h->sf_chain) {
+        if (sf && h->sf_chain && !mid) {
             // the whole of conv2_i in one launch (conv_sf.hip, conv3x3_sf_chain_kernel): per (clip, tile) the shared half stays in
             // registers as the initial C of the T frame tiles; in place on inp0 (residual)
             ProfScope ps(h, s, PFNL_K_CONV3X3);
@@ -713,6 +726,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             p.act = 1;
             if (algo == 4) {
                 ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + (sf ? h->off16s_c2b_sf[i] : h->off16s_c2b[i]), p.bias, p.addend, p.resid, p.out, H, W, F, T, 1};
+                q.flat = mid ? 1 : 0;
                 HIPCHK(sf ? launch_conv3x3_sf(q, s) : launch_conv3x3_split16(q, s));
             } else if (wsl) {
                 ConvWsParams q{p.in, w16w + h->off16w_c2b[i], p.bias, p.addend, p.resid, p.out, H, W, F, T, 1};
@@ -826,6 +840,8 @@ int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
     if (const char* e = std::getenv("PFNL_SMALL_C10")) h->small_c10 = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_SF_CHAIN")) h->sf_chain = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_SF_C10")) h->sf_c10 = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
+    if (const char* e = std::getenv("PFNL_SF_MID")) h->sf_mid = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
+    if (const char* e = std::getenv("PFNL_SF_MID_CHAINS")) h->sf_mid_chains = std::atoi(e);   // (threshold sweeps)
     if (const char* e = std::getenv("PFNL_SPLIT16_SF")) h->sf_path = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_CONV3X3")) {
         const std::string v(e);
@@ -964,6 +980,12 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         if (v == "on") h->sf_c10 = true;
         else if (v == "off") h->sf_c10 = false;
         else return fail(PFNL_ERR_INVALID, "split16_c10 must be on or off");
+        return 0;
+    }
+    if (k == "split16_mid") {
+        if (v == "auto") h->sf_mid = true;
+        else if (v == "off") h->sf_mid = false;
+        else return fail(PFNL_ERR_INVALID, "split16_mid must be auto or off");
         return 0;
     }
     if (k == "split16_sf") {

@@ -22,6 +22,8 @@ struct ConvBf16Params {
     // convmerge1 (accumulating mode; out == addend == x_out == nullptr): wpack = add_div consecutive packs (one per frame of
     // a clip), out_f32[clip] = act(sum_t conv(in[clip*add_div + t]; W_t) + bias), fp32 [items/add_div][H][W][64]
     float* out_f32;
+    int flat;                // addend launches on the third-generation kernel: 1 = deal the tiles out one by one instead of as chains of the add_div
+                             // frames of a (clip, tile) (capi.hip, "MID shapes": fewer chains than workgroups); same result bit for bit
 };
 hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s);
 // the second-generation kernel (conv_bf16_v2.hip: halo by LDS-DMA, MFMA groups with nothing else in them, a serial epilogue phase) for

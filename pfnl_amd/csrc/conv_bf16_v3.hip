@@ -122,8 +122,9 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
     const int per_item = tiles_x * tiles_y;
     const int item_bytes = H * W * 128;
     const int wbytes = W * 128;
-    // work order: chains of the gT frames of a clip at one spatial tile, dealt out XCD by XCD (conv_bf16.hip)
-    const int gT = (FUSE || WITH10) ? p.add_div : 1;
+    // work order: chains of the gT frames of a clip at one spatial tile, dealt out XCD by XCD (conv_bf16.hip); p.flat (mode 1): single
+    // tiles - every unit is then the first of its "chain" (f == 0) and fetches its addend pieces itself
+    const int gT = ((FUSE && !p.flat) || WITH10) ? p.add_div : 1;
     const int nchains = per_item * (p.items / gT);
     const int xcd = blockIdx.x & 7, xj = blockIdx.x >> 3, cpx = gridDim.x >> 3;
     const int per_xcd = (nchains + 7) >> 3;

@@ -97,8 +97,9 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_kernel(ConvSplitPara
     const int per_item = tiles_x * tiles_y;
     const int item_bytes = H * W * 256;
     const int wbytes = W * 256;
-    // work order: chains of the gT frames of a clip at one spatial tile, dealt out XCD by XCD (conv_split16.hip)
-    const int gT = FUSE ? p.add_div : 1;
+    // work order: chains of the gT frames of a clip at one spatial tile, dealt out XCD by XCD (conv_split16.hip); p.flat: single tiles
+    // (a chain keeps the addend's tile in L2 for its frames, but a launch with fewer chains than workgroups leaves CUs idle)
+    const int gT = (FUSE && !p.flat) ? p.add_div : 1;
     const int nchains = per_item * (p.items / gT);
     const int xcd = blockIdx.x & 7, xj = blockIdx.x >> 3, cpx = gridDim.x >> 3;
     const int per_xcd = (nchains + 7) >> 3;

@@ -28,6 +28,10 @@ struct ConvSplitParams {
     const uint16_t* wpack2;  // ... and the packed kernel rows that multiply it (identity rows); launch_conv3x3_c1c10: conv10_i (conv1x1_c10_pack_weights)
     const float* bias2;      // launch_conv3x3_c1c10 only: conv10_i's bias [64]
     float* out2;             // ... and its output `base` [items/add_div][H][W] in the split format
+    int flat;                // launch_conv3x3_sf with an addend only: 1 = deal the tiles out one by one instead of as chains of the add_div frames
+                             // of a (clip, tile) - for launches with fewer chains than workgroups (capi.hip, "MID shapes").  The two input-channel
+                             // halves of a tile are summed in the order its position in the workgroup's sequence gives (boustrophedon:
+                             // the weights in LDS serve two units in a row), so the work order moves the last bit of some results
 };
 
 // THE SPLIT FORMAT ("SF") of an activation tensor that only ever feeds MFMA operands (conv1_i's output, conv10_i's output):

@@ -109,6 +109,31 @@ def test_forward_bf16_matches_rounded_oracle(geom, B, H, W):
     eng.close()
 
 
+@pytest.mark.parametrize("B,H,W,nb", [(1, 32, 32, 20), (1, 100, 130, 2), (2, 96, 96, 2), (1, 144, 180, 1)])
+def test_forward_bf16_mid_shapes_take_the_per_tile_structure(B, H, W, nb):
+    """Below 136 (clip, tile) chains the bf16 trunk runs conv10_i as its own launch and the per-frame half of conv2_i in flat tile order
+    (option split16_mid=auto, capi.hip "MID shapes"; the chained launches leave most CUs idle there: 1x7x32x32 1.37 -> 0.79 ms, 1x7x128x128
+    1.46 -> 1.06).  The flat order changes no bit (bf16_conv10=separate + split16_mid=off is the same arithmetic in chain order); the
+    fused structure differs from both only by conv10_i's summation order."""
+    geom = PFNLGeometry(num_block=nb)
+    w = synth.synthetic_weights(geom, seed=0)
+    x, _ = synth.moving_field_clips(B, 7, H, W, 4, seed=7)
+    eng = PFNLEngine(geom, device=0)
+    eng.load_weights(w)
+    eng.set_option("precision", "bf16")
+    y = eng.forward(x)                                             # split16_mid=auto (default)
+    assert np.array_equal(y, eng.forward(x))
+    eng.set_option("split16_mid", "off")
+    y_fused = eng.forward(x)                                       # conv1_i + conv10_i in one launch, chains
+    eng.set_option("bf16_conv10", "separate")
+    y_sep = eng.forward(x)                                         # the mid structure's launches, chain order
+    eng.close()
+    assert np.array_equal(y, y_sep)
+    o16 = pfnl_fast.FastOracle(w, 7, 4, nb, trunk_dtype="bf16").forward(x)
+    assert synth.psnr(y, o16) > 55.0 and synth.psnr(y_fused, o16) > 55.0
+    assert synth.psnr(y, y_fused) > 55.0
+
+
 def test_forward_bf16_1080p_against_oracle_subsample():
     """BASELINE.json configs[3] (1080p, bf16) against the ORACLE with the same rounding points
     (oracle/pfnl_fast.py trunk_dtype="bf16"): every 8th HR pixel + a dense 64x64 crop, generated once in the build

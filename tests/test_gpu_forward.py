@@ -751,6 +751,31 @@ def test_forward_option_wsplit(B, T, H, W, nb, scale):
     eng.close()
 
 
+@pytest.mark.parametrize("B,H,W,nb", [(1, 128, 128, 2), (2, 96, 96, 2), (1, 100, 130, 3), (1, 144, 180, 1), (4, 64, 64, 2)])
+def test_forward_mid_shapes_take_the_per_tile_structure(B, H, W, nb):
+    """Between the small-shape rule (< 256 tiles of 8x32 pixels per launch) and 136 (clip, tile) chains the default fp32 forward runs a
+    block as four launches that deal out single tiles (option split16_mid=auto, capi.hip "MID shapes"; the two-launch block gives every
+    workgroup a whole chain of T frames and leaves most CUs idle there: one clip of 128x128 took 3.06 ms, now 2.14).  Same kernels as
+    split16_c10=off + split16_chain=off; the flat work order of conv3x3_sf_kernel<1> changes which input-channel half of a tile is summed
+    first (its position in the workgroup's sequence decides), i.e. the last bit of some values: repeatable, inside the oracle's tolerance,
+    and within summation-order noise of the other structures."""
+    geom = PFNLGeometry(num_block=nb)
+    w = synth.synthetic_weights(geom, seed=0)
+    x = synth.uniform_clips(B, 7, H, W, seed=11)
+    eng = _engine_with(geom, w)
+    y = eng.forward(x)                                             # split16_mid=auto (default)
+    assert np.array_equal(y, eng.forward(x))
+    eng.set_option("split16_mid", "off")
+    y2 = eng.forward(x)                                            # the two-launch block
+    eng.set_option("split16_c10", "off")
+    eng.set_option("split16_chain", "off")
+    y4 = eng.forward(x)                                            # four launches, the per-frame half in chain order
+    eng.close()
+    assert np.abs(y - y4).max() < 2e-6 and np.abs(y - y2).max() < 2e-5
+    ref = pfnl_fast.FastOracle(w, num_frames=7, scale=4, num_block=nb).forward(x)
+    assert np.abs(y - ref).max() < 5e-5 and np.abs(y2 - ref).max() < 5e-5
+
+
 def test_harness_reruns_out_of_range_batches_bf16(tmp_path):
     """under precision=bf16 `strict_fp32` changes no kernel (the non-local block and conv0 keep binary16 operands), so
     the recomputation of a flagged batch re-ran the same kernels, cleared the flag and wrote quantised non-finite values.  Now the flagged
