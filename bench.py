@@ -448,7 +448,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads and the sustained run")
     ap.add_argument("--conv3x3", choices=["auto", "split16", "winograd", "winograd_tile", "direct"], default=None,
-                    help="override the 3x3 conv algorithm (default auto: split16 for launches of >= 256 tiles, winograd below)")
+                    help="override the 3x3 conv algorithm (default auto: split16 for launches of >= 200 tiles, the small-shape kernels below)")
     ap.add_argument("--conv1x1", choices=["split16", "stream", "tiled"], default=None, help="override the conv10_i algorithm")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="trunk arithmetic: fp32 = the reference's (the judged line); bf16 = BASELINE.json configs[3]'s")

@@ -81,7 +81,7 @@ int pfnl_missing_weights(pfnl_handle* h, int* count);
 int pfnl_finalize_weights(pfnl_handle* h);
 
 /* Tuning knobs (all parity-tested):  key "conv3x3" =
- *   "auto"          (default) "split16" when a launch has at least 256 tiles of 8x32 pixels, "winograd" below that;
+ *   "auto"          (default) "split16" when a launch has at least 200 tiles of 8x32 pixels, "winograd" below that;
  *   "winograd"      fused Winograd F(2x2,3x3) on f32 MFMA (2.25x fewer multiplies), persistent
  *                   wave-specialised kernel: matrix waves + helper waves (conv_wino_ws.hip);
  *   "winograd_tile" same maths, one 4-wave workgroup per tile (conv_wino.hip);
@@ -99,7 +99,7 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *   kernels before returning (pfnl_range_reruns counts them), so they cover the whole fp32 range; device-pointer calls are
  *   asynchronous: pfnl_sync returns PFNL_ERR_RANGE.  "on" (or env PFNL_STRICT_FP32=1) uses the f32-MFMA kernels throughout; weights
  *   beyond binary16's range select them by themselves at pfnl_finalize_weights.
- * key "small" = "auto" (default: the small-shape trunk kernels of conv_small.hip when a 3x3 launch has fewer than 256 tiles of 8x32
+ * key "small" = "auto" (default: the small-shape trunk kernels of conv_small.hip when a 3x3 launch has fewer than 200 tiles (256 until round 5) of 8x32
  *   pixels - conv2_i as one 128 -> 64 convolution) | "on" | "off".
  * key "small_c10" = "on" (default since round 4: TWO launches per progressive-fusion block at small shapes - the conv1_i launch also
  *   runs its finished tile through this frame's 64 x 64 slice of conv10_i and writes the partial sum; the conv2_i launch adds the T
@@ -114,7 +114,7 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *   written once and never read back by a 1x1 launch (2 launches per progressive-fusion block with split16_chain).
  * key "split16_mid" = "auto" (default since round 5) | "off": the two-launch block deals out CHAINS - a workgroup takes the T frames of
  *   a (clip, 8x32-pixel tile) - so a launch with fewer chains than CUs leaves most of the chip idle (one clip of 128x128: 64 chains).
- *   Below 136 chains (and above the small-shape rule's 256 tiles) the block runs as four launches that deal out single tiles:
+ *   Below 136 chains (and above the small-shape rule's 200 tiles) the block runs as four launches that deal out single tiles:
  *   conv1_i, conv10_i, the shared half of conv2_i, the per-frame half in flat order (same arithmetic as split16_c10=off +
  *   split16_chain=off; tools/precision_ladder.py has the crossover).  Only with conv3x3=auto and both of those options on.
  * key "conv1x1" = "split16" (default: streaming kernel on the f16 pipe, exactly split fp32 operands) | "stream" (streaming f32-MFMA

@@ -161,6 +161,11 @@ struct HostPool {
 
 }  // namespace
 
+// a 3x3 launch with fewer tiles of 8x32 pixels than this takes the small-shape trunk (conv_small.hip) under the default choices; from
+// here on the split-f16 kernels' per-tile launches are faster (tools/precision_ladder.py: 210 - 224 tiles 1.99 - 2.14 -> 1.85 - 1.90 ms;
+// 168 tiles 1.08 against 1.88).  256 (a tile per CU) until round 5.
+static constexpr int kSmallTiles = 200;
+
 struct pfnl_handle {
     pfnl_config cfg;
     hipStream_t stream = nullptr;
@@ -541,7 +546,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
     // has at least ~a tile per CU, the Winograd f32 kernel for small shapes (BASELINE.json configs[0], configs[4])
     const int tiles8x32 = F * ((W + 31) / 32) * ((H + 7) / 8);
     const bool strict = !h->bf16 && (h->strict || h->strict_once || !h->weights_f16_ok);   // f32-MFMA kernels only
-    const int algo0 = h->conv_algo == 5 ? ((tiles8x32 >= 256 && (long long)H * W * 256 < 0x7fffffffLL) ? 4 : 3) : h->conv_algo;
+    const int algo0 = h->conv_algo == 5 ? ((tiles8x32 >= kSmallTiles && (long long)H * W * 256 < 0x7fffffffLL) ? 4 : 3) : h->conv_algo;
     const int algo = (strict && (algo0 == 4 || algo0 == 6)) ? 3 : algo0;                       // 6: Winograd on the f16 pipe, split operands (conv_wsplit.hip)
     const bool wsl = algo == 6;
     const uint16_t* const w16w = reinterpret_cast<const uint16_t*>(h->wdev16s.p);
@@ -550,7 +555,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
     // small shapes (BASELINE.json configs[0], configs[4]): the trunk through conv_small.hip - 3 launches per block, conv2_i as the
     // reference writes it (3x3 over concat([base, f])); only under the default algorithm choices
     const bool small = !h->bf16 && !strict && (long long)H * W * 256 < 0x7fffffffLL &&
-                       (h->small_mode == 1 || (h->small_mode == 0 && h->conv_algo == 5 && h->conv1x1_algo == 2 && tiles8x32 < 256));
+                       (h->small_mode == 1 || (h->small_mode == 0 && h->conv_algo == 5 && h->conv1x1_algo == 2 && tiles8x32 < kSmallTiles));
     const uint16_t* const w16m = reinterpret_cast<const uint16_t*>(h->wdev16s.p);
     for (int i = 0; i < (h->bf16 ? 0 : c.num_block); ++i) {   // model/pfnl.py:65-71
         if (h->prof_mode == 2) {          // sampled profiling: see prof_sampled; each sampled block with a fresh event chain
@@ -1325,7 +1330,7 @@ int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes) {
         const long long tiles8x32 = (long long)B * T * ((W + 31) / 32) * ((H + 7) / 8);
         const bool strict = !h->bf16 && (h->strict || !h->weights_f16_ok);
         const bool small = !h->bf16 && !strict && (long long)H * W * 256 < 0x7fffffffLL &&
-                           (h->small_mode == 1 || (h->small_mode == 0 && h->conv_algo == 5 && h->conv1x1_algo == 2 && tiles8x32 < 256));
+                           (h->small_mode == 1 || (h->small_mode == 0 && h->conv_algo == 5 && h->conv1x1_algo == 2 && tiles8x32 < kSmallTiles));
         if (small && h->small_c10) f += B * T * P * 64;
     }
     *bytes = f * sizeof(float);

@@ -753,7 +753,7 @@ def test_forward_option_wsplit(B, T, H, W, nb, scale):
 
 @pytest.mark.parametrize("B,H,W,nb", [(1, 128, 128, 2), (2, 96, 96, 2), (1, 100, 130, 3), (1, 144, 180, 1), (4, 64, 64, 2)])
 def test_forward_mid_shapes_take_the_per_tile_structure(B, H, W, nb):
-    """Between the small-shape rule (< 256 tiles of 8x32 pixels per launch) and 136 (clip, tile) chains the default fp32 forward runs a
+    """Between the small-shape rule (< 200 tiles of 8x32 pixels per launch) and 136 (clip, tile) chains the default fp32 forward runs a
     block as four launches that deal out single tiles (option split16_mid=auto, capi.hip "MID shapes"; the two-launch block gives every
     workgroup a whole chain of T frames and leaves most CUs idle there: one clip of 128x128 took 3.06 ms, now 2.14).  Same kernels as
     split16_c10=off + split16_chain=off; the flat work order of conv3x3_sf_kernel<1> changes which input-channel half of a tile is summed
