@@ -11,7 +11,7 @@ from pfnl_amd import synth
 
 CASES = (("configs[0] 1x7x32x32", 1, 32, 32), ("configs[1] 4x7x128x128", 4, 128, 128), ("eval batch 4x7x128x240", 4, 128, 240),
          ("Vid4 calendar 41x7x144x180 (one `part`)", 41, 144, 180), ("Vid4 city 34x7x144x176", 34, 144, 176),
-         ("Vid4 foliage 49x7x120x180", 49, 120, 180), ("UDM10 32x7x180x318", 32, 180, 318), ("UDM10 one window 1x7x180x318", 1, 180, 318),
+         ("Vid4 foliage 49x7x120x180", 49, 120, 180), ("Vid4 one window 1x7x144x180", 1, 144, 180), ("UDM10 32x7x180x318", 32, 180, 318), ("UDM10 one window 1x7x180x318", 1, 180, 318),
          ("configs[3] 1x7x270x480 -> 1080p", 1, 270, 480))
 
 geom = PFNLGeometry()
