@@ -188,8 +188,11 @@ __device__ __forceinline__ void c1_split4(f32x4 v, c1u2& hi, c1u2& lo, float nsc
 
 // ISF: `in` is in the split format (conv_split16.h): the two operands of a k-step are two 16-byte loads, no arithmetic.
 // OSF: `out` is written in the split format (base feeds the shared half of conv2_i only: conv_sf.hip).
-template <bool ISF, bool OSF>
-__global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_split16_kernel(const float* __restrict__ in,
+// NW = waves per workgroup (one 32-pixel group each): 8 for launches with at least a workgroup per CU; 2 for the mid shapes' launches
+// (capi.hip "MID shapes": one clip of 128x128 = 512 groups = 64 workgroups of 8 waves on 64 CUs, each moving 80 KB per frame through its
+// port - 24.9 us; as 256 workgroups of 2 waves 32 KB per frame and CU).  Same arithmetic per wave: no bit changes.
+template <bool ISF, bool OSF, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void conv1x1_split16_kernel(const float* __restrict__ in,
                                                                         const uint16_t* __restrict__ wpack,
                                                                         const float* __restrict__ bias,
                                                                         float* __restrict__ out, int HW, int T, int items,
@@ -202,13 +205,16 @@ __global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_split16_kernel(const fl
     const int kh = lane >> 5;
     const int gpi = (HW + 31) >> 5;
     const int ngroups = gpi * items;
-    const int g = min(blockIdx.x * 8 + wave, ngroups - 1);          // surplus waves redo the last group (same values)
+    constexpr int NT = NW * 64, WR = C1_WF / NT;                    // threads; 16-byte weight pieces per thread and frame
+    const int g = min((int)blockIdx.x * NW + wave, ngroups - 1);    // surplus waves redo the last group (same values)
     const int item = g / gpi;
     const int p0 = (g - item * gpi) * 32;
     const float nscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -2048.0f)));
 
-    const c1u4* wsrc = reinterpret_cast<const c1u4*>(wpack) + tid;  // + f*C1_WF (+512)
-    c1u4 wr0 = wsrc[0], wr1 = wsrc[C1_THREADS];
+    const c1u4* wsrc = reinterpret_cast<const c1u4*>(wpack) + tid;  // + f*C1_WF (+ k NT)
+    c1u4 wr[WR];
+#pragma unroll
+    for (int k = 0; k < WR; ++k) wr[k] = wsrc[k * NT];
     // fp32: piece (q >> 2) * 8 + kh * 4 + (q & 3) of the pixel's 16 (4 channels each); pieces 2q', 2q'+1 = k-step q' = (M, h).
     // SF: 16-byte chunks of the pixel: [M][part][4]: k-step (M, h) takes chunk 2 kh + h of part hi (-> dst[2q']) and lo' (-> dst[2q'+1])
     const f32x4* ap = reinterpret_cast<const f32x4*>(in) + (((size_t)item * T * HW + min(p0 + xl, HW - 1)) * 16 + (ISF ? kh * 2 : kh * 4));
@@ -221,8 +227,8 @@ __global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_split16_kernel(const fl
     f32x4 a0[8] = {}, a1[8] = {}, a2[8] = {};
     C1S_LOAD_A(a0, ap);
     C1S_LOAD_A(a1, ap + (size_t)min(1, T - 1) * aframe);
-    sw[0][tid] = wr0;
-    sw[0][tid + C1_THREADS] = wr1;
+#pragma unroll
+    for (int k = 0; k < WR; ++k) sw[0][tid + k * NT] = wr[k];
     const float bias0 = bias[xl], bias1 = bias[32 + xl];
     __syncthreads();
 
@@ -242,15 +248,13 @@ __global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_split16_kernel(const fl
     do {                                                                                               \
         const int fn_ = min((f_) + 1, T - 1);                   /* past the end: harmless re-read */   \
         C1S_LOAD_A(far, ap + (size_t)min((f_) + 2, T - 1) * aframe);                                   \
-        wr0 = wsrc[(size_t)fn_ * C1_WF];                                                               \
-        wr1 = wsrc[(size_t)fn_ * C1_WF + C1_THREADS];                                                  \
+        _Pragma("unroll") for (int k_ = 0; k_ < WR; ++k_) wr[k_] = wsrc[(size_t)fn_ * C1_WF + k_ * NT]; \
         __builtin_amdgcn_sched_barrier(0);                                                             \
         const c1u4* wl_ = &sw[(f_) & 1][lane];                                                         \
         const c1u4* wn_ = &sw[((f_) + 1) & 1][lane];                                                   \
         _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {      /* k-step q = (M, h): pieces 2q, 2q+1 of the frame */ \
             if (q_ == 2) {                                      /* next frame's weights -> the other buffer */ \
-                sw[((f_) + 1) & 1][tid] = wr0;                                                         \
-                sw[((f_) + 1) & 1][tid + C1_THREADS] = wr1;                                            \
+                _Pragma("unroll") for (int k_ = 0; k_ < WR; ++k_) sw[((f_) + 1) & 1][tid + k_ * NT] = wr[k_]; \
             }                                                                                          \
             if (q_ == 3) __syncthreads();                                                              \
             const c1u4* wp_ = q_ < 3 ? wl_ + ((q_ + 1) * 4) * 64 : wn_;                                \
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_split16_kernel(const fl
 #undef C1S_FRAME
 #undef C1S_LOAD_A
 
-    if ((int)(blockIdx.x * 8 + wave) >= ngroups) return;
+    if ((int)blockIdx.x * NW + wave >= ngroups) return;
     const float slope = act ? 0.2f : 1.0f;
     float* ob = out + ((size_t)item * HW + p0) * 64 + xl;
 #pragma unroll
@@ -315,11 +319,20 @@ hipError_t launch_conv1x1_split16(const float* in, const uint16_t* wpack, const 
                                   int HW, int act, hipStream_t s, bool in_sf, bool out_sf) {
     if (!in || !wpack || !bias || !out || items < 1 || T < 1 || HW < 1) return hipErrorInvalidValue;
     const int ngroups = ((HW + 31) / 32) * items;
+    const int ncu = device_cu_count();
+    if ((ngroups + 7) / 8 < (ncu ? ncu : 256)) {                    // fewer 8-wave workgroups than CUs: 2 waves per workgroup
+        const dim3 grid((ngroups + 1) / 2), block(128);
+        if (in_sf && out_sf) hipLaunchKernelGGL((conv1x1_split16_kernel<true, true, 2>), grid, block, 0, s, in, wpack, bias, out, HW, T, items, act);
+        else if (in_sf) hipLaunchKernelGGL((conv1x1_split16_kernel<true, false, 2>), grid, block, 0, s, in, wpack, bias, out, HW, T, items, act);
+        else if (out_sf) hipLaunchKernelGGL((conv1x1_split16_kernel<false, true, 2>), grid, block, 0, s, in, wpack, bias, out, HW, T, items, act);
+        else hipLaunchKernelGGL((conv1x1_split16_kernel<false, false, 2>), grid, block, 0, s, in, wpack, bias, out, HW, T, items, act);
+        return hipGetLastError();
+    }
     const dim3 grid((ngroups + 7) / 8), block(C1_THREADS);
-    if (in_sf && out_sf) hipLaunchKernelGGL((conv1x1_split16_kernel<true, true>), grid, block, 0, s, in, wpack, bias, out, HW, T, items, act);
-    else if (in_sf) hipLaunchKernelGGL((conv1x1_split16_kernel<true, false>), grid, block, 0, s, in, wpack, bias, out, HW, T, items, act);
-    else if (out_sf) hipLaunchKernelGGL((conv1x1_split16_kernel<false, true>), grid, block, 0, s, in, wpack, bias, out, HW, T, items, act);
-    else hipLaunchKernelGGL((conv1x1_split16_kernel<false, false>), grid, block, 0, s, in, wpack, bias, out, HW, T, items, act);
+    if (in_sf && out_sf) hipLaunchKernelGGL((conv1x1_split16_kernel<true, true, 8>), grid, block, 0, s, in, wpack, bias, out, HW, T, items, act);
+    else if (in_sf) hipLaunchKernelGGL((conv1x1_split16_kernel<true, false, 8>), grid, block, 0, s, in, wpack, bias, out, HW, T, items, act);
+    else if (out_sf) hipLaunchKernelGGL((conv1x1_split16_kernel<false, true, 8>), grid, block, 0, s, in, wpack, bias, out, HW, T, items, act);
+    else hipLaunchKernelGGL((conv1x1_split16_kernel<false, false, 8>), grid, block, 0, s, in, wpack, bias, out, HW, T, items, act);
     return hipGetLastError();
 }
 
