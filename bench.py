@@ -18,7 +18,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                 what the kernel executes on the matrix pipe (3 f16 MFMAs per product block) is in mfma_executed_*, next to the
                 ceiling the chip sustains on that instruction stream under its power cap (tools/ubench/conv_core)
   sustained     >= 2 s of back-to-back steps (no events): ms/step, so clock droop is visible
-  secondary     measured in the same process after the headline: configs[3] (1080p bf16), configs[0], configs[4]
+  secondary     measured in the same process after the headline: configs[3] (1080p bf16), one Vid4 window, configs[0], configs[4]
                 (2x, T=5, 64x64) and the HOST-pointer configs[1] path (H2D + D2H inside, what the reference's
                 sess.run timing covers, model/pfnl.py:249-253)
   cpu_baseline  (N=1) the torch-CPU fp32 oracle = the stand-in for the reference's TF1 CPU path, on a bounded sample.
@@ -418,7 +418,7 @@ def resolve_conv3x3(name, B, H, W, T=7):
     """What conv3x3=auto runs for this shape (the rule of forward_device in pfnl_amd/csrc/capi.hip)."""
     name = name or os.environ.get("PFNL_CONV3X3", "auto")
     if name not in CONV3X3_KERNELS:
-        name = "split16" if B * T * ((W + 31) // 32) * ((H + 7) // 8) >= 256 else ("winograd" if os.environ.get("PFNL_SMALL") == "off" else "small")
+        name = "split16" if B * T * ((W + 31) // 32) * ((H + 7) // 8) >= 200 else ("winograd" if os.environ.get("PFNL_SMALL") == "off" else "small")
     return name
 
 
@@ -792,6 +792,11 @@ def secondary_workloads(eng, geom, weights, local_dev, dev, x_cfg2, out_cfg2):
     # configs[3] geometry in fp32 (the reference's arithmetic at 1080p)
     rec, prof = run(eng, geom, 1, 270, 480, 5, 4040, label="configs[3] geometry in fp32: 7x270x480 -> 1080x1920, batch 1")
     rec["roofline"] = conv3x3_roofline(geom, prof, 1, 270, 480, resolve_conv3x3(None, 1, 270, 480), False, "cfg4")
+    out.append(rec)
+    # one window at the reference harness's Vid4 geometry (model/pfnl.py:236-247 batches `part` windows; a caller's own forward(x) of one
+    # clip is this): 108 (clip, tile) chains - below 136 the block runs as four per-tile launches, so the two-launch
+    # byte model of `roofline` does not describe it: timing and the per-class breakdown only
+    rec, prof = run(eng, geom, 1, 144, 180, 20, 77, label="reference harness geometry: one Vid4 window 7x144x180 -> 576x720, batch 1, fp32 (mid shapes: four per-tile launches per block)")
     out.append(rec)
     # configs[0]: 7x32x32, batch 1 (the reference's CPU-runnable plumbing case; latency-bound on a GPU)
     rec, prof = run(eng, geom, 1, 32, 32, 100, 1234, label="BASELINE.json configs[0]: 4xSR 7x32x32 -> 128x128, batch 1, fp32", small=True)
