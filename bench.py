@@ -227,11 +227,14 @@ def timed_steps(step, fence, steps):
     return time.perf_counter() - t0
 
 
-def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
-    """`roofline` of the dominant kernel class from the live HIP-event timing (k = prof["conv3x3"])."""
+def conv3x3_roofline(geom, prof, B, H, W, plan, workload):
+    """`roofline` of the dominant kernel class from the live HIP-event timing (k = prof["conv3x3"]).  `plan` = PFNLEngine.plan(B, H, W)
+    (pfnl_plan): the launch structure that ran - structure name, launches per block, c10_fused / chain / sf0 - is READ there, not re-derived."""
     k = prof["conv3x3"]
     if not k["launches"]:
         return None
+    bf16 = plan.get("precision") == "bf16"
+    algo = plan_algo(plan)
     P, F = H * W, B * geom.num_frames
     avg_ms = k["ms"] / k["launches"]                                   # over the launches that were timed
     flops3 = geom.num_block * (2 * F + B) * P * 9 * 64 * 64 * 2.0      # direct-convolution FLOPs, shared-base split (DESIGN.md 3)
@@ -239,7 +242,7 @@ def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
         # bf16 trunk: the 3x3 launches are bound by HBM, not by the matrix pipe: algorithmic bytes
         # per PF block of the IMPLEMENTED launch structure = conv1_i + conv10_i in one launch (read F, write F + B tiles of 128 B per
         # pixel) + shared half (read B, write B) + per-frame half (read F + residual F + addend B, write F), over 3 launches
-        launches_per_step = 3 * geom.num_block
+        launches_per_step = 3 * geom.num_block                              # (conv10_i as its own launch - bf16_4 / bf16_mid4 - is the conv1x1 class)
         bytes_per_launch = P * 128.0 * (5 * F + 4 * B) / 3.0
         gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         name, files = CONV3X3_KERNELS["bf16"]
@@ -252,10 +255,10 @@ def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
     # fp32: conv1_i + conv2_i; the default kernel runs the whole of conv2_i as one grouped launch, the others launch its
     # shared half and its per-frame half separately
     # launches of the class per PF block: 2 with conv2_i as one launch (Winograd's grouped mode; the split-f16 chain kernel), else 3
-    chain = algo == "split16" and os.environ.get("PFNL_SF_CHAIN", "1") not in ("0", "off") and os.environ.get("PFNL_SPLIT16_SF", "1") not in ("0", "off")
-    launches_per_step = (2 if (algo == "winograd" or chain) else 3) * geom.num_block
+    chain, c10, sf0 = bool(plan.get("chain")), bool(plan.get("c10_fused")), bool(plan.get("sf0"))
+    # launches of THIS class per block: the plan's, minus conv10_i's own launch (class conv1x1) where it is not fused into conv1_i's
+    launches_per_step = (plan["launches_per_block"] - (0 if (c10 or plan["structure"].startswith("small2")) else 1)) * geom.num_block
     # conv10_i rides in the conv1_i launch of the default path (conv3x3_c1c10_kernel): its work belongs to this class then
-    c10 = algo == "split16" and os.environ.get("PFNL_SF_C10", "1") not in ("0", "off") and os.environ.get("PFNL_SPLIT16_SF", "1") not in ("0", "off")
     if c10:
         flops3 += geom.num_block * F * P * 64 * 64 * 2.0
     flops_per_launch = flops3 / launches_per_step
@@ -284,11 +287,19 @@ def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
             rec.update({"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(f_h, 4)})
         else:
             rec.update({"achieved": round(direct_tflops, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(f_m, 4)})
+        # chain2_sf0: blocks 0 .. nb-2 write their output a second time in the split format (F tiles) - REDUNDANT bytes: they stay out of the
+        # algorithmic figure `frac` is priced on and must show up as traffic / algorithmic ~ 1.19 instead
+        nb = geom.num_block
+        sf_copy = P * 256.0 * F * (nb - 1) / float(launches_per_step) if sf0 else 0.0
+        if sf0:
+            rec["sf_copy"] = {"redundant_mbytes_per_launch": round(sf_copy / 1e6, 2), "moved_mbytes_per_launch": round((bytes_per_launch + sf_copy) / 1e6, 2),
+                              "expected_traffic_over_algorithmic": round((bytes_per_launch + sf_copy) / bytes_per_launch, 3),
+                              "moved_gbs": round((bytes_per_launch + sf_copy) / (avg_ms * 1e-3) / 1e9, 1)}
         # what passes through a CU's memory port besides the compulsory bytes: the split weight pack does not fit next to the halo buffers
         # (147 KB), so every 8 x 32-pixel tile replaces one channel half of it from L2 (73 728 B; conv_split16.hip / conv_sf.hip) - bytes
         # that never reach HBM but share the port's ~11 B per clock and CU (tools/ubench/cu_stream_mix) with the ones that do
         tiles_item = ((H + 7) // 8) * ((W + 31) // 32)
-        wstream = 73728.0 * tiles_item * (2 * F + B) * geom.num_block / launches_per_step
+        wstream = 73728.0 * tiles_item * (2 * F + B) * nb / launches_per_step
         traffic = stamped_traffic("traffic_split16.json", files, (algo, workload))
         if traffic is not None and traffic < 0.95 * bytes_per_launch:
             # counter bytes below the compulsory bytes: the byte model and the launch structure that ran disagree - say so instead
@@ -298,11 +309,11 @@ def conv3x3_roofline(geom, prof, B, H, W, algo, bf16, workload):
         rec.update({"traffic": traffic, "kernel": name,
                     "avg_launch_ms": round(avg_ms, 4), "launches_timed": k["launches"], "launches_per_step": launches_per_step,
                     "mbytes_per_launch": round(bytes_per_launch / 1e6, 2),
-                    "tiles_per_block": "5F+%dB" % ((1 if c10 else 0) + (1 if chain else 3)),
+                    "tiles_per_block": "5F+%dB" % ((1 if c10 else 0) + (1 if chain else 3)), "plan": plan["structure"],
                     "stream_mix_ceiling_gbs": STREAM_MIX_CEILING_GBS, "hbm_vs_stream_mix_ceiling": round(gbs / STREAM_MIX_CEILING_GBS, 4),
                     "cu_port": {"l2_weight_stream_mbytes_per_launch": round(wstream / 1e6, 2),
-                                "mbytes_per_launch": round((bytes_per_launch + wstream) / 1e6, 2),
-                                "gbs": round((bytes_per_launch + wstream) / (avg_ms * 1e-3) / 1e9, 1),
+                                "mbytes_per_launch": round((bytes_per_launch + sf_copy + wstream) / 1e6, 2),
+                                "gbs": round((bytes_per_launch + sf_copy + wstream) / (avg_ms * 1e-3) / 1e9, 1),
                                 "ceiling_b_per_clk_cu": CU_PORT_B_PER_CLK,
                                 "note": "compulsory bytes + the weight halves a tile re-reads from L2; b_per_clk_cu / frac are filled in "
                                         "from the shader clock of the sustained run (power.sclk_mhz) when rocm-smi reports it"},
@@ -414,12 +425,10 @@ def hbm_class_rooflines(geom, kernel_ms, B, H, W, merge_stride=64):
     return out
 
 
-def resolve_conv3x3(name, B, H, W, T=7):
-    """What conv3x3=auto runs for this shape (the rule of forward_device in pfnl_amd/csrc/capi.hip)."""
-    name = name or os.environ.get("PFNL_CONV3X3", "auto")
-    if name not in CONV3X3_KERNELS:
-        name = "split16" if B * T * ((W + 31) // 32) * ((H + 7) // 8) >= 200 else ("winograd" if os.environ.get("PFNL_SMALL") == "off" else "small")
-    return name
+def plan_algo(plan):
+    """The key of CONV3X3_KERNELS / conv3x3_roofline for a launch plan (PFNLEngine.plan = pfnl_plan: the rule itself lives in capi.hip's
+    trunk_plan and nowhere else)."""
+    return "bf16" if plan.get("precision") == "bf16" else plan["conv3x3"]
 
 
 def stamped_traffic(suffix, files, key):
@@ -594,6 +603,10 @@ def main():
     bf16 = args.precision == "bf16"
     if bf16:
         eng.set_option("precision", "bf16")
+    for kv in os.environ.get("BENCH_OPTIONS", "").split(","):         # same-box A/B runs (tools/ab_r06.sh): engine options by name
+        if "=" in kv:
+            eng.set_option(*kv.split("=", 1))
+    plan = eng.plan(B_PER_GPU, H, W)                                   # the launch structure that will run (pfnl_plan: the one statement of the rule)
     x = torch.from_numpy(synth.uniform_clips(B_PER_GPU, T_WL, H, W, seed=1234 + rank)).to(dev)   # resident in HBM
     out = torch.empty(eng.out_shape(B_PER_GPU, H, W), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
@@ -624,7 +637,7 @@ def main():
     # forward comes from a separate, untimed pass with events on two blocks and on everything outside the blocks (--full-profile: the
     # timed steps carry events around every launch instead - an event costs the stream 2 us and more where it splits back-to-back launches)
     prof_mode = 0 if args.no_profile else (1 if args.full_profile else 3)
-    small_shape = resolve_conv3x3(args.conv3x3, B_PER_GPU, H, W, T=T_WL) == "small" and not bf16
+    small_shape = plan["structure"].startswith("small")
     if small_shape and prof_mode == 3:
         # launch-bound shapes (~47 launches of 5 - 15 us): even three events move the step; the timed steps carry none and the
         # breakdown pass below runs in "class runs" mode (one event per change of kernel class: pfnl_profile_enable(4))
@@ -657,8 +670,8 @@ def main():
     value = clips_total / elapsed                                     # 1 HR frame per clip
     ms_per_step = 1e3 * elapsed / args.steps
 
-    algo = resolve_conv3x3(args.conv3x3, B_PER_GPU, H, W, T=T_WL)
-    roof = conv3x3_roofline(geom, prof, B_PER_GPU, H, W, algo, bf16, args.workload)
+    algo = plan_algo(plan)
+    roof = conv3x3_roofline(geom, prof, B_PER_GPU, H, W, plan, args.workload)
     f_ref = geom.flops_per_clip(H, W) * B_PER_GPU
     f_exec = geom.flops_per_clip(H, W, shared_base=True) * B_PER_GPU
     # sampled mode: the two classes inside the PF blocks were timed in ceil(nb/4) of the nb blocks
@@ -690,7 +703,7 @@ def main():
                    "clips_per_gpu": B_PER_GPU, "global_batch": GB, "parallelism": "dp%d" % world, "backend": (args.backend if use_dist else None),
                    "comm": (("pfnl_comm (RCCL)" if comm is not None else "torch.distributed") if use_dist else None),
                    "comm_nranks": comm_nranks, "comm_required": bool(args.require_comm),
-                   "weights": "synthetic Xavier (seed 0)", "input": "resident in HBM", "conv3x3": algo},
+                   "weights": "synthetic Xavier (seed 0)", "input": "resident in HBM", "conv3x3": algo, "plan": plan["structure"]},
         "roofline": roof,
         "roofline_nl": nonlocal_roofline(geom, breakdown, B_PER_GPU, H, W, bf16),
         "roofline_hbm_classes": hbm_class_rooflines(geom, breakdown, B_PER_GPU, H, W),
@@ -786,28 +799,34 @@ def secondary_workloads(eng, geom, weights, local_dev, dev, x_cfg2, out_cfg2):
     # configs[3]: 1080p, bf16 trunk
     eng.set_option("precision", "bf16")
     rec, prof = run(eng, geom, 1, 270, 480, 10, 4040, bf16=True, label="BASELINE.json configs[3]: 4xSR 7x270x480 -> 1080x1920, batch 1, bf16 trunk")
-    rec["roofline"] = conv3x3_roofline(geom, prof, 1, 270, 480, "bf16", True, "cfg4")
+    rec["roofline"] = conv3x3_roofline(geom, prof, 1, 270, 480, eng.plan(1, 270, 480), "cfg4")
     out.append(rec)
+    rec["plan"] = eng.plan(1, 270, 480)["structure"]
     eng.set_option("precision", "fp32")
     # configs[3] geometry in fp32 (the reference's arithmetic at 1080p)
     rec, prof = run(eng, geom, 1, 270, 480, 5, 4040, label="configs[3] geometry in fp32: 7x270x480 -> 1080x1920, batch 1")
-    rec["roofline"] = conv3x3_roofline(geom, prof, 1, 270, 480, resolve_conv3x3(None, 1, 270, 480), False, "cfg4")
+    rec["roofline"] = conv3x3_roofline(geom, prof, 1, 270, 480, eng.plan(1, 270, 480), "cfg4")
+    rec["plan"] = eng.plan(1, 270, 480)["structure"]
     out.append(rec)
     # one window at the reference harness's Vid4 geometry (model/pfnl.py:236-247 batches `part` windows; a caller's own forward(x) of one
     # clip is this): 108 (clip, tile) chains - below 136 the block runs as four per-tile launches, so the two-launch
     # byte model of `roofline` does not describe it: timing and the per-class breakdown only
     rec, prof = run(eng, geom, 1, 144, 180, 20, 77, label="reference harness geometry: one Vid4 window 7x144x180 -> 576x720, batch 1, fp32 (mid shapes: four per-tile launches per block)")
+    rec["roofline"] = conv3x3_roofline(geom, prof, 1, 144, 180, eng.plan(1, 144, 180), "vid4")   # (mid4: conv1_i, shared half, per-frame half = 5F + 3B over 3 launches of this class)
+    rec["plan"] = eng.plan(1, 144, 180)["structure"]
     out.append(rec)
     # configs[0]: 7x32x32, batch 1 (the reference's CPU-runnable plumbing case; latency-bound on a GPU)
     rec, prof = run(eng, geom, 1, 32, 32, 100, 1234, label="BASELINE.json configs[0]: 4xSR 7x32x32 -> 128x128, batch 1, fp32", small=True)
-    rec["roofline"] = conv3x3_roofline(geom, prof, 1, 32, 32, resolve_conv3x3(None, 1, 32, 32), False, "cfg1")
+    rec["roofline"] = conv3x3_roofline(geom, prof, 1, 32, 32, eng.plan(1, 32, 32), "cfg1")
+    rec["plan"] = eng.plan(1, 32, 32)["structure"]
     out.append(rec)
     # configs[4]: 2x, 5 frames, 64x64 (build-defined tail; 20 blocks)
     g5 = PFNLGeometry(num_frames=5, scale=2, num_block=20)
     e5 = PFNLEngine(g5, device=local_dev)
     e5.load_weights(synth.synthetic_weights(g5, seed=0))
     rec, prof = run(e5, g5, 1, 64, 64, 100, 55, label="BASELINE.json configs[4]: 2xSR 5x64x64 -> 128x128, batch 1, fp32", small=True)
-    rec["roofline"] = conv3x3_roofline(g5, prof, 1, 64, 64, resolve_conv3x3(None, 1, 64, 64, T=5), False, "cfg5")
+    rec["roofline"] = conv3x3_roofline(g5, prof, 1, 64, 64, e5.plan(1, 64, 64), "cfg5")
+    rec["plan"] = e5.plan(1, 64, 64)["structure"]
     out.append(rec)
     e5.close()
     # configs[1] through HOST pointers: numpy in -> numpy out, H2D + kernels + D2H inside pfnl_forward
@@ -828,7 +847,7 @@ def secondary_workloads(eng, geom, weights, local_dev, dev, x_cfg2, out_cfg2):
     eng.profile(False)
     prof_h = eng.profile_read()
     Bh, Hh, Wh = int(xh.shape[0]), int(xh.shape[2]), int(xh.shape[3])          # [B, T, H, W, 3]
-    rf_h = conv3x3_roofline(geom, prof_h, Bh, Hh, Wh, resolve_conv3x3(None, Bh, Hh, Wh), False, "cfg2")
+    rf_h = conv3x3_roofline(geom, prof_h, Bh, Hh, Wh, eng.plan(Bh, Hh, Wh), "cfg2")
     out.append({"roofline": rf_h, "pcie_mbytes_per_step": round((xh.nbytes + yh.nbytes) / 1e6, 2),
                 "workload": "BASELINE.json configs[1] through HOST pointers (pageable numpy in/out: 5.5 MB H2D + 12.6 MB D2H inside pfnl_forward; "
                             "what the reference's sess.run timing covers, model/pfnl.py:249-253)",

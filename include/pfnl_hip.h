@@ -88,10 +88,6 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *   "direct"        implicit-GEMM f32 MFMA (conv_mfma.hip);
  *   "split16"       direct 3x3 on the f16 matrix pipe with exactly split fp32 operands (3 f16 MFMAs per product block,
  *                   fp32 accumulation, >= 22 mantissa bits per product: conv_split16.hip);
- *   "wsplit"        (round 5) Winograd F(2x2,3x3) on the f16 matrix pipe with the same split operands - 2.25x fewer MFMAs, the
- *                   transformed weights resident in the registers of a 4-wave workgroup (conv_wsplit.hip); four launches per block
- *                   (conv1_i, conv10_i, both halves of conv2_i).  Parity-tested, measured SLOWER than "split16" at every shape
- *                   (a lone wave per SIMD pays its LDS reads and its input transform in full): not chosen by "auto".
  * key "strict_fp32" = "off" (default) | "on".  The default fp32 path computes on the f16 matrix pipe with exactly split operands
  *   (fp32 tensors, fp32 accumulation, >= 22 mantissa bits per product) and therefore has a DOMAIN the reference's fp32 kernels do
  *   not have: |activation|, |weight| < 65504, and inputs of the non-local block on a [0,1] scale (|x| < ~350).  Leaving it makes
@@ -114,9 +110,14 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *   written once and never read back by a 1x1 launch (2 launches per progressive-fusion block with split16_chain).
  * key "split16_mid" = "auto" (default since round 5) | "off": the two-launch block deals out CHAINS - a workgroup takes the T frames of
  *   a (clip, 8x32-pixel tile) - so a launch with fewer chains than CUs leaves most of the chip idle (one clip of 128x128: 64 chains).
- *   Below 136 chains (and above the small-shape rule's 200 tiles) the block runs as four launches that deal out single tiles:
+ *   Below 136 chains (and above the small-shape rule's 200 tiles; both scale with the device's CU count / 256) the block runs as four launches that deal out single tiles:
  *   conv1_i, conv10_i, the shared half of conv2_i, the per-frame half in flat order (same arithmetic as split16_c10=off +
  *   split16_chain=off; tools/precision_ladder.py has the crossover).  Only with conv3x3=auto and both of those options on.
+ * key "split16_sf0" = "off" (default) | "on" (round 6): in the two-launch block ("chain2") the chain kernel writes the block's output - the
+ *   next block's inp0 - a second time in the split format, and conv3x3_c1c10_kernel takes its halo from that copy by LDS-DMA in operand form
+ *   (no fp32 -> binary16 split on the VALU, no register-staged commit).  Same operands in the same order: BIT-IDENTICAL results (tested).
+ *   Measured slower on the same box (configs[1]: 4.86 against 4.45 ms per step - the copy costs the chain kernel 22 us per launch, the
+ *   DMA halo saves conv1_i + conv10_i 0.6 us: DESIGN.md R6.1), so it is not the default; kept as the switch that reproduces the measurement.
  * key "conv1x1" = "split16" (default: streaming kernel on the f16 pipe, exactly split fp32 operands) | "stream" (streaming f32-MFMA
  *                 kernel) | "tiled" (conv_mfma.hip).
  * key "nonlocal" (fp32 precision only) = "auto" (default: "split16" from 1024 keys, "f32" below) | "f32" (f32 MFMA, nonlocal.hip) |
@@ -154,6 +155,10 @@ int pfnl_finalize_weights(pfnl_handle* h);
  * Gone since round 5: PFNL_BF16_V2 (first-generation bf16 kernel for modes 0 - 2), PFNL_NL_SW (first-generation non-local kernel; batches
  * beyond 2 GB of packed operands run through the one kernel in clip chunks). */
 int pfnl_set_option(pfnl_handle* h, const char* key, const char* value);
+/* The current value of option `key` in the spelling pfnl_set_option takes back - whatever set it (a call, an environment variable read by
+ * pfnl_create, the default).  For callers that change an option temporarily (the harness's range-flag recovery, model.py) and must put back
+ * what was there, not what they remember having set.  NUL-terminated into buf[buflen]. */
+int pfnl_get_option(pfnl_handle* h, const char* key, char* buf, size_t buflen);
 
 /* ---- the hot path ------------------------------------------------------------------------ */
 /* Replaces sess.run(SR_test, feed_dict={L_test: ...}) (reference model/pfnl.py:252,309) /
@@ -170,6 +175,16 @@ int pfnl_forward(pfnl_handle* h, const void* in, int in_is_device, void* out, in
  * union of the strips equals pfnl_forward's output up to summation order (tile alignment differs). */
 int pfnl_forward_strip(pfnl_handle* h, const void* in, void* out, int B, int H, int W, int row0, int nrows, void* stream);
 int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes);
+/* THE LAUNCH PLAN of the progressive-fusion trunk (reference model/pfnl.py:65-71) for a [B,T,H,W,3] forward under the handle's current
+ * options, as text: "<structure> launches_per_block=<n> precision=<..> conv3x3=<..> conv1x1=<..> c10_fused=<0|1> chain=<0|1> sf0=<0|1>
+ * strict=<0|1> tiles=<8x32-pixel tiles per per-frame launch> chains=<(clip, tile) chains>".  Structures: "small2" / "small3" (conv_small.hip,
+ * below ~0.78 tiles per CU: 200 on a 256-CU device), "mid4" (four per-tile launches, below ~0.53 chains per CU: 136), "chain2" (conv1_i +
+ * conv10_i, then the whole of conv2_i) and "chain2_sf0" (the same with a split-format copy of every block's output so that the next block's
+ * conv1_i takes its halo by LDS-DMA: option split16_sf0=on), "split16_3" / "split16_4", "winograd_ws3" / "winograd_ws4", "winograd_tile4",
+ * "direct4"; bf16: "bf16_3", "bf16_4", "bf16_mid4".  The ONE statement of the dispatch rule: pfnl_forward runs it, pfnl_workspace_bytes sizes
+ * from it, bench.py's byte model and the tests read it here.  The structure changes the summation order, hence the last bits: the same clip
+ * gives bit-different (oracle-equal) results in a batch that takes "chain2" and alone ("mid4" / "small2"). */
+int pfnl_plan(pfnl_handle* h, int B, int H, int W, char* buf, size_t buflen);
 int pfnl_sync(pfnl_handle* h);
 /* number of synchronous forwards that were redone on the f32-MFMA kernels because the f16-pipe range flag was set */
 int pfnl_range_reruns(pfnl_handle* h, long long* count);
@@ -297,12 +312,6 @@ int pfnl_op_conv3x3_bf16(const uint16_t* in, const float* kernel_host, const flo
  * product).  Same contract as pfnl_op_conv3x3_winograd (any H, W); out may alias resid. */
 int pfnl_op_conv3x3_split16(const float* in, const float* kernel_host, const float* bias_host, const float* addend, int add_div,
                             const float* resid, float* out, int items, int H, int W, int act, void* stream);
-/* The same convolution as Winograd F(2x2,3x3) on the f16 matrix pipe with split operands (option conv3x3=wsplit, conv_wsplit.hip;
- * replaces the Conv2D nodes of reference model/pfnl.py:49,51 as run at :66,69): U = G g G^T (fp64 on the host) and V = B^T d B (fp32 in
- * the kernel) are each taken as f16(x) + f16((x - f16(x)) 2^11) 2^-11, fp32 accumulation, 2.25x fewer MFMAs than the direct form; the
- * transformed weights stay in the registers of a 4-wave workgroup.  Same contract as pfnl_op_conv3x3_split16; out may alias resid. */
-int pfnl_op_conv3x3_wsplit(const float* in, const float* kernel_host, const float* bias_host, const float* addend, int add_div,
-                           const float* resid, float* out, int items, int H, int W, int act, void* stream);
 /* conv1_i + conv10_i of a progressive-fusion block as ONE launch of the fp32 path (reference model/pfnl.py:66-68;
  * conv3x3_c1c10_kernel, option split16_c10): in [clips*T,H,W,64] fp32 (device) -> out1 = lrelu(conv3x3(in; k1) + b1) per frame,
  * base = lrelu(conv1x1(concat_t out1; k10) + b10) [clips,H,W,64]; k1_host HWIO [3,3,64,64], k10_host HWIO [1,1,64T,64].  The kernel
@@ -310,6 +319,17 @@ int pfnl_op_conv3x3_wsplit(const float* in, const float* kernel_host, const floa
 int pfnl_op_conv1_conv10_split16(const float* in, const float* k1_host, const float* b1_host, const float* k10_host,
                                  const float* b10_host, float* out1, float* base, int clips, int frames_per_clip, int H, int W,
                                  void* stream);
+/* ... with its input taken in the split format by LDS-DMA (conv3x3_c1c10_kernel<true>: what blocks 1 .. nb-1 of the default "chain2_sf0"
+ * plan run, reference model/pfnl.py:66-68).  The hook converts `in` with the producer's own split first; results are BIT-IDENTICAL to
+ * pfnl_op_conv1_conv10_split16 (same binary16 operand pairs, same order). */
+int pfnl_op_conv1_conv10_split16_sf0(const float* in, const float* k1_host, const float* b1_host, const float* k10_host,
+                                     const float* b10_host, float* out1, float* base, int clips, int frames_per_clip, int H, int W,
+                                     void* stream);
+/* The whole of conv2_i in one launch (pfnl_op_conv3x3_split16_sf which = 2; reference model/pfnl.py:69-71) that ALSO writes its result in
+ * the split format (conv3x3_sf_chain_kernel<true>): out [items,H,W,64] fp32 as before; out_sf [items,H,W,128] binary16 bit patterns
+ * (device) = per pixel [channel half][hi 32 | lo' 32], hi = f16(out), lo' = f16((out - hi) 2^11). */
+int pfnl_op_conv2_chain_sf0(const float* in, const float* kernel_host, const float* bias_host, const float* base, int add_div, const float* resid,
+                            float* out, uint16_t* out_sf, int items, int H, int W, int act, void* stream);
 /* The split-format variants of the split-f16 kernels (pfnl_amd/csrc/conv_split16.h "SF": an activation tensor that only feeds MFMA
  * operands - conv1_i's and conv10_i's outputs, model/pfnl.py:66-68 - is kept as (hi, lo') binary16 pairs, built once by its
  * producer).  fp32 at the hook's interface: conversions bracket the kernel under test.

@@ -46,6 +46,8 @@ SIGNATURES = {
     "pfnl_forward": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_forward_strip": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pfnl_workspace_bytes": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_size_t)]),
+    "pfnl_plan": (_i, [_vp, _i, _i, _i, C.c_char_p, C.c_size_t]),
+    "pfnl_get_option": (_i, [_vp, C.c_char_p, C.c_char_p, C.c_size_t]),
     "pfnl_sync": (_i, [_vp]),
     "pfnl_range_reruns": (_i, [_vp, C.POINTER(C.c_longlong)]),
     "pfnl_range_flag": (_i, [_vp, C.POINTER(_i)]),
@@ -67,7 +69,6 @@ SIGNATURES = {
     "pfnl_op_conv1_conv10_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv3x3_winograd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv3x3_split16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "pfnl_op_conv3x3_wsplit": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv3x3_split16_sf": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv_small": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv_small_pf_block": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -81,6 +82,8 @@ SIGNATURES = {
     "pfnl_selftest_mfma": (_i, [_i]),
     "pfnl_op_nonlocal_embedded": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv1_conv10_split16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pfnl_op_conv1_conv10_split16_sf0": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pfnl_op_conv2_chain_sf0": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_nonlocal_block": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_conv0": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pfnl_op_tail": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -21,7 +21,6 @@
 #include "common.h"
 #include "conv_bf16.h"
 #include "conv_split16.h"
-#include "conv_wsplit.h"
 #include "conv_small.h"
 
 namespace {
@@ -164,7 +163,14 @@ struct HostPool {
 // a 3x3 launch with fewer tiles of 8x32 pixels than this takes the small-shape trunk (conv_small.hip) under the default choices; from
 // here on the split-f16 kernels' per-tile launches are faster (tools/precision_ladder.py: 210 - 224 tiles 1.99 - 2.14 -> 1.85 - 1.90 ms;
 // 168 tiles 1.08 against 1.88).  256 (a tile per CU) until round 5.
-static constexpr int kSmallTiles = 200;
+// Both work-order thresholds were measured on the 256-CU part and are a fraction of the CUs a launch can occupy: they scale with
+// device_cu_count() (a CPX partition or a smaller device keeps the same tiles-per-CU crossover).
+static constexpr int kSmallTiles256 = 200;                  // tiles of 8x32 pixels per 3x3 launch below which the small-shape trunk runs (0.78 per CU)
+static constexpr int kMidChains256 = 136;                   // (clip, tile) chains below which a block runs as four per-tile launches (0.53 per CU)
+static int scaled_by_cus(int v256) {
+    const int ncu = pfnl::device_cu_count();
+    return ncu > 0 && ncu != 256 ? std::max(1, (int)((long long)v256 * ncu / 256)) : v256;
+}
 
 struct pfnl_handle {
     pfnl_config cfg;
@@ -202,7 +208,6 @@ struct pfnl_handle {
     int nl_algo = 2;                                          // non-local block of the fp32 path: 0 f32 MFMA (nonlocal.hip), 1 split-f16 (nonlocal_f16.hip), 2 auto (1 from N = 1024 keys)
     DevBuf wdev16s;                                           // split-f16 packs of the 3x3 kernels (offsets in 16-bit elements)
     std::vector<size_t> off16s_c1, off16s_c2a, off16s_c2b, off16s_c10, off16s_c10f;   // (c10f: conv10_i as conv3x3_c1c10_kernel takes it)
-    std::vector<size_t> off16w_c1, off16w_c2a, off16w_c2b;    // Winograd packs of conv_wsplit.hip (conv3x3=wsplit), in the same blob
     std::vector<size_t> off16s_c2a_sf, off16s_c2b_sf;         // ... with the identity row map conv3x3_sf_kernel takes (conv_sf.hip)
     std::vector<size_t> off16m_c1, off16m_c10, off16m_c2;     // small-shape packs (conv_small.hip), in the same blob
     size_t off16m_m1 = 0;
@@ -228,7 +233,12 @@ struct pfnl_handle {
     bool sf_chain = true;                                     // ... and conv2_i is ONE launch (option split16_chain=on|off)
     bool sf_c10 = true;                                       // ... and conv1_i + conv10_i are ONE launch (option split16_c10=on|off)
     bool sf_mid = true;                                       // option split16_mid=auto|off: launches with fewer (clip, tile) chains than sf_mid_chains run the block as four per-tile launches
-    int sf_mid_chains = 136;                                  // (measured crossover, tools/precision_ladder.py; env PFNL_SF_MID_CHAINS for sweeps)
+    int sf_mid_chains = 0;                                    // 0: kMidChains256 scaled by the device's CUs (measured crossover, tools/precision_ladder.py; env PFNL_SF_MID_CHAINS for sweeps)
+    bool sf0 = false;                                         // option split16_sf0=off|on: in the two-launch block the chain kernel ALSO writes the block's output in the split
+                                                              // format (`inp0sf`), and the next block's conv1_i + conv10_i launch takes its halo from there by LDS-DMA (round 6).
+                                                              // Bit-identical; MEASURED SLOWER (configs[1], same box: 4.86 vs 4.45 ms - the chain kernel pays 22 us for the copy,
+                                                              // conv1_i + conv10_i gains 0.6: DESIGN.md R6.1), hence off
+    DevBuf inp0sf;                                            // ... that copy [B*T][H][W] x 256 B
     bool sf_path = true;                                      // option split16_sf=on|off: with conv3x3 = conv1x1 = split16, conv1_i and conv10_i write the
                                                               // split format (conv_split16.h) and both halves of conv2_i read it by LDS-DMA (conv_sf.hip)
 
@@ -392,6 +402,72 @@ size_t numel(const std::vector<int64_t>& s) {
     return n;
 }
 
+// THE LAUNCH PLAN of the progressive-fusion trunk for a shape under the handle's current options: the one place the dispatch rule lives.
+// forward_device runs it, pfnl_workspace_bytes sizes from it, pfnl_plan reports it (bench.py's byte model and the tests read it there).
+struct TrunkPlan {
+    bool bf16 = false, strict = false;
+    // bf16 trunk
+    bool bmid = false, fuse10 = false;
+    // fp32 trunk
+    int algo = 0, conv1x1_algo = 0;        // resolved 3x3 / 1x1 algorithm (conv_algo 5 = auto is resolved here)
+    bool sf = false;                       // inp1 and base in the split format
+    bool small = false, small_c10 = false; // conv_small.hip: 3 (2 with small_c10) launches per block
+    bool mid = false;                      // four per-tile launches per block
+    bool c10_fused = false;                // conv1_i + conv10_i in one launch (conv3x3_c1c10_kernel)
+    bool chain = false;                    // conv2_i in one launch (conv3x3_sf_chain_kernel)
+    bool sf0 = false;                      // chain2 only: split-format copy of the block output, conv1_i's halo by LDS-DMA
+    bool conv2_grouped = false;            // Winograd: conv2_i as one grouped launch
+    int launches_per_block = 0;
+    int tiles8x32 = 0, chains = 0;
+    const char* name = "";
+};
+
+TrunkPlan trunk_plan(const pfnl_handle* h, int B, int H, int W) {
+    TrunkPlan pl;
+    const int T = h->cfg.num_frames;
+    pl.bf16 = h->bf16;
+    pl.tiles8x32 = B * T * ((W + 31) / 32) * ((H + 7) / 8);
+    pl.chains = pl.tiles8x32 / T;
+    const int mid_chains = h->sf_mid_chains > 0 ? h->sf_mid_chains : scaled_by_cus(kMidChains256);
+    const int small_tiles = scaled_by_cus(kSmallTiles256);
+    const bool fits32 = (long long)H * W * 256 < 0x7fffffffLL;
+    if (h->bf16) {
+        // MID shapes (as in the fp32 trunk): with fewer (clip, tile) chains than mid_chains the chained launches leave most CUs idle
+        pl.bmid = h->sf_mid && h->bf16_fuse10 && pl.chains < mid_chains;
+        pl.fuse10 = h->bf16_fuse10 && !pl.bmid;
+        pl.launches_per_block = pl.fuse10 ? 3 : 4;
+        pl.name = pl.bmid ? "bf16_mid4" : (pl.fuse10 ? "bf16_3" : "bf16_4");
+        return pl;
+    }
+    pl.strict = h->strict || h->strict_once || !h->weights_f16_ok;   // f32-MFMA kernels only
+    // conv3x3 = auto (default): the split-f16 kernels when a launch has at least ~0.78 tiles per CU, the Winograd f32 kernel below
+    const int algo0 = h->conv_algo == 5 ? ((pl.tiles8x32 >= small_tiles && fits32) ? 4 : 3) : h->conv_algo;
+    pl.algo = (pl.strict && algo0 == 4) ? 3 : algo0;
+    pl.conv1x1_algo = (pl.strict && h->conv1x1_algo == 2) ? 1 : h->conv1x1_algo;
+    pl.sf = pl.algo == 4 && pl.conv1x1_algo == 2 && h->sf_path;
+    // small shapes (BASELINE.json configs[0], configs[4]): the trunk through conv_small.hip; only under the default algorithm choices
+    pl.small = !pl.strict && fits32 &&
+               (h->small_mode == 1 || (h->small_mode == 0 && h->conv_algo == 5 && h->conv1x1_algo == 2 && pl.tiles8x32 < small_tiles));
+    pl.small_c10 = pl.small && h->small_c10;
+    if (pl.small) {
+        pl.launches_per_block = pl.small_c10 ? 2 : 3;
+        pl.name = pl.small_c10 ? "small2" : "small3";
+        return pl;
+    }
+    pl.mid = pl.sf && h->sf_mid && h->conv_algo == 5 && h->sf_c10 && h->sf_chain && pl.chains < mid_chains;   // (only under the default choices, like `small`)
+    pl.c10_fused = pl.sf && h->sf_c10 && !pl.mid;
+    pl.chain = pl.sf && h->sf_chain && !pl.mid;
+    pl.sf0 = pl.c10_fused && pl.chain && h->sf0;
+    const int wino_groups = B * ((W + 31) / 32) * ((H + 3) / 4);
+    pl.conv2_grouped = pl.algo == 3 && h->conv2_grouped && wino_groups >= 224 && fits32;
+    pl.launches_per_block = (pl.c10_fused ? 1 : 2) + ((pl.chain || pl.conv2_grouped) ? 1 : 2);
+    pl.name = pl.mid ? "mid4" : (pl.c10_fused && pl.chain) ? (pl.sf0 ? "chain2_sf0" : "chain2")
+            : pl.algo == 4 ? (pl.launches_per_block == 3 ? "split16_3" : "split16_4")
+            : pl.algo == 3 ? (pl.conv2_grouped ? "winograd_ws3" : "winograd_ws4")
+            : pl.algo == 1 ? "winograd_tile4" : "direct4";
+    return pl;
+}
+
 // forward over device buffers
 // `strip` != null: only LR rows [strip->yoff + core0, strip->yoff + core1) of the result are produced (single-clip sharding,
 // pfnl_forward_strip): the non-local block runs its queries [q0, q1) against ALL keys, the trunk runs on the strip + halo.
@@ -404,6 +480,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
     const int N = (Hfull / 2) * (W / 2);
     const int C = 12 * T, CP = nl_padded_ch(C);
     const float* wd = h->wdev.p;
+    const TrunkPlan pl = trunk_plan(h, B, H, W);
 
     if (h->X.ensure((size_t)B * N * CP) || h->Xo.ensure((size_t)B * N * CP) ||     // (N: the FULL frame - keys are global)
         h->nlp.ensure(nl_partial_floats(B, N, C)) ||
@@ -478,11 +555,10 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
         uint16_t* const ab = reinterpret_cast<uint16_t*>(h->base.p);
         uint16_t* const ap = reinterpret_cast<uint16_t*>(h->pb.p);
         const uint16_t* const w16 = reinterpret_cast<const uint16_t*>(h->wdev16.p);
-        // MID shapes (as in the fp32 trunk below): with fewer (clip, tile) chains than sf_mid_chains the chained launches - conv1_i +
-        // conv10_i, the per-frame half of conv2_i - leave most CUs idle for T tile times; conv10_i then runs as its own launch and the
-        // per-frame half deals out single tiles (bit-identical: this kernel has one summation order)
-        const bool bmid = h->sf_mid && h->bf16_fuse10 && B * ((W + 31) / 32) * ((H + 7) / 8) < h->sf_mid_chains;
-        const bool fuse10 = h->bf16_fuse10 && !bmid;
+        // MID shapes (trunk_plan): the chained launches - conv1_i + conv10_i, the per-frame half of conv2_i - leave most CUs idle for T
+        // tile times; conv10_i then runs as its own launch and the per-frame half deals out single tiles (bit-identical: this kernel
+        // has one summation order)
+        const bool bmid = pl.bmid, fuse10 = pl.fuse10;
         for (int i = 0; i < c.num_block; ++i) {   // model/pfnl.py:65-71
             if (h->prof_mode == 2) {
                 h->prof_gate = prof_sampled(c.num_block, i);
@@ -542,20 +618,14 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
     p.in_cstride = 64;
     p.chunks_per_frame = 64 / CONV_CK;
     const int wino_groups = B * ((W + 31) / 32) * ((H + 3) / 4);   // (clip, 4x32-pixel tile) groups of conv_wino_ws
-    // conv3x3 = auto (default): the split-f16 kernel (persistent, 72 KB of weights per workgroup in its prologue) when a launch
-    // has at least ~a tile per CU, the Winograd f32 kernel for small shapes (BASELINE.json configs[0], configs[4])
-    const int tiles8x32 = F * ((W + 31) / 32) * ((H + 7) / 8);
-    const bool strict = !h->bf16 && (h->strict || h->strict_once || !h->weights_f16_ok);   // f32-MFMA kernels only
-    const int algo0 = h->conv_algo == 5 ? ((tiles8x32 >= kSmallTiles && (long long)H * W * 256 < 0x7fffffffLL) ? 4 : 3) : h->conv_algo;
-    const int algo = (strict && (algo0 == 4 || algo0 == 6)) ? 3 : algo0;                       // 6: Winograd on the f16 pipe, split operands (conv_wsplit.hip)
-    const bool wsl = algo == 6;
-    const uint16_t* const w16w = reinterpret_cast<const uint16_t*>(h->wdev16s.p);
-    const int conv1x1_algo = (strict && h->conv1x1_algo == 2) ? 1 : h->conv1x1_algo;
-    const bool sf = algo == 4 && conv1x1_algo == 2 && h->sf_path;   // inp1 and base in the split format (conv_split16.h)
-    // small shapes (BASELINE.json configs[0], configs[4]): the trunk through conv_small.hip - 3 launches per block, conv2_i as the
-    // reference writes it (3x3 over concat([base, f])); only under the default algorithm choices
-    const bool small = !h->bf16 && !strict && (long long)H * W * 256 < 0x7fffffffLL &&
-                       (h->small_mode == 1 || (h->small_mode == 0 && h->conv_algo == 5 && h->conv1x1_algo == 2 && tiles8x32 < kSmallTiles));
+    // the launch structure of a block: trunk_plan (conv3x3 = auto: the split-f16 kernels - persistent, 72 KB of weights per workgroup in
+    // their prologue - when a launch has enough tiles, the small-shape trunk / the Winograd f32 kernel below that)
+    const int algo = pl.algo, conv1x1_algo = pl.conv1x1_algo;
+    const bool sf = pl.sf;                                          // inp1 and base in the split format (conv_split16.h)
+    // small shapes (BASELINE.json configs[0], configs[4]): the trunk through conv_small.hip - conv2_i as the reference writes it
+    // (3x3 over concat([base, f]))
+    const bool small = pl.small;
+    if (pl.sf0 && h->inp0sf.ensure((size_t)F * P * 64)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
     const uint16_t* const w16m = reinterpret_cast<const uint16_t*>(h->wdev16s.p);
     for (int i = 0; i < (h->bf16 ? 0 : c.num_block); ++i) {   // model/pfnl.py:65-71
         if (h->prof_mode == 2) {          // sampled profiling: see prof_sampled; each sampled block with a fresh event chain
@@ -565,7 +635,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             h->prof_gate = i == c.num_block / 2;
             h->chain_open = false;
         }
-        if (small && h->small_c10) {
+        if (pl.small_c10) {
             // two launches per block: conv10_i rides in the conv1_i launch as per-frame partials (W10_t^T . inp1_t), which conv2_i's
             // prologue adds up (+ bias, leaky-relu) into its `base` source - no 1x1 launch, no inter-workgroup traffic inside a launch
             if (h->p10.ensure((size_t)F * P * 64)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
@@ -606,16 +676,19 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
         }
         // MID shapes: the two-launch block deals out CHAINS (a workgroup takes the T frames of a (clip, tile), + the shared half), so a
         // launch with fewer chains than CUs leaves most of the chip idle for T + 2 tile times (1 clip of 128x128: 64 chains - 3.06 ms
-        // for a quarter of configs[1]'s work).  Below sf_mid_chains the block runs as four launches that deal out single tiles: conv1_i,
-        // conv10_i (1x1), the shared half of conv2_i, the per-frame half in flat order.
-        const bool mid = sf && h->sf_mid && h->conv_algo == 5 && h->sf_c10 && h->sf_chain && tiles8x32 / T < h->sf_mid_chains;   // (only under the default choices, like `small`)
-        const bool c10_fused = sf && h->sf_c10 && !mid;
+        // for a quarter of configs[1]'s work).  Below ~0.53 chains per CU (trunk_plan) the block runs as four launches that deal out
+        // single tiles: conv1_i, conv10_i (1x1), the shared half of conv2_i, the per-frame half in flat order.
+        const bool mid = pl.mid, c10_fused = pl.c10_fused;
+        // chain2_sf0 (round 6): blocks 1 .. nb-1 read the split-format copy of inp0 the previous block's chain kernel wrote (halo by
+        // LDS-DMA); block 0 reads conv0's fp32 output, the last block writes no copy (convmerge1 reads fp32).  Bit-identical to chain2.
+        const bool in_sf0 = pl.sf0 && i > 0, out_sf0 = pl.sf0 && i + 1 < c.num_block;
         if (c10_fused) {
             // conv1_i AND conv10_i in one launch (conv_split16.hip, conv3x3_c1c10_kernel): per (clip, tile) the T frame tiles of conv1_i
             // leave as split-format lines through LDS, where conv10_i picks them up as MFMA operands; inp1 is written, never read back
             ProfScope ps(h, s, PFNL_K_CONV3X3);
             const uint16_t* const w16s = reinterpret_cast<const uint16_t*>(h->wdev16s.p);
-            ConvSplitParams q{h->inp0.p, w16s + h->off16s_c1[i], wd + h->off_c1_b[i], nullptr, nullptr, h->inp1.p, H, W, F, T, 1};
+            ConvSplitParams q{in_sf0 ? h->inp0sf.p : h->inp0.p, w16s + h->off16s_c1[i], wd + h->off_c1_b[i], nullptr, nullptr, h->inp1.p, H, W, F, T, 1};
+            q.in_sf = in_sf0 ? 1 : 0;
             q.wpack2 = w16s + h->off16s_c10f[i];
             q.bias2 = wd + h->off_c10_b[i];
             q.out2 = h->base.p;
@@ -639,9 +712,6 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
                 ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_c1[i], p.bias, nullptr, nullptr, p.out, H, W, F, 1, 1};
                 q.out_sf = sf ? 1 : 0;                              // inp1 in the split format: it only feeds conv10_i and conv2_i's MFMA operands
                 HIPCHK(launch_conv3x3_split16(q, s));
-            } else if (wsl) {
-                ConvWsParams q{p.in, w16w + h->off16w_c1[i], p.bias, nullptr, nullptr, p.out, H, W, F, 1, 1};
-                HIPCHK(launch_conv_wsplit(q, s));
             } else if (algo == 1 || algo == 3) {
                 WinoParams wp{p.in, wd + h->off_c1_u[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 1, F, nullptr};
                 HIPCHK(algo == 3 ? launch_conv_wino_ws(wp, s) : launch_conv_wino(wp, s));
@@ -666,8 +736,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
         }
         // grouped / accumulating modes chain T(+1) units inside one workgroup: only worth it when there are enough
         // (clip, tile) groups to occupy the chip (below ~220 the split launches finish sooner)
-        const bool conv2_grouped = algo == 3 && h->conv2_grouped && wino_groups >= 224 && (long long)H * W * 256 < 0x7fffffffLL;
-        if (conv2_grouped) {
+        if (pl.conv2_grouped) {
             // the whole of conv2_i in one launch: per (clip, tile) the shared half stays in LDS (conv_wino_ws MODE 2)
             ProfScope ps(h, s, PFNL_K_CONV3X3);
             WinoParams wp{};
@@ -686,7 +755,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             HIPCHK(launch_conv_wino_ws(wp, s));
             continue;
         }
-        if (sf && h->sf_chain && !mid) {
+        if (pl.chain) {
             // the whole of conv2_i in one launch (conv_sf.hip, conv3x3_sf_chain_kernel): per (clip, tile) the shared half stays in
             // registers as the initial C of the T frame tiles; in place on inp0 (residual)
             ProfScope ps(h, s, PFNL_K_CONV3X3);
@@ -694,6 +763,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             ConvSplitParams q{h->inp1.p, w16s + h->off16s_c2b_sf[i], wd + h->off_c2_b[i], nullptr, h->inp0.p, h->inp0.p, H, W, F, T, 1};
             q.in2 = h->base.p;
             q.wpack2 = w16s + h->off16s_c2a_sf[i];
+            q.out2 = out_sf0 ? h->inp0sf.p : nullptr;
             HIPCHK(launch_conv3x3_sf_chain(q, s));
             continue;
         }
@@ -709,9 +779,6 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             if (algo == 4) {
                 ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + (sf ? h->off16s_c2a_sf[i] : h->off16s_c2a[i]), p.bias, nullptr, nullptr, p.out, H, W, B, 1, 0};
                 HIPCHK(sf ? launch_conv3x3_sf(q, s) : launch_conv3x3_split16(q, s));
-            } else if (wsl) {
-                ConvWsParams q{p.in, w16w + h->off16w_c2a[i], p.bias, nullptr, nullptr, p.out, H, W, B, 1, 0};
-                HIPCHK(launch_conv_wsplit(q, s));
             } else if (algo == 1 || algo == 3) {
                 WinoParams wp{p.in, wd + h->off_c2a_u[i], p.bias, nullptr, nullptr, p.out, H, W, 1, 0, B, nullptr};
                 HIPCHK(algo == 3 ? launch_conv_wino_ws(wp, s) : launch_conv_wino(wp, s));
@@ -733,9 +800,6 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
                 ConvSplitParams q{p.in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + (sf ? h->off16s_c2b_sf[i] : h->off16s_c2b[i]), p.bias, p.addend, p.resid, p.out, H, W, F, T, 1};
                 q.flat = mid ? 1 : 0;
                 HIPCHK(sf ? launch_conv3x3_sf(q, s) : launch_conv3x3_split16(q, s));
-            } else if (wsl) {
-                ConvWsParams q{p.in, w16w + h->off16w_c2b[i], p.bias, p.addend, p.resid, p.out, H, W, F, T, 1};
-                HIPCHK(launch_conv_wsplit(q, s));
             } else if (algo == 1 || algo == 3) {
                 WinoParams wp{p.in, wd + h->off_c2b_u[i], p.bias, p.addend, p.resid, p.out, H, W, T, 1, F, nullptr};
                 HIPCHK(algo == 3 ? launch_conv_wino_ws(wp, s) : launch_conv_wino(wp, s));
@@ -762,7 +826,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
         h->prof_gate = h->prof_mode != 3;
         return 0;
     }
-    const bool m1_s16 = (algo == 4 || algo == 6) && h->m1_algo != 2 && (long long)H * W * 256 < 0x7fffffffLL;
+    const bool m1_s16 = algo == 4 && h->m1_algo != 2 && (long long)H * W * 256 < 0x7fffffffLL;
     const bool m1_wino = !m1_s16 && (algo == 3 || algo == 4) && wino_groups >= 224 && (long long)H * W * 256 < 0x7fffffffLL;
     const int mstride = (m1_wino || m1_s16) ? 64 : 48;
     h->merge_cstride = mstride;
@@ -847,10 +911,11 @@ int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
     if (const char* e = std::getenv("PFNL_SF_C10")) h->sf_c10 = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_SF_MID")) h->sf_mid = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_SF_MID_CHAINS")) h->sf_mid_chains = std::atoi(e);   // (threshold sweeps)
+    if (const char* e = std::getenv("PFNL_SF0")) h->sf0 = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_SPLIT16_SF")) h->sf_path = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_CONV3X3")) {
         const std::string v(e);
-        h->conv_algo = v == "direct" ? 0 : (v == "winograd_tile" ? 1 : (v == "split16" ? 4 : (v == "wsplit" ? 6 : (v == "winograd" ? 3 : 5))));
+        h->conv_algo = v == "direct" ? 0 : (v == "winograd_tile" ? 1 : (v == "split16" ? 4 : (v == "winograd" ? 3 : 5)));
     }
     // A BLOCKING stream: it is implicitly ordered with the legacy null stream (= torch's default stream) in both
     // directions, so host-pointer calls and graph replays on it are ordered with the caller's default-stream work.
@@ -906,7 +971,7 @@ int pfnl_destroy(pfnl_handle* h) {
     h->pin_in.release();
     h->pin_out.release();
     if (h->rflag_host) hipHostFree(h->rflag_host);
-    for (DevBuf* b : {&h->p10, &h->Xs, &h->Q, &h->wdev16s, &h->wdev, &h->wdev16, &h->nl16, &h->X, &h->Xo, &h->nlp, &h->inp0, &h->inp1, &h->base, &h->pb, &h->merge,
+    for (DevBuf* b : {&h->p10, &h->Xs, &h->Q, &h->wdev16s, &h->wdev, &h->wdev16, &h->nl16, &h->X, &h->Xo, &h->nlp, &h->inp0, &h->inp0sf, &h->inp1, &h->base, &h->pb, &h->merge,
                       &h->stage_in, &h->stage_out, &h->scratch})
         b->release();
     delete h;
@@ -957,9 +1022,8 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         else if (v == "winograd_tile") h->conv_algo = 1;
         else if (v == "direct") h->conv_algo = 0;
         else if (v == "split16") h->conv_algo = 4;
-        else if (v == "wsplit") h->conv_algo = 6;
         else if (v == "auto") h->conv_algo = 5;
-        else return fail(PFNL_ERR_INVALID, "conv3x3 must be auto, split16, wsplit, winograd, winograd_tile or direct");
+        else return fail(PFNL_ERR_INVALID, "conv3x3 must be auto, split16, winograd, winograd_tile or direct");
         return 0;
     }
     if (k == "strict_fp32") {
@@ -991,6 +1055,12 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         if (v == "auto") h->sf_mid = true;
         else if (v == "off") h->sf_mid = false;
         else return fail(PFNL_ERR_INVALID, "split16_mid must be auto or off");
+        return 0;
+    }
+    if (k == "split16_sf0") {
+        if (v == "on") h->sf0 = true;
+        else if (v == "off") h->sf0 = false;
+        else return fail(PFNL_ERR_INVALID, "split16_sf0 must be on or off");
         return 0;
     }
     if (k == "split16_sf") {
@@ -1064,6 +1134,38 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         return 0;
     }
     return fail(PFNL_ERR_INVALID, "unknown option " + k);
+}
+
+// the CURRENT value of an option as pfnl_set_option would take it back - whatever set it (pfnl_set_option, an environment variable read by
+// pfnl_create, the default): a caller that changes options temporarily restores from here, not from a mirror of its own calls
+int pfnl_get_option(pfnl_handle* h, const char* key, char* buf, size_t buflen) {
+    if (!h || !key || !buf || buflen < 1) return fail(PFNL_ERR_INVALID, "NULL argument");
+    const std::string k(key);
+    std::string v;
+    auto onoff = [](bool b) { return std::string(b ? "on" : "off"); };
+    if (k == "graph") v = h->graph_mode == 1 ? "auto" : (h->graph_mode == 2 ? "on" : "off");
+    else if (k == "conv3x3") v = h->conv_algo == 3 ? "winograd" : h->conv_algo == 1 ? "winograd_tile" : h->conv_algo == 0 ? "direct" : h->conv_algo == 4 ? "split16" : "auto";
+    else if (k == "strict_fp32") v = onoff(h->strict);
+    else if (k == "small") v = h->small_mode == 1 ? "on" : (h->small_mode == 2 ? "off" : "auto");
+    else if (k == "split16_chain") v = onoff(h->sf_chain);
+    else if (k == "split16_c10") v = onoff(h->sf_c10);
+    else if (k == "split16_mid") v = h->sf_mid ? "auto" : "off";
+    else if (k == "split16_sf0") v = onoff(h->sf0);
+    else if (k == "split16_sf") v = onoff(h->sf_path);
+    else if (k == "conv2") v = h->conv2_grouped ? "grouped" : "split";
+    else if (k == "bf16_conv10") v = h->bf16_fuse10 ? "fused" : "separate";
+    else if (k == "precision") v = h->bf16 ? "bf16" : "fp32";
+    else if (k == "merge1") v = h->m1_algo == 1 ? "split16" : (h->m1_algo == 2 ? "winograd" : "auto");
+    else if (k == "nl_type") v = h->nl_type < 0 ? "auto" : std::to_string(h->nl_type);
+    else if (k == "nl_sub_sample") v = std::to_string(h->nl_sub);
+    else if (k == "small_c10") v = onoff(h->small_c10);
+    else if (k == "bf16_nonlocal") v = "f16";
+    else if (k == "nonlocal") v = h->nl_algo == 0 ? "f32" : (h->nl_algo == 1 ? "split16" : "auto");
+    else if (k == "conv1x1") v = h->conv1x1_algo == 1 ? "stream" : (h->conv1x1_algo == 0 ? "tiled" : "split16");
+    else return fail(PFNL_ERR_INVALID, "unknown option " + k);
+    if (v.size() + 1 > buflen) return fail(PFNL_ERR_INVALID, "buffer too small");
+    std::memcpy(buf, v.c_str(), v.size() + 1);
+    return 0;
 }
 
 int pfnl_missing_weights(pfnl_handle* h, int* count) {
@@ -1252,20 +1354,7 @@ int pfnl_finalize_weights(pfnl_handle* h) {
         h->off16m_c10.assign(nb, 0);
         h->off16m_c2.assign(nb, 0);
         h->off16m_m1 = small_base + (size_t)nb * (3 * m3 + m10);
-        const size_t ws_base = (h->off16m_m1 + (size_t)T * m3 + 2 + 127) / 128 * 128, nw = pfnl::conv_wsplit_pack_halfs();
-        h->off16w_c1.assign(nb, 0);
-        h->off16w_c2a.assign(nb, 0);
-        h->off16w_c2b.assign(nb, 0);
-        b16.resize(ws_base + (size_t)nb * 3 * nw + 2, 0);             // ... + the Winograd packs of conv_wsplit.hip (conv3x3=wsplit)
-        for (int i = 0; i < nb; ++i) {
-            const std::string s = std::to_string(i);
-            h->off16w_c1[i] = ws_base + (size_t)i * 3 * nw;
-            h->off16w_c2a[i] = h->off16w_c1[i] + nw;
-            h->off16w_c2b[i] = h->off16w_c1[i] + 2 * nw;
-            pfnl::conv_wsplit_pack_weights(W("conv1_" + s).data(), 64, 0, &b16[h->off16w_c1[i]]);
-            pfnl::conv_wsplit_pack_weights(W("conv2_" + s).data(), 128, 0, &b16[h->off16w_c2a[i]]);
-            pfnl::conv_wsplit_pack_weights(W("conv2_" + s).data(), 128, 64, &b16[h->off16w_c2b[i]]);
-        }
+        b16.resize(h->off16m_m1 + (size_t)T * m3 + 2, 0);
         pfnl::conv_small_pack_weights(W("convmerge1").data(), 3, T, 48, &b16[h->off16m_m1]);
         for (int f = 0; f < T; ++f)
             pfnl::conv3x3_split16_pack_weights(W("convmerge1").data(), 64 * T, 64 * f, &b16[h->off16s_m1 + (size_t)f * n3], 48);
@@ -1326,14 +1415,31 @@ int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes) {
     if (h->bf16 || h->nl_algo != 0) f += (pfnl::nl_f16_scratch_halfs(B, (int)N) + 1) / 2;   // split K / V^T operands (bf16 or f16)
     if (h->nl_theta) f += (size_t)B * N * CP;                   // projected queries (nltype 0 / 2)
     if (h->nl_sub > 1) f += (size_t)B * ((H / 2) / h->nl_sub) * ((W / 2) / h->nl_sub) * CP;   // pooled keys
-    {   // the small-shape trunk's conv10_i partials (the rule of forward_device)
-        const long long tiles8x32 = (long long)B * T * ((W + 31) / 32) * ((H + 7) / 8);
-        const bool strict = !h->bf16 && (h->strict || !h->weights_f16_ok);
-        const bool small = !h->bf16 && !strict && (long long)H * W * 256 < 0x7fffffffLL &&
-                           (h->small_mode == 1 || (h->small_mode == 0 && h->conv_algo == 5 && h->conv1x1_algo == 2 && tiles8x32 < kSmallTiles));
-        if (small && h->small_c10) f += B * T * P * 64;
+    {   // buffers that depend on the launch plan: the small-shape trunk's conv10_i partials; the split-format copy of inp0
+        const TrunkPlan pl = trunk_plan(h, B, H, W);
+        if (pl.small_c10) f += B * T * P * 64;
+        if (pl.sf0) f += B * T * P * 64;
     }
     *bytes = f * sizeof(float);
+    return 0;
+}
+
+int pfnl_plan(pfnl_handle* h, int B, int H, int W, char* buf, size_t buflen) {
+    if (!h || !buf || buflen < 1) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return fail(PFNL_ERR_INVALID, "bad shape");
+    const TrunkPlan pl = trunk_plan(h, B, H, W);
+    static const char* const a3[] = {"direct", "winograd_tile", "?", "winograd", "split16"};
+    static const char* const a1[] = {"tiled", "stream", "split16"};
+    char tmp[256];
+    if (pl.bf16)
+        std::snprintf(tmp, sizeof tmp, "%s launches_per_block=%d precision=bf16 tiles=%d chains=%d", pl.name, pl.launches_per_block, pl.tiles8x32, pl.chains);
+    else
+        std::snprintf(tmp, sizeof tmp, "%s launches_per_block=%d precision=fp32 conv3x3=%s conv1x1=%s c10_fused=%d chain=%d sf0=%d strict=%d tiles=%d chains=%d",
+                      pl.name, pl.launches_per_block, pl.small ? "small" : a3[pl.algo < 0 || pl.algo > 4 ? 2 : pl.algo],
+                      a1[pl.conv1x1_algo < 0 || pl.conv1x1_algo > 2 ? 0 : pl.conv1x1_algo], pl.c10_fused ? 1 : 0, pl.chain ? 1 : 0, pl.sf0 ? 1 : 0,
+                      pl.strict ? 1 : 0, pl.tiles8x32, pl.chains);
+    if (std::strlen(tmp) + 1 > buflen) return fail(PFNL_ERR_INVALID, "buffer too small");
+    std::strcpy(buf, tmp);
     return 0;
 }
 
@@ -1997,27 +2103,6 @@ int pfnl_op_conv3x3_split16(const float* in, const float* kernel_host, const flo
     return 0;
 }
 
-int pfnl_op_conv3x3_wsplit(const float* in, const float* kernel_host, const float* bias_host, const float* addend, int add_div,
-                           const float* resid, float* out, int items, int H, int W, int act, void* stream) {
-    if (!in || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
-    if (items < 1 || H < 1 || W < 1 || (addend == nullptr) != (resid == nullptr)) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
-    if (addend && (add_div < 1 || items % add_div)) return fail(PFNL_ERR_INVALID, "items must be a multiple of add_div");
-    hipStream_t s = (hipStream_t)stream;
-    const size_t nh = pfnl::conv_wsplit_pack_halfs();
-    std::vector<uint16_t> pack(nh + 128, 0);
-    pfnl::conv_wsplit_pack_weights(kernel_host, 64, 0, pack.data());
-    if (bias_host) std::memcpy(&pack[nh], bias_host, 64 * sizeof(float));
-    uint16_t* dw = nullptr;
-    HIPCHK(hipMalloc(&dw, pack.size() * sizeof(uint16_t)));
-    hipError_t e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
-    pfnl::ConvWsParams q{in, dw, reinterpret_cast<const float*>(dw + nh), addend, resid, out, H, W, items, add_div < 1 ? 1 : add_div, act};
-    if (e == hipSuccess) e = pfnl::launch_conv_wsplit(q, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(dw);
-    if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv3x3 wsplit op: ") + hipGetErrorString(e));
-    return 0;
-}
-
 int pfnl_op_conv1_conv10_bf16(const uint16_t* in, const float* k1_host, const float* b1_host, const float* k10_host,
                               const float* b10_host, uint16_t* out1, uint16_t* base, int clips, int frames_per_clip, int H, int W,
                               void* stream) {
@@ -2182,13 +2267,10 @@ int pfnl_op_conv_small_pf_block(const float* x, const float* k1_host, const floa
 // against the fp64 spec at its own scale and not only inside the forward.
 //   which = 0: conv3x3_sf_kernel (input SF by LDS-DMA, epilogue from registers; plain or fused with addend + resid)
 //   which = 1: conv3x3_split16_kernel<0, OSF> (conv1_i: fp32 in, SF out)
-int pfnl_op_conv3x3_split16_sf(int which, const float* in, const float* kernel_host, const float* bias_host, const float* addend,
-                               int add_div, const float* resid, float* out, int items, int H, int W, int act, void* stream) {
-    if (!in || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
-    if (which < 0 || which > 2 || items < 1 || H < 1 || W < 1 || (addend == nullptr) != (resid == nullptr)) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
-    if (addend && ((which != 0 && which != 2) || add_div < 1 || items % add_div)) return fail(PFNL_ERR_INVALID, "fused mode: which = 0 or 2, items a multiple of add_div");
-    if (which == 2) {   // the whole of conv2_i (conv3x3_sf_chain_kernel): kernel_host = HWIO [3,3,128,64], `addend` = base [items/add_div][H][W][64] fp32
-        if (!addend) return fail(PFNL_ERR_INVALID, "which = 2 needs base (addend argument) and resid");
+static int op_conv2_chain(const float* in, const float* kernel_host, const float* bias_host, const float* addend, int add_div, const float* resid,
+                          float* out, uint16_t* out_sf, int items, int H, int W, int act, void* stream) {
+    {
+        {
         hipStream_t s2 = (hipStream_t)stream;
         const size_t nh2 = pfnl::conv3x3_split16_pack_halfs();
         std::vector<uint16_t> pk(2 * nh2 + 128, 0);
@@ -2207,6 +2289,7 @@ int pfnl_op_conv3x3_split16_sf(int which, const float* in, const float* kernel_h
         pfnl::ConvSplitParams q{reinterpret_cast<const float*>(tf), dw2 + nh2, reinterpret_cast<const float*>(dw2 + 2 * nh2), nullptr, out, out, H, W, items, add_div, act};
         q.in2 = reinterpret_cast<const float*>(tb);
         q.wpack2 = dw2;
+        q.out2 = reinterpret_cast<float*>(out_sf);                      // (null: no split-format copy)
         if (e2 == hipSuccess) e2 = pfnl::launch_conv3x3_sf_chain(q, s2);
         if (e2 == hipSuccess) e2 = hipStreamSynchronize(s2);
         (void)hipFree(dw2);
@@ -2214,6 +2297,26 @@ int pfnl_op_conv3x3_split16_sf(int which, const float* in, const float* kernel_h
         (void)hipFree(tb);
         if (e2 != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv2 chain op: ") + hipGetErrorString(e2));
         return 0;
+        }
+    }
+}
+// the whole of conv2_i in one launch WITH the split-format copy of its output (conv3x3_sf_chain_kernel<true>, option split16_sf0):
+// out as pfnl_op_conv3x3_split16_sf(which = 2); out_sf [items][H][W][128] binary16 bit patterns (device) = the split format of `out`
+int pfnl_op_conv2_chain_sf0(const float* in, const float* kernel_host, const float* bias_host, const float* base, int add_div, const float* resid,
+                            float* out, uint16_t* out_sf, int items, int H, int W, int act, void* stream) {
+    if (!in || !kernel_host || !out || !out_sf || !base || !resid) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (items < 1 || H < 1 || W < 1 || add_div < 1 || items % add_div) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
+    return op_conv2_chain(in, kernel_host, bias_host, base, add_div, resid, out, out_sf, items, H, W, act, stream);
+}
+
+int pfnl_op_conv3x3_split16_sf(int which, const float* in, const float* kernel_host, const float* bias_host, const float* addend,
+                               int add_div, const float* resid, float* out, int items, int H, int W, int act, void* stream) {
+    if (!in || !kernel_host || !out) return fail(PFNL_ERR_INVALID, "NULL argument");
+    if (which < 0 || which > 2 || items < 1 || H < 1 || W < 1 || (addend == nullptr) != (resid == nullptr)) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
+    if (addend && ((which != 0 && which != 2) || add_div < 1 || items % add_div)) return fail(PFNL_ERR_INVALID, "fused mode: which = 0 or 2, items a multiple of add_div");
+    if (which == 2) {   // the whole of conv2_i (conv3x3_sf_chain_kernel): kernel_host = HWIO [3,3,128,64], `addend` = base [items/add_div][H][W][64] fp32
+        if (!addend) return fail(PFNL_ERR_INVALID, "which = 2 needs base (addend argument) and resid");
+        return op_conv2_chain(in, kernel_host, bias_host, addend, add_div, resid, out, nullptr, items, H, W, act, stream);
     }
     hipStream_t s = (hipStream_t)stream;
     const size_t nh = pfnl::conv3x3_split16_pack_halfs();
@@ -2244,9 +2347,9 @@ int pfnl_op_conv3x3_split16_sf(int which, const float* in, const float* kernel_h
 
 // conv1_i + conv10_i as ONE launch (conv3x3_c1c10_kernel): in fp32 [clips*T][H][W][64] -> out1 = inp1 [clips*T][H][W][64], base [clips][H][W][64];
 // the kernel writes both in the split format, the hook hands them back as fp32 (hi + lo' 2^-11: what the consumers' MFMAs see)
-int pfnl_op_conv1_conv10_split16(const float* in, const float* k1_host, const float* b1_host, const float* k10_host,
-                                 const float* b10_host, float* out1, float* base, int clips, int frames_per_clip, int H, int W,
-                                 void* stream) {
+static int op_conv1_conv10_split16(const float* in, const float* k1_host, const float* b1_host, const float* k10_host,
+                                   const float* b10_host, float* out1, float* base, int clips, int frames_per_clip, int H, int W,
+                                   void* stream, bool in_sf) {
     if (!in || !k1_host || !k10_host || !out1 || !base) return fail(PFNL_ERR_INVALID, "NULL argument");
     const int T = frames_per_clip;
     if (clips < 1 || T < 1 || T > 7 || H < 1 || W < 1) return fail(PFNL_ERR_INVALID, "unsupported conv geometry");
@@ -2258,12 +2361,15 @@ int pfnl_op_conv1_conv10_split16(const float* in, const float* k1_host, const fl
     if (b1_host) std::memcpy(&pack[n3 + n1], b1_host, 64 * sizeof(float));
     if (b10_host) std::memcpy(&pack[n3 + n1 + 128], b10_host, 64 * sizeof(float));
     const size_t np1 = (size_t)clips * T * H * W, npb = (size_t)clips * H * W;
-    uint16_t *dw = nullptr, *t1 = nullptr, *tb = nullptr;
+    uint16_t *dw = nullptr, *t1 = nullptr, *tb = nullptr, *ti = nullptr;
     HIPCHK(hipMalloc(&dw, pack.size() * sizeof(uint16_t)));
     hipError_t e = hipMalloc(&t1, np1 * 256);
     if (e == hipSuccess) e = hipMalloc(&tb, npb * 256);
+    if (e == hipSuccess && in_sf) e = hipMalloc(&ti, np1 * 256);
     if (e == hipSuccess) e = hipMemcpy(dw, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
-    pfnl::ConvSplitParams q{in, dw, reinterpret_cast<const float*>(dw + n3 + n1), nullptr, nullptr, reinterpret_cast<float*>(t1), H, W, clips * T, T, 1};
+    if (e == hipSuccess && in_sf) e = pfnl::launch_sf_from_f32(in, ti, np1, s);   // (the same split the chain kernel's epilogue applies: sf_split4)
+    pfnl::ConvSplitParams q{in_sf ? reinterpret_cast<const float*>(ti) : in, dw, reinterpret_cast<const float*>(dw + n3 + n1), nullptr, nullptr, reinterpret_cast<float*>(t1), H, W, clips * T, T, 1};
+    q.in_sf = in_sf ? 1 : 0;
     q.wpack2 = dw + n3;
     q.bias2 = reinterpret_cast<const float*>(dw + n3 + n1 + 128);
     q.out2 = reinterpret_cast<float*>(tb);
@@ -2274,8 +2380,21 @@ int pfnl_op_conv1_conv10_split16(const float* in, const float* k1_host, const fl
     (void)hipFree(dw);
     (void)hipFree(t1);
     (void)hipFree(tb);
+    if (ti) (void)hipFree(ti);
     if (e != hipSuccess) return fail(PFNL_ERR_HIP, std::string("conv1+conv10 split16 op: ") + hipGetErrorString(e));
     return 0;
+}
+int pfnl_op_conv1_conv10_split16(const float* in, const float* k1_host, const float* b1_host, const float* k10_host,
+                                 const float* b10_host, float* out1, float* base, int clips, int frames_per_clip, int H, int W,
+                                 void* stream) {
+    return op_conv1_conv10_split16(in, k1_host, b1_host, k10_host, b10_host, out1, base, clips, frames_per_clip, H, W, stream, false);
+}
+// ... with the input converted to the split format first and the halo taken from there by LDS-DMA (conv3x3_c1c10_kernel<true>, option
+// split16_sf0): the same operands in the same order - bit-identical to pfnl_op_conv1_conv10_split16
+int pfnl_op_conv1_conv10_split16_sf0(const float* in, const float* k1_host, const float* b1_host, const float* k10_host,
+                                     const float* b10_host, float* out1, float* base, int clips, int frames_per_clip, int H, int W,
+                                     void* stream) {
+    return op_conv1_conv10_split16(in, k1_host, b1_host, k10_host, b10_host, out1, base, clips, frames_per_clip, H, W, stream, true);
 }
 
 // conv10_i with its input and / or output in the split format (fp32 at the hook's interface, see above)

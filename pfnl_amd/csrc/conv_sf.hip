@@ -67,6 +67,28 @@ __device__ __forceinline__ void sf_store_b32(float v, __amdgpu_buffer_rsrc_t rs,
     asm volatile("s_nop 1" ::"v"(v));
 }
 
+template <int AUX>
+__device__ __forceinline__ void sf_store_u32(unsigned v, __amdgpu_buffer_rsrc_t rs, int voffset, int soffset) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, rs, voffset, soffset, AUX);
+    asm volatile("s_nop 1" ::"v"(v));
+}
+typedef unsigned sfu2 __attribute__((ext_vector_type(2)));
+typedef _Float16 sfh4 __attribute__((ext_vector_type(4)));
+// x -> (hi, lo') for 4 values, exactly as conv_split16.hip's split4 (same instructions, same bits): hi = f16(x), lo' = f16(x 2^11 - hi 2^11)
+__device__ __forceinline__ void sf_split4(f32x4 v, sfu2& hi, sfu2& lo, float nscale) {
+    const sfh4 h = __builtin_convertvector(v, sfh4);
+    hi = __builtin_bit_cast(sfu2, h);
+    f32x4 t;
+    asm("v_mul_f32 %0, %4, %5\n\tv_mul_f32 %1, %4, %6\n\tv_mul_f32 %2, %4, %7\n\tv_mul_f32 %3, %4, %8"
+        : "=&v"(t.x), "=&v"(t.y), "=&v"(t.z), "=&v"(t.w) : "s"(2048.0f), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+    unsigned l0, l1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi.x), "s"(nscale), "v"(t.x));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l0) : "v"(hi.x), "s"(nscale), "v"(t.y));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi.y), "s"(nscale), "v"(t.z));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l1) : "v"(hi.y), "s"(nscale), "v"(t.w));
+    lo = sfu2{l0, l1};
+}
+
 __device__ __forceinline__ f32x16 sf_mfma(sfh8 a, sfh8 b, f32x16 c) {
 #ifdef SF_X_NOMFMA   /* timing experiments only (wrong results on purpose; tools/sf_variants.sh) */
     c[0] += (float)a[0] * (float)b[0];
@@ -426,6 +448,12 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_kernel(ConvSplitPara
 #ifdef PFNL_SFC_TIMING
 __device__ long long sfc_dbg[256 * 2 * 160];
 #endif
+// SFCOPY (round 6): the block's output - the next block's inp0 - is ALSO written in the split format (p.out2, [items][H][W] x 256 B), so
+// that conv3x3_c1c10_kernel can take its halo by LDS-DMA in operand form instead of splitting fp32 on the VALU at every commit.  A lane
+// owns one channel (D[pixel][cout]) where an SF chunk is 8 channels of one pixel: neighbouring lanes swap one binary16 pair per pixel
+// (DPP quad_perm), the even lane then stores the hi halves of channels (c, c + 1), the odd lane their lo' halves - 32 lanes x 4 B = the
+// 128 bytes [hi 64 B | lo' 64 B] of a (pixel, channel half): the same line-per-instruction pattern as the fp32 stores.
+template <bool SFCOPY>
 __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSplitParams p) {
 #ifdef PFNL_SFC_TIMING
     int dbg_n = 0;
@@ -536,37 +564,61 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
     const float slope = p.act ? 0.2f : 1.0f;
 
     __amdgpu_buffer_rsrc_t rsO;                                     // out == resid (the launcher checks): one resource per row
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rsS;                    // SFCOPY: the same row of the split-format copy
     int evoff = 0;
+    [[maybe_unused]] int evoff_sf = 0;
     float rres[8];                                                  // the residual of two quarters at a time
+    const float nscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -2048.0f)));
     auto row_setup = [&](int n) __attribute__((always_inline)) {
         const int ey = ey0p + 2 * rp + n;
         const int nrec = (pending && ey < H) ? wbytes : 0;
         rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + ((size_t)eitemp * H + ey) * W * 64, 0, nrec, 0x00020000);
         evoff = (ex0p + 4 * (lane >> 5)) * 256 + ech * 4;
+        if constexpr (SFCOPY) {
+            rsS = __builtin_amdgcn_make_buffer_rsrc(p.out2 + ((size_t)eitemp * H + ey) * W * 64, 0, nrec, 0x00020000);
+            // even lane: hi pair of channels (c, c + 1) at [half nt][hi][c]; odd lane: the lo' pair of (c - 1, c) at [half nt][lo'][c - 1]
+            evoff_sf = (ex0p + 4 * (lane >> 5)) * 256 + nt * 128 + (lane & 1) * 64 + ((lane & 31) >> 1) * 4;
+        }
+    };
+    // the four finished values of a quarter (pixels 8 q + j of the lane's channel) -> split, pair exchange, 4 dword stores
+    auto sf_copy_quarter = [&](const float (&v)[4], int q) __attribute__((always_inline)) {
+        if constexpr (SFCOPY) {
+            sfu2 hi, lo;
+            sf_split4(f32x4{v[0], v[1], v[2], v[3]}, hi, lo, nscale);
+            const bool odd = lane & 1;
+            const unsigned s0 = odd ? hi.x : lo.x, s1 = odd ? hi.y : lo.y;         // what the partner lane needs: its hi (to an even lane), its lo' (to an odd one)
+            const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xf, 0xf, false);   // quad_perm [1, 0, 3, 2]: lane ^ 1
+            const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xf, 0xf, false);
+            const unsigned a0 = odd ? r0 : hi.x, a1 = odd ? r1 : hi.y;             // channel c (even) / c - 1 (odd): the low halfword
+            const unsigned b0 = odd ? lo.x : r0, b1 = odd ? lo.y : r1;             // channel c + 1 (even) / c (odd): the high halfword
+            sf_store_u32<SF_STORE_AUX>(__builtin_amdgcn_perm(b0, a0, 0x05040100u), rsS, evoff_sf, q * 2048);
+            sf_store_u32<SF_STORE_AUX>(__builtin_amdgcn_perm(b0, a0, 0x07060302u), rsS, evoff_sf + 256, q * 2048);
+            sf_store_u32<SF_STORE_AUX>(__builtin_amdgcn_perm(b1, a1, 0x05040100u), rsS, evoff_sf + 512, q * 2048);
+            sf_store_u32<SF_STORE_AUX>(__builtin_amdgcn_perm(b1, a1, 0x07060302u), rsS, evoff_sf + 768, q * 2048);
+        }
     };
     auto quarter_request = [&](int q) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) rres[4 * (q & 1) + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsO, evoff + j * 256, q * 2048, 0));
     };
-    auto quarter_finish = [&](int n, int q) __attribute__((always_inline)) {
+    auto quarter_finish_with = [&](int n, int q, const float (&rv)[4]) __attribute__((always_inline)) {
+        float vv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float v = accp[n][4 * q + j];                           // (shared half + bias are already in: initial C of the tile)
             const float sv = v * slope;
             asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(sv));
-            v += rres[4 * (q & 1) + j];
-            sf_store_b32<SF_STORE_AUX>(v, rsO, evoff + j * 256, q * 2048);
-        }
-    };
-    auto quarter_finish_with = [&](int n, int q, const float (&rv)[4]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v = accp[n][4 * q + j];
-            const float sv = v * slope;
-            asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(sv));
             v += rv[j];
+            vv[j] = v;
             sf_store_b32<SF_STORE_AUX>(v, rsO, evoff + j * 256, q * 2048);
         }
+        sf_copy_quarter(vv, q);
+    };
+    auto quarter_finish = [&](int n, int q) __attribute__((always_inline)) {
+        float rv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rv[j] = rres[4 * (q & 1) + j];
+        quarter_finish_with(n, q, rv);
     };
 #define SFC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #ifndef SFC_SPREAD_HALO
@@ -853,13 +905,16 @@ hipError_t launch_conv3x3_sf_chain(const ConvSplitParams& p, hipStream_t s) {
     const int ncu = device_cu_count();
     if (!ncu) return hipErrorUnknown;
     const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;
-    static std::atomic<int> attr_dev[64];
-    if (!attr_dev[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_sf_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
+    static std::atomic<int> attr_dev[64][2];
+    const int sfcopy = p.out2 ? 1 : 0;                                     // out2: the split-format copy of the output (the next block's inp0)
+    const void* fn = sfcopy ? reinterpret_cast<const void*>(conv3x3_sf_chain_kernel<true>) : reinterpret_cast<const void*>(conv3x3_sf_chain_kernel<false>);
+    if (!attr_dev[dev][sfcopy]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_dev[dev] = 1;
+        attr_dev[dev][sfcopy] = 1;
     }
-    hipLaunchKernelGGL(conv3x3_sf_chain_kernel, dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, p);
+    if (sfcopy) hipLaunchKernelGGL(conv3x3_sf_chain_kernel<true>, dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, p);
+    else hipLaunchKernelGGL(conv3x3_sf_chain_kernel<false>, dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, p);
     return hipGetLastError();
 }
 

@@ -28,6 +28,7 @@ struct ConvSplitParams {
     const uint16_t* wpack2;  // ... and the packed kernel rows that multiply it (identity rows); launch_conv3x3_c1c10: conv10_i (conv1x1_c10_pack_weights)
     const float* bias2;      // launch_conv3x3_c1c10 only: conv10_i's bias [64]
     float* out2;             // ... and its output `base` [items/add_div][H][W] in the split format
+    int in_sf;               // launch_conv3x3_c1c10 only: 1 = `in` is the split-format copy of inp0 (launch_conv3x3_sf_chain's out2): halo by LDS-DMA
     int flat;                // launch_conv3x3_sf with an addend only: 1 = deal the tiles out one by one instead of as chains of the add_div frames
                              // of a (clip, tile) - for launches with fewer chains than workgroups (capi.hip, "MID shapes").  The two input-channel
                              // halves of a tile are summed in the order its position in the workgroup's sequence gives (boustrophedon:
@@ -54,7 +55,8 @@ void conv1x1_c10_pack_weights(const float* hwio, int T, uint16_t* dst);
 // data ([items][H][W] x 256 B); wpack = conv3x3_split16_pack_weights(..., identity_rows = true); plain and fused (addend + resid) modes.
 hipError_t launch_conv3x3_sf(const ConvSplitParams& p, hipStream_t s);
 // the whole of conv2_i in one launch: per (clip, tile) the shared half (in2, wpack2) stays in registers as the initial C of the
-// add_div frame tiles (in, wpack) that follow; bias, leaky-relu and the residual in the epilogue; out may alias resid
+// add_div frame tiles (in, wpack) that follow; bias, leaky-relu and the residual in the epilogue; out may alias resid.
+// out2 != null: the result is ALSO written in the split format ([items][H][W] x 256 B) - the next block's launch_conv3x3_c1c10 input (in_sf)
 hipError_t launch_conv3x3_sf_chain(const ConvSplitParams& p, hipStream_t s);
 hipError_t launch_sf_from_f32(const float* in, uint16_t* out, size_t npix, hipStream_t s);   // [npix][64] fp32 -> SF (tests / taps)
 hipError_t launch_sf_to_f32(const uint16_t* in, float* out, size_t npix, hipStream_t s);     // SF -> hi + lo' 2^-11

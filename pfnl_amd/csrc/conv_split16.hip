@@ -756,11 +756,23 @@ __device__ __forceinline__ void k1_dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds
 #define K1_COMMIT_PAIR8 1     // halo commit: the two pixels of a 16-lane ds_write_b64 group are 8 apart (bank-conflict-free), not neighbours
 #endif
 constexpr int K1_LDS_BYTES = CS_LDS_BYTES + 64 * 4;                 // + conv10_i's bias
+// ISF (round 6): `in` is the SPLIT-FORMAT copy of inp0 that conv3x3_sf_chain_kernel<true> writes next to the fp32 one (conv_sf.hip): the
+// halo of a unit travels HBM -> LDS by LDS-DMA in operand form (43 wave instructions of 1 KB, the XOR swizzle applied to the source
+// address, out-of-image pixels = out-of-range offsets = zeros: exactly conv_sf.hip's input path) - no staging registers, no split4 on
+// the VALU (48 per thread and unit), no ds_write commit (12 per thread and unit).  The operands are the same binary16 pairs the fp32
+// path builds (one split4 per value in the producer's epilogue instead of 1.33 per halo value here): results are bit-identical.
+constexpr int K1_DMA_NDMA = (CS_IH * CS_IW + 7) / 8;                // 43 DMA instructions of 8 pixels x 128 B
+constexpr int K1_DMA_ITERS = (K1_DMA_NDMA + 7) / 8;                 // 6 per wave (waves 3..7: 5)
+constexpr int K1_SF_TILE_BYTES = K1_DMA_NDMA * 1024;                // 44 032: the last instruction's 4 surplus pixels land in padding
+constexpr int K1_SF_LDS_BYTES = 2 * K1_SF_TILE_BYTES + CS_W_BYTES + 2 * 64 * 4;   // 162 304 of 163 840
+static_assert(K1_SF_LDS_BYTES <= 160 * 1024, "LDS budget");
 
+template <bool ISF>
 __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitParams p) {
+    constexpr int TILE_BYTES = ISF ? K1_SF_TILE_BYTES : CS_TILE_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_smem[];
-    unsigned char* const wl = cs_smem + 2 * CS_TILE_BYTES;
-    float* const bl = reinterpret_cast<float*>(cs_smem + 2 * CS_TILE_BYTES + CS_W_BYTES);
+    unsigned char* const wl = cs_smem + 2 * TILE_BYTES;
+    float* const bl = reinterpret_cast<float*>(cs_smem + 2 * TILE_BYTES + CS_W_BYTES);
     float* const bl2 = bl + 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -802,10 +814,33 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
     for (int k = 0; k < CS_W_BYTES / 16 / CS_THREADS; ++k) w0reg[k] = reinterpret_cast<const u32x4*>(p.wpack)[k * CS_THREADS + tid];
     const float bias_r = tid < 64 ? p.bias[tid] : (tid < 128 ? p.bias2[tid - 64] : 0.f);
 
-    int lpk[CS_ITERS];                                              // staging map: as conv3x3_split16_kernel; the source offset of a piece
+    [[maybe_unused]] int lpk[CS_ITERS];                             // staging map: as conv3x3_split16_kernel; the source offset of a piece
     const int wbytes = W * 256;                                     // (py * wbytes + px * 256 + 16 (tid & 7)) is recomputed from it: no registers to spare
+    [[maybe_unused]] int dpk[K1_DMA_ITERS];                         // ISF: py | px << 8 of the lane's halo pixel per DMA instruction (conv_sf.hip)
+    if constexpr (ISF) {
 #pragma unroll
-    for (int k = 0; k < CS_ITERS; ++k) {
+        for (int k = 0; k < K1_DMA_ITERS; ++k) {
+            const int pix = 8 * (wave + 8 * k) + (lane >> 3);
+            const int py = pix / CS_IW, px = pix - py * CS_IW;
+            dpk[k] = py | (px << 8);
+        }
+    }
+    [[maybe_unused]] const unsigned lds0 = (unsigned)(uintptr_t)cs_smem;   // LDS byte address of halo buffer 0
+#define K1_DMA_HALO(rs_, org_, interior_, y0_, x0_, buf_)                                        \
+    do {                                                                                         \
+        _Pragma("unroll") for (int k_ = 0; k_ < K1_DMA_ITERS; ++k_) {                            \
+            const int i_ = wave + 8 * k_;                                                        \
+            if (k_ < K1_DMA_ITERS - 1 || i_ < K1_DMA_NDMA) {                                     \
+                const int py_ = dpk[k_] & 0xff, px_ = dpk[k_] >> 8;                              \
+                const int gy_ = (y0_) + py_ - 1, gx_ = (x0_) + px_ - 1;                          \
+                const bool in_ = (interior_) || ((unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W && py_ < CS_IH); \
+                const int rel_ = py_ * wbytes + px_ * 256 + (((lane & 7) ^ ((px_ >> 1) & 7)) << 4); \
+                k1_dma16(rs_, lds0 + (buf_) * TILE_BYTES + i_ * 1024, in_ ? (org_) + rel_ : 0x7fffffff, 0); \
+            }                                                                                    \
+        }                                                                                        \
+    } while (0)
+#pragma unroll
+    for (int k = 0; k < (ISF ? 0 : CS_ITERS); ++k) {
         // surplus threads redo a piece of the last pixel - the one with THEIR channel piece (tid & 7), so that the recomputed source
         // offset below and the LDS address agree and the duplicate writes carry the same bytes
         const int id = k * CS_THREADS + tid < CS_PIECES ? k * CS_THREADS + tid : CS_PIECES - 8 + (tid & 7);
@@ -823,7 +858,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
     }
     const int c16 = (tid & 7) * 16;                                 // (piece id = k * 512 + tid: its 4-channel piece of the pixel is tid & 7 for every k)
     const float nscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -CS_SCALE)));
-    f32x4 stg[CS_ITERS];
+    [[maybe_unused]] f32x4 stg[CS_ITERS];
 #define K1_REQUEST_ALL(rs_, org_, interior_, y0_, x0_)                                           \
     do {                                                                                         \
         _Pragma("unroll") for (int k_ = 0; k_ < CS_ITERS; ++k_) {                                \
@@ -847,8 +882,8 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
         u32x2 hi_, lo2_;                                                                         \
         split4(stg[k_], hi_, lo2_, nscale);                                                      \
         const int lo_ = lpk[k_] & 0xffff;                                                        \
-        *reinterpret_cast<u32x2*>(cs_smem + (buf_) * CS_TILE_BYTES + lo_) = hi_;                 \
-        *reinterpret_cast<u32x2*>(cs_smem + (buf_) * CS_TILE_BYTES + (lo_ ^ 64)) = lo2_;         \
+        *reinterpret_cast<u32x2*>(cs_smem + (buf_) * TILE_BYTES + lo_) = hi_;                    \
+        *reinterpret_cast<u32x2*>(cs_smem + (buf_) * TILE_BYTES + (lo_ ^ 64)) = lo2_;            \
     } while (0)
 #endif
 
@@ -894,7 +929,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
     // products of those lines; the lines to HBM.  Pixel slot pp = row pair * 32 + column; 16-byte chunk c of a line (conv_split16.h:
     // c = 8 M + 4 part + channel group) sits in slot c ^ (pp & 15): conflict-free for the dump (lanes = consecutive pixels, one
     // chunk), for the operand reads (the same) and for the line read-back (16 lanes = the 16 chunks of one pixel).
-    unsigned char* const scratch = cs_smem + CS_TILE_BYTES;         // unit B's halo buffer: free behind the tile's closing barrier
+    unsigned char* const scratch = cs_smem + TILE_BYTES;            // unit B's halo buffer: free behind the tile's closing barrier
     struct RowHalves { u32x2 hi[4], lo[4]; };                       // one output row of a wave (16 channels of a pixel per lane) as binary16 pairs
     auto quarter_prep = [&](RowHalves& h, const f32x16& m, const f32x16& c, int q, bool fold) __attribute__((always_inline)) {
         // channels ech + 4q .. + 3: (cross terms folded in,) leaky-relu, split - 4 VALU per value
@@ -980,13 +1015,23 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(p.in) + (size_t)c_item * H * W * 64, 0, item_bytes, 0x00020000);
         const int org = ((c_y0 - 1) * W + c_x0 - 1) * 256;          // (unit 0: channel half 0)
-        const bool interior = c_y0 > 0 && c_y0 + CS_IH - 1 <= H && c_x0 > 0 && c_x0 + CS_IW - 1 <= W;
-        K1_REQUEST_ALL(rs, org, interior, c_y0, c_x0);
+        [[maybe_unused]] const bool interior = c_y0 > 0 && c_y0 + CS_IH - 1 <= H && c_x0 > 0 && c_x0 + CS_IW - 1 <= W;
+        [[maybe_unused]] unsigned fence0 = 0;
+        if constexpr (ISF) {
+            K1_DMA_HALO(rs, org, false, c_y0, c_x0, 0);
+            fence0 = __builtin_amdgcn_raw_buffer_load_b32(rs, 0, 0, 0);   // fence load (conv_sf.hip): vmcnt is in order
+        } else {
+            K1_REQUEST_ALL(rs, org, interior, c_y0, c_x0);
+        }
 #pragma unroll
         for (int k = 0; k < CS_W_BYTES / 16 / CS_THREADS; ++k) reinterpret_cast<u32x4*>(wl)[k * CS_THREADS + tid] = w0reg[k];
         if (tid < 128) bl[tid] = bias_r;                            // (bl2 = bl + 64)
+        if constexpr (ISF) {
+            asm volatile("" ::"v"(fence0));                         // the DMAs have landed
+        } else {
 #pragma unroll
-        for (int k = 0; k < CS_ITERS; ++k) K1_COMMIT1(k, 0);
+            for (int k = 0; k < CS_ITERS; ++k) K1_COMMIT1(k, 0);
+        }
     }
     __syncthreads();
     base_init();
@@ -997,7 +1042,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
         auto unit = [&](auto par) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par)::value;
             constexpr int cb = PAR;
-            const unsigned char* const tile = cs_smem + cb * CS_TILE_BYTES;
+            const unsigned char* const tile = cs_smem + cb * TILE_BYTES;
             h8 X[4][2], Wv[2][2];
             CS_STAMP();                                             // 0 / 1: unit A / B start
 #define CS_PX(g_, r_, part_) (*reinterpret_cast<const h8*>(tile + (paddr[(g_) >> 1] ^ (((part_) ? lo_xor : 0) | (((g_) & 1) << 5))) + (r_) * (CS_IW * 128)))
@@ -1023,7 +1068,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
                 const_cast<float*>(p.in) + (size_t)q_item * H * W * 64, 0, item_bytes, 0x00020000);
             const int org = ((y0q - 1) * W + x0q - 1) * 256 + q_half * 128;
             const bool interior = y0q > 0 && y0q + CS_IH - 1 <= H && x0q > 0 && x0q + CS_IW - 1 <= W;
-            K1_REQUEST_ALL(rs, org, interior, y0q, x0q);
+            if constexpr (!ISF) K1_REQUEST_ALL(rs, org, interior, y0q, x0q);
             [[maybe_unused]] f32x16 bias16;
             if constexpr (PAR == 0) {
 #pragma unroll
@@ -1055,6 +1100,12 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
                         if constexpr (PAR == 1) asm volatile("" ::"v"(fence_w));   // tap 2 of this unit's weights has landed
                         K1_BARRIER();                               // b0: column tap 0 of the weights consumed (unit B: tap 2 complete)
                         if constexpr (PAR == 0) K1_DMA_W(half_a ^ 1, 0);
+                        if constexpr (ISF) {
+                            // the next unit's halo by DMA, behind b0: unit A's target is the SCRATCH of the previous tile's serial phase, whose
+                            // last line reads (row_pass(1)) no barrier followed - every wave has passed them here.  12 sub-steps to land.
+                            K1_DMA_HALO(rs, org, interior, y0q, x0q, cb ^ 1);
+                            if constexpr (PAR == 1) fence_w = __builtin_amdgcn_raw_buffer_load_b32(rsf, 0, 0, 0);   // (unit A: the fence behind b1 covers it)
+                        }
                     }
                     if constexpr (g == 3 && PAR == 0) {
                         const int kn = min(kt + 1, nt - 1);         // decode the next tile (past the end: this one again - a harmless re-read)
@@ -1066,12 +1117,14 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
                             K1_DMA_W(half_a ^ 1, 1);
                             fence_w = __builtin_amdgcn_raw_buffer_load_b32(rsf, 0, 0, 0);   // covers taps 0 and 1 of the next unit's weights
                         }
+                        if constexpr (!ISF) {
 #pragma unroll
-                        for (int k = 0; k < CS_ITERS; ++k) asm volatile("" : "+v"(lpk[k]));
+                            for (int k = 0; k < CS_ITERS; ++k) asm volatile("" : "+v"(lpk[k]));
 #pragma unroll
-                        for (int k = 0; k < CS_ITERS / 2; ++k) K1_COMMIT1(k, cb ^ 1);
+                            for (int k = 0; k < CS_ITERS / 2; ++k) K1_COMMIT1(k, cb ^ 1);
+                        }
                     }
-                    if constexpr (g == 5) {
+                    if constexpr (g == 5 && !ISF) {
 #pragma unroll
                         for (int k = CS_ITERS / 2; k < CS_ITERS; ++k) K1_COMMIT1(k, cb ^ 1);
                     }
@@ -1179,6 +1232,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
 #pragma unroll
                 for (int q = 0; q < 4; ++q) quarter_prep(h0, accm[0], accc[0], q, true);
                 CS_STAMP();                                         // 2: sub-steps done, row 0 prepared
+                if constexpr (ISF) asm volatile("" ::"v"(fence_w)); // the next tile's first halo has landed
                 K1_BARRIER();                                       // b2: this unit's buffer (the scratch) is free, the next unit's is complete
                 CS_STAMP();                                         // 3: past b2
                 row_dump(h0);
@@ -1239,6 +1293,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
 #pragma unroll
     for (int j = 0; j < 8; ++j) held_store(j, p.out);               // the last tile's lines (nothing held: dropped)
 #undef K1_TILE
+#undef K1_DMA_HALO
 #undef K1_REQUEST_ALL
 #undef K1_COMMIT1
 #undef K1_BARRIER
@@ -1254,13 +1309,17 @@ hipError_t launch_conv3x3_c1c10(const ConvSplitParams& p, hipStream_t s) {
     const int ncu = device_cu_count();
     if (!ncu) return hipErrorUnknown;
     const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;
-    static std::atomic<int> attr_dev[64];
-    if (!attr_dev[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c1c10_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, K1_LDS_BYTES);
+    static std::atomic<int> attr_dev[64][2];
+    const int isf = p.in_sf ? 1 : 0;                                // `in` is the split-format copy of inp0 (conv3x3_sf_chain_kernel<true>)
+    const void* fn = isf ? reinterpret_cast<const void*>(conv3x3_c1c10_kernel<true>) : reinterpret_cast<const void*>(conv3x3_c1c10_kernel<false>);
+    const int lds = isf ? K1_SF_LDS_BYTES : K1_LDS_BYTES;
+    if (!attr_dev[dev][isf]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        attr_dev[dev] = 1;
+        attr_dev[dev][isf] = 1;
     }
-    hipLaunchKernelGGL(conv3x3_c1c10_kernel, dim3(grid), dim3(CS_THREADS), K1_LDS_BYTES, s, p);
+    if (isf) hipLaunchKernelGGL(conv3x3_c1c10_kernel<true>, dim3(grid), dim3(CS_THREADS), lds, s, p);
+    else hipLaunchKernelGGL(conv3x3_c1c10_kernel<false>, dim3(grid), dim3(CS_THREADS), lds, s, p);
     return hipGetLastError();
 }
 

@@ -28,7 +28,9 @@ class _PinnedPool:
         import threading
         self._free = {}                       # nbytes -> [ptr, ...]
         self._free_bytes = 0
-        self._lock = threading.Lock()
+        # re-entrant: the finalizer (_give) takes the lock too, and the cyclic GC may run it on the thread that already holds it inside
+        # array() or _give() (a pinned result caught in a reference cycle)
+        self._lock = threading.RLock()
 
     def _cap(self) -> int:
         return int(float(os.environ.get("PFNL_PINNED_POOL_MB", "256")) * (1 << 20))
@@ -48,7 +50,8 @@ class _PinnedPool:
                 return None                    # no pinned memory to be had: the caller falls back to pageable memory
             ptr = p.value
         base = (C.c_float * (nbytes // 4)).from_address(ptr)
-        weakref.finalize(base, self._give, ptr, nbytes)
+        fin = weakref.finalize(base, self._give, ptr, nbytes)
+        fin.atexit = False                     # at interpreter exit the HIP runtime may be gone already: the OS reclaims the blocks
         return np.ctypeslib.as_array(base).reshape(shape)
 
     def _give(self, ptr: int, nbytes: int) -> None:
@@ -82,7 +85,7 @@ class PFNLEngine:
         _capi.check(self._lib.pfnl_create(C.byref(cfg), C.byref(h)))
         self._h = h
         self._ready = False
-        self._options: Dict[str, str] = {}       # what set_option was called with (the library keeps no getter)
+        self._options: Dict[str, str] = {}       # what set_option was called with (the library's own view: get_option)
 
     # ---- lifetime --------------------------------------------------------------------------
     def close(self) -> None:
@@ -235,6 +238,24 @@ class PFNLEngine:
         n = C.c_size_t(0)
         _capi.check(self._lib.pfnl_workspace_bytes(self._h, B, H, W, C.byref(n)))
         return n.value
+
+    def plan(self, B: int, H: int, W: int) -> Dict[str, object]:
+        """The launch plan of the progressive-fusion trunk for this shape under the current options (pfnl_plan: the one statement of the
+        dispatch rule).  {"structure": "chain2_sf0", "launches_per_block": 2, "conv3x3": "split16", "sf0": 1, ...}."""
+        buf = C.create_string_buffer(256)
+        _capi.check(self._lib.pfnl_plan(self._h, B, H, W, buf, 256))
+        toks = buf.value.decode().split()
+        d: Dict[str, object] = {"structure": toks[0]}
+        for t in toks[1:]:
+            k, v = t.split("=", 1)
+            d[k] = int(v) if v.lstrip("-").isdigit() else v
+        return d
+
+    def get_option(self, key: str) -> str:
+        """The CURRENT value of an option (pfnl_get_option): whatever set it - set_option, the environment at pfnl_create, the default."""
+        buf = C.create_string_buffer(64)
+        _capi.check(self._lib.pfnl_get_option(self._h, key.encode(), buf, 64))
+        return buf.value.decode()
 
     # ---- measurement / debugging ---------------------------------------------------------------
     def profile(self, enable) -> None:

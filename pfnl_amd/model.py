@@ -306,17 +306,22 @@ class PFNL(VSR):
         # precision=bf16: `strict_fp32` changes nothing there (its non-local block and conv0 keep their binary16 operands, capi.hip
         # nl_strict), so the recomputation - and the rest of the sequence - runs at precision=fp32 on the strict kernels: the only
         # path of the library that covers the whole fp32 range.  Both options are restored when the sequence ends, however it ends.
+        # What is restored is what the LIBRARY held before (pfnl_get_option: a value set by PFNL_STRICT_FP32 / a precision chosen outside this
+        # engine's own set_option calls are seen too), and only the keys go_strict changed.
         state = {"strict": False, "redo_next": False}
-        was_bf16 = eng.option("precision", "fp32") == "bf16"
-        was_strict_engine = eng.option("strict_fp32", "off") == "on"
+        prior = {}                                                   # option -> the library's value before go_strict changed it
+        was_bf16 = eng.get_option("precision") == "bf16"
 
         def go_strict():
             stream.synchronize()                                     # no forward of the old configuration is in flight when it changes
             if was_bf16:
+                prior["precision"] = "bf16"
                 eng.set_option("precision", "fp32")
                 print('precision=bf16: a batch left the binary16 range of its non-local block / conv0; recomputed (and the rest of the '
                       'sequence computed) at precision=fp32, strict_fp32=on')
-            eng.set_option("strict_fp32", "on")
+            if eng.get_option("strict_fp32") != "on":
+                prior["strict_fp32"] = eng.get_option("strict_fp32")
+                eng.set_option("strict_fp32", "on")
             state["strict"] = True
 
         def recompute_strict(buf, first_, count_):
@@ -367,12 +372,10 @@ class PFNL(VSR):
                 for j in jobs:
                     j.result()
         finally:
-            if state["strict"]:                                      # back to the caller's configuration (also when an encoder raised)
+            if prior:                                                # back to the configuration the library held (also when an encoder raised)
                 stream.synchronize()
-                if not was_strict_engine:
-                    eng.set_option("strict_fp32", "off")
-                if was_bf16:
-                    eng.set_option("precision", "bf16")
+                for key, value in prior.items():
+                    eng.set_option(key, value)
         all_time = np.array(all_time)
         avg = np.mean(all_time[1:]) if len(all_time) > 1 else float('nan')
         print('spent {} s in total and {} s in average'.format(np.sum(all_time), avg))

@@ -251,7 +251,7 @@ def conv3x3_winograd(x, kernel, bias=None, act=True, addend=None, add_div=1, res
             _req(resid, "resid") if resid is not None else None, _req(out, "out"), F, H, W, 1 if act else 0, _stream(x)))
         return out
     fn = {"winograd": lib.pfnl_op_conv3x3_winograd, "winograd_ws": lib.pfnl_op_conv3x3_winograd_ws,
-          "split16": lib.pfnl_op_conv3x3_split16, "wsplit": lib.pfnl_op_conv3x3_wsplit}[variant]
+          "split16": lib.pfnl_op_conv3x3_split16}[variant]
     _capi.check(fn(
         _req(x, "x"), k.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p) if b is not None else None,
         _req(addend, "addend") if addend is not None else None, int(add_div),
@@ -324,9 +324,10 @@ def nonlocal_embedded(x, wg, bg, ww, bw, wt, bt, wp, bp):
     return out
 
 
-def conv1_conv10_split16(x, k1, b1, k10, b10, frames_per_clip: int):
+def conv1_conv10_split16(x, k1, b1, k10, b10, frames_per_clip: int, sf0: bool = False):
     """conv1_i + conv10_i of a progressive-fusion block as one launch (reference model/pfnl.py:66-68): x [clips*T,H,W,64] (cuda) ->
-    (inp1 [clips*T,H,W,64], base [clips,H,W,64]), both activated; k1 HWIO [3,3,64,64], k10 HWIO [1,1,64T,64]."""
+    (inp1 [clips*T,H,W,64], base [clips,H,W,64]), both activated; k1 HWIO [3,3,64,64], k10 HWIO [1,1,64T,64].  sf0: the input is
+    converted to the split format first and the kernel takes its halo from there by LDS-DMA (bit-identical results)."""
     import torch
     lib = _capi.load_library()
     F, H, W, c = x.shape
@@ -336,9 +337,27 @@ def conv1_conv10_split16(x, k1, b1, k10, b10, frames_per_clip: int):
         raise ValueError("conv1_conv10_split16: geometry mismatch")
     out1 = torch.empty((F, H, W, 64), dtype=torch.float32, device=x.device)
     base = torch.empty((F // T, H, W, 64), dtype=torch.float32, device=x.device)
-    _capi.check(lib.pfnl_op_conv1_conv10_split16(_req(x, "x"), _hp(k1h), _hp(_host(b1, "b1")), _hp(k10h), _hp(_host(b10, "b10")),
+    fn = lib.pfnl_op_conv1_conv10_split16_sf0 if sf0 else lib.pfnl_op_conv1_conv10_split16
+    _capi.check(fn(_req(x, "x"), _hp(k1h), _hp(_host(b1, "b1")), _hp(k10h), _hp(_host(b10, "b10")),
                                                  _req(out1, "out1"), _req(base, "base"), F // T, T, H, W, _stream(x)))
     return out1, base
+
+
+def conv2_chain_sf0(x, kernel, bias, base, resid, add_div: int, act: bool = True):
+    """The whole of conv2_i in one launch with the split-format copy of its output (reference model/pfnl.py:69-71; option split16_sf0):
+    x = inp1 [F,H,W,64], kernel HWIO [3,3,128,64], base [F/add_div,H,W,64], resid [F,H,W,64] (all cuda fp32) ->
+    (out [F,H,W,64] fp32, out_sf [F,H,W,128] int16 bit patterns of binary16: per pixel [channel half][hi 32 | lo' 32])."""
+    import torch
+    lib = _capi.load_library()
+    F, H, W, c = x.shape
+    k, b = _host(kernel, "kernel"), _host(bias, "bias")
+    if c != 64 or k.shape != (3, 3, 128, 64) or F % add_div:
+        raise ValueError("conv2_chain_sf0: geometry mismatch")
+    out = torch.empty((F, H, W, 64), dtype=torch.float32, device=x.device)
+    out_sf = torch.empty((F, H, W, 128), dtype=torch.int16, device=x.device)
+    _capi.check(lib.pfnl_op_conv2_chain_sf0(_req(x, "x"), _hp(k), _hp(b) if b is not None else None, _req(base, "base"), int(add_div),
+                                            _req(resid, "resid"), _req(out, "out"), C.c_void_p(out_sf.data_ptr()), F, H, W, 1 if act else 0, _stream(x)))
+    return out, out_sf
 
 
 def nonlocal_block(x, wg, bg, ww, bw, theta=None, phi=None, nltype: int = 1, sub_sample: int = 1):

@@ -65,5 +65,7 @@ def test_no_store_data_hazard_in_emitted_isa():
     if not (os.path.exists(hipcc) or shutil.which(hipcc)):
         pytest.skip("no hipcc")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    st = subprocess.run([sys.executable, os.path.join(root, "tools", "lint_store_hazard.py"), "--selftest"], capture_output=True, text=True)
+    assert st.returncode == 0, st.stdout + st.stderr                 # the rule fires on known-bad snippets (VGPR and AGPR destinations), not on good ones
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "lint_store_hazard.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr

@@ -534,6 +534,73 @@ def test_split16_launch_structure_options(T, scale, nb, B, H, W):
     eng.close()
 
 
+@pytest.mark.parametrize("T,scale,nb,B,H,W", [(7, 4, 3, 3, 128, 128), (7, 4, 20, 4, 128, 128), (7, 4, 2, 3, 100, 130), (5, 2, 3, 5, 96, 128), (3, 4, 2, 6, 90, 98),
+                                               (7, 4, 1, 3, 128, 128), (7, 4, 2, 1, 270, 480)])
+def test_forward_sf0_is_bit_identical(T, scale, nb, B, H, W):
+    """Round 6, option split16_sf0 (off by default: measured slower; reference model/pfnl.py:65-71): in the two-launch block the chain kernel writes every
+    block's output a second time in the split format and the next block's conv1_i + conv10_i launch takes its halo from that copy by
+    LDS-DMA.  Same binary16 operand pairs in the same order: the forward must be BIT-IDENTICAL with the option off - 20 blocks at
+    configs[1], ragged tiles, T = 3 / 5, 2x, one block (no copy is written or read at all), 1080p - and equal to the oracle as before.
+    The plan says which structure ran; the workspace accounting covers the copy."""
+    geom = PFNLGeometry(num_frames=T, scale=scale, num_block=nb)
+    w = synth.synthetic_weights(geom, seed=T + nb)
+    x = synth.uniform_clips(B, T, H, W, seed=H + B)
+    eng = _engine_with(geom, w)
+    assert eng.get_option("split16_sf0") == "off" and eng.plan(B, H, W)["structure"] == "chain2"
+    eng.set_option("split16_sf0", "on")
+    pl = eng.plan(B, H, W)
+    assert pl["structure"] == "chain2_sf0" and pl["launches_per_block"] == 2 and pl["sf0"] == 1, pl
+    ws_on = eng.workspace_bytes(B, H, W)
+    y_on = eng.forward(x)
+    assert np.array_equal(y_on, eng.forward(x))
+    eng.set_option("split16_sf0", "off")
+    pl = eng.plan(B, H, W)
+    assert pl["structure"] == "chain2" and pl["sf0"] == 0, pl
+    assert ws_on - eng.workspace_bytes(B, H, W) == B * T * H * W * 256
+    y_off = eng.forward(x)
+    assert np.array_equal(y_on.view(np.uint32), y_off.view(np.uint32)), np.abs(y_on - y_off).max()
+    if B * T * H * W <= 4 * 7 * 128 * 128 and nb <= 3:
+        ref = pfnl_fast.FastOracle(w, T, scale, nb).forward(x)
+        assert np.abs(y_on - ref).max() < ABS_TOL
+    eng.close()
+
+
+def test_plan_is_what_runs():
+    """pfnl_plan is the ONE statement of the trunk's dispatch rule (capi.hip trunk_plan; reference model/pfnl.py:65-71): for every structure
+    the launches the profiler counts per block equal the plan's, in both precisions and under the options that change it; the thresholds
+    it prints (tiles, chains) are the shape's; pfnl_get_option reads back what set_option / the defaults put there."""
+    geom = PFNLGeometry(num_block=2)
+    w = synth.synthetic_weights(geom, seed=0)
+    eng = _engine_with(geom, w)
+    cases = [((1, 32, 32), {}, "small2"), ((1, 32, 32), {"small_c10": "off"}, "small3"), ((1, 128, 128), {}, "mid4"),
+             ((1, 128, 128), {"split16_mid": "off"}, "chain2"), ((3, 128, 128), {}, "chain2"), ((3, 128, 128), {"split16_sf0": "on"}, "chain2_sf0"),
+             ((3, 128, 128), {"split16_c10": "off"}, "split16_3"), ((3, 128, 128), {"split16_chain": "off"}, "split16_3"),
+             ((3, 128, 128), {"split16_sf": "off"}, "split16_4"), ((3, 128, 128), {"strict_fp32": "on"}, "winograd_ws3"),
+             ((1, 64, 64), {"conv3x3": "direct", "conv1x1": "tiled", "small": "off"}, "direct4"),
+             ((3, 128, 128), {"precision": "bf16"}, "bf16_3"), ((1, 128, 128), {"precision": "bf16"}, "bf16_mid4"),
+             ((3, 128, 128), {"precision": "bf16", "bf16_conv10": "separate"}, "bf16_4")]
+    for (B, H, W), opts, want in cases:
+        before = {k: eng.get_option(k) for k in opts}
+        for k, v in opts.items():
+            eng.set_option(k, v)
+            assert eng.get_option(k) == v
+        pl = eng.plan(B, H, W)
+        assert pl["structure"] == want, (B, H, W, opts, pl)
+        assert pl["tiles"] == B * 7 * ((W + 31) // 32) * ((H + 7) // 8) and pl["chains"] == pl["tiles"] // 7
+        x = synth.uniform_clips(B, 7, H, W, seed=3)
+        eng.profile(1)
+        eng.profile_reset()
+        eng.forward(x)
+        p = eng.profile_read()
+        eng.profile(0)
+        assert p["conv3x3"]["launches"] + p["conv1x1"]["launches"] == pl["launches_per_block"] * 2, (want, p, pl)
+        for k, v in before.items():
+            eng.set_option(k, v)
+    with pytest.raises(Exception):
+        eng.get_option("no_such_option")
+    eng.close()
+
+
 @pytest.mark.parametrize("T,scale,nb,B,H,W", [(7, 4, 3, 1, 32, 32), (5, 2, 2, 1, 64, 64), (7, 4, 2, 2, 18, 40)])
 def test_small_shape_launch_structures(T, scale, nb, B, H, W):
     """The small-shape trunk with conv10_i inside the conv1_i launch (small_c10 = on, default since round 4: 2 launches per block, the
@@ -730,24 +797,6 @@ def test_harness_reruns_out_of_range_batches(tmp_path):
     assert m._get_engine().range_flagged() is False
     y = m.forward(lrs[None, :7])                                    # the engine is back on its default kernels afterwards
     assert np.isfinite(y).all() and m._get_engine().range_reruns() == 1
-    eng.close()
-
-
-@pytest.mark.parametrize("B,T,H,W,nb,scale", [(1, 7, 16, 24, 2, 4), (2, 7, 32, 32, 20, 4), (1, 5, 20, 36, 3, 2), (1, 7, 46, 78, 2, 4)])
-def test_forward_option_wsplit(B, T, H, W, nb, scale):
-    """The whole forward with conv3x3=wsplit (conv1_i, both halves of conv2_i through conv_wsplit.hip; conv10_i and convmerge1 on the
-    split-f16 kernels) against the oracle - same tolerance as the default path."""
-    geom = PFNLGeometry(num_frames=T, scale=scale, num_block=nb)
-    w = synth.synthetic_weights(geom, seed=0)
-    x = synth.uniform_clips(B, T, H, W, seed=5)
-    eng = _engine_with(geom, w)
-    eng.set_option("conv3x3", "wsplit")
-    y = eng.forward(x)
-    ref = pfnl_fast.FastOracle(w, num_frames=T, scale=scale, num_block=nb).forward(x)
-    assert np.abs(y - ref).max() < 5e-5
-    eng.set_option("strict_fp32", "on")                            # the strict path replaces it like the other f16-pipe kernels
-    ys = eng.forward(x)
-    assert np.abs(ys - ref).max() < 5e-5
     eng.close()
 
 

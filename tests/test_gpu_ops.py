@@ -478,69 +478,6 @@ def test_conv3x3_split16(items, H, W, fused, act):
     assert e_s <= 1.5 * e_d + 1e-7, (e_s, e_d)                    # as good as the fp32 FMA chain of the direct kernel
 
 
-@pytest.mark.parametrize("items,H,W,fused,act", [(1, 8, 16, False, False), (1, 8, 32, False, True), (7, 10, 38, True, True), (3, 5, 7, False, False),
-                                                  (1, 1, 1, False, True), (7, 33, 70, True, True), (2, 64, 96, False, True), (28, 24, 40, True, True),
-                                                  (1, 9, 130, False, True), (21, 16, 32, True, False), (4, 128, 128, False, False), (2, 2, 2, False, False),
-                                                  (1, 30, 18, True, True), (300, 8, 16, False, True)])
-def test_conv3x3_wsplit(items, H, W, fused, act):
-    """conv_wsplit_kernel (option conv3x3=wsplit; reference model/pfnl.py:49-51 at :66-71): Winograd F(2x2,3x3) on the f16 pipe with exactly
-    split operands, the transformed weights resident in the AGPRs of a 4-wave workgroup.  U is transformed in fp64 on the host, V in fp32 in
-    the kernel, both split into binary16 pairs (>= 22 mantissa bits per product): the error against the fp64 spec stays below the direct
-    split-f16 kernel's bound.  Odd sizes, ragged M-blocks (8 x 16 pixels), single pixels, more blocks than workgroups, the fused epilogue."""
-    rng = np.random.default_rng(items * 1000 + H * 10 + W)
-    x = rng.normal(size=(items, H, W, 64)).astype(np.float32)
-    k = (rng.normal(size=(3, 3, 64, 64)) / 24.0).astype(np.float32)
-    b = (rng.normal(size=64) * 0.1).astype(np.float32)
-    ref = pfnl_spec.conv2d_same(x.astype(np.float64), k.astype(np.float64), b.astype(np.float64))
-    kw = {}
-    if fused:
-        div = 7 if items % 7 == 0 else 1
-        add = rng.normal(size=(items // div, H, W, 64)).astype(np.float32)
-        res = rng.normal(size=(items, H, W, 64)).astype(np.float32)
-        ref = ref + np.repeat(add.astype(np.float64), div, axis=0)
-        kw = dict(addend=dev(add), add_div=div, resid=dev(res))
-    if act:
-        ref = pfnl_spec.lrelu(ref)
-    if fused:
-        ref = ref + res
-    got = ops.conv3x3_winograd(dev(x), k, b, act=act, variant="wsplit", **kw).cpu().numpy()
-    direct = ops.conv2d(dev(x), k, b, act=act, **kw).cpu().numpy()
-    e_w, e_d = np.abs(got - ref).max(), np.abs(direct - ref).max()
-    assert e_w < 4e-6 * max(1.0, np.abs(ref).max()), (e_w, e_d)
-    assert e_w <= 1.5 * e_d + 2e-7, (e_w, e_d)                    # as good as the fp32 FMA chain of the direct kernel
-    again = ops.conv3x3_winograd(dev(x), k, b, act=act, variant="wsplit", **kw).cpu().numpy()
-    assert np.array_equal(got, again)                              # deterministic (no atomics, fixed meeting order of the four waves)
-
-
-def test_conv3x3_wsplit_random_geometries():
-    """Random geometries through conv_wsplit_kernel (the halo arrives by LDS-DMA behind a counted wait, the four waves meet in LDS behind two
-    barriers per block: a piece that lands late or an exchange area reused early is a wrong 8 x 16 block - far above the tolerance): ~8 s of
-    random (items, H, W, fused, act) incl. sizes around the M-block edges, more blocks than workgroups and single rows / columns."""
-    import time
-    rng = np.random.default_rng(77)
-    k = (rng.normal(size=(3, 3, 64, 64)) / 24.0).astype(np.float32)
-    b = (rng.normal(size=64) * 0.1).astype(np.float32)
-    t_end, n = time.time() + 8.0, 0
-    while time.time() < t_end or n < 12:
-        items = int(rng.choice([1, 2, 3, 7, 14, 40]))
-        H = int(rng.choice([1, 2, 7, 8, 9, 15, 16, 17, 24, 31, 33, 50]))
-        W = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 80]))
-        fused, act = bool(rng.integers(2)), bool(rng.integers(2))
-        x = rng.normal(size=(items, H, W, 64)).astype(np.float32)
-        kw, div = {}, 1
-        if fused:
-            div = 7 if items % 7 == 0 else 1
-            add = rng.normal(size=(items // div, H, W, 64)).astype(np.float32)
-            res = rng.normal(size=(items, H, W, 64)).astype(np.float32)
-            kw = dict(addend=dev(add), add_div=div, resid=dev(res))
-        got = ops.conv3x3_winograd(dev(x), k, b, act=act, variant="wsplit", **kw).cpu().numpy()
-        ref = ops.conv3x3_winograd(dev(x), k, b, act=act, variant="split16", **kw).cpu().numpy()   # (itself oracle-tested above)
-        err = np.abs(got - ref).max()
-        assert err < 8e-6 * max(1.0, np.abs(ref).max()), (items, H, W, fused, act, err)
-        n += 1
-    assert n >= 12
-
-
 @pytest.mark.parametrize("items,H,W,fused,act", [(1, 8, 32, False, True), (7, 10, 38, True, True), (3, 5, 7, False, False), (1, 1, 1, False, True),
                                                   (7, 33, 70, True, True), (2, 64, 96, False, True), (28, 24, 40, True, True),
                                                   (1, 9, 130, False, True), (21, 16, 32, True, False), (4, 128, 128, False, False)])
@@ -661,6 +598,60 @@ def test_conv1_conv10_fused_split16(T, clips, H, W):
     assert d1 <= 2.0 ** -20 * max(1.0, np.abs(ref1).max()), d1                      # the same MFMAs in the same order (the fold of the cross terms
                                                                                      # may contract differently): one step of the 22-bit split
     assert db < 2e-6 * max(1.0, np.abs(refb).max()), db
+
+
+@pytest.mark.parametrize("T,clips,H,W", [(7, 1, 8, 32), (7, 2, 16, 64), (5, 1, 9, 38), (3, 3, 5, 7), (7, 1, 1, 1), (7, 1, 33, 70),
+                                          (7, 4, 128, 128), (5, 2, 64, 96), (1, 2, 24, 40), (7, 40, 8, 32), (7, 2, 50, 34), (7, 300, 8, 16)])
+def test_conv1_conv10_fused_split16_sf0_is_bit_identical(T, clips, H, W):
+    """Round 6 (option split16_sf0; reference model/pfnl.py:66-68): conv3x3_c1c10_kernel<true> takes its halo by LDS-DMA from the
+    split-format copy of inp0 instead of splitting fp32 on the VALU when it commits a halo tile.  The operands are the same binary16
+    pairs in the same order, so inp1 and base must be BIT-IDENTICAL to the fp32-input launch - on ragged tiles, single pixels, image
+    borders inside a tile (out-of-range DMA offsets = zeros), more chains than workgroups and the configs[1] geometry.  Repeated: the DMA
+    lands behind a fence load, a late piece would be a wrong tile."""
+    rng = np.random.default_rng(T * 1000 + H * 10 + W + clips)
+    F = clips * T
+    x = rng.normal(size=(F, H, W, 64)).astype(np.float32)
+    x[0, 0, 0, :8] = [0.0, -0.0, 1e-30, 65000.0, -3.1e4, 2.0 ** -14, 2.0 ** -25, 1.0 + 2.0 ** -12]   # zero, tiny, near binary16's range ends
+    k1 = (rng.normal(size=(3, 3, 64, 64)) / 24.0).astype(np.float32)
+    b1 = (rng.normal(size=64) * 0.1).astype(np.float32)
+    k10 = (rng.normal(size=(1, 1, 64 * T, 64)) / np.sqrt(64 * T)).astype(np.float32)
+    b10 = (rng.normal(size=64) * 0.1).astype(np.float32)
+    ref1, refb = (t.cpu().numpy() for t in ops.conv1_conv10_split16(dev(x), k1, b1, k10, b10, T))
+    for rep in range(3):
+        got1, gotb = (t.cpu().numpy() for t in ops.conv1_conv10_split16(dev(x), k1, b1, k10, b10, T, sf0=True))
+        assert np.array_equal(got1.view(np.uint32), ref1.view(np.uint32)), (rep, np.abs(got1 - ref1).max())
+        assert np.array_equal(gotb.view(np.uint32), refb.view(np.uint32)), (rep, np.abs(gotb - refb).max())
+
+
+def _sf_split_host(v):
+    """The split format of an fp32 array [..., 64] as the kernels build it (conv_split16.h): per pixel [channel half][hi 32 | lo' 32]
+    binary16, hi = f16(x) (nearest even), lo' = f16((x - hi) 2^11) - x - hi and the scaling are exact in fp32, one rounding each."""
+    hi = v.astype(np.float16)
+    lo = ((v - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    hi, lo = hi.reshape(v.shape[:-1] + (2, 32)), lo.reshape(v.shape[:-1] + (2, 32))
+    return np.concatenate([hi, lo], axis=-1).reshape(v.shape[:-1] + (128,)).view(np.int16)
+
+
+@pytest.mark.parametrize("T,clips,H,W", [(7, 1, 8, 32), (7, 2, 10, 38), (5, 1, 33, 70), (3, 3, 16, 24), (7, 4, 128, 128), (7, 1, 1, 1), (7, 3, 9, 130), (7, 40, 8, 32)])
+def test_conv2_chain_sf0_writes_the_split_format_copy(T, clips, H, W):
+    """Round 6 (option split16_sf0; reference model/pfnl.py:69-71): conv3x3_sf_chain_kernel<true> writes its output - the next block's
+    inp0 - a second time in the split format (a lane owns one channel there, an SF chunk is 8 channels of a pixel: lane pairs swap
+    binary16 pairs by DPP and store hi / lo' dwords).  The fp32 output must be BIT-IDENTICAL to the kernel without the copy, and the
+    copy must be exactly the split of that output (what conv3x3_c1c10_kernel<false> would have built from it in LDS)."""
+    rng = np.random.default_rng(T * 1000 + H * 10 + W)
+    F = clips * T
+    x = rng.normal(size=(F, H, W, 64)).astype(np.float32)
+    base = rng.normal(size=(clips, H, W, 64)).astype(np.float32)
+    res = rng.normal(size=(F, H, W, 64)).astype(np.float32)
+    k2 = (rng.normal(size=(3, 3, 128, 64)) / 34.0).astype(np.float32)
+    b = (rng.normal(size=64) * 0.1).astype(np.float32)
+    plain = ops.conv3x3_winograd(dev(x), k2, b, act=True, addend=dev(base), add_div=T, resid=dev(res), variant="split16_sf_chain").cpu().numpy()
+    out, out_sf = ops.conv2_chain_sf0(dev(x), k2, b, dev(base), dev(res), T)
+    out, out_sf = out.cpu().numpy(), out_sf.cpu().numpy()
+    assert np.array_equal(out.view(np.uint32), plain.view(np.uint32))
+    want = _sf_split_host(out)
+    bad = np.argwhere(out_sf != want)
+    assert bad.size == 0, (len(bad), bad[:4], out_sf[tuple(bad[0])], want[tuple(bad[0])])
 
 
 @pytest.mark.parametrize("T,clips,H,W", [(7, 1, 32, 32), (5, 1, 64, 64), (7, 2, 9, 38), (3, 1, 2, 2), (7, 1, 33, 70), (5, 3, 16, 24)])

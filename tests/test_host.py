@@ -364,19 +364,25 @@ def test_bench_byte_model_matches_the_launch_structure_and_the_committed_traffic
     import bench
     g = PFNLGeometry()
     B, H, W, F = 4, 128, 128, 28
-    for env, tiles, launches in (({}, 5 * F + 2 * B, 2), ({"PFNL_SF_C10": "0"}, 5 * F + B, 2), ({"PFNL_SF_CHAIN": "0"}, 5 * F + 4 * B, 3),
-                                 ({"PFNL_SF_C10": "0", "PFNL_SF_CHAIN": "0"}, 5 * F + 3 * B, 3)):
-        old = {k: os.environ.pop(k, None) for k in ("PFNL_SF_C10", "PFNL_SF_CHAIN", "PFNL_SPLIT16_SF")}
-        os.environ.update(env)
-        try:
-            rec = bench.conv3x3_roofline(g, {"conv3x3": {"ms": 2.0, "launches": 20}}, B, H, W, "split16", False, "cfg2")
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
-            os.environ.update({k: v for k, v in old.items() if v is not None})
-        assert rec["launches_per_step"] == launches * g.num_block
-        assert abs(rec["mbytes_per_launch"] * 1e6 - H * W * 256 * tiles / launches) < 1e4, (env, rec["mbytes_per_launch"])
-    rec = bench.conv3x3_roofline(g, {"conv3x3": {"ms": 2.0, "launches": 20}}, B, H, W, "split16", False, "cfg2")
+
+    def plan(structure, lpb, c10, chain, sf0=0):                     # what PFNLEngine.plan (pfnl_plan) returns for the structure (tests/test_gpu_forward.py::
+        return {"structure": structure, "launches_per_block": lpb, "precision": "fp32", "conv3x3": "split16", "conv1x1": "split16",   # test_plan_is_what_runs ties
+                "c10_fused": c10, "chain": chain, "sf0": sf0}                                                                        # these to the launches that run)
+    # (structure, launches of the conv3x3 class per block, algorithmic tiles per block)
+    for pl, launches, tiles in ((plan("chain2", 2, 1, 1), 2, 5 * F + 2 * B), (plan("split16_3", 3, 0, 1), 2, 5 * F + B), (plan("split16_3", 3, 1, 0), 3, 5 * F + 4 * B),
+                                (plan("split16_4", 4, 0, 0), 3, 5 * F + 3 * B), (plan("mid4", 4, 0, 0), 3, 5 * F + 3 * B), (plan("chain2_sf0", 2, 1, 1, 1), 2, 5 * F + 2 * B)):
+        rec = bench.conv3x3_roofline(g, {"conv3x3": {"ms": 2.0, "launches": 20}}, B, H, W, pl, "cfg2")
+        assert rec["launches_per_step"] == launches * g.num_block, pl
+        assert abs(rec["mbytes_per_launch"] * 1e6 - H * W * 256 * tiles / launches) < 1e4, (pl, rec["mbytes_per_launch"])
+        assert rec["plan"] == pl["structure"]
+        if pl["sf0"]:
+            # the split-format copy of inp0 (blocks 0 .. nb-2) is REDUNDANT traffic: outside the algorithmic bytes `frac` is priced on, and named
+            sc = rec["sf_copy"]
+            assert abs(sc["redundant_mbytes_per_launch"] * 1e6 - H * W * 256 * F * (g.num_block - 1) / (2.0 * g.num_block)) < 1e4
+            assert abs(sc["expected_traffic_over_algorithmic"] - (1 + F * 19 / 20.0 / (5 * F + 2 * B))) < 2e-3
+        else:
+            assert "sf_copy" not in rec
+    rec = bench.conv3x3_roofline(g, {"conv3x3": {"ms": 2.0, "launches": 20}}, B, H, W, plan("chain2", 2, 1, 1), "cfg2")
     newest = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_traffic_split16.json")))[-1]
     tj = json.load(open(newest))
     ratio = tj["hbm_bytes_per_launch_avg"] / (rec["mbytes_per_launch"] * 1e6)
@@ -387,7 +393,7 @@ def test_bench_byte_model_matches_the_launch_structure_and_the_committed_traffic
     assert abs(port["l2_weight_stream_mbytes_per_launch"] * 1e6 - 73728 * tiles) < 1e4
     assert abs(port["mbytes_per_launch"] - rec["mbytes_per_launch"] - port["l2_weight_stream_mbytes_per_launch"]) < 0.02
     # bf16 trunk at 1080p: conv1_i + conv10_i, shared half, per-frame half = 5F + 4B tiles of P x 128 B over three launches
-    rb = bench.conv3x3_roofline(g, {"conv3x3": {"ms": 3.0, "launches": 30}}, 1, 270, 480, "bf16", True, "cfg4")
+    rb = bench.conv3x3_roofline(g, {"conv3x3": {"ms": 3.0, "launches": 30}}, 1, 270, 480, {"structure": "bf16_3", "launches_per_block": 3, "precision": "bf16"}, "cfg4")
     assert abs(rb["mbytes_per_launch"] * 1e6 - 270 * 480 * 128 * (5 * 7 + 4) / 3) < 1e4
 
 

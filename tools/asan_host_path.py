@@ -29,7 +29,7 @@ def main():
         ref = pfnl_spec.forward(x, w, scale=scale, num_block=nb)
         eng = PFNLEngine(geom, device=0)
         eng.load_weights(w)
-        for opts in ({}, {"conv3x3": "split16", "small": "off"}, {"conv3x3": "wsplit"}, {"conv3x3": "winograd"}, {"conv3x3": "direct", "conv1x1": "tiled"},
+        for opts in ({}, {"conv3x3": "split16", "small": "off"}, {"conv3x3": "winograd"}, {"conv3x3": "direct", "conv1x1": "tiled"},
                      {"strict_fp32": "on"}, {"small_c10": "off"}, {"split16_sf": "off"}, {"split16_chain": "off"}, {"split16_c10": "off"}, {"graph": "on"}, {"precision": "bf16"},
                      {"precision": "bf16", "bf16_conv10": "separate"}):
             for k, v in opts.items():

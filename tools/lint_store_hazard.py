@@ -12,8 +12,9 @@ written it back.  Found as run-to-run noise of 1e-7 in the -O1 (ASAN) build afte
 v_fma_f32 (repeatable, within every tolerance, at -O3).  The lint flags every instruction inside an ;;#ASMSTART / ;;#ASMEND block that
 reads a VGPR written by a v_mfma fewer than MFMA_STATES issue slots earlier (another MFMA that takes it whole as C is the accumulate
 chain: exempt; an s_nop n counts n + 1 slots; every other instruction 1 - conservative: an MFMA in between occupies more).  The
-reverse case is checked too: an MFMA that is ITSELF inline asm (conv_wsplit.hip: B operands in AGPRs) is unknown to the compiler, so any
-instruction reading its result inside the window is flagged.
+reverse case is checked too: an MFMA that is ITSELF inline asm (tools/experiments/wsplit: B operands in AGPRs) is unknown to the compiler, so
+any instruction reading its result inside the window is flagged.  Destinations and sources in the AGPR half (a[..], v_accvgpr_read) are
+tracked like VGPRs (round 6); `--selftest` feeds known-bad and known-good snippets through the rule.
 
 usage: python tools/lint_store_hazard.py [file.hip ...]      (default: every pfnl_amd/csrc/*.hip)      exit status 1 on a hit
 """
@@ -70,8 +71,8 @@ def lint(asm, need=2):
     return hits
 
 
-MFMA = re.compile(r"^\s*v_mfma_\S+\s+v\[(\d+):(\d+)\]")
-VREG = re.compile(r"v\[(\d+):(\d+)\]|\bv(\d+)\b")
+MFMA = re.compile(r"^\s*v_mfma_\S+\s+([va])\[(\d+):(\d+)\]")          # destination in the VGPR or the AGPR half of the register file
+VREG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
 MFMA_STATES = 11                                                   # 8-pass XDL write -> VALU read (12 for safety below 16-pass: these kernels use 8-pass MFMAs)
 
 
@@ -92,8 +93,8 @@ def raw_lines(path):
 
 
 def regs_read(ins):
-    """VGPRs an instruction names as sources (every operand behind the first: destinations that are also sources - accumulate forms - are
-    named again among them)"""
+    """Registers ("v12" / "a12": VGPRs and AGPRs) an instruction names as sources (every operand behind the first: destinations that are
+    also sources - accumulate forms - are named again among them).  v_accvgpr_read_b32 v, aN reads aN."""
     ops = ins.split(None, 1)
     if len(ops) < 2:
         return set()
@@ -101,21 +102,25 @@ def regs_read(ins):
     out = set()
     for part in parts[1:]:
         for m in VREG.finditer(part):
-            if m.group(3) is not None:
-                out.add(int(m.group(3)))
+            if m.group(4) is not None:
+                out.add(m.group(4) + m.group(5))
             else:
-                out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+                out.update(m.group(1) + str(r) for r in range(int(m.group(2)), int(m.group(3)) + 1))
     return out
 
 
-def lint_mfma_asm(asm):
-    ins = list(raw_lines(asm))
+def mfma_dst(ins):
+    m = MFMA.match(ins)
+    return {m.group(1) + str(r) for r in range(int(m.group(2)), int(m.group(3)) + 1)} if m else None
+
+
+def lint_mfma_lines(ins):
+    """ins: [(instruction, inside inline asm)]"""
     hits = []
     for i, (s, mfma_in_asm) in enumerate(ins):
-        m = MFMA.match(s)
-        if not m:
+        dst = mfma_dst(s)
+        if not dst:
             continue
-        dst = set(range(int(m.group(1)), int(m.group(2)) + 1))
         waited, j = 0, i + 1
         while waited < MFMA_STATES and j < len(ins):
             t, inside = ins[j]
@@ -123,9 +128,10 @@ def lint_mfma_asm(asm):
             if n:
                 waited += int(n.group(1)) + 1
             else:
-                if MFMA.match(t) and (written_mfma := set(range(int(MFMA.match(t).group(1)), int(MFMA.match(t).group(2)) + 1))) & dst:
+                d2 = mfma_dst(t)
+                if d2 and d2 & dst:
                     break                                            # the accumulate chain (or the register is rewritten): the rule ends here
-                # (an MFMA that is itself inline asm - conv_wsplit.hip - is unknown to the compiler: then EVERY reader counts)
+                # (an MFMA that is itself inline asm is unknown to the compiler: then EVERY reader counts)
                 if (inside or mfma_in_asm) and not t.lstrip().startswith(("s_", "v_mfma")) and regs_read(t) & dst:
                     hits.append((s.strip(), t.strip(), waited))
                     break
@@ -134,7 +140,37 @@ def lint_mfma_asm(asm):
     return hits
 
 
+def lint_mfma_asm(asm):
+    return lint_mfma_lines(list(raw_lines(asm)))
+
+
+def selftest():
+    """Known-bad and known-good snippets (a CPU test runs this): the rule must fire on an inline-asm reader of a fresh MFMA result in the
+    VGPR AND in the AGPR half (v_accvgpr_read of an AGPR accumulator), on any reader of an inline-asm MFMA, and stay quiet behind enough
+    wait states, on the accumulate chain, and on compiler-generated readers of compiler-generated MFMAs."""
+    A, C_ = True, False                                              # inside inline asm / compiler-generated
+    bad = [
+        [("v_mfma_f32_32x32x16_f16 v[0:15], v[16:19], v[20:23], v[0:15]", C_), ("v_fma_f32 v40, v3, v41, v42", A)],
+        [("v_mfma_f32_32x32x16_f16 a[0:15], v[16:19], v[20:23], a[0:15]", C_), ("s_nop 3", C_), ("v_accvgpr_read_b32 v40, a7", A)],
+        [("v_mfma_f32_32x32x16_f16 a[16:31], v[16:19], a[0:3], a[16:31]", A), ("v_accvgpr_read_b32 v40, a16", C_)],
+        [("v_mfma_f32_32x32x16_f16 v[0:15], v[16:19], a[0:3], v[0:15]", A), ("v_add_f32 v40, v[0:1], v41", C_)],
+    ]
+    good = [
+        [("v_mfma_f32_32x32x16_f16 v[0:15], v[16:19], v[20:23], v[0:15]", C_), ("s_nop 7", C_), ("s_nop 2", C_), ("v_fma_f32 v40, v3, v41, v42", A)],
+        [("v_mfma_f32_32x32x16_f16 a[0:15], v[16:19], v[20:23], a[0:15]", C_), ("v_mfma_f32_32x32x16_f16 a[0:15], v[24:27], v[20:23], a[0:15]", C_)],
+        [("v_mfma_f32_32x32x16_f16 v[0:15], v[16:19], v[20:23], v[0:15]", C_), ("v_add_f32 v40, v3, v41", C_)],
+        [("v_mfma_f32_32x32x16_f16 a[0:15], v[16:19], v[20:23], a[0:15]", C_), ("v_accvgpr_read_b32 v40, a16", A)],
+    ]
+    for k, snip in enumerate(bad):
+        assert len(lint_mfma_lines(snip)) == 1, ("bad snippet %d not flagged" % k, snip)
+    for k, snip in enumerate(good):
+        assert not lint_mfma_lines(snip), ("good snippet %d flagged" % k, snip)
+    return 0
+
+
 def main():
+    if sys.argv[1:] == ["--selftest"]:
+        return selftest()
     files = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "pfnl_amd", "csrc", "*.hip")))
     bad = 0
     with tempfile.TemporaryDirectory() as tmp:

@@ -15,11 +15,9 @@ from pfnl_amd.spec import PFNLGeometry
 # (label, geometry kwargs, options, B, H, W)
 CASES = [
     ("fp32 configs[1]", {}, {}, 4, 128, 128),
-    ("fp32 configs[1] wsplit", {}, {"conv3x3": "wsplit"}, 4, 128, 128),
     ("fp32 configs[0]", {}, {}, 1, 32, 32),
     ("fp32 configs[4] 2x T=5", {"scale": 2, "num_frames": 5}, {}, 1, 64, 64),
     ("fp32 Vid4 144x180", {}, {}, 2, 144, 180),
-    ("fp32 UDM10 180x318 wsplit", {}, {"conv3x3": "wsplit"}, 1, 180, 318),
     ("fp32 ragged 66x130", {}, {}, 3, 66, 130),
     ("bf16 1080p", {}, {"precision": "bf16"}, 1, 270, 480),
     ("fp32 1080p", {}, {}, 1, 270, 480),
