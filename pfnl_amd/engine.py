@@ -116,6 +116,19 @@ class PFNLEngine:
         _capi.check(self._lib.pfnl_copy_weights(self._h, other._h))
         self._ready = True
 
+    OPTION_KEYS = ("precision", "strict_fp32", "conv3x3", "conv1x1", "conv2", "merge1", "nonlocal", "nl_type", "nl_sub_sample", "small", "small_c10",
+                   "split16_sf", "split16_chain", "split16_c10", "split16_mid", "split16_sf0", "bf16_conv10", "graph")
+
+    def clone(self) -> "PFNLEngine":
+        """A second handle on the same device with the same weights (device-to-device copy of the packed blobs: pfnl_copy_weights) and the
+        same option values as the library holds them now (pfnl_get_option).  Handles are independent: two of them on two streams keep two
+        forwards in flight (the harness's small batches, model.py)."""
+        other = PFNLEngine(self.geom, device=self.device)
+        for k in self.OPTION_KEYS:
+            other.set_option(k, self.get_option(k))
+        other.copy_weights_from(self)
+        return other
+
     def set_option(self, key: str, value: str) -> None:
         """e.g. ("conv3x3", "auto" | "split16" | "winograd" | "winograd_tile" | "direct"); see include/pfnl_hip.h."""
         _capi.check(self._lib.pfnl_set_option(self._h, key.encode(), value.encode()))

@@ -102,6 +102,7 @@ class VSR(object):
 
     # -- engine plumbing (not in the reference; replaces tf.Session / tf.train.Saver) ------------
     _engine = None
+    _engine2 = None                # second handle of the inference harness (two forwards in flight on small batches); made on first use
     _weights: Optional[Dict[str, np.ndarray]] = None
     device = 0
     num_block = 20
@@ -114,6 +115,8 @@ class VSR(object):
         self._weights = {k: np.asarray(v, np.float32) for k, v in weights.items()}
         if self._engine is not None:
             self._engine.load_weights(self._weights)
+        if getattr(self, "_engine2", None) is not None:      # the harness's second handle (two forwards in flight) follows the first
+            self._engine2.copy_weights_from(self._engine)
 
     allow_random_init = False      # opt-in: run without a checkpoint on a seeded random initialisation
     loaded_step: Optional[int] = None
@@ -296,7 +299,31 @@ class PFNL(VSR):
         jobs = []
         stream = torch.cuda.current_stream(frames.device)
         host = [None, None]                                          # pinned uint8 landing buffers, double-buffered
-        inflight = None                                              # (done event, start event, host buffer, first, count, ran strict)
+        inflight = None                                              # (done event, start event, host buffer, first, count, ran strict, lane)
+
+        # TWO FORWARDS IN FLIGHT (round 6).  The reference calls this with part = 50 / 1000 (model/pfnl.py:264, 332), i.e. ONE window per
+        # sess.run for every Vid4 / UDM10 sequence (:211-216) - and one clip of that size is the launch-structure with the most idle
+        # time per pixel (pfnl_plan "mid4" / "small2": ~80 launches of 10 - 30 us whose prologues and last tiles leave CUs idle).  The
+        # batches are independent, so they alternate between TWO handles on two streams: the launches of batch i + 1 fill what batch i
+        # leaves idle.  Every forward keeps its batch size and launch structure, so the frames - and the PNG bytes - are those of the
+        # serial loop (tests/test_gpu_forward.py::test_harness_two_in_flight_is_byte_identical).  Larger batches (the "chain2" structure
+        # of `part`-sized batches) already fill the chip and keep one handle (and one workspace).  PFNL_HARNESS_INFLIGHT=1 | 2 overrides.
+        H_lr, W_lr = int(frames.shape[1]), int(frames.shape[2])
+        want = os.environ.get("PFNL_HARNESS_INFLIGHT", "auto")
+        structure = eng.plan(min(num_once, max_frame), H_lr, W_lr)["structure"]
+        lanes = 2 if (want == "2" or (want == "auto" and structure in ("mid4", "small2", "small3", "bf16_mid4"))) and part > 1 else 1
+        engines, streams = [eng], [stream]
+        if lanes == 2:
+            if getattr(self, "_engine2", None) is None:
+                self._engine2 = eng.clone()
+            else:                                                    # (options may have changed since the clone was made)
+                for key in eng.OPTION_KEYS:
+                    if self._engine2.get_option(key) != eng.get_option(key):
+                        self._engine2.set_option(key, eng.get_option(key))
+            s2 = torch.cuda.Stream(device=frames.device)
+            s2.wait_stream(stream)                                   # the uploaded frames
+            engines.append(self._engine2)
+            streams.append(s2)
 
         # The device-pointer forwards below are asynchronous: the f16-pipe kernels' range fence (include/pfnl_hip.h, "strict_fp32")
         # cannot re-run them by itself.  Once per batch, when its frames have arrived, the flag is read (pfnl_range_flag: no
@@ -313,33 +340,43 @@ class PFNL(VSR):
         was_bf16 = eng.get_option("precision") == "bf16"
 
         def go_strict():
-            stream.synchronize()                                     # no forward of the old configuration is in flight when it changes
+            for st in streams:
+                st.synchronize()                                     # no forward of the old configuration is in flight when it changes
             if was_bf16:
                 prior["precision"] = "bf16"
-                eng.set_option("precision", "fp32")
                 print('precision=bf16: a batch left the binary16 range of its non-local block / conv0; recomputed (and the rest of the '
                       'sequence computed) at precision=fp32, strict_fp32=on')
             if eng.get_option("strict_fp32") != "on":
                 prior["strict_fp32"] = eng.get_option("strict_fp32")
-                eng.set_option("strict_fp32", "on")
+            for e in engines:
+                if was_bf16:
+                    e.set_option("precision", "fp32")
+                e.set_option("strict_fp32", "on")
             state["strict"] = True
 
-        def recompute_strict(buf, first_, count_):
-            win_ = ops.gather_windows(frames, first_, count_, self.num_frames)
-            u8_ = ops.quantise_u8(eng.forward(win_))
-            buf[:count_].copy_(u8_, non_blocking=True)
-            stream.synchronize()
-            eng.range_flagged()                                      # (strict path: the fence is not armed; clears a stale flag)
+        def recompute_strict(buf, first_, count_, lane_):
+            with torch.cuda.stream(streams[lane_]):
+                win_ = ops.gather_windows(frames, first_, count_, self.num_frames)
+                u8_ = ops.quantise_u8(engines[lane_].forward(win_))
+                buf[:count_].copy_(u8_, non_blocking=True)
+            streams[lane_].synchronize()
+            engines[lane_].range_flagged()                           # (strict path: the fence is not armed; clears a stale flag)
+
+        last_done = [None]
 
         def drain(item, pool):
-            done, started, buf, first_, count_, was_strict = item
+            done, started, buf, first_, count_, was_strict, lane_ = item
             done.synchronize()                                       # this batch's frames are on the host
-            all_time.append(started.elapsed_time(done) * 1e-3)       # device time of the batch: gather + forward + quantise + D2H
-            if not was_strict and (eng.range_flagged() or state["redo_next"]):
+            # device time of the batch: gather + forward + quantise + D2H.  Two in flight: the time from the previous batch's arrival to
+            # this one's (the batches overlap: their own spans would count the shared time twice)
+            ref_ev = started if (lanes == 1 or last_done[0] is None) else last_done[0]
+            all_time.append(max(ref_ev.elapsed_time(done), 0.0) * 1e-3)
+            last_done[0] = done
+            if not was_strict and (engines[lane_].range_flagged() or state["redo_next"]):
                 state["redo_next"] = not state["strict"]             # the batch already in flight ran on the f16 pipe as well
                 if not state["strict"]:
                     go_strict()
-                recompute_strict(buf, first_, count_)
+                recompute_strict(buf, first_, count_, lane_)
             elif was_strict:
                 state["redo_next"] = False
             frames_u8 = buf[:count_].numpy().copy()                  # (the pinned buffer is reused two batches later)
@@ -353,29 +390,35 @@ class PFNL(VSR):
                     count = min(num_once, max_frame - first)
                     if count <= 0:
                         break
-                    started, done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    started.record(stream)
-                    was_strict = state["strict"]
-                    win = ops.gather_windows(frames, first, count, self.num_frames)
-                    sr = eng.forward(win)
-                    u8 = ops.quantise_u8(sr)
-                    k = i & 1
-                    if host[k] is None or host[k].shape[0] < count:
-                        host[k] = torch.empty((num_once,) + tuple(u8.shape[1:]), dtype=torch.uint8).pin_memory()
-                    host[k][:count].copy_(u8, non_blocking=True)
-                    done.record(stream)
+                    lane = i % lanes
+                    with torch.cuda.stream(streams[lane]):
+                        started, done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        started.record(streams[lane])
+                        was_strict = state["strict"]
+                        win = ops.gather_windows(frames, first, count, self.num_frames)
+                        sr = engines[lane].forward(win)
+                        u8 = ops.quantise_u8(sr)
+                        k = i & 1
+                        if host[k] is None or host[k].shape[0] < count:
+                            host[k] = torch.empty((num_once,) + tuple(u8.shape[1:]), dtype=torch.uint8).pin_memory()
+                        host[k][:count].copy_(u8, non_blocking=True)
+                        done.record(streams[lane])
                     if inflight is not None:                         # while the GPU runs batch i: batch i-1 goes to the PNG encoders
                         drain(inflight, pool)
-                    inflight = (done, started, host[k], first, count, was_strict)
+                    inflight = (done, started, host[k], first, count, was_strict, lane)
                 if inflight is not None:
                     drain(inflight, pool)
                 for j in jobs:
                     j.result()
         finally:
+            for st in streams:
+                st.synchronize()
+            if lanes == 2:
+                stream.wait_stream(streams[1])
             if prior:                                                # back to the configuration the library held (also when an encoder raised)
-                stream.synchronize()
-                for key, value in prior.items():
-                    eng.set_option(key, value)
+                for e in engines:
+                    for key, value in prior.items():
+                        e.set_option(key, value)
         all_time = np.array(all_time)
         avg = np.mean(all_time[1:]) if len(all_time) > 1 else float('nan')
         print('spent {} s in total and {} s in average'.format(np.sum(all_time), avg))
