@@ -298,20 +298,23 @@ class PFNL(VSR):
         all_time = []
         jobs = []
         stream = torch.cuda.current_stream(frames.device)
-        host = [None, None]                                          # pinned uint8 landing buffers, double-buffered
-        inflight = None                                              # (done event, start event, host buffer, first, count, ran strict, lane)
+        host = []                                                    # pinned uint8 landing buffers: a ring of lanes + 1 (one being drained, `lanes` in flight)
+        inflight = []                                                # FIFO of (done event, start event, host buffer, first, count, ran strict, lane)
 
-        # TWO FORWARDS IN FLIGHT (round 6).  The reference calls this with part = 50 / 1000 (model/pfnl.py:264, 332), i.e. ONE window per
-        # sess.run for every Vid4 / UDM10 sequence (:211-216) - and one clip of that size is the launch-structure with the most idle
-        # time per pixel (pfnl_plan "mid4" / "small2": ~80 launches of 10 - 30 us whose prologues and last tiles leave CUs idle).  The
-        # batches are independent, so they alternate between TWO handles on two streams: the launches of batch i + 1 fill what batch i
-        # leaves idle.  Every forward keeps its batch size and launch structure, so the frames - and the PNG bytes - are those of the
-        # serial loop (tests/test_gpu_forward.py::test_harness_two_in_flight_is_byte_identical).  Larger batches (the "chain2" structure
-        # of `part`-sized batches) already fill the chip and keep one handle (and one workspace).  PFNL_HARNESS_INFLIGHT=1 | 2 overrides.
+        # TWO FORWARDS IN FLIGHT (round 6, opt-in: PFNL_HARNESS_INFLIGHT=2).  The reference calls this with part = 50 / 1000 (model/pfnl.py:264,
+        # 332), i.e. ONE window per sess.run for every Vid4 / UDM10 sequence (:211-216) - and one clip of that size is the launch structure
+        # with the most idle time per pixel (pfnl_plan "mid4" / "small2": ~80 launches of 10 - 30 us).  The batches are independent, so they
+        # can alternate between TWO handles on two streams; every forward keeps its batch size and launch structure, so the frames - and the
+        # PNG bytes - are those of the serial loop (tests/test_gpu_forward.py::test_harness_two_in_flight_is_byte_identical).  MEASURED
+        # (tools/harness_inflight_timing.py, 41 frames of 144x180, profiles/r06_harness_inflight.txt): device time per frame 2.61 -> 2.34 - 2.67 ms
+        # (fp32), 1.38 -> 1.12 - 1.38 (bf16) - the gain comes and goes with how the two streams' launches interleave - and the WALL time of
+        # the sequence is 5 - 10 % WORSE (a second stream's worth of host work in a loop that is host-bound at this size).  Why it cannot do
+        # more: every 3x3 launch fills a CU's LDS with one workgroup, so a second forward's workgroups only start where the first's have
+        # exited - what overlaps is launch latency (2 us x 80), not prologues.  Hence not the default; `part` is the lever that works
+        # (part = 8: six windows per forward on the "chain2" structure, 0.074 instead of 0.099 us per LR pixel).
         H_lr, W_lr = int(frames.shape[1]), int(frames.shape[2])
         want = os.environ.get("PFNL_HARNESS_INFLIGHT", "auto")
-        structure = eng.plan(min(num_once, max_frame), H_lr, W_lr)["structure"]
-        lanes = 2 if (want == "2" or (want == "auto" and structure in ("mid4", "small2", "small3", "bf16_mid4"))) and part > 1 else 1
+        lanes = 2 if want == "2" and part > 1 else 1                 # ("auto" = 1: see above)
         engines, streams = [eng], [stream]
         if lanes == 2:
             if getattr(self, "_engine2", None) is None:
@@ -335,7 +338,7 @@ class PFNL(VSR):
         # path of the library that covers the whole fp32 range.  Both options are restored when the sequence ends, however it ends.
         # What is restored is what the LIBRARY held before (pfnl_get_option: a value set by PFNL_STRICT_FP32 / a precision chosen outside this
         # engine's own set_option calls are seen too), and only the keys go_strict changed.
-        state = {"strict": False, "redo_next": False}
+        state = {"strict": False}
         prior = {}                                                   # option -> the library's value before go_strict changed it
         was_bf16 = eng.get_option("precision") == "bf16"
 
@@ -369,16 +372,18 @@ class PFNL(VSR):
             done.synchronize()                                       # this batch's frames are on the host
             # device time of the batch: gather + forward + quantise + D2H.  Two in flight: the time from the previous batch's arrival to
             # this one's (the batches overlap: their own spans would count the shared time twice)
-            ref_ev = started if (lanes == 1 or last_done[0] is None) else last_done[0]
-            all_time.append(max(ref_ev.elapsed_time(done), 0.0) * 1e-3)
+            # (= from the later of "its stream reached it" and "the previous batch arrived" to its own arrival: with two forwards in flight
+            # the batches overlap and their own spans would count the shared time twice; serial batches: started -> done as before)
+            t_own = started.elapsed_time(done)
+            t_gap = last_done[0].elapsed_time(done) if last_done[0] is not None else t_own
+            all_time.append(max(min(t_own, t_gap), 0.0) * 1e-3)
             last_done[0] = done
-            if not was_strict and (engines[lane_].range_flagged() or state["redo_next"]):
-                state["redo_next"] = not state["strict"]             # the batch already in flight ran on the f16 pipe as well
+            # a flagged batch - and every batch that was enqueued on the f16 pipe before the flag was seen (up to `lanes` of them) - is
+            # computed again on the strict kernels
+            if not was_strict and (engines[lane_].range_flagged() or state["strict"]):
                 if not state["strict"]:
                     go_strict()
                 recompute_strict(buf, first_, count_, lane_)
-            elif was_strict:
-                state["redo_next"] = False
             frames_u8 = buf[:count_].numpy().copy()                  # (the pinned buffer is reused two batches later)
             for j in range(count_):
                 jobs.append(pool.submit(imsave_rgb, join(save_path, '{:0>4}.png'.format(first_ + j)), frames_u8[j][0]))
@@ -398,16 +403,16 @@ class PFNL(VSR):
                         win = ops.gather_windows(frames, first, count, self.num_frames)
                         sr = engines[lane].forward(win)
                         u8 = ops.quantise_u8(sr)
-                        k = i & 1
-                        if host[k] is None or host[k].shape[0] < count:
-                            host[k] = torch.empty((num_once,) + tuple(u8.shape[1:]), dtype=torch.uint8).pin_memory()
+                        k = i % (lanes + 1)
+                        if len(host) <= k:
+                            host.append(torch.empty((num_once,) + tuple(u8.shape[1:]), dtype=torch.uint8).pin_memory())
                         host[k][:count].copy_(u8, non_blocking=True)
                         done.record(streams[lane])
-                    if inflight is not None:                         # while the GPU runs batch i: batch i-1 goes to the PNG encoders
-                        drain(inflight, pool)
-                    inflight = (done, started, host[k], first, count, was_strict, lane)
-                if inflight is not None:
-                    drain(inflight, pool)
+                    inflight.append((done, started, host[k], first, count, was_strict, lane))
+                    if len(inflight) > lanes:                        # while the GPU runs the `lanes` newest batches: the oldest goes to the PNG encoders
+                        drain(inflight.pop(0), pool)
+                while inflight:
+                    drain(inflight.pop(0), pool)
                 for j in jobs:
                     j.result()
         finally:

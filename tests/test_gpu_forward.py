@@ -219,9 +219,10 @@ def test_harness_on_device_is_byte_identical(tmp_path):
 def test_harness_two_in_flight_is_byte_identical(tmp_path, monkeypatch, H, W, nb, frames):
     """Round 6 (reference model/pfnl.py:211-216, 249-258, 264, 332): the reference's own calls give ONE window per
     forward for every Vid4 / UDM10 sequence (part = 50 / 1000 >= the frame count), the launch structure with the most idle time per pixel.
-    The harness alternates such batches between TWO handles on two streams (two forwards in flight; automatic for the "mid4" / "small"
-    structures).  Every forward keeps its batch size and structure, so the PNG bytes are those of the serial loop - at the Vid4 geometry
-    (mid4), a small shape (small2) and a 96x128 window - and those of the host restatement around single forwards."""
+    With PFNL_HARNESS_INFLIGHT=2 the harness alternates such batches between TWO handles on two streams (two forwards in flight, a ring of
+    three landing buffers; opt-in: the measured gain is unreliable and the wall time worse).  Every forward keeps its batch
+    size and structure, so the PNG bytes are those of the serial loop - at the Vid4 geometry (mid4), a small shape (small2) and a 96x128
+    window - and those of the host restatement around single forwards."""
     from PIL import Image
     from model.pfnl import PFNL
     from pfnl_amd import model as M
@@ -238,19 +239,18 @@ def test_harness_two_in_flight_is_byte_identical(tmp_path, monkeypatch, H, W, nb
     m.set_weights(synth.synthetic_weights(geom, seed=0))
     assert m._get_engine().plan(1, H, W)["structure"] in ("mid4", "small2")
     outs = {}
-    for mode in ("1", "2", "auto"):
+    for mode in ("1", "auto", "2"):
         monkeypatch.setenv("PFNL_HARNESS_INFLIGHT", mode)
         m.test_video_lr(str(seq), name="out" + mode, part=50)       # part >= frames: num_once = 1 (model/pfnl.py:211-216)
         outs[mode] = np.stack([np.asarray(Image.open(p)) for p in sorted((seq / ("out" + mode)).glob("*.png"))])
-        assert (m._engine2 is not None) == (mode != "1") or mode == "1"
-    assert m._engine2 is not None                                   # "auto" took two lanes for these structures
+        assert (m._engine2 is not None) == (mode != "1")            # the second handle exists once it has been asked for; "auto" is serial
     assert np.array_equal(outs["1"], outs["2"]) and np.array_equal(outs["1"], outs["auto"])
     lrs = (lr_u8 / 255.).astype(np.float32)
     win = np.ascontiguousarray(M.sliding_windows(lrs, 7))
     eng = engine_for(geom)
     want = np.concatenate([M.quantise(eng.forward(win[i:i + 1])[:, 0]) for i in range(frames)])   # B = 1 forwards, as the harness runs them
     assert np.array_equal(outs["2"], want)
-    m.set_weights(synth.synthetic_weights(geom, seed=5))            # new weights reach the second handle too
+    m.set_weights(synth.synthetic_weights(geom, seed=5))            # new weights reach the second handle too (still PFNL_HARNESS_INFLIGHT=2)
     m.test_video_lr(str(seq), name="outw", part=50)
     e5 = _engine_with(geom, synth.synthetic_weights(geom, seed=5))
     want5 = np.concatenate([M.quantise(e5.forward(win[i:i + 1])[:, 0]) for i in range(frames)])
