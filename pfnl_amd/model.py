@@ -312,7 +312,6 @@ class PFNL(VSR):
         # more: every 3x3 launch fills a CU's LDS with one workgroup, so a second forward's workgroups only start where the first's have
         # exited - what overlaps is launch latency (2 us x 80), not prologues.  Hence not the default; `part` is the lever that works
         # (part = 8: six windows per forward on the "chain2" structure, 0.074 instead of 0.099 us per LR pixel).
-        H_lr, W_lr = int(frames.shape[1]), int(frames.shape[2])
         want = os.environ.get("PFNL_HARNESS_INFLIGHT", "auto")
         lanes = 2 if want == "2" and part > 1 else 1                 # ("auto" = 1: see above)
         engines, streams = [eng], [stream]
