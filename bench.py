@@ -260,7 +260,8 @@ def conv3x3_roofline(geom, prof, B, H, W, plan, workload):
     # launches of the class per PF block: 2 with conv2_i as one launch (Winograd's grouped mode; the split-f16 chain kernel), else 3
     chain, c10, sf0 = bool(plan.get("chain")), bool(plan.get("c10_fused")), bool(plan.get("sf0"))
     # launches of THIS class per block: the plan's, minus conv10_i's own launch (class conv1x1) where it is not fused into conv1_i's
-    launches_per_step = (plan["launches_per_block"] - (0 if (c10 or plan["structure"].startswith("small2")) else 1)) * geom.num_block
+    c1x1 = plan["c1x1"] if "c1x1" in plan else (0 if (c10 or plan["structure"].startswith("small2")) else 1)
+    launches_per_step = (plan["launches_per_block"] - c1x1) * geom.num_block
     # conv10_i rides in the conv1_i launch of the default path (conv3x3_c1c10_kernel): its work belongs to this class then
     if c10:
         flops3 += geom.num_block * F * P * 64 * 64 * 2.0

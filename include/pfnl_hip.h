@@ -113,6 +113,13 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *   Below 136 chains (and above the small-shape rule's 200 tiles; both scale with the device's CU count / 256) the block runs as four launches that deal out single tiles:
  *   conv1_i, conv10_i, the shared half of conv2_i, the per-frame half in flat order (same arithmetic as split16_c10=off +
  *   split16_chain=off; tools/precision_ladder.py has the crossover).  Only with conv3x3=auto and both of those options on.
+ * key "split16_splitchains" = "auto" (default since round 6) | "off": the two-launch block deals out whole (clip, tile) chains, so a batch whose
+ *   chains are not a whole number of rounds of the grid (256 workgroups) pays a whole extra chain for its last, partial round (5 clips of
+ *   128x128 = 1.25 rounds took 1.57x the time of 4).  When that round has at most grid / 2 chains, they are cut by FRAMES into parts (one per
+ *   workgroup): conv3x3_c1c10_kernel leaves a part's share of conv10_i's sum as raw fp32 and c10_finalize_kernel adds the parts up in fixed
+ *   order (+ leaky-relu, split format); the chain kernel recomputes the shared half per part.  Deterministic; batches that are whole rounds
+ *   (configs[1]) run exactly as before (bit-identical); the clips of the whole rounds keep their bits, the cut chains differ from the uncut
+ *   launch in summation order (oracle tolerance).  pfnl_plan: "chain2_split", whole_chains / split_parts / part_frames.
  * key "split16_sf0" = "off" (default) | "on" (round 6): in the two-launch block ("chain2") the chain kernel writes the block's output - the
  *   next block's inp0 - a second time in the split format, and conv3x3_c1c10_kernel takes its halo from that copy by LDS-DMA in operand form
  *   (no fp32 -> binary16 split on the VALU, no register-staged commit).  Same operands in the same order: BIT-IDENTICAL results (tested).
@@ -176,10 +183,12 @@ int pfnl_forward(pfnl_handle* h, const void* in, int in_is_device, void* out, in
 int pfnl_forward_strip(pfnl_handle* h, const void* in, void* out, int B, int H, int W, int row0, int nrows, void* stream);
 int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes);
 /* THE LAUNCH PLAN of the progressive-fusion trunk (reference model/pfnl.py:65-71) for a [B,T,H,W,3] forward under the handle's current
- * options, as text: "<structure> launches_per_block=<n> precision=<..> conv3x3=<..> conv1x1=<..> c10_fused=<0|1> chain=<0|1> sf0=<0|1>
- * strict=<0|1> tiles=<8x32-pixel tiles per per-frame launch> chains=<(clip, tile) chains>".  Structures: "small2" / "small3" (conv_small.hip,
+ * options, as text: "<structure> launches_per_block=<n> c1x1=<launches of class conv1x1 among them> precision=<..> conv3x3=<..> conv1x1=<..>
+ * c10_fused=<0|1> chain=<0|1> sf0=<0|1> strict=<0|1> tiles=<8x32-pixel tiles per per-frame launch> chains=<(clip, tile) chains>
+ * whole_chains=<n> split_parts=<s> part_frames=<q>".  Structures: "small2" / "small3" (conv_small.hip,
  * below ~0.78 tiles per CU: 200 on a 256-CU device), "mid4" (four per-tile launches, below ~0.53 chains per CU: 136), "chain2" (conv1_i +
- * conv10_i, then the whole of conv2_i) and "chain2_sf0" (the same with a split-format copy of every block's output so that the next block's
+ * conv10_i, then the whole of conv2_i), "chain2_split" (the same with the chains of a last, partial round cut by frames: option
+ * split16_splitchains) and "chain2_sf0" (the same with a split-format copy of every block's output so that the next block's
  * conv1_i takes its halo by LDS-DMA: option split16_sf0=on), "split16_3" / "split16_4", "winograd_ws3" / "winograd_ws4", "winograd_tile4",
  * "direct4"; bf16: "bf16_3", "bf16_4", "bf16_mid4".  The ONE statement of the dispatch rule: pfnl_forward runs it, pfnl_workspace_bytes sizes
  * from it, bench.py's byte model and the tests read it here.  The structure changes the summation order, hence the last bits: the same clip

@@ -239,6 +239,9 @@ struct pfnl_handle {
                                                               // Bit-identical; MEASURED SLOWER (configs[1], same box: 4.86 vs 4.45 ms - the chain kernel pays 22 us for the copy,
                                                               // conv1_i + conv10_i gains 0.6: DESIGN.md R6.1), hence off
     DevBuf inp0sf;                                            // ... that copy [B*T][H][W] x 256 B
+    bool split_chains = true;                                 // option split16_splitchains=auto|off: in the two-launch block, a batch that is not a whole number of rounds of
+                                                              // (clip, tile) chains runs its last, partial round as PARTS of chains cut by frames (conv_split16.h "SPLIT CHAINS")
+    DevBuf c10part;                                           // ... conv10_i's partial sums of those parts: [slot][8][32][64] fp32
     bool sf_path = true;                                      // option split16_sf=on|off: with conv3x3 = conv1x1 = split16, conv1_i and conv10_i write the
                                                               // split format (conv_split16.h) and both halves of conv2_i read it by LDS-DMA (conv_sf.hip)
 
@@ -417,6 +420,8 @@ struct TrunkPlan {
     bool chain = false;                    // conv2_i in one launch (conv3x3_sf_chain_kernel)
     bool sf0 = false;                      // chain2 only: split-format copy of the block output, conv1_i's halo by LDS-DMA
     bool conv2_grouped = false;            // Winograd: conv2_i as one grouped launch
+    int n_full = 0, split_s = 0, split_q = 0;   // chain2 only: SPLIT CHAINS (conv_split16.h) - the chains behind the first n_full are cut into split_s parts of <= split_q frames
+    int c1x1_launches = 0;                 // launches per block of class conv1x1 (conv10_i on its own / c10_finalize_kernel)
     int launches_per_block = 0;
     int tiles8x32 = 0, chains = 0;
     const char* name = "";
@@ -436,6 +441,7 @@ TrunkPlan trunk_plan(const pfnl_handle* h, int B, int H, int W) {
         pl.bmid = h->sf_mid && h->bf16_fuse10 && pl.chains < mid_chains;
         pl.fuse10 = h->bf16_fuse10 && !pl.bmid;
         pl.launches_per_block = pl.fuse10 ? 3 : 4;
+        pl.c1x1_launches = pl.fuse10 ? 0 : 1;
         pl.name = pl.bmid ? "bf16_mid4" : (pl.fuse10 ? "bf16_3" : "bf16_4");
         return pl;
     }
@@ -451,6 +457,7 @@ TrunkPlan trunk_plan(const pfnl_handle* h, int B, int H, int W) {
     pl.small_c10 = pl.small && h->small_c10;
     if (pl.small) {
         pl.launches_per_block = pl.small_c10 ? 2 : 3;
+        pl.c1x1_launches = pl.small_c10 ? 0 : 1;
         pl.name = pl.small_c10 ? "small2" : "small3";
         return pl;
     }
@@ -461,7 +468,25 @@ TrunkPlan trunk_plan(const pfnl_handle* h, int B, int H, int W) {
     const int wino_groups = B * ((W + 31) / 32) * ((H + 3) / 4);
     pl.conv2_grouped = pl.algo == 3 && h->conv2_grouped && wino_groups >= 224 && fits32;
     pl.launches_per_block = (pl.c10_fused ? 1 : 2) + ((pl.chain || pl.conv2_grouped) ? 1 : 2);
-    pl.name = pl.mid ? "mid4" : (pl.c10_fused && pl.chain) ? (pl.sf0 ? "chain2_sf0" : "chain2")
+    pl.c1x1_launches = pl.c10_fused ? 0 : 1;
+    if (pl.c10_fused && pl.chain && h->split_chains && T <= 7) {
+        // SPLIT CHAINS: with R = chains mod grid chains in a last, partial round, a workgroup with one chain more than the others sets the time of
+        // both launches (5 clips of 128x128 = 1.25 rounds: 7.2 ms against 4.5 for 4).  When at least two parts of a chain fit the idle
+        // workgroups (R <= grid / 2), those R chains are cut by frames: s = grid / R parts of q = ceil(T / s) frames.
+        const int grid = conv_split16_grid();
+        const int R = pl.chains % grid;
+        if (pl.chains > grid && R > 0 && grid / R >= 2) {
+            const int s0 = std::min(T, grid / R), q = (T + s0 - 1) / s0, s = (T + q - 1) / q;
+            if (s >= 2) {
+                pl.n_full = pl.chains - R;
+                pl.split_s = s;
+                pl.split_q = q;
+                pl.launches_per_block += 1;                             // c10_finalize_kernel
+                pl.c1x1_launches = 1;
+            }
+        }
+    }
+    pl.name = pl.mid ? "mid4" : (pl.c10_fused && pl.chain) ? (pl.sf0 ? "chain2_sf0" : (pl.split_s ? "chain2_split" : "chain2"))
             : pl.algo == 4 ? (pl.launches_per_block == 3 ? "split16_3" : "split16_4")
             : pl.algo == 3 ? (pl.conv2_grouped ? "winograd_ws3" : "winograd_ws4")
             : pl.algo == 1 ? "winograd_tile4" : "direct4";
@@ -626,6 +651,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
     // (3x3 over concat([base, f]))
     const bool small = pl.small;
     if (pl.sf0 && h->inp0sf.ensure((size_t)F * P * 64)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
+    if (pl.split_s && h->c10part.ensure((size_t)(pl.chains - pl.n_full) * pl.split_s * 8 * 32 * 64)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
     const uint16_t* const w16m = reinterpret_cast<const uint16_t*>(h->wdev16s.p);
     for (int i = 0; i < (h->bf16 ? 0 : c.num_block); ++i) {   // model/pfnl.py:65-71
         if (h->prof_mode == 2) {          // sampled profiling: see prof_sampled; each sampled block with a fresh event chain
@@ -692,7 +718,26 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             q.wpack2 = w16s + h->off16s_c10f[i];
             q.bias2 = wd + h->off_c10_b[i];
             q.out2 = h->base.p;
+            q.n_full = pl.n_full;
+            q.split_s = pl.split_s;
+            q.split_q = pl.split_q;
+            q.partial = pl.split_s ? h->c10part.p : nullptr;
             HIPCHK(launch_conv3x3_c1c10(q, s));
+        }
+        if (c10_fused && pl.split_s) {   // split chains: the parts' raw conv10_i sums -> base (+ leaky-relu, split format) for the chains that were cut
+            ProfScope ps(h, s, PFNL_K_CONV1X1);
+            ConvSplitParams q{};
+            q.H = H;
+            q.W = W;
+            q.items = F;
+            q.add_div = T;
+            q.act = 1;
+            q.n_full = pl.n_full;
+            q.split_s = pl.split_s;
+            q.split_q = pl.split_q;
+            q.partial = h->c10part.p;
+            q.out2 = h->base.p;
+            HIPCHK(launch_c10_finalize(q, s));
         }
         if (!c10_fused) {   // conv1_i: per frame 3x3 64->64 + lrelu                       (:66)
             ProfScope ps(h, s, PFNL_K_CONV3X3);
@@ -764,6 +809,9 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             q.in2 = h->base.p;
             q.wpack2 = w16s + h->off16s_c2a_sf[i];
             q.out2 = out_sf0 ? h->inp0sf.p : nullptr;
+            q.n_full = pl.n_full;
+            q.split_s = pl.split_s;
+            q.split_q = pl.split_q;
             HIPCHK(launch_conv3x3_sf_chain(q, s));
             continue;
         }
@@ -911,6 +959,7 @@ int pfnl_create(const pfnl_config* cfg, pfnl_handle** out) {
     if (const char* e = std::getenv("PFNL_SF_C10")) h->sf_c10 = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_SF_MID")) h->sf_mid = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_SF_MID_CHAINS")) h->sf_mid_chains = std::atoi(e);   // (threshold sweeps)
+    if (const char* e = std::getenv("PFNL_SPLIT_CHAINS")) h->split_chains = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_SF0")) h->sf0 = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_SPLIT16_SF")) h->sf_path = std::string(e) != "0" && std::string(e) != "off";   // (A/B runs)
     if (const char* e = std::getenv("PFNL_CONV3X3")) {
@@ -971,7 +1020,7 @@ int pfnl_destroy(pfnl_handle* h) {
     h->pin_in.release();
     h->pin_out.release();
     if (h->rflag_host) hipHostFree(h->rflag_host);
-    for (DevBuf* b : {&h->p10, &h->Xs, &h->Q, &h->wdev16s, &h->wdev, &h->wdev16, &h->nl16, &h->X, &h->Xo, &h->nlp, &h->inp0, &h->inp0sf, &h->inp1, &h->base, &h->pb, &h->merge,
+    for (DevBuf* b : {&h->p10, &h->Xs, &h->Q, &h->wdev16s, &h->wdev, &h->wdev16, &h->nl16, &h->X, &h->Xo, &h->nlp, &h->inp0, &h->inp0sf, &h->c10part, &h->inp1, &h->base, &h->pb, &h->merge,
                       &h->stage_in, &h->stage_out, &h->scratch})
         b->release();
     delete h;
@@ -1063,6 +1112,12 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         else return fail(PFNL_ERR_INVALID, "split16_sf0 must be on or off");
         return 0;
     }
+    if (k == "split16_splitchains") {
+        if (v == "auto") h->split_chains = true;
+        else if (v == "off") h->split_chains = false;
+        else return fail(PFNL_ERR_INVALID, "split16_splitchains must be auto or off");
+        return 0;
+    }
     if (k == "split16_sf") {
         if (v == "on") h->sf_path = true;
         else if (v == "off") h->sf_path = false;
@@ -1152,6 +1207,7 @@ int pfnl_get_option(pfnl_handle* h, const char* key, char* buf, size_t buflen) {
     else if (k == "split16_mid") v = h->sf_mid ? "auto" : "off";
     else if (k == "split16_sf0") v = onoff(h->sf0);
     else if (k == "split16_sf") v = onoff(h->sf_path);
+    else if (k == "split16_splitchains") v = h->split_chains ? "auto" : "off";
     else if (k == "conv2") v = h->conv2_grouped ? "grouped" : "split";
     else if (k == "bf16_conv10") v = h->bf16_fuse10 ? "fused" : "separate";
     else if (k == "precision") v = h->bf16 ? "bf16" : "fp32";
@@ -1419,6 +1475,7 @@ int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes) {
         const TrunkPlan pl = trunk_plan(h, B, H, W);
         if (pl.small_c10) f += B * T * P * 64;
         if (pl.sf0) f += B * T * P * 64;
+        if (pl.split_s) f += (size_t)(pl.chains - pl.n_full) * pl.split_s * 8 * 32 * 64;
     }
     *bytes = f * sizeof(float);
     return 0;
@@ -1430,14 +1487,15 @@ int pfnl_plan(pfnl_handle* h, int B, int H, int W, char* buf, size_t buflen) {
     const TrunkPlan pl = trunk_plan(h, B, H, W);
     static const char* const a3[] = {"direct", "winograd_tile", "?", "winograd", "split16"};
     static const char* const a1[] = {"tiled", "stream", "split16"};
-    char tmp[256];
+    char tmp[384];
     if (pl.bf16)
-        std::snprintf(tmp, sizeof tmp, "%s launches_per_block=%d precision=bf16 tiles=%d chains=%d", pl.name, pl.launches_per_block, pl.tiles8x32, pl.chains);
+        std::snprintf(tmp, sizeof tmp, "%s launches_per_block=%d c1x1=%d precision=bf16 tiles=%d chains=%d", pl.name, pl.launches_per_block, pl.c1x1_launches, pl.tiles8x32, pl.chains);
     else
-        std::snprintf(tmp, sizeof tmp, "%s launches_per_block=%d precision=fp32 conv3x3=%s conv1x1=%s c10_fused=%d chain=%d sf0=%d strict=%d tiles=%d chains=%d",
-                      pl.name, pl.launches_per_block, pl.small ? "small" : a3[pl.algo < 0 || pl.algo > 4 ? 2 : pl.algo],
+        std::snprintf(tmp, sizeof tmp, "%s launches_per_block=%d c1x1=%d precision=fp32 conv3x3=%s conv1x1=%s c10_fused=%d chain=%d sf0=%d strict=%d tiles=%d chains=%d "
+                      "whole_chains=%d split_parts=%d part_frames=%d",
+                      pl.name, pl.launches_per_block, pl.c1x1_launches, pl.small ? "small" : a3[pl.algo < 0 || pl.algo > 4 ? 2 : pl.algo],
                       a1[pl.conv1x1_algo < 0 || pl.conv1x1_algo > 2 ? 0 : pl.conv1x1_algo], pl.c10_fused ? 1 : 0, pl.chain ? 1 : 0, pl.sf0 ? 1 : 0,
-                      pl.strict ? 1 : 0, pl.tiles8x32, pl.chains);
+                      pl.strict ? 1 : 0, pl.tiles8x32, pl.chains, pl.split_s ? pl.n_full : pl.chains, pl.split_s, pl.split_q);
     if (std::strlen(tmp) + 1 > buflen) return fail(PFNL_ERR_INVALID, "buffer too small");
     std::strcpy(buf, tmp);
     return 0;

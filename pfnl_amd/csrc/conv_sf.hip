@@ -477,17 +477,32 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
     const int T = p.add_div, gT = T + 1;                            // tiles of a chain: the shared half, then the T frames
     const int nchains = per_item * (p.items / T);
     const int xcd = blockIdx.x & 7, xj = blockIdx.x >> 3, cpx = gridDim.x >> 3;
-    const int per_xcd = (nchains + 7) >> 3;
+    // SPLIT CHAINS (round 6; p.split_s > 0; conv_split16.h): whole chains for the first p.n_full, one PART per workgroup of each chain behind
+    // them - the shared half (recomputed per part: one tile in 1 + frames) and the part's frames [sp_f0, sp_f1)
+    const int n_full = p.split_s > 0 ? p.n_full : nchains;
+    const int per_xcd = (n_full + 7) >> 3;
     const int cbeg = xcd * per_xcd;
-    const int ccnt = min(per_xcd, nchains - cbeg);
-    if (xj >= ccnt) return;
-    const int nt_tiles = ((ccnt - xj + cpx - 1) / cpx) * gT;
-    // tile k -> (f = position in the chain: 0 = shared half, clip, y0, x0)
+    const int ccnt = min(per_xcd, n_full - cbeg);
+    const int nfull_tiles = (xj < ccnt ? (ccnt - xj + cpx - 1) / cpx : 0) * gT;
+    const int slot = xcd * cpx + xj;
+    const bool has_part = p.split_s > 0 && slot < (nchains - n_full) * p.split_s;
+    const int sp_chain = has_part ? n_full + slot / p.split_s : 0;
+    const int sp_f0 = has_part ? (slot % p.split_s) * p.split_q : 0, sp_f1 = has_part ? min(T, sp_f0 + p.split_q) : 0;
+    const int nt_tiles = nfull_tiles + (has_part ? 1 + sp_f1 - sp_f0 : 0);
+    if (nt_tiles <= 0) return;
+    // tile k -> (f = position in the chain: 0 = shared half, 1 .. T = frame f - 1; clip, y0, x0)
 #define SFC_TILE(k_, f_, clip_, y0_, x0_)                                                        \
     do {                                                                                         \
-        const int ci_ = (k_) / gT;                                                               \
-        f_ = (k_) - ci_ * gT;                                                                    \
-        const int ch_ = cbeg + xj + ci_ * cpx;                                                   \
+        int ch_;                                                                                 \
+        if ((k_) < nfull_tiles) {                                                                \
+            const int ci_ = (k_) / gT;                                                           \
+            f_ = (k_) - ci_ * gT;                                                                \
+            ch_ = cbeg + xj + ci_ * cpx;                                                         \
+        } else {                                                                                 \
+            const int kk_ = (k_) - nfull_tiles;                                                  \
+            f_ = kk_ == 0 ? 0 : sp_f0 + kk_;                                                     \
+            ch_ = sp_chain;                                                                      \
+        }                                                                                        \
         clip_ = ch_ / per_item;                                                                  \
         const int sp_ = ch_ - clip_ * per_item;                                                  \
         const int ty_ = sp_ / tiles_x;                                                           \
@@ -849,7 +864,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
                 // (+ bias) as the initial C of the frames that follow, and is cleared behind the chain's last frame (the next
                 // tile is a shared half again: initial C = 0).  Branch-free (selects on wave-uniform conditions): arms that
                 // define 32-register vectors cost the allocator live copies of both.
-                const bool head = c_f == 0, last = c_f == T;
+                const bool head = c_f == 0, last = c_f == (kt >= nfull_tiles ? sp_f1 : T);   // (the last frame of a whole chain / of this workgroup's part)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     const f32x16 fold = accm[n] + accc[n] * SF_ISCALE;
@@ -905,6 +920,12 @@ hipError_t launch_conv3x3_sf_chain(const ConvSplitParams& p, hipStream_t s) {
     const int ncu = device_cu_count();
     if (!ncu) return hipErrorUnknown;
     const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;
+    if (p.split_s) {                                                       // (the geometry conv3x3_c1c10_kernel was launched with: conv_split16.hip checks it in full)
+        const long long nch = (long long)((p.W + SF_TW - 1) / SF_TW) * ((p.H + SF_TH - 1) / SF_TH) * (p.items / p.add_div);
+        if (p.split_s < 2 || p.split_q < 1 || p.n_full % grid || p.n_full >= nch || (nch - p.n_full) * p.split_s > grid ||
+            (long long)(p.split_s - 1) * p.split_q >= p.add_div || (long long)p.split_s * p.split_q < p.add_div)
+            return hipErrorInvalidValue;
+    }
     static std::atomic<int> attr_dev[64][2];
     const int sfcopy = p.out2 ? 1 : 0;                                     // out2: the split-format copy of the output (the next block's inp0)
     const void* fn = sfcopy ? reinterpret_cast<const void*>(conv3x3_sf_chain_kernel<true>) : reinterpret_cast<const void*>(conv3x3_sf_chain_kernel<false>);

@@ -28,6 +28,12 @@ struct ConvSplitParams {
     const uint16_t* wpack2;  // ... and the packed kernel rows that multiply it (identity rows); launch_conv3x3_c1c10: conv10_i (conv1x1_c10_pack_weights)
     const float* bias2;      // launch_conv3x3_c1c10 only: conv10_i's bias [64]
     float* out2;             // ... and its output `base` [items/add_div][H][W] in the split format
+    // SPLIT CHAINS (launch_conv3x3_c1c10, launch_conv3x3_sf_chain; split_s = 0: off): the first n_full (clip, tile) chains - a whole number of
+    // rounds of the grid - are dealt out whole; each chain behind them is cut by frames into split_s parts of <= split_q frames, one part per
+    // workgroup.  c1c10: a part leaves its share of conv10_i's sum as raw fp32 in partial[slot] ([8][32][64] floats per slot, slot = split
+    // chain * split_s + part; part 0 includes the bias) and launch_c10_finalize builds `base`; the chain kernel recomputes the shared half per part
+    int n_full, split_s, split_q;
+    float* partial;
     int in_sf;               // launch_conv3x3_c1c10 only: 1 = `in` is the split-format copy of inp0 (launch_conv3x3_sf_chain's out2): halo by LDS-DMA
     int flat;                // launch_conv3x3_sf with an addend only: 1 = deal the tiles out one by one instead of as chains of the add_div frames
                              // of a (clip, tile) - for launches with fewer chains than workgroups (capi.hip, "MID shapes").  The two input-channel
@@ -48,6 +54,11 @@ void conv3x3_split16_pack_weights(const float* hwio, int cin_total, int cin_begi
 // conv1_i + conv10_i of a progressive-fusion block in one launch (reference model/pfnl.py:66-68): in fp32 [clips*T][H][W][64], add_div = T;
 // out = inp1 and out2 = base, both in the split format; act applies to both convolutions
 hipError_t launch_conv3x3_c1c10(const ConvSplitParams& p, hipStream_t s);
+// split chains: base[clip][tile of chain n_full + j] = split format of act(sum over the parts r of partial[j * split_s + r]), j < nchains - n_full
+// (p: H, W, items = clips * T, add_div = T, act, n_full, split_s, partial, out2 = base)
+hipError_t launch_c10_finalize(const ConvSplitParams& p, hipStream_t s);
+// the grid the persistent split-f16 launches use on the current device (whole XCDs): what n_full must be a multiple of
+int conv_split16_grid();
 size_t conv1x1_c10_pack_halfs(int T);
 void conv1x1_c10_pack_weights(const float* hwio, int T, uint16_t* dst);
 

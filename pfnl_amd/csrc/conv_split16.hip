@@ -792,18 +792,37 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
     const int gT = p.add_div;                                       // frames per clip = tiles per chain
     const int nchains = per_item * (p.items / gT);
     const int xcd = blockIdx.x & 7, xj = blockIdx.x >> 3, cpx = gridDim.x >> 3;
-    const int per_xcd = (nchains + 7) >> 3;
+    // SPLIT CHAINS (round 6; p.split_s > 0): the first p.n_full chains - a whole number of rounds of the grid - are dealt out as whole
+    // chains, as ever; every chain behind them is cut by FRAMES into p.split_s parts of <= p.split_q frames, one part per workgroup (slot
+    // = xcd * cpx + xj -> chain n_full + slot / s, part slot % s).  A launch of 1.25 rounds of chains then takes 1 chain + 2 tiles
+    // instead of 2 chains.  A part cannot finish conv10_i - it only sees its own frames: it leaves its partial sum (part 0 starts from
+    // the bias, the others from 0) as raw fp32 in p.partial[slot], and c10_finalize_kernel adds the parts up in fixed order.
+    const int n_full = p.split_s > 0 ? p.n_full : nchains;
+    const int per_xcd = (n_full + 7) >> 3;
     const int cbeg = xcd * per_xcd;
-    const int ccnt = min(per_xcd, nchains - cbeg);
-    if (xj >= ccnt) return;
-    const int nt = ((ccnt - xj + cpx - 1) / cpx) * gT;              // tiles of this workgroup
-#define K1_TILE(k_, item_, y0_, x0_)                                                             \
+    const int ccnt = min(per_xcd, n_full - cbeg);
+    const int nfull_tiles = (xj < ccnt ? (ccnt - xj + cpx - 1) / cpx : 0) * gT;   // tiles of this workgroup's whole chains
+    const int slot = xcd * cpx + xj;
+    const bool has_part = p.split_s > 0 && slot < (nchains - n_full) * p.split_s;
+    const int sp_chain = has_part ? n_full + slot / p.split_s : 0;
+    const int sp_r = has_part ? slot % p.split_s : 0;
+    const int sp_f0 = sp_r * p.split_q, sp_f1 = has_part ? min(gT, sp_f0 + p.split_q) : 0;   // frames [sp_f0, sp_f1) of chain sp_chain
+    const int nt = nfull_tiles + (sp_f1 - sp_f0);                   // tiles of this workgroup
+    if (nt <= 0) return;
+#define K1_TILE(k_, item_, y0_, x0_, fr_)                                                        \
     do {                                                                                         \
-        const int ci_ = (k_) / gT, f_ = (k_) - ci_ * gT;                                         \
-        const int ch_ = cbeg + xj + ci_ * cpx;                                                   \
+        int ch_;                                                                                 \
+        if ((k_) < nfull_tiles) {                                                                \
+            const int ci_ = (k_) / gT;                                                           \
+            fr_ = (k_) - ci_ * gT;                                                               \
+            ch_ = cbeg + xj + ci_ * cpx;                                                         \
+        } else {                                                                                 \
+            fr_ = sp_f0 + ((k_) - nfull_tiles);                                                  \
+            ch_ = sp_chain;                                                                      \
+        }                                                                                        \
         const int cl_ = ch_ / per_item;                                                          \
         const int sp_ = ch_ - cl_ * per_item;                                                    \
-        item_ = cl_ * gT + f_;                                                                   \
+        item_ = cl_ * gT + fr_;                                                                  \
         const int ty_ = sp_ / tiles_x;                                                           \
         y0_ = ty_ * CS_TH;                                                                       \
         x0_ = (sp_ - ty_ * tiles_x) * CS_TW;                                                     \
@@ -998,19 +1017,20 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
         const int off = (gy * W + gx) * 256 + c * 16;
         buffer_store_b128_guarded<K1_STORE_AUX>(held[j], rsO, (hpend & (gx < W)) ? off : 0x7fffffff, 0);
     };
-    auto base_init = [&]() __attribute__((always_inline)) {         // conv10_i's bias: the initial value of a chain's sum
+    auto base_init = [&](bool zero) __attribute__((always_inline)) {   // conv10_i's bias: the initial value of a chain's sum (parts > 0 of a split chain: 0)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) base_m[n][r] = bl2[ech + r];
+            for (int r = 0; r < 16; ++r) base_m[n][r] = zero ? 0.f : bl2[ech + r];
     };
 
     // ---- prologue: halo of unit 0 -> buffer 0; weights of half 0, both biases -> LDS ----------------------------------------
-    int c_item, c_y0, c_x0, n_item, n_y0, n_x0;
-    K1_TILE(0, c_item, c_y0, c_x0);
+    int c_item, c_y0, c_x0, n_item, n_y0, n_x0, fch, n_f;           // fch / n_f: frame of its chain the current / the next tile is
+    K1_TILE(0, c_item, c_y0, c_x0, fch);
     n_item = c_item;
     n_y0 = c_y0;
     n_x0 = c_x0;
+    n_f = fch;
     {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(p.in) + (size_t)c_item * H * W * 64, 0, item_bytes, 0x00020000);
@@ -1034,9 +1054,8 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
         }
     }
     __syncthreads();
-    base_init();
+    base_init(nfull_tiles == 0 && sp_r > 0);
 
-    int fch = 0;                                                    // frame of the chain the current tile is
     for (int kt = 0; kt < nt; ++kt) {
         const int half_a = kt & 1;
         auto unit = [&](auto par) __attribute__((always_inline)) {
@@ -1109,7 +1128,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
                     }
                     if constexpr (g == 3 && PAR == 0) {
                         const int kn = min(kt + 1, nt - 1);         // decode the next tile (past the end: this one again - a harmless re-read)
-                        K1_TILE(kn, n_item, n_y0, n_x0);
+                        K1_TILE(kn, n_item, n_y0, n_x0, n_f);
                     }
                     if constexpr (g == 4) {
                         K1_BARRIER();                               // b1: column tap 1 consumed
@@ -1252,8 +1271,20 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
                 hy0 = c_y0;
                 hitem = c_item;
                 hpend = true;
-                const bool last = fch + 1 == gT;                    // (wave-uniform)
-                if (last) {                                         // the chain's sum -> `base` (out2), and back to its initial value
+                const bool is_part = kt >= nfull_tiles;             // (wave-uniform) a tile of this workgroup's part of a split chain
+                const bool last = fch + 1 == (is_part ? sp_f1 : gT);
+                if (last && is_part) {                              // a PART's sum leaves as raw fp32 (no activation: c10_finalize_kernel adds the parts up)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) held_store(j, p.out);
+                    float* const pt = p.partial + (size_t)slot * (CS_TH * CS_TW * 64) + (size_t)(2 * rp * CS_TW + (lane & 31)) * 64 + ech;
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *reinterpret_cast<f32x4*>(pt + n * (CS_TW * 64) + 4 * q) =
+                                f32x4{base_m[n][4 * q], base_m[n][4 * q + 1], base_m[n][4 * q + 2], base_m[n][4 * q + 3]};
+                    hpend = false;                                  // (the part is this workgroup's last item)
+                } else if (last) {                                  // the chain's sum -> `base` (out2), and back to its initial value
                     // (once per chain: stored at once; the frame tile's own lines leave first - `held` is reused)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) held_store(j, p.out);
@@ -1275,9 +1306,9 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
 #pragma unroll
                     for (int j = 0; j < 8; ++j) held_store(j, p.out2);
                     hpend = false;
-                    base_init();
+                    base_init(kt + 1 == nfull_tiles && sp_r > 0);   // (the next item is a part > 0 of a split chain: it starts from 0)
                 }
-                fch = last ? 0 : fch + 1;
+                fch = n_f;
                 c_item = n_item;
                 c_y0 = n_y0;
                 c_x0 = n_x0;
@@ -1300,6 +1331,70 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
 #undef K1_DMA_W
 }
 
+int conv_split16_grid() {
+    const int ncu = device_cu_count();
+    return ncu >= 8 ? ncu / 8 * 8 : 8;                              // whole XCDs; surplus workgroups exit at once
+}
+
+// the geometry of a split-chain launch must be the one the kernels assume: whole rounds of the grid in front, one part per workgroup behind
+static bool split_params_ok(const ConvSplitParams& p, int grid) {
+    if (p.split_s == 0) return true;
+    const int T = p.add_div;
+    const long long nchains = (long long)((p.W + CS_TW - 1) / CS_TW) * ((p.H + CS_TH - 1) / CS_TH) * (p.items / T);
+    if (p.split_s < 2 || p.split_q < 1 || p.n_full < 0 || p.n_full % grid || p.n_full >= nchains) return false;
+    if ((long long)p.split_s * p.split_q < T || (long long)(p.split_s - 1) * p.split_q >= T) return false;   // every part non-empty, together the T frames
+    return (nchains - p.n_full) * p.split_s <= grid;
+}
+
+// ---- split chains: the parts' raw conv10_i sums -> `base` in the split format (see conv3x3_c1c10_kernel).  One workgroup per split chain;
+// thread = (pixel, 4-channel group) of its 8 x 32 tile, the parts added in the fixed order r = 0 .. s-1 (part 0 carries the bias).
+__global__ __launch_bounds__(256) void c10_finalize_kernel(ConvSplitParams p) {
+    const int H = p.H, W = p.W;
+    const int tiles_x = (W + CS_TW - 1) / CS_TW, tiles_y = (H + CS_TH - 1) / CS_TH;
+    const int per_item = tiles_x * tiles_y;
+    const int j = blockIdx.x >> 3, ch = p.n_full + j;                // 8 workgroups per split chain: one tile row (32 pixels x 16 groups = 512 ids) each
+    const int clip = ch / per_item, sp = ch - clip * per_item;
+    const int ty = sp / tiles_x, y0 = ty * CS_TH, x0 = (sp - ty * tiles_x) * CS_TW;
+    const float slope = p.act ? 0.2f : 1.0f;
+    const int S = p.split_s;                                        // 2 .. 7
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int id = (blockIdx.x & 7) * 512 + it * 256 + threadIdx.x;
+        const int pix = id >> 4, c4 = id & 15;
+        const int y = y0 + pix / CS_TW, x = x0 + (pix & (CS_TW - 1));
+        const float* src = p.partial + ((size_t)j * S * (CS_TH * CS_TW) + pix) * 64 + c4 * 4;
+        f32x4 part[7];                                              // every part's piece requested before any is used (a loop of dependent
+#pragma unroll                                                      // loads made this 16 KB-per-workgroup kernel 17 us long)
+        for (int r = 0; r < 7; ++r) part[r] = r < S ? *reinterpret_cast<const f32x4*>(src + (size_t)r * (CS_TH * CS_TW * 64)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 v = part[0];
+#pragma unroll
+        for (int r = 1; r < 7; ++r)
+            if (r < S) v += part[r];                                // fixed order r = 0 .. S-1 (wave-uniform S: no divergence)
+        v.x = fmaxf(v.x, slope * v.x);
+        v.y = fmaxf(v.y, slope * v.y);
+        v.z = fmaxf(v.z, slope * v.z);
+        v.w = fmaxf(v.w, slope * v.w);
+        const h4 hi = __builtin_convertvector(v, h4);
+        const h4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * CS_SCALE, h4);   // exact before the one rounding: = split4
+        if (y < H && x < W) {
+            // split format: pixel 256 B = [channel half M][hi 32 | lo' 32] binary16; channels 4 c4 .. + 3 -> half c4 >> 3, position (c4 & 7) * 4
+            unsigned char* dst = reinterpret_cast<unsigned char*>(p.out2) + (((size_t)clip * H + y) * W + x) * 256 + (c4 >> 3) * 128 + (c4 & 7) * 8;
+            *reinterpret_cast<h4*>(dst) = hi;
+            *reinterpret_cast<h4*>(dst + 64) = lo;
+        }
+    }
+}
+
+hipError_t launch_c10_finalize(const ConvSplitParams& p, hipStream_t s) {
+    if (!p.partial || !p.out2 || p.items < 1 || p.H < 1 || p.W < 1 || p.add_div < 1 || p.items % p.add_div) return hipErrorInvalidValue;
+    const int grid = conv_split16_grid();
+    if (p.split_s < 2 || !split_params_ok(p, grid)) return hipErrorInvalidValue;
+    const long long nchains = (long long)((p.W + CS_TW - 1) / CS_TW) * ((p.H + CS_TH - 1) / CS_TH) * (p.items / p.add_div);
+    if (p.split_s > 7) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(c10_finalize_kernel, dim3((unsigned)(nchains - p.n_full) * 8), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv3x3_c1c10(const ConvSplitParams& p, hipStream_t s) {
     if (!p.in || !p.wpack || !p.bias || !p.wpack2 || !p.bias2 || !p.out || !p.out2 || p.items < 1 || p.H < 1 || p.W < 1) return hipErrorInvalidValue;
     if (p.add_div < 1 || p.add_div > 7 || p.items % p.add_div || p.addend || p.resid || p.accum) return hipErrorInvalidValue;
@@ -1309,6 +1404,7 @@ hipError_t launch_conv3x3_c1c10(const ConvSplitParams& p, hipStream_t s) {
     const int ncu = device_cu_count();
     if (!ncu) return hipErrorUnknown;
     const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;
+    if (!split_params_ok(p, grid) || (p.split_s && !p.partial)) return hipErrorInvalidValue;
     static std::atomic<int> attr_dev[64][2];
     const int isf = p.in_sf ? 1 : 0;                                // `in` is the split-format copy of inp0 (conv3x3_sf_chain_kernel<true>)
     const void* fn = isf ? reinterpret_cast<const void*>(conv3x3_c1c10_kernel<true>) : reinterpret_cast<const void*>(conv3x3_c1c10_kernel<false>);

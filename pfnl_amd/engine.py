@@ -117,7 +117,7 @@ class PFNLEngine:
         self._ready = True
 
     OPTION_KEYS = ("precision", "strict_fp32", "conv3x3", "conv1x1", "conv2", "merge1", "nonlocal", "nl_type", "nl_sub_sample", "small", "small_c10",
-                   "split16_sf", "split16_chain", "split16_c10", "split16_mid", "split16_sf0", "bf16_conv10", "graph")
+                   "split16_sf", "split16_chain", "split16_c10", "split16_mid", "split16_sf0", "split16_splitchains", "bf16_conv10", "graph")
 
     def clone(self) -> "PFNLEngine":
         """A second handle on the same device with the same weights (device-to-device copy of the packed blobs: pfnl_copy_weights) and the
@@ -255,8 +255,8 @@ class PFNLEngine:
     def plan(self, B: int, H: int, W: int) -> Dict[str, object]:
         """The launch plan of the progressive-fusion trunk for this shape under the current options (pfnl_plan: the one statement of the
         dispatch rule).  {"structure": "chain2_sf0", "launches_per_block": 2, "conv3x3": "split16", "sf0": 1, ...}."""
-        buf = C.create_string_buffer(256)
-        _capi.check(self._lib.pfnl_plan(self._h, B, H, W, buf, 256))
+        buf = C.create_string_buffer(512)
+        _capi.check(self._lib.pfnl_plan(self._h, B, H, W, buf, 512))
         toks = buf.value.decode().split()
         d: Dict[str, object] = {"structure": toks[0]}
         for t in toks[1:]:

@@ -639,6 +639,48 @@ def test_forward_repeats_bit_for_bit(label, gk, opts, B, H, W):
     eng.close()
 
 
+@pytest.mark.parametrize("T,scale,nb,H,W,Bs", [(7, 4, 2, 128, 128, (4, 5, 6, 7, 9)), (7, 4, 2, 100, 130, (5, 9)), (5, 2, 2, 96, 128, (7,)), (3, 4, 2, 90, 98, (11,)),
+                                                (7, 4, 20, 128, 128, (5,))])
+def test_forward_split_chains(T, scale, nb, H, W, Bs):
+    """Round 6 (reference model/pfnl.py:44, 55: forward takes any batch): the two-launch block deals out whole (clip,
+    tile) chains, so a batch that is not a whole number of rounds of the 256 workgroups paid a full extra chain (5 clips of 128x128: 7.2 ms
+    against 4.5 for 4).  Option split16_splitchains (auto): the chains of the last, partial round are cut by frames into parts, conv10_i's
+    partial sums meet in c10_finalize_kernel, the chain kernel recomputes the shared half per part.  Every batch size: against the oracle,
+    repeatable bit for bit, within summation-order noise of the uncut launch; whole rounds (B = 4) are untouched (same plan, same bits)."""
+    geom = PFNLGeometry(num_frames=T, scale=scale, num_block=nb)
+    w = synth.synthetic_weights(geom, seed=T)
+    eng = _engine_with(geom, w)
+    assert eng.get_option("split16_splitchains") == "auto"
+    fo = pfnl_fast.FastOracle(w, T, scale, nb) if nb <= 3 else None
+    chains_clip = ((W + 31) // 32) * ((H + 7) // 8)
+    for B in Bs:
+        x = synth.uniform_clips(B, T, H, W, seed=100 + H)         # (the first clips of every batch are the same clips)
+        pl = eng.plan(B, H, W)
+        R = (B * chains_clip) % 256
+        cut = B * chains_clip > 256 and 0 < R <= 128 and min(T, 256 // R) >= 2
+        assert pl["structure"] == ("chain2_split" if cut else "chain2"), (B, pl)
+        if cut:
+            assert pl["whole_chains"] == B * chains_clip - R and pl["split_parts"] * pl["part_frames"] >= T > (pl["split_parts"] - 1) * pl["part_frames"]
+            assert (B * chains_clip - pl["whole_chains"]) * pl["split_parts"] <= 256 and pl["launches_per_block"] == 3 and pl["c1x1"] == 1
+        y = eng.forward(x)
+        assert np.array_equal(y, eng.forward(x)), B                # deterministic: fixed summation order of the parts
+        eng.set_option("split16_splitchains", "off")
+        assert eng.plan(B, H, W)["structure"] == "chain2"
+        y_off = eng.forward(x)
+        eng.set_option("split16_splitchains", "auto")
+        if cut:
+            # (the uncut launch deals its chains out differently - 40 instead of 32 per XCD at B = 5 -, so a chain's position in its workgroup's
+            # sequence, hence the order of its channel halves, differs: summation-order noise on every clip)
+            assert np.abs(y - y_off).max() < 2e-5, (B, np.abs(y - y_off).max())
+        else:
+            assert np.array_equal(y.view(np.uint32), y_off.view(np.uint32)), B
+        if fo is not None:
+            ref = fo.forward(x)
+            assert np.abs(y - ref).max() < ABS_TOL, (B, np.abs(y - ref).max())
+    eng.close()                                                    # (a clip's bits inside a larger batch differ from the smaller batch's anyway: the
+                                                                   # non-local block's key split - its summation order - depends on the batch size)
+
+
 def test_plan_is_what_runs():
     """pfnl_plan is the ONE statement of the trunk's dispatch rule (capi.hip trunk_plan; reference model/pfnl.py:65-71): for every structure
     the launches the profiler counts per block equal the plan's, in both precisions and under the options that change it; the thresholds
