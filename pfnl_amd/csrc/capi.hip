@@ -523,9 +523,18 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
     // own result (nltype 2 divides 0 by 0 for a query without a positive affinity, utils.py:59-62).
     const int nlt_fence = h->nl_type < 0 ? (h->nl_theta ? 0 : 1) : h->nl_type;
     unsigned* const rflag = (nl_strict || nlt_fence == 2) ? nullptr : h->rflag_dev + flag_slot;
+    // the non-local block on the f16 matrix pipe (PFNL's own call: nltype 1, no sub-sampling; fp32 precision from 1024 keys, bf16 always)
+    const int nlt_plan = h->nl_type < 0 ? (h->nl_theta ? 0 : 1) : h->nl_type;
+    const bool nl_f16 = nlt_plan == 1 && h->nl_sub <= 1 && (h->bf16 || (!nl_strict && (h->nl_algo == 1 || (h->nl_algo == 2 && N >= 1024))));
+    const bool nl_fused_pack = nl_f16 && nl_f16_fits_one_launch(B, N);   // one pack launch: x -> X fp32 + the binary16 K / V^T operands (round 6)
     {   // model/pfnl.py:55-60 (+ utils.py:18-71)
         ProfScope ps(h, s, PFNL_K_NL_PACK);
-        HIPCHK(launch_nl_pack(in, h->X.p, B, T, Hfull, W, s));
+        if (nl_fused_pack) {
+            if (h->nl16.ensure((nl_f16_scratch_halfs(B, N) + 1) / 2)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
+            HIPCHK(launch_nl_pack_fused(in, h->X.p, reinterpret_cast<uint16_t*>(h->nl16.p), B, T, Hfull, W, s));
+        } else {
+            HIPCHK(launch_nl_pack(in, h->X.p, B, T, Hfull, W, s));
+        }
     }
     {
         ProfScope ps(h, s, PFNL_K_NL_ATTN);
@@ -555,11 +564,11 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
         } else if (!h->bf16 && !nl_strict && (h->nl_algo == 1 || (h->nl_algo == 2 && N >= 1024))) {   // fp32 path on the f16 pipe, exactly split operands
             if (h->nl16.ensure((nl_f16_scratch_halfs(B, N) + 1) / 2)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
             HIPCHK(launch_nl_attn_f16(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p,
-                                      reinterpret_cast<uint16_t*>(h->nl16.p), B, N, C, s, q0, q1));
+                                      reinterpret_cast<uint16_t*>(h->nl16.p), B, N, C, s, q0, q1, true, nl_fused_pack));
         } else if (h->bf16) {   // 16-bit operands throughout: the f16 kernel on the hi parts only
             if (h->nl16.ensure((nl_f16_scratch_halfs(B, N) + 1) / 2)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
             HIPCHK(launch_nl_attn_f16(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p,
-                                      reinterpret_cast<uint16_t*>(h->nl16.p), B, N, C, s, q0, q1, false));
+                                      reinterpret_cast<uint16_t*>(h->nl16.p), B, N, C, s, q0, q1, false, nl_fused_pack));
         } else {
             HIPCHK(launch_nl_attn(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p, B, N, C, s, nullptr, q0, q1));
         }

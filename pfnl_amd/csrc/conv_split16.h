@@ -76,6 +76,11 @@ hipError_t launch_sf_to_f32(const uint16_t* in, float* out, size_t npix, hipStre
 // (common.h) plus the operand scratch; split = false: the hi parts only (the non-local block of precision=bf16)
 size_t nl_f16_scratch_halfs(int B, int N);
 hipError_t launch_nl_attn_f16(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, uint16_t* scratch16,
-                              int B, int N, int C, hipStream_t s, int q0 = 0, int q1 = -1, bool split = true);
+                              int B, int N, int C, hipStream_t s, int q0 = 0, int q1 = -1, bool split = true,
+                              bool prepacked = false);   // prepacked: launch_nl_pack_fused has filled X and scratch16 (no pack launch here)
+// round 6: nl_pack_kernel's and nl_pack_f16_kernel's jobs in ONE launch: x [B][T][H][W][3] -> X [B][N][CP] fp32 + the binary16 operand arrays
+// (for batches whose packed operands fit one launch: nl_f16_fits_one_launch; larger ones keep launch_nl_pack + the chunked launch_nl_attn_f16)
+bool nl_f16_fits_one_launch(int B, int N);
+hipError_t launch_nl_pack_fused(const float* x, float* X, uint16_t* scratch16, int B, int T, int H, int W, hipStream_t s);
 
 }  // namespace pfnl

@@ -411,21 +411,75 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ mer
     // every value of the result passes through.  One compare per value on a bandwidth-bound kernel; an atomic only when it fires.
     bool bad = false;
     if (CO == 12) {
+        // The thread's 2 x 2 HR pixels (rows 2 Yf + i, columns 2 X + j) lie in ONE LR cell: floor((2 Yf + i) / 4) = Yf >> 1 and floor((2 X + j) / 4)
+        // = X >> 1 for i, j in {0, 1} - they share the 4 x 4 window of clamped taps and differ only in the phase of the weights (2 (Yf & 1) + i,
+        // 2 (X & 1) + j quarters).  The window is loaded ONCE (48 values, not 4 x 48) and the sums keep bicubic_px's order - over the columns with
+        // wx, then over the rows with wy, both from 0 with fmaf: the same bits as the pixel-by-pixel form (round 6: 26 -> us at configs[1]).
+        const int Yf = Y + 2 * yoff;                                // frame coordinates of the thread's row of the 2H x 2W grid
+        const int iy = Yf >> 1, ix = X >> 1;
+        float wy[2][4], wx[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            cubic_taps((float)(2 * (Yf & 1) + i) / 4.0f, wy[i]);
+            cubic_taps((float)(2 * (X & 1) + i) / 4.0f, wx[i]);
+        }
+        float res[2][2][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int oy = 2 * (Y + 2 * yoff) + i, ox = 2 * X + j;          // frame coordinates
-                float bic[3];
-                bicubic_px(xc, H, W, (size_t)W * 3, SCALE, oy, ox, bic);
-                float* dst = ob + ((size_t)oy * OW + ox) * 3;
+            for (int j = 0; j < 2; ++j) res[i][j][0] = res[i][j][1] = res[i][j][2] = 0.f;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float v = acc[(2 * i + j) * 3 + c] + bic[c];
-                    bad |= !(fabsf(v) <= 3.4028234e38f);
-                    dst[c] = v;
+        for (int a = 0; a < 4; ++a) {
+            const int yy = min(max(iy - 1 + a, 0), H - 1);
+            float px[4][3];
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const int xx = min(max(ix - 1 + bb, 0), W - 1);
+                const float* p = xc + ((size_t)yy * W + xx) * 3;
+                px[bb][0] = p[0];
+                px[bb][1] = p[1];
+                px[bb][2] = p[2];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float row[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    row[0] = fmaf(wx[j][bb], px[bb][0], row[0]);
+                    row[1] = fmaf(wx[j][bb], px[bb][1], row[1]);
+                    row[2] = fmaf(wx[j][bb], px[bb][2], row[2]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    res[i][j][0] = fmaf(wy[i][a], row[0], res[i][j][0]);
+                    res[i][j][1] = fmaf(wy[i][a], row[1], res[i][j][1]);
+                    res[i][j][2] = fmaf(wy[i][a], row[2], res[i][j][2]);
                 }
             }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int oy = 2 * Yf + i;
+            float v[6];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    v[3 * j + c] = acc[(2 * i + j) * 3 + c] + res[i][j][c];
+                    bad |= !(fabsf(v[3 * j + c]) <= 3.4028234e38f);
+                }
+            // the thread's two pixels of the row are 24 contiguous bytes, 8-byte aligned when `out` is (24 X from a row start): three 8-byte stores
+            float* dstf = ob + ((size_t)oy * OW + 2 * X) * 3;
+            if ((reinterpret_cast<uintptr_t>(out) & 7) == 0) {      // (uniform over the launch)
+                float2* dst = reinterpret_cast<float2*>(dstf);
+                dst[0] = make_float2(v[0], v[1]);
+                dst[1] = make_float2(v[2], v[3]);
+                dst[2] = make_float2(v[4], v[5]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) dstf[k] = v[k];
+            }
+        }
     } else {
         float bic[3];
         bicubic_px(xc, H, W, (size_t)W * 3, SCALE, Y + 2 * yoff, X, bic);

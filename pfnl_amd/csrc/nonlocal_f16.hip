@@ -61,19 +61,36 @@ __device__ __forceinline__ float bf16_float(unsigned short u) { return (float)__
 // 32-block, channel C = 1 (the row-sum channel), channels > C = 0.  One workgroup per 32-key block: rows of X in, rows of K out, the
 // transposed block through LDS so that V^T leaves as 64-byte row segments (round 4: the element-per-thread form wrote V^T as 2-byte
 // stores a row apart - 38 us at 1080p for 31 MB).
+// FROMX (round 6): the same launch ALSO does nl_pack_kernel's job - it reads the clip x [B][T][H][W][3] itself through the space_to_depth
+// index map (model/pfnl.py:55-57: channel (dy 2 + dx) 3T + 3t + c of grid cell n) and writes X [B][N][CPin] fp32 (pad columns 0) next to the
+// binary16 operands: one launch and one pass over the frames instead of two launches of ~10 us with X read back in between.
+template <bool FROMX>
 __global__ __launch_bounds__(256) void nl_pack_f16_kernel(const float* __restrict__ X, uint16_t* __restrict__ Khi, uint16_t* __restrict__ Klo,
                                                           uint16_t* __restrict__ Vthi, uint16_t* __restrict__ Vtlo, int B, int N, int Npad, int C,
-                                                          int CPin) {
+                                                          int CPin, const float* __restrict__ xraw, float* __restrict__ Xout, int H, int W) {
     __shared__ uint16_t vth[NF_CP][34], vtl[NF_CP][34];             // [channel][position in the block] (+2: odd word stride)
     const int nblk = Npad / 32;
     const int b = blockIdx.x / nblk, n0 = (blockIdx.x - b * nblk) * 32;
     const int tid = threadIdx.x;
+    [[maybe_unused]] const int C3 = C / 4, T = C / 12, W2 = W / 2;
 #pragma unroll
     for (int j = 0; j < 32 * NF_CP / 256; ++j) {
         const int i = tid + 256 * j;
         const int kk = i / NF_CP, c = i - kk * NF_CP;
         const int n = n0 + kk;
-        const float v = (n < N && c < C) ? X[((size_t)b * N + n) * CPin + c] * NF_XSCALE : 0.f;
+        float raw = 0.f;
+        if constexpr (FROMX) {
+            if (n < N && c < C) {
+                const int sub = c / C3, k = c - sub * C3;
+                const int t = k / 3, cc = k - 3 * t;
+                const int y = 2 * (n / W2) + (sub >> 1), xx = 2 * (n % W2) + (sub & 1);
+                raw = xraw[((((size_t)b * T + t) * H + y) * W + xx) * 3 + cc];
+            }
+            if (n < N && c < CPin) Xout[((size_t)b * N + n) * CPin + c] = raw;
+        } else {
+            raw = (n < N && c < C) ? X[((size_t)b * N + n) * CPin + c] : 0.f;
+        }
+        const float v = raw * NF_XSCALE;
         const unsigned short hi = bf16_bits(v);
         const unsigned short lo = bf16_bits(v - bf16_float(hi));
         // key rows up to Npad (>= the last tile's end).  Keys past N carry -65504 in the pad channel C: a query operand with a
@@ -589,11 +606,32 @@ static size_t nl_f16_chunk_limit() {                              // bytes of pa
 }
 
 static hipError_t nl_attn_f16_run(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, uint16_t* scratch16,
-                                  int B, int N, int C, hipStream_t s, int q0, int q1, bool split, int ks_cap);
+                                  int B, int N, int C, hipStream_t s, int q0, int q1, bool split, int ks_cap, bool prepacked = false);
+
+bool nl_f16_fits_one_launch(int B, int N) { return 2 * nl_f16_scratch_halfs(1, N) * (size_t)B <= nl_f16_chunk_limit(); }
+
+// x [B][T][H][W][3] -> X [B][N][CP] fp32 AND the binary16 operand arrays of nl_attn_f16_sw_kernel in scratch16, in ONE launch (the batch must
+// fit one launch: nl_f16_fits_one_launch); launch_nl_attn_f16(..., prepacked = true) then skips its own pack
+hipError_t launch_nl_pack_fused(const float* x, float* X, uint16_t* scratch16, int B, int T, int H, int W, hipStream_t s) {
+    const int C = 12 * T, N = (H / 2) * (W / 2);
+    if (!x || !X || !scratch16 || B < 1 || (C != 84 && C != 60 && C != 36) || (H & 1) || (W & 1) || !nl_f16_fits_one_launch(B, N)) return hipErrorInvalidValue;
+    const int CP = nl_padded_ch(C);
+    const int npad = (N + 31) / 32 * 32 + 64;
+    uint16_t* Khi = scratch16;
+    uint16_t* Klo = Khi + (size_t)B * npad * NF_CP;
+    uint16_t* Vthi = Klo + (size_t)B * npad * NF_CP;
+    uint16_t* Vtlo = Vthi + (size_t)B * NF_CP * npad;
+    hipLaunchKernelGGL(nl_pack_f16_kernel<true>, dim3(B * (npad / 32)), dim3(256), 0, s, nullptr, Khi, Klo, Vthi, Vtlo, B, N, npad, C, CP, x, X, H, W);
+    return hipGetLastError();
+}
 
 hipError_t launch_nl_attn_f16(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, uint16_t* scratch16,
-                               int B, int N, int C, hipStream_t s, int q0, int q1, bool split) {
+                               int B, int N, int C, hipStream_t s, int q0, int q1, bool split, bool prepacked) {
     if (B < 1 || N < 1) return hipErrorInvalidValue;
+    if (prepacked) {                                                  // launch_nl_pack_fused filled X and scratch16 for the whole batch
+        if (!nl_f16_fits_one_launch(B, N)) return hipErrorInvalidValue;
+        return nl_attn_f16_run(X, Xo, Wp, bp, partial, scratch16, B, N, C, s, q0, q1, split, nl_key_splits(B, N), true);
+    }
     // The kernel reaches its packed operands through one buffer resource with 32-bit offsets: a batch whose operands exceed the limit runs in
     // chunks of whole clips, one after the other on the stream, through the same scratch and partial buffers (sized for the whole batch; the
     // key split is capped by what the whole batch's partial buffer was sized for).  A single clip never reaches it (N < 2.1 M keys by the
@@ -611,7 +649,7 @@ hipError_t launch_nl_attn_f16(const float* X, float* Xo, const float* Wp, const 
 }
 
 static hipError_t nl_attn_f16_run(const float* X, float* Xo, const float* Wp, const float* bp, float* partial, uint16_t* scratch16,
-                                  int B, int N, int C, hipStream_t s, int q0, int q1, bool split, int ks_cap) {
+                                  int B, int N, int C, hipStream_t s, int q0, int q1, bool split, int ks_cap, bool prepacked) {
     if (C != 84 && C != 60 && C != 36) return hipErrorInvalidValue;
     if (q1 < 0) q1 = N;
     if (q0 < 0 || q0 >= q1 || q1 > N) return hipErrorInvalidValue;
@@ -621,8 +659,8 @@ static hipError_t nl_attn_f16_run(const float* X, float* Xo, const float* Wp, co
     uint16_t* Klo = Khi + (size_t)B * npad * NF_CP;
     uint16_t* Vthi = Klo + (size_t)B * npad * NF_CP;
     uint16_t* Vtlo = Vthi + (size_t)B * NF_CP * npad;
-    {
-        hipLaunchKernelGGL(nl_pack_f16_kernel, dim3(B * (npad / 32)), dim3(256), 0, s, X, Khi, Klo, Vthi, Vtlo, B, N, npad, C, CP);
+    if (!prepacked) {
+        hipLaunchKernelGGL(nl_pack_f16_kernel<false>, dim3(B * (npad / 32)), dim3(256), 0, s, X, Khi, Klo, Vthi, Vtlo, B, N, npad, C, CP, nullptr, nullptr, 0, 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

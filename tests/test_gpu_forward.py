@@ -12,7 +12,7 @@ torch = pytest.importorskip("torch")
 
 from conftest import geometry_of, load_golden  # noqa: E402
 from oracle import pfnl_fast, pfnl_spec  # noqa: E402
-from pfnl_amd import synth  # noqa: E402
+from pfnl_amd import ops, synth  # noqa: E402
 from pfnl_amd.engine import PFNLEngine  # noqa: E402
 from pfnl_amd.spec import PFNLGeometry  # noqa: E402
 
@@ -679,6 +679,28 @@ def test_forward_split_chains(T, scale, nb, H, W, Bs):
             assert np.abs(y - ref).max() < ABS_TOL, (B, np.abs(y - ref).max())
     eng.close()                                                    # (a clip's bits inside a larger batch differ from the smaller batch's anyway: the
                                                                    # non-local block's key split - its summation order - depends on the batch size)
+
+
+@pytest.mark.parametrize("T,scale,B,H,W,prec", [(7, 4, 2, 64, 64, "fp32"), (7, 4, 1, 66, 130, "fp32"), (5, 2, 3, 64, 64, "fp32"), (3, 4, 2, 40, 72, "bf16"),
+                                                 (7, 4, 1, 20, 36, "bf16")])
+def test_forward_fused_nl_pack_is_bit_identical(T, scale, B, H, W, prec):
+    """Round 6 (reference model/pfnl.py:55-57): the forward packs the non-local block's operands in ONE launch -
+    nl_pack_f16_kernel<true> reads the clip through the space_to_depth index map and writes X fp32 AND the binary16 K / V^T arrays - where
+    the op hook (and batches beyond one launch's addressing) run nl_pack_kernel and then nl_pack_f16_kernel<false>.  Same values in the same
+    places: the block's output inside the forward (tap nl_out) must equal the op hook's BIT FOR BIT, ragged key counts and T = 3 / 5 included."""
+    geom = PFNLGeometry(num_frames=T, scale=scale, num_block=1)
+    w = synth.synthetic_weights(geom, seed=3)
+    x = synth.uniform_clips(B, T, H, W, seed=H)
+    eng = _engine_with(geom, w)
+    eng.set_option("nonlocal", "split16")                            # (also below 1024 keys)
+    if prec == "bf16":
+        eng.set_option("precision", "bf16")
+    eng.forward(x)
+    got = eng.tap("nl_out", B, H, W)
+    names = ["nlvsr/nlblock_0/g/g/kernel", "nlvsr/nlblock_0/g/g/bias", "nlvsr/nlblock_0/w/w/kernel", "nlvsr/nlblock_0/w/w/bias"]
+    want = ops.nonlocal_residual(torch.from_numpy(x).cuda(), *[w[n] for n in names], precision="split16" if prec == "fp32" else "f16").cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+    eng.close()
 
 
 def test_plan_is_what_runs():
