@@ -453,7 +453,8 @@ __device__ long long sfc_dbg[256 * 2 * 160];
 // owns one channel (D[pixel][cout]) where an SF chunk is 8 channels of one pixel: neighbouring lanes swap one binary16 pair per pixel
 // (DPP quad_perm), the even lane then stores the hi halves of channels (c, c + 1), the odd lane their lo' halves - 32 lanes x 4 B = the
 // 128 bytes [hi 64 B | lo' 64 B] of a (pixel, channel half): the same line-per-instruction pattern as the fp32 stores.
-template <bool SFCOPY>
+// SPLIT: split chains (below) - a template parameter so that the whole-round launches keep their instruction stream (conv_split16.hip).
+template <bool SFCOPY, bool SPLIT>
 __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSplitParams p) {
 #ifdef PFNL_SFC_TIMING
     int dbg_n = 0;
@@ -479,22 +480,23 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
     const int xcd = blockIdx.x & 7, xj = blockIdx.x >> 3, cpx = gridDim.x >> 3;
     // SPLIT CHAINS (round 6; p.split_s > 0; conv_split16.h): whole chains for the first p.n_full, one PART per workgroup of each chain behind
     // them - the shared half (recomputed per part: one tile in 1 + frames) and the part's frames [sp_f0, sp_f1)
-    const int n_full = p.split_s > 0 ? p.n_full : nchains;
+    const int n_full = SPLIT ? p.n_full : nchains;
     const int per_xcd = (n_full + 7) >> 3;
     const int cbeg = xcd * per_xcd;
     const int ccnt = min(per_xcd, n_full - cbeg);
-    const int nfull_tiles = (xj < ccnt ? (ccnt - xj + cpx - 1) / cpx : 0) * gT;
-    const int slot = xcd * cpx + xj;
-    const bool has_part = p.split_s > 0 && slot < (nchains - n_full) * p.split_s;
+    if (!SPLIT && xj >= ccnt) return;
+    const int nfull_tiles = ((!SPLIT || xj < ccnt) ? (ccnt - xj + cpx - 1) / cpx : 0) * gT;
+    [[maybe_unused]] const int slot = xcd * cpx + xj;
+    const bool has_part = SPLIT && slot < (nchains - n_full) * p.split_s;
     const int sp_chain = has_part ? n_full + slot / p.split_s : 0;
     const int sp_f0 = has_part ? (slot % p.split_s) * p.split_q : 0, sp_f1 = has_part ? min(T, sp_f0 + p.split_q) : 0;
     const int nt_tiles = nfull_tiles + (has_part ? 1 + sp_f1 - sp_f0 : 0);
-    if (nt_tiles <= 0) return;
+    if (SPLIT && nt_tiles <= 0) return;
     // tile k -> (f = position in the chain: 0 = shared half, 1 .. T = frame f - 1; clip, y0, x0)
 #define SFC_TILE(k_, f_, clip_, y0_, x0_)                                                        \
     do {                                                                                         \
         int ch_;                                                                                 \
-        if ((k_) < nfull_tiles) {                                                                \
+        if (!SPLIT || (k_) < nfull_tiles) {                                                      \
             const int ci_ = (k_) / gT;                                                           \
             f_ = (k_) - ci_ * gT;                                                                \
             ch_ = cbeg + xj + ci_ * cpx;                                                         \
@@ -864,7 +866,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
                 // (+ bias) as the initial C of the frames that follow, and is cleared behind the chain's last frame (the next
                 // tile is a shared half again: initial C = 0).  Branch-free (selects on wave-uniform conditions): arms that
                 // define 32-register vectors cost the allocator live copies of both.
-                const bool head = c_f == 0, last = c_f == (kt >= nfull_tiles ? sp_f1 : T);   // (the last frame of a whole chain / of this workgroup's part)
+                const bool head = c_f == 0, last = c_f == ((SPLIT && kt >= nfull_tiles) ? sp_f1 : T);   // (the last frame of a whole chain / of this workgroup's part)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     const f32x16 fold = accm[n] + accc[n] * SF_ISCALE;
@@ -926,16 +928,21 @@ hipError_t launch_conv3x3_sf_chain(const ConvSplitParams& p, hipStream_t s) {
             (long long)(p.split_s - 1) * p.split_q >= p.add_div || (long long)p.split_s * p.split_q < p.add_div)
             return hipErrorInvalidValue;
     }
-    static std::atomic<int> attr_dev[64][2];
-    const int sfcopy = p.out2 ? 1 : 0;                                     // out2: the split-format copy of the output (the next block's inp0)
-    const void* fn = sfcopy ? reinterpret_cast<const void*>(conv3x3_sf_chain_kernel<true>) : reinterpret_cast<const void*>(conv3x3_sf_chain_kernel<false>);
-    if (!attr_dev[dev][sfcopy]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
+    static std::atomic<int> attr_dev[64][4];
+    const int var = (p.out2 ? 1 : 0) + (p.split_s ? 2 : 0);               // out2: the split-format copy of the output (the next block's inp0)
+    const void* const fns[4] = {reinterpret_cast<const void*>(conv3x3_sf_chain_kernel<false, false>), reinterpret_cast<const void*>(conv3x3_sf_chain_kernel<true, false>),
+                                reinterpret_cast<const void*>(conv3x3_sf_chain_kernel<false, true>), reinterpret_cast<const void*>(conv3x3_sf_chain_kernel<true, true>)};
+    if (!attr_dev[dev][var]) {
+        hipError_t e = hipFuncSetAttribute(fns[var], hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_dev[dev][sfcopy] = 1;
+        attr_dev[dev][var] = 1;
     }
-    if (sfcopy) hipLaunchKernelGGL(conv3x3_sf_chain_kernel<true>, dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, p);
-    else hipLaunchKernelGGL(conv3x3_sf_chain_kernel<false>, dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, p);
+    switch (var) {
+        case 0: hipLaunchKernelGGL((conv3x3_sf_chain_kernel<false, false>), dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, p); break;
+        case 1: hipLaunchKernelGGL((conv3x3_sf_chain_kernel<true, false>), dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, p); break;
+        case 2: hipLaunchKernelGGL((conv3x3_sf_chain_kernel<false, true>), dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, p); break;
+        default: hipLaunchKernelGGL((conv3x3_sf_chain_kernel<true, true>), dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, p); break;
+    }
     return hipGetLastError();
 }
 

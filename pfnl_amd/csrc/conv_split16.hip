@@ -767,7 +767,9 @@ constexpr int K1_SF_TILE_BYTES = K1_DMA_NDMA * 1024;                // 44 032: t
 constexpr int K1_SF_LDS_BYTES = 2 * K1_SF_TILE_BYTES + CS_W_BYTES + 2 * 64 * 4;   // 162 304 of 163 840
 static_assert(K1_SF_LDS_BYTES <= 160 * 1024, "LDS budget");
 
-template <bool ISF>
+// SPLIT: the launch cuts the chains of its last, partial round by frames (p.split_s > 0; below).  A template parameter, not a run-time
+// test: with the part bookkeeping compiled in, the whole-round launches (configs[1]) ran 1.3 us per launch slower on the same box.
+template <bool ISF, bool SPLIT>
 __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitParams p) {
     constexpr int TILE_BYTES = ISF ? K1_SF_TILE_BYTES : CS_TILE_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_smem[];
@@ -797,22 +799,23 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
     // = xcd * cpx + xj -> chain n_full + slot / s, part slot % s).  A launch of 1.25 rounds of chains then takes 1 chain + 2 tiles
     // instead of 2 chains.  A part cannot finish conv10_i - it only sees its own frames: it leaves its partial sum (part 0 starts from
     // the bias, the others from 0) as raw fp32 in p.partial[slot], and c10_finalize_kernel adds the parts up in fixed order.
-    const int n_full = p.split_s > 0 ? p.n_full : nchains;
+    const int n_full = SPLIT ? p.n_full : nchains;
     const int per_xcd = (n_full + 7) >> 3;
     const int cbeg = xcd * per_xcd;
     const int ccnt = min(per_xcd, n_full - cbeg);
-    const int nfull_tiles = (xj < ccnt ? (ccnt - xj + cpx - 1) / cpx : 0) * gT;   // tiles of this workgroup's whole chains
-    const int slot = xcd * cpx + xj;
-    const bool has_part = p.split_s > 0 && slot < (nchains - n_full) * p.split_s;
+    if (!SPLIT && xj >= ccnt) return;
+    const int nfull_tiles = ((!SPLIT || xj < ccnt) ? (ccnt - xj + cpx - 1) / cpx : 0) * gT;   // tiles of this workgroup's whole chains
+    [[maybe_unused]] const int slot = xcd * cpx + xj;
+    const bool has_part = SPLIT && slot < (nchains - n_full) * p.split_s;
     const int sp_chain = has_part ? n_full + slot / p.split_s : 0;
     const int sp_r = has_part ? slot % p.split_s : 0;
-    const int sp_f0 = sp_r * p.split_q, sp_f1 = has_part ? min(gT, sp_f0 + p.split_q) : 0;   // frames [sp_f0, sp_f1) of chain sp_chain
-    const int nt = nfull_tiles + (sp_f1 - sp_f0);                   // tiles of this workgroup
-    if (nt <= 0) return;
+    const int sp_f0 = has_part ? sp_r * p.split_q : 0, sp_f1 = has_part ? min(gT, sp_f0 + p.split_q) : 0;   // frames [sp_f0, sp_f1) of chain sp_chain
+    const int nt = SPLIT ? nfull_tiles + (sp_f1 - sp_f0) : nfull_tiles;   // tiles of this workgroup
+    if (SPLIT && nt <= 0) return;
 #define K1_TILE(k_, item_, y0_, x0_, fr_)                                                        \
     do {                                                                                         \
         int ch_;                                                                                 \
-        if ((k_) < nfull_tiles) {                                                                \
+        if (!SPLIT || (k_) < nfull_tiles) {                                                      \
             const int ci_ = (k_) / gT;                                                           \
             fr_ = (k_) - ci_ * gT;                                                               \
             ch_ = cbeg + xj + ci_ * cpx;                                                         \
@@ -1054,7 +1057,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
         }
     }
     __syncthreads();
-    base_init(nfull_tiles == 0 && sp_r > 0);
+    base_init(SPLIT && nfull_tiles == 0 && sp_r > 0);
 
     for (int kt = 0; kt < nt; ++kt) {
         const int half_a = kt & 1;
@@ -1271,7 +1274,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
                 hy0 = c_y0;
                 hitem = c_item;
                 hpend = true;
-                const bool is_part = kt >= nfull_tiles;             // (wave-uniform) a tile of this workgroup's part of a split chain
+                const bool is_part = SPLIT && kt >= nfull_tiles;    // (wave-uniform) a tile of this workgroup's part of a split chain
                 const bool last = fch + 1 == (is_part ? sp_f1 : gT);
                 if (last && is_part) {                              // a PART's sum leaves as raw fp32 (no activation: c10_finalize_kernel adds the parts up)
 #pragma unroll
@@ -1306,9 +1309,10 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
 #pragma unroll
                     for (int j = 0; j < 8; ++j) held_store(j, p.out2);
                     hpend = false;
-                    base_init(kt + 1 == nfull_tiles && sp_r > 0);   // (the next item is a part > 0 of a split chain: it starts from 0)
+                    base_init(SPLIT && kt + 1 == nfull_tiles && sp_r > 0);   // (the next item is a part > 0 of a split chain: it starts from 0)
                 }
-                fch = n_f;
+                if constexpr (SPLIT) fch = n_f;
+                else fch = last ? 0 : fch + 1;
                 c_item = n_item;
                 c_y0 = n_y0;
                 c_x0 = n_x0;
@@ -1405,17 +1409,23 @@ hipError_t launch_conv3x3_c1c10(const ConvSplitParams& p, hipStream_t s) {
     if (!ncu) return hipErrorUnknown;
     const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;
     if (!split_params_ok(p, grid) || (p.split_s && !p.partial)) return hipErrorInvalidValue;
-    static std::atomic<int> attr_dev[64][2];
-    const int isf = p.in_sf ? 1 : 0;                                // `in` is the split-format copy of inp0 (conv3x3_sf_chain_kernel<true>)
-    const void* fn = isf ? reinterpret_cast<const void*>(conv3x3_c1c10_kernel<true>) : reinterpret_cast<const void*>(conv3x3_c1c10_kernel<false>);
+    static std::atomic<int> attr_dev[64][4];
+    const int isf = p.in_sf ? 1 : 0;                                // `in` is the split-format copy of inp0 (conv3x3_sf_chain_kernel<true, .>)
+    const int var = isf + (p.split_s ? 2 : 0);
+    const void* const fns[4] = {reinterpret_cast<const void*>(conv3x3_c1c10_kernel<false, false>), reinterpret_cast<const void*>(conv3x3_c1c10_kernel<true, false>),
+                                reinterpret_cast<const void*>(conv3x3_c1c10_kernel<false, true>), reinterpret_cast<const void*>(conv3x3_c1c10_kernel<true, true>)};
     const int lds = isf ? K1_SF_LDS_BYTES : K1_LDS_BYTES;
-    if (!attr_dev[dev][isf]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (!attr_dev[dev][var]) {
+        hipError_t e = hipFuncSetAttribute(fns[var], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        attr_dev[dev][isf] = 1;
+        attr_dev[dev][var] = 1;
     }
-    if (isf) hipLaunchKernelGGL(conv3x3_c1c10_kernel<true>, dim3(grid), dim3(CS_THREADS), lds, s, p);
-    else hipLaunchKernelGGL(conv3x3_c1c10_kernel<false>, dim3(grid), dim3(CS_THREADS), lds, s, p);
+    switch (var) {
+        case 0: hipLaunchKernelGGL((conv3x3_c1c10_kernel<false, false>), dim3(grid), dim3(CS_THREADS), lds, s, p); break;
+        case 1: hipLaunchKernelGGL((conv3x3_c1c10_kernel<true, false>), dim3(grid), dim3(CS_THREADS), lds, s, p); break;
+        case 2: hipLaunchKernelGGL((conv3x3_c1c10_kernel<false, true>), dim3(grid), dim3(CS_THREADS), lds, s, p); break;
+        default: hipLaunchKernelGGL((conv3x3_c1c10_kernel<true, true>), dim3(grid), dim3(CS_THREADS), lds, s, p); break;
+    }
     return hipGetLastError();
 }
 

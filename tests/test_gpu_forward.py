@@ -590,16 +590,16 @@ def test_forward_sf0_is_bit_identical(T, scale, nb, B, H, W):
     w = synth.synthetic_weights(geom, seed=T + nb)
     x = synth.uniform_clips(B, T, H, W, seed=H + B)
     eng = _engine_with(geom, w)
-    assert eng.get_option("split16_sf0") == "off" and eng.plan(B, H, W)["structure"] == "chain2"
+    assert eng.get_option("split16_sf0") == "off" and eng.plan(B, H, W)["structure"] in ("chain2", "chain2_split")   # (6 clips of 90x98: a cut last round as well)
     eng.set_option("split16_sf0", "on")
     pl = eng.plan(B, H, W)
-    assert pl["structure"] == "chain2_sf0" and pl["launches_per_block"] == 2 and pl["sf0"] == 1, pl
+    assert pl["structure"] == "chain2_sf0" and pl["launches_per_block"] == 2 + pl["c1x1"] and pl["sf0"] == 1, pl   # (+ c10_finalize_kernel with a cut last round)
     ws_on = eng.workspace_bytes(B, H, W)
     y_on = eng.forward(x)
     assert np.array_equal(y_on, eng.forward(x))
     eng.set_option("split16_sf0", "off")
     pl = eng.plan(B, H, W)
-    assert pl["structure"] == "chain2" and pl["sf0"] == 0, pl
+    assert pl["structure"] in ("chain2", "chain2_split") and pl["sf0"] == 0, pl
     assert ws_on - eng.workspace_bytes(B, H, W) == B * T * H * W * 256
     y_off = eng.forward(x)
     assert np.array_equal(y_on.view(np.uint32), y_off.view(np.uint32)), np.abs(y_on - y_off).max()
