@@ -366,7 +366,7 @@ def nl_sources_sha():
     return kernel_source_sha(["nonlocal_f16.hip", "nonlocal.hip"])
 
 
-def nonlocal_roofline(geom, kernel_ms, B, H, W, bf16):
+def nonlocal_roofline(geom, kernel_ms, B, H, W, bf16, plan=None):
     """`roofline_nl`: the affinity matmul + softmax class (reference utils.py:53-64) against the dense f16 MFMA peak.  Algorithmic FLOPs
     = SURVEY.md 8(a)-C: 4 N^2 C + 4 N C^2 per clip (S = X X^T and Y = P X, then the folded 1x1 pair); executed = what the kernel's MFMAs
     do: channels padded to CP = 32 ceil(C / 32), three f16 MFMAs per product block in the fp32 path (exactly split operands), one under
@@ -378,7 +378,8 @@ def nonlocal_roofline(geom, kernel_ms, B, H, W, bf16):
     C = 4 * 3 * geom.num_frames
     CP = 32 * ((C + 31) // 32)
     alg = B * (4.0 * N * N * C + 4.0 * N * C * C)
-    mult = 1 if bf16 else 3
+    fam = (plan or {}).get("nl", "f16" if bf16 else "split16")      # pfnl_plan: the kernel family that ran
+    mult = {"f16": 1, "split16": 3}.get(fam, 1)                      # f16 MFMAs per product block (the f32-MFMA kernels: one f32 MFMA, priced against the f16 peak all the same)
     ex = B * (4.0 * N * N * CP * mult + 4.0 * N * CP * CP)
     t = ms * 1e-3
     rec = {"bound": "mfma", "achieved": round(alg / t / 1e12, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -386,7 +387,8 @@ def nonlocal_roofline(geom, kernel_ms, B, H, W, bf16):
            "algorithmic_gflop_per_step": round(alg / 1e9, 3), "keys": N, "channels": C, "channels_padded": CP,
            "mfma_per_product": mult, "mfma_executed_tflops": round(ex / t / 1e12, 1),
            "mfma_executed_frac": round(ex / t / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
-           "kernel": "nl_attn_f16_sw_kernel<C, %s> (+ nl_pack_f16 / nl_merge in the class time)" % ("false" if bf16 else "true"),
+           "kernel": ("nl_attn_f16_sw_kernel<C, %s> (+ nl_merge in the class time)" % ("false" if fam == "f16" else "true")) if fam in ("f16", "split16")
+                     else "nl_attn_kernel<C> (f32 MFMA: small key counts / strict_fp32 / the general form of the block)", "family": fam,
            "matrix_pipe_busy": None,
            "note": "frac = algorithmic FLOPs / class time / 2.5 PFLOP/s; the class time includes the pack and merge launches around the attention kernel"}
     import glob
@@ -400,7 +402,7 @@ def nonlocal_roofline(geom, kernel_ms, B, H, W, bf16):
     return rec
 
 
-def hbm_class_rooflines(geom, kernel_ms, B, H, W, merge_stride=64):
+def hbm_class_rooflines(geom, kernel_ms, B, H, W, merge_stride=64, plan=None):
     """Achieved GB/s of the bandwidth-class kernels (gather / scatter / tail / bicubic) against 8 TB/s: the
     ALGORITHMIC bytes each class must move (inputs read once, outputs written once) over its HIP-event time per step."""
     T, sc = geom.num_frames, geom.scale
@@ -410,7 +412,8 @@ def hbm_class_rooflines(geom, kernel_ms, B, H, W, merge_stride=64):
     out = {}
     model = {
         # x [B,T,H,W,3] fp32 -> X [B,N,CP] fp32 (space_to_depth of the stacked frames, model/pfnl.py:55-57)
-        "nl_pack": B * (T * P * 3 * 4.0 + N * CP * 4.0),
+        # (+ the binary16 K / V^T operands - hi and lo' parts, keys padded to 32 + 64 - when the one fused pack launch writes them too: pfnl_plan)
+        "nl_pack": B * (T * P * 3 * 4.0 + N * CP * 4.0 + (4.0 * 96 * ((N + 31) // 32 * 32 + 64) * 2.0 if (plan or {}).get("nl_pack_fused") else 0.0)),
         # Xo [B,N,CP] (+ the LR frames' residual already inside) -> conv 5x5 3->64 + lrelu -> inp0 [B*T,H,W,64] fp32 (model/pfnl.py:61-62)
         "conv0": B * (N * CP * 4.0 + T * P * 64 * 4.0),
         # convmerge1: reads the trunk [B*T,H,W,64], writes merge [B,H,W,merge_stride] (model/pfnl.py:73-74)
@@ -709,8 +712,8 @@ def main():
                    "comm_nranks": comm_nranks, "comm_required": bool(args.require_comm),
                    "weights": "synthetic Xavier (seed 0)", "input": "resident in HBM", "conv3x3": algo, "plan": plan["structure"]},
         "roofline": roof,
-        "roofline_nl": nonlocal_roofline(geom, breakdown, B_PER_GPU, H, W, bf16),
-        "roofline_hbm_classes": hbm_class_rooflines(geom, breakdown, B_PER_GPU, H, W),
+        "roofline_nl": nonlocal_roofline(geom, breakdown, B_PER_GPU, H, W, bf16, plan),
+        "roofline_hbm_classes": hbm_class_rooflines(geom, breakdown, B_PER_GPU, H, W, plan=plan),
         "whole_forward": {"tflops_ref_graph": round(f_ref / (ms_per_step * 1e-3) / 1e12, 2),
                           "tflops_direct_shared_base": round(f_exec / (ms_per_step * 1e-3) / 1e12, 2),
                           "kernel_ms_per_step": breakdown},
@@ -796,7 +799,7 @@ def secondary_workloads(eng, geom, weights, local_dev, dev, x_cfg2, out_cfg2):
                "value": round(B * steps / el, 3), "unit": "HR frames/s", "input": "resident in HBM",
                "kernel_ms_per_step": {n: round(v["ms"] / steps * (sc if n in ("conv3x3", "conv1x1") else 1.0), 4) for n, v in prof.items()}}
         assert torch.isfinite(o).all().item(), "non-finite output (%s)" % label
-        rec["roofline_nl"] = nonlocal_roofline(g, rec["kernel_ms_per_step"], B, H, W, bf16)
+        rec["roofline_nl"] = nonlocal_roofline(g, rec["kernel_ms_per_step"], B, H, W, bf16, e.plan(B, H, W))
         return rec, prof
 
     out = []

@@ -185,7 +185,7 @@ int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes);
 /* THE LAUNCH PLAN of the progressive-fusion trunk (reference model/pfnl.py:65-71) for a [B,T,H,W,3] forward under the handle's current
  * options, as text: "<structure> launches_per_block=<n> c1x1=<launches of class conv1x1 among them> precision=<..> conv3x3=<..> conv1x1=<..>
  * c10_fused=<0|1> chain=<0|1> sf0=<0|1> strict=<0|1> tiles=<8x32-pixel tiles per per-frame launch> chains=<(clip, tile) chains>
- * whole_chains=<n> split_parts=<s> part_frames=<q>".  Structures: "small2" / "small3" (conv_small.hip,
+ * whole_chains=<n> split_parts=<s> part_frames=<q> nl=<split16 | f16 | f32 | general_f32: the non-local block's kernel family> nl_pack_fused=<0|1>".  Structures: "small2" / "small3" (conv_small.hip,
  * below ~0.78 tiles per CU: 200 on a 256-CU device), "mid4" (four per-tile launches, below ~0.53 chains per CU: 136), "chain2" (conv1_i +
  * conv10_i, then the whole of conv2_i), "chain2_split" (the same with the chains of a last, partial round cut by frames: option
  * split16_splitchains) and "chain2_sf0" (the same with a split-format copy of every block's output so that the next block's

@@ -493,6 +493,17 @@ TrunkPlan trunk_plan(const pfnl_handle* h, int B, int H, int W) {
     return pl;
 }
 
+// which kernel family the non-local block takes (the same one statement for forward_device and pfnl_plan): 0 the general form (nltype 0 / 2 or
+// sub-sampling: f32 MFMA), 1 the f16 pipe with exactly split operands (fp32 precision, from 1024 keys), 2 the f16 pipe on the hi parts (precision
+// bf16), 3 f32 MFMA (small key counts, strict_fp32)
+int nl_family(const pfnl_handle* h, int N) {
+    const int nlt = h->nl_type < 0 ? (h->nl_theta ? 0 : 1) : h->nl_type;
+    if (nlt != 1 || h->nl_sub > 1) return 0;
+    if (h->bf16) return 2;
+    const bool nl_strict = h->strict || h->strict_once || !h->weights_f16_ok;
+    return (!nl_strict && (h->nl_algo == 1 || (h->nl_algo == 2 && N >= 1024))) ? 1 : 3;
+}
+
 // forward over device buffers
 // `strip` != null: only LR rows [strip->yoff + core0, strip->yoff + core1) of the result are produced (single-clip sharding,
 // pfnl_forward_strip): the non-local block runs its queries [q0, q1) against ALL keys, the trunk runs on the strip + halo.
@@ -524,9 +535,8 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
     const int nlt_fence = h->nl_type < 0 ? (h->nl_theta ? 0 : 1) : h->nl_type;
     unsigned* const rflag = (nl_strict || nlt_fence == 2) ? nullptr : h->rflag_dev + flag_slot;
     // the non-local block on the f16 matrix pipe (PFNL's own call: nltype 1, no sub-sampling; fp32 precision from 1024 keys, bf16 always)
-    const int nlt_plan = h->nl_type < 0 ? (h->nl_theta ? 0 : 1) : h->nl_type;
-    const bool nl_f16 = nlt_plan == 1 && h->nl_sub <= 1 && (h->bf16 || (!nl_strict && (h->nl_algo == 1 || (h->nl_algo == 2 && N >= 1024))));
-    const bool nl_fused_pack = nl_f16 && nl_f16_fits_one_launch(B, N);   // one pack launch: x -> X fp32 + the binary16 K / V^T operands (round 6)
+    const int nl_fam = nl_family(h, N);
+    const bool nl_fused_pack = (nl_fam == 1 || nl_fam == 2) && nl_f16_fits_one_launch(B, N);   // one pack launch: x -> X fp32 + the binary16 K / V^T operands (round 6)
     {   // model/pfnl.py:55-60 (+ utils.py:18-71)
         ProfScope ps(h, s, PFNL_K_NL_PACK);
         if (nl_fused_pack) {
@@ -561,11 +571,11 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
                 Qp = h->Q.p;
             }
             HIPCHK(launch_nl_attn_general(h->X.p, Kx, Nk, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p, B, N, C, s, Qp, q0, q1, nlt == 2));
-        } else if (!h->bf16 && !nl_strict && (h->nl_algo == 1 || (h->nl_algo == 2 && N >= 1024))) {   // fp32 path on the f16 pipe, exactly split operands
+        } else if (nl_fam == 1) {   // fp32 path on the f16 pipe, exactly split operands
             if (h->nl16.ensure((nl_f16_scratch_halfs(B, N) + 1) / 2)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
             HIPCHK(launch_nl_attn_f16(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p,
                                       reinterpret_cast<uint16_t*>(h->nl16.p), B, N, C, s, q0, q1, true, nl_fused_pack));
-        } else if (h->bf16) {   // 16-bit operands throughout: the f16 kernel on the hi parts only
+        } else if (nl_fam == 2) {   // 16-bit operands throughout: the f16 kernel on the hi parts only
             if (h->nl16.ensure((nl_f16_scratch_halfs(B, N) + 1) / 2)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
             HIPCHK(launch_nl_attn_f16(h->X.p, h->Xo.p, wd + h->off_nl_w, wd + h->off_nl_b, h->nlp.p,
                                       reinterpret_cast<uint16_t*>(h->nl16.p), B, N, C, s, q0, q1, false, nl_fused_pack));
@@ -1494,17 +1504,21 @@ int pfnl_plan(pfnl_handle* h, int B, int H, int W, char* buf, size_t buflen) {
     if (!h || !buf || buflen < 1) return fail(PFNL_ERR_INVALID, "NULL argument");
     if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return fail(PFNL_ERR_INVALID, "bad shape");
     const TrunkPlan pl = trunk_plan(h, B, H, W);
+    const int N = (H / 2) * (W / 2), nlf = nl_family(h, N);
+    static const char* const nln[] = {"general_f32", "split16", "f16", "f32"};
+    const int nl_fused = (nlf == 1 || nlf == 2) && pfnl::nl_f16_fits_one_launch(B, N);
     static const char* const a3[] = {"direct", "winograd_tile", "?", "winograd", "split16"};
     static const char* const a1[] = {"tiled", "stream", "split16"};
     char tmp[384];
     if (pl.bf16)
-        std::snprintf(tmp, sizeof tmp, "%s launches_per_block=%d c1x1=%d precision=bf16 tiles=%d chains=%d", pl.name, pl.launches_per_block, pl.c1x1_launches, pl.tiles8x32, pl.chains);
+        std::snprintf(tmp, sizeof tmp, "%s launches_per_block=%d c1x1=%d precision=bf16 tiles=%d chains=%d nl=%s nl_pack_fused=%d", pl.name, pl.launches_per_block,
+                      pl.c1x1_launches, pl.tiles8x32, pl.chains, nln[nlf], nl_fused);
     else
         std::snprintf(tmp, sizeof tmp, "%s launches_per_block=%d c1x1=%d precision=fp32 conv3x3=%s conv1x1=%s c10_fused=%d chain=%d sf0=%d strict=%d tiles=%d chains=%d "
-                      "whole_chains=%d split_parts=%d part_frames=%d",
+                      "whole_chains=%d split_parts=%d part_frames=%d nl=%s nl_pack_fused=%d",
                       pl.name, pl.launches_per_block, pl.c1x1_launches, pl.small ? "small" : a3[pl.algo < 0 || pl.algo > 4 ? 2 : pl.algo],
                       a1[pl.conv1x1_algo < 0 || pl.conv1x1_algo > 2 ? 0 : pl.conv1x1_algo], pl.c10_fused ? 1 : 0, pl.chain ? 1 : 0, pl.sf0 ? 1 : 0,
-                      pl.strict ? 1 : 0, pl.tiles8x32, pl.chains, pl.split_s ? pl.n_full : pl.chains, pl.split_s, pl.split_q);
+                      pl.strict ? 1 : 0, pl.tiles8x32, pl.chains, pl.split_s ? pl.n_full : pl.chains, pl.split_s, pl.split_q, nln[nlf], nl_fused);
     if (std::strlen(tmp) + 1 > buflen) return fail(PFNL_ERR_INVALID, "buffer too small");
     std::strcpy(buf, tmp);
     return 0;

@@ -243,7 +243,7 @@ def test_harness_two_in_flight_is_byte_identical(tmp_path, monkeypatch, H, W, nb
         monkeypatch.setenv("PFNL_HARNESS_INFLIGHT", mode)
         m.test_video_lr(str(seq), name="out" + mode, part=50)       # part >= frames: num_once = 1 (model/pfnl.py:211-216)
         outs[mode] = np.stack([np.asarray(Image.open(p)) for p in sorted((seq / ("out" + mode)).glob("*.png"))])
-        assert (m._engine2 is not None) == (mode != "1")            # the second handle exists once it has been asked for; "auto" is serial
+        assert (m._engine2 is not None) == (mode == "2")            # the second handle exists once it has been asked for; "auto" is serial
     assert np.array_equal(outs["1"], outs["2"]) and np.array_equal(outs["1"], outs["auto"])
     lrs = (lr_u8 / 255.).astype(np.float32)
     win = np.ascontiguousarray(M.sliding_windows(lrs, 7))
