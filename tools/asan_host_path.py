@@ -22,7 +22,9 @@ def main():
     assert "asan" in _capi.LIB_PATH, "run through tools/run_asan.sh --host"
     n = 0
     # (the third shape moves 1.4 MB in and 3.4 MB out per call: the pinned strips and the copy thread pool of the host-pointer path)
-    for T, scale, nb, B, H, W in ((7, 4, 2, 1, 16, 24), (5, 2, 1, 2, 10, 38), (7, 4, 1, 3, 64, 88), (3, 4, 1, 1, 34, 18), (7, 4, 1, 1, 2, 2)):
+    # (the last shape: 9 clips x 32 chains = 288 (clip, tile) chains = a whole round + 32 chains cut into 7 parts each: round 6's split chains,
+    # c10_finalize_kernel, the fused non-local pack (2 048 keys), pfnl_plan / pfnl_get_option)
+    for T, scale, nb, B, H, W in ((7, 4, 2, 1, 16, 24), (5, 2, 1, 2, 10, 38), (7, 4, 1, 3, 64, 88), (3, 4, 1, 1, 34, 18), (7, 4, 1, 1, 2, 2), (7, 4, 1, 9, 128, 64)):
         geom = PFNLGeometry(num_frames=T, scale=scale, num_block=nb)
         w = synth.synthetic_weights(geom, seed=T)
         x = synth.uniform_clips(B, T, H, W, seed=H)
@@ -31,9 +33,16 @@ def main():
         eng.load_weights(w)
         for opts in ({}, {"conv3x3": "split16", "small": "off"}, {"conv3x3": "winograd"}, {"conv3x3": "direct", "conv1x1": "tiled"},
                      {"strict_fp32": "on"}, {"small_c10": "off"}, {"split16_sf": "off"}, {"split16_chain": "off"}, {"split16_c10": "off"}, {"graph": "on"}, {"precision": "bf16"},
-                     {"precision": "bf16", "bf16_conv10": "separate"}):
+                     {"precision": "bf16", "bf16_conv10": "separate"}, {"split16_sf0": "on"}, {"split16_splitchains": "off"}, {"split16_mid": "off"}):
+            if B == 9 and opts.get("conv3x3") in ("winograd", "direct") or (B == 9 and opts.get("strict_fp32")):
+                continue                                         # (the f32-MFMA families at the large shape: covered at the small ones, minutes under ASAN)
             for k, v in opts.items():
                 eng.set_option(k, v)
+                assert eng.get_option(k) == v
+            pl = eng.plan(B, H, W)
+            assert pl["structure"] and pl["launches_per_block"] >= 2, pl
+            if B == 9 and not opts:
+                assert pl["structure"] == "chain2_split" and pl["split_parts"] == 7 and pl["nl_pack_fused"] == 1, pl
             for _ in range(2):                                 # (graph=on captures on the second call)
                 y = eng.forward(x)
             tol = 3e-2 if opts.get("precision") == "bf16" else 5e-5
@@ -43,7 +52,7 @@ def main():
             for k in opts:
                 eng.set_option(k, {"conv3x3": "auto", "small": "auto", "small_c10": "on", "conv1x1": "split16", "strict_fp32": "off", "split16_sf": "on",
                                    "split16_chain": "on", "split16_c10": "on", "graph": "off", "precision": "fp32", "bf16_nonlocal": "f16",
-                                   "bf16_conv10": "fused"}[k])
+                                   "bf16_conv10": "fused", "split16_sf0": "off", "split16_splitchains": "auto", "split16_mid": "auto"}[k])
             n += 1
         eng.profile(1)
         eng.forward(x)
