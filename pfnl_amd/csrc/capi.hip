@@ -900,10 +900,34 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
     if (m1_s16) {
         // convmerge1 (:73-74) on the f16 pipe: the accumulating mode of conv3x3_split16_kernel (the T frame tiles of a clip run
         // through the same accumulators, every unit with its own weights; cout zero-padded to 64; one epilogue per clip tile)
-        ProfScope ps(h, s, PFNL_K_MERGE1);
-        ConvSplitParams q{merge_in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_m1, wd + h->off_m1_b, nullptr, nullptr,
-                          h->merge.p, H, W, F, T, 1, 1};
-        HIPCHK(launch_conv3x3_split16(q, s));
+        {
+            ProfScope ps(h, s, PFNL_K_MERGE1);
+            ConvSplitParams q{merge_in, reinterpret_cast<const uint16_t*>(h->wdev16s.p) + h->off16s_m1, wd + h->off_m1_b, nullptr, nullptr,
+                              h->merge.p, H, W, F, T, 1, 1};
+            // split chains (trunk_plan): convmerge1's chains are the trunk's - the same last, partial round is cut by frames, the parts' raw sums
+            // meet in c10_finalize_kernel (+ bias, leaky-relu); c10part is free behind the last block
+            q.n_full = pl.n_full;
+            q.split_s = pl.split_s;
+            q.split_q = pl.split_q;
+            q.partial = pl.split_s ? h->c10part.p : nullptr;
+            HIPCHK(launch_conv3x3_split16(q, s));
+        }
+        if (pl.split_s) {
+            ProfScope ps(h, s, PFNL_K_MERGE1);
+            ConvSplitParams f{};
+            f.H = H;
+            f.W = W;
+            f.items = F;
+            f.add_div = T;
+            f.act = 1;
+            f.n_full = pl.n_full;
+            f.split_s = pl.split_s;
+            f.split_q = pl.split_q;
+            f.partial = h->c10part.p;
+            f.bias = wd + h->off_m1_b;
+            f.out = h->merge.p;
+            HIPCHK(launch_c10_finalize(f, s));
+        }
     } else if (m1_wino) {
         // convmerge1 (:73-74) = sum over the T frames of a 3x3 64->48 convolution: one launch of the persistent
         // Winograd kernel in its accumulating mode (cout zero-padded to 64; the T frame tiles of a clip add into

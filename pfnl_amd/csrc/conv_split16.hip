@@ -132,10 +132,14 @@ __device__ __forceinline__ void split4(f32x4 v, u32x2& hi, u32x2& lo, float nsca
 // OSF (MODE 0 only; conv1_i): the output is written in the SPLIT FORMAT the consumers' MFMA operands are made of (conv_split16.h:
 // per pixel 256 B = [channel half][hi 32 x f16 | lo' 32 x f16]) - the split costs 2 VALU per value once, in the producer, instead
 // of once per consumer and halo pixel, and the consumers can bring their halos in by LDS-DMA (conv_sf.hip).
-template <int MODE, bool OSF = false>
+// SPLIT (MODE 2 only; round 6): split chains (conv3x3_c1c10_kernel below has the scheme) - behind the whole rounds of (clip, tile) chains every
+// workgroup takes ONE part (frames [sp_f0, sp_f1)) of a cut chain; its sum leaves raw (no bias, no activation) as a dense [8][32][64] fp32 tile
+// in p.partial[slot], and c10_finalize_kernel adds the parts up.  A template parameter: the common instantiations keep their instruction streams.
+template <int MODE, bool OSF = false, bool SPLIT = false>
 __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSplitParams p) {
     constexpr bool FUSE = MODE == 1, ACCUM = MODE == 2;
     static_assert(!OSF || MODE == 0, "split-format output: plain mode only");
+    static_assert(!SPLIT || MODE == 2, "split chains: the accumulating mode only");
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_smem[];
     unsigned char* const wl = cs_smem + 2 * CS_TILE_BYTES;
     float* const bl = reinterpret_cast<float*>(cs_smem + 2 * CS_TILE_BYTES + CS_W_BYTES);
@@ -159,17 +163,31 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
     const int gT = (FUSE || ACCUM) ? p.add_div : 1;
     const int nchains = per_item * (p.items / gT);
     const int xcd = blockIdx.x & 7, xj = blockIdx.x >> 3, cpx = gridDim.x >> 3;
-    const int per_xcd = (nchains + 7) >> 3;
+    const int n_full = SPLIT ? p.n_full : nchains;
+    const int per_xcd = (n_full + 7) >> 3;
     const int cbeg = xcd * per_xcd;
-    const int ccnt = min(per_xcd, nchains - cbeg);
-    if (xj >= ccnt) return;
-    const int nt = ((ccnt - xj + cpx - 1) / cpx) * gT;              // tiles of this workgroup
+    const int ccnt = min(per_xcd, n_full - cbeg);
+    if (!SPLIT && xj >= ccnt) return;
+    const int nfull_tiles = ((!SPLIT || xj < ccnt) ? (ccnt - xj + cpx - 1) / cpx : 0) * gT;   // tiles of this workgroup's whole chains
+    [[maybe_unused]] const int slot = xcd * cpx + xj;
+    const bool has_part = SPLIT && slot < (nchains - n_full) * p.split_s;
+    const int sp_chain = has_part ? n_full + slot / p.split_s : 0;
+    const int sp_f0 = has_part ? (slot % p.split_s) * p.split_q : 0, sp_f1 = has_part ? min(gT, sp_f0 + p.split_q) : 0;
+    const int nt = SPLIT ? nfull_tiles + (sp_f1 - sp_f0) : nfull_tiles;   // tiles of this workgroup
+    if (SPLIT && nt <= 0) return;
     [[maybe_unused]] const int nu = 2 * nt;                         // units: (tile, channel half); nu >= 2
     // tile k -> (item, y0, x0)
 #define CS_TILE(k_, item_, y0_, x0_)                                                             \
     do {                                                                                         \
-        const int ci_ = (k_) / gT, f_ = (k_) - ci_ * gT;                                         \
-        const int ch_ = cbeg + xj + ci_ * cpx;                                                   \
+        int ci_, f_, ch_;                                                                        \
+        if (!SPLIT || (k_) < nfull_tiles) {                                                      \
+            ci_ = (k_) / gT;                                                                     \
+            f_ = (k_) - ci_ * gT;                                                                \
+            ch_ = cbeg + xj + ci_ * cpx;                                                         \
+        } else {                                                                                 \
+            f_ = sp_f0 + ((k_) - nfull_tiles);                                                   \
+            ch_ = sp_chain;                                                                      \
+        }                                                                                        \
         const int cl_ = ch_ / per_item;                                                          \
         const int sp_ = ch_ - cl_ * per_item;                                                    \
         item_ = cl_ * gT + f_;                                                                   \
@@ -469,7 +487,9 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
             // next unit requested; group 3: slot 0 written, slot 1 requested; group 5: slot 1 written, slot 2 requested.
             [[maybe_unused]] int w_next = 0;
             if constexpr (ACCUM) {
-                const int fn = fch + 1 == gT ? 0 : fch + 1;
+                // (SPLIT: behind this workgroup's last whole chain comes its part, which starts at frame sp_f0)
+                const int f_end = (SPLIT && kt >= nfull_tiles) ? sp_f1 : gT;
+                const int fn = fch + 1 == f_end ? ((SPLIT && kt + 1 == nfull_tiles) ? sp_f0 : 0) : fch + 1;
                 w_next = PAR == 0 ? 2 * fch + (half_a ^ 1) : 2 * fn + (half_a ^ 1);   // unit B's half is also the next tile's first half
             }
             if constexpr (PAR == 0 && !ACCUM) w_request(half_a ^ 1, 0);
@@ -652,7 +672,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
 #undef CS_PX
 #undef CS_WT
             if constexpr (PAR == 1 && ACCUM) {                      // a tile is one frame of the chain: only the last one ends a sum
-                const bool last = fch + 1 == gT;                    // (wave-uniform; arithmetic only inside the branch)
+                const bool last = fch + 1 == ((SPLIT && kt >= nfull_tiles) ? sp_f1 : gT);   // (wave-uniform; arithmetic only inside the branch)
                 if (last) {
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
@@ -668,7 +688,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
                     eitemp = c_item / gT;                           // output item = the clip
                 }
                 pending = last;
-                fch = last ? 0 : fch + 1;
+                fch = last ? ((SPLIT && kt + 1 == nfull_tiles) ? sp_f0 : 0) : fch + 1;
                 c_item = n_item;
                 c_y0 = n_y0;
                 c_x0 = n_x0;
@@ -695,6 +715,24 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_split16_kernel(ConvSpli
     }
 
     // ---- the last tile: both passes, any buffer is free now ------------------------------------------
+    if constexpr (SPLIT) {
+        if (has_part) {                                             // (wave-uniform) the part's sum: raw, a dense [row][column][64] fp32 tile in its slot
+            float* const pt = p.partial + (size_t)slot * (CS_TH * CS_TW * 64);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                unsigned char* const scratch = cs_smem + n * CS_TILE_BYTES;
+                dump(scratch, n, 0);
+                dump(scratch, n, 1);
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {                       // piece k = chunk tid & 15 of pixel (row pair k, column tid >> 4) of output row 2 k + n
+                    piece_read(scratch, k);
+                    *reinterpret_cast<f32x4*>(pt + ((size_t)(2 * k + n) * CS_TW + (tid >> 4)) * 64 + (tid & 15) * 4) = pv;
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         unsigned char* const scratch = cs_smem + n * CS_TILE_BYTES;
@@ -1374,13 +1412,16 @@ __global__ __launch_bounds__(256) void c10_finalize_kernel(ConvSplitParams p) {
 #pragma unroll
         for (int r = 1; r < 7; ++r)
             if (r < S) v += part[r];                                // fixed order r = 0 .. S-1 (wave-uniform S: no divergence)
+        if (p.out) v += *reinterpret_cast<const f32x4*>(p.bias + c4 * 4);   // convmerge1's parts carry no bias (conv10_i's part 0 does)
         v.x = fmaxf(v.x, slope * v.x);
         v.y = fmaxf(v.y, slope * v.y);
         v.z = fmaxf(v.z, slope * v.z);
         v.w = fmaxf(v.w, slope * v.w);
         const h4 hi = __builtin_convertvector(v, h4);
         const h4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * CS_SCALE, h4);   // exact before the one rounding: = split4
-        if (y < H && x < W) {
+        if (p.out) {                                                // convmerge1: fp32 [clip][y][x][64]
+            if (y < H && x < W) *reinterpret_cast<f32x4*>(p.out + (((size_t)clip * H + y) * W + x) * 64 + c4 * 4) = v;
+        } else if (y < H && x < W) {
             // split format: pixel 256 B = [channel half M][hi 32 | lo' 32] binary16; channels 4 c4 .. + 3 -> half c4 >> 3, position (c4 & 7) * 4
             unsigned char* dst = reinterpret_cast<unsigned char*>(p.out2) + (((size_t)clip * H + y) * W + x) * 256 + (c4 >> 3) * 128 + (c4 & 7) * 8;
             *reinterpret_cast<h4*>(dst) = hi;
@@ -1390,7 +1431,7 @@ __global__ __launch_bounds__(256) void c10_finalize_kernel(ConvSplitParams p) {
 }
 
 hipError_t launch_c10_finalize(const ConvSplitParams& p, hipStream_t s) {
-    if (!p.partial || !p.out2 || p.items < 1 || p.H < 1 || p.W < 1 || p.add_div < 1 || p.items % p.add_div) return hipErrorInvalidValue;
+    if (!p.partial || (!p.out2 == !p.out) || (p.out && !p.bias) || p.items < 1 || p.H < 1 || p.W < 1 || p.add_div < 1 || p.items % p.add_div) return hipErrorInvalidValue;
     const int grid = conv_split16_grid();
     if (p.split_s < 2 || !split_params_ok(p, grid)) return hipErrorInvalidValue;
     const long long nchains = (long long)((p.W + CS_TW - 1) / CS_TW) * ((p.H + CS_TH - 1) / CS_TH) * (p.items / p.add_div);
@@ -1441,6 +1482,17 @@ hipError_t launch_conv3x3_split16(const ConvSplitParams& p, hipStream_t s) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (p.out_sf && (p.accum || p.addend)) return hipErrorInvalidValue;
+    if (p.split_s) {                                                       // split chains: convmerge1's accumulating launch only
+        if (!p.accum || !p.partial || !split_params_ok(p, grid)) return hipErrorInvalidValue;
+        static std::atomic<int> attr_split[64];
+        if (!attr_split[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split16_kernel<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS_BYTES);
+            if (e != hipSuccess) return e;
+            attr_split[dev] = 1;
+        }
+        hipLaunchKernelGGL((conv3x3_split16_kernel<2, false, true>), dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, p);
+        return hipGetLastError();
+    }
     const int mode = p.out_sf ? 3 : p.accum ? 2 : p.addend ? 1 : 0;
     const void* fn = mode == 3 ? reinterpret_cast<const void*>(conv3x3_split16_kernel<0, true>)
                    : mode == 2 ? reinterpret_cast<const void*>(conv3x3_split16_kernel<2>)

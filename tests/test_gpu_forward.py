@@ -662,6 +662,12 @@ def test_forward_split_chains(T, scale, nb, H, W, Bs):
         if cut:
             assert pl["whole_chains"] == B * chains_clip - R and pl["split_parts"] * pl["part_frames"] >= T > (pl["split_parts"] - 1) * pl["part_frames"]
             assert (B * chains_clip - pl["whole_chains"]) * pl["split_parts"] <= 256 and pl["launches_per_block"] == 3 and pl["c1x1"] == 1
+            eng.profile(1)
+            eng.profile_reset()
+            eng.forward(x)
+            pr = eng.profile_read()
+            eng.profile(0)
+            assert pr["conv3x3"]["launches"] == 2 * nb and pr["conv1x1"]["launches"] == nb and pr["merge1"]["launches"] == 2, pr   # (convmerge1 cut as well: + its finalize)
         y = eng.forward(x)
         assert np.array_equal(y, eng.forward(x)), B                # deterministic: fixed summation order of the parts
         eng.set_option("split16_splitchains", "off")
