@@ -709,6 +709,21 @@ def test_forward_fused_nl_pack_is_bit_identical(T, scale, B, H, W, prec):
     eng.close()
 
 
+def test_split_chains_random_geometries():
+    """tools/stress_r06.py as a test (12 s of it; the tool ran 12 741 geometries for profiles/r06_stress.txt): random (T, scale, blocks, B, H, W)
+    with more than one round of (clip, tile) chains - every forward repeated bit for bit, split16_sf0 bit-equal to the default, a cut last round
+    within summation-order noise of the uncut launch and of the f32-MFMA kernels.  The parts hand conv10_i's / convmerge1's sums over through
+    memory between launches and the chain kernel recomputes shared halves per part: a wrong frame range or slot is a wrong tile, far above
+    the tolerance; timing-dependent faults show up in the repeats (reference model/pfnl.py:65-74)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("stress_r06", os.path.join(root, "tools", "stress_r06.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, ncut, worst, worst_strict, parts = mod.run(seed=5, seconds=12.0)
+    assert n >= 20 and ncut >= 8 and worst < 2e-5 and worst_strict < 1e-4, (n, ncut, worst, worst_strict, parts)
+
+
 def test_plan_is_what_runs():
     """pfnl_plan is the ONE statement of the trunk's dispatch rule (capi.hip trunk_plan; reference model/pfnl.py:65-71): for every structure
     the launches the profiler counts per block equal the plan's, in both precisions and under the options that change it; the thresholds
