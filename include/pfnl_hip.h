@@ -58,7 +58,7 @@ typedef struct pfnl_config {
 } pfnl_config;
 
 const char* pfnl_last_error(void);
-int pfnl_version(void);                        /* ABI version, currently 2 */
+int pfnl_version(void);                        /* ABI version, currently 3 (round 6: + pfnl_plan, pfnl_get_option, the _sf0 op hooks; - pfnl_op_conv3x3_wsplit) */
 int pfnl_device_count(int* count);
 
 /* ---- model lifetime ---------------------------------------------------------------------- */

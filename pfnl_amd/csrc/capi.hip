@@ -976,7 +976,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
 extern "C" {
 
 const char* pfnl_last_error(void) { return g_err.c_str(); }
-int pfnl_version(void) { return 2; }
+int pfnl_version(void) { return 3; }
 
 int pfnl_device_count(int* count) {
     if (!count) return fail(PFNL_ERR_INVALID, "count is NULL");

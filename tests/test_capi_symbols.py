@@ -29,7 +29,7 @@ def test_library_built_and_exports_header_symbols():
 
 def test_version_and_argument_validation_without_gpu():
     lib = _capi.load_library()
-    assert lib.pfnl_version() == 2
+    assert lib.pfnl_version() == 3
     h = C.c_void_p()
     bad = _capi.pfnl_config(4, 4, 64, 20, 0, (C.c_int32 * 3)(0, 0, 0))        # even num_frames
     assert lib.pfnl_create(C.byref(bad), C.byref(h)) == -1
