@@ -65,24 +65,31 @@ int main() {
     for (int l = 0; l < 64; ++l) a[l] = (((l >> 4) * 4 + (l & 3)) * 1024 + 4 * ((l & 15) >> 2)) * 2;
     o = run(a, nelem);
     show("lane l -> row 4 (l >> 4) + (l & 3), columns 4 ((l & 15) >> 2) .. + 3 of a [16][1024] image", a, o, 32);
-    // model check: hypothesis H = "within a 16-lane group, lane g (0 .. 15) receives element [g & 3] of the 8-byte pieces of lanes 4 (g >> 2) .. + 3"
-    // i.e. out[lane 16 q + g][j] = piece(lane 16 q + 4 (g >> 2) + j)[g & 3]
+    // THE LAW (checked on every pattern above): out[16 q + g][j] = piece(lane 16 q + 4 j + (g >> 2))[g & 3], piece(p) = the 4 contiguous elements at lane
+    // p's own address.  A 16-lane group reads a [4 rows][16 columns] block - row j = the pieces of lanes 4 j .. 4 j + 3 - and lane g gets column g.
+    auto law = [&](const std::vector<int>& ad, const std::vector<unsigned short>& ou) {
+        int bad = 0;
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 4; ++j) {
+                const int src_lane = (l & ~15) + 4 * j + ((l & 15) >> 2);
+                if (ou[4 * l + j] != (unsigned short)(ad[src_lane] / 2 + (l & 3))) ++bad;
+            }
+        return bad;
+    };
+    int total = law(a, o);
+    for (int l = 0; l < 64; ++l) a[l] = 8 * l;
+    total += law(a, run(a, nelem));
+    for (int l = 0; l < 64; ++l) a[l] = ((l & 15) * 1024 + 4 * (l >> 4)) * 2;
+    total += law(a, run(a, nelem));
+    // the use the non-local block has for it: a K tile [key][channel], row stride S elements; lane (i = l & 31, kh = l >> 5) of a P V A operand wants keys
+    // k0 + 4 kh + 0 .. 3 of channel c0 + i: lane p = l & 15 of its group points at row k0 + 4 kh + (p >> 2), channels c0 + 16 ((l >> 4) & 1) + 4 (p & 3)
+    const int S = 104, k0 = 16, c0 = 32;                            // (208-byte rows as nonlocal_f16.hip's K tile)
+    for (int l = 0; l < 64; ++l) a[l] = ((k0 + 4 * (l >> 5) + ((l & 15) >> 2)) * S + c0 + 16 * ((l >> 4) & 1) + 4 * (l & 3)) * 2;
+    o = run(a, nelem);
     int bad = 0;
     for (int l = 0; l < 64; ++l)
-        for (int j = 0; j < 4; ++j) {
-            const int src_lane = (l & ~15) + 4 * ((l & 15) >> 2) + j;
-            const int want = a[src_lane] / 2 + (l & 3);
-            if (o[4 * l + j] != want) ++bad;
-        }
-    printf("hypothesis H (4 x 4 transposes inside groups of 4 lanes): %s (%d mismatches)\n", bad ? "NO" : "YES", bad);
-    bad = 0;
-    for (int l = 0; l < 64; ++l)
-        for (int j = 0; j < 4; ++j) {
-            // hypothesis G (the guide's formula): a 16-lane group reads a [4][16] block; lane g gets column g, rows j: the piece of the lane that holds
-            // (row j, columns 4 (g >> 2) ..): lane 4 * j' ... expressed for pattern (c): row index = l & 3 -> source lane = group + 4 ((g) >> 2) ... probe only
-            const int g = l & 15;
-            const int src_lane = (l & ~15) + (g >> 2) * 4 + j;      // same as H for this pattern: kept for the record
-            (void)src_lane;
-        }
+        for (int j = 0; j < 4; ++j)
+            if (o[4 * l + j] != (unsigned short)((k0 + 4 * (l >> 5) + j) * S + c0 + (l & 31))) ++bad;
+    printf("the law out[16q+g][j] = piece(16q + 4j + (g>>2))[g&3]: %d mismatches on three patterns; K-tile -> P V operand addressing: %d mismatches\n", total, bad);
     return 0;
 }
