@@ -47,6 +47,17 @@ constexpr int NF_THREADS = 512;           // 8 waves x 32 queries share every ke
                                           // bounds this kernel - with 128 queries per workgroup it ran at 6.6 TB/s of L2 -> CU traffic
                                           // (11 B/clk/CU) and 43 % matrix-pipe use, whatever was done to its instruction schedule
 constexpr int NF_QB = NF_THREADS / 2;     // queries per workgroup
+// The transposing-read form of nl_attn_f16_sw_kernel (round 6; TR = true below): built, parity-green on its first run (every non-local test and golden
+// forward), and NOT faster - 0.0995 against 0.0990 ms at configs[1], 0.956 - 0.981 against 0.961 - 0.966 at 1080p fp32, 0.413 - 0.417 against 0.417 - 0.423 at
+// 1080p bf16 (profiles/r06_nl_tr.txt): halving the bytes a key tile pulls through the CU's port does not move a kernel whose matrix pipe is 79 % busy at 1080p
+// (and whose 16 tiles per workgroup at configs[1] sit between a query prologue and a 96 x 96 f32-MFMA epilogue); its reads conflict on this tile's 208-byte
+// rows (SQ_LDS_BANK_CONFLICT 5.0e7 per launch, 0 without).  The product library does not instantiate it: build with -DNF_TR_BUILD (tools/build_variant.sh) and
+// run with PFNL_NL_TR=1 to reproduce.
+#ifdef NF_TR_BUILD
+#define NF_TR_INSTANCES 1
+#else
+#define NF_TR_INSTANCES 0
+#endif
 
 constexpr float NF_XSCALE = 128.0f;                       // 2^7 on K, V and Q
 constexpr float NF_SINV = 1.0f / (128.0f * 128.0f);       // logits leave the MFMA scaled by 2^14
@@ -95,7 +106,9 @@ __global__ __launch_bounds__(256) void nl_pack_f16_kernel(const float* __restric
         const unsigned short lo = bf16_bits(v - bf16_float(hi));
         // key rows up to Npad (>= the last tile's end).  Keys past N carry -65504 in the pad channel C: a query operand with a
         // positive entry there (nl_attn_f16_sw_kernel: 1024) gets a logit of -4 000 for them - the key mask as DATA, no code
-        Khi[((size_t)b * Npad + n) * NF_CP + c] = (n >= N && c == C) ? (unsigned short)0xfbff : hi;
+        // channel C + 1 = 1.0 for every key: the row-sum ("ones") channel of the TR form of the kernel, which reads its P V operands out of the K tile
+        // (nl_attn_f16_sw_kernel<C, SPLIT, true>); the query operand is 0 there, so the logits of either form do not see it
+        Khi[((size_t)b * Npad + n) * NF_CP + c] = (n >= N && c == C) ? (unsigned short)0xfbff : (c == C + 1 ? (unsigned short)0x3c00 : hi);
         Klo[((size_t)b * Npad + n) * NF_CP + c] = lo;
         // position of key kk inside its 32-block: key = (e&3) + 8(2t + (e>>2)) + 4kh  ->  pos = 16t + 8kh + e
         const int e = (kk & 3) | (((kk >> 3) & 1) << 2), kh = (kk >> 2) & 1, t = kk >> 4;
@@ -146,20 +159,35 @@ __global__ __launch_bounds__(256) void nl_pack_f16_kernel(const float* __restric
 // ride on the MFMA gaps of half-body b.  A wave waits for its own pieces of tile t + 1 in front of that barrier with `s_waitcnt
 // vmcnt((NSLOT - 3) x pieces per wave)`: the counter retires in issue order and every wave issues the same number of pieces per tile (past
 // the last tile: against an empty resource), so the count is exact.
-template <bool SPLIT>
+// TR (round 6): the tile is the K rows ONLY - the P V operands (per lane 8 keys of one channel: a column of the K tile) come out of them by the
+// transposing read ds_read_b64_tr_b16 (tools/ubench/ds_tr_b16.hip has its law), so V^T is neither packed, nor moved, nor held: half the bytes a tile pulls
+// through the CU's port (what bounds the split form), a ring of 5 / 8 tiles.
+template <bool SPLIT, bool TR = false>
 struct NfSW {
     static constexpr int KLO_OFF = NF_KT * NF_KROW;                                    // 13 312 (split only)
     static constexpr int VHI_OFF = SPLIT ? 2 * NF_KT * NF_KROW : NF_KT * NF_KROW;      // 26 624 | 13 312
     static constexpr int VLO_OFF = VHI_OFF + NF_CP * NF_VROW;                          // + 13 824 (split only)
-    static constexpr int TILE_BYTES = SPLIT ? VLO_OFF + NF_CP * NF_VROW : VLO_OFF;     // 54 272 | 27 136
-    static constexpr int NSLOT = SPLIT ? 3 : 5;
-    static constexpr int PIECES = SPLIT ? 53 : 32;                                     // 1 KB DMA instructions per tile (hi only: 27 carry data)
-    static constexpr int SLOT_BYTES = PIECES * 1024;                                   // 54 272 | 32 768
-    static constexpr int PW = (PIECES + 7) / 8;                                        // per wave: 7 (waves 5-7: 6) | 4
-    static constexpr int LDS_BYTES = NSLOT * SLOT_BYTES;                               // 162 816 | 163 840
+    static constexpr int TILE_BYTES = TR ? VHI_OFF : (SPLIT ? VLO_OFF + NF_CP * NF_VROW : VLO_OFF);   // 54 272 | 27 136; TR: 26 624 | 13 312
+    static constexpr int NSLOT = TR ? (SPLIT ? 5 : 8) : (SPLIT ? 3 : 5);
+    static constexpr int PIECES = TR ? (SPLIT ? 32 : 16) : (SPLIT ? 53 : 32);          // 1 KB DMA instructions per tile (hi only: 27 carry data; TR: 26 | 13)
+    static constexpr int SLOT_BYTES = PIECES * 1024;                                   // 54 272 | 32 768; TR: 32 768 | 16 384
+    static constexpr int PW = (PIECES + 7) / 8;                                        // per wave: 7 (waves 5-7: 6) | 4; TR: 4 | 2
+    static constexpr int LDS_BYTES = NSLOT * SLOT_BYTES;                               // 162 816 | 163 840; TR: 163 840 | 131 072
     static_assert(TILE_BYTES <= SLOT_BYTES && LDS_BYTES <= 160 * 1024, "LDS budget");
-    static_assert(SPLIT || PIECES % 8 == 0, "the vmcnt wait of the hi-only ring counts on equal shares");
+    static_assert((SPLIT && !TR) || PIECES % 8 == 0, "the vmcnt wait of a ring deeper than 3 counts on equal shares");
 };
+
+// P V operand of a v_mfma_f32_32x32x16_f16 out of K rows: `p` = this lane's piece address for the operand's first four keys (row k0 + 4 kh + ((lane & 15) >> 2),
+// channels c0 + 16 ((lane >> 4) & 1) + 4 (lane & 3) .. + 3); the second four keys are 8 rows on.  Lane (i = lane & 31, kh) receives keys k0 + 4 kh + {0..3, 8..11}
+// of channel c0 + i - the order the S^T accumulator registers 8 t .. 8 t + 7 hold them in (tools/ubench/ds_tr_b16.hip checks exactly this addressing).
+typedef __fp16 nf_fp4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef unsigned nf_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x8 nf_tr_operand(const unsigned char* p) {
+    typedef __attribute__((address_space(3))) nf_fp4 lds_fp4;
+    const nf_u2 a = __builtin_bit_cast(nf_u2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp4*)(p)));
+    const nf_u2 b = __builtin_bit_cast(nf_u2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp4*)(p + 8 * NF_KROW)));
+    return __builtin_bit_cast(bf16x8, u32x4{a.x, a.y, b.x, b.y});
+}
 
 __device__ __forceinline__ void nf_dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds_dst, int voff) {
     unsigned keep;
@@ -175,16 +203,16 @@ __device__ long long np_dbg[256 * 2 * 128];
 #endif
 
 // K16 = Khi (the lowest address of the scratch); rel_* = byte offsets of Klo, Vthi, Vtlo from it; scratch_bytes = the whole allocation
-template <int C, bool SPLIT>
+template <int C, bool SPLIT, bool TR>
 __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_sw_kernel(const float* __restrict__ X, const uint16_t* __restrict__ K16,
                                                                  unsigned rel_klo, unsigned rel_vhi, unsigned rel_vlo, unsigned scratch_bytes,
                                                                  float* __restrict__ Xo, const float* __restrict__ Wp,
                                                                  const float* __restrict__ bp, float* __restrict__ Zp,
                                                                  float* __restrict__ ML, int N, int Npad, int q0, int q1) {
-    using G = NfSW<SPLIT>;
+    using G = NfSW<SPLIT, TR>;
     constexpr int CT = 3;
     constexpr int CP = (C + 31) / 32 * 32;                          // row stride of X / Xo / Wp (nl_padded_ch)
-    static_assert(C < NF_CP && C % 2 == 0, "needs a pad channel inside 96");
+    static_assert(C + 1 < NF_CP && C % 2 == 0, "needs two pad channels inside 96");
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];   // NSLOT tiles: K hi | (K lo) | V^T hi | (V^T lo)
 
     const int tid = threadIdx.x;
@@ -216,7 +244,8 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_sw_kernel(const flo
             qh[ks][e] = h;
             if constexpr (SPLIT) ql[ks][e] = (_Float16)(v - (float)h);
         }
-    constexpr int LCT = C / 32, LI = C % 32;                        // where the row-sum channel C lives in the D layout
+    constexpr int CS = TR ? C + 1 : C;                              // the row-sum ("ones") channel: V^T's channel C; TR: K's channel C + 1 (C is the key mask)
+    constexpr int LCT = CS / 32, LI = CS % 32;                      // where it lives in the D layout
     constexpr int LKH = (LI % 8) >= 4 ? 1 : 0, LR = (LI / 8) * 4 + (LI % 8) % 4;
 
     f32x16 o[CT];
@@ -241,7 +270,7 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_sw_kernel(const flo
             if (col < NF_CP * 2) {
                 sr = (int)((lo ? rel_klo : 0u) + (unsigned)(((size_t)b * Npad + row) * (NF_CP * 2)) + col);
             }
-        } else if (p < G::TILE_BYTES) {
+        } else if (!TR && p < G::TILE_BYTES) {
             const bool lo = SPLIT && p >= G::VLO_OFF;
             const int r = p - (lo ? G::VLO_OFF : G::VHI_OFF);
             const int ch = r / NF_VROW, col = r - ch * NF_VROW;
@@ -258,7 +287,7 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_sw_kernel(const flo
         if (G::PIECES % 8 == 0 || 8 * k + 7 < G::PIECES || i < G::PIECES) {   // (wave-uniform; split: waves 5-7 have no seventh piece)
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(K16), 0, live ? scratch_bytes : 0, 0x00020000);
             const int k0 = kt * NF_KT;
-            const bool isk = i * 1024 < (SPLIT ? 2 : 1) * NF_KT * NF_KROW;   // (the K | V^T boundary is a multiple of 1024)
+            const bool isk = TR || i * 1024 < (SPLIT ? 2 : 1) * NF_KT * NF_KROW;   // (the K | V^T boundary is a multiple of 1024)
             const int off = (int)((unsigned)srel[k] + (unsigned)(k0 * (isk ? NF_CP * 2 : 2)));   // (a pad chunk stays past the range)
             nf_dma16(rs, lds0 + slot * G::SLOT_BYTES + i * 1024, off);
         }
@@ -310,18 +339,22 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_sw_kernel(const flo
         // S^T(h + 1): key rows 32 (1 - H) .. of `qbuf`;  P V(h - 1): V^T keys 32 (1 - H) .. of `vbuf`, P^T = pt[1 - H]
         const unsigned char* const kah = qbuf + ((1 - H) * 32 + xl) * NF_KROW + kh * 16;
         const unsigned char* const vah = vbuf + G::VHI_OFF + xl * NF_VROW + kh * 16 + (1 - H) * 64;
+        // TR: this lane's piece of the first P V operand of the half (keys 32 (1 - H) ..; + 16 keys per key step jj, + 64 bytes per channel tile ct)
+        [[maybe_unused]] const unsigned char* const vtr = vbuf + ((1 - H) * 32 + 4 * kh + ((lane & 15) >> 2)) * NF_KROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
         auto read = [&](auto qc) __attribute__((always_inline)) {
             constexpr int q = decltype(qc)::value;
             if constexpr (q < NR) {
                 constexpr int d = q % RING;
                 if constexpr (!SPLIT) {
                     if constexpr (q < 6) rb[d] = *reinterpret_cast<const bf16x8*>(kah + q * 32);
+                    else if constexpr (TR) rb[d] = nf_tr_operand(vtr + ((q - 6) / 3) * 16 * NF_KROW + ((q - 6) % 3) * 64);
                     else rb[d] = *reinterpret_cast<const bf16x8*>(vah + ((q - 6) % 3) * 32 * NF_VROW + ((q - 6) / 3) * 32);
                 } else {
                     if constexpr (q < 12) rb[d] = *reinterpret_cast<const bf16x8*>(kah + (q & 1) * G::KLO_OFF + (q >> 1) * 32);
                     else {
                         constexpr int u = (q - 12) >> 1, lo = (q - 12) & 1;   // u = 3 jj + ct
-                        rb[d] = *reinterpret_cast<const bf16x8*>(vah + lo * (G::VLO_OFF - G::VHI_OFF) + (u % 3) * 32 * NF_VROW + (u / 3) * 32);
+                        if constexpr (TR) rb[d] = nf_tr_operand(vtr + lo * G::KLO_OFF + (u / 3) * 16 * NF_KROW + (u % 3) * 64);
+                        else rb[d] = *reinterpret_cast<const bf16x8*>(vah + lo * (G::VLO_OFF - G::VHI_OFF) + (u % 3) * 32 * NF_VROW + (u / 3) * 32);
                     }
                 }
             }
@@ -528,14 +561,16 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_sw_kernel(const flo
     }
     {   // the last half's P V
         const unsigned char* const vah = sm + s_prv * G::SLOT_BYTES + G::VHI_OFF + xl * NF_VROW + kh * 16 + 64;
+        [[maybe_unused]] const unsigned char* const vtr = sm + s_prv * G::SLOT_BYTES + (32 + 4 * kh + ((lane & 15) >> 2)) * NF_KROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                const bf16x8 vh = *reinterpret_cast<const bf16x8*>(vah + ct * 32 * NF_VROW + jj * 32);
+                const bf16x8 vh = TR ? nf_tr_operand(vtr + jj * 16 * NF_KROW + ct * 64) : *reinterpret_cast<const bf16x8*>(vah + ct * 32 * NF_VROW + jj * 32);
                 o[ct] = NP_MFMA(vh, pt[1][jj], o[ct]);
                 if constexpr (SPLIT) {
-                    const bf16x8 vl = *reinterpret_cast<const bf16x8*>(vah + (G::VLO_OFF - G::VHI_OFF) + ct * 32 * NF_VROW + jj * 32);
+                    const bf16x8 vl = TR ? nf_tr_operand(vtr + G::KLO_OFF + jj * 16 * NF_KROW + ct * 64)
+                                         : *reinterpret_cast<const bf16x8*>(vah + (G::VLO_OFF - G::VHI_OFF) + ct * 32 * NF_VROW + jj * 32);
                     o[ct] = NP_MFMA(vh, pl[1][jj], o[ct]);
                     o[ct] = NP_MFMA(vl, pt[1][jj], o[ct]);
                 }
@@ -690,28 +725,44 @@ static hipError_t nl_attn_f16_run(const float* X, float* Xo, const float* Wp, co
     // the kernel addresses the four packed arrays as ONE buffer resource with 32-bit offsets and an out-of-range sentinel of 2^31 - 1:
     // a batch whose packed operands reach 2 GB (> 2.7 M keys) runs in clip chunks (see below)
     const size_t scratch_bytes = 2 * nl_f16_scratch_halfs(B, N);
+    // TR (round 6): the P V operands out of the K tile by ds_read_b64_tr_b16 - no V^T arrays in the tile (PFNL_NL_TR=0: the form with V^T tiles)
+    static const bool use_tr = [] {
+        const char* e = std::getenv("PFNL_NL_TR");
+        return NF_TR_INSTANCES && e && e[0] != '0';
+    }();
     static std::atomic<int> attr_sw[64];
     if (!attr_sw[dev]) {
-        for (const void* fn : {reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<84, true>), reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<60, true>),
-                               reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<36, true>)}) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NfSW<true>::LDS_BYTES);
-            if (e != hipSuccess) return e;
-        }
-        for (const void* fn : {reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<84, false>), reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<60, false>),
-                               reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<36, false>)}) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NfSW<false>::LDS_BYTES);
+        const void* const fns[12] = {
+            reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<84, true, false>), reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<60, true, false>),
+            reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<36, true, false>), reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<84, false, false>),
+            reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<60, false, false>), reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<36, false, false>),
+#if NF_TR_INSTANCES
+            reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<84, true, true>), reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<60, true, true>),
+            reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<36, true, true>), reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<84, false, true>),
+            reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<60, false, true>), reinterpret_cast<const void*>(nl_attn_f16_sw_kernel<36, false, true>)
+#endif
+        };
+        const int lds[4] = {NfSW<true, false>::LDS_BYTES, NfSW<false, false>::LDS_BYTES, NfSW<true, true>::LDS_BYTES, NfSW<false, true>::LDS_BYTES};
+        for (int i = 0; i < (NF_TR_INSTANCES ? 12 : 6); ++i) {
+            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, lds[i / 3]);
             if (e != hipSuccess) return e;
         }
         attr_sw[dev] = 1;
     }
     const unsigned rel_klo = (unsigned)((Klo - Khi) * 2), rel_vhi = (unsigned)((Vthi - Khi) * 2), rel_vlo = (unsigned)((Vtlo - Khi) * 2);
-#define NP_LAUNCH(C_, S_) hipLaunchKernelGGL((nl_attn_f16_sw_kernel<C_, S_>), grid, block, NfSW<S_>::LDS_BYTES, s, X, Khi, rel_klo, rel_vhi, rel_vlo, \
-                                             (unsigned)scratch_bytes, Xo, Wp, bp, Zp, ML, N, npad, q0, q1)
+#define NP_LAUNCH(C_, S_, T_) hipLaunchKernelGGL((nl_attn_f16_sw_kernel<C_, S_, T_>), grid, block, (NfSW<S_, T_>::LDS_BYTES), s, X, Khi, rel_klo, rel_vhi, rel_vlo, \
+                                                 (unsigned)scratch_bytes, Xo, Wp, bp, Zp, ML, N, npad, q0, q1)
+#if NF_TR_INSTANCES
+#define NP_LAUNCH2(C_, S_) do { if (use_tr) NP_LAUNCH(C_, S_, true); else NP_LAUNCH(C_, S_, false); } while (0)
+#else
+#define NP_LAUNCH2(C_, S_) do { (void)use_tr; NP_LAUNCH(C_, S_, false); } while (0)
+#endif
     switch (C) {
-        case 84: if (split) NP_LAUNCH(84, true); else NP_LAUNCH(84, false); break;
-        case 60: if (split) NP_LAUNCH(60, true); else NP_LAUNCH(60, false); break;
-        case 36: if (split) NP_LAUNCH(36, true); else NP_LAUNCH(36, false); break;
+        case 84: if (split) NP_LAUNCH2(84, true); else NP_LAUNCH2(84, false); break;
+        case 60: if (split) NP_LAUNCH2(60, true); else NP_LAUNCH2(60, false); break;
+        case 36: if (split) NP_LAUNCH2(36, true); else NP_LAUNCH2(36, false); break;
     }
+#undef NP_LAUNCH2
 #undef NP_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ks == 1) return e;
