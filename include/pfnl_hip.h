@@ -119,7 +119,8 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *   workgroup): conv3x3_c1c10_kernel leaves a part's share of conv10_i's sum as raw fp32 and c10_finalize_kernel adds the parts up in fixed
  *   order (+ leaky-relu, split format); the chain kernel recomputes the shared half per part.  Deterministic; batches that are whole rounds
  *   (configs[1]) run exactly as before (bit-identical); the clips of the whole rounds keep their bits, the cut chains differ from the uncut
- *   launch in summation order (oracle tolerance).  pfnl_plan: "chain2_split", whole_chains / split_parts / part_frames.
+ *   launch in summation order (oracle tolerance).  pfnl_plan: "chain2_split", whole_chains / split_parts / part_frames.  The bf16 trunk's two chained
+ *   launches and convmerge1's accumulating launch are cut the same way ("bf16_3_split").
  * key "split16_sf0" = "off" (default) | "on" (round 6): in the two-launch block ("chain2") the chain kernel writes the block's output - the
  *   next block's inp0 - a second time in the split format, and conv3x3_c1c10_kernel takes its halo from that copy by LDS-DMA in operand form
  *   (no fp32 -> binary16 split on the VALU, no register-staged commit).  Same operands in the same order: BIT-IDENTICAL results (tested).
@@ -190,7 +191,7 @@ int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes);
  * conv10_i, then the whole of conv2_i), "chain2_split" (the same with the chains of a last, partial round cut by frames: option
  * split16_splitchains) and "chain2_sf0" (the same with a split-format copy of every block's output so that the next block's
  * conv1_i takes its halo by LDS-DMA: option split16_sf0=on), "split16_3" / "split16_4", "winograd_ws3" / "winograd_ws4", "winograd_tile4",
- * "direct4"; bf16: "bf16_3", "bf16_4", "bf16_mid4".  The ONE statement of the dispatch rule: pfnl_forward runs it, pfnl_workspace_bytes sizes
+ * "direct4"; bf16: "bf16_3", "bf16_3_split", "bf16_4", "bf16_mid4".  The ONE statement of the dispatch rule: pfnl_forward runs it, pfnl_workspace_bytes sizes
  * from it, bench.py's byte model and the tests read it here.  The structure changes the summation order, hence the last bits: the same clip
  * gives bit-different (oracle-equal) results in a batch that takes "chain2" and alone ("mid4" / "small2"). */
 int pfnl_plan(pfnl_handle* h, int B, int H, int W, char* buf, size_t buflen);

@@ -442,7 +442,21 @@ TrunkPlan trunk_plan(const pfnl_handle* h, int B, int H, int W) {
         pl.fuse10 = h->bf16_fuse10 && !pl.bmid;
         pl.launches_per_block = pl.fuse10 ? 3 : 4;
         pl.c1x1_launches = pl.fuse10 ? 0 : 1;
-        pl.name = pl.bmid ? "bf16_mid4" : (pl.fuse10 ? "bf16_3" : "bf16_4");
+        if (pl.fuse10 && h->split_chains && T <= 7 && fits32) {        // SPLIT CHAINS of the two chained launches (the rule of the fp32 trunk below)
+            const int grid = conv_split16_grid();
+            const int R = pl.chains % grid;
+            if (pl.chains > grid && R > 0 && grid / R >= 2) {
+                const int s0 = std::min(T, grid / R), q = (T + s0 - 1) / s0, s = (T + q - 1) / q;
+                if (s >= 2) {
+                    pl.n_full = pl.chains - R;
+                    pl.split_s = s;
+                    pl.split_q = q;
+                    pl.launches_per_block += 1;                         // c10_finalize_bf16_kernel
+                    pl.c1x1_launches = 1;
+                }
+            }
+        }
+        pl.name = pl.bmid ? "bf16_mid4" : (pl.fuse10 ? (pl.split_s ? "bf16_3_split" : "bf16_3") : "bf16_4");
         return pl;
     }
     pl.strict = h->strict || h->strict_once || !h->weights_f16_ok;   // f32-MFMA kernels only
@@ -603,6 +617,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
         // tile times; conv10_i then runs as its own launch and the per-frame half deals out single tiles (bit-identical: this kernel
         // has one summation order)
         const bool bmid = pl.bmid, fuse10 = pl.fuse10;
+        if (pl.split_s && h->c10part.ensure((size_t)(pl.chains - pl.n_full) * pl.split_s * 8 * 32 * 64)) return fail(PFNL_ERR_NOMEM, "workspace allocation failed");
         for (int i = 0; i < c.num_block; ++i) {   // model/pfnl.py:65-71
             if (h->prof_mode == 2) {
                 h->prof_gate = prof_sampled(c.num_block, i);
@@ -619,8 +634,27 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
                     q.x_w = w16 + h->off16_c10[i];
                     q.x_bias = wd + h->off_c10_b[i];
                     q.x_out = ab;
+                    q.n_full = pl.n_full;
+                    q.split_s = pl.split_s;
+                    q.split_q = pl.split_q;
+                    q.partial = pl.split_s ? h->c10part.p : nullptr;
                 }
                 HIPCHK(launch_conv3x3_bf16(q, s));
+            }
+            if (fuse10 && pl.split_s) {   // split chains: the parts' raw conv10_i sums -> base (+ bias, leaky-relu, bf16) for the chains that were cut
+                ProfScope ps(h, s, PFNL_K_CONV1X1);
+                ConvBf16Params q{};
+                q.H = H;
+                q.W = W;
+                q.items = F;
+                q.add_div = T;
+                q.n_full = pl.n_full;
+                q.split_s = pl.split_s;
+                q.split_q = pl.split_q;
+                q.partial = h->c10part.p;
+                q.x_bias = wd + h->off_c10_b[i];
+                q.x_out = ab;
+                HIPCHK(launch_c10_finalize_bf16(q, s));
             }
             if (!fuse10) {   // conv10_i as a launch of its own
                 ProfScope ps(h, s, PFNL_K_CONV1X1);
@@ -635,6 +669,9 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
                 ProfScope ps(h, s, PFNL_K_CONV3X3);
                 ConvBf16Params q{a1, w16 + h->off16_c2b[i], wd + h->off_c2_b[i], ap, a0, a0, H, W, F, T, 1};
                 q.flat = bmid ? 1 : 0;
+                q.n_full = pl.n_full;
+                q.split_s = pl.split_s;
+                q.split_q = pl.split_q;
                 HIPCHK(launch_conv3x3_bf16(q, s));
             }
         }
@@ -1535,8 +1572,8 @@ int pfnl_plan(pfnl_handle* h, int B, int H, int W, char* buf, size_t buflen) {
     static const char* const a1[] = {"tiled", "stream", "split16"};
     char tmp[384];
     if (pl.bf16)
-        std::snprintf(tmp, sizeof tmp, "%s launches_per_block=%d c1x1=%d precision=bf16 tiles=%d chains=%d nl=%s nl_pack_fused=%d", pl.name, pl.launches_per_block,
-                      pl.c1x1_launches, pl.tiles8x32, pl.chains, nln[nlf], nl_fused);
+        std::snprintf(tmp, sizeof tmp, "%s launches_per_block=%d c1x1=%d precision=bf16 tiles=%d chains=%d whole_chains=%d split_parts=%d part_frames=%d nl=%s nl_pack_fused=%d",
+                      pl.name, pl.launches_per_block, pl.c1x1_launches, pl.tiles8x32, pl.chains, pl.split_s ? pl.n_full : pl.chains, pl.split_s, pl.split_q, nln[nlf], nl_fused);
     else
         std::snprintf(tmp, sizeof tmp, "%s launches_per_block=%d c1x1=%d precision=fp32 conv3x3=%s conv1x1=%s c10_fused=%d chain=%d sf0=%d strict=%d tiles=%d chains=%d "
                       "whole_chains=%d split_parts=%d part_frames=%d nl=%s nl_pack_fused=%d",

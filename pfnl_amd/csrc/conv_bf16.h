@@ -22,6 +22,11 @@ struct ConvBf16Params {
     // convmerge1 (accumulating mode; out == addend == x_out == nullptr): wpack = add_div consecutive packs (one per frame of
     // a clip), out_f32[clip] = act(sum_t conv(in[clip*add_div + t]; W_t) + bias), fp32 [items/add_div][H][W][64]
     float* out_f32;
+    // SPLIT CHAINS (third-generation kernel, modes 1 and 2; split_s = 0: off; conv_split16.h has the scheme): the first n_full (clip, tile) chains - a
+    // whole number of rounds of the grid - whole, each chain behind them cut by frames into split_s parts of <= split_q frames, one per workgroup.
+    // Mode 2: a part leaves its share of conv10_i's sum as raw fp32 in partial[slot] ([8][32][64] floats) and launch_c10_finalize_bf16 builds x_out
+    int n_full, split_s, split_q;
+    float* partial;
     int flat;                // addend launches on the third-generation kernel: 1 = deal the tiles out one by one instead of as chains of the add_div
                              // frames of a (clip, tile) (capi.hip, "MID shapes": fewer chains than workgroups); same result bit for bit
 };
@@ -31,6 +36,9 @@ hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s);
 hipError_t launch_conv3x3_bf16_v2(const ConvBf16Params& p, int mode, hipStream_t s);
 // the third-generation kernel (conv_bf16_v3.hip: the two halves of the workgroup half a tile period apart), same modes
 hipError_t launch_conv3x3_bf16_v3(const ConvBf16Params& p, int mode, hipStream_t s);
+// split chains: x_out[clip][tile of chain n_full + j] = bf16(lrelu(sum over the parts r of partial[j * split_s + r] + x_bias)) (p: H, W, items, add_div,
+// n_full, split_s, partial, x_bias, x_out)
+hipError_t launch_c10_finalize_bf16(const ConvBf16Params& p, hipStream_t s);
 hipError_t launch_conv1x1_bf16(const uint16_t* in, const uint16_t* wpack, const float* bias, uint16_t* out, int items, int T,
                                int HW, int act, hipStream_t s);
 hipError_t launch_cast_bf16_f32(const uint16_t* in, float* out, size_t n, hipStream_t s);   // n % 8 == 0

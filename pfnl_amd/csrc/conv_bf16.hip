@@ -590,7 +590,8 @@ hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s) {
             const char* e = std::getenv("PFNL_BF16_V3");
             return e ? std::atoi(e) : 12;
         }();
-        if (v3 == 1 || (v3 == 12 && mode != 0) || (v3 == 2 && mode == 2)) return launch_conv3x3_bf16_v3(p, mode, s);
+        if (p.split_s && mode == 0) return hipErrorInvalidValue;         // (split chains exist in the third generation's chained modes only)
+        if (p.split_s || v3 == 1 || (v3 == 12 && mode != 0) || (v3 == 2 && mode == 2)) return launch_conv3x3_bf16_v3(p, mode, s);
         return launch_conv3x3_bf16_v2(p, mode, s);
     }
     static std::atomic<int> attr_dev[64];                                  // the attribute is per device

@@ -98,10 +98,14 @@ __device__ long long b3_dbg[256 * 2 * 128];
 
 // MODE 0: out = act(conv + bias).  MODE 1 (conv2_i per-frame half): out = act(conv + bias + addend[item / add_div]) + resid.
 // MODE 2 (conv1_i + conv10_i): MODE 0, and per chain of add_div frames x_out = lrelu(sum_t W10_t out_t + x_bias).
-template <int MODE>
+// SPLIT (round 6, modes 1 and 2): split chains - behind the whole rounds of (clip, tile) chains every workgroup takes ONE part (frames [sp_f0, sp_f1)) of a
+// cut chain (conv_split16.h).  Mode 1: the part fetches the chain's addend pieces with its own first frame; mode 2: its share of conv10_i's sum leaves raw
+// (fp32, no bias, no activation) in p.partial[slot] and c10_finalize_bf16_kernel adds the parts.  A template parameter: the whole-round launches keep their stream.
+template <int MODE, bool SPLIT = false>
 __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16Params p) {
     constexpr bool FUSE = MODE == 1;
     constexpr bool WITH10 = MODE == 2;
+    static_assert(!SPLIT || MODE != 0, "split chains: the chained modes only");
     extern __shared__ __attribute__((aligned(16))) unsigned char b3_smem[];
     unsigned char* const wl = b3_smem + 2 * B3_TILE_BYTES;
     float* const bl = reinterpret_cast<float*>(b3_smem + 2 * B3_TILE_BYTES + B3_W_BYTES);
@@ -127,23 +131,32 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
     const int gT = ((FUSE && !p.flat) || WITH10) ? p.add_div : 1;
     const int nchains = per_item * (p.items / gT);
     const int xcd = blockIdx.x & 7, xj = blockIdx.x >> 3, cpx = gridDim.x >> 3;
-    const int per_xcd = (nchains + 7) >> 3;
+    const int n_full = SPLIT ? p.n_full : nchains;
+    const int per_xcd = (n_full + 7) >> 3;
     const int cbeg = xcd * per_xcd;
-    const int ccnt = min(per_xcd, nchains - cbeg);
-    if (xj >= ccnt) return;
-    const int nu = ((ccnt - xj + cpx - 1) / cpx) * gT;              // tiles of this workgroup
-    // a unit = (item, y0, x0) + its position (chain ci of this workgroup, frame f of the chain); all wave-uniform.  Stepping inside a
-    // chain is an increment; the three integer divisions (~450 cycles) happen once per chain, in an interval that has the slack.
-    struct Unit { int item, y0, x0, f, ci; };
+    const int ccnt = min(per_xcd, n_full - cbeg);
+    if (!SPLIT && xj >= ccnt) return;
+    const int nfc = (!SPLIT || xj < ccnt) ? (ccnt - xj + cpx - 1) / cpx : 0;   // whole chains of this workgroup
+    [[maybe_unused]] const int slot = xcd * cpx + xj;
+    const bool has_part = SPLIT && slot < (nchains - n_full) * p.split_s;
+    const int sp_chain = has_part ? n_full + slot / p.split_s : 0;
+    const int sp_f0 = has_part ? (slot % p.split_s) * p.split_q : 0, sp_f1 = has_part ? min(gT, sp_f0 + p.split_q) : 0;
+    const int nu = nfc * gT + (sp_f1 - sp_f0);                      // tiles of this workgroup
+    if (SPLIT && nu <= 0) return;
+    // a unit = (item, y0, x0) + its position (chain ci of this workgroup, frame f of the chain; the chain's frames are [f0, fe)); all wave-uniform.
+    // Stepping inside a chain is an increment; the three integer divisions (~450 cycles) happen once per chain, in an interval that has the slack.
+    struct Unit { int item, y0, x0, f, ci, f0, fe; };
     auto unit_head = [&](int ci) __attribute__((always_inline)) {
-        const int ch = cbeg + xj + ci * cpx;
+        const bool part = SPLIT && ci >= nfc;                       // (wave-uniform) this workgroup's part of a cut chain: its last item
+        const int ch = part ? sp_chain : cbeg + xj + ci * cpx;
         const int cl = ch / per_item;
         const int sp = ch - cl * per_item;
         const int ty = sp / tiles_x;
-        return Unit{cl * gT, ty * B3_TH, (sp - ty * tiles_x) * B3_TW, 0, ci};
+        const int f0 = part ? sp_f0 : 0;
+        return Unit{cl * gT + f0, ty * B3_TH, (sp - ty * tiles_x) * B3_TW, f0, ci, f0, part ? sp_f1 : gT};
     };
     auto unit_next = [&](const Unit& c) __attribute__((always_inline)) {
-        if (c.f + 1 < gT) return Unit{c.item + 1, c.y0, c.x0, c.f + 1, c.ci};
+        if (c.f + 1 < c.fe) return Unit{c.item + 1, c.y0, c.x0, c.f + 1, c.ci, c.f0, c.fe};
         return unit_head(c.ci + 1);
     };
 
@@ -229,7 +242,7 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     rq[2 * n + h] = __builtin_bit_cast(b3u4, __builtin_amdgcn_raw_buffer_load_b128(rsR, eoff, (ech + 8 * h) * 2, 0));
-                    if (un.f == 0) radd[n][h] = __builtin_bit_cast(b3u4, __builtin_amdgcn_raw_buffer_load_b128(rsA, eoff, (ech + 8 * h) * 2, 0));
+                    if (un.f == un.f0) radd[n][h] = __builtin_bit_cast(b3u4, __builtin_amdgcn_raw_buffer_load_b128(rsA, eoff, (ech + 8 * h) * 2, 0));
                 }
             }
         }
@@ -433,7 +446,17 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
                 for (int n = 0; n < 2; ++n)
                     bacc[n] = b3_mfma(__builtin_bit_cast(b3h8, xw[ks]), *reinterpret_cast<const b3h8*>(bp + n * 32 * 128), bacc[n]);
             }
-            if (cu.f == gT - 1) {                                   // (wave-uniform) the chain is complete: bias, leaky_relu, bf16, store; clear
+            if (SPLIT && cu.ci >= nfc && cu.f == cu.fe - 1) {       // (wave-uniform) a PART is complete: its raw fp32 sum -> partial[slot] ([row][column][64]); clear
+                float* const pt = p.partial + (size_t)slot * (B3_TH * B3_TW * 64) + (size_t)(2 * rp * B3_TW + (lane & 31)) * 64 + ech;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<f32x4*>(pt + n * (B3_TW * 64) + 4 * q) = f32x4{bacc[n][4 * q], bacc[n][4 * q + 1], bacc[n][4 * q + 2], bacc[n][4 * q + 3]};
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) bacc[n][r] = 0.f;
+                }
+            } else if (cu.f == cu.fe - 1) {                         // (wave-uniform) the chain is complete: bias, leaky_relu, bf16, store; clear
                 const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(p.x_out + (size_t)(item / gT) * H * W * 64, 0, item_bytes, 0x00020000);
                 const int sx = x0 + (lane & 31);
 #pragma unroll
@@ -470,15 +493,63 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
     }
 }
 
-template <int MODE>
+template <int MODE, bool SPLIT = false>
 static hipError_t b3_launch(const ConvBf16Params& p, int grid, int dev, hipStream_t s) {
     static std::atomic<int> attr_dev[64];
     if (!attr_dev[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16_v3_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16_v3_kernel<MODE, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_dev[dev] = 1;
     }
-    hipLaunchKernelGGL(conv3x3_bf16_v3_kernel<MODE>, dim3(grid), dim3(B3_THREADS), B3_LDS_BYTES, s, p);
+    hipLaunchKernelGGL((conv3x3_bf16_v3_kernel<MODE, SPLIT>), dim3(grid), dim3(B3_THREADS), B3_LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
+// split chains: the parts' raw conv10_i sums -> x_out (bf16).  8 workgroups per cut chain, thread = (pixel, 4-channel group), the parts added in the fixed
+// order r = 0 .. s-1, then + x_bias, leaky-relu, bf16 (the rounding point of the uncut launch)
+__global__ __launch_bounds__(256) void c10_finalize_bf16_kernel(ConvBf16Params p) {
+    const int H = p.H, W = p.W;
+    const int tiles_x = (W + B3_TW - 1) / B3_TW, tiles_y = (H + B3_TH - 1) / B3_TH;
+    const int per_item = tiles_x * tiles_y;
+    const int j = blockIdx.x >> 3, ch = p.n_full + j;
+    const int clip = ch / per_item, sp = ch - clip * per_item;
+    const int ty = sp / tiles_x, y0 = ty * B3_TH, x0 = (sp - ty * tiles_x) * B3_TW;
+    const int S = p.split_s;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int id = (blockIdx.x & 7) * 512 + it * 256 + threadIdx.x;
+        const int pix = id >> 4, c4 = id & 15;
+        const int y = y0 + pix / B3_TW, x = x0 + (pix & (B3_TW - 1));
+        const float* src = p.partial + ((size_t)j * S * (B3_TH * B3_TW) + pix) * 64 + c4 * 4;
+        f32x4 part[7];
+#pragma unroll
+        for (int r = 0; r < 7; ++r) part[r] = r < S ? *reinterpret_cast<const f32x4*>(src + (size_t)r * (B3_TH * B3_TW * 64)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 v = part[0];
+#pragma unroll
+        for (int r = 1; r < 7; ++r)
+            if (r < S) v += part[r];
+        v += *reinterpret_cast<const f32x4*>(p.x_bias + c4 * 4);
+        v = b3_lrelu4(v, 0.2f);
+        if (y < H && x < W) *reinterpret_cast<b3u2*>(p.x_out + (((size_t)clip * H + y) * W + x) * 64 + c4 * 4) = b3_to_bf16(v);
+    }
+}
+
+static bool b3_split_ok(const ConvBf16Params& p, int grid) {
+    const int T = p.add_div;
+    const long long nchains = (long long)((p.W + B3_TW - 1) / B3_TW) * ((p.H + B3_TH - 1) / B3_TH) * (p.items / T);
+    if (p.split_s < 2 || p.split_s > 7 || p.split_q < 1 || p.n_full < 0 || p.n_full % grid || p.n_full >= nchains) return false;
+    if ((long long)p.split_s * p.split_q < T || (long long)(p.split_s - 1) * p.split_q >= T) return false;
+    return (nchains - p.n_full) * p.split_s <= grid;
+}
+
+hipError_t launch_c10_finalize_bf16(const ConvBf16Params& p, hipStream_t s) {
+    if (!p.partial || !p.x_out || !p.x_bias || p.items < 1 || p.add_div < 1 || p.items % p.add_div) return hipErrorInvalidValue;
+    const int ncu = device_cu_count();
+    if (!ncu) return hipErrorUnknown;
+    const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;
+    if (!b3_split_ok(p, grid)) return hipErrorInvalidValue;
+    const long long nchains = (long long)((p.W + B3_TW - 1) / B3_TW) * ((p.H + B3_TH - 1) / B3_TH) * (p.items / p.add_div);
+    hipLaunchKernelGGL(c10_finalize_bf16_kernel, dim3((unsigned)(nchains - p.n_full) * 8), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
@@ -490,6 +561,10 @@ hipError_t launch_conv3x3_bf16_v3(const ConvBf16Params& p, int mode, hipStream_t
     const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;                    // whole XCDs; surplus workgroups exit at once
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (p.split_s) {                                                // split chains: the chained modes only, geometry as the kernels assume it
+        if (mode == 0 || p.flat || !b3_split_ok(p, grid) || (mode == 2 && !p.partial)) return hipErrorInvalidValue;
+        return mode == 1 ? b3_launch<1, true>(p, grid, dev, s) : b3_launch<2, true>(p, grid, dev, s);
+    }
     if (mode == 1) return b3_launch<1>(p, grid, dev, s);
     if (mode == 2) return b3_launch<2>(p, grid, dev, s);
     return b3_launch<0>(p, grid, dev, s);

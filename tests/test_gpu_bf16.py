@@ -134,6 +134,42 @@ def test_forward_bf16_mid_shapes_take_the_per_tile_structure(B, H, W, nb):
     assert synth.psnr(y, y_fused) > 55.0
 
 
+@pytest.mark.parametrize("T,scale,nb,H,W,Bs", [(7, 4, 2, 128, 128, (4, 5, 6, 9)), (7, 4, 2, 100, 130, (5,)), (5, 2, 2, 96, 128, (7,)), (3, 4, 2, 90, 98, (11,))])
+def test_forward_bf16_split_chains(T, scale, nb, H, W, Bs):
+    """Round 6: split chains in the bf16 trunk (option split16_splitchains, conv_bf16_v3.hip SPLIT; reference model/pfnl.py:44, 55, 65-71).  A batch whose
+    (clip, tile) chains are not a whole number of rounds of the grid ran its last round at the price of a whole one (5 clips of 128x128: 1.52x the
+    time of 4); the chains of that round are cut by frames - conv1_i + conv10_i leaves a part's raw conv10_i sum, c10_finalize_bf16_kernel adds the parts
+    (+ bias, leaky-relu, the bf16 rounding point of the uncut launch), the per-frame half fetches the addend per part.  Every batch: repeatable bit
+    for bit, against the oracle with the same rounding points, and within bf16 rounding of the uncut launch (conv10_i's summation order moves the fp32
+    sum in front of its rounding); whole rounds keep plan and bits."""
+    geom = PFNLGeometry(num_frames=T, scale=scale, num_block=nb)
+    w = synth.synthetic_weights(geom, seed=T)
+    eng = PFNLEngine(geom, device=0)
+    eng.load_weights(w)
+    eng.set_option("precision", "bf16")
+    fo = pfnl_fast.FastOracle(w, T, scale, nb, trunk_dtype="bf16")
+    chains_clip = ((W + 31) // 32) * ((H + 7) // 8)
+    for B in Bs:
+        x, _ = synth.moving_field_clips(B, T, H, W, scale, seed=3)
+        pl = eng.plan(B, H, W)
+        R = (B * chains_clip) % 256
+        cut = B * chains_clip > 256 and 0 < R <= 128 and min(T, 256 // R) >= 2
+        assert pl["structure"] == ("bf16_3_split" if cut else "bf16_3"), (B, pl)
+        y = eng.forward(x)
+        assert np.array_equal(y, eng.forward(x)), B
+        eng.set_option("split16_splitchains", "off")
+        assert eng.plan(B, H, W)["structure"] == "bf16_3"
+        y_off = eng.forward(x)
+        eng.set_option("split16_splitchains", "auto")
+        if cut:
+            assert pl["launches_per_block"] == 4 and pl["c1x1"] == 1 and pl["split_parts"] * pl["part_frames"] >= T
+            assert synth.psnr(y, y_off) > 60.0, (B, synth.psnr(y, y_off))
+        else:
+            assert np.array_equal(y.view(np.uint32), y_off.view(np.uint32)), B
+        assert synth.psnr(y, fo.forward(x)) > 55.0, B
+    eng.close()
+
+
 def test_forward_bf16_1080p_against_oracle_subsample():
     """BASELINE.json configs[3] (1080p, bf16) against the ORACLE with the same rounding points
     (oracle/pfnl_fast.py trunk_dtype="bf16"): every 8th HR pixel + a dense 64x64 crop, generated once in the build

@@ -1,6 +1,6 @@
 """ms per forward against the batch size at 7x128x128 (64 (clip, tile) chains per clip, 256 workgroups): the cliff behind every whole round of
 chains, with the chains of a partial round cut by frames (option split16_splitchains=auto, the default) and uncut (off).  DESIGN.md R6.4.
-usage: python tools/batch_cliff.py [H] [W]"""
+usage: python tools/batch_cliff.py [H] [W] [precision]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,9 +10,11 @@ from pfnl_amd.spec import PFNLGeometry
 
 H = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+prec = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 g = PFNLGeometry()
 e = PFNLEngine(g)
 e.load_weights(synth.synthetic_weights(g, seed=0))
+e.set_option("precision", prec)
 st = torch.cuda.current_stream().cuda_stream
 
 
@@ -43,5 +45,5 @@ for B in (3, 4, 5, 6, 7, 8, 9, 10, 12):
     b = ms(B)
     if B == 4:
         base = (a, b)
-    print("%-3d %-16s %7.3f  %7.3f   %s" % (B, pl["structure"] + ("(%d x %d)" % (pl["split_parts"], pl["part_frames"]) if pl["split_parts"] else ""), a, b,
+    print("%-3d %-16s %7.3f  %7.3f   %s" % (B, pl["structure"] + ("(%d x %d)" % (pl["split_parts"], pl["part_frames"]) if pl.get("split_parts") else ""), a, b,
                                             ("%.2f       %.2f      %.2f" % (a / base[0], b / base[1], B / 4.0)) if base else ""), flush=True)

@@ -51,6 +51,18 @@ def run(seed=0, seconds=60.0):
             eng.set_option("strict_fp32", "off")
             worst_strict = max(worst_strict, ds)
             assert ds < 1e-4, ("cut vs strict", key, B, H, W, pl, ds)
+        if pl["structure"] == "chain2_split":                         # the bf16 trunk cuts the same chains (conv_bf16_v3.hip SPLIT): repeatable, within bf16
+            eng.set_option("precision", "bf16")                      # rounding of its uncut launch
+            p16 = eng.plan(B, H, W)
+            assert p16["structure"] == "bf16_3_split", p16
+            y16 = eng.forward(x)
+            assert np.isfinite(y16).all() and np.array_equal(y16, eng.forward(x)), ("bf16 not repeatable", key, B, H, W, p16)
+            eng.set_option("split16_splitchains", "off")
+            y16u = eng.forward(x)
+            eng.set_option("split16_splitchains", "auto")
+            eng.set_option("precision", "fp32")
+            ps = synth.psnr(y16, y16u)
+            assert ps > 55.0 and synth.psnr(y16, y) > 50.0, ("bf16 cut vs uncut", key, B, H, W, ps)
         n += 1
     return n, ncut, worst, worst_strict, parts
 
