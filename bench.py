@@ -44,6 +44,11 @@ SUSTAINED_F16_MFMA_TFLOPS = 1500.0
 # residual lines, output lines: 5.5 - 5.8 TB/s of compulsory bytes, ~11 B per clock and CU (tools/ubench/cu_stream_mix.hip,
 # profiles/r04_ubench_cu_stream_mix.txt).  Context next to `frac` (which is priced on the 8 TB/s spec), not a substitute for it.
 STREAM_MIX_CEILING_GBS = 5600.0
+# the package power cap as a roofline (tools/ubench/energy_mix.hip, profiles/r06_ubench_energy_mix.txt): a launch that runs f16 MFMAs on data-like
+# operands next to an HBM stream takes t = a F + b B - the matrix pipe alone sustains 1 / a = 1.67 - 1.74 PFLOP/s at 1.7 GHz under the 1 400 W
+# cap, and every HBM byte costs the time of ~210 MFMA FLOPs on top (NOT max(t_mfma, t_bytes): at the trunk's mixes that would be 1.4 - 1.6x less)
+POWER_CAP_MS_PER_TFLOP = 0.587
+POWER_CAP_US_PER_GB = 123.0
 CU_PORT_B_PER_CLK = 11.2                                           # what a CU's memory port moved per shader clock with nothing else to do (ibid.)
 PREWARM_S = 0.3                                                    # untimed steps in front of the warm-up: the clock ramp of an idle chip
 T = 7
@@ -77,6 +82,16 @@ CONV3X3_KERNELS = {
              "half a tile period apart) + conv3x3_bf16_v2_kernel<0> (the shared half of conv2_i): direct 3x3 64->64, bf16 MFMA, fp32 "
              "accumulation, persistent", ["conv_bf16.hip", "conv_bf16_v2.hip", "conv_bf16_v3.hip"]),
 }
+
+
+def power_cap_model(executed_flops, moved_bytes, avg_ms):
+    """What a launch with this many executed MFMA FLOPs and HBM bytes takes on the power cap according to the micro-benchmark's fit (no LDS
+    operand reads, no VALU, no launch ramp: a floor), next to what it took."""
+    t = POWER_CAP_MS_PER_TFLOP * executed_flops / 1e12 + POWER_CAP_US_PER_GB * 1e-3 * moved_bytes / 1e9
+    return {"model_ms_per_launch": round(t, 4), "measured_ms_per_launch": round(avg_ms, 4), "model_over_measured": round(t / avg_ms, 4),
+            "ms_per_tflop": POWER_CAP_MS_PER_TFLOP, "us_per_gb": POWER_CAP_US_PER_GB,
+            "note": "t = a F + b B under the 1 400 W package cap, a and b measured by tools/ubench/energy_mix.hip (profiles/r06_ubench_energy_mix.txt): "
+                    "MFMAs on data-like operands + an HBM stream, nothing else; model_over_measured near 1 = the launch is at the chip's power roofline"}
 
 
 def kernel_source_sha(files):
@@ -254,7 +269,8 @@ def conv3x3_roofline(geom, prof, B, H, W, plan, workload):
                 "traffic": traffic, "kernel": name, "avg_launch_ms": round(avg_ms, 4), "launches_timed": k["launches"],
                 "launches_per_step": launches_per_step, "mbytes_per_launch": round(bytes_per_launch / 1e6, 2), "tiles_per_block": "5F+4B",
                 "stream_mix_ceiling_gbs": STREAM_MIX_CEILING_GBS, "hbm_vs_stream_mix_ceiling": round(gbs / STREAM_MIX_CEILING_GBS, 4),
-                "mfma_tflops": round(flops3 / launches_per_step / (avg_ms * 1e-3) / 1e12, 1), "mfma_peak_bf16_tflops": PEAK_F16_MFMA_TFLOPS}
+                "mfma_tflops": round(flops3 / launches_per_step / (avg_ms * 1e-3) / 1e12, 1), "mfma_peak_bf16_tflops": PEAK_F16_MFMA_TFLOPS,
+                "power_cap_model": power_cap_model((flops3 + geom.num_block * F * P * 64 * 64 * 2.0) / launches_per_step, bytes_per_launch, avg_ms)}
     # fp32: conv1_i + conv2_i; the default kernel runs the whole of conv2_i as one grouped launch, the others launch its
     # shared half and its per-frame half separately
     # launches of the class per PF block: 2 with conv2_i as one launch (Winograd's grouped mode; the split-f16 chain kernel), else 3
@@ -327,6 +343,7 @@ def conv3x3_roofline(geom, prof, B, H, W, plan, workload):
                     "mfma_sustained_ceiling_tflops": SUSTAINED_F16_MFMA_TFLOPS,
                     "mfma_executed_vs_sustained_ceiling": round(ex / SUSTAINED_F16_MFMA_TFLOPS, 4),
                     "algorithmic_vs_f32_mfma_roof": round(direct_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+                    "power_cap_model": power_cap_model(3.0 * flops_per_launch, bytes_per_launch + sf_copy, avg_ms),
                     "note": "frac = algorithmic bytes (or FLOPs) / time / peak.  mfma_executed_* counts the 3 f16 MFMAs a product block costs; "
                             "mfma_sustained_ceiling = what the chip sustains on this kernel's MFMA + LDS core alone under its power cap "
                             "(shader clock 1.3 - 1.6 GHz; profiles/r03_ubench_conv_core.txt)"})
