@@ -557,6 +557,12 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
             sf_dma16(rw_, ldsw + (slot_) * SF_SLOT_BYTES + (wave + 8 * k_) * 1024, (half_) * SF_W_BYTES + (slot_) * SF_SLOT_BYTES + wvoff + k_ * 8192); \
     } while (0)
 
+#ifdef PFNL_X_NOWSTREAM   /* timing experiment only (wrong results on purpose), as in conv_split16.hip */
+#define SFC_DMA_WX(pk_, half_, slot_) do {} while (0)
+#else
+#define SFC_DMA_WX(pk_, half_, slot_) SFC_DMA_W(pk_, half_, slot_)
+#endif
+
     int paddr[3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
@@ -696,7 +702,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
             __builtin_amdgcn_sched_barrier(0);
             // slice 2 of THIS unit's weights (its slot was free only after the previous unit's closing barrier), then the next
             // unit's halo; one fence load covers both (slice 2 is first read after b0, the halo after this unit's closing barrier)
-            if (w_slice2_owed) SFC_DMA_W(w_pk, half_u, 2);
+            if (w_slice2_owed) SFC_DMA_WX(w_pk, half_u, 2);
             const int q_f = PAR == 0 ? c_f : n_f, q_clip = PAR == 0 ? c_clip : n_clip, y0q = PAR == 0 ? c_y0 : n_y0, x0q = PAR == 0 ? c_x0 : n_x0;
             const float* const qsrc = q_f == 0 ? p.in2 + (size_t)q_clip * H * W * 64 : p.in + ((size_t)q_clip * T + (q_f - 1)) * H * W * 64;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qsrc), 0, item_bytes, 0x00020000);
@@ -747,7 +753,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
                         SFC_STAMP();                                // 2: fence passed
                         SFC_BARRIER();                              // b0: column tap 0 consumed; slice 2 complete
                         SFC_STAMP();                                // 3: past b0
-                        if (w_replace) SFC_DMA_W(nx_pk, nx_half, 0);
+                        if (w_replace) SFC_DMA_WX(nx_pk, nx_half, 0);
 #if SFC_SPREAD_HALO
                         SFC_DMA_HALO_PIECE(0, rs, org, interior, y0q, x0q, cb ^ 1);
 #endif
@@ -760,7 +766,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
                         SFC_STAMP();                                // 4: groups 2-3 done
                         SFC_BARRIER();                              // b1: column tap 1 consumed
                         SFC_STAMP();                                // 5: past b1
-                        if (w_replace) SFC_DMA_W(nx_pk, nx_half, 1);
+                        if (w_replace) SFC_DMA_WX(nx_pk, nx_half, 1);
                         fence_w = __builtin_amdgcn_raw_buffer_load_b32(rs, 0, 0, 0);   // covers slices 0 and 1 of the next unit's weights
                     }
                 }

@@ -983,6 +983,11 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
         _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_)                                         \
             k1_dma16(rw_, ldsw + (slot_) * CS_SLOT_BYTES + (wave + 8 * k_) * 1024, wvoff, (half_) * CS_W_BYTES + (slot_) * CS_SLOT_BYTES + k_ * 8192); \
     } while (0)
+#ifdef PFNL_X_NOWSTREAM   /* timing experiment only (wrong results on purpose): no weight replacement - what does the 73 KB per tile from L2 cost? */
+#define K1_DMA_WX(half_, slot_) do {} while (0)
+#else
+#define K1_DMA_WX(half_, slot_) K1_DMA_W(half_, slot_)
+#endif
 #define K1_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
     // ---- a finished row (n) of the workgroup's tile: leaky-relu, split, 128 pixel lines in `scratch`; optionally conv10_i's
@@ -1118,7 +1123,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
             [[maybe_unused]] unsigned fence_w = 0;
             const __amdgpu_buffer_rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, 256, 0x00020000);
             if constexpr (PAR == 1) {
-                K1_DMA_W(half_a ^ 1, 2);
+                K1_DMA_WX(half_a ^ 1, 2);
                 fence_w = __builtin_amdgcn_raw_buffer_load_b32(rsf, 0, 0, 0);
             }
             // the NEXT unit's halo: unit A asks for the other half of ITS tile, unit B for the first half of the next tile
@@ -1159,7 +1164,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
                     if constexpr (g == 2) {
                         if constexpr (PAR == 1) asm volatile("" ::"v"(fence_w));   // tap 2 of this unit's weights has landed
                         K1_BARRIER();                               // b0: column tap 0 of the weights consumed (unit B: tap 2 complete)
-                        if constexpr (PAR == 0) K1_DMA_W(half_a ^ 1, 0);
+                        if constexpr (PAR == 0) K1_DMA_WX(half_a ^ 1, 0);
                         if constexpr (ISF) {
                             // the next unit's halo by DMA, behind b0: unit A's target is the SCRATCH of the previous tile's serial phase, whose
                             // last line reads (row_pass(1)) no barrier followed - every wave has passed them here.  12 sub-steps to land.
@@ -1174,7 +1179,7 @@ __global__ __launch_bounds__(CS_THREADS, 1) void conv3x3_c1c10_kernel(ConvSplitP
                     if constexpr (g == 4) {
                         K1_BARRIER();                               // b1: column tap 1 consumed
                         if constexpr (PAR == 0) {
-                            K1_DMA_W(half_a ^ 1, 1);
+                            K1_DMA_WX(half_a ^ 1, 1);
                             fence_w = __builtin_amdgcn_raw_buffer_load_b32(rsf, 0, 0, 0);   // covers taps 0 and 1 of the next unit's weights
                         }
                         if constexpr (!ISF) {
