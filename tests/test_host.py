@@ -397,6 +397,31 @@ def test_bench_byte_model_matches_the_launch_structure_and_the_committed_traffic
     assert abs(rb["mbytes_per_launch"] * 1e6 - 270 * 480 * 128 * (5 * 7 + 4) / 3) < 1e4
 
 
+
+def test_bench_power_cap_model_and_the_committed_bench_line():
+    """under the package power cap a launch takes a F + b B (tools/ubench/energy_mix.hip measured a and b).  The model
+    is arithmetic on the launch's executed MFMA FLOPs (3 per product on the split-f16 path, conv10_i's included) and its HBM bytes - and
+    the newest committed bench line must sit at that roofline (within the +-5 % the boxes of the pool differ by, both ways)."""
+    import glob
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    g = PFNLGeometry()
+    B, H, W, F = 4, 128, 128, 28
+    pl = {"structure": "chain2", "launches_per_block": 2, "precision": "fp32", "conv3x3": "split16", "conv1x1": "split16", "c10_fused": 1, "chain": 1, "sf0": 0, "c1x1": 0}
+    rec = bench.conv3x3_roofline(g, {"conv3x3": {"ms": 0.108 * 20, "launches": 20}}, B, H, W, pl, "cfg2")
+    m = rec["power_cap_model"]
+    flops = 3.0 * (2 * F + B) * H * W * 9 * 64 * 64 * 2 / 2 + 3.0 * F * H * W * 64 * 64 * 2 / 2       # per launch: half a block's 3x3s + conv10_i
+    want = bench.POWER_CAP_MS_PER_TFLOP * flops / 1e12 + bench.POWER_CAP_US_PER_GB * 1e-3 * (H * W * 256 * (5 * F + 2 * B) / 2) / 1e9
+    assert abs(m["model_ms_per_launch"] - want) < 2e-4 and abs(m["measured_ms_per_launch"] - 0.108) < 1e-6, (m, want)
+    assert 0.10 < want < 0.11                                          # 106.5 us
+    newest = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_bench.json")))[-1]
+    line = json.loads(open(newest).read().strip().splitlines()[-1])
+    if "power_cap_model" in line["roofline"]:                          # (lines of the rounds before the model existed carry none)
+        assert 0.93 <= line["roofline"]["power_cap_model"]["model_over_measured"] <= 1.07, (newest, line["roofline"]["power_cap_model"])
+
 def test_bench_nonlocal_flop_model_and_hbm_classes():
     """bench.py's `roofline_nl` prices the affinity class on SURVEY.md 8(a)-C's FLOPs (4 N^2 C + 4 N C^2 per clip:
     5.75 GFLOP at configs[1], 353.6 at 1080p) and on what the kernel's MFMAs execute (channels padded to 96, x3 for exactly split operands,
