@@ -95,6 +95,30 @@ __global__ void k(int iters, long long* out, float* sink) {
 #define X(j) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v[j]) : "s"(sc));
             REP64(X)
 #undef X
+        } else if constexpr (OP == 16) {
+#define X(j) asm volatile("v_exp_f32 %0, %0" : "+v"(v[j]));
+            REP64(X)
+#undef X
+        } else if constexpr (OP == 17) {
+#define X(j) asm volatile("v_exp_f16 %0, %0" : "+v"(u[j]));
+            REP64(X)
+#undef X
+        } else if constexpr (OP == 18) {
+#define X(j) asm volatile("v_pk_fma_f16 %0, %0, %1, %0" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
+            REP64(X)
+#undef X
+        } else if constexpr (OP == 19) {
+#define X(j) asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(v[j]) : "v"(u[j]));
+            REP64(X)
+#undef X
+        } else if constexpr (OP == 20) {
+#define X(j) asm volatile("v_fract_f32 %0, %0" : "+v"(v[j]));
+            REP64(X)
+#undef X
+        } else if constexpr (OP == 21) {
+#define X(j) asm volatile("v_rcp_f32 %0, %0" : "+v"(v[j]));
+            REP64(X)
+#undef X
         }
     }
     const long long t1 = clock64();
@@ -139,6 +163,12 @@ int main() {
     run<4>("v_fma_mixlo_f16", out, sink);
     run<5>("v_fma_mixhi_f16", out, sink);
     run<9>("v_pk_mul_f16", out, sink);
+    run<16>("v_exp_f32", out, sink);
+    run<17>("v_exp_f16", out, sink);
+    run<21>("v_rcp_f32", out, sink);
+    run<18>("v_pk_fma_f16", out, sink);
+    run<19>("v_ldexp_f32", out, sink);
+    run<20>("v_fract_f32", out, sink);
     run<12>("ds_write_b64", out, sink);
     run<13>("ds_write_b128", out, sink);
     return 0;
