@@ -599,7 +599,13 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_sw_kernel(const flo
         for (int ct = 0; ct < CTW; ++ct) {
             const float* wa = Wp + (size_t)(ct * 32 + 4 * kh) * CP + cot * 32 + xl;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) z = mfma32(wa[((s & 3) + 8 * (s >> 2)) * CP], o[ct][s], z);
+            for (int s = 0; s < 16; ++s) {
+#ifdef NF_X_NOPROJ   /* timing experiment only (wrong results on purpose): what does the 96 x 96 projection on the f32 matrix pipe cost a launch? */
+                if (ct == cot) z[s] = o[ct][s] + (s == 0 ? wa[0] : 0.f);
+#else
+                z = mfma32(wa[((s & 3) + 8 * (s >> 2)) * CP], o[ct][s], z);
+#endif
+            }
         }
         if (q < q1) {
             if (ksp == 1) {
