@@ -19,7 +19,8 @@
 //   * P = exp2(S' - running max) in fp32, rounded to bf16 only as the MFMA operand; the row sum accumulates the SAME
 //     rounded values through the "ones" channel, so the normalisation is exact for what was summed;
 //   * V = X also as hi + lo (12 MFMAs per tile): a query dominated by one key returns that key's fp32 value;
-//   * running max / rescale, normalisation, the folded 1x1 projection (f32 MFMA) and the residual as in nonlocal.hip.
+//   * running max / rescale, normalisation and the residual as in nonlocal.hip; the folded 1x1 projection in the same split arithmetic (round 6:
+//     W' through LDS in operand form, O^T from the accumulators as the B operand - see the kernel's epilogue).
 // Operand layouts (lane = (l & 31, kh = l >> 5), 8 bf16 per lane and MFMA):
 //   K tile in LDS  [key][96 ch] (+ pad to 208 B: conflict-free b128 reads), hi and lo: A of S^T = K Q^T;
 //   Q in registers [6 k-steps] hi and lo, pre-scaled by log2(e): B of S^T;
@@ -50,7 +51,7 @@ constexpr int NF_QB = NF_THREADS / 2;     // queries per workgroup
 // The transposing-read form of nl_attn_f16_sw_kernel (round 6; TR = true below): built, parity-green on its first run (every non-local test and golden
 // forward), and NOT faster - 0.0995 against 0.0990 ms at configs[1], 0.956 - 0.981 against 0.961 - 0.966 at 1080p fp32, 0.413 - 0.417 against 0.417 - 0.423 at
 // 1080p bf16 (profiles/r06_nl_tr.txt): halving the bytes a key tile pulls through the CU's port does not move a kernel whose matrix pipe is 79 % busy at 1080p
-// (and whose 16 tiles per workgroup at configs[1] sit between a query prologue and a 96 x 96 f32-MFMA epilogue); its reads conflict on this tile's 208-byte
+// (and whose 16 tiles per workgroup at configs[1] sit between a query prologue and the 96 x 96 projection epilogue); its reads conflict on this tile's 208-byte
 // rows (SQ_LDS_BANK_CONFLICT 5.0e7 per launch, 0 without).  The product library does not instantiate it: build with -DNF_TR_BUILD (tools/build_variant.sh) and
 // run with PFNL_NL_TR=1 to reproduce.
 #ifdef NF_TR_BUILD
@@ -582,31 +583,70 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_sw_kernel(const flo
         const float lo = __shfl_xor(l, 32);
         if (kh != LKH) l = lo;
     }
-    const float inv = (ksp == 1) ? (1.0f / NF_XSCALE) / l : (1.0f / NF_XSCALE);   // V carries 2^7; l and O share the 2^14 of P
+    // V carries 2^7; l and O share the 2^14 of P.  O is normalised by its row sum for the projection in EITHER case - a key split's partial sums reach
+    // 2^14 x keys, beyond binary16 - and a partial result gets its l back behind the projection (nl_merge_kernel weighs the parts with their (m, l))
+    const float inv = (1.0f / NF_XSCALE) / l;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[ct][r] *= inv;
 
-    // Z^T = W'^T O^T on the f32 matrix pipe, as in nonlocal.hip (pad rows of W' are zero: the row-sum channel drops out)
+    // Z^T = W'^T O^T (the folded 1x1 projections, model/pfnl.py:58 -> utils.py:26,67) in the arithmetic of the rest of the kernel: both operands split
+    // into binary16 pairs (lo' = (v - hi) 2^11), 3 v_mfma_f32_32x32x16_f16 per product block, cross terms in a second accumulator.  (Until round 6 this was
+    // 16 v_mfma_f32_32x32x2_f32 per 32 x 32 x 32 block with W' fetched by every lane: 144 MFMAs of 64 cycles and 36 KB of loads PER WAVE - measured, with
+    // the projection removed, at 9 - 16 us of every launch whatever its size.)  W' goes through LDS once per workgroup, in operand form: pair g = (cot, ct, t)
+    // = the A operand of k-step t of channel tile ct for output tile cot, lane (m, kh) element i = W'[32 ct + 16 t + 4 kh + (i & 3) + 8 (i >> 2)][32 cot + m] -
+    // the channel order registers 8 t .. 8 t + 7 of an O^T accumulator hold (the P^T trick of the loop above), so O^T is the B operand as it stands.
     constexpr int CTW = CP / 32;
+    constexpr int NPAIR = CTW * CTW * 2;
+    static_assert(NPAIR * 2048 <= G::SLOT_BYTES * G::NSLOT, "W' in operand form fits the ring");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the ring's last (empty) requests have landed
+    __syncthreads();                                                // every wave is through its last P V: the ring is free
+    for (int pp = tid; pp < NPAIR * 64; pp += NF_THREADS) {
+        const int ln = pp & 63, g = pp >> 6;
+        const int t = g & 1, ctp = (g >> 1) % CTW, cotp = (g >> 1) / CTW;
+        const float* w = Wp + (size_t)(ctp * 32 + 16 * t + 4 * (ln >> 5)) * CP + cotp * 32 + (ln & 31);
+        bf16x8 h, l;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float v = w[((i & 3) + 8 * (i >> 2)) * CP];
+            const _Float16 hh = (_Float16)v;
+            h[i] = hh;
+            l[i] = (_Float16)((v - (float)hh) * 2048.0f);
+        }
+        *reinterpret_cast<bf16x8*>(sm + g * 2048 + ln * 16) = h;
+        *reinterpret_cast<bf16x8*>(sm + g * 2048 + 1024 + ln * 16) = l;
+    }
+    bf16x8 bh[CTW][2], bl[CTW][2];
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float v = o[ct][8 * t + i];
+                const _Float16 hh = (_Float16)v;
+                bh[ct][t][i] = hh;
+                bl[ct][t][i] = (_Float16)((v - (float)hh) * 2048.0f);
+            }
+    __syncthreads();
 #pragma unroll
     for (int cot = 0; cot < CTW; ++cot) {
-        f32x16 z;
+        f32x16 z, zc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        for (int r = 0; r < 16; ++r) z[r] = zc[r] = 0.f;
 #pragma unroll
-        for (int ct = 0; ct < CTW; ++ct) {
-            const float* wa = Wp + (size_t)(ct * 32 + 4 * kh) * CP + cot * 32 + xl;
+        for (int ct = 0; ct < CTW; ++ct)
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-#ifdef NF_X_NOPROJ   /* timing experiment only (wrong results on purpose): what does the 96 x 96 projection on the f32 matrix pipe cost a launch? */
-                if (ct == cot) z[s] = o[ct][s] + (s == 0 ? wa[0] : 0.f);
-#else
-                z = mfma32(wa[((s & 3) + 8 * (s >> 2)) * CP], o[ct][s], z);
-#endif
+            for (int t = 0; t < 2; ++t) {
+                const unsigned char* wa = sm + ((cot * CTW + ct) * 2 + t) * 2048 + lane * 16;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(wa), al = *reinterpret_cast<const bf16x8*>(wa + 1024);
+                z = NP_MFMA(ah, bh[ct][t], z);
+                zc = NP_MFMA(ah, bl[ct][t], zc);
+                zc = NP_MFMA(al, bh[ct][t], zc);
             }
-        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = (z[r] + zc[r] * (1.0f / 2048.0f)) * (ksp == 1 ? 1.0f : l);
         if (q < q1) {
             if (ksp == 1) {
 #pragma unroll
