@@ -199,8 +199,11 @@ __device__ __forceinline__ void nf_dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds
 #ifdef PFNL_NP_TIMING   /* phase timeline (tools/np_timing.py); not part of the product build */
 __device__ long long np_dbg[256 * 2 * 128];
 #define NP_STAMP() do { if (SPLIT == (PFNL_NP_TIMING != 0) && lane == 0 && (wave == 0 || wave == 4) && dbg_n < 128 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 256) np_dbg[(blockIdx.x * 2 + (wave != 0)) * 128 + dbg_n++] = __builtin_readcyclecounter(); } while (0)
+__device__ long long np_ph[256 * 8];                                // phases of a workgroup (tools/np_phases.py): constant-clock ticks (10 ns)
+#define NP_PHASE(i_) do { if (SPLIT == (PFNL_NP_TIMING != 0) && tid == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 256) np_ph[blockIdx.x * 8 + (i_)] = wall_clock64(); } while (0)
 #else
 #define NP_STAMP() do {} while (0)
+#define NP_PHASE(i_) do {} while (0)
 #endif
 
 // K16 = Khi (the lowest address of the scratch); rel_* = byte offsets of Klo, Vthi, Vtlo from it; scratch_bytes = the whole allocation
@@ -222,6 +225,7 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_sw_kernel(const flo
 #ifdef PFNL_NP_TIMING
     int dbg_n = 0;
 #endif
+    NP_PHASE(0);                                                    // entry
     const int xl = lane & 31;
     const int kh = lane >> 5;
     const int b = blockIdx.y;
@@ -541,6 +545,7 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_sw_kernel(const flo
             }
         }
     }
+    NP_PHASE(1);                                                    // query operands, first tiles: the loop starts
     for (int kt = kt0; kt < kt1; ++kt) {
         NP_STAMP();                                                 // 0
         const unsigned char* const cur = sm + s_cur * G::SLOT_BYTES;
@@ -560,6 +565,7 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_sw_kernel(const flo
         s_cur = s_nxt;
         s_nxt = s_nxt + 1 == G::NSLOT ? 0 : s_nxt + 1;
     }
+    NP_PHASE(2);                                                    // the loop is through
     {   // the last half's P V
         const unsigned char* const vah = sm + s_prv * G::SLOT_BYTES + G::VHI_OFF + xl * NF_VROW + kh * 16 + 64;
         [[maybe_unused]] const unsigned char* const vtr = sm + s_prv * G::SLOT_BYTES + (32 + 4 * kh + ((lane & 15) >> 2)) * NF_KROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
@@ -602,6 +608,7 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_sw_kernel(const flo
     static_assert(NPAIR * 2048 <= G::SLOT_BYTES * G::NSLOT, "W' in operand form fits the ring");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the ring's last (empty) requests have landed
     __syncthreads();                                                // every wave is through its last P V: the ring is free
+    NP_PHASE(3);
     for (int pp = tid; pp < NPAIR * 64; pp += NF_THREADS) {
         const int ln = pp & 63, g = pp >> 6;
         const int t = g & 1, ctp = (g >> 1) % CTW, cotp = (g >> 1) / CTW;
@@ -630,6 +637,7 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_sw_kernel(const flo
                 bl[ct][t][i] = (_Float16)((v - (float)hh) * 2048.0f);
             }
     __syncthreads();
+    NP_PHASE(4);                                                    // W' is in LDS
 #pragma unroll
     for (int cot = 0; cot < CTW; ++cot) {
         f32x16 z, zc;
@@ -669,6 +677,7 @@ __global__ __launch_bounds__(NF_THREADS, 2) void nl_attn_f16_sw_kernel(const flo
         ml[0] = m;
         ml[1] = l;
     }
+    NP_PHASE(5);                                                    // projection and stores issued
 }
 
 size_t nl_f16_scratch_halfs(int B, int N) {                        // Khi, Klo, Vthi, Vtlo
@@ -820,5 +829,8 @@ static hipError_t nl_attn_f16_run(const float* X, float* Xo, const float* Wp, co
 #ifdef PFNL_NP_TIMING
 extern "C" int pfnl_debug_read_np_stamps(long long* host, size_t n) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(pfnl::np_dbg), n * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+extern "C" int pfnl_debug_read_np_phases(long long* host, size_t n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(pfnl::np_ph), n * sizeof(long long)) == hipSuccess ? 0 : -1;
 }
 #endif
