@@ -29,6 +29,7 @@ struct Params {
     float* sink;
     long long* clk;           // per workgroup: shader cycles, constant-clock ticks (100 MHz)
     int steps, wrap;          // wrap: a wave's stream restarts every `wrap` steps (footprint = waves x wrap x L KB each way: Infinity-Cache- or L2-resident)
+    int rot;                  // operand rotation: 0 = as written (A changes every 4th MFMA, B every MFMA), 1 = the same A and B for every MFMA, 2 = both change every MFMA
     unsigned amask, bmask;    // and-masks on the operands' binary16 patterns (0xffff = data-like; fewer mantissa bits / zeros: does the power follow the data?)
 };
 
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(512, 1) void mix_kernel(Params p) {
                 asm volatile("" :: "v"(r));
                 if ((m & 7) == 7) b[(m >> 3) & 3] = r;              // (consumed now and then: the reads must really deliver)
             }
-            acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(m >> 2) & 3], b[(m + (m >> 4)) & 3], acc[m & 3], 0, 0, 0);
+            acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[p.rot == 1 ? 0 : p.rot == 2 ? (m & 3) : ((m >> 2) & 3)], b[p.rot == 1 ? 0 : ((m + (m >> 4)) & 3)], acc[m & 3], 0, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < L; ++j) {
@@ -181,6 +182,9 @@ int main() {
     }
     {   // does the matrix pipe's power follow its operands?  (not part of the fit)
         Params q = p;
+        q.rot = 1; run<32, 0, 0>("MFMA only, the SAME A and B every MFMA", q, ncu, cap_pieces_per_wave);
+        q.rot = 2; run<32, 0, 0>("MFMA only, A and B change every MFMA", q, ncu, cap_pieces_per_wave);
+        q.rot = 0;
         q.amask = q.bmask = 0xffc0u; run<32, 0, 0>("MFMA only, 5 mantissa bits in A and B", q, ncu, cap_pieces_per_wave);
         q.amask = 0xffffu; q.bmask = 0xffc0u; run<32, 0, 0>("MFMA only, 5 mantissa bits in B", q, ncu, cap_pieces_per_wave);
         q.amask = q.bmask = 0xfc00u; run<32, 0, 0>("MFMA only, powers of two in A and B", q, ncu, cap_pieces_per_wave);
