@@ -82,6 +82,17 @@ __device__ __forceinline__ f32x16 mfma_f16(h8 a, h8 b, f32x16 c) {
     c[0] += (float)a[0] * (float)b[0];
     return c;
 #endif
+#ifdef PFNL_X_MFMA16   /* timing experiment only (wrong results on purpose): the same FLOPs as two v_mfma_f32_16x16x32_f16 on the same operand registers */
+    {
+        typedef float f32x4_ __attribute__((ext_vector_type(4)));
+        f32x4_ lo = {c[0], c[1], c[2], c[3]}, hi = {c[4], c[5], c[6], c[7]};
+        lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, lo, 0, 0, 0);
+        hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, a, hi, 0, 0, 0);
+        c[0] = lo[0]; c[1] = lo[1]; c[2] = lo[2]; c[3] = lo[3];
+        c[4] = hi[0]; c[5] = hi[1]; c[6] = hi[2]; c[7] = hi[3];
+        return c;
+    }
+#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 

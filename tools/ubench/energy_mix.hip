@@ -33,7 +33,7 @@ struct Params {
     unsigned amask, bmask;    // and-masks on the operands' binary16 patterns (0xffff = data-like; fewer mantissa bits / zeros: does the power follow the data?)
 };
 
-template <int M, int L, int D, bool NT = true>
+template <int M, int L, int D, bool NT = true, int SHAPE = 32>
 __global__ __launch_bounds__(512, 1) void mix_kernel(Params p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[65536];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -47,6 +47,9 @@ __global__ __launch_bounds__(512, 1) void mix_kernel(Params p) {
         }
     float16v acc[4];
     for (int k = 0; k < 4; ++k) for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v acc16[8];                                                   // SHAPE = 16: v_mfma_f32_16x16x32_f16, two per 32x32x16's worth of FLOPs
+    for (int k = 0; k < 8; ++k) for (int i = 0; i < 4; ++i) acc16[k][i] = 0.f;
     if (D) { for (int i = tid; i < 65536 / 4; i += 512) ((unsigned*)lds)[i] = 0x38003800u + (i * 2654435761u & 0x87ff87ffu); }
     __syncthreads();
     const long long per_wave = (long long)p.steps * L * 64;
@@ -66,7 +69,12 @@ __global__ __launch_bounds__(512, 1) void mix_kernel(Params p) {
                 asm volatile("" :: "v"(r));
                 if ((m & 7) == 7) b[(m >> 3) & 3] = r;              // (consumed now and then: the reads must really deliver)
             }
-            acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[p.rot == 1 ? 0 : p.rot == 2 ? (m & 3) : ((m >> 2) & 3)], b[p.rot == 1 ? 0 : ((m + (m >> 4)) & 3)], acc[m & 3], 0, 0, 0);
+            if constexpr (SHAPE == 32) {
+                acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[p.rot == 1 ? 0 : p.rot == 2 ? (m & 3) : ((m >> 2) & 3)], b[p.rot == 1 ? 0 : ((m + (m >> 4)) & 3)], acc[m & 3], 0, 0, 0);
+            } else {
+                acc16[(2 * m) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(m >> 2) & 3], b[(m + (m >> 4)) & 3], acc16[(2 * m) & 7], 0, 0, 0);
+                acc16[(2 * m + 1) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(m >> 1) & 3], b[(m + 1 + (m >> 4)) & 3], acc16[(2 * m + 1) & 7], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int j = 0; j < L; ++j) {
@@ -77,6 +85,7 @@ __global__ __launch_bounds__(512, 1) void mix_kernel(Params p) {
     const long long t1 = clock64(), w1 = wall_clock64();
     float r = 0.f;
     for (int k = 0; k < 4; ++k) for (int i = 0; i < 16; ++i) r += acc[k][i];
+    for (int k = 0; k < 8; ++k) for (int i = 0; i < 4; ++i) r += acc16[k][i];
     for (int j = 0; j < (L ? L : 1); ++j) r += (float)cur[j][0];
     if (r == 123.456f) p.sink[0] = r;
     if (tid == 0) { p.clk[2 * blockIdx.x] = t1 - t0; p.clk[2 * blockIdx.x + 1] = w1 - w0; }
@@ -89,7 +98,7 @@ __global__ void fill_kernel(unsigned* p, long long n) {              // data-lik
 
 struct Point { const char* name; int M, L, D; double ms, ghz; double flops, bytes, reads; };
 
-template <int M, int L, int D, bool NT = true>
+template <int M, int L, int D, bool NT = true, int SHAPE = 32>
 static Point run(const char* name, Params p, int ncu, long long cap_pieces_per_wave) {
     // steps: ~1.5 ms per launch at the expected rates, within the buffer
     long long steps = 4096;
@@ -98,7 +107,7 @@ static Point run(const char* name, Params p, int ncu, long long cap_pieces_per_w
     if (p.wrap <= 0 || p.wrap > steps) p.wrap = (int)steps;
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    auto launch = [&]() { hipLaunchKernelGGL((mix_kernel<M, L, D, NT>), dim3(ncu), dim3(512), 0, 0, p); };
+    auto launch = [&]() { hipLaunchKernelGGL((mix_kernel<M, L, D, NT, SHAPE>), dim3(ncu), dim3(512), 0, 0, p); };
     launch(); CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0)); launch(); CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
     float one = 0.f; CHECK(hipEventElapsedTime(&one, e0, e1));
@@ -179,6 +188,16 @@ int main() {
         printf("    b = %.1f us per GB\n", (m2.ms - a * m2.flops) / m2.bytes * 1e12);
         const Point m3 = run<33, 1, 0, false>("MFMA + bytes 528, small footprint, plain ld/st", q, ncu, cap_pieces_per_wave);
         printf("    b = %.1f us per GB\n", (m3.ms - a * m3.flops) / m3.bytes * 1e12);
+    }
+    {   // the other f16 shape: v_mfma_f32_16x16x32_f16 (two per 32x32x16's worth of FLOPs; tools/ubench/mfma_shape_power.hip) at the same mixes
+        printf("# v_mfma_f32_16x16x32_f16 (M counts pairs: the same FLOPs per step)\n");
+        run<32, 0, 0, true, 16>("16x16x32: MFMA only", p, ncu, cap_pieces_per_wave);
+        run<33, 1, 0, true, 16>("16x16x32: MFMA + bytes 528", p, ncu, cap_pieces_per_wave);
+        run<21, 1, 0, true, 16>("16x16x32: MFMA + bytes 336", p, ncu, cap_pieces_per_wave);
+        run<32, 0, 16, true, 16>("16x16x32: MFMA + 0.5 ds_read_b128 per 32 KFLOP", p, ncu, cap_pieces_per_wave);
+        run<33, 1, 16, true, 16>("16x16x32: bytes 528 + 0.5 ds_read_b128", p, ncu, cap_pieces_per_wave);
+        run<37, 2, 0, true, 16>("16x16x32: MFMA + bytes 296 (bf16 mix)", p, ncu, cap_pieces_per_wave);
+        run<23, 2, 0, true, 16>("16x16x32: MFMA + bytes 184 (bf16 mix)", p, ncu, cap_pieces_per_wave);
     }
     {   // does the matrix pipe's power follow its operands?  (not part of the fit)
         Params q = p;
