@@ -62,7 +62,20 @@ __device__ __forceinline__ void b3_dma4(__amdgpu_buffer_rsrc_t rs, unsigned lds_
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rs) : "memory");
 }
-__device__ __forceinline__ f32x16 b3_mfma(b3h8 a, b3h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 b3_mfma(b3h8 a, b3h8 b, f32x16 c) {
+#ifdef PFNL_X_MFMA16   /* timing experiment only (wrong results on purpose): the same FLOPs as two v_mfma_f32_16x16x32_bf16 on the same operand registers */
+    {
+        typedef float f32x4_ __attribute__((ext_vector_type(4)));
+        f32x4_ lo = {c[0], c[1], c[2], c[3]}, hi = {c[4], c[5], c[6], c[7]};
+        lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, lo, 0, 0, 0);
+        hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, hi, 0, 0, 0);
+        c[0] = lo[0]; c[1] = lo[1]; c[2] = lo[2]; c[3] = lo[3];
+        c[4] = hi[0]; c[5] = hi[1]; c[6] = hi[2]; c[7] = hi[3];
+        return c;
+    }
+#endif
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 __device__ __forceinline__ f32x4 b3_to_f32(b3u2 v) {
     return f32x4{__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xffff0000u),
                  __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xffff0000u)};
