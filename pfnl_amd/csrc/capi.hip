@@ -198,6 +198,8 @@ struct pfnl_handle {
     int merge_cstride = 48;                                   // floats per pixel of `merge` as written by the last forward
     int conv1x1_algo = 2;                                     // conv10: 2 streaming kernel on the f16 pipe, split operands (default), 1 streaming f32-MFMA kernel (conv1x1.hip), 0 LDS-tiled implicit GEMM
     bool bf16_fuse10 = true;                                  // bf16 trunk: conv10_i inside the conv1_i launch (option bf16_conv10=fused|separate)
+    bool bf16_m16 = true;                                     // bf16 trunk: the two chained 3x3 launches on v_mfma_f32_16x16x32_bf16 (option bf16_mfma=16|32)
+    std::vector<size_t> off16_c1_m16, off16_c2b_m16;          // conv3x3_bf16_pack_weights16 of conv1_i / conv2_i's per-frame half
     bool bf16 = false;                                        // option precision=bf16: progressive-fusion trunk in bf16 (conv_bf16.hip); NL, conv0 maths, merge, tail stay fp32
     DevBuf wdev16;                                            // bf16 packs (offsets in 16-bit elements)
     std::vector<size_t> off16_c1, off16_c10, off16_c2a, off16_c2b;
@@ -638,6 +640,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
                     q.split_s = pl.split_s;
                     q.split_q = pl.split_q;
                     q.partial = pl.split_s ? h->c10part.p : nullptr;
+                    if (h->bf16_m16) q.wpack16 = w16 + h->off16_c1_m16[i];
                 }
                 HIPCHK(launch_conv3x3_bf16(q, s));
             }
@@ -672,6 +675,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
                 q.n_full = pl.n_full;
                 q.split_s = pl.split_s;
                 q.split_q = pl.split_q;
+                if (h->bf16_m16) q.wpack16 = w16 + h->off16_c2b_m16[i];
                 HIPCHK(launch_conv3x3_bf16(q, s));
             }
         }
@@ -1210,6 +1214,12 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         else return fail(PFNL_ERR_INVALID, "conv2 must be grouped or split");
         return 0;
     }
+    if (k == "bf16_mfma") {
+        if (v == "16") h->bf16_m16 = true;
+        else if (v == "32") h->bf16_m16 = false;
+        else return fail(PFNL_ERR_INVALID, "bf16_mfma must be 16 or 32");
+        return PFNL_OK;
+    }
     if (k == "bf16_conv10") {
         if (v == "fused") h->bf16_fuse10 = true;
         else if (v == "separate") h->bf16_fuse10 = false;
@@ -1290,6 +1300,7 @@ int pfnl_get_option(pfnl_handle* h, const char* key, char* buf, size_t buflen) {
     else if (k == "split16_splitchains") v = h->split_chains ? "auto" : "off";
     else if (k == "conv2") v = h->conv2_grouped ? "grouped" : "split";
     else if (k == "bf16_conv10") v = h->bf16_fuse10 ? "fused" : "separate";
+    else if (k == "bf16_mfma") v = h->bf16_m16 ? "16" : "32";
     else if (k == "precision") v = h->bf16 ? "bf16" : "fp32";
     else if (k == "merge1") v = h->m1_algo == 1 ? "split16" : (h->m1_algo == 2 ? "winograd" : "auto");
     else if (k == "nl_type") v = h->nl_type < 0 ? "auto" : std::to_string(h->nl_type);
@@ -1453,6 +1464,8 @@ int pfnl_finalize_weights(pfnl_handle* h) {
         h->off16_c10.assign(nb, 0);
         h->off16_c2a.assign(nb, 0);
         h->off16_c2b.assign(nb, 0);
+        h->off16_c1_m16.assign(nb, 0);
+        h->off16_c2b_m16.assign(nb, 0);
         for (int i = 0; i < nb; ++i) {
             const std::string s = std::to_string(i);
             h->off16_c1[i] = reserve16(pfnl::conv3x3_bf16_pack_halfs());
@@ -1463,6 +1476,10 @@ int pfnl_finalize_weights(pfnl_handle* h) {
             pfnl::conv3x3_bf16_pack_weights(W("conv2_" + s).data(), 128, 0, &b16[h->off16_c2a[i]]);
             h->off16_c2b[i] = reserve16(pfnl::conv3x3_bf16_pack_halfs());
             pfnl::conv3x3_bf16_pack_weights(W("conv2_" + s).data(), 128, 64, &b16[h->off16_c2b[i]]);
+            h->off16_c1_m16[i] = reserve16(pfnl::conv3x3_bf16_pack_halfs());
+            pfnl::conv3x3_bf16_pack_weights16(W("conv1_" + s).data(), 64, 0, &b16[h->off16_c1_m16[i]]);
+            h->off16_c2b_m16[i] = reserve16(pfnl::conv3x3_bf16_pack_halfs());
+            pfnl::conv3x3_bf16_pack_weights16(W("conv2_" + s).data(), 128, 64, &b16[h->off16_c2b_m16[i]]);
         }
         h->off16_m1 = reserve16((size_t)T * pfnl::conv3x3_bf16_pack_halfs());
         for (int f = 0; f < T; ++f)

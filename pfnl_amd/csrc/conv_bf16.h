@@ -29,6 +29,8 @@ struct ConvBf16Params {
     float* partial;
     int flat;                // addend launches on the third-generation kernel: 1 = deal the tiles out one by one instead of as chains of the add_div
                              // frames of a (clip, tile) (capi.hip, "MID shapes": fewer chains than workgroups); same result bit for bit
+    const uint16_t* wpack16; // conv3x3_bf16_pack_weights16 of the same kernel (or null): modes 1 / 2 of the third-generation kernel then run on
+                             // v_mfma_f32_16x16x32_bf16 (conv_bf16_v3.hip, M16)
 };
 hipError_t launch_conv3x3_bf16(const ConvBf16Params& p, hipStream_t s);
 // the second-generation kernel (conv_bf16_v2.hip: halo by LDS-DMA, MFMA groups with nothing else in them, a serial epilogue phase) for
@@ -46,6 +48,7 @@ hipError_t launch_cast_f32_bf16(const float* in, uint16_t* out, size_t n, hipStr
 uint16_t bf16_rne(float f);
 size_t conv3x3_bf16_pack_halfs();
 void conv3x3_bf16_pack_weights(const float* hwio, int cin_total, int cin_begin, uint16_t* dst, int cout = 64);   // cout < 64: zero-padded
+void conv3x3_bf16_pack_weights16(const float* hwio, int cin_total, int cin_begin, uint16_t* dst);   // the M16 form's order (ConvBf16Params::wpack16), 64 output channels
 size_t conv1x1_bf16_pack_halfs(int T);
 void conv1x1_bf16_pack_weights(const float* hwio, int T, uint16_t* dst);
 // conv0 writing the bf16 trunk input (misc_kernels.hip)

@@ -758,6 +758,22 @@ void conv3x3_bf16_pack_weights(const float* hwio, int cin_total, int cin_begin, 
                     }
 }
 
+// The same kernel for the M16 form of conv3x3_bf16_v3_kernel (v_mfma_f32_16x16x32_bf16, A = weights): [ky][kx][kk][output tile c4][lane][e] =
+// W[ky][kx][cin_begin + 32 kk + 8 (lane >> 4) + e][32 (c4 >> 1) + 8 (m >> 2) + 4 (c4 & 1) + (m & 3)], m = lane & 15: row m of output tile c4 is
+// permuted so that lane group g = l >> 4 of the RESULT (rows 4 g + r of both tiles of a channel half) holds the 8 consecutive channels 8 g .. 8 g + 7
+void conv3x3_bf16_pack_weights16(const float* hwio, int cin_total, int cin_begin, uint16_t* dst) {
+    for (int tap = 0; tap < 9; ++tap)
+        for (int kk = 0; kk < 2; ++kk)
+            for (int c4 = 0; c4 < 4; ++c4)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int m = lane & 15;
+                        const int ci = cin_begin + 32 * kk + 8 * (lane >> 4) + e;
+                        const int co = 32 * (c4 >> 1) + 8 * (m >> 2) + 4 * (c4 & 1) + (m & 3);
+                        dst[((((size_t)tap * 2 + kk) * 4 + c4) * 64 + lane) * 8 + e] = bf16_rne(hwio[((size_t)tap * cin_total + ci) * 64 + co]);
+                    }
+}
+
 size_t conv1x1_bf16_pack_halfs(int T) { return (size_t)T * 4096; }
 
 // HWIO [1,1,T*64,64] -> [f][ks][m][lane][e]: W[64 f + 16 ks + 8 (lane>>5) + e][32 m + bf16_row_channel(lane&31)]

@@ -109,12 +109,22 @@ __device__ long long b3_dbg[256 * 2 * 128];
 #define B3_PSTAMP() do {} while (0)
 #endif
 
+// (M16) the K = 32 shape: 16 x 16 outputs, 4 accumulator registers - 14 % less energy per FLOP than 32x32x16 under the package power cap
+typedef float b3f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ b3f4 b3_mfma16(b3h8 a, b3h8 b, b3f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
 // MODE 0: out = act(conv + bias).  MODE 1 (conv2_i per-frame half): out = act(conv + bias + addend[item / add_div]) + resid.
 // MODE 2 (conv1_i + conv10_i): MODE 0, and per chain of add_div frames x_out = lrelu(sum_t W10_t out_t + x_bias).
 // SPLIT (round 6, modes 1 and 2): split chains - behind the whole rounds of (clip, tile) chains every workgroup takes ONE part (frames [sp_f0, sp_f1)) of a
 // cut chain (conv_split16.h).  Mode 1: the part fetches the chain's addend pieces with its own first frame; mode 2: its share of conv10_i's sum leaves raw
 // (fp32, no bias, no activation) in p.partial[slot] and c10_finalize_bf16_kernel adds the parts.  A template parameter: the whole-round launches keep their stream.
-template <int MODE, bool SPLIT = false>
+// M16 (round 6, late): the 3x3's products on v_mfma_f32_16x16x32_bf16.  A = weights (16 output channels x 32 input channels), B = pixels (32 channels x 16
+// pixels): lane (n = l & 15, g = l >> 4) reads chunk 4 kk + g (8 channels) of halo pixel 16 ph + n + kx for the k-step kk of 32 channels, and owns, per output row
+// and pixel half ph, the 8 CONSECUTIVE output channels 32 mt + 8 g .. + 7 of pixel 16 ph + n (two 16-channel output tiles ct = 0, 1 whose rows the weight pack
+// - conv3x3_bf16_pack_weights16, p.wpack16 - permutes: row 4 g + r of tile ct = channel 8 g + 4 ct + r): one 16-byte piece of a scratch line, one 16-byte residual
+// / addend piece.  6 groups (column tap kx, k-step kk) of 24 MFMAs per tile instead of 12 of 6; LDS image, scratch lines, conv10_i's stage, the work order,
+// the two half-workgroups and every barrier are those of the 32x32x16 form.  Summation order differs (K = 32 per instruction): not bit-equal to it.
+template <int MODE, bool SPLIT = false, bool M16 = false>
 __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16Params p) {
     constexpr bool FUSE = MODE == 1;
     constexpr bool WITH10 = MODE == 2;
@@ -216,18 +226,26 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
 
     // operand addresses (conv_bf16.hip): pixel operand of (column tap kx, k-step ks) = chunk 2*ks + (lane >> 5) of halo pixel
     // (row 2*rp + ..., column (lane & 31) + kx); weights: 16 bytes per lane
-    int paddr[3][4];
+    int paddr[3][4];                                                // M16: [kx][2 kk + ph]
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-        const int col = (lane & 31) + kx;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            paddr[kx][ks] = ((2 * rp) * B3_IW + col) * 128 + (((2 * ks + (lane >> 5)) ^ ((col >> 1) & 7)) << 4);
+        for (int ks = 0; ks < 4; ++ks) {
+            if constexpr (M16) {
+                const int col = 16 * (ks & 1) + (lane & 15) + kx;
+                paddr[kx][ks] = ((2 * rp) * B3_IW + col) * 128 + (((4 * (ks >> 1) + (lane >> 4)) ^ ((col >> 1) & 7)) << 4);
+            } else {
+                const int col = (lane & 31) + kx;
+                paddr[kx][ks] = ((2 * rp) * B3_IW + col) * 128 + (((2 * ks + (lane >> 5)) ^ ((col >> 1) & 7)) << 4);
+            }
+        }
     }
-    const unsigned char* const wlane = wl + mt * 1024 + lane * 16;
+    const unsigned char* const wlane = wl + (M16 ? 2 * mt : mt) * 1024 + lane * 16;
+    [[maybe_unused]] const int ech16 = 32 * mt + 8 * (lane >> 4);   // M16: the lane's 8 consecutive channels (of pixels 16 ph + (lane & 15))
     // register r of a lane = channel 32mt + 16(lane>>5) + r (the row -> channel map of the packed weights), pixel lane & 31 of the row
     const int ech = 32 * mt + 16 * (lane >> 5);
-    f32x16 acc[2];
+    [[maybe_unused]] f32x16 acc[2];
+    [[maybe_unused]] b3f4 acc4[2][4];                               // M16: [output row][2 ph + ct]
     [[maybe_unused]] b3u4 radd[2][2];                               // FUSE: addend pieces (accumulator layout; fetched once per chain)
     [[maybe_unused]] b3u4 rq[4];                                    // FUSE: this lane's residual pieces (row n, channel half h: index 2n + h)
     [[maybe_unused]] b3u4 xw[4];                                    // WITH10: W10 operands of the tile's frame
@@ -251,11 +269,21 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int oy = un.y0 + 2 * rp + n;
+                if constexpr (M16) {                                // pieces in the M16 accumulator layout: (row n, pixel half ph) -> channels ech16 .. + 7
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int ox16 = un.x0 + 16 * h + (lane & 15);
+                        const int eoff = (ox16 < W && oy < H) ? (oy * W + ox16) * 128 + ech16 * 2 : 0x7fffffff;
+                        rq[2 * n + h] = __builtin_bit_cast(b3u4, __builtin_amdgcn_raw_buffer_load_b128(rsR, eoff, 0, 0));
+                        if (un.f == un.f0) radd[n][h] = __builtin_bit_cast(b3u4, __builtin_amdgcn_raw_buffer_load_b128(rsA, eoff, 0, 0));
+                    }
+                } else {
                 const int eoff = (ox < W && oy < H) ? (oy * W + ox) * 128 : 0x7fffffff;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     rq[2 * n + h] = __builtin_bit_cast(b3u4, __builtin_amdgcn_raw_buffer_load_b128(rsR, eoff, (ech + 8 * h) * 2, 0));
                     if (un.f == un.f0) radd[n][h] = __builtin_bit_cast(b3u4, __builtin_amdgcn_raw_buffer_load_b128(rsA, eoff, (ech + 8 * h) * 2, 0));
+                }
                 }
             }
         }
@@ -292,15 +320,23 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
         for (int part = 0; part < 2; ++part)
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
-                const bool early = 4 * (j % 3) + ks0 < 7;           // (wave-uniform)
+                const bool early = M16 ? (j % 3) < 2 : 4 * (j % 3) + ks0 < 7;   // (wave-uniform; M16: piece w = ((ky 3 + kx) 2 + kk) 4 + output tile: up to its mid barrier a tile reads - and prefetches - column taps 0 and 1)
                 if (early == (part == 0)) b3_dma16(rsW, lds0 + 2 * B3_TILE_BYTES + (wave + 8 * j) * 1024, (wave + 8 * j) * 1024 + lane * 16);
             }
     }
     B3_PSTAMP();                                                // P4: weights requested
-    if (wave < 6) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // all but the late weight pieces (waves 0-5: three of nine, waves 6-7: six)
+    if (M16 || wave < 6) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // all but the late weight pieces (waves 0-5: three of nine, waves 6-7: six; M16: three for every wave)
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     B3_PSTAMP();                                                // P5: halo and the early weights landed
     __syncthreads();
+    [[maybe_unused]] b3f4 bias4[2];                                 // M16: output tile ct, rows 4 g + r = channels ech16 + 4 ct + r
+    if constexpr (M16) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + ech16 + 4 * ct);
+            bias4[ct] = b3f4{b4.x, b4.y, b4.z, b4.w};
+        }
+    }
     f32x16 bias16;                                                  // the tile's first MFMAs take C = bias (register r of a lane = channel ech + r)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -332,6 +368,75 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
 
         // ---- I0 | I1: 12 groups (column tap kx, k-step ks): the 4 halo rows 2rp..2rp+3 serve the 3 row taps of both output rows - 4 pixel
         // reads + 3 weight reads feed 6 MFMAs; the operands of group g + 1 are requested in the MFMA gaps of group g
+        if constexpr (M16) {
+            // 6 groups (column tap kx, k-step kk of 32 channels): 4 halo rows x 2 pixel halves + 3 row taps x 2 output tiles = 14 operand reads feed 24 MFMAs
+            // (row tap ky outermost: 8 different accumulators between two MFMAs on the same one); the operands of group g + 1 are requested one per gap
+            // Operands are refilled IN PLACE for group g + 1 as soon as group g has read them for the last time (halo row 0 behind its 4th MFMA, row tap 0's
+            // weights behind the 8th, row 1 behind the 12th ...): 8 + 6 operand sets live, not 16 + 12 - the conv1_i + conv10_i mode has conv10_i's
+            // accumulators and operands on top and spilled with a full double buffer.
+            b3h8 px[4][2], wv[3][2];
+#define B3_PX16(g_, r_, ph_) (*reinterpret_cast<const b3h8*>(tile + paddr[(g_) >> 1][2 * ((g_) & 1) + (ph_)] + (r_) * (B3_IW * 128)))
+#define B3_WT16(g_, ky_, ct_) (*reinterpret_cast<const b3h8*>(wlane + (((((ky_) * 3 + ((g_) >> 1)) * 2 + ((g_) & 1)) * 4 + (ct_)) << 10)))
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) px[r][ph] = B3_PX16(0, r, ph);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) wv[ky][ct] = B3_WT16(0, ky, ct);
+            auto group16 = [&](auto gc) __attribute__((always_inline)) {
+                constexpr int g = decltype(gc)::value;
+#define B3_M(ky_, n_, ph_, ct_)                                                                                                        \
+    do {                                                                                                                               \
+        if constexpr (g == 0 && (ky_) == 0) acc4[n_][2 * (ph_) + (ct_)] = b3_mfma16(wv[ky_][ct_], px[(n_) + (ky_)][ph_], bias4[ct_]);   \
+        else acc4[n_][2 * (ph_) + (ct_)] = b3_mfma16(wv[ky_][ct_], px[(n_) + (ky_)][ph_], acc4[n_][2 * (ph_) + (ct_)]);                \
+        __builtin_amdgcn_sched_barrier(0);                                                                                             \
+    } while (0)
+#define B3_RP(r_, ph_) do { if constexpr (g < 5) px[r_][ph_] = B3_PX16(g + 1, r_, ph_); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define B3_RW(k_, ct_) do { if constexpr (g < 5) wv[k_][ct_] = B3_WT16(g + 1, k_, ct_); __builtin_amdgcn_sched_barrier(0); } while (0)
+                __builtin_amdgcn_sched_barrier(0);
+                B3_M(0, 0, 0, 0);
+                B3_M(0, 0, 0, 1);
+                B3_M(0, 0, 1, 0);
+                B3_M(0, 0, 1, 1); B3_RP(0, 0);
+                B3_M(0, 1, 0, 0); B3_RP(0, 1);
+                B3_M(0, 1, 0, 1);
+                B3_M(0, 1, 1, 0);
+                B3_M(0, 1, 1, 1); B3_RW(0, 0);
+                B3_M(1, 0, 0, 0); B3_RW(0, 1);
+                B3_M(1, 0, 0, 1);
+                B3_M(1, 0, 1, 0);
+                B3_M(1, 0, 1, 1); B3_RP(1, 0);
+                B3_M(1, 1, 0, 0); B3_RP(1, 1);
+                B3_M(1, 1, 0, 1);
+                B3_M(1, 1, 1, 0);
+                B3_M(1, 1, 1, 1); B3_RW(1, 0);
+                B3_M(2, 0, 0, 0); B3_RW(1, 1);
+                B3_M(2, 0, 0, 1);
+                B3_M(2, 0, 1, 0);
+                B3_M(2, 0, 1, 1); B3_RP(2, 0);
+                B3_M(2, 1, 0, 0); B3_RP(2, 1);
+                B3_M(2, 1, 0, 1);
+                B3_M(2, 1, 1, 0);
+                B3_M(2, 1, 1, 1); B3_RP(3, 0); B3_RP(3, 1); B3_RW(2, 0); B3_RW(2, 1);
+#undef B3_M
+#undef B3_RP
+#undef B3_RW
+            };
+            group16(std::integral_constant<int, 0>{});
+            group16(std::integral_constant<int, 1>{});
+            group16(std::integral_constant<int, 2>{});
+            B3_STAMP();                                             // 1: groups 0-2 issued
+            if (u == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the late weight pieces of the prologue (column tap 2)
+            B3_BARRIER();                                           // interval boundary (the other half's dump | lines)
+            B3_STAMP();                                             // 2
+            group16(std::integral_constant<int, 3>{});
+            group16(std::integral_constant<int, 4>{});
+            group16(std::integral_constant<int, 5>{});
+#undef B3_PX16
+#undef B3_WT16
+        } else {
         b3h8 px[2][4], wv[2][3];
 #define B3_PX(g_, r_) (*reinterpret_cast<const b3h8*>(tile + paddr[(g_) >> 2][(g_) & 3] + (r_) * (B3_IW * 128)))
 #define B3_WT(g_, ky_) (*reinterpret_cast<const b3h8*>(wlane + ((((ky_) * 3 + ((g_) >> 2)) * 4 + ((g_) & 3)) << 11)))
@@ -391,6 +496,7 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
         group(std::integral_constant<int, 11>{});
 #undef B3_PX
 #undef B3_WT
+        }
         B3_STAMP();                                                 // 3: groups 6-11 issued
         if (grp) B3_PIECES_LANDED();                                // group B's share of the next halo has landed (group A reads it after this barrier)
         B3_BARRIER();                                               // this half is past its last operand read of its rows: they are its scratch now
@@ -413,14 +519,16 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {                           // row n, channels ech + 8h .. + 7: bias is in (initial C); addend, leaky_relu, residual, bf16
-                const int j = lane & 31;
-                const int c = 4 * mt + 2 * (lane >> 5) + h;         // piece of the pixel's line
+                                                                    // (M16: h = pixel half; the lane's channels ech16 .. + 7 = output tiles ct = 0, 1)
+                const int j = M16 ? 16 * h + (lane & 15) : (lane & 31);
+                const int c = M16 ? 4 * mt + (lane >> 4) : 4 * mt + 2 * (lane >> 5) + h;   // piece of the pixel's line
                 b3u4* const slot = reinterpret_cast<b3u4*>(scr + ((2 * rl + n) * 32 + j) * 128 + ((c ^ ((j >> 1) & 7)) << 4));
                 f32x4 v[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int r0 = 8 * h + 4 * q;
-                    v[q] = f32x4{acc[n][r0], acc[n][r0 + 1], acc[n][r0 + 2], acc[n][r0 + 3]};
+                    if constexpr (M16) v[q] = f32x4{acc4[n][2 * h + q][0], acc4[n][2 * h + q][1], acc4[n][2 * h + q][2], acc4[n][2 * h + q][3]};
+                    else v[q] = f32x4{acc[n][r0], acc[n][r0 + 1], acc[n][r0 + 2], acc[n][r0 + 3]};
                     if constexpr (FUSE) v[q] += b3_to_f32(b3u2{radd[n][h][2 * q], radd[n][h][2 * q + 1]});
                     v[q] = b3_lrelu4(v[q], eslope);
                     if constexpr (FUSE) v[q] += b3_to_f32(b3u2{rq[2 * n + h][2 * q], rq[2 * n + h][2 * q + 1]});
@@ -506,15 +614,15 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
     }
 }
 
-template <int MODE, bool SPLIT = false>
+template <int MODE, bool SPLIT = false, bool M16 = false>
 static hipError_t b3_launch(const ConvBf16Params& p, int grid, int dev, hipStream_t s) {
     static std::atomic<int> attr_dev[64];
     if (!attr_dev[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16_v3_kernel<MODE, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16_v3_kernel<MODE, SPLIT, M16>), hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_dev[dev] = 1;
     }
-    hipLaunchKernelGGL((conv3x3_bf16_v3_kernel<MODE, SPLIT>), dim3(grid), dim3(B3_THREADS), B3_LDS_BYTES, s, p);
+    hipLaunchKernelGGL((conv3x3_bf16_v3_kernel<MODE, SPLIT, M16>), dim3(grid), dim3(B3_THREADS), B3_LDS_BYTES, s, p);
     return hipGetLastError();
 }
 
@@ -574,10 +682,16 @@ hipError_t launch_conv3x3_bf16_v3(const ConvBf16Params& p, int mode, hipStream_t
     const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;                    // whole XCDs; surplus workgroups exit at once
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    // p.wpack16 (conv3x3_bf16_pack_weights16): the M16 form of the kernel (modes 1 and 2: the trunk's two big launches) on that pack
+    ConvBf16Params q = p;
+    const bool m16 = p.wpack16 != nullptr && mode != 0;
+    if (m16) q.wpack = p.wpack16;
     if (p.split_s) {                                                // split chains: the chained modes only, geometry as the kernels assume it
         if (mode == 0 || p.flat || !b3_split_ok(p, grid) || (mode == 2 && !p.partial)) return hipErrorInvalidValue;
+        if (m16) return mode == 1 ? b3_launch<1, true, true>(q, grid, dev, s) : b3_launch<2, true, true>(q, grid, dev, s);
         return mode == 1 ? b3_launch<1, true>(p, grid, dev, s) : b3_launch<2, true>(p, grid, dev, s);
     }
+    if (m16) return mode == 1 ? b3_launch<1, false, true>(q, grid, dev, s) : b3_launch<2, false, true>(q, grid, dev, s);
     if (mode == 1) return b3_launch<1>(p, grid, dev, s);
     if (mode == 2) return b3_launch<2>(p, grid, dev, s);
     return b3_launch<0>(p, grid, dev, s);

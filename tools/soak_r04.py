@@ -1,8 +1,9 @@
 """Race detector for the round-4 kernels whose LDS traffic is ordered by counted `s_waitcnt vmcnt` waits and workgroup barriers only
 (conv_bf16_v3.hip: halo pieces by LDS-DMA into buffers that double as scratch; nl_attn_f16_sw_kernel: a ring of LDS-DMA tiles): a piece that
 lands late or a slot that is refilled early shows up as run-to-run NONDETERMINISM.  Every forward below is repeated and compared bit for
-bit with its first run; the bf16 forward is also compared bit for bit with the second-generation kernels' (same arithmetic, other schedule),
-whose output a child process with PFNL_BF16_V3=0 writes first.
+bit with its first run; the bf16 forward on the 32x32x16 form (bf16_mfma=32) is also compared bit for bit with the second-generation kernels' (same
+arithmetic, other schedule), whose output a child process with PFNL_BF16_V3=0 writes first.  The default form since round 6 (bf16_mfma=16: K = 32 per
+MFMA, another summation order) is repeated bit for bit and compared with the 32x32x16 form as PSNR (> 60 dB).
 usage: python tools/soak_r04.py [repeats]"""
 import os, subprocess, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,12 +15,13 @@ from pfnl_amd.spec import PFNLGeometry
 CASES = [("bf16", 1, 270, 480), ("bf16", 2, 96, 160), ("fp32", 1, 270, 480), ("fp32", 4, 128, 128), ("bf16", 1, 66, 130)]
 
 
-def run(prec, B, H, W, reps):
+def run(prec, B, H, W, reps, mfma="32"):
     g = PFNLGeometry()
     e = PFNLEngine(g)
     e.load_weights(synth.synthetic_weights(g, seed=0))
     if prec == "bf16":
         e.set_option("precision", "bf16")
+        e.set_option("bf16_mfma", mfma)
     x = torch.from_numpy(synth.uniform_clips(B, 7, H, W, seed=B + H)).cuda()
     first = None
     for r in range(reps):
@@ -51,4 +53,11 @@ if __name__ == "__main__":
                 raise SystemExit("bf16 forward %s: third-generation 3x3 kernels differ from the second generation's in %d values"
                                  % (key, int((v2[key] != y).sum())))
             print("%s %dx7x%dx%d: %d runs bit-identical%s" % (*c, reps, "; equal to the second-generation kernels' output" if key in v2.files else ""))
+            if c[0] == "bf16":
+                y16 = run(*c, reps, mfma="16")
+                mse = float(np.mean((y16.astype(np.float64) - y.astype(np.float64)) ** 2))
+                psnr = 10 * np.log10(1.0 / max(mse, 1e-30))
+                if psnr < 60.0:
+                    raise SystemExit("bf16 forward %s: the 16x16x32 form is %.1f dB from the 32x32x16 form" % (key, psnr))
+                print("%s %dx7x%dx%d on v_mfma_f32_16x16x32_bf16: %d runs bit-identical, %.1f dB from the 32x32x16 form" % (*c, reps, psnr))
     print("soak_r04: ok")
