@@ -150,6 +150,10 @@ int pfnl_finalize_weights(pfnl_handle* h);
  *                 returns the mathematically defined softmax (tested against the stabilised fp64 oracle), everywhere else the same
  *                 values as the reference's formula.  There is no "as written" switch: reproducing an overflow is not a feature.
  * key "bf16_conv10" = "fused" (default: conv10_i runs inside the conv1_i launch of the bf16 trunk) | "separate".
+ * key "bf16_mfma" = "16" (default since round 6: the two chained 3x3 launches of the bf16 trunk issue v_mfma_f32_16x16x32_bf16 - the K = 32 shape costs 14 %
+ *   less energy per FLOP on a package that sits on its power cap; 1080p 3.77 -> 3.58 ms) | "32" (the 32x32x16 form: same rounding points, another summation order).
+ * key "split16_mfma" = "32" (default) | "16": the chain launch of conv2_i (fp32 path) on v_mfma_f32_16x16x32_f16 - an EXPERIMENT that is not in the product
+ *   build (-DPFNL_CHAIN16_BUILD): "16" is refused with PFNL_ERR_INVALID.
  * key "bf16_nonlocal" = "f16" (the only value since round 4: the non-local block of precision=bf16 on the f16 matrix pipe with
  *                 binary16 operands, fp32 accumulation and softmax state - nonlocal_f16.hip, hi parts only; within 1e-3 of the
  *                 fp64 block on [0,1]-scale outputs, measured 1e-4 ... 5e-4.  Round 1's split-operand bf16 kernel - 2.5x the

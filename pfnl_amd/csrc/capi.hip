@@ -211,6 +211,8 @@ struct pfnl_handle {
     DevBuf wdev16s;                                           // split-f16 packs of the 3x3 kernels (offsets in 16-bit elements)
     std::vector<size_t> off16s_c1, off16s_c2a, off16s_c2b, off16s_c10, off16s_c10f;   // (c10f: conv10_i as conv3x3_c1c10_kernel takes it)
     std::vector<size_t> off16s_c2a_sf, off16s_c2b_sf;         // ... with the identity row map conv3x3_sf_kernel takes (conv_sf.hip)
+    std::vector<size_t> off16s_c2a_m16, off16s_c2b_m16;       // ... in the order of the v_mfma_f32_16x16x32_f16 chain kernel (conv3x3_split16_pack_weights16)
+    bool s16_m16 = false;                                     // option split16_mfma=16|32: the chain launch of conv2_i on 16x16x32 - an EXPERIMENT (builds with -DPFNL_CHAIN16_BUILD only)
     std::vector<size_t> off16m_c1, off16m_c10, off16m_c2;     // small-shape packs (conv_small.hip), in the same blob
     size_t off16m_m1 = 0;
     // The f16-pipe kernels of the fp32 path have a DOMAIN (operands inside binary16's range; the non-local kernel: inputs x 2^7).
@@ -872,6 +874,10 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             q.n_full = pl.n_full;
             q.split_s = pl.split_s;
             q.split_q = pl.split_q;
+            if (h->s16_m16 && !out_sf0) {                           // the 16x16x32 form of the launch (whole rounds; split chains stay on 32x32x16)
+                q.wpack_m16 = w16s + h->off16s_c2b_m16[i];
+                q.wpack2_m16 = w16s + h->off16s_c2a_m16[i];
+            }
             HIPCHK(launch_conv3x3_sf_chain(q, s));
             continue;
         }
@@ -1214,11 +1220,20 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         else return fail(PFNL_ERR_INVALID, "conv2 must be grouped or split");
         return 0;
     }
+    if (k == "split16_mfma") {
+#ifndef PFNL_CHAIN16_BUILD
+        if (v == "16") return fail(PFNL_ERR_INVALID, "split16_mfma=16: the 16x16x32 chain kernel is an experiment and not in this build (-DPFNL_CHAIN16_BUILD)");
+#endif
+        if (v == "16") h->s16_m16 = true;
+        else if (v == "32") h->s16_m16 = false;
+        else return fail(PFNL_ERR_INVALID, "split16_mfma must be 16 or 32");
+        return 0;
+    }
     if (k == "bf16_mfma") {
         if (v == "16") h->bf16_m16 = true;
         else if (v == "32") h->bf16_m16 = false;
         else return fail(PFNL_ERR_INVALID, "bf16_mfma must be 16 or 32");
-        return PFNL_OK;
+        return 0;
     }
     if (k == "bf16_conv10") {
         if (v == "fused") h->bf16_fuse10 = true;
@@ -1301,6 +1316,7 @@ int pfnl_get_option(pfnl_handle* h, const char* key, char* buf, size_t buflen) {
     else if (k == "conv2") v = h->conv2_grouped ? "grouped" : "split";
     else if (k == "bf16_conv10") v = h->bf16_fuse10 ? "fused" : "separate";
     else if (k == "bf16_mfma") v = h->bf16_m16 ? "16" : "32";
+    else if (k == "split16_mfma") v = h->s16_m16 ? "16" : "32";
     else if (k == "precision") v = h->bf16 ? "bf16" : "fp32";
     else if (k == "merge1") v = h->m1_algo == 1 ? "split16" : (h->m1_algo == 2 ? "winograd" : "auto");
     else if (k == "nl_type") v = h->nl_type < 0 ? "auto" : std::to_string(h->nl_type);
@@ -1498,7 +1514,13 @@ int pfnl_finalize_weights(pfnl_handle* h) {
         h->off16s_c10.assign(nb, 0);
         h->off16s_c2a_sf.assign(nb, 0);
         h->off16s_c2b_sf.assign(nb, 0);
+        h->off16s_c2a_m16.assign(nb, 0);
+        h->off16s_c2b_m16.assign(nb, 0);
+#ifdef PFNL_CHAIN16_BUILD
+        const size_t blk = 7 * n3 + n1 + pfnl::conv1x1_c10_pack_halfs(T);   // (+ the two packs of the experimental 16x16x32 chain kernel)
+#else
         const size_t blk = 5 * n3 + n1 + pfnl::conv1x1_c10_pack_halfs(T);
+#endif
         h->off16s_c10f.assign(nb, 0);
         h->off16s_m1 = (size_t)nb * blk;
         const size_t m3 = pfnl::conv_small_pack_halfs(3, 1), m10 = pfnl::conv_small_pack_halfs(1, T);
@@ -1520,6 +1542,12 @@ int pfnl_finalize_weights(pfnl_handle* h) {
             h->off16s_c2a_sf[i] = h->off16s_c10[i] + n1;
             h->off16s_c2b_sf[i] = h->off16s_c2a_sf[i] + n3;
             h->off16s_c10f[i] = h->off16s_c2b_sf[i] + n3;
+            h->off16s_c2a_m16[i] = h->off16s_c10f[i] + pfnl::conv1x1_c10_pack_halfs(T);
+            h->off16s_c2b_m16[i] = h->off16s_c2a_m16[i] + n3;
+#ifdef PFNL_CHAIN16_BUILD
+            pfnl::conv3x3_split16_pack_weights16(W("conv2_" + s).data(), 128, 0, &b16[h->off16s_c2a_m16[i]]);
+            pfnl::conv3x3_split16_pack_weights16(W("conv2_" + s).data(), 128, 64, &b16[h->off16s_c2b_m16[i]]);
+#endif
             pfnl::conv1x1_c10_pack_weights(W("conv10_" + s).data(), T, &b16[h->off16s_c10f[i]]);
             pfnl::conv3x3_split16_pack_weights(W("conv2_" + s).data(), 128, 0, &b16[h->off16s_c2a_sf[i]], 64, true);
             pfnl::conv3x3_split16_pack_weights(W("conv2_" + s).data(), 128, 64, &b16[h->off16s_c2b_sf[i]], 64, true);

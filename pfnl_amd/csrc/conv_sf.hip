@@ -929,6 +929,395 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
 #undef SFC_BARRIER
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// EXPERIMENT, not in the product build (-DPFNL_CHAIN16_BUILD; option split16_mfma=16).  Status at the end of round 6: parity-green (the golden
+// and full-size forwards), no spills at 256 VGPRs, no LDS bank conflicts - and 117 us per launch at configs[1] where the 32x32x16 kernel takes 105: it comes off the
+// power cap (1 365 W, 1.95 GHz) and loses ~2 500 cycles per unit that have not been found yet (not the epilogue's access width, not the accumulator distance,
+// not the conflicts the first swizzle had).  The timing build that says what is to be had (-DPFNL_X_MFMA16, two 16x16x32 per former 32x32x16 in the OLD
+// schedule): 95.6 us.
+#ifdef PFNL_CHAIN16_BUILD
+// The same launch on v_mfma_f32_16x16x32_f16 (round 6, late; DESIGN.md R6.9: the K = 32 shape costs 14 % less energy per FLOP under the package power cap).
+// A = pixels (16 pixels x 32 input channels = a unit's channel half in ONE k-step), B = weights (32 channels x 16 output channels): lane (n = l & 15, kq = l >> 4)
+// reads chunk kq (hi) / 4 + kq (lo') of halo pixel 16 ph + n + kx and of the weights of output channel 16 (2 nt + ct) + n, and owns - per output row, pixel half
+// ph and 16-channel output tile ct - channel 32 nt + 16 ct + n of the 4 pixels 16 ph + 4 kq .. + 3: a dword access of the epilogue is 16 lanes x 4 B = 64 contiguous
+// bytes of a pixel (the roles the other way round - a lane owning 4 channels of one pixel, 16-byte accesses - measured the same).  9 sub-steps (column tap, row tap) of 24 MFMAs per unit instead of 18 of 6; weights in the order conv3x3_split16_pack_weights16 writes
+// ([kx][ky][output tile][hi / lo'][lane]: the same 24 KB slices per column tap); the LDS image of the halo, the work order, the DMA requests, the three barriers of a
+// unit and the fences are those of conv3x3_sf_chain_kernel.  Operand registers are refilled for the next sub-step behind the MFMAs that read them last.
+// Summation order differs from the 32x32x16 form (K = 32 per instruction): equal to it within rounding, not bit for bit.
+typedef float sff4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ sff4 sf_mfma16(sfh8 a, sfh8 b, sff4 c) {
+#ifdef SF_X_NOMFMA   /* timing experiments only (wrong results on purpose) */
+    c[0] += (float)a[0] * (float)b[0];
+    return c;
+#endif
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// The XOR swizzle of this kernel's LDS image: chunk c of halo pixel (py, px) sits in slot c ^ SF_SWZ16(px), SF_SWZ16 = 2 ((px >> 1) & 3).  A 16x16x32 pixel
+// operand is read by lane (n = l & 15, kq = l >> 4), and ds_read_b128 serves a wave in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32
+// (MI355X_MICROARCH.md, LDS): a group is ALL 16 pixels of the operand, the outer eight with chunk kq and the inner eight with kq ^ 1.  With the (px >> 1) & 7 of the
+// 32x32x16 kernels (whose groups are 16 consecutive pixels of ONE chunk) those collide for column taps 1 and 2: SQ_LDS_BANK_CONFLICT 4.2e6 per launch, +27 us.
+// Searched over the XOR masks linear in px >> 1: this one is conflict-free for every column tap, pixel half, chunk pair and part.
+#define SF_SWZ16(px_) ((((px_) >> 1) & 3) << 1)
+template <bool SPLIT>
+__global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain16_kernel(ConvSplitParams p) {
+#ifdef PFNL_SFC_TIMING
+    int dbg_n = 0;
+#endif
+    extern __shared__ __attribute__((aligned(16))) unsigned char sf_smem[];
+    unsigned char* const wl = sf_smem + 2 * SF_TILE_BYTES;
+    float* const bl = reinterpret_cast<float*>(sf_smem + 2 * SF_TILE_BYTES + SF_W_BYTES);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if PFNL_S16_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(PFNL_S16_PRIO);
+#endif
+    const int rp = wave >> 1;
+    const int nt = wave & 1;
+    const int H = p.H, W = p.W;
+    const int tiles_x = (W + SF_TW - 1) / SF_TW, tiles_y = (H + SF_TH - 1) / SF_TH;
+    const int per_item = tiles_x * tiles_y;
+    const int item_bytes = H * W * 256;
+    const int wbytes = W * 256;
+    const int T = p.add_div, gT = T + 1;                            // tiles of a chain: the shared half, then the T frames
+    const int nchains = per_item * (p.items / T);
+    const int xcd = blockIdx.x & 7, xj = blockIdx.x >> 3, cpx = gridDim.x >> 3;
+    // SPLIT CHAINS (round 6; p.split_s > 0; conv_split16.h): whole chains for the first p.n_full, one PART per workgroup of each chain behind
+    // them - the shared half (recomputed per part: one tile in 1 + frames) and the part's frames [sp_f0, sp_f1)
+    const int n_full = SPLIT ? p.n_full : nchains;
+    const int per_xcd = (n_full + 7) >> 3;
+    const int cbeg = xcd * per_xcd;
+    const int ccnt = min(per_xcd, n_full - cbeg);
+    if (!SPLIT && xj >= ccnt) return;
+    const int nfull_tiles = ((!SPLIT || xj < ccnt) ? (ccnt - xj + cpx - 1) / cpx : 0) * gT;
+    [[maybe_unused]] const int slot = xcd * cpx + xj;
+    const bool has_part = SPLIT && slot < (nchains - n_full) * p.split_s;
+    const int sp_chain = has_part ? n_full + slot / p.split_s : 0;
+    const int sp_f0 = has_part ? (slot % p.split_s) * p.split_q : 0, sp_f1 = has_part ? min(T, sp_f0 + p.split_q) : 0;
+    const int nt_tiles = nfull_tiles + (has_part ? 1 + sp_f1 - sp_f0 : 0);
+    if (SPLIT && nt_tiles <= 0) return;
+    // tile k -> (f = position in the chain: 0 = shared half, 1 .. T = frame f - 1; clip, y0, x0)
+#define SFC_TILE(k_, f_, clip_, y0_, x0_)                                                        \
+    do {                                                                                         \
+        int ch_;                                                                                 \
+        if (!SPLIT || (k_) < nfull_tiles) {                                                      \
+            const int ci_ = (k_) / gT;                                                           \
+            f_ = (k_) - ci_ * gT;                                                                \
+            ch_ = cbeg + xj + ci_ * cpx;                                                         \
+        } else {                                                                                 \
+            const int kk_ = (k_) - nfull_tiles;                                                  \
+            f_ = kk_ == 0 ? 0 : sp_f0 + kk_;                                                     \
+            ch_ = sp_chain;                                                                      \
+        }                                                                                        \
+        clip_ = ch_ / per_item;                                                                  \
+        const int sp_ = ch_ - clip_ * per_item;                                                  \
+        const int ty_ = sp_ / tiles_x;                                                           \
+        y0_ = ty_ * SF_TH;                                                                       \
+        x0_ = (sp_ - ty_ * tiles_x) * SF_TW;                                                     \
+    } while (0)
+#define SFC_HALF(u_) ((((u_) >> 1) ^ (u_)) & 1)
+
+    const float bias_r = tid < 64 ? p.bias[tid] : 0.f;
+    // (py, px) of the lane's halo pixel per DMA instruction: recomputed at every request (a multiply-high and two more VALU per piece - this kernel has no
+    // registers to spare for a table)
+    const unsigned lds0 = (unsigned)(uintptr_t)sf_smem;
+    const unsigned ldsw = lds0 + 2 * SF_TILE_BYTES;                 // LDS byte address of the weights
+#define SFC_DMA_HALO(rs_, org_, interior_, y0_, x0_, buf_)                                       \
+    do {                                                                                         \
+        _Pragma("unroll") for (int k_ = 0; k_ < SF_DMA_ITERS; ++k_) {                            \
+            const int i_ = wave + 8 * k_;                                                        \
+            if (k_ < SF_DMA_ITERS - 1 || i_ < SF_NDMA) {                                         \
+                const int pix_ = 8 * (wave + 8 * k_) + (lane >> 3);                              \
+                const int py_ = (pix_ * 1928) >> 16, px_ = pix_ - py_ * SF_IW;                   \
+                const int gy_ = (y0_) + py_ - 1, gx_ = (x0_) + px_ - 1;                          \
+                const bool in_ = (interior_) || ((unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W && py_ < SF_IH); \
+                const int rel_ = py_ * wbytes + px_ * 256 + (((lane & 7) ^ SF_SWZ16(px_)) << 4);    \
+                sf_dma16(rs_, lds0 + (buf_) * SF_TILE_BYTES + i_ * 1024, in_ ? (org_) + rel_ : 0x7fffffff); \
+            }                                                                                    \
+        }                                                                                        \
+    } while (0)
+    // one 24 KB weight slice (column tap `slot` of pack `pk_`, channel half `half_`): 24 DMA instructions, 3 per wave
+    const int wvoff = wave * 1024 + lane * 16;
+#define SFC_DMA_W(pk_, half_, slot_)                                                             \
+    do {                                                                                         \
+        const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc(                    \
+            const_cast<uint16_t*>((pk_) ? p.wpack : p.wpack2), 0, 2 * SF_W_BYTES, 0x00020000);   \
+        _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_)                                         \
+            sf_dma16(rw_, ldsw + (slot_) * SF_SLOT_BYTES + (wave + 8 * k_) * 1024, (half_) * SF_W_BYTES + (slot_) * SF_SLOT_BYTES + wvoff + k_ * 8192); \
+    } while (0)
+
+#ifdef PFNL_X_NOWSTREAM   /* timing experiment only (wrong results on purpose), as in conv_split16.hip */
+#define SFC_DMA_WX(pk_, half_, slot_) do {} while (0)
+#else
+#define SFC_DMA_WX(pk_, half_, slot_) SFC_DMA_W(pk_, half_, slot_)
+#endif
+
+    int paddr[3][2];                                                // [column tap][pixel half]
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            const int col = 16 * ph + (lane & 15) + kx;
+            paddr[kx][ph] = ((2 * rp) * SF_IW + col) * 128 + (((lane >> 4) ^ SF_SWZ16(col)) << 4);
+        }
+    const int lo_xor = 4 << 4;
+    const unsigned char* const wlane = wl + nt * 4096 + lane * 16;  // [kx][ky][output tile 2 nt + ct][hi / lo'][lane] x 16 B
+    const int ech = 32 * nt + (lane & 15);                          // the lane's channels: ech + 16 ct (D[pixel][channel]: rows 4 (lane >> 4) + r = pixels)
+    sff4 accm[2][4], accc[2][4], accp[2][4], pbv[2][4];             // [output row][2 ph + ct]; pbv: shared half + bias of the chain = initial C of its frames
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            accm[n][q] = sff4{0.f, 0.f, 0.f, 0.f};
+            accc[n][q] = sff4{0.f, 0.f, 0.f, 0.f};
+            accp[n][q] = sff4{0.f, 0.f, 0.f, 0.f};
+            pbv[n][q] = sff4{0.f, 0.f, 0.f, 0.f};
+        }
+    int ex0p = 0, ey0p = 0, eitemp = 0;
+    bool pending = false;
+    const float slope = p.act ? 0.2f : 1.0f;
+
+    __amdgpu_buffer_rsrc_t rsO;                                     // out == resid (the launcher checks): one resource per row
+    int evoff = 0;
+    sff4 rres;                                                      // the residual piece of the quarter that is finished next
+    auto row_setup = [&](int n) __attribute__((always_inline)) {
+        const int ey = ey0p + 2 * rp + n;
+        const int nrec = (pending && ey < H) ? wbytes : 0;
+        rsO = __builtin_amdgcn_make_buffer_rsrc(p.out + ((size_t)eitemp * H + ey) * W * 64, 0, nrec, 0x00020000);
+        evoff = (ex0p + 4 * (lane >> 4)) * 256 + ech * 4;
+    };
+    // quarter q = 2 ph + ct of a row: channel ech + 16 ct of the 4 pixels 16 ph + 4 (lane >> 4) + j - 16 lanes x 4 B = 64 contiguous bytes per pixel and access
+    auto quarter_request = [&](int q) __attribute__((always_inline)) {
+#ifdef SF_X_NOEPI   /* experiment: no residual loads, no stores (wrong results on purpose) */
+        return;
+#endif
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rres[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsO, evoff + j * 256, (q >> 1) * 4096 + (q & 1) * 64, 0));
+    };
+    auto quarter_finish_with = [&](int n, int q, const sff4 rv) __attribute__((always_inline)) {
+#ifdef SF_X_NOEPI
+        return;
+#endif
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = accp[n][q][j];                                // (shared half + bias are already in: initial C of the tile)
+            const float sv = v * slope;
+            asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(sv));
+            sf_store_b32<SF_STORE_AUX>(v + rv[j], rsO, evoff + j * 256, (q >> 1) * 4096 + (q & 1) * 64);
+        }
+    };
+    auto quarter_finish = [&](int n, int q) __attribute__((always_inline)) { quarter_finish_with(n, q, rres); };
+#define SFC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifndef SFC_SPREAD_HALO
+#define SFC_SPREAD_HALO 0
+#endif
+#ifdef PFNL_SFC_TIMING   /* phase timeline of the chain kernel (tools/sfc_timing.py); not part of the product build */
+#define SFC_STAMP() do { if (lane == 0 && (wave == 0 || wave == 5) && dbg_n < 160) sfc_dbg[(blockIdx.x * 2 + (wave != 0)) * 160 + dbg_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SFC_STAMP() do {} while (0)
+#endif
+
+    // ---- prologue: halo of unit 0 (the first chain's shared half: `base`) and its weights (pack 0 = shared half, channel half 0)
+    int c_f, c_clip, c_y0, c_x0, n_f, n_clip, n_y0, n_x0;
+    SFC_TILE(0, c_f, c_clip, c_y0, c_x0);
+    n_f = c_f;
+    n_clip = c_clip;
+    n_y0 = c_y0;
+    n_x0 = c_x0;
+    {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.in2) + (size_t)c_clip * H * W * 64, 0, item_bytes, 0x00020000);
+        const int org = ((c_y0 - 1) * W + c_x0 - 1) * 256 + SFC_HALF(0) * 128;
+        SFC_DMA_HALO(rs, org, false, c_y0, c_x0, 0);
+        SFC_DMA_W(0, SFC_HALF(0), 0);
+        SFC_DMA_W(0, SFC_HALF(0), 1);
+        SFC_DMA_W(0, SFC_HALF(0), 2);
+        const unsigned fence = __builtin_amdgcn_raw_buffer_load_b32(rs, 0, 0, 0);
+        if (tid < 64) bl[tid] = bias_r;
+        asm volatile("" ::"v"(fence));
+    }
+    __syncthreads();
+
+    // weights in LDS now: (pack, half) of the current unit; the slice-2 request that is still owed to the current unit
+    int w_pk = 0;                                                   // pack of the current unit: 0 = shared half, 1 = per-frame half
+    bool w_slice2_owed = false;                                     // slice 2 of the current unit's weights still has to be brought (its slot was busy)
+
+    for (int kt = 0; kt < nt_tiles; ++kt) {
+        const int half_a = kt & 1;
+        auto unit = [&](auto par) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par)::value;
+            constexpr int cb = PAR;
+            const unsigned char* const tile = sf_smem + cb * SF_TILE_BYTES;
+            const int half_u = PAR == 0 ? half_a : half_a ^ 1;      // channel half of this unit
+            // the next unit: unit B of this tile (same pack, other half), or unit A of the next tile (same half, that tile's pack)
+            const int nx_pk = PAR == 0 ? w_pk : (n_f != 0);
+            const int nx_half = half_a ^ 1;
+            const bool w_replace = PAR == 0 || nx_pk != w_pk;       // (wave-uniform; unit B -> next A only at the two ends of a chain)
+            SFC_STAMP();                                            // 0: unit start
+            // operands: X[halo row of the column tap][pixel half][hi / lo'], Wv[row tap][output tile][hi / lo'] - never more than ~16 of the 28 live: every
+            // register set is refilled for the next sub-step behind the MFMAs that read it last
+            sfh8 X[4][2][2], Wv[3][2][2];
+#ifdef SF_X_PXLIN   /* experiment: linear (conflict-free) pixel operand reads - wrong results on purpose: where do the bank conflicts come from? */
+#define SF_PX16(kx_, ph_, r_, part_) (*reinterpret_cast<const sfh8*>(tile + lane * 16 + ((kx_) * 16 + (ph_) * 8 + (r_) * 2 + (part_)) * 1024))
+#else
+#define SF_PX16(kx_, ph_, r_, part_) (*reinterpret_cast<const sfh8*>(tile + (paddr[kx_][ph_] ^ ((part_) ? lo_xor : 0)) + (r_) * (SF_IW * 128)))
+#endif
+#define SF_WT16(kx_, ky_, ct_, part_) (*reinterpret_cast<const sfh8*>(wlane + (((kx_) * 3 + (ky_)) << 13) + (((ct_) * 2 + (part_)) << 10)))
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int part = 0; part < 2; ++part) Wv[0][ct][part] = SF_WT16(0, 0, ct, part);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                    for (int part = 0; part < 2; ++part) X[r][ph][part] = SF_PX16(0, ph, r, part);
+            __builtin_amdgcn_sched_barrier(0);
+            // slice 2 of THIS unit's weights (its slot was free only after the previous unit's closing barrier), then the next
+            // unit's halo; one fence load covers both (slice 2 is first read after b0, the halo after this unit's closing barrier)
+            if (w_slice2_owed) SFC_DMA_WX(w_pk, half_u, 2);
+            const int q_f = PAR == 0 ? c_f : n_f, q_clip = PAR == 0 ? c_clip : n_clip, y0q = PAR == 0 ? c_y0 : n_y0, x0q = PAR == 0 ? c_x0 : n_x0;
+            const float* const qsrc = q_f == 0 ? p.in2 + (size_t)q_clip * H * W * 64 : p.in + ((size_t)q_clip * T + (q_f - 1)) * H * W * 64;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qsrc), 0, item_bytes, 0x00020000);
+            const int org = ((y0q - 1) * W + x0q - 1) * 256 + nx_half * 128;
+            const bool interior = y0q > 0 && y0q + SF_IH - 1 <= H && x0q > 0 && x0q + SF_IW - 1 <= W;
+            SFC_DMA_HALO(rs, org, interior, y0q, x0q, cb ^ 1);
+            const unsigned fence = __builtin_amdgcn_raw_buffer_load_b32(rs, 0, 0, 0);
+            unsigned fence_w = 0;
+            row_setup(PAR);
+
+            auto substep = [&](auto sc) __attribute__((always_inline)) {
+                constexpr int S = decltype(sc)::value;              // 3 kx + ky
+                constexpr int kx = S / 3, ky = S % 3;
+                // the residual piece of a quarter is requested two sub-steps before the quarter is finished (one piece in flight: 4 registers)
+                if constexpr (S == 0) quarter_request(0);
+                if constexpr (S == 2 || S == 4 || S == 6) {
+                    const sff4 v = rres;
+                    quarter_request(S / 2);                         // (requested BEFORE the store: vmcnt is in order and counts stores)
+                    quarter_finish_with(PAR, S / 2 - 1, v);
+                }
+                if constexpr (S == 8) quarter_finish(PAR, 3);
+                if constexpr (ky == 0) {
+                    if constexpr (kx == 1) {
+                        SFC_STAMP();                                // 1: column tap 0 done
+                        asm volatile("" ::"v"(fence));              // slice 2 of this unit's weights has landed (and the halo, as it happens)
+                        SFC_STAMP();                                // 2: fence passed
+                        SFC_BARRIER();                              // b0: column tap 0 consumed; slice 2 complete
+                        SFC_STAMP();                                // 3: past b0
+                        if (w_replace) SFC_DMA_WX(nx_pk, nx_half, 0);
+                        if constexpr (PAR == 0) {                   // decode the next tile (past the end: this one again - a harmless re-read)
+                            const int kn = min(kt + 1, nt_tiles - 1);
+                            SFC_TILE(kn, n_f, n_clip, n_y0, n_x0);
+                        }
+                    }
+                    if constexpr (kx == 2) {
+                        SFC_STAMP();                                // 4: column tap 1 done
+                        SFC_BARRIER();                              // b1: column tap 1 consumed
+                        SFC_STAMP();                                // 5: past b1
+                        if (w_replace) SFC_DMA_WX(nx_pk, nx_half, 1);
+                        fence_w = __builtin_amdgcn_raw_buffer_load_b32(rs, 0, 0, 0);   // covers slices 0 and 1 of the next unit's weights
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr bool FIRST = PAR == 0 && S == 0;          // a tile's first products: C = the chain's shared half + bias (or 0 for that half itself)
+                constexpr bool NX = S < 8;                          // there is a next sub-step in this unit: (kx1, ky1)
+                constexpr int kx1 = (S + 1) / 3, ky1 = (S + 1) % 3;
+                const sff4 zero4 = sff4{0.f, 0.f, 0.f, 0.f};
+                // the three products of output row n_, output tile ct_, pixel half ph_: main += Wh Xh; cross += Wl Xh; cross += Wh Xl
+#define SF_MM(n_, ct_, ph_) do { accm[n_][2 * (ph_) + (ct_)] = sf_mfma16(X[ky + (n_)][ph_][0], Wv[ky][ct_][0], FIRST ? pbv[n_][2 * (ph_) + (ct_)] : accm[n_][2 * (ph_) + (ct_)]); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SF_CA(n_, ct_, ph_) do { accc[n_][2 * (ph_) + (ct_)] = sf_mfma16(X[ky + (n_)][ph_][0], Wv[ky][ct_][1], FIRST ? zero4 : accc[n_][2 * (ph_) + (ct_)]); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SF_CB(n_, ct_, ph_) do { accc[n_][2 * (ph_) + (ct_)] = sf_mfma16(X[ky + (n_)][ph_][1], Wv[ky][ct_][0], accc[n_][2 * (ph_) + (ct_)]); __builtin_amdgcn_sched_barrier(0); } while (0)
+                // refills for the next sub-step (one LDS read each, pinned between two MFMAs)
+#define SF_LW(ct_, part_) do { if constexpr (NX) Wv[ky1][ct_][part_] = SF_WT16(kx1, ky1, ct_, part_); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SF_LX(r_, ph_, part_) do { if constexpr (NX) X[r_][ph_][part_] = SF_PX16(kx1, ph_, r_, part_); __builtin_amdgcn_sched_barrier(0); } while (0)
+                // output row 0 (halo row ky), pixel half by pixel half; output row 1 (halo row ky + 1), output tile by output tile.  A register set is refilled
+                // two or three MFMAs behind its last reader (an LDS return into a register an MFMA has just read costs wait states on a 16-cycle instruction):
+                // the next sub-step's weights go where halo row ky was, the next halo row (or rows 0 / 1 of the next column tap) where this sub-step's weights were
+                SF_MM(0, 0, 0); SF_MM(0, 1, 0); SF_CA(0, 0, 0); SF_CA(0, 1, 0); SF_CB(0, 0, 0); SF_CB(0, 1, 0);
+                SF_MM(0, 0, 1); SF_LW(0, 0);
+                SF_MM(0, 1, 1); SF_LW(0, 1);
+                SF_CA(0, 0, 1); SF_CA(0, 1, 1); SF_CB(0, 0, 1); SF_CB(0, 1, 1);
+                SF_MM(1, 0, 0); SF_LW(1, 0);
+                SF_MM(1, 0, 1); SF_CA(1, 0, 0); SF_LW(1, 1);
+                SF_CA(1, 0, 1); SF_CB(1, 0, 0); SF_CB(1, 0, 1);
+                SF_MM(1, 1, 0); SF_LX(ky1 != 0 ? ky + 2 : 0, 0, 0);
+                SF_MM(1, 1, 1); SF_CA(1, 1, 0); SF_LX(ky1 != 0 ? ky + 2 : 0, 0, 1);
+                SF_CA(1, 1, 1); SF_CB(1, 1, 0); SF_CB(1, 1, 1);
+                SF_LX(ky1 != 0 ? ky + 2 : 0, 1, 0); SF_LX(ky1 != 0 ? ky + 2 : 0, 1, 1);
+                if constexpr (ky1 == 0) { SF_LX(1, 0, 0); SF_LX(1, 0, 1); SF_LX(1, 1, 0); SF_LX(1, 1, 1); }
+#undef SF_MM
+#undef SF_CA
+#undef SF_CB
+#undef SF_LW
+#undef SF_LX
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            substep(std::integral_constant<int, 0>{});
+            substep(std::integral_constant<int, 1>{});
+            substep(std::integral_constant<int, 2>{});
+            substep(std::integral_constant<int, 3>{});
+            substep(std::integral_constant<int, 4>{});
+            substep(std::integral_constant<int, 5>{});
+            substep(std::integral_constant<int, 6>{});
+            substep(std::integral_constant<int, 7>{});
+            substep(std::integral_constant<int, 8>{});
+#undef SF_PX16
+#undef SF_WT16
+            if constexpr (PAR == 1) {
+                // The tile is complete.  A frame tile is handed to the epilogue; the shared half of a chain stays in registers
+                // (+ bias) as the initial C of the frames that follow, and is cleared behind the chain's last frame (the next
+                // tile is a shared half again: initial C = 0).  Branch-free (selects on wave-uniform conditions): arms that
+                // define 32-register vectors cost the allocator live copies of both.
+                const bool head = c_f == 0, last = c_f == ((SPLIT && kt >= nfull_tiles) ? sp_f1 : T);   // (the last frame of a whole chain / of this workgroup's part)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const sff4 fold = accm[n][q] + accc[n][q] * SF_ISCALE;
+                        accp[n][q] = fold;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pbv[n][q][r] = head ? fold[r] + bl[ech + 16 * (q & 1)] : (last ? 0.f : pbv[n][q][r]);   // (bias: from LDS, once per chain)
+                    }
+                ex0p = c_x0;
+                ey0p = c_y0;
+                eitemp = c_clip * T + (c_f - 1);
+                pending = !head;
+                c_f = n_f;
+                c_clip = n_clip;
+                c_y0 = n_y0;
+                c_x0 = n_x0;
+            }
+            w_slice2_owed = w_replace;                              // slice 2 of the next unit's weights goes once this unit's is consumed: at its start
+            w_pk = nx_pk;
+            SFC_STAMP();                                            // 6: groups 4-5 done
+            asm volatile("" ::"v"(fence), "v"(fence_w));            // the next unit's halo and weight slices 0, 1 have landed
+            SFC_STAMP();                                            // 7: fences passed
+            SFC_BARRIER();                                          // b2
+        };
+        unit(std::integral_constant<int, 0>{});
+        unit(std::integral_constant<int, 1>{});
+    }
+    // ---- the last tile (a frame tile): both rows
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        row_setup(n);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            quarter_request(q);
+            quarter_finish(n, q);
+        }
+    }
+#undef SFC_DMA_HALO
+#undef SFC_DMA_W
+#undef SFC_HALF
+#undef SFC_TILE
+#undef SFC_BARRIER
+}
+
+#endif  // PFNL_CHAIN16_BUILD
+
 hipError_t launch_conv3x3_sf_chain(const ConvSplitParams& p, hipStream_t s) {
     if (!p.in || !p.in2 || !p.wpack || !p.wpack2 || !p.bias || !p.out || !p.resid || p.items < 1 || p.H < 1 || p.W < 1 || p.accum || p.out_sf)
         return hipErrorInvalidValue;
@@ -945,6 +1334,24 @@ hipError_t launch_conv3x3_sf_chain(const ConvSplitParams& p, hipStream_t s) {
             (long long)(p.split_s - 1) * p.split_q >= p.add_div || (long long)p.split_s * p.split_q < p.add_div)
             return hipErrorInvalidValue;
     }
+    if ((p.wpack_m16 == nullptr) != (p.wpack2_m16 == nullptr) || (p.wpack_m16 && p.out2)) return hipErrorInvalidValue;
+#ifdef PFNL_CHAIN16_BUILD
+    if (p.wpack_m16 && !p.split_s) {                                       // the 16x16x32 form, on its own packs (split chains: the 32x32x16 kernel - its bookkeeping does not fit the registers)
+        ConvSplitParams q = p;
+        q.wpack = p.wpack_m16;
+        q.wpack2 = p.wpack2_m16;
+        static std::atomic<int> attr16[64];
+        if (!attr16[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_sf_chain16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
+            if (e != hipSuccess) return e;
+            attr16[dev] = 1;
+        }
+        hipLaunchKernelGGL((conv3x3_sf_chain16_kernel<false>), dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, q);
+        return hipGetLastError();
+    }
+#else
+    if (p.wpack_m16) return hipErrorInvalidValue;                          // (the 16x16x32 chain kernel is not in this build)
+#endif
     static std::atomic<int> attr_dev[64][4];
     const int var = (p.out2 ? 1 : 0) + (p.split_s ? 2 : 0);               // out2: the split-format copy of the output (the next block's inp0)
     const void* const fns[4] = {reinterpret_cast<const void*>(conv3x3_sf_chain_kernel<false, false>), reinterpret_cast<const void*>(conv3x3_sf_chain_kernel<true, false>),

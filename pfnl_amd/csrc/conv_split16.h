@@ -39,6 +39,8 @@ struct ConvSplitParams {
                              // of a (clip, tile) - for launches with fewer chains than workgroups (capi.hip, "MID shapes").  The two input-channel
                              // halves of a tile are summed in the order its position in the workgroup's sequence gives (boustrophedon:
                              // the weights in LDS serve two units in a row), so the work order moves the last bit of some results
+    const uint16_t* wpack_m16;   // launch_conv3x3_sf_chain only, both or neither: conv3x3_split16_pack_weights16 of wpack / wpack2 - the launch then runs on
+    const uint16_t* wpack2_m16;  // v_mfma_f32_16x16x32_f16 (conv3x3_sf_chain16_kernel).  Not with out2
 };
 
 // THE SPLIT FORMAT ("SF") of an activation tensor that only ever feeds MFMA operands (conv1_i's output, conv10_i's output):
@@ -48,6 +50,7 @@ struct ConvSplitParams {
 // 32 M + 8 (c & 3) .. + 7 of part c >> 2: the unit the 3x3 kernels' LDS tiles and the 1x1 kernel's operands are made of.
 hipError_t launch_conv3x3_split16(const ConvSplitParams& p, hipStream_t s);
 size_t conv3x3_split16_pack_halfs();                                  // 16-bit elements per packed 3x3 64->64 kernel
+void conv3x3_split16_pack_weights16(const float* hwio, int cin_total, int cin_begin, uint16_t* dst);   // the order of the 16x16x32 kernels: [half][kx][ky][16-channel output tile][hi / lo'][lane] (64 output channels)
 void conv3x3_split16_pack_weights(const float* hwio, int cin_total, int cin_begin, uint16_t* dst, int cout = 64,   // cout < 64: zero-padded
                                   bool identity_rows = false);        // true: the pack conv3x3_sf_kernel takes
 

@@ -1561,6 +1561,27 @@ void conv3x3_split16_pack_weights(const float* hwio, int cin_total, int cin_begi
                             }
 }
 
+// The same kernel in the order of the v_mfma_f32_16x16x32_f16 kernels (conv_sf.hip, conv3x3_sf_chain16_kernel: A = weights, 16 output channels x 32 input
+// channels per operand): [half][kx][ky][output tile c4][part][lane][e] = W[ky][kx][cin_begin + 32 half + 8 (lane >> 4) + e][16 c4 + (lane & 15)] - the 24 KB per
+// column tap kx are again one LDS-DMA slice
+void conv3x3_split16_pack_weights16(const float* hwio, int cin_total, int cin_begin, uint16_t* dst) {
+    for (int half = 0; half < 2; ++half)
+        for (int kx = 0; kx < 3; ++kx)
+            for (int ky = 0; ky < 3; ++ky)
+                for (int c4 = 0; c4 < 4; ++c4)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int ci = cin_begin + 32 * half + 8 * (lane >> 4) + e;
+                            const int co = 16 * c4 + (lane & 15);
+                            const float w = hwio[((size_t)(ky * 3 + kx) * cin_total + ci) * 64 + co];
+                            const _Float16 hi = (_Float16)w;
+                            const float lo = (w - (float)hi) * CS_SCALE;
+                            const size_t base = (size_t)half * (CS_W_BYTES / 2) + ((((size_t)(kx * 3 + ky) * 4 + c4) * 2) * 512);
+                            dst[base + lane * 8 + e] = f16_bits((float)hi);
+                            dst[base + 512 + lane * 8 + e] = f16_bits(lo);
+                        }
+}
+
 size_t conv1x1_c10_pack_halfs(int T) { return (size_t)T * 8192; }      // 16 KB per frame
 
 // conv10_i for conv3x3_c1c10_kernel: HWIO [1,1,T*64,64] -> [f][k-step q = 2M + h][g][part][lane][e] =

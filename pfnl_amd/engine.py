@@ -117,7 +117,7 @@ class PFNLEngine:
         self._ready = True
 
     OPTION_KEYS = ("precision", "strict_fp32", "conv3x3", "conv1x1", "conv2", "merge1", "nonlocal", "nl_type", "nl_sub_sample", "small", "small_c10",
-                   "split16_sf", "split16_chain", "split16_c10", "split16_mid", "split16_sf0", "split16_splitchains", "bf16_conv10", "bf16_mfma", "graph")
+                   "split16_sf", "split16_chain", "split16_c10", "split16_mid", "split16_sf0", "split16_splitchains", "bf16_conv10", "bf16_mfma", "split16_mfma", "graph")
 
     def clone(self) -> "PFNLEngine":
         """A second handle on the same device with the same weights (device-to-device copy of the packed blobs: pfnl_copy_weights) and the

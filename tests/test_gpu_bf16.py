@@ -170,6 +170,33 @@ def test_forward_bf16_split_chains(T, scale, nb, H, W, Bs):
     eng.close()
 
 
+@pytest.mark.parametrize("T,scale,nb,B,H,W", [(7, 4, 3, 4, 128, 128), (7, 4, 2, 5, 128, 128), (5, 2, 2, 2, 130, 98), (3, 4, 2, 1, 270, 480), (7, 4, 2, 1, 64, 96)])
+def test_forward_bf16_mfma_forms(T, scale, nb, B, H, W):
+    """Round 6 (late): the two chained 3x3 launches of the bf16 trunk (reference model/pfnl.py:49-51, 65-71) on v_mfma_f32_16x16x32_bf16 (option bf16_mfma=16, the
+    default: the K = 32 shape costs 14 % less energy per FLOP under the package power cap) against the 32x32x16 form (=32): another summation
+    order inside the same rounding points - each repeatable bit for bit, each within the tolerance of the bf16 oracle, and within bf16 rounding of each other;
+    shapes with whole rounds of chains, split chains, ragged tiles, T = 3 / 5, 2x, and a mid shape (per-tile launches: the option changes nothing there)."""
+    geom = PFNLGeometry(num_frames=T, scale=scale, num_block=nb)
+    w = synth.synthetic_weights(geom, seed=T)
+    eng = PFNLEngine(geom, device=0)
+    eng.load_weights(w)
+    eng.set_option("precision", "bf16")
+    assert eng.get_option("bf16_mfma") == "16"
+    x, _ = synth.moving_field_clips(B, T, H, W, scale, seed=5)
+    y16 = eng.forward(x)
+    assert np.array_equal(y16, eng.forward(x))
+    eng.set_option("bf16_mfma", "32")
+    y32 = eng.forward(x)
+    assert np.array_equal(y32, eng.forward(x))
+    eng.set_option("bf16_mfma", "16")
+    ref = pfnl_fast.FastOracle(w, T, scale, nb, trunk_dtype="bf16").forward(x)
+    assert synth.psnr(y16, ref) > 55.0 and synth.psnr(y32, ref) > 55.0, (synth.psnr(y16, ref), synth.psnr(y32, ref))
+    assert synth.psnr(y16, y32) > 60.0, synth.psnr(y16, y32)
+    with pytest.raises(Exception):
+        eng.set_option("bf16_mfma", "8")
+    eng.close()
+
+
 def test_forward_bf16_1080p_against_oracle_subsample():
     """BASELINE.json configs[3] (1080p, bf16) against the ORACLE with the same rounding points
     (oracle/pfnl_fast.py trunk_dtype="bf16"): every 8th HR pixel + a dense 64x64 crop, generated once in the build

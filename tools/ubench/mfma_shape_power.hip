@@ -11,7 +11,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-template <int SHAPE>
+template <int SHAPE, int NACC = 8>
 __global__ __launch_bounds__(512, 1) void k(float* sink, long long* clk, int steps) {
     const int tid = threadIdx.x;
     half8 a[4], b[4];
@@ -29,10 +29,10 @@ __global__ __launch_bounds__(512, 1) void k(float* sink, long long* clk, int ste
     for (int st = 0; st < steps; ++st) {
 #pragma unroll
         for (int m = 0; m < 32; ++m) {
-            if (SHAPE == 32) acc32[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(m >> 2) & 3], b[m & 3], acc32[m & 3], 0, 0, 0);
+            if (SHAPE == 32) acc32[m % (NACC > 4 ? 4 : NACC)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(m >> 2) & 3], b[m & 3], acc32[m % (NACC > 4 ? 4 : NACC)], 0, 0, 0);
             else {
-                acc16[(2 * m) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(m >> 2) & 3], b[m & 3], acc16[(2 * m) & 7], 0, 0, 0);
-                acc16[(2 * m + 1) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(m >> 1) & 3], b[(m + 1) & 3], acc16[(2 * m + 1) & 7], 0, 0, 0);
+                acc16[(2 * m) % NACC] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(m >> 2) & 3], b[m & 3], acc16[(2 * m) % NACC], 0, 0, 0);
+                acc16[(2 * m + 1) % NACC] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(m >> 1) & 3], b[(m + 1) & 3], acc16[(2 * m + 1) % NACC], 0, 0, 0);
             }
         }
     }
@@ -44,12 +44,12 @@ __global__ __launch_bounds__(512, 1) void k(float* sink, long long* clk, int ste
     if (tid == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = w1 - w0; }
 }
 
-template <int SHAPE>
+template <int SHAPE, int NACC = 8>
 static void run(const char* name, float* sink, long long* clk, int ncu) {
     const int steps = 4096;
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    auto launch = [&]() { hipLaunchKernelGGL((k<SHAPE>), dim3(ncu), dim3(512), 0, 0, sink, clk, steps); };
+    auto launch = [&]() { hipLaunchKernelGGL((k<SHAPE, NACC>), dim3(ncu), dim3(512), 0, 0, sink, clk, steps); };
     launch(); CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0)); launch(); CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
     float one = 0.f; CHECK(hipEventElapsedTime(&one, e0, e1));
@@ -76,5 +76,13 @@ int main() {
     run<16>("v_mfma_f32_16x16x32_f16", sink, clk, ncu);
     run<32>("v_mfma_f32_32x32x16_f16", sink, clk, ncu);
     run<16>("v_mfma_f32_16x16x32_f16", sink, clk, ncu);
+    // how far apart must two 16x16x32 MFMAs on the SAME accumulator be?  (2 waves per SIMD: the partner fills what it can)
+    run<16, 4>("16x16x32, 4 accumulators in rotation", sink, clk, ncu);
+    run<16, 3>("16x16x32, 3 accumulators", sink, clk, ncu);
+    run<16, 2>("16x16x32, 2 accumulators", sink, clk, ncu);
+    run<16, 1>("16x16x32, 1 accumulator", sink, clk, ncu);
+    run<32, 4>("32x32x16, 4 accumulators in rotation", sink, clk, ncu);
+    run<32, 2>("32x32x16, 2 accumulators", sink, clk, ncu);
+    run<32, 1>("32x32x16, 1 accumulator", sink, clk, ncu);
     return 0;
 }
