@@ -642,8 +642,8 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
                     q.split_s = pl.split_s;
                     q.split_q = pl.split_q;
                     q.partial = pl.split_s ? h->c10part.p : nullptr;
-                    if (h->bf16_m16) q.wpack16 = w16 + h->off16_c1_m16[i];
                 }
+                if (h->bf16_m16) q.wpack16 = w16 + h->off16_c1_m16[i];   // (used where the launch goes to the third-generation kernel)
                 HIPCHK(launch_conv3x3_bf16(q, s));
             }
             if (fuse10 && pl.split_s) {   // split chains: the parts' raw conv10_i sums -> base (+ bias, leaky-relu, bf16) for the chains that were cut

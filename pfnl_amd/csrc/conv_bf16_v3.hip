@@ -682,16 +682,16 @@ hipError_t launch_conv3x3_bf16_v3(const ConvBf16Params& p, int mode, hipStream_t
     const int grid = ncu >= 8 ? ncu / 8 * 8 : 8;                    // whole XCDs; surplus workgroups exit at once
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    // p.wpack16 (conv3x3_bf16_pack_weights16): the M16 form of the kernel (modes 1 and 2: the trunk's two big launches) on that pack
+    // p.wpack16 (conv3x3_bf16_pack_weights16): the M16 form of the kernel on that pack
     ConvBf16Params q = p;
-    const bool m16 = p.wpack16 != nullptr && mode != 0;
+    const bool m16 = p.wpack16 != nullptr;
     if (m16) q.wpack = p.wpack16;
     if (p.split_s) {                                                // split chains: the chained modes only, geometry as the kernels assume it
         if (mode == 0 || p.flat || !b3_split_ok(p, grid) || (mode == 2 && !p.partial)) return hipErrorInvalidValue;
         if (m16) return mode == 1 ? b3_launch<1, true, true>(q, grid, dev, s) : b3_launch<2, true, true>(q, grid, dev, s);
         return mode == 1 ? b3_launch<1, true>(p, grid, dev, s) : b3_launch<2, true>(p, grid, dev, s);
     }
-    if (m16) return mode == 1 ? b3_launch<1, false, true>(q, grid, dev, s) : b3_launch<2, false, true>(q, grid, dev, s);
+    if (m16) return mode == 1 ? b3_launch<1, false, true>(q, grid, dev, s) : mode == 2 ? b3_launch<2, false, true>(q, grid, dev, s) : b3_launch<0, false, true>(q, grid, dev, s);
     if (mode == 1) return b3_launch<1>(p, grid, dev, s);
     if (mode == 2) return b3_launch<2>(p, grid, dev, s);
     return b3_launch<0>(p, grid, dev, s);
