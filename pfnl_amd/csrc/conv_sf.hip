@@ -931,10 +931,15 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
 // EXPERIMENT, not in the product build (-DPFNL_CHAIN16_BUILD; option split16_mfma=16).  Status at the end of round 6: parity-green (the golden
-// and full-size forwards), no spills at 256 VGPRs, no LDS bank conflicts - and 117 us per launch at configs[1] where the 32x32x16 kernel takes 105: it comes off the
-// power cap (1 365 W, 1.95 GHz) and loses ~2 500 cycles per unit that have not been found yet (not the epilogue's access width, not the accumulator distance,
-// not the conflicts the first swizzle had).  The timing build that says what is to be had (-DPFNL_X_MFMA16, two 16x16x32 per former 32x32x16 in the OLD
-// schedule): 95.6 us.
+// and full-size forwards), 256 VGPRs without a spill, no LDS bank conflicts - and AT PARITY with the 32x32x16 kernel, not ahead of it: configs[1] 4.659 against
+// 4.641 - 4.657 ms (sustained, same box); this launch 114 against 110 us, with conv3x3_c1c10_kernel 3.8 us faster beside it because the package leaves its power
+// cap (1 377 W, 1.83 against 1.64 GHz).  It needs 21 % more CYCLES than the kernel it replaces.  What was found on the way (each cost more than the MFMA shape gains):
+//   * ds_read_b128's lane groups make a 16x16x32 pixel operand collide under the 32x32x16 kernels' swizzle (SF_SWZ16 below: 4.2e6 conflict cycles -> 0);
+//   * the vector-memory counter is in order: a residual value used two sub-steps after its request waits behind the unit's halo DMA (an HBM round trip) - four
+//     sub-steps of flight (two quarters in flight) were worth 3 %;
+//   * ONE spilled register is a scratch load + s_waitcnt vmcnt(0), i.e. a wait for every DMA piece in flight: no spill is affordable in a kernel that keeps
+//     LDS-DMA in flight (the second pixel half's offset became an immediate for that: SF_SWZ16(px + 16) = SF_SWZ16(px)).
+// The timing build that says what is to be had (-DPFNL_X_MFMA16, two 16x16x32 per former 32x32x16 in the OLD schedule): -7 % on the forward.
 #ifdef PFNL_CHAIN16_BUILD
 // The same launch on v_mfma_f32_16x16x32_f16 (round 6, late; DESIGN.md R6.9: the K = 32 shape costs 14 % less energy per FLOP under the package power cap).
 // A = pixels (16 pixels x 32 input channels = a unit's channel half in ONE k-step), B = weights (32 channels x 16 output channels): lane (n = l & 15, kq = l >> 4)
@@ -1053,14 +1058,12 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain16_kernel(ConvS
 #define SFC_DMA_WX(pk_, half_, slot_) SFC_DMA_W(pk_, half_, slot_)
 #endif
 
-    int paddr[3][2];                                                // [column tap][pixel half]
+    int paddr[3];                                                   // [column tap]: pixel half 0; half 1 is 16 pixels = 2 048 bytes further (SF_SWZ16(px + 16) = SF_SWZ16(px)): an immediate
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
-            const int col = 16 * ph + (lane & 15) + kx;
-            paddr[kx][ph] = ((2 * rp) * SF_IW + col) * 128 + (((lane >> 4) ^ SF_SWZ16(col)) << 4);
-        }
+    for (int kx = 0; kx < 3; ++kx) {
+        const int col = (lane & 15) + kx;
+        paddr[kx] = ((2 * rp) * SF_IW + col) * 128 + (((lane >> 4) ^ SF_SWZ16(col)) << 4);
+    }
     const int lo_xor = 4 << 4;
     const unsigned char* const wlane = wl + nt * 4096 + lane * 16;  // [kx][ky][output tile 2 nt + ct][hi / lo'][lane] x 16 B
     const int ech = 32 * nt + (lane & 15);                          // the lane's channels: ech + 16 ct (D[pixel][channel]: rows 4 (lane >> 4) + r = pixels)
@@ -1080,7 +1083,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain16_kernel(ConvS
 
     __amdgpu_buffer_rsrc_t rsO;                                     // out == resid (the launcher checks): one resource per row
     int evoff = 0;
-    sff4 rres;                                                      // the residual piece of the quarter that is finished next
+    sff4 rres[2];                                                   // the residual values of two quarters in flight (an HBM load needs ~4 sub-steps: requested at S, used at S + 4)
     auto row_setup = [&](int n) __attribute__((always_inline)) {
         const int ey = ey0p + 2 * rp + n;
         const int nrec = (pending && ey < H) ? wbytes : 0;
@@ -1093,7 +1096,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain16_kernel(ConvS
         return;
 #endif
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rres[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsO, evoff + j * 256, (q >> 1) * 4096 + (q & 1) * 64, 0));
+        for (int j = 0; j < 4; ++j) rres[q & 1][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsO, evoff + j * 256, (q >> 1) * 4096 + (q & 1) * 64, 0));
     };
     auto quarter_finish_with = [&](int n, int q, const sff4 rv) __attribute__((always_inline)) {
 #ifdef SF_X_NOEPI
@@ -1107,7 +1110,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain16_kernel(ConvS
             sf_store_b32<SF_STORE_AUX>(v + rv[j], rsO, evoff + j * 256, (q >> 1) * 4096 + (q & 1) * 64);
         }
     };
-    auto quarter_finish = [&](int n, int q) __attribute__((always_inline)) { quarter_finish_with(n, q, rres); };
+    auto quarter_finish = [&](int n, int q) __attribute__((always_inline)) { quarter_finish_with(n, q, rres[q & 1]); };
 #define SFC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #ifndef SFC_SPREAD_HALO
 #define SFC_SPREAD_HALO 0
@@ -1161,7 +1164,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain16_kernel(ConvS
 #ifdef SF_X_PXLIN   /* experiment: linear (conflict-free) pixel operand reads - wrong results on purpose: where do the bank conflicts come from? */
 #define SF_PX16(kx_, ph_, r_, part_) (*reinterpret_cast<const sfh8*>(tile + lane * 16 + ((kx_) * 16 + (ph_) * 8 + (r_) * 2 + (part_)) * 1024))
 #else
-#define SF_PX16(kx_, ph_, r_, part_) (*reinterpret_cast<const sfh8*>(tile + (paddr[kx_][ph_] ^ ((part_) ? lo_xor : 0)) + (r_) * (SF_IW * 128)))
+#define SF_PX16(kx_, ph_, r_, part_) (*reinterpret_cast<const sfh8*>(tile + (paddr[kx_] ^ ((part_) ? lo_xor : 0)) + (r_) * (SF_IW * 128) + (ph_) * 2048))
 #endif
 #define SF_WT16(kx_, ky_, ct_, part_) (*reinterpret_cast<const sfh8*>(wlane + (((kx_) * 3 + (ky_)) << 13) + (((ct_) * 2 + (part_)) << 10)))
 #pragma unroll
@@ -1191,14 +1194,21 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain16_kernel(ConvS
             auto substep = [&](auto sc) __attribute__((always_inline)) {
                 constexpr int S = decltype(sc)::value;              // 3 kx + ky
                 constexpr int kx = S / 3, ky = S % 3;
-                // the residual piece of a quarter is requested two sub-steps before the quarter is finished (one piece in flight: 4 registers)
-                if constexpr (S == 0) quarter_request(0);
-                if constexpr (S == 2 || S == 4 || S == 6) {
-                    const sff4 v = rres;
-                    quarter_request(S / 2);                         // (requested BEFORE the store: vmcnt is in order and counts stores)
-                    quarter_finish_with(PAR, S / 2 - 1, v);
+                // the residual values of quarters 0, 1 are requested at the unit's start and used 4 - 5 sub-steps (~1 500 cycles: an HBM round trip with the unit's halo
+                // pieces in front of it in the in-order counter) later; those of quarters 2, 3 take their registers over (requested BEFORE the stores of 0, 1)
+                if constexpr (S == 0) {
+                    quarter_request(0);
+                    quarter_request(1);
                 }
-                if constexpr (S == 8) quarter_finish(PAR, 3);
+                if constexpr (S == 4 || S == 5) {
+                    const sff4 v = rres[S & 1];
+                    quarter_request(S - 2);
+                    quarter_finish_with(PAR, S - 4, v);
+                }
+                if constexpr (S == 8) {
+                    quarter_finish(PAR, 2);
+                    quarter_finish(PAR, 3);
+                }
                 if constexpr (ky == 0) {
                     if constexpr (kx == 1) {
                         SFC_STAMP();                                // 1: column tap 0 done
