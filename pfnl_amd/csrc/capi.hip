@@ -212,7 +212,11 @@ struct pfnl_handle {
     std::vector<size_t> off16s_c1, off16s_c2a, off16s_c2b, off16s_c10, off16s_c10f;   // (c10f: conv10_i as conv3x3_c1c10_kernel takes it)
     std::vector<size_t> off16s_c2a_sf, off16s_c2b_sf;         // ... with the identity row map conv3x3_sf_kernel takes (conv_sf.hip)
     std::vector<size_t> off16s_c2a_m16, off16s_c2b_m16;       // ... in the order of the v_mfma_f32_16x16x32_f16 chain kernel (conv3x3_split16_pack_weights16)
-    bool s16_m16 = false;                                     // option split16_mfma=16|32: the chain launch of conv2_i on 16x16x32 - an EXPERIMENT (builds with -DPFNL_CHAIN16_BUILD only)
+#ifdef PFNL_CHAIN16_BUILD
+    bool s16_m16 = true;                                      // option split16_mfma=16|32: the chain launch of conv2_i on v_mfma_f32_16x16x32_f16
+#else
+    bool s16_m16 = false;                                     // (the 16x16x32 chain kernel is not in this build)
+#endif
     std::vector<size_t> off16m_c1, off16m_c10, off16m_c2;     // small-shape packs (conv_small.hip), in the same blob
     size_t off16m_m1 = 0;
     // The f16-pipe kernels of the fp32 path have a DOMAIN (operands inside binary16's range; the non-local kernel: inputs x 2^7).

@@ -1281,6 +1281,9 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain16_kernel(ConvS
                 // tile is a shared half again: initial C = 0).  Branch-free (selects on wave-uniform conditions): arms that
                 // define 32-register vectors cost the allocator live copies of both.
                 const bool head = c_f == 0, last = c_f == ((SPLIT && kt >= nfull_tiles) ? sp_f1 : T);   // (the last frame of a whole chain / of this workgroup's part)
+                // (the lane's two bias values: read from LDS HERE, once per tile and in front of the loop - as 32 reads inside it, each with its own wait, they
+                // cost the kernel ~1 500 cycles per unit)
+                const float bias_q[2] = {bl[ech], bl[ech + 16]};
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -1288,7 +1291,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain16_kernel(ConvS
                         const sff4 fold = accm[n][q] + accc[n][q] * SF_ISCALE;
                         accp[n][q] = fold;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) pbv[n][q][r] = head ? fold[r] + bl[ech + 16 * (q & 1)] : (last ? 0.f : pbv[n][q][r]);   // (bias: from LDS, once per chain)
+                        for (int r = 0; r < 4; ++r) pbv[n][q][r] = head ? fold[r] + bias_q[q & 1] : (last ? 0.f : pbv[n][q][r]);
                     }
                 ex0p = c_x0;
                 ey0p = c_y0;
