@@ -212,11 +212,7 @@ struct pfnl_handle {
     std::vector<size_t> off16s_c1, off16s_c2a, off16s_c2b, off16s_c10, off16s_c10f;   // (c10f: conv10_i as conv3x3_c1c10_kernel takes it)
     std::vector<size_t> off16s_c2a_sf, off16s_c2b_sf;         // ... with the identity row map conv3x3_sf_kernel takes (conv_sf.hip)
     std::vector<size_t> off16s_c2a_m16, off16s_c2b_m16;       // ... in the order of the v_mfma_f32_16x16x32_f16 chain kernel (conv3x3_split16_pack_weights16)
-#ifdef PFNL_CHAIN16_BUILD
     bool s16_m16 = true;                                      // option split16_mfma=16|32: the chain launch of conv2_i on v_mfma_f32_16x16x32_f16
-#else
-    bool s16_m16 = false;                                     // (the 16x16x32 chain kernel is not in this build)
-#endif
     std::vector<size_t> off16m_c1, off16m_c10, off16m_c2;     // small-shape packs (conv_small.hip), in the same blob
     size_t off16m_m1 = 0;
     // The f16-pipe kernels of the fp32 path have a DOMAIN (operands inside binary16's range; the non-local kernel: inputs x 2^7).
@@ -1225,9 +1221,6 @@ int pfnl_set_option(pfnl_handle* h, const char* key, const char* value) {
         return 0;
     }
     if (k == "split16_mfma") {
-#ifndef PFNL_CHAIN16_BUILD
-        if (v == "16") return fail(PFNL_ERR_INVALID, "split16_mfma=16: the 16x16x32 chain kernel is an experiment and not in this build (-DPFNL_CHAIN16_BUILD)");
-#endif
         if (v == "16") h->s16_m16 = true;
         else if (v == "32") h->s16_m16 = false;
         else return fail(PFNL_ERR_INVALID, "split16_mfma must be 16 or 32");
@@ -1520,11 +1513,7 @@ int pfnl_finalize_weights(pfnl_handle* h) {
         h->off16s_c2b_sf.assign(nb, 0);
         h->off16s_c2a_m16.assign(nb, 0);
         h->off16s_c2b_m16.assign(nb, 0);
-#ifdef PFNL_CHAIN16_BUILD
-        const size_t blk = 7 * n3 + n1 + pfnl::conv1x1_c10_pack_halfs(T);   // (+ the two packs of the experimental 16x16x32 chain kernel)
-#else
-        const size_t blk = 5 * n3 + n1 + pfnl::conv1x1_c10_pack_halfs(T);
-#endif
+        const size_t blk = 7 * n3 + n1 + pfnl::conv1x1_c10_pack_halfs(T);   // (5 packs of the 32x32x16 kernels + 2 of the 16x16x32 chain kernel)
         h->off16s_c10f.assign(nb, 0);
         h->off16s_m1 = (size_t)nb * blk;
         const size_t m3 = pfnl::conv_small_pack_halfs(3, 1), m10 = pfnl::conv_small_pack_halfs(1, T);
@@ -1548,10 +1537,8 @@ int pfnl_finalize_weights(pfnl_handle* h) {
             h->off16s_c10f[i] = h->off16s_c2b_sf[i] + n3;
             h->off16s_c2a_m16[i] = h->off16s_c10f[i] + pfnl::conv1x1_c10_pack_halfs(T);
             h->off16s_c2b_m16[i] = h->off16s_c2a_m16[i] + n3;
-#ifdef PFNL_CHAIN16_BUILD
             pfnl::conv3x3_split16_pack_weights16(W("conv2_" + s).data(), 128, 0, &b16[h->off16s_c2a_m16[i]]);
             pfnl::conv3x3_split16_pack_weights16(W("conv2_" + s).data(), 128, 64, &b16[h->off16s_c2b_m16[i]]);
-#endif
             pfnl::conv1x1_c10_pack_weights(W("conv10_" + s).data(), T, &b16[h->off16s_c10f[i]]);
             pfnl::conv3x3_split16_pack_weights(W("conv2_" + s).data(), 128, 0, &b16[h->off16s_c2a_sf[i]], 64, true);
             pfnl::conv3x3_split16_pack_weights(W("conv2_" + s).data(), 128, 64, &b16[h->off16s_c2b_sf[i]], 64, true);

@@ -930,17 +930,16 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain_kernel(ConvSpl
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
-// EXPERIMENT, not in the product build (-DPFNL_CHAIN16_BUILD; option split16_mfma=16).  Status at the end of round 6: parity-green (the golden
-// and full-size forwards), 256 VGPRs without a spill, no LDS bank conflicts - and AT PARITY with the 32x32x16 kernel, not ahead of it: configs[1] 4.659 against
-// 4.641 - 4.657 ms (sustained, same box); this launch 114 against 110 us, with conv3x3_c1c10_kernel 3.8 us faster beside it because the package leaves its power
-// cap (1 377 W, 1.83 against 1.64 GHz).  It needs 21 % more CYCLES than the kernel it replaces.  What was found on the way (each cost more than the MFMA shape gains):
+// conv3x3_sf_chain16_kernel (round 6, late): what it took to get the 16x16x32 shape's energy gain through a kernel with no register to spare - each of these
+// cost MORE than the shape gains, and the first version was 12 % slower than the kernel it replaces:
 //   * ds_read_b128's lane groups make a 16x16x32 pixel operand collide under the 32x32x16 kernels' swizzle (SF_SWZ16 below: 4.2e6 conflict cycles -> 0);
-//   * the vector-memory counter is in order: a residual value used two sub-steps after its request waits behind the unit's halo DMA (an HBM round trip) - four
-//     sub-steps of flight (two quarters in flight) were worth 3 %;
+//   * the vector-memory counter is in order: a residual value used two sub-steps after its request waits behind the unit's halo DMA (an HBM round trip) - two
+//     quarters in flight for four sub-steps;
 //   * ONE spilled register is a scratch load + s_waitcnt vmcnt(0), i.e. a wait for every DMA piece in flight: no spill is affordable in a kernel that keeps
-//     LDS-DMA in flight (the second pixel half's offset became an immediate for that: SF_SWZ16(px + 16) = SF_SWZ16(px)).
-// The timing build that says what is to be had (-DPFNL_X_MFMA16, two 16x16x32 per former 32x32x16 in the OLD schedule): -7 % on the forward.
-#ifdef PFNL_CHAIN16_BUILD
+//     LDS-DMA in flight (the halo-DMA coordinates are recomputed per piece, the second pixel half's offset is an immediate: SF_SWZ16(px + 16) = SF_SWZ16(px));
+//   * 32 one-dword LDS reads of the bias inside the fold, each with its own full wait, were ~1 500 cycles per unit: two reads in front of the loop.
+// Found by comparing instruction counts of the two kernels' ISA (s_waitcnt lgkmcnt(0): 45 against 13) - the phase-stamp build spills.  Split chains stay on the
+// 32x32x16 kernel (their bookkeeping does not fit the registers).
 // The same launch on v_mfma_f32_16x16x32_f16 (round 6, late; DESIGN.md R6.9: the K = 32 shape costs 14 % less energy per FLOP under the package power cap).
 // A = pixels (16 pixels x 32 input channels = a unit's channel half in ONE k-step), B = weights (32 channels x 16 output channels): lane (n = l & 15, kq = l >> 4)
 // reads chunk kq (hi) / 4 + kq (lo') of halo pixel 16 ph + n + kx and of the weights of output channel 16 (2 nt + ct) + n, and owns - per output row, pixel half
@@ -1329,8 +1328,6 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain16_kernel(ConvS
 #undef SFC_BARRIER
 }
 
-#endif  // PFNL_CHAIN16_BUILD
-
 hipError_t launch_conv3x3_sf_chain(const ConvSplitParams& p, hipStream_t s) {
     if (!p.in || !p.in2 || !p.wpack || !p.wpack2 || !p.bias || !p.out || !p.resid || p.items < 1 || p.H < 1 || p.W < 1 || p.accum || p.out_sf)
         return hipErrorInvalidValue;
@@ -1348,7 +1345,6 @@ hipError_t launch_conv3x3_sf_chain(const ConvSplitParams& p, hipStream_t s) {
             return hipErrorInvalidValue;
     }
     if ((p.wpack_m16 == nullptr) != (p.wpack2_m16 == nullptr) || (p.wpack_m16 && p.out2)) return hipErrorInvalidValue;
-#ifdef PFNL_CHAIN16_BUILD
     if (p.wpack_m16 && !p.split_s) {                                       // the 16x16x32 form, on its own packs (split chains: the 32x32x16 kernel - its bookkeeping does not fit the registers)
         ConvSplitParams q = p;
         q.wpack = p.wpack_m16;
@@ -1362,9 +1358,6 @@ hipError_t launch_conv3x3_sf_chain(const ConvSplitParams& p, hipStream_t s) {
         hipLaunchKernelGGL((conv3x3_sf_chain16_kernel<false>), dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, q);
         return hipGetLastError();
     }
-#else
-    if (p.wpack_m16) return hipErrorInvalidValue;                          // (the 16x16x32 chain kernel is not in this build)
-#endif
     static std::atomic<int> attr_dev[64][4];
     const int var = (p.out2 ? 1 : 0) + (p.split_s ? 2 : 0);               // out2: the split-format copy of the output (the next block's inp0)
     const void* const fns[4] = {reinterpret_cast<const void*>(conv3x3_sf_chain_kernel<false, false>), reinterpret_cast<const void*>(conv3x3_sf_chain_kernel<true, false>),

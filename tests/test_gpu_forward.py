@@ -590,6 +590,7 @@ def test_forward_sf0_is_bit_identical(T, scale, nb, B, H, W):
     w = synth.synthetic_weights(geom, seed=T + nb)
     x = synth.uniform_clips(B, T, H, W, seed=H + B)
     eng = _engine_with(geom, w)
+    eng.set_option("split16_mfma", "32")                            # (the copy is written by the 32x32x16 chain kernel: the bit identity is with THAT kernel)
     assert eng.get_option("split16_sf0") == "off" and eng.plan(B, H, W)["structure"] in ("chain2", "chain2_split")   # (6 clips of 90x98: a cut last round as well)
     eng.set_option("split16_sf0", "on")
     pl = eng.plan(B, H, W)

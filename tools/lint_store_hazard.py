@@ -109,6 +109,24 @@ def regs_read(ins):
     return out
 
 
+def written_regs(ins):
+    """Registers the first operand of a vector instruction names (its destination); stores, branches, waits: none."""
+    t = ins.strip()
+    if not t.startswith(("v_", "ds_read", "global_load", "buffer_load", "scratch_load")) or t.startswith("v_cmp"):
+        return set()
+    ops = t.split(None, 1)
+    if len(ops) < 2:
+        return set()
+    first = ops[1].split(",")[0]
+    out = set()
+    for m in VREG.finditer(first):
+        if m.group(4) is not None:
+            out.add(m.group(4) + m.group(5))
+        else:
+            out.update(m.group(1) + str(r) for r in range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
 def mfma_dst(ins):
     m = MFMA.match(ins)
     return {m.group(1) + str(r) for r in range(int(m.group(2)), int(m.group(3)) + 1)} if m else None
@@ -135,6 +153,13 @@ def lint_mfma_lines(ins):
                 if (inside or mfma_in_asm) and not t.lstrip().startswith(("s_", "v_mfma")) and regs_read(t) & dst:
                     hits.append((s.strip(), t.strip(), waited))
                     break
+                if not inside and not mfma_in_asm:
+                    # a COMPILER-generated instruction that overwrites a result register (it got its own wait states): what is read from that
+                    # register from here on is not the MFMA's result any more (round 6: v_mul_f32 v48, .. / asm v_max_f32 v48, .., v48 behind a
+                    # v_mfma .. v[48:51] that had just MOVED its accumulator elsewhere)
+                    dst = dst - written_regs(t)
+                    if not dst:
+                        break
                 waited += 1
             j += 1
     return hits
@@ -160,7 +185,10 @@ def selftest():
         [("v_mfma_f32_32x32x16_f16 a[0:15], v[16:19], v[20:23], a[0:15]", C_), ("v_mfma_f32_32x32x16_f16 a[0:15], v[24:27], v[20:23], a[0:15]", C_)],
         [("v_mfma_f32_32x32x16_f16 v[0:15], v[16:19], v[20:23], v[0:15]", C_), ("v_add_f32 v40, v3, v41", C_)],
         [("v_mfma_f32_32x32x16_f16 a[0:15], v[16:19], v[20:23], a[0:15]", C_), ("v_accvgpr_read_b32 v40, a16", A)],
+        # (round 6) a compiler-generated VALU has overwritten the result register: the inline-asm reader reads THAT value, not the MFMA's
+        [("v_mfma_f32_16x16x32_f16 v[48:51], v[16:19], v[20:23], v[48:51]", C_), ("s_nop 3", C_), ("v_mul_f32_e32 v48, v60, v86", C_), ("v_max_f32 v48, v86, v48", A)],
     ]
+    bad.append([("v_mfma_f32_16x16x32_f16 v[48:51], v[16:19], v[20:23], v[48:51]", C_), ("v_mul_f32_e32 v48, v60, v86", C_), ("v_max_f32 v40, v86, v49", A)])   # (v49 is still the MFMA's)
     for k, snip in enumerate(bad):
         assert len(lint_mfma_lines(snip)) == 1, ("bad snippet %d not flagged" % k, snip)
     for k, snip in enumerate(good):

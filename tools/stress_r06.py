@@ -11,10 +11,14 @@ from pfnl_amd.spec import PFNLGeometry
 from pfnl_amd import synth
 
 
+worst16 = 0.0
+
+
 def run(seed=0, seconds=60.0):
     rng = np.random.default_rng(seed)
     t_end = time.time() + seconds
     n, ncut, worst, worst_strict = 0, 0, 0.0, 0.0
+    global worst16
     parts = {}
     engines = {}
     while time.time() < t_end:
@@ -35,9 +39,14 @@ def run(seed=0, seconds=60.0):
         x = synth.uniform_clips(B, T, H, W, seed=int(rng.integers(0, 1 << 30)))
         y = eng.forward(x)
         assert np.isfinite(y).all() and np.array_equal(y, eng.forward(x)), ("not repeatable", key, B, H, W, pl)
+        eng.set_option("split16_mfma", "32")                        # (split16_sf0's chain kernel is the 32x32x16 one: bit identity is with that kernel ...
+        y32 = eng.forward(x)
         eng.set_option("split16_sf0", "on")
-        assert np.array_equal(y, eng.forward(x)), ("split16_sf0 moved a bit", key, B, H, W, pl)
+        assert np.array_equal(y32, eng.forward(x)), ("split16_sf0 moved a bit", key, B, H, W, pl)
         eng.set_option("split16_sf0", "off")
+        eng.set_option("split16_mfma", "16")
+        worst16 = max(worst16, float(np.abs(y - y32).max()))        # ... and the default 16x16x32 chain kernel within summation-order noise of it)
+        assert np.abs(y - y32).max() < 2e-5, ("16x16x32 chain kernel", key, B, H, W, float(np.abs(y - y32).max()))
         if pl["structure"] == "chain2_split":
             ncut += 1
             parts[(pl["split_parts"], pl["part_frames"])] = parts.get((pl["split_parts"], pl["part_frames"]), 0) + 1
@@ -70,4 +79,4 @@ def run(seed=0, seconds=60.0):
 if __name__ == "__main__":
     n, ncut, worst, ws, parts = run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, float(sys.argv[2]) if len(sys.argv) > 2 else 60.0)
     print("stress_r06: %d geometries on the two-launch block (all repeated bit for bit, split16_sf0 bit-equal), %d with split chains "
-          "(parts x frames: %s): max |cut - uncut| %.3g, max |cut - strict_fp32| %.3g" % (n, ncut, sorted(parts.items()), worst, ws))
+          "(parts x frames: %s): max |cut - uncut| %.3g, max |cut - strict_fp32| %.3g, max |16x16x32 - 32x32x16 chain kernel| %.3g" % (n, ncut, sorted(parts.items()), worst, ws, worst16))
