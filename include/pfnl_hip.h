@@ -152,8 +152,9 @@ int pfnl_finalize_weights(pfnl_handle* h);
  * key "bf16_conv10" = "fused" (default: conv10_i runs inside the conv1_i launch of the bf16 trunk) | "separate".
  * key "bf16_mfma" = "16" (default since round 6: the two chained 3x3 launches of the bf16 trunk issue v_mfma_f32_16x16x32_bf16 - the K = 32 shape costs 14 %
  *   less energy per FLOP on a package that sits on its power cap; 1080p 3.77 -> 3.58 ms) | "32" (the 32x32x16 form: same rounding points, another summation order).
- * key "split16_mfma" = "32" (default) | "16": the chain launch of conv2_i (fp32 path) on v_mfma_f32_16x16x32_f16 - an EXPERIMENT that is not in the product
- *   build (-DPFNL_CHAIN16_BUILD): "16" is refused with PFNL_ERR_INVALID.
+ * key "split16_mfma" = "16" (default since round 6: the chain launch of conv2_i - fp32 path, whole rounds of at least one (clip, tile) chain per CU - issues
+ *   v_mfma_f32_16x16x32_f16, conv3x3_sf_chain16_kernel; split chains, split16_sf0 and launches with fewer chains stay on the 32x32x16 kernel) | "32".
+ *   pfnl_plan's mfma field says which ran.  Same operands, another summation order: results agree within rounding (observed 2e-7), not bit for bit.
  * key "bf16_nonlocal" = "f16" (the only value since round 4: the non-local block of precision=bf16 on the f16 matrix pipe with
  *                 binary16 operands, fp32 accumulation and softmax state - nonlocal_f16.hip, hi parts only; within 1e-3 of the
  *                 fp64 block on [0,1]-scale outputs, measured 1e-4 ... 5e-4.  Round 1's split-operand bf16 kernel - 2.5x the
@@ -190,7 +191,7 @@ int pfnl_workspace_bytes(pfnl_handle* h, int B, int H, int W, size_t* bytes);
 /* THE LAUNCH PLAN of the progressive-fusion trunk (reference model/pfnl.py:65-71) for a [B,T,H,W,3] forward under the handle's current
  * options, as text: "<structure> launches_per_block=<n> c1x1=<launches of class conv1x1 among them> precision=<..> conv3x3=<..> conv1x1=<..>
  * c10_fused=<0|1> chain=<0|1> sf0=<0|1> strict=<0|1> tiles=<8x32-pixel tiles per per-frame launch> chains=<(clip, tile) chains>
- * whole_chains=<n> split_parts=<s> part_frames=<q> nl=<split16 | f16 | f32 | general_f32: the non-local block's kernel family> nl_pack_fused=<0|1>".  Structures: "small2" / "small3" (conv_small.hip,
+ * whole_chains=<n> split_parts=<s> part_frames=<q> nl=<split16 | f16 | f32 | general_f32: the non-local block's kernel family> nl_pack_fused=<0|1> mfma=<16|32: the MFMA shape of the chained 3x3 launches - 16 = v_mfma_f32_16x16x32_*: the bf16 trunk's, and the fp32 chain launch of conv2_i when every CU has a chain>".  Structures: "small2" / "small3" (conv_small.hip,
  * below ~0.78 tiles per CU: 200 on a 256-CU device), "mid4" (four per-tile launches, below ~0.53 chains per CU: 136), "chain2" (conv1_i +
  * conv10_i, then the whole of conv2_i), "chain2_split" (the same with the chains of a last, partial round cut by frames: option
  * split16_splitchains) and "chain2_sf0" (the same with a split-format copy of every block's output so that the next block's

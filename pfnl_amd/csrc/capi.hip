@@ -428,6 +428,8 @@ struct TrunkPlan {
     int c1x1_launches = 0;                 // launches per block of class conv1x1 (conv10_i on its own / c10_finalize_kernel)
     int launches_per_block = 0;
     int tiles8x32 = 0, chains = 0;
+    int mfma = 32;                         // MFMA shape of the chained 3x3 launches: 16 = v_mfma_f32_16x16x32_* (bf16: conv_bf16_v3.hip M16; fp32: the chain launch
+                                           // of conv2_i, conv3x3_sf_chain16_kernel - whole rounds of at least a chain per CU only), 32 = 32x32x16
     const char* name = "";
 };
 
@@ -461,6 +463,7 @@ TrunkPlan trunk_plan(const pfnl_handle* h, int B, int H, int W) {
             }
         }
         pl.name = pl.bmid ? "bf16_mid4" : (pl.fuse10 ? (pl.split_s ? "bf16_3_split" : "bf16_3") : "bf16_4");
+        pl.mfma = h->bf16_m16 ? 16 : 32;
         return pl;
     }
     pl.strict = h->strict || h->strict_once || !h->weights_f16_ok;   // f32-MFMA kernels only
@@ -504,6 +507,9 @@ TrunkPlan trunk_plan(const pfnl_handle* h, int B, int H, int W) {
             }
         }
     }
+    // the chain launch on 16x16x32: where every CU has a chain the launch sits on the power cap and the shape's energy counts; below that (UDM10: 230
+    // chains) its extra cycles do (+0.9 %); split chains and the split-format copy stay on the 32x32x16 kernel
+    pl.mfma = (h->s16_m16 && pl.c10_fused && pl.chain && !pl.sf0 && !pl.split_s && pl.chains >= conv_split16_grid()) ? 16 : 32;
     pl.name = pl.mid ? "mid4" : (pl.c10_fused && pl.chain) ? (pl.sf0 ? "chain2_sf0" : (pl.split_s ? "chain2_split" : "chain2"))
             : pl.algo == 4 ? (pl.launches_per_block == 3 ? "split16_3" : "split16_4")
             : pl.algo == 3 ? (pl.conv2_grouped ? "winograd_ws3" : "winograd_ws4")
@@ -643,7 +649,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
                     q.split_q = pl.split_q;
                     q.partial = pl.split_s ? h->c10part.p : nullptr;
                 }
-                if (h->bf16_m16) q.wpack16 = w16 + h->off16_c1_m16[i];   // (used where the launch goes to the third-generation kernel)
+                if (pl.mfma == 16) q.wpack16 = w16 + h->off16_c1_m16[i];   // (used where the launch goes to the third-generation kernel)
                 HIPCHK(launch_conv3x3_bf16(q, s));
             }
             if (fuse10 && pl.split_s) {   // split chains: the parts' raw conv10_i sums -> base (+ bias, leaky-relu, bf16) for the chains that were cut
@@ -677,7 +683,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
                 q.n_full = pl.n_full;
                 q.split_s = pl.split_s;
                 q.split_q = pl.split_q;
-                if (h->bf16_m16) q.wpack16 = w16 + h->off16_c2b_m16[i];
+                if (pl.mfma == 16) q.wpack16 = w16 + h->off16_c2b_m16[i];
                 HIPCHK(launch_conv3x3_bf16(q, s));
             }
         }
@@ -874,7 +880,7 @@ int forward_device(pfnl_handle* h, const float* in, float* out, int B, int Hfull
             q.n_full = pl.n_full;
             q.split_s = pl.split_s;
             q.split_q = pl.split_q;
-            if (h->s16_m16 && !out_sf0) {                           // the 16x16x32 form of the launch (whole rounds; split chains stay on 32x32x16)
+            if (pl.mfma == 16) {                                    // (trunk_plan: whole rounds with a chain per CU)
                 q.wpack_m16 = w16s + h->off16s_c2b_m16[i];
                 q.wpack2_m16 = w16s + h->off16s_c2a_m16[i];
             }
@@ -1608,14 +1614,14 @@ int pfnl_plan(pfnl_handle* h, int B, int H, int W, char* buf, size_t buflen) {
     static const char* const a1[] = {"tiled", "stream", "split16"};
     char tmp[384];
     if (pl.bf16)
-        std::snprintf(tmp, sizeof tmp, "%s launches_per_block=%d c1x1=%d precision=bf16 tiles=%d chains=%d whole_chains=%d split_parts=%d part_frames=%d nl=%s nl_pack_fused=%d",
-                      pl.name, pl.launches_per_block, pl.c1x1_launches, pl.tiles8x32, pl.chains, pl.split_s ? pl.n_full : pl.chains, pl.split_s, pl.split_q, nln[nlf], nl_fused);
+        std::snprintf(tmp, sizeof tmp, "%s launches_per_block=%d c1x1=%d precision=bf16 tiles=%d chains=%d whole_chains=%d split_parts=%d part_frames=%d nl=%s nl_pack_fused=%d mfma=%d",
+                      pl.name, pl.launches_per_block, pl.c1x1_launches, pl.tiles8x32, pl.chains, pl.split_s ? pl.n_full : pl.chains, pl.split_s, pl.split_q, nln[nlf], nl_fused, pl.mfma);
     else
         std::snprintf(tmp, sizeof tmp, "%s launches_per_block=%d c1x1=%d precision=fp32 conv3x3=%s conv1x1=%s c10_fused=%d chain=%d sf0=%d strict=%d tiles=%d chains=%d "
-                      "whole_chains=%d split_parts=%d part_frames=%d nl=%s nl_pack_fused=%d",
+                      "whole_chains=%d split_parts=%d part_frames=%d nl=%s nl_pack_fused=%d mfma=%d",
                       pl.name, pl.launches_per_block, pl.c1x1_launches, pl.small ? "small" : a3[pl.algo < 0 || pl.algo > 4 ? 2 : pl.algo],
                       a1[pl.conv1x1_algo < 0 || pl.conv1x1_algo > 2 ? 0 : pl.conv1x1_algo], pl.c10_fused ? 1 : 0, pl.chain ? 1 : 0, pl.sf0 ? 1 : 0,
-                      pl.strict ? 1 : 0, pl.tiles8x32, pl.chains, pl.split_s ? pl.n_full : pl.chains, pl.split_s, pl.split_q, nln[nlf], nl_fused);
+                      pl.strict ? 1 : 0, pl.tiles8x32, pl.chains, pl.split_s ? pl.n_full : pl.chains, pl.split_s, pl.split_q, nln[nlf], nl_fused, pl.mfma);
     if (std::strlen(tmp) + 1 > buflen) return fail(PFNL_ERR_INVALID, "buffer too small");
     std::strcpy(buf, tmp);
     return 0;

@@ -610,6 +610,35 @@ def test_forward_sf0_is_bit_identical(T, scale, nb, B, H, W):
     eng.close()
 
 
+def test_chain_launch_mfma_shapes():
+    """Round 6 (late): the chain launch of conv2_i (reference model/pfnl.py:51, 69-71) on v_mfma_f32_16x16x32_f16 (conv3x3_sf_chain16_kernel, option split16_mfma=16, the
+    default) against the 32x32x16 kernel: pfnl_plan's mfma field says which runs (16 only for whole rounds with a chain per CU), each form repeats bit for bit, both
+    agree with the oracle and with each other within summation-order noise; split chains and fewer chains than CUs stay on 32x32x16 (same bits under either value)."""
+    geom = PFNLGeometry(num_block=3)
+    w = synth.synthetic_weights(geom, seed=3)
+    eng = _engine_with(geom, w)
+    fo = pfnl_fast.FastOracle(w, 7, 4, 3)
+    for B, H, W, want in ((4, 128, 128, 16), (2, 180, 318, 16), (1, 180, 318, 32), (5, 128, 128, 32), (1, 64, 64, 32)):
+        x = synth.uniform_clips(B, 7, H, W, seed=B + W)
+        assert eng.get_option("split16_mfma") == "16"
+        pl = eng.plan(B, H, W)
+        assert pl["mfma"] == want, (B, H, W, pl)
+        y16 = eng.forward(x)
+        assert np.array_equal(y16, eng.forward(x))
+        eng.set_option("split16_mfma", "32")
+        assert eng.plan(B, H, W)["mfma"] == 32
+        y32 = eng.forward(x)
+        eng.set_option("split16_mfma", "16")
+        if want == 32:
+            assert np.array_equal(y16.view(np.uint32), y32.view(np.uint32)), (B, H, W)
+        else:
+            assert np.abs(y16 - y32).max() < 2e-6, (B, H, W, np.abs(y16 - y32).max())
+        if B * H * W <= 4 * 128 * 128:
+            ref = fo.forward(x)
+            assert np.abs(y16 - ref).max() < ABS_TOL and np.abs(y32 - ref).max() < ABS_TOL
+    eng.close()
+
+
 @pytest.mark.parametrize("label,gk,opts,B,H,W", [
     ("fp32 configs[1]", {}, {}, 4, 128, 128),
     ("fp32 configs[0]", {}, {}, 1, 32, 32),
