@@ -1166,16 +1166,19 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain16_kernel(ConvS
 #define SF_PX16(kx_, ph_, r_, part_) (*reinterpret_cast<const sfh8*>(tile + (paddr[kx_] ^ ((part_) ? lo_xor : 0)) + (r_) * (SF_IW * 128) + (ph_) * 2048))
 #endif
 #define SF_WT16(kx_, ky_, ct_, part_) (*reinterpret_cast<const sfh8*>(wlane + (((kx_) * 3 + (ky_)) << 13) + (((ct_) * 2 + (part_)) << 10)))
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int part = 0; part < 2; ++part) Wv[0][ct][part] = SF_WT16(0, 0, ct, part);
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int ph = 0; ph < 2; ++ph)
-#pragma unroll
-                    for (int part = 0; part < 2; ++part) X[r][ph][part] = SF_PX16(0, ph, r, part);
+            // (in the order the first sub-step uses them: LDS returns are in order, so its first MFMA waits for two reads, not for twelve)
+            Wv[0][0][0] = SF_WT16(0, 0, 0, 0);
+            X[0][0][0] = SF_PX16(0, 0, 0, 0);
+            Wv[0][1][0] = SF_WT16(0, 0, 1, 0);
+            Wv[0][0][1] = SF_WT16(0, 0, 0, 1);
+            Wv[0][1][1] = SF_WT16(0, 0, 1, 1);
+            X[0][0][1] = SF_PX16(0, 0, 0, 1);
+            X[0][1][0] = SF_PX16(0, 1, 0, 0);
+            X[0][1][1] = SF_PX16(0, 1, 0, 1);
+            X[1][0][0] = SF_PX16(0, 0, 1, 0);
+            X[1][1][0] = SF_PX16(0, 1, 1, 0);
+            X[1][0][1] = SF_PX16(0, 0, 1, 1);
+            X[1][1][1] = SF_PX16(0, 1, 1, 1);
             __builtin_amdgcn_sched_barrier(0);
             // slice 2 of THIS unit's weights (its slot was free only after the previous unit's closing barrier), then the next
             // unit's halo; one fence load covers both (slice 2 is first read after b0, the halo after this unit's closing barrier)
