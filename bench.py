@@ -73,7 +73,7 @@ CONV3X3_KERNELS = {
                       ["conv_wino.hip", "wino_geom.h"]),
     "direct": ("conv_mfma_kernel<3,16,*> (3x3 64->64 f32 MFMA implicit GEMM)", ["conv_mfma.hip"]),
     "split16": ("conv3x3_c1c10_kernel (conv1_i + conv10_i in one launch: the frame tiles leave as split-format lines through LDS, where conv10_i takes them "
-                "as MFMA operands) + conv3x3_sf_chain_kernel (the whole of conv2_i: split-format input and weights by LDS-DMA, shared half "
+                "as MFMA operands) + conv3x3_sf_chain16_kernel / conv3x3_sf_chain_kernel (the whole of conv2_i on v_mfma_f32_16x16x32_f16 / 32x32x16 - pfnl_plan mfma: split-format input and weights by LDS-DMA, shared half "
                 "in registers): direct 3x3 64->64 on f16 MFMA with exactly split fp32 operands, 3 MFMAs per product block, fp32 accumulation",
                 ["conv_split16.hip", "conv_sf.hip"]),
     "small": ("conv_small_kernel<3,R> (small-shape trunk: conv1_i and the whole of conv2_i, 4 waves per R x 32-pixel tile, split-f16 MFMA, weights "
