@@ -1091,16 +1091,10 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain16_kernel(ConvS
     };
     // quarter q = 2 ph + ct of a row: channel ech + 16 ct of the 4 pixels 16 ph + 4 (lane >> 4) + j - 16 lanes x 4 B = 64 contiguous bytes per pixel and access
     auto quarter_request = [&](int q) __attribute__((always_inline)) {
-#ifdef SF_X_NOEPI   /* experiment: no residual loads, no stores (wrong results on purpose) */
-        return;
-#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) rres[q & 1][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsO, evoff + j * 256, (q >> 1) * 4096 + (q & 1) * 64, 0));
     };
     auto quarter_finish_with = [&](int n, int q, const sff4 rv) __attribute__((always_inline)) {
-#ifdef SF_X_NOEPI
-        return;
-#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float v = accp[n][q][j];                                // (shared half + bias are already in: initial C of the tile)
