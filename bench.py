@@ -48,6 +48,7 @@ STREAM_MIX_CEILING_GBS = 5600.0
 # operands next to an HBM stream takes t = a F + b B - the matrix pipe alone sustains 1 / a = 1.67 - 1.74 PFLOP/s at 1.7 GHz under the 1 400 W
 # cap, and every HBM byte costs the time of ~210 MFMA FLOPs on top (NOT max(t_mfma, t_bytes): at the trunk's mixes that would be 1.4 - 1.6x less)
 POWER_CAP_MS_PER_TFLOP = 0.587
+POWER_CAP_MS_PER_TFLOP_16 = 0.49                                    # the same for v_mfma_f32_16x16x32_* (2 030 - 2 060 TFLOP/s back to back: tools/ubench/mfma_shape_power.hip)
 POWER_CAP_US_PER_GB = 123.0
 CU_PORT_B_PER_CLK = 11.2                                           # what a CU's memory port moved per shader clock with nothing else to do (ibid.)
 PREWARM_S = 0.3                                                    # untimed steps in front of the warm-up: the clock ramp of an idle chip
@@ -84,12 +85,14 @@ CONV3X3_KERNELS = {
 }
 
 
-def power_cap_model(executed_flops, moved_bytes, avg_ms):
+def power_cap_model(executed_flops, moved_bytes, avg_ms, share16=0.0):
     """What a launch with this many executed MFMA FLOPs and HBM bytes takes on the power cap according to the micro-benchmark's fit (no LDS
-    operand reads, no VALU, no launch ramp: a floor), next to what it took."""
-    t = POWER_CAP_MS_PER_TFLOP * executed_flops / 1e12 + POWER_CAP_US_PER_GB * 1e-3 * moved_bytes / 1e9
+    operand reads, no VALU, no launch ramp: a floor), next to what it took.  share16: the part of the FLOPs issued as v_mfma_f32_16x16x32_*
+    (pfnl_plan mfma=16: the bf16 trunk's chained launches; the fp32 chain launch of conv2_i), which cost 14 % less."""
+    a = POWER_CAP_MS_PER_TFLOP * (1.0 - share16) + POWER_CAP_MS_PER_TFLOP_16 * share16
+    t = a * executed_flops / 1e12 + POWER_CAP_US_PER_GB * 1e-3 * moved_bytes / 1e9
     return {"model_ms_per_launch": round(t, 4), "measured_ms_per_launch": round(avg_ms, 4), "model_over_measured": round(t / avg_ms, 4),
-            "ms_per_tflop": POWER_CAP_MS_PER_TFLOP, "us_per_gb": POWER_CAP_US_PER_GB,
+            "ms_per_tflop": round(a, 4), "us_per_gb": POWER_CAP_US_PER_GB, "flop_share_on_16x16x32": round(share16, 3),
             "note": "t = a F + b B under the 1 400 W package cap, a and b measured by tools/ubench/energy_mix.hip (profiles/r06_ubench_energy_mix.txt): "
                     "MFMAs on data-like operands + an HBM stream, nothing else; model_over_measured near 1 = the launch is at the chip's power roofline"}
 
@@ -270,7 +273,8 @@ def conv3x3_roofline(geom, prof, B, H, W, plan, workload):
                 "launches_per_step": launches_per_step, "mbytes_per_launch": round(bytes_per_launch / 1e6, 2), "tiles_per_block": "5F+4B",
                 "stream_mix_ceiling_gbs": STREAM_MIX_CEILING_GBS, "hbm_vs_stream_mix_ceiling": round(gbs / STREAM_MIX_CEILING_GBS, 4),
                 "mfma_tflops": round(flops3 / launches_per_step / (avg_ms * 1e-3) / 1e12, 1), "mfma_peak_bf16_tflops": PEAK_F16_MFMA_TFLOPS,
-                "power_cap_model": power_cap_model((flops3 + geom.num_block * F * P * 64 * 64 * 2.0) / launches_per_step, bytes_per_launch, avg_ms)}
+                "power_cap_model": power_cap_model((flops3 + geom.num_block * F * P * 64 * 64 * 2.0) / launches_per_step, bytes_per_launch, avg_ms,
+                                                   share16=(2.0 * F / (2.0 * F + B)) * flops3 / (flops3 + geom.num_block * F * P * 64 * 64 * 2.0) if plan.get("mfma") == 16 else 0.0)}
     # fp32: conv1_i + conv2_i; the default kernel runs the whole of conv2_i as one grouped launch, the others launch its
     # shared half and its per-frame half separately
     # launches of the class per PF block: 2 with conv2_i as one launch (Winograd's grouped mode; the split-f16 chain kernel), else 3
@@ -343,7 +347,9 @@ def conv3x3_roofline(geom, prof, B, H, W, plan, workload):
                     "mfma_sustained_ceiling_tflops": SUSTAINED_F16_MFMA_TFLOPS,
                     "mfma_executed_vs_sustained_ceiling": round(ex / SUSTAINED_F16_MFMA_TFLOPS, 4),
                     "algorithmic_vs_f32_mfma_roof": round(direct_tflops / PEAK_F32_MFMA_TFLOPS, 4),
-                    "power_cap_model": power_cap_model(3.0 * flops_per_launch, bytes_per_launch + sf_copy, avg_ms),
+                    # (mfma=16: the chain launch of conv2_i = (F + B) of the (2F + B) 3x3 tile-layers of a block; conv1_i and conv10_i stay on 32x32x16)
+                    "power_cap_model": power_cap_model(3.0 * flops_per_launch, bytes_per_launch + sf_copy, avg_ms,
+                                                       share16=((F + B) * 9.0 / ((2 * F + B) * 9.0 + (F if c10 else 0))) if (plan.get("mfma") == 16 and chain) else 0.0),
                     "note": "frac = algorithmic bytes (or FLOPs) / time / peak.  mfma_executed_* counts the 3 f16 MFMAs a product block costs; "
                             "mfma_sustained_ceiling = what the chip sustains on this kernel's MFMA + LDS core alone under its power cap "
                             "(shader clock 1.3 - 1.6 GHz; profiles/r03_ubench_conv_core.txt)"})
