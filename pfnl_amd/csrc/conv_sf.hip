@@ -1192,8 +1192,10 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain16_kernel(ConvS
                 constexpr int kx = S / 3, ky = S % 3;
                 // the residual values of quarters 0, 1 are requested at the unit's start and used 4 - 5 sub-steps (~1 500 cycles: an HBM round trip with the unit's halo
                 // pieces in front of it in the in-order counter) later; those of quarters 2, 3 take their registers over (requested BEFORE the stores of 0, 1)
-                if constexpr (S == 0) quarter_request(0);
-                if constexpr (S == 1) quarter_request(1);
+                if constexpr (S == 0) {
+                    quarter_request(0);
+                    quarter_request(1);
+                }
                 if constexpr (S == 4 || S == 5) {
                     const sff4 v = rres[S & 1];
                     quarter_request(S - 2);
