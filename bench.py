@@ -733,7 +733,7 @@ def main():
                    "clips_per_gpu": B_PER_GPU, "global_batch": GB, "parallelism": "dp%d" % world, "backend": (args.backend if use_dist else None),
                    "comm": (("pfnl_comm (RCCL)" if comm is not None else "torch.distributed") if use_dist else None),
                    "comm_nranks": comm_nranks, "comm_required": bool(args.require_comm),
-                   "weights": "synthetic Xavier (seed 0)", "input": "resident in HBM", "conv3x3": algo, "plan": plan["structure"]},
+                   "weights": "synthetic Xavier (seed 0)", "input": "resident in HBM", "conv3x3": algo, "plan": plan["structure"], "mfma": plan.get("mfma")},
         "roofline": roof,
         "roofline_nl": nonlocal_roofline(geom, breakdown, B_PER_GPU, H, W, bf16, plan),
         "roofline_hbm_classes": hbm_class_rooflines(geom, breakdown, B_PER_GPU, H, W, plan=plan),
