@@ -1139,6 +1139,9 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain16_kernel(ConvS
     int w_pk = 0;                                                   // pack of the current unit: 0 = shared half, 1 = per-frame half
     bool w_slice2_owed = false;                                     // slice 2 of the current unit's weights still has to be brought (its slot was busy)
 
+    row_setup(0);                                                   // (nothing pending yet: an empty resource, zeros)
+    quarter_request(0);
+    quarter_request(1);
     for (int kt = 0; kt < nt_tiles; ++kt) {
         const int half_a = kt & 1;
         auto unit = [&](auto par) __attribute__((always_inline)) {
@@ -1185,24 +1188,21 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain16_kernel(ConvS
             SFC_DMA_HALO(rs, org, interior, y0q, x0q, cb ^ 1);
             const unsigned fence = __builtin_amdgcn_raw_buffer_load_b32(rs, 0, 0, 0);
             unsigned fence_w = 0;
-            row_setup(PAR);
 
             auto substep = [&](auto sc) __attribute__((always_inline)) {
                 constexpr int S = decltype(sc)::value;              // 3 kx + ky
                 constexpr int kx = S / 3, ky = S % 3;
                 // the residual values of quarters 0, 1 are requested at the unit's start and used 4 - 5 sub-steps (~1 500 cycles: an HBM round trip with the unit's halo
                 // pieces in front of it in the in-order counter) later; those of quarters 2, 3 take their registers over (requested BEFORE the stores of 0, 1)
-                if constexpr (S == 0) {
-                    quarter_request(0);
-                    quarter_request(1);
+                // (quarters 0, 1 of this unit's row were requested at the END of the previous unit - row_setup + two requests in front of its closing fences: the
+                // wait at the barrier and the unit's start are flight time - so the last sub-step carries no epilogue work in front of the closing barrier)
+                if constexpr (S == 3 || S == 4) {
+                    const sff4 v = rres[(S - 3) & 1];
+                    quarter_request(S - 1);
+                    quarter_finish_with(PAR, S - 3, v);
                 }
-                if constexpr (S == 4 || S == 5) {
-                    const sff4 v = rres[S & 1];
-                    quarter_request(S - 2);
-                    quarter_finish_with(PAR, S - 4, v);
-                }
-                if constexpr (S == 7) quarter_finish(PAR, 2);          // (one per sub-step: both in the last one put 8 stores and their VALU in front of the unit's closing barrier)
-                if constexpr (S == 8) quarter_finish(PAR, 3);
+                if constexpr (S == 6) quarter_finish(PAR, 2);
+                if constexpr (S == 7) quarter_finish(PAR, 3);
                 if constexpr (ky == 0) {
                     if constexpr (kx == 1) {
                         SFC_STAMP();                                // 1: column tap 0 done
@@ -1298,6 +1298,9 @@ __global__ __launch_bounds__(SF_THREADS, 1) void conv3x3_sf_chain16_kernel(ConvS
             }
             w_slice2_owed = w_replace;                              // slice 2 of the next unit's weights goes once this unit's is consumed: at its start
             w_pk = nx_pk;
+            row_setup(PAR ^ 1);                                     // the NEXT unit's epilogue row (unit A: row 0 of the tile that has just been folded; unit B: row 1)
+            quarter_request(0);
+            quarter_request(1);
             SFC_STAMP();                                            // 6: groups 4-5 done
             asm volatile("" ::"v"(fence), "v"(fence_w));            // the next unit's halo and weight slices 0, 1 have landed
             SFC_STAMP();                                            // 7: fences passed
