@@ -33,7 +33,7 @@ def main():
         eng.load_weights(w)
         for opts in ({}, {"conv3x3": "split16", "small": "off"}, {"conv3x3": "winograd"}, {"conv3x3": "direct", "conv1x1": "tiled"},
                      {"strict_fp32": "on"}, {"small_c10": "off"}, {"split16_sf": "off"}, {"split16_chain": "off"}, {"split16_c10": "off"}, {"graph": "on"}, {"precision": "bf16"},
-                     {"precision": "bf16", "bf16_conv10": "separate"}, {"split16_sf0": "on"}, {"split16_splitchains": "off"}, {"split16_mid": "off"}):
+                     {"precision": "bf16", "bf16_conv10": "separate"}, {"split16_sf0": "on"}, {"split16_splitchains": "off"}, {"split16_mid": "off"}, {"split16_mfma": "32"}, {"precision": "bf16", "bf16_mfma": "32"}):
             if B == 9 and opts.get("conv3x3") in ("winograd", "direct") or (B == 9 and opts.get("strict_fp32")):
                 continue                                         # (the f32-MFMA families at the large shape: covered at the small ones, minutes under ASAN)
             for k, v in opts.items():
@@ -52,7 +52,7 @@ def main():
             for k in opts:
                 eng.set_option(k, {"conv3x3": "auto", "small": "auto", "small_c10": "on", "conv1x1": "split16", "strict_fp32": "off", "split16_sf": "on",
                                    "split16_chain": "on", "split16_c10": "on", "graph": "off", "precision": "fp32", "bf16_nonlocal": "f16",
-                                   "bf16_conv10": "fused", "split16_sf0": "off", "split16_splitchains": "auto", "split16_mid": "auto"}[k])
+                                   "bf16_conv10": "fused", "split16_sf0": "off", "split16_splitchains": "auto", "split16_mid": "auto", "split16_mfma": "16", "bf16_mfma": "16"}[k])
             n += 1
         eng.profile(1)
         eng.forward(x)
