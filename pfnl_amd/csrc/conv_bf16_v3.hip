@@ -371,6 +371,61 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
         if constexpr (M16) {
             // 6 groups (column tap kx, k-step kk of 32 channels): 4 halo rows x 2 pixel halves + 3 row taps x 2 output tiles = 14 operand reads feed 24 MFMAs
             // (row tap ky outermost: 8 different accumulators between two MFMAs on the same one); the operands of group g + 1 are requested one per gap
+            // Two orders of the 24 MFMAs of a group.  Mode 1 (the per-frame half of conv2_i, which has the registers): ACCUMULATOR-major - the three row taps of one
+            // accumulator back to back, operands double-buffered per group: consecutive 16x16x32 MFMAs that share their accumulator cost less energy
+            // (tools/ubench/mfma_shape_power.hip: 2 220 against 2 000 TFLOP/s under the cap), the launch 72.3 -> 69.8 us at 1080p.  The other modes (conv10_i's
+            // accumulators and operands on top: the double buffer spills): row-tap-major with operands refilled in place.
+            if constexpr (FUSE) {
+            b3h8 px[2][4][2], wv[2][3][2];
+#define B3_PX16(g_, r_, ph_) (*reinterpret_cast<const b3h8*>(tile + paddr[(g_) >> 1][2 * ((g_) & 1) + (ph_)] + (r_) * (B3_IW * 128)))
+#define B3_WT16(g_, ky_, ct_) (*reinterpret_cast<const b3h8*>(wlane + (((((ky_) * 3 + ((g_) >> 1)) * 2 + ((g_) & 1)) * 4 + (ct_)) << 10)))
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) px[0][r][ph] = B3_PX16(0, r, ph);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) wv[0][ky][ct] = B3_WT16(0, ky, ct);
+            auto group16 = [&](auto gc) __attribute__((always_inline)) {
+                constexpr int g = decltype(gc)::value;
+                constexpr int cur = g & 1;
+#define B3_M(ky_, n_, ph_, ct_)                                                                                                        \
+    do {                                                                                                                               \
+        if constexpr (g == 0 && (ky_) == 0) acc4[n_][2 * (ph_) + (ct_)] = b3_mfma16(wv[cur][ky_][ct_], px[cur][(n_) + (ky_)][ph_], bias4[ct_]);   \
+        else acc4[n_][2 * (ph_) + (ct_)] = b3_mfma16(wv[cur][ky_][ct_], px[cur][(n_) + (ky_)][ph_], acc4[n_][2 * (ph_) + (ct_)]);      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                             \
+    } while (0)
+#define B3_A(n_, ph_, ct_) do { B3_M(0, n_, ph_, ct_); B3_M(1, n_, ph_, ct_); B3_M(2, n_, ph_, ct_); } while (0)
+#define B3_RP(r_, ph_) do { if constexpr (g < 5) px[cur ^ 1][r_][ph_] = B3_PX16(g + 1, r_, ph_); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define B3_RW(k_, ct_) do { if constexpr (g < 5) wv[cur ^ 1][k_][ct_] = B3_WT16(g + 1, k_, ct_); __builtin_amdgcn_sched_barrier(0); } while (0)
+                __builtin_amdgcn_sched_barrier(0);
+                B3_A(0, 0, 0); B3_RP(0, 0); B3_RW(0, 0);
+                B3_A(0, 0, 1); B3_RP(1, 0); B3_RW(0, 1);
+                B3_A(0, 1, 0); B3_RP(0, 1); B3_RW(1, 0);
+                B3_A(0, 1, 1); B3_RP(1, 1); B3_RW(1, 1);
+                B3_A(1, 0, 0); B3_RP(2, 0); B3_RW(2, 0);
+                B3_A(1, 0, 1); B3_RP(2, 1); B3_RW(2, 1);
+                B3_A(1, 1, 0); B3_RP(3, 0);
+                B3_A(1, 1, 1); B3_RP(3, 1);
+#undef B3_A
+#undef B3_M
+#undef B3_RP
+#undef B3_RW
+            };
+            group16(std::integral_constant<int, 0>{});
+            group16(std::integral_constant<int, 1>{});
+            group16(std::integral_constant<int, 2>{});
+            B3_STAMP();                                             // 1: groups 0-2 issued
+            if (u == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the late weight pieces of the prologue (column tap 2)
+            B3_BARRIER();                                           // interval boundary (the other half's dump | lines)
+            B3_STAMP();                                             // 2
+            group16(std::integral_constant<int, 3>{});
+            group16(std::integral_constant<int, 4>{});
+            group16(std::integral_constant<int, 5>{});
+#undef B3_PX16
+#undef B3_WT16
+            } else {
             // Operands are refilled IN PLACE for group g + 1 as soon as group g has read them for the last time (halo row 0 behind its 4th MFMA, row tap 0's
             // weights behind the 8th, row 1 behind the 12th ...): 8 + 6 operand sets live, not 16 + 12 - the conv1_i + conv10_i mode has conv10_i's
             // accumulators and operands on top and spilled with a full double buffer.
@@ -436,6 +491,7 @@ __global__ __launch_bounds__(B3_THREADS, 1) void conv3x3_bf16_v3_kernel(ConvBf16
             group16(std::integral_constant<int, 5>{});
 #undef B3_PX16
 #undef B3_WT16
+            }
         } else {
         b3h8 px[2][4], wv[2][3];
 #define B3_PX(g_, r_) (*reinterpret_cast<const b3h8*>(tile + paddr[(g_) >> 2][(g_) & 3] + (r_) * (B3_IW * 128)))
